@@ -1,0 +1,191 @@
+"""User-facing API: ``clonealign()``, ``run_clonealign()`` and the ``clonealign_fit`` object.
+
+Mirrors ``R/clonealign.R`` (exports in NAMESPACE:3-7) argument for argument; the only
+compute-heavy callee, ``inference_tflow``, runs on the MI355X engine.
+"""
+import string
+import warnings
+from collections import Counter
+
+import numpy as np
+
+from . import hostprep
+from .inference import inference_tflow
+
+
+class ClonealignFit(dict):
+    """The ``clonealign_fit`` S3 list (R/clonealign.R:303): a dict with attribute access."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __repr__(self):                                             # print.clonealign_fit, :348-357
+        N = len(self["clone"])
+        G = len(self["ml_params"]["mu"])
+        C = self["ml_params"]["clone_probs"].shape[1]
+        return (f"A clonealign_fit for {N} cells, {G} genes, and {C} clones\n"
+                "To access clone assignments, call x$clone\n"
+                "To access ML parameter estimates, call x$ml_params\n")
+
+    __str__ = __repr__
+
+
+def clone_assignment(gamma, clone_names, clone_assignment_probability=0.95):
+    """R/inference-tflow.R:22-29: arg-max clone (first maximum) or ``"unassigned"``."""
+    gamma = np.asarray(gamma)
+    best = gamma.argmax(1)
+    mx = gamma.max(1)
+    names = np.asarray(list(clone_names), dtype=object)
+    out = names[best]
+    out[mx < clone_assignment_probability] = "unassigned"
+    return out
+
+
+def recompute_clone_assignment(ca, clone_assignment_probability=0.95):
+    """R/inference-tflow.R:36-46."""
+    ca = ClonealignFit(ca)
+    ca["clone"] = clone_assignment(ca["ml_params"]["clone_probs"], ca["clone_names"],
+                                   clone_assignment_probability)
+    return ca
+
+
+def compute_correlations(Y, L, clones, clone_names):
+    """R/clonealign.R:318-334: per-gene Pearson correlation of scaled counts vs the
+    copy number of the assigned clone (NaN where undefined, like R's NA)."""
+    Y = np.asarray(Y, dtype=np.float64)
+    L = np.asarray(L, dtype=np.float64)
+    clones = np.asarray(clones, dtype=object)
+    unassigned = clones == "unassigned"
+    Y = Y[~unassigned]
+    clones = clones[~unassigned]
+    idx = {c: i for i, c in enumerate(clone_names)}
+    ci = np.array([idx[c] for c in clones], dtype=np.int64)
+    G = Y.shape[1]
+    out = np.full(G, np.nan)
+    if Y.shape[0] < 2:
+        return out
+    Ys = hostprep.r_scale(Y)
+    X = L[:, ci].T                                                  # [n, G]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        xc = X - X.mean(0, keepdims=True)
+        yc = Ys - Ys.mean(0, keepdims=True)
+        num = (xc * yc).sum(0)
+        den = np.sqrt((xc ** 2).sum(0) * (yc ** 2).sum(0))
+        out = np.where(den > 0, num / den, np.nan)
+    return out
+
+
+def _parse_expression(gene_expression_data):
+    """R/clonealign.R:207-222.  Returns (Y[cells,genes], gene_names or None)."""
+    g = gene_expression_data
+    if hasattr(g, "assays") or (isinstance(g, dict) and "assays" in g):        # SCE / SE stand-in
+        assays = g["assays"] if isinstance(g, dict) else g.assays
+        if "counts" not in assays:
+            raise ValueError("counts not in assays(gene_expression_data). Available assays: "
+                             + ",".join(assays))
+        counts = assays["counts"]                                    # genes x cells
+        names = None
+        if hasattr(counts, "index"):
+            names = [str(i) for i in counts.index]
+        elif isinstance(g, dict) and "rownames" in g:
+            names = list(g["rownames"])
+        return np.asarray(counts, dtype=np.float64).T, names
+    if hasattr(g, "columns") and hasattr(g, "values"):               # pandas DataFrame cells x genes
+        return np.asarray(g.values, dtype=np.float64), [str(c) for c in g.columns]
+    if isinstance(g, np.ndarray) and g.ndim == 2:
+        return np.asarray(g, dtype=np.float64), None
+    raise TypeError("Input gene_expression_data must be SingleCellExperiment, SummarizedExperiment, or matrix")
+
+
+def _parse_cnv(copy_number_data):
+    """R/clonealign.R:237-243.  Returns (L[genes,clones], clone_names or None)."""
+    c = copy_number_data
+    if hasattr(c, "columns") and hasattr(c, "values"):
+        return np.asarray(c.values, dtype=np.float64), [str(n) for n in c.columns]
+    if isinstance(c, np.ndarray) and c.ndim == 2:
+        return np.asarray(c, dtype=np.float64), None
+    raise TypeError("copy_number_data must be a matrix, data.frame or DataFrame. Current class: "
+                    + type(c).__name__)
+
+
+def _default_gene_names(G):
+    # R/clonealign.R:256-258 uses ``letters`` (only 26 of them); beyond that we number.
+    lt = string.ascii_lowercase
+    return [f"gene_{lt[i]}" if i < 26 else f"gene_{i + 1}" for i in range(G)]
+
+
+def clonealign(gene_expression_data, copy_number_data, max_iter=200, rel_tol=1e-6,
+               gene_filter_threshold=0, learning_rate=0.1, x=None, clone_allele=None,
+               cov=None, ref=None, fix_alpha=False, dtype="float32", saturate=True,
+               saturation_threshold=6, K=None, mc_samples=1, verbose=True, initial_shrink=5,
+               clone_call_probability=0.95, data_init_mu=True, *, seed=None, engine=None,
+               engine_opts=None, clone_names=None):
+    """Assign scRNA-seq cells to clones.  Arguments as R/clonealign.R:184-203."""
+    Y, gene_names = _parse_expression(gene_expression_data)
+    N, G = Y.shape
+    if K is None:
+        K = 1                                                        # :226-232 (both branches give 1)
+    L, cn = _parse_cnv(copy_number_data)
+    if L.shape[0] != G:
+        raise ValueError("copy_number_data must have same number of genes (rows) as gene_expression_data")
+    C = L.shape[1]
+    if clone_names is None:
+        clone_names = cn
+    if clone_names is None:
+        clone_names = [f"clone_{string.ascii_lowercase[i]}" for i in range(C)]   # :251-253
+    if gene_names is None:
+        gene_names = _default_gene_names(G)
+    # NB the reference forwards ``ref = cov`` (R/clonealign.R:271); kept for drop-in behaviour
+    res = inference_tflow(Y, L, max_iter=max_iter, rel_tol=rel_tol, learning_rate=learning_rate,
+                          gene_filter_threshold=gene_filter_threshold, x=x,
+                          clone_allele=clone_allele, cov=cov, ref=cov, fix_alpha=fix_alpha,
+                          dtype=dtype, saturate=saturate, saturation_threshold=saturation_threshold,
+                          K=K, mc_samples=mc_samples, verbose=verbose, initial_shrink=initial_shrink,
+                          data_init_mu=data_init_mu, gene_names=gene_names, seed=seed,
+                          engine=engine, engine_opts=engine_opts)
+    res = ClonealignFit(res)
+    res["clone"] = clone_assignment(res["ml_params"]["clone_probs"], clone_names,
+                                    clone_call_probability)          # :283
+    res["clone_names"] = list(clone_names)                           # colnames(clone_probs), :286
+    keep = np.array([g in set(res["retained_genes"]) for g in gene_names])
+    res["correlations"] = compute_correlations(Y[:, keep], L[keep, :], res["clone"], clone_names)  # :292-294
+    cor = res["correlations"]
+    if np.any(~np.isnan(cor)):
+        if np.nanquantile(cor, 0.25) < 0:                            # :296-300
+            warnings.warn("Less than 75% of genes positively correlated with expression - "
+                          "assignment may have failed\n")
+    return res
+
+
+def run_clonealign(gene_expression_data, copy_number_data, initial_shrinks=(0, 5, 10),
+                   n_repeats=3, print_elbos=True, *, seed=None, devices=None, **kwargs):
+    """R/clonealign.R:35-75: fit across restarts and keep the best final ELBO.
+
+    ``devices``: list of GPU ordinals; restarts are dealt round-robin over them (one fit per
+    GPU at a time, independent replicas -- SURVEY.md §8e config 5).  Default: device 0.
+    """
+    from .multirun import run_restarts
+    jobs = []
+    ss = np.random.SeedSequence(seed)
+    for is_ in initial_shrinks:
+        for _ in range(int(n_repeats)):
+            jobs.append(dict(initial_shrink=is_))
+    seeds = [int(s.generate_state(1)[0]) for s in ss.spawn(len(jobs))]
+    fits = run_restarts(gene_expression_data, copy_number_data, jobs, seeds, devices, kwargs)
+    final_elbos = np.array([f["convergence_info"]["final_elbo"] for f in fits])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        median_correlations = np.array([np.nanmedian(f["correlations"]) if np.any(~np.isnan(f["correlations"]))
+                                        else np.nan for f in fits])
+    if print_elbos:
+        print("ELBOs:  " + " ".join(repr(float(e)) for e in final_elbos))       # :61-63
+    best = fits[int(np.nanargmax(final_elbos))]                                   # which.max, :65
+    best["multirun_info"] = {
+        "clone_prevalences_at_different_shrinks": [dict(Counter(f["clone"])) for f in fits],   # :69
+        "elbos": final_elbos,
+        "median_correlations": median_correlations,
+    }
+    return best

@@ -1,0 +1,483 @@
+// Device kernels of the clonealign VI engine, written for gfx950 (CDNA4, wave64).
+//
+// The model is R/inference-tflow.R:240-346 of the reference; the fused evaluation order
+// (what is hoisted, what each sweep computes) is DESIGN.md §3.  Notation used below:
+//   F[N][D]   cell factors  (psi | X)          V[G][D]  gene loadings (W | beta)
+//   E_ng = exp(F_n . V_g)                      M_gc = mu_g * L_gc
+//   Z_nc = sum_g E_ng M_gc                     coef_nc = -gamma_nc s_n / (S Z_nc)
+// E is never stored: both sweeps regenerate it from F and V (one v_exp_f32 per (n,g)).
+// To keep v_exp_f32 in range the exponent is shifted per cell by an upper bound
+// etamax2_n >= max_g log2(E_ng); the shift cancels exactly in coef * E and is added back
+// to log Z in the cell epilogue.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CA_CW 8  // clones per sweep launch ("chunk"); M, L, coef, Z rows are padded to 8 floats
+#define CA_LOG2E_F 1.44269504088896340736f
+#define CA_LN2 0.69314718055994530942
+#define CA_LOG2PI 1.83787706640934548356
+#define CA_TB 256
+
+// ------------------------------------------------------------------ wave / block helpers
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float ca_dpp_pull(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+// sum over the 64 lanes of a wave; the total is valid in lane 63 (DPP only, no LDS)
+__device__ __forceinline__ float ca_wave_sum_lane63(float v) {
+  v += ca_dpp_pull<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += ca_dpp_pull<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += ca_dpp_pull<0x141, 0xF>(v);  // row_half_mirror
+  v += ca_dpp_pull<0x140, 0xF>(v);  // row_mirror
+  v += ca_dpp_pull<0x142, 0xA>(v);  // row_bcast:15 into rows 1,3
+  v += ca_dpp_pull<0x143, 0xC>(v);  // row_bcast:31 into rows 2,3
+  return v;
+}
+
+// deterministic block tree sum of doubles (blockDim.x == CA_TB); result valid in every thread
+__device__ __forceinline__ double ca_block_sum(double v, double* sm) {
+  const int t = threadIdx.x;
+  __syncthreads();
+  sm[t] = v;
+  __syncthreads();
+#pragma unroll
+  for (int s = CA_TB / 2; s > 0; s >>= 1) {
+    if (t < s) sm[t] += sm[t + s];
+    __syncthreads();
+  }
+  return sm[0];
+}
+
+__device__ __forceinline__ double ca_softplus_d(double x) { return x > 0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
+__device__ __forceinline__ double ca_sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
+
+// ------------------------------------------------------------------ count-matrix element decode
+template <typename YT> struct YVec;
+template <> struct YVec<float> {
+  static constexpr int VEC = 4;
+  __device__ static void load(const float* p, float (&y)[4]) {
+    const float4 v = *reinterpret_cast<const float4*>(p);
+    y[0] = v.x; y[1] = v.y; y[2] = v.z; y[3] = v.w;
+  }
+};
+template <> struct YVec<uint16_t> {
+  static constexpr int VEC = 8;
+  __device__ static void load(const uint16_t* p, float (&y)[8]) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      y[2 * i] = (float)(w[i] & 0xFFFFu);
+      y[2 * i + 1] = (float)(w[i] >> 16);
+    }
+  }
+};
+template <> struct YVec<uint8_t> {
+  static constexpr int VEC = 16;
+  __device__ static void load(const uint8_t* p, float (&y)[16]) {
+    const uint4 v = *reinterpret_cast<const uint4*>(p);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      y[4 * i] = (float)(w[i] & 0xFFu);            // v_cvt_f32_ubyte0..3
+      y[4 * i + 1] = (float)((w[i] >> 8) & 0xFFu);
+      y[4 * i + 2] = (float)((w[i] >> 16) & 0xFFu);
+      y[4 * i + 3] = (float)(w[i] >> 24);
+    }
+  }
+};
+
+// ------------------------------------------------------------------ upload / conversion
+// src is N x G in either layout and any ca_dtype; dst is row-major [N][Gp] of YT, zero padded.
+template <typename ST, typename YT>
+__global__ void k_convert_y(const ST* __restrict__ src, YT* __restrict__ dst, int64_t N, int G, int Gp,
+                            int64_t sn, int64_t sg, int* __restrict__ flags) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * (int64_t)Gp) return;
+  const int64_t n = i / Gp;
+  const int g = (int)(i - n * Gp);
+  YT out = 0;
+  if (g < G) {
+    const double v = (double)src[n * sn + (int64_t)g * sg];
+    out = (YT)v;
+    if ((double)out != v) atomicOr(flags, 1);  // not representable in the storage type
+    if (!(v >= 0.0)) atomicOr(flags, 2);       // negative or NaN count
+  }
+  dst[i] = out;
+}
+
+// max / integrality scan used to choose the storage width (flags bit0: non-integer, bit1: negative/NaN)
+template <typename ST>
+__global__ void k_scan_y(const ST* __restrict__ src, int64_t total, double* __restrict__ maxv, int* __restrict__ flags) {
+  __shared__ double sm[CA_TB];
+  double m = 0.0;
+  int f = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const double v = (double)src[i];
+    if (!(v >= 0.0)) f |= 2;
+    if (v != floor(v)) f |= 1;
+    m = v > m ? v : m;
+  }
+  if (f) atomicOr(flags, f);
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  for (int s = CA_TB / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) sm[threadIdx.x] = sm[threadIdx.x] > sm[threadIdx.x + s] ? sm[threadIdx.x] : sm[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    // doubles >= 0 order like their bit patterns
+    atomicMax(reinterpret_cast<unsigned long long*>(maxv), (unsigned long long)__double_as_longlong(sm[0]));
+  }
+}
+
+// ------------------------------------------------------------------ fit constants (once per fit)
+// One block per cell: s_n, c_n = lgamma(s_n+1) - sum_g lgamma(y+1), A_nc = sum_g xlogy(y, L_gc).
+// (the terms TF recomputes in every run of tfd$Multinomial$log_prob, R/inference-tflow.R:294-296)
+template <typename YT>
+__global__ void __launch_bounds__(CA_TB) k_prep_cells(const YT* __restrict__ Y, const double* __restrict__ logL /*[G][C]*/,
+                                                      const double* __restrict__ extra /*[N][C] or null*/,
+                                                      double* __restrict__ A, double* __restrict__ cn,
+                                                      double* __restrict__ s64, float* __restrict__ s32, int64_t N, int G,
+                                                      int Gp, int C) {
+  __shared__ double sm[CA_TB];
+  const int64_t n = blockIdx.x;
+  const YT* row = Y + n * (int64_t)Gp;
+  double ssum = 0.0, lg = 0.0;
+  for (int g = threadIdx.x; g < G; g += CA_TB) {
+    const double y = (double)row[g];
+    ssum += y;
+    if (y > 1.0) lg += lgamma(y + 1.0);
+    else if (y > 0.0 && y < 1.0) lg += lgamma(y + 1.0);
+  }
+  const double st = ca_block_sum(ssum, sm);
+  const double lt = ca_block_sum(lg, sm);
+  if (threadIdx.x == 0) {
+    s64[n] = st;
+    s32[n] = (float)st;
+    cn[n] = lgamma(st + 1.0) - lt;
+  }
+  for (int c = 0; c < C; ++c) {
+    double a = 0.0;
+    for (int g = threadIdx.x; g < G; g += CA_TB) {
+      const double y = (double)row[g];
+      if (y != 0.0) a += y * logL[(int64_t)g * C + c];  // xlogy: 0*log(0) := 0, y>0 & L=0 -> -inf
+    }
+    const double at = ca_block_sum(a, sm);
+    if (threadIdx.x == 0) A[n * C + c] = at + (extra ? extra[n * C + c] : 0.0);
+  }
+}
+
+// ------------------------------------------------------------------ Y stream: YW = Y.W and YtPsi = Y^T.psi
+// The only kernel that reads the count matrix inside the iteration loop (HBM-bound).  One wave
+// owns a strip of TR cells x (64*VEC) genes: 16-byte coalesced loads, per-lane column partials
+// in registers, per-row partial reduced across the wave with DPP.
+//   YWpart[seg][n][k]  = sum over the strip's genes of y_ng W_gk          (summed over seg later)
+//   YTpart[rb][g][k]   = sum over the strip's cells of y_ng psi_nk        (summed over rb later)
+template <typename YT, int KK>
+__global__ void __launch_bounds__(CA_TB) k_ypass(const YT* __restrict__ Y, const float* __restrict__ F, int Dstride,
+                                                 const float* __restrict__ V, int koff, float* __restrict__ YWpart,
+                                                 float* __restrict__ YTpart, int64_t N, int G, int Gp, int nseg,
+                                                 int nrb, int TR, int K) {
+  constexpr int VEC = YVec<YT>::VEC;
+  const int lane = threadIdx.x & 63;
+  const int64_t task = (int64_t)blockIdx.x * (CA_TB / 64) + (threadIdx.x >> 6);
+  const int64_t rb = task / nseg;
+  const int sg = (int)(task - rb * nseg);
+  if (rb >= nrb) return;
+  const int col0 = sg * 64 * VEC + lane * VEC;
+  float w[VEC][KK], acc[VEC][KK];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j)
+#pragma unroll
+    for (int k = 0; k < KK; ++k) {
+      w[j][k] = (col0 + j < G) ? V[(int64_t)(col0 + j) * Dstride + koff + k] : 0.f;
+      acc[j][k] = 0.f;
+    }
+  const int64_t r0 = rb * TR;
+  const int64_t r1 = (r0 + TR < N) ? r0 + TR : N;
+  const YT* base = Y + col0;
+#pragma unroll 4
+  for (int64_t r = r0; r < r1; ++r) {
+    float y[VEC];
+    YVec<YT>::load(base + r * Gp, y);
+    float p[KK], ps[KK];
+#pragma unroll
+    for (int k = 0; k < KK; ++k) {
+      p[k] = 0.f;
+      ps[k] = F[r * Dstride + koff + k];  // wave-uniform -> scalar load
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j)
+#pragma unroll
+      for (int k = 0; k < KK; ++k) {
+        p[k] = fmaf(y[j], w[j][k], p[k]);
+        acc[j][k] = fmaf(y[j], ps[k], acc[j][k]);
+      }
+#pragma unroll
+    for (int k = 0; k < KK; ++k) {
+      const float tot = ca_wave_sum_lane63(p[k]);
+      if (lane == 63) YWpart[((int64_t)sg * N + r) * K + koff + k] = tot;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j)
+#pragma unroll
+    for (int k = 0; k < KK; ++k) YTpart[((int64_t)rb * Gp + col0 + j) * K + koff + k] = acc[j][k];
+}
+
+// sum the per-row-block partials of Y^T.psi in fixed order (fp64)
+__global__ void k_yt_reduce(const float* __restrict__ YTpart, double* __restrict__ ytpsi, int G, int Gp, int K, int nrb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= G * K) return;
+  const int g = i / K, k = i - g * K;
+  double a = 0.0;
+  for (int rb = 0; rb < nrb; ++rb) a += (double)YTpart[((int64_t)rb * Gp + g) * K + k];
+  ytpsi[i] = a;
+}
+
+// ------------------------------------------------------------------ per-gene preparation of one pass
+// x = loc + exp(ls) eps, mu = softplus(x) (R/inference-tflow.R:260-269), M = mu * L (:288), and the
+// per-gene ELBO terms of :322-323,332 reduced per block:
+//   gene_part[blk][0] = sum_g (1/S) sum_s [ colsum_g log mu + N(log mu;0,1) - log q(mu) ]
+//   gene_part[blk][1+k] = sum_g W_gk^2
+__global__ void __launch_bounds__(CA_TB) k_gene_pre(const float* __restrict__ loc, const float* __restrict__ ls,
+                                                    const float* __restrict__ eps /*[S][G]*/,
+                                                    const double* __restrict__ colsum, const float* __restrict__ Lb /*[nchunk][G][8]*/,
+                                                    const float* __restrict__ V, int Dstride, int K,
+                                                    float* __restrict__ mu32 /*[S][G]*/, float* __restrict__ Mb /*[S][nchunk][G][8]*/,
+                                                    double* __restrict__ gene_part, int G, int S, int nchunk) {
+  __shared__ double sm[CA_TB];
+  const int g = blockIdx.x * CA_TB + threadIdx.x;
+  const bool ok = g < G;
+  double term = 0.0;
+  if (ok) {
+    const double l = (double)loc[g], sd = exp((double)ls[g]), lsd = (double)ls[g];
+    const double cs = colsum[g];
+    for (int s = 0; s < S; ++s) {
+      const double e = (double)eps[(int64_t)s * G + g];
+      const double x = l + sd * e;
+      const double mu = ca_softplus_d(x);
+      const double lm = log(mu);
+      const float muf = (float)mu;
+      mu32[(int64_t)s * G + g] = muf;
+      for (int ch = 0; ch < nchunk; ++ch) {
+        const float4* lp = reinterpret_cast<const float4*>(Lb + ((int64_t)ch * G + g) * CA_CW);
+        float4 a = lp[0], b = lp[1];
+        a.x *= muf; a.y *= muf; a.z *= muf; a.w *= muf;
+        b.x *= muf; b.y *= muf; b.z *= muf; b.w *= muf;
+        float4* mp = reinterpret_cast<float4*>(Mb + (((int64_t)s * nchunk + ch) * G + g) * CA_CW);
+        mp[0] = a;
+        mp[1] = b;
+      }
+      // log q(mu) = Normal(x; loc, sd) + softplus(-x),  softplus(-x) = softplus(x) - x
+      const double logq = -0.5 * e * e - lsd - 0.5 * CA_LOG2PI + (mu - x);
+      term += cs * lm + (-0.5 * lm * lm - 0.5 * CA_LOG2PI) - logq;
+    }
+    term /= (double)S;
+  }
+  const double tsum = ca_block_sum(term, sm);
+  if (threadIdx.x == 0) gene_part[(int64_t)blockIdx.x * (1 + K) + 0] = tsum;
+  for (int k = 0; k < K; ++k) {
+    const double w = ok ? (double)V[(int64_t)g * Dstride + k] : 0.0;
+    const double wsum = ca_block_sum(w * w, sm);
+    if (threadIdx.x == 0) gene_part[(int64_t)blockIdx.x * (1 + K) + 1 + k] = wsum;
+  }
+}
+
+// Vs = V * log2(e) and per-block min/max of each column (for the per-cell exponent bound)
+__global__ void __launch_bounds__(CA_TB) k_vprep(const float* __restrict__ V, float* __restrict__ Vs,
+                                                 float* __restrict__ vmm_part /*[nblk][2][D]*/, int G, int D) {
+  __shared__ float smin[CA_TB], smax[CA_TB];
+  const int g = blockIdx.x * CA_TB + threadIdx.x;
+  for (int d = 0; d < D; ++d) {
+    float v = 0.f;
+    if (g < G) {
+      v = V[(int64_t)g * D + d] * CA_LOG2E_F;
+      Vs[(int64_t)g * D + d] = v;
+    }
+    __syncthreads();
+    smin[threadIdx.x] = (g < G) ? v : INFINITY;
+    smax[threadIdx.x] = (g < G) ? v : -INFINITY;
+    __syncthreads();
+    for (int s = CA_TB / 2; s > 0; s >>= 1) {
+      if (threadIdx.x < s) {
+        smin[threadIdx.x] = fminf(smin[threadIdx.x], smin[threadIdx.x + s]);
+        smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + s]);
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      vmm_part[((int64_t)blockIdx.x * 2 + 0) * D + d] = smin[0];
+      vmm_part[((int64_t)blockIdx.x * 2 + 1) * D + d] = smax[0];
+    }
+  }
+}
+
+__global__ void k_vmm_final(const float* __restrict__ vmm_part, float* __restrict__ vmm /*[2][D]*/, int nblk, int D) {
+  const int d = threadIdx.x;
+  if (d >= D) return;
+  float mn = INFINITY, mx = -INFINITY;
+  for (int b = 0; b < nblk; ++b) {
+    mn = fminf(mn, vmm_part[((int64_t)b * 2 + 0) * D + d]);
+    mx = fmaxf(mx, vmm_part[((int64_t)b * 2 + 1) * D + d]);
+  }
+  vmm[d] = mn;
+  vmm[D + d] = mx;
+}
+
+// etamax2_n = sum_d max(F_nd * Vs_min_d, F_nd * Vs_max_d)  >=  max_g log2 E_ng
+__global__ void k_etamax(const float* __restrict__ F, const float* __restrict__ vmm, float* __restrict__ etamax2,
+                         int64_t N, int D) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float e = 0.f;
+  for (int d = 0; d < D; ++d) {
+    const float f = F[n * D + d];
+    e += fmaxf(f * vmm[d], f * vmm[D + d]);
+  }
+  etamax2[n] = e;
+}
+
+// ------------------------------------------------------------------ forward sweep  Z = E . M
+// (R/inference-tflow.R:278-292 without materialising [S,G,C,N]).  lane = cell, loop over a
+// slice of genes; M_g[0..NC) and Vs_g[0..D) are wave-uniform and arrive through the scalar
+// cache (s_load), so the VALU does 1 fma (exponent) + v_exp_f32 + NC fma per (n,g).
+template <int NC, int D>
+__global__ void __launch_bounds__(CA_TB) k_fwd(const float* __restrict__ F, const float* __restrict__ etamax2,
+                                               const float* __restrict__ Vs, const float* __restrict__ M /*[G][8]*/,
+                                               float* __restrict__ Zpart /*[gsplit][N][8]*/, int64_t N, int G,
+                                               int gchunk, int Drt) {
+  constexpr int DM = (D < 0) ? 8 : (D > 0 ? D : 1);
+  const int Dn = (D < 0) ? Drt : D;
+  const int64_t n = (int64_t)blockIdx.x * CA_TB + threadIdx.x;
+  const int64_t nn = n < N ? n : N - 1;
+  const int g0 = blockIdx.y * gchunk;
+  const int g1 = (g0 + gchunk < G) ? g0 + gchunk : G;
+  float f[DM];
+#pragma unroll
+  for (int d = 0; d < DM; ++d) f[d] = (d < Dn) ? F[nn * Dn + d] : 0.f;
+  const float em = (Dn > 0) ? etamax2[nn] : 0.f;
+  float z[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) z[c] = 0.f;
+#pragma unroll 4
+  for (int g = g0; g < g1; ++g) {
+    float e = 1.f;
+    if (Dn > 0) {
+      float eta = -em;
+#pragma unroll
+      for (int d = 0; d < DM; ++d)
+        if (d < Dn) eta = fmaf(f[d], Vs[(int64_t)g * Dn + d], eta);
+      e = __builtin_amdgcn_exp2f(eta);
+    }
+    const float* mg = M + (int64_t)g * CA_CW;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) z[c] = fmaf(e, mg[c], z[c]);
+  }
+  if (n < N) {
+    float* zp = Zpart + ((int64_t)blockIdx.y * N + n) * CA_CW;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) zp[c] = z[c];
+  }
+}
+
+// ------------------------------------------------------------------ backward sweep
+// Reverse mode of Z = E.M given coef = dELBO/dZ.  lane = gene (RG genes per lane), loop over a
+// slice of cells whose coef/F/etamax are wave-uniform (scalar loads):
+//   t_ng  = sum_c coef_nc L_gc          u_ng = E_ng t_ng
+//   gpart[split][g][s]     += sum_n u_ng                         (-> d/d mu_sg)
+//   gpart[split][g][S + d] += mu_g sum_n u_ng F_nd               (-> d/d V_gd)
+//   dFpart[tile][n][d]     += sum_{g in tile} mu_g u_ng V_gd     (-> d/d F_nd), DPP wave reduction
+template <int NC, int D, int RG>
+__global__ void __launch_bounds__(CA_TB) k_bwd(const float* __restrict__ coef /*[N][8]*/, const float* __restrict__ F,
+                                               const float* __restrict__ etamax2, const float* __restrict__ Lb /*[G][8]*/,
+                                               const float* __restrict__ mu /*[G]*/, const float* __restrict__ Vs,
+                                               const float* __restrict__ V, float* __restrict__ gpart /*[csplit][G][S+Dn]*/,
+                                               float* __restrict__ dFpart /*[ntile][N][Dn]*/, int64_t N, int G,
+                                               int64_t cchunk, int Drt, int S, int sidx, int first_s, int first) {
+  constexpr int DM = (D < 0) ? 8 : (D > 0 ? D : 1);
+  const int Dn = (D < 0) ? Drt : D;
+  const int lane = threadIdx.x & 63;
+  const int tile = blockIdx.x * (CA_TB / 64) + (threadIdx.x >> 6);
+  const int gbase = tile * 64 * RG;
+  if (gbase >= G) return;
+  float l[RG][NC], m_[RG], vs[RG][DM], v[RG][DM], accU[RG], accUF[RG][DM];
+#pragma unroll
+  for (int r = 0; r < RG; ++r) {
+    const int g = gbase + r * 64 + lane;
+    const bool ok = g < G;
+    const int gg = ok ? g : G - 1;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) l[r][c] = ok ? Lb[(int64_t)gg * CA_CW + c] : 0.f;
+    m_[r] = ok ? mu[gg] : 0.f;
+#pragma unroll
+    for (int d = 0; d < DM; ++d) {
+      vs[r][d] = (ok && d < Dn) ? Vs[(int64_t)gg * Dn + d] : 0.f;
+      v[r][d] = (ok && d < Dn) ? V[(int64_t)gg * Dn + d] : 0.f;
+      accUF[r][d] = 0.f;
+    }
+    accU[r] = 0.f;
+  }
+  const int64_t n0 = (int64_t)blockIdx.y * cchunk;
+  const int64_t n1 = (n0 + cchunk < N) ? n0 + cchunk : N;
+  for (int64_t n = n0; n < n1; ++n) {
+    float cf[NC], f[DM];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) cf[c] = coef[n * CA_CW + c];
+#pragma unroll
+    for (int d = 0; d < DM; ++d) f[d] = (d < Dn) ? F[n * Dn + d] : 0.f;
+    const float em = (Dn > 0) ? etamax2[n] : 0.f;
+    float dsum[DM];
+#pragma unroll
+    for (int d = 0; d < DM; ++d) dsum[d] = 0.f;
+#pragma unroll
+    for (int r = 0; r < RG; ++r) {
+      float e = 1.f;
+      if (Dn > 0) {
+        float eta = -em;
+#pragma unroll
+        for (int d = 0; d < DM; ++d) eta = fmaf(f[d], vs[r][d], eta);
+        e = __builtin_amdgcn_exp2f(eta);
+      }
+      float t = 0.f;
+#pragma unroll
+      for (int c = 0; c < NC; ++c) t = fmaf(cf[c], l[r][c], t);
+      const float u = e * t;
+      accU[r] += u;
+      const float deta = m_[r] * u;
+#pragma unroll
+      for (int d = 0; d < DM; ++d) {
+        accUF[r][d] = fmaf(u, f[d], accUF[r][d]);
+        dsum[d] = fmaf(deta, v[r][d], dsum[d]);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < DM; ++d) {
+      if (d < Dn) {
+        const float tot = ca_wave_sum_lane63(dsum[d]);
+        if (lane == 63) {
+          float* p = dFpart + ((int64_t)tile * N + n) * Dn + d;
+          *p = first ? tot : (*p + tot);
+        }
+      }
+    }
+  }
+  const int W_ = S + Dn;
+#pragma unroll
+  for (int r = 0; r < RG; ++r) {
+    const int g = gbase + r * 64 + lane;
+    if (g < G) {
+      float* gp = gpart + ((int64_t)blockIdx.y * G + g) * W_;
+      gp[sidx] = first_s ? accU[r] : gp[sidx] + accU[r];
+#pragma unroll
+      for (int d = 0; d < DM; ++d)
+        if (d < Dn) {
+          const float val = m_[r] * accUF[r][d];
+          gp[S + d] = first ? val : gp[S + d] + val;
+        }
+    }
+  }
+}

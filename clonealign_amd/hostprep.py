@@ -1,0 +1,105 @@
+"""Host-side preparation that the reference does in R before building its graph.
+
+Everything here is O(N*G) one-shot work that stays on the host in the reference too
+(SURVEY.md §8 rows a1, a2); the iteration loop itself runs in the HIP engine.
+"""
+import numpy as np
+
+
+def softplus(x):
+    """R/inference-tflow.R:13-15."""
+    return np.logaddexp(0.0, np.asarray(x, dtype=np.float64))
+
+
+def inverse_softplus(x):
+    """R/inference-tflow.R:1-3."""
+    return np.log(np.exp(np.asarray(x, dtype=np.float64)) - 1.0)
+
+
+def safe_inverse_softplus(x):
+    """R/inference-tflow.R:5-10: ``log(1 - exp(-|x|)) + max(x, 0)``; errors on x < 0."""
+    x = np.asarray(x, dtype=np.float64)
+    if np.any(x < 0):
+        raise ValueError("Inverse softplus only takes positive values")
+    with np.errstate(divide="ignore"):
+        return np.log(1.0 - np.exp(-np.abs(x))) + np.maximum(x, 0.0)
+
+
+def saturate(x, threshold=4):
+    """R/clonealign.R:394-397: clip copy number above ``threshold``."""
+    x = np.array(x, dtype=np.float64, copy=True)
+    x[x > threshold] = threshold
+    return x
+
+
+def gene_filter(Y, L, gene_filter_threshold=0):
+    """R/inference-tflow.R:117-124: drop genes with ``colSums(Y) <= threshold``.
+
+    Returns (Y_kept, L_kept, keep_mask)."""
+    zero_gene_means = Y.sum(0) <= gene_filter_threshold
+    keep = ~zero_gene_means
+    return Y[:, keep], L[keep, :], keep
+
+
+def r_scale(x):
+    """R's ``scale(x)``: centre columns, divide by the (n-1) standard deviation."""
+    x = np.asarray(x, dtype=np.float64)
+    xc = x - x.mean(0, keepdims=True)
+    sd = np.sqrt((xc ** 2).sum(0, keepdims=True) / (x.shape[0] - 1))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return xc / sd
+
+
+def pca_init(Y, K, noise=None):
+    """R/inference-tflow.R:204-208.
+
+    ``prcomp(log2(Y+1), center=TRUE, scale=TRUE)$x[, 1:K]`` -> ``scale()`` -> ``+ noise``
+    where the reference's noise is ``rnorm(N*K, 0, 0.05)`` filled column-major; here the
+    caller supplies ``noise[N,K]`` (already multiplied by 0.05) or None.
+    Signs of principal components follow LAPACK's SVD and are only defined up to +-1.
+    """
+    N, G = Y.shape
+    K = int(K)
+    if K == 0:
+        return np.zeros((N, 0))
+    X = np.log2(np.asarray(Y, dtype=np.float64) + 1.0)
+    Xc = X - X.mean(0, keepdims=True)
+    sd = np.sqrt((Xc ** 2).sum(0) / (N - 1))
+    if np.any(sd == 0):
+        raise ValueError("cannot rescale a constant/zero column to unit variance")
+    Xs = Xc / sd
+    if N * G <= 4_000_000 or K > 8:
+        _, _, Vt = np.linalg.svd(Xs, full_matrices=False)
+        V = Vt[:K].T
+    else:
+        V = _top_eigvecs(Xs, K)
+    pcs = r_scale(Xs @ V)
+    if noise is not None:
+        pcs = pcs + np.asarray(noise, dtype=np.float64).reshape(N, K)
+    return pcs
+
+
+def _top_eigvecs(Xs, K, iters=60, seed=0):
+    """Blocked subspace iteration on X^T X for large N*G (same subspace as the SVD)."""
+    rng = np.random.default_rng(seed)
+    Q = np.linalg.qr(rng.normal(size=(Xs.shape[1], K + 4)))[0]
+    for _ in range(iters):
+        Q = np.linalg.qr(Xs.T @ (Xs @ Q))[0]
+    B = Xs @ Q
+    _, _, Wt = np.linalg.svd(B, full_matrices=False)
+    return (Q @ Wt.T)[:, :K]
+
+
+def mu_guess(Y, data_init_mu=True):
+    """R/inference-tflow.R:220-235."""
+    G = Y.shape[1]
+    if isinstance(data_init_mu, (bool, np.bool_)):
+        if data_init_mu:
+            Yd = np.asarray(Y, dtype=np.float64)
+            return (Yd / Yd.mean(1, keepdims=True)).mean(0)
+        return np.ones(G)
+    v = np.asarray(data_init_mu, dtype=np.float64)
+    if v.dtype.kind in "fiu" and v.size > 0:
+        # the reference's length check is vacuous (``length(data_init_mu == data$G)``)
+        return v / v.mean()
+    raise ValueError("object 'mu_guess' not found")

@@ -1,0 +1,189 @@
+"""``inference_tflow`` -- host mirror of the reference's only inference routine.
+
+Reference: ``R/inference-tflow.R:71-481`` (signature ``:71-89``, man/inference_tflow.Rd).
+The R-side preparation (gene filter, saturation, PCA / mu initialisation) is restated in
+``hostprep.py``; the TensorFlow graph + session loop (``:240-457``) is replaced by the HIP
+engine behind the C ABI of ``include/clonealign_hip.h``.  The function keeps the
+reference's name, argument names, defaults, return structure and error messages so the
+reference's own tests (tests/testthat/test_clonealign.R) translate line by line.
+"""
+import math
+
+import numpy as np
+from scipy.special import gammaln, logsumexp
+
+from . import hostprep
+from .rng import EpsStream
+
+N_FINAL_ELBO = 20  # R/inference-tflow.R:447
+
+
+def beta_binomial_log_prob(k, n, alpha, beta):
+    """R/allele-specific.R:52-58."""
+    ll = gammaln(n + 1) - gammaln(k + 1) - gammaln(n - k + 1)
+    ll = ll + gammaln(k + alpha) + gammaln(n - k + beta) - gammaln(alpha + beta + n)
+    return ll - gammaln(alpha) - gammaln(beta) + gammaln(alpha + beta)
+
+
+def construct_ai_likelihood(clone_allele, alt, cov):
+    """R/allele-specific.R:17-48.  clone_allele [V,C], alt/cov [V,N] -> [N,C] (parameter free)."""
+    p1_low = math.log(0.5) + beta_binomial_log_prob(alt, cov, 0.1, 1.9)
+    p1_high = math.log(0.5) + beta_binomial_log_prob(alt, cov, 1.9, 0.1)
+    p1 = np.logaddexp(p1_low, p1_high)                      # [V,N]
+    p2 = beta_binomial_log_prob(alt, cov, 2.0, 2.0)
+    is2 = (np.asarray(clone_allele) == 2)                   # [V,C]
+    Lcvn = np.where(is2.T[:, :, None], p2[None], p1[None])  # [C,V,N]
+    return Lcvn.sum(1).T                                    # [N,C]
+
+
+def sanitize_allele_info(V, clone_allele, cov, ref, N, C):
+    """R/allele-specific.R:61-70."""
+    assert clone_allele.shape[1] == C
+    assert cov.shape[0] == N and ref.shape[0] == N
+    assert ref.shape[1] == V and cov.shape[1] == V
+
+
+def _default_engine_factory():
+    from .engine import HipEngine  # fails loudly when the HIP library is missing
+    return HipEngine
+
+
+def run_vi_loop(eng, eps, max_iter, rel_tol, verbose=False):
+    """The session loop of R/inference-tflow.R:368-417 driven call by call.
+
+    ``eng`` exposes gamma_init/elbo/step; ``eps.next()`` yields eps[S,G] per ``sess$run``."""
+    eng.gamma_init(eps.next())                                   # :368-369
+    elbo_val = eng.elbo(eps.next())                              # :372
+    if math.isnan(elbo_val):
+        raise FloatingPointError("Initial elbo is NA")           # :374-376
+    elbo_diffs = [1e3] * 10                                      # :379
+    elbos = [elbo_val]
+    for _ in range(int(max_iter)):                               # :394
+        eng.step(eps.next())                                     # :401
+        elbo_new = eng.elbo(eps.next())                          # :403
+        elbo_diff = (elbo_new - elbo_val) / abs(elbo_val)
+        elbo_diffs = elbo_diffs[1:] + [elbo_diff]
+        elbos.append(elbo_new)
+        elbo_val = elbo_new
+        mean_change = float(np.mean(np.abs(elbo_diffs)))
+        if math.isnan(mean_change):
+            raise FloatingPointError("missing value where TRUE/FALSE needed")  # R's `if (NA)` at :414
+        if mean_change < rel_tol:                                # :414
+            break
+    return elbos
+
+
+def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
+                    gene_filter_threshold=0, x=None, clone_allele=None, cov=None, ref=None,
+                    fix_alpha=False, dtype="float32", saturate=True, saturation_threshold=6,
+                    K=1, mc_samples=1, verbose=True, initial_shrink=5, data_init_mu=True,
+                    *, gene_names=None, seed=None, engine=None, engine_opts=None,
+                    psi_noise=None, eps_stream=None):
+    """EM/VI inference on the MI355X engine.  Arguments as R/inference-tflow.R:71-89.
+
+    Keyword-only extras (no reference counterpart): ``seed`` (replaces R's ``set.seed``
+    state feeding ``rnorm`` at :208 and ``get_next_seed`` at :269), ``gene_names``
+    (``colnames(Y_dat)``), ``engine`` (engine class; default the HIP engine),
+    ``psi_noise`` / ``eps_stream`` to inject the two noise sources explicitly.
+    """
+    log = (lambda m: print(m)) if verbose else (lambda m: None)
+    log("Constructing HIP engine")                               # :102-104 ("Constructing tensorflow graph")
+    if dtype not in ("float32", "float64"):
+        raise ValueError("'arg' should be one of 'float32', 'float64'")   # match.arg, :112
+    if dtype == "float64":
+        raise NotImplementedError(
+            "dtype='float64': the reference graph cannot be built for float64 "
+            "(R/inference-tflow.R:323 divides a float64 tensor by tf$to_float(S)); only float32 is supported")
+    Y_dat = np.asarray(Y_dat, dtype=np.float64)
+    L_dat = np.asarray(L_dat, dtype=np.float64)
+    Y_dat, L_dat, keep = hostprep.gene_filter(Y_dat, L_dat, gene_filter_threshold)   # :117-124
+    log(f"Removing {int((~keep).sum())} genes with low counts")
+    if gene_names is not None:
+        retained_genes = [g for g, k in zip(gene_names, keep) if k]     # :126-131
+    else:
+        retained_genes = np.flatnonzero(keep)                           # 0-based (R: which(), 1-based)
+    N, G = Y_dat.shape
+    C = L_dat.shape[1]
+    K = int(K)
+    if L_dat.shape[0] != G:
+        raise ValueError("nrow(L_dat) == G is not TRUE")               # :139
+    if saturate:
+        L_dat = hostprep.saturate(L_dat, saturation_threshold)          # :142-144
+    P = 0
+    if x is not None:                                                   # :147-153
+        x = np.asarray(x, dtype=np.float64)
+        if x.ndim == 1:
+            x = x.reshape(-1, 1)
+        if x.ndim != 2:
+            raise ValueError("is.matrix(x) is not TRUE")
+        P = x.shape[1]
+        if x.shape[0] != N:
+            raise ValueError("nrow(x) == N is not TRUE")
+    # allelic imbalance (:166-187): a parameter-free [N,C] additive term
+    use_allele = clone_allele is not None and ref is not None and cov is not None
+    extra = None
+    clone_probs_from_snv = None
+    if use_allele:
+        log("Using allelic imbalance info")
+        clone_allele = np.asarray(clone_allele, dtype=np.float64)
+        cov = np.asarray(cov, dtype=np.float64)
+        ref = np.asarray(ref, dtype=np.float64)
+        V = clone_allele.shape[0]
+        sanitize_allele_info(V, clone_allele, cov, ref, N, C)
+        alt = cov.T - ref.T
+        extra = construct_ai_likelihood(clone_allele, alt, cov.T)      # [N,C]
+        clone_probs_from_snv = np.exp(extra - logsumexp(extra, 1, keepdims=True))   # :436-440
+    rng = np.random.default_rng(seed)
+    # initialisation (:204-235)
+    if psi_noise is None:
+        psi_noise = rng.normal(0.0, 0.05, size=(K, N)).T if K > 0 else np.zeros((N, 0))  # column-major fill
+    pcs = hostprep.pca_init(Y_dat, K, psi_noise)
+    s_init = Y_dat.sum(1)
+    if np.any(s_init == 0):
+        raise ValueError("Some cells have no counts mapping")          # :212-214
+    mu_g = hostprep.mu_guess(Y_dat, data_init_mu)
+    loc0 = hostprep.safe_inverse_softplus(mu_g)                         # :262
+    S = int(mc_samples)
+    if eps_stream is None:
+        eps_seed = int(rng.integers(1, 2**31 - 1))                      # get_next_seed(), :49-51
+        eps_stream = EpsStream(eps_seed, S, G)
+
+    Engine = engine if engine is not None else _default_engine_factory()
+    eng = Engine(Y_dat, L_dat, pcs, loc0, K, S, X=x, extra_loglik=extra,
+                 learning_rate=learning_rate, **(engine_opts or {}))
+    try:
+        log("Optimizing ELBO")
+        if hasattr(eng, "run"):
+            elbos = eng.run(eps_stream, max_iter, rel_tol)
+        else:
+            elbos = run_vi_loop(eng, eps_stream, max_iter, rel_tol, verbose)
+        log("\nELBO converged or reached max iterations")
+        rlist = eng.get_params()                                        # :424-434
+        log("Computing final ELBO")
+        if hasattr(eng, "final_elbo"):
+            final = eng.final_elbo(eps_stream, N_FINAL_ELBO)
+        else:
+            final = [eng.elbo(eps_stream.next()) for _ in range(N_FINAL_ELBO)]   # :447-449
+    finally:
+        eng.close()                                                     # :457
+    final = np.asarray(final, dtype=np.float64)
+    convergence_info = {
+        "final_elbo": float(final.mean()),
+        "sd_final_elbo": float(final.std(ddof=1)),
+        "elbo": np.asarray(elbos, dtype=np.float64),
+    }
+    # ordering/naming of :465-473
+    order = ["mu", "clone_probs", "s", "alpha"]
+    if P > 0 and K > 0:
+        order += ["beta", "psi", "W", "chi"]
+    elif K > 0:
+        order += ["psi", "W", "chi"]
+    elif P > 0:
+        order += ["beta"]        # the reference leaves this fifth element unnamed (:471-473)
+    ml_params = {k: rlist[k] for k in order if k in rlist}
+    return {
+        "ml_params": ml_params,
+        "convergence_info": convergence_info,
+        "retained_genes": retained_genes,
+        "clone_probs_from_snv": clone_probs_from_snv,
+    }

@@ -1,0 +1,37 @@
+"""Multi-restart dispatch for ``run_clonealign`` (R/clonealign.R:50-56).
+
+The reference runs ``length(initial_shrinks) * n_repeats`` fits sequentially.  Restarts
+are independent ("replicas only"): here they are dealt over the
+visible GPUs, one fit per GPU at a time, each on its own engine handle and HIP stream.
+No collective is involved; the host picks ``which.max(final_elbo)`` afterwards.
+"""
+from concurrent.futures import ThreadPoolExecutor
+
+
+def run_restarts(gene_expression_data, copy_number_data, jobs, seeds, devices, kwargs):
+    from .api import clonealign
+    devices = list(devices) if devices else [None]
+    base_opts = dict(kwargs.pop("engine_opts", None) or {})
+
+    def one(i):
+        kw = dict(kwargs)
+        kw.update(jobs[i])
+        opts = dict(base_opts)
+        dev = devices[i % len(devices)]
+        if dev is not None:
+            opts["device"] = int(dev)
+        return clonealign(gene_expression_data, copy_number_data, seed=seeds[i],
+                          engine_opts=opts or None, **kw)
+
+    if len(devices) == 1:
+        return [one(i) for i in range(len(jobs))]
+    # one worker thread per GPU; job i runs on devices[i % D] so each GPU has one fit in flight
+    fits = [None] * len(jobs)
+
+    def lane(d):
+        for i in range(d, len(jobs), len(devices)):
+            fits[i] = one(i)
+
+    with ThreadPoolExecutor(max_workers=len(devices)) as ex:
+        list(ex.map(lane, range(len(devices))))
+    return fits

@@ -1,0 +1,161 @@
+/*
+ * clonealign_hip.h -- C ABI of the MI355X (gfx950) variational-inference engine that
+ * replaces the TensorFlow-backed ELBO loop of kieranrcampbell/clonealign.
+ *
+ * Boundary: the reference's only compute call site is
+ *   inference_tflow()            R/inference-tflow.R:71-481
+ * whose graph build (:240-346) and session loop (:351-457) talk to TensorFlow through
+ * reticulate.  Each entry point below replaces one `sess$run(...)` granularity of that
+ * loop, so an R shim can either keep the R-level loop verbatim or hand the whole loop to
+ * ca_run().  Plain C types only: no R, Python, torch or HIP types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns CA_OK (0) or an error code; ca_last_error() gives the text.
+ *   - matrices are passed in ONE layout per problem (`layout`): CA_COL_MAJOR is what R
+ *     hands over (column-major, i.e. Y is gene-major in memory), CA_ROW_MAJOR is C/numpy.
+ *   - `eps` arguments are host pointers to S*G float32 standard normals, sample-major
+ *     (eps[s*G + g]): the noise of ONE `qmu$sample()` evaluation
+ *     (R/inference-tflow.R:268-269).  Passing the stream explicitly is what makes results
+ *     reproducible across engines; NULL selects the built-in Philox4x32-10 stream keyed by
+ *     ca_options.seed (draw index kept in the handle).
+ *   - handles are independent and re-entrant (no globals); one host thread per handle.
+ */
+#ifndef CLONEALIGN_HIP_H
+#define CLONEALIGN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CA_ABI_VERSION 1
+
+typedef struct ca_engine* ca_handle;
+
+enum ca_status {
+  CA_OK = 0,
+  CA_ERR_INVALID = 1, /* bad argument / shape (the reference's stopifnot()/stop() cases) */
+  CA_ERR_HIP = 2,     /* HIP runtime failure */
+  CA_ERR_NOMEM = 3,
+  CA_ERR_NAN = 4,     /* "Initial elbo is NA" (R/inference-tflow.R:374-376) or NaN in the window test (:414) */
+  CA_ERR_COMM = 5,    /* RCCL failure */
+  CA_ERR_STATE = 6
+};
+
+enum ca_dtype { CA_F64 = 0, CA_F32 = 1, CA_I32 = 2, CA_U16 = 3, CA_U8 = 4 };
+enum ca_layout { CA_ROW_MAJOR = 0, CA_COL_MAJOR = 1 };
+enum ca_ystore { CA_YSTORE_AUTO = 0, CA_YSTORE_F32 = 1, CA_YSTORE_U16 = 2, CA_YSTORE_U8 = 3 };
+
+/* Inputs of one fit: what inference_tflow() has in hand at R/inference-tflow.R:236,
+ * after its gene filter (:117-124), saturate (:142-144) and initialisation (:204-235). */
+typedef struct ca_problem {
+  int64_t N;           /* cells held by THIS process (a shard when world > 1) */
+  int32_t G, C;        /* genes, clones */
+  int32_t K, P, S;     /* latent dims (:136), covariates (:147-153), MC samples (:268) */
+  int32_t layout;      /* ca_layout, applies to Y, L, psi0, X, extra_loglik and ca_get_param outputs */
+  int32_t y_dtype;     /* ca_dtype of Y */
+  int32_t y_on_device; /* nonzero: Y is a device pointer on ca_options.device */
+  const void* Y;       /* N x G counts (:190,355) */
+  const double* L;     /* G x C copy number (:191) */
+  const double* psi0;  /* N x K  (:204-208, `pcs`)   -- may be NULL when K == 0 */
+  const double* loc0;  /* G      (:262, safe_inverse_softplus(mu_guess)) */
+  const double* X;     /* N x P covariates or NULL (:147-153) */
+  const double* extra_loglik; /* N x C additive log-lik (allele term, :302-304) or NULL */
+} ca_problem;
+
+typedef struct ca_options {
+  double learning_rate;             /* :75,345 */
+  double beta1, beta2, adam_eps;    /* tf.train.AdamOptimizer defaults 0.9, 0.999, 1e-8 */
+  uint64_t seed;                    /* key of the built-in eps stream */
+  int32_t device;                   /* HIP device ordinal */
+  int32_t y_storage;                /* ca_ystore: on-device width of the count matrix */
+  int32_t rank, world;              /* cell-sharded data parallel: shard `rank` of `world` */
+  int32_t profile;                  /* nonzero: time kernels with HIP events (ca_get_kernel_times) */
+  int32_t reserved[7];
+} ca_options;
+
+typedef struct ca_info {
+  int64_t N;
+  int32_t G, C, K, P, S;
+  int32_t y_storage;         /* ca_ystore actually used */
+  int32_t y_bytes_per_elem;
+  int64_t y_device_bytes;    /* resident size of the count matrix */
+  int64_t device_bytes;      /* total device allocation of this handle */
+  int32_t gsplit, csplit;    /* gene / cell splits of the forward / backward sweeps */
+  int32_t n_cu;
+  int32_t reserved[8];
+} ca_info;
+
+/* kernel classes reported by ca_get_kernel_times() */
+enum ca_kernel_id {
+  CA_KERNEL_FWD = 0,    /* Z = E.M sweep            (R/inference-tflow.R:278-292) */
+  CA_KERNEL_BWD = 1,    /* reverse sweep of the same contraction (autodiff of :288-296) */
+  CA_KERNEL_YPASS = 2,  /* Y.W and Y^T.psi stream   (the y*log p part of :294-296) */
+  CA_KERNEL_CELL = 3,   /* per-cell epilogue: log-lik, softmax, ELBO partials (:294-308,332-333) */
+  CA_KERNEL_OTHER = 4,  /* per-gene terms, reductions, Adam (:311-336,345-346) */
+  CA_KERNEL_COUNT = 5
+};
+
+int ca_abi_version(void);
+int ca_default_options(ca_options* opts);
+
+/* Build the engine: upload Y/L/init, precompute the fit constants (lgamma terms,
+ * A = Y.log L, column sums), zero-initialise the variables as :240-272 does.
+ * Replaces graph construction + `sess$run(init)` (:240-353). */
+int ca_create(const ca_problem* problem, const ca_options* opts, ca_handle* out);
+int ca_destroy(ca_handle h);
+const char* ca_last_error(ca_handle h); /* h may be NULL: error of the last failed ca_create on this thread */
+int ca_get_info(ca_handle h, ca_info* info);
+int ca_synchronize(ca_handle h);
+
+/* cell-sharded multi-GPU (one process per GPU): RCCL communicator over xGMI.
+ * Rank 0 calls ca_comm_unique_id() and distributes the 128 bytes out of band. */
+int ca_comm_unique_id(char id[128]);
+int ca_comm_init(ca_handle h, const char id[128]);
+
+/* `sess$run(gamma_init)` + `sess$run(init_gamma)`   (:338-342,368-369) */
+int ca_gamma_init(ca_handle h, const float* eps);
+/* `sess$run(elbo)`                                   (:336,372,403,448) */
+int ca_elbo(ca_handle h, const float* eps, double* elbo);
+/* the three summands of :336 -- EE_p_y, E_log_p_p, E_log_q */
+int ca_elbo_terms(ca_handle h, const float* eps, double terms[3]);
+/* `sess$run(train)`: forward + backward + TF1 Adam on all variables (:345-346,401) */
+int ca_step(ca_handle h, const float* eps);
+/* gradients of the ELBO without the Adam update (for parity checks); fetch with ca_get_gradient */
+int ca_gradients(ca_handle h, const float* eps, double* elbo);
+
+/* The whole session loop :368-417: gamma init (draw 0), initial ELBO (draw 1), then up to
+ * max_iter iterations of {train, monitor} with the 10-long mean |relative change| < rel_tol
+ * stop rule.  eps_stream: n_draws*S*G floats consumed in order (needs >= 2 + 2*max_iter
+ * draws) or NULL for the built-in stream.  elbo_trace receives 1 + iterations values. */
+int ca_run(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_stream, int64_t n_draws,
+           double* elbo_trace, int32_t* n_elbo);
+/* n_iter iterations of {train, monitor} with no convergence test and no host sync inside
+ * (the benchmark "step"); last_elbo may be NULL. */
+int ca_iterate(ca_handle h, int32_t n_iter, const float* eps_stream, int64_t n_draws, double* last_elbo);
+/* `replicate(20, sess$run(elbo))` (:447-454): values[n_rep], mean and sample sd */
+int ca_final_elbo(ca_handle h, int32_t n_rep, const float* eps_stream, int64_t n_draws, double* values,
+                  double* mean, double* sd);
+
+/* Fetch (:424-434).  name in {"mu","clone_probs","s","alpha","beta","psi","W","chi"} (the
+ * reference's ml_params) or a raw variable {"loc","ls","gamma_logits","alpha_unconstr","v"}.
+ * Output is float64 in the problem's layout; sizes: mu/loc/ls G, clone_probs/gamma_logits
+ * N*C, s N, alpha/alpha_unconstr C, beta G*P, psi N*K, W G*K, chi/v K. */
+int ca_get_param(ca_handle h, const char* name, double* out);
+/* Overwrite a raw variable (same names as above, raw set + "psi","W","beta"); resets nothing else. */
+int ca_set_param(ca_handle h, const char* name, const double* in);
+/* after ca_gradients(): d ELBO / d variable, raw-variable names as in ca_set_param */
+int ca_get_gradient(ca_handle h, const char* name, double* out);
+
+/* profile != 0: accumulated HIP-event time per kernel class since the last reset */
+int ca_get_kernel_times(ca_handle h, double ms[CA_KERNEL_COUNT], int64_t launches[CA_KERNEL_COUNT]);
+int ca_reset_kernel_times(ca_handle h);
+
+/* built-in eps stream (Philox4x32-10 + Box-Muller), host side: out[n] for draw `draw` */
+int ca_eps_draw(uint64_t seed, uint64_t draw, int64_t n, float* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CLONEALIGN_HIP_H */
