@@ -240,19 +240,21 @@ __global__ void k_yt_reduce(const float* __restrict__ YTpart, double* __restrict
 
 // ------------------------------------------------------------------ per-gene preparation of one pass
 // x = loc + exp(ls) eps, mu = softplus(x) (R/inference-tflow.R:260-269), M = mu * L (:288), and the
-// per-gene ELBO terms of :322-323,332 reduced per block:
-//   gene_part[blk][0] = sum_g (1/S) sum_s [ colsum_g log mu + N(log mu;0,1) - log q(mu) ]
-//   gene_part[blk][1+k] = sum_g W_gk^2
+// per-gene ELBO terms of :322-323,332 reduced per block (W_ = 3 + K slots per block):
+//   [0] sum_g (1/S) sum_s colsum_g log mu_sg  + sum_p beta_gp (Y^T X)_gp      (part of EE_p_y)
+//   [1] sum_g (1/S) sum_s Normal(log mu_sg; 0, 1)                             (part of E_log_p_p)
+//   [2] sum_g (1/S) sum_s log q(mu_sg)                                        (part of E_log_q)
+//   [3+k] sum_g W_gk^2
 __global__ void __launch_bounds__(CA_TB) k_gene_pre(const float* __restrict__ loc, const float* __restrict__ ls,
                                                     const float* __restrict__ eps /*[S][G]*/,
                                                     const double* __restrict__ colsum, const float* __restrict__ Lb /*[nchunk][G][8]*/,
-                                                    const float* __restrict__ V, int Dstride, int K,
+                                                    const float* __restrict__ V, int D, int K, const double* __restrict__ YtX,
                                                     float* __restrict__ mu32 /*[S][G]*/, float* __restrict__ Mb /*[S][nchunk][G][8]*/,
                                                     double* __restrict__ gene_part, int G, int S, int nchunk) {
   __shared__ double sm[CA_TB];
   const int g = blockIdx.x * CA_TB + threadIdx.x;
   const bool ok = g < G;
-  double term = 0.0;
+  double t0 = 0.0, t1 = 0.0, t2 = 0.0;
   if (ok) {
     const double l = (double)loc[g], sd = exp((double)ls[g]), lsd = (double)ls[g];
     const double cs = colsum[g];
@@ -272,18 +274,27 @@ __global__ void __launch_bounds__(CA_TB) k_gene_pre(const float* __restrict__ lo
         mp[0] = a;
         mp[1] = b;
       }
+      t0 += cs * lm;
+      t1 += -0.5 * lm * lm - 0.5 * CA_LOG2PI;
       // log q(mu) = Normal(x; loc, sd) + softplus(-x),  softplus(-x) = softplus(x) - x
-      const double logq = -0.5 * e * e - lsd - 0.5 * CA_LOG2PI + (mu - x);
-      term += cs * lm + (-0.5 * lm * lm - 0.5 * CA_LOG2PI) - logq;
+      t2 += -0.5 * e * e - lsd - 0.5 * CA_LOG2PI + (mu - x);
     }
-    term /= (double)S;
+    t0 /= (double)S; t1 /= (double)S; t2 /= (double)S;
+    for (int p = K; p < D; ++p) t0 += (double)V[(int64_t)g * D + p] * YtX[(int64_t)g * (D - K) + (p - K)];
   }
-  const double tsum = ca_block_sum(term, sm);
-  if (threadIdx.x == 0) gene_part[(int64_t)blockIdx.x * (1 + K) + 0] = tsum;
+  const int W_ = 3 + K;
+  const double s0 = ca_block_sum(t0, sm);
+  const double s1 = ca_block_sum(t1, sm);
+  const double s2 = ca_block_sum(t2, sm);
+  if (threadIdx.x == 0) {
+    gene_part[(int64_t)blockIdx.x * W_ + 0] = s0;
+    gene_part[(int64_t)blockIdx.x * W_ + 1] = s1;
+    gene_part[(int64_t)blockIdx.x * W_ + 2] = s2;
+  }
   for (int k = 0; k < K; ++k) {
-    const double w = ok ? (double)V[(int64_t)g * Dstride + k] : 0.0;
+    const double w = ok ? (double)V[(int64_t)g * D + k] : 0.0;
     const double wsum = ca_block_sum(w * w, sm);
-    if (threadIdx.x == 0) gene_part[(int64_t)blockIdx.x * (1 + K) + 1 + k] = wsum;
+    if (threadIdx.x == 0) gene_part[(int64_t)blockIdx.x * W_ + 3 + k] = wsum;
   }
 }
 
@@ -480,4 +491,291 @@ __global__ void __launch_bounds__(CA_TB) k_bwd(const float* __restrict__ coef /*
         }
     }
   }
+}
+
+// ------------------------------------------------------------------ per-cell epilogue
+// Everything of R/inference-tflow.R:294-308,322,327,332-333,338-342 that is per cell, in fp64:
+// log-lik ll'_nc = A_nc - s_n mean_s log Z_snc, gamma = softmax(logits), the cell's ELBO
+// summands, d ELBO / d logits, coef for the backward sweep, or (mode 2) the gamma_init logits.
+//   cell_part[blk][0] = sum_n [ c_n + sum_c gamma ll' + psi_n.(YW)_n ]     (EE_p_y part)
+//   cell_part[blk][1] = sum_n [ sum_c gamma log alpha + Normal(psi_n;0,1) ] (E_log_p_p part)
+//   cell_part[blk][2] = sum_n sum_c gamma log gamma                         (E_log_q part)
+//   cell_part[blk][3+c] = sum_n gamma_nc
+#define CA_MODE_ELBO 0
+#define CA_MODE_TRAIN 1
+#define CA_MODE_GINIT 2
+__global__ void __launch_bounds__(CA_TB) k_cell(const float* __restrict__ Zpart /*[S][nchunk][gsplit][N][8]*/, const double* __restrict__ A,
+                                                const double* __restrict__ cn, const double* __restrict__ s64,
+                                                const float* __restrict__ etamax2, float* __restrict__ glogit,
+                                                const float* __restrict__ alpha_u, const float* __restrict__ F,
+                                                const float* __restrict__ YWpart, float* __restrict__ YW,
+                                                float* __restrict__ coef, float* __restrict__ dgl, double* __restrict__ scratch /*[N][C]*/,
+                                                double* __restrict__ cell_part, int64_t N, int C, int S, int D, int K,
+                                                int gsplit, int nchunk, int nseg, int mode) {
+  __shared__ double sm[CA_TB];
+  __shared__ double la[256];
+  // log_alpha = log_softmax(alpha_unconstr) (:255); C is small
+  if (threadIdx.x == 0) {
+    double mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmax(mx, (double)alpha_u[c]);
+    double se = 0.0;
+    for (int c = 0; c < C; ++c) se += exp((double)alpha_u[c] - mx);
+    const double lse = mx + log(se);
+    for (int c = 0; c < C; ++c) la[c] = (double)alpha_u[c] - lse;
+  }
+  __syncthreads();
+  const int64_t n = (int64_t)blockIdx.x * CA_TB + threadIdx.x;
+  const bool ok = n < N;
+  double ee = 0.0, pr = 0.0, q = 0.0;
+  double lse = 0.0, sn = 0.0, em = 0.0;
+  if (ok) {
+    sn = s64[n];
+    em = (D > 0) ? (double)etamax2[n] * CA_LN2 : 0.0;
+    double mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmax(mx, (double)glogit[n * C + c]);
+    double se = 0.0;
+    for (int c = 0; c < C; ++c) se += exp((double)glogit[n * C + c] - mx);
+    lse = mx + log(se);
+    double fbar = 0.0;
+    for (int c = 0; c < C; ++c) {
+      const int ch = c / CA_CW, cc = c % CA_CW;
+      const double lg = (double)glogit[n * C + c] - lse;
+      const double gam = exp(lg);
+      double lzsum = 0.0;
+      for (int s = 0; s < S; ++s) {
+        double Z = 0.0;
+        for (int sp = 0; sp < gsplit; ++sp)
+          Z += (double)Zpart[((((int64_t)s * nchunk + ch) * gsplit + sp) * N + n) * CA_CW + cc];
+        lzsum += log(Z) + em;
+        if (mode == CA_MODE_TRAIN)
+          coef[(((int64_t)s * nchunk + ch) * N + n) * CA_CW + cc] = (float)(-gam * sn / ((double)S * Z));
+      }
+      if (mode == CA_MODE_GINIT) {
+        // sum over samples, no log_alpha (:338)
+        scratch[n * C + c] = (double)S * A[n * C + c] - sn * lzsum;
+        continue;
+      }
+      const double llp = A[n * C + c] - sn * lzsum / (double)S;
+      const double f = llp + la[c] - lg;
+      if (gam != 0.0) {
+        ee += gam * llp;
+        pr += gam * la[c];
+        q += gam * lg;
+        fbar += gam * f;
+      }
+      if (mode == CA_MODE_TRAIN) scratch[n * C + c] = f;
+    }
+    if (mode == CA_MODE_TRAIN) {
+      const double* fs = scratch;
+      for (int c = 0; c < C; ++c) {
+        const double gam = exp((double)glogit[n * C + c] - lse);
+        dgl[n * C + c] = (gam != 0.0) ? (float)(gam * (fs[n * C + c] - fbar)) : 0.f;
+      }
+    }
+    if (mode == CA_MODE_GINIT) {
+      const double* lls = scratch;
+      double m2 = -INFINITY;
+      for (int c = 0; c < C; ++c) m2 = fmax(m2, lls[n * C + c]);
+      double s2 = 0.0;
+      for (int c = 0; c < C; ++c) s2 += exp(lls[n * C + c] - m2);
+      const double l2 = m2 + log(s2);
+      for (int c = 0; c < C; ++c) glogit[n * C + c] = (float)(lls[n * C + c] - l2);
+    } else {
+      ee += cn[n];
+      for (int k = 0; k < K; ++k) {
+        double yw = 0.0;
+        for (int sg = 0; sg < nseg; ++sg) yw += (double)YWpart[((int64_t)sg * N + n) * K + k];
+        YW[n * K + k] = (float)yw;
+        const double ps = (double)F[n * D + k];
+        ee += ps * yw;
+        pr += -0.5 * ps * ps - 0.5 * CA_LOG2PI;
+      }
+    }
+  }
+  if (mode == CA_MODE_GINIT) return;
+  const int W_ = 3 + C;
+  const double r0 = ca_block_sum(ee, sm);
+  const double r1 = ca_block_sum(pr, sm);
+  const double r2 = ca_block_sum(q, sm);
+  if (threadIdx.x == 0) {
+    cell_part[(int64_t)blockIdx.x * W_ + 0] = r0;
+    cell_part[(int64_t)blockIdx.x * W_ + 1] = r1;
+    cell_part[(int64_t)blockIdx.x * W_ + 2] = r2;
+  }
+  for (int c = 0; c < C; ++c) {
+    const double gam = ok ? exp((double)glogit[n * C + c] - lse) : 0.0;
+    const double r = ca_block_sum(gam, sm);
+    if (threadIdx.x == 0) cell_part[(int64_t)blockIdx.x * W_ + 3 + c] = r;
+  }
+}
+
+// fixed-order reduction of block partials: out[j] = sum_b part[b][j]  (one block)
+__global__ void __launch_bounds__(CA_TB) k_reduce_part(const double* __restrict__ part, double* __restrict__ out, int nblk, int W_) {
+  __shared__ double sm[CA_TB];
+  for (int j = 0; j < W_; ++j) {
+    double a = 0.0;
+    for (int b = threadIdx.x; b < nblk; b += CA_TB) a += part[(int64_t)b * W_ + j];
+    const double r = ca_block_sum(a, sm);
+    if (threadIdx.x == 0) out[j] = r;
+  }
+}
+
+// per-gene sums of the backward sweep over the cell splits (fp64, fixed order), then the local Y^T.psi
+//   red_g[g][j], j < S+D  <- sum_split gpart[split][g][j];   red_y[g][k] <- ytpsi[g][k]
+__global__ void k_gene_reduce(const float* __restrict__ gpart, const double* __restrict__ ytpsi, double* __restrict__ red_g,
+                              double* __restrict__ red_y, int G, int W_, int csplit, int K) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t ng = (int64_t)G * W_;
+  if (i < ng) {
+    double a = 0.0;
+    for (int sp = 0; sp < csplit; ++sp) a += (double)gpart[(int64_t)sp * ng + i];
+    red_g[i] = a;
+  } else if (i < ng + (int64_t)G * K) {
+    red_y[i - ng] = ytpsi[i - ng];
+  }
+}
+
+// TF1 Adam (tf.train.AdamOptimizer, R/inference-tflow.R:345): epsilon outside the bias correction
+__device__ __forceinline__ void ca_adam(float& th, float& m, float& v, float g, float lr_t, float b1, float b2, float eps) {
+  m = b1 * m + (1.f - b1) * g;
+  v = b2 * v + (1.f - b2) * g * g;
+  th = th - lr_t * m / (sqrtf(v) + eps);
+}
+
+// ------------------------------------------------------------------ per-gene gradients + Adam
+// d ELBO / d loc, ls (through mu = softplus(loc + exp(ls) eps)), W, beta; minimises -ELBO.
+__global__ void __launch_bounds__(CA_TB) k_final_gene(const double* __restrict__ red_g /*[G][S+D]*/, const double* __restrict__ red_y /*[G][K]*/,
+                                                      const float* __restrict__ eps, const double* __restrict__ colsum,
+                                                      const double* __restrict__ YtX, const float* __restrict__ vchi,
+                                                      float* __restrict__ loc, float* __restrict__ ls, float* __restrict__ V,
+                                                      float* __restrict__ m_loc, float* __restrict__ v_loc, float* __restrict__ m_ls,
+                                                      float* __restrict__ v_ls, float* __restrict__ m_V, float* __restrict__ v_V,
+                                                      float* __restrict__ g_loc, float* __restrict__ g_ls, float* __restrict__ g_V,
+                                                      int G, int S, int D, int K, int apply, float lr_t, float b1, float b2, float aeps) {
+  const int g = blockIdx.x * CA_TB + threadIdx.x;
+  if (g >= G) return;
+  const double l = (double)loc[g], lsd = (double)ls[g], sd = exp(lsd), cs = colsum[g];
+  const int W_ = S + D;
+  double gl = 0.0, gs = 0.0;
+  for (int s = 0; s < S; ++s) {
+    const double e = (double)eps[(int64_t)s * G + g];
+    const double x = l + sd * e;
+    const double mu = ca_softplus_d(x), lm = log(mu), sig = ca_sigmoid_d(x);
+    const double dmu = cs / ((double)S * mu) + red_g[(int64_t)g * W_ + s] - lm / ((double)S * mu);
+    const double dx = dmu * sig + (1.0 - sig) / (double)S;
+    gl += dx;
+    gs += dx * e * sd;
+  }
+  gs += 1.0;
+  g_loc[g] = (float)gl;
+  g_ls[g] = (float)gs;
+  if (apply) {
+    float th = loc[g], m = m_loc[g], v = v_loc[g];
+    ca_adam(th, m, v, -(float)gl, lr_t, b1, b2, aeps);
+    loc[g] = th; m_loc[g] = m; v_loc[g] = v;
+    th = ls[g]; m = m_ls[g]; v = v_ls[g];
+    ca_adam(th, m, v, -(float)gs, lr_t, b1, b2, aeps);
+    ls[g] = th; m_ls[g] = m; v_ls[g] = v;
+  }
+  for (int d = 0; d < D; ++d) {
+    double gv = red_g[(int64_t)g * W_ + S + d];
+    if (d < K) gv += red_y[(int64_t)g * K + d] - exp((double)vchi[d]) * (double)V[(int64_t)g * D + d];
+    else gv += YtX[(int64_t)g * (D - K) + (d - K)];
+    g_V[(int64_t)g * D + d] = (float)gv;
+    if (apply) {
+      float th = V[(int64_t)g * D + d], m = m_V[(int64_t)g * D + d], v = v_V[(int64_t)g * D + d];
+      ca_adam(th, m, v, -(float)gv, lr_t, b1, b2, aeps);
+      V[(int64_t)g * D + d] = th; m_V[(int64_t)g * D + d] = m; v_V[(int64_t)g * D + d] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ ELBO assembly + the O(K + C) variables
+// red[0..2] cell sums (all-reduced when sharded), red[3..3+C) sum_n gamma_nc; gene_part block partials.
+// Uses W^2 sums taken BEFORE this step's Adam update of W (k_gene_pre), as autodiff does.
+__global__ void __launch_bounds__(CA_TB) k_final_small(const double* __restrict__ red, const double* __restrict__ gene_part, int ngblk,
+                                                       float* __restrict__ vchi, float* __restrict__ alpha_u,
+                                                       float* __restrict__ m_v, float* __restrict__ v_v, float* __restrict__ m_a,
+                                                       float* __restrict__ v_a, float* __restrict__ g_v, float* __restrict__ g_a,
+                                                       double* __restrict__ elbo_out, double* __restrict__ terms_out, int G, int C, int K,
+                                                       int apply, float lr_t, float b1, float b2, float aeps) {
+  __shared__ double sm[CA_TB];
+  __shared__ double gs[3 + 16];
+  const int W_ = 3 + K;
+  for (int j = 0; j < W_; ++j) {
+    double a = 0.0;
+    for (int b = threadIdx.x; b < ngblk; b += CA_TB) a += gene_part[(int64_t)b * W_ + j];
+    const double r = ca_block_sum(a, sm);
+    if (threadIdx.x == 0) gs[j] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  // log alpha and the Dirichlet(1/C) log-pdf evaluated at alpha + 1e-3 (:324, argument not renormalised)
+  double mx = -INFINITY;
+  for (int c = 0; c < C; ++c) mx = fmax(mx, (double)alpha_u[c]);
+  double se = 0.0;
+  for (int c = 0; c < C; ++c) se += exp((double)alpha_u[c] - mx);
+  const double lse = mx + log(se);
+  const double conc = 1.0 / (double)C;
+  double dir = -((double)C * lgamma(conc) - lgamma(1.0));
+  double dla_sum = 0.0;
+  for (int c = 0; c < C; ++c) {
+    const double al = exp((double)alpha_u[c] - lse);
+    dir += (conc - 1.0) * log(al + 1e-3);
+    dla_sum += red[3 + c] + (conc - 1.0) * al / (al + 1e-3);
+  }
+  double EE = red[0] + gs[0];
+  double Ep = red[1] + gs[1] + dir;
+  double Eq = red[2] + gs[2];
+  for (int k = 0; k < K; ++k) {
+    const double v = (double)vchi[k], chi = exp(v);
+    Ep += -0.5 * chi * gs[3 + k] + (double)G * (0.5 * v - 0.5 * CA_LOG2PI) + (v - chi);
+    const double gv = -0.5 * chi * gs[3 + k] + 0.5 * (double)G + 1.0 - chi;
+    g_v[k] = (float)gv;
+    if (apply) {
+      float th = vchi[k], m = m_v[k], vv = v_v[k];
+      ca_adam(th, m, vv, -(float)gv, lr_t, b1, b2, aeps);
+      vchi[k] = th; m_v[k] = m; v_v[k] = vv;
+    }
+  }
+  if (elbo_out) *elbo_out = EE + Ep - Eq;
+  if (terms_out) { terms_out[0] = EE; terms_out[1] = Ep; terms_out[2] = Eq; }
+  for (int c = 0; c < C; ++c) {
+    const double al = exp((double)alpha_u[c] - lse);
+    const double dla = red[3 + c] + (conc - 1.0) * al / (al + 1e-3);
+    g_a[c] = (float)(dla - al * dla_sum);
+  }
+  if (apply)
+    for (int c = 0; c < C; ++c) {
+      float th = alpha_u[c], m = m_a[c], vv = v_a[c];
+      ca_adam(th, m, vv, -g_a[c], lr_t, b1, b2, aeps);
+      alpha_u[c] = th; m_a[c] = m; v_a[c] = vv;
+    }
+}
+
+// ------------------------------------------------------------------ per-cell variables: psi and the q(z) logits
+__global__ void __launch_bounds__(CA_TB) k_adam_cell(float* __restrict__ F, const float* __restrict__ YW, const float* __restrict__ dFpart,
+                                                     float* __restrict__ glogit, const float* __restrict__ dgl,
+                                                     float* __restrict__ m_psi, float* __restrict__ v_psi, float* __restrict__ m_gl,
+                                                     float* __restrict__ v_gl, float* __restrict__ g_psi, int64_t N, int C, int D, int K,
+                                                     int ntile, int apply, float lr_t, float b1, float b2, float aeps) {
+  const int64_t n = (int64_t)blockIdx.x * CA_TB + threadIdx.x;
+  if (n >= N) return;
+  for (int k = 0; k < K; ++k) {
+    double dF = 0.0;
+    for (int t = 0; t < ntile; ++t) dF += (double)dFpart[((int64_t)t * N + n) * D + k];
+    const float gp = (float)((double)YW[n * K + k] + dF - (double)F[n * D + k]);
+    g_psi[n * K + k] = gp;
+    if (apply) {
+      float th = F[n * D + k], m = m_psi[n * K + k], v = v_psi[n * K + k];
+      ca_adam(th, m, v, -gp, lr_t, b1, b2, aeps);
+      F[n * D + k] = th; m_psi[n * K + k] = m; v_psi[n * K + k] = v;
+    }
+  }
+  if (apply)
+    for (int c = 0; c < C; ++c) {
+      float th = glogit[n * C + c], m = m_gl[n * C + c], v = v_gl[n * C + c];
+      ca_adam(th, m, v, -dgl[n * C + c], lr_t, b1, b2, aeps);
+      glogit[n * C + c] = th; m_gl[n * C + c] = m; v_gl[n * C + c] = v;
+    }
 }

@@ -1,0 +1,1044 @@
+// Host side of the clonealign VI engine + the C ABI of include/clonealign_hip.h.
+//
+// One ca_engine = one fit = what the reference holds in one TF graph + session
+// (R/inference-tflow.R:99,351,457).  Everything runs on one HIP stream per handle; the only
+// host synchronisation inside the loop is the ELBO read-back the reference's convergence
+// test needs (:403-415).  Built for gfx950 only:  hipcc --offload-arch=gfx950 (see build.py).
+#include "clonealign_hip.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ca_kernels.hip.h"
+#include "philox_host.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+// ---- RCCL, loaded lazily so that single-GPU use never touches it
+typedef struct { char internal[128]; } ca_nccl_uid;
+typedef void* ca_nccl_comm;
+struct RcclApi {
+  void* lib = nullptr;
+  int (*GetUniqueId)(ca_nccl_uid*) = nullptr;
+  int (*CommInitRank)(ca_nccl_comm*, int, ca_nccl_uid, int) = nullptr;
+  int (*CommDestroy)(ca_nccl_comm) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, ca_nccl_comm, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  std::string err;
+  bool load() {
+    if (lib) return true;
+    const char* cands[] = {getenv("CLONEALIGN_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1",
+                           "/opt/rocm/lib/librccl.so"};
+    for (const char* c : cands) {
+      if (!c || !*c) continue;
+      lib = dlopen(c, RTLD_NOW | RTLD_LOCAL);
+      if (lib) break;
+    }
+    if (!lib) { err = std::string("cannot dlopen librccl: ") + dlerror(); return false; }
+    GetUniqueId = (decltype(GetUniqueId))dlsym(lib, "ncclGetUniqueId");
+    CommInitRank = (decltype(CommInitRank))dlsym(lib, "ncclCommInitRank");
+    CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+    AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
+    GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+    if (!GetUniqueId || !CommInitRank || !CommDestroy || !AllReduce) { err = "librccl lacks expected symbols"; return false; }
+    return true;
+  }
+};
+RcclApi g_rccl;
+constexpr int kNcclFloat64 = 8;  // ncclDouble
+constexpr int kNcclSum = 0;      // ncclSum
+
+struct EvPair { hipEvent_t a, b; int kid; };
+
+}  // namespace
+
+struct ca_engine {
+  // ---- problem
+  int64_t N = 0;
+  int G = 0, C = 0, K = 0, P = 0, S = 0, D = 0;  // D = K + P, or 0 when K == 0 (:279-285)
+  int layout = 0;
+  int nchunk = 0;
+  ca_options opt{};
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  std::vector<void*> allocs;
+  int64_t dev_bytes = 0;
+  // ---- count matrix
+  int ystore = 0, ybytes = 0, VEC = 0, Gp = 0, nseg = 0, TR = 0, nrb = 0;
+  void* Y = nullptr;
+  int64_t y_dev_bytes = 0;
+  // ---- constants
+  float* Lb = nullptr;       // [nchunk][G][8]
+  double *A = nullptr, *cn = nullptr, *s64 = nullptr, *colsum = nullptr, *YtX = nullptr;
+  float* s32 = nullptr;
+  // ---- variables + Adam slots
+  float *F = nullptr, *m_psi = nullptr, *v_psi = nullptr;           // F [N][D] = (psi | X)
+  float *glogit = nullptr, *m_gl = nullptr, *v_gl = nullptr;        // [N][C]
+  float *V = nullptr, *m_V = nullptr, *v_V = nullptr;               // V [G][D] = (W | beta)
+  float *loc = nullptr, *ls = nullptr, *m_loc = nullptr, *v_loc = nullptr, *m_ls = nullptr, *v_ls = nullptr;
+  float *vchi = nullptr, *m_v = nullptr, *v_v = nullptr;            // [K]
+  float *alpha_u = nullptr, *m_a = nullptr, *v_a = nullptr;         // [C]
+  float b1p = 0.f, b2p = 0.f;  // running beta powers, float32 like TF's beta*_power variables
+  // ---- gradients (d ELBO / d var)
+  float *g_loc = nullptr, *g_ls = nullptr, *g_V = nullptr, *g_v = nullptr, *g_a = nullptr, *g_psi = nullptr, *dgl = nullptr;
+  // ---- per-pass buffers
+  float* eps_dev = nullptr; int64_t eps_cap = 0;  // capacity in draws
+  float *mu32 = nullptr, *Mb = nullptr, *Vs = nullptr, *vmm = nullptr, *vmm_part = nullptr, *etamax2 = nullptr;
+  double* gene_part = nullptr; int ngblk = 0;
+  float *Zpart = nullptr, *coef = nullptr; double* scratch = nullptr;
+  double* cell_part = nullptr; int ncblk = 0;
+  float *gpart = nullptr, *dFpart = nullptr; int gsplit = 1, gchunk = 0, csplit = 1; int64_t cchunk = 0; int RG = 4, ntile = 0;
+  float *YWpart = nullptr, *YTpart = nullptr, *YW = nullptr; double* ytpsi = nullptr;
+  double* red = nullptr; int64_t red_n = 0, off_g = 0, off_y = 0;
+  double* elbo_dev = nullptr; int64_t elbo_cap = 0; double* terms_dev = nullptr;
+  double* host_pinned = nullptr;  // 8 doubles
+  bool ycache_valid = false;
+  uint64_t draw = 0;  // built-in stream position
+  // ---- comm
+  ca_nccl_comm comm = nullptr;
+  // ---- profiling
+  std::vector<EvPair> ev_pool; size_t ev_used = 0;
+  double k_ms[CA_KERNEL_COUNT] = {0}; int64_t k_n[CA_KERNEL_COUNT] = {0};
+  int n_cu = 256;
+};
+
+namespace {
+
+#define HIPCK(h, call)                                                                       \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                          \
+      return CA_ERR_HIP;                                                                     \
+    }                                                                                        \
+  } while (0)
+
+#define CACK(call)                \
+  do {                            \
+    int rc_ = (call);             \
+    if (rc_ != CA_OK) return rc_; \
+  } while (0)
+
+template <typename T>
+int dalloc(ca_engine* h, T** p, int64_t n) {
+  if (n <= 0) n = 1;
+  void* q = nullptr;
+  hipError_t e = hipMalloc(&q, (size_t)n * sizeof(T));
+  if (e != hipSuccess) {
+    h->err = std::string("hipMalloc of ") + std::to_string(n * sizeof(T)) + " bytes: " + hipGetErrorString(e);
+    return CA_ERR_NOMEM;
+  }
+  e = hipMemsetAsync(q, 0, (size_t)n * sizeof(T), h->stream);
+  if (e != hipSuccess) { h->err = hipGetErrorString(e); return CA_ERR_HIP; }
+  h->allocs.push_back(q);
+  h->dev_bytes += n * (int64_t)sizeof(T);
+  *p = (T*)q;
+  return CA_OK;
+}
+
+// ---- profiling wrappers ------------------------------------------------------------------
+int prof_flush(ca_engine* h) {
+  if (h->ev_used == 0) return CA_OK;
+  HIPCK(h, hipStreamSynchronize(h->stream));
+  for (size_t i = 0; i < h->ev_used; ++i) {
+    float ms = 0.f;
+    HIPCK(h, hipEventElapsedTime(&ms, h->ev_pool[i].a, h->ev_pool[i].b));
+    h->k_ms[h->ev_pool[i].kid] += ms;
+    h->k_n[h->ev_pool[i].kid] += 1;
+  }
+  h->ev_used = 0;
+  return CA_OK;
+}
+int prof_begin(ca_engine* h, int kid) {
+  if (!h->opt.profile) return CA_OK;
+  if (h->ev_used == h->ev_pool.size()) {
+    if (h->ev_pool.size() < 2048) {
+      EvPair p; p.kid = kid;
+      HIPCK(h, hipEventCreate(&p.a));
+      HIPCK(h, hipEventCreate(&p.b));
+      h->ev_pool.push_back(p);
+    } else {
+      CACK(prof_flush(h));
+    }
+  }
+  h->ev_pool[h->ev_used].kid = kid;
+  HIPCK(h, hipEventRecord(h->ev_pool[h->ev_used].a, h->stream));
+  return CA_OK;
+}
+int prof_end(ca_engine* h) {
+  if (!h->opt.profile) return CA_OK;
+  HIPCK(h, hipEventRecord(h->ev_pool[h->ev_used].b, h->stream));
+  h->ev_used++;
+  return CA_OK;
+}
+#define LAUNCH(h, kid, ...)                 \
+  do {                                      \
+    CACK(prof_begin(h, kid));               \
+    __VA_ARGS__;                            \
+    HIPCK(h, hipGetLastError());            \
+    CACK(prof_end(h));                      \
+  } while (0)
+
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// ---- template dispatch of the sweeps -------------------------------------------------------
+template <int NC>
+void fwd_nc(int D, dim3 grid, hipStream_t st, const float* F, const float* em, const float* Vs, const float* M, float* Zp,
+            int64_t N, int G, int gchunk) {
+  switch (D) {
+    case 0: hipLaunchKernelGGL((k_fwd<NC, 0>), grid, dim3(CA_TB), 0, st, F, em, Vs, M, Zp, N, G, gchunk, D); break;
+    case 1: hipLaunchKernelGGL((k_fwd<NC, 1>), grid, dim3(CA_TB), 0, st, F, em, Vs, M, Zp, N, G, gchunk, D); break;
+    case 2: hipLaunchKernelGGL((k_fwd<NC, 2>), grid, dim3(CA_TB), 0, st, F, em, Vs, M, Zp, N, G, gchunk, D); break;
+    default: hipLaunchKernelGGL((k_fwd<NC, -1>), grid, dim3(CA_TB), 0, st, F, em, Vs, M, Zp, N, G, gchunk, D); break;
+  }
+}
+void launch_fwd(int nc, int D, dim3 grid, hipStream_t st, const float* F, const float* em, const float* Vs, const float* M,
+                float* Zp, int64_t N, int G, int gchunk) {
+  switch (nc) {
+    case 1: fwd_nc<1>(D, grid, st, F, em, Vs, M, Zp, N, G, gchunk); break;
+    case 2: fwd_nc<2>(D, grid, st, F, em, Vs, M, Zp, N, G, gchunk); break;
+    case 3: fwd_nc<3>(D, grid, st, F, em, Vs, M, Zp, N, G, gchunk); break;
+    case 4: fwd_nc<4>(D, grid, st, F, em, Vs, M, Zp, N, G, gchunk); break;
+    case 5: fwd_nc<5>(D, grid, st, F, em, Vs, M, Zp, N, G, gchunk); break;
+    case 6: fwd_nc<6>(D, grid, st, F, em, Vs, M, Zp, N, G, gchunk); break;
+    case 7: fwd_nc<7>(D, grid, st, F, em, Vs, M, Zp, N, G, gchunk); break;
+    default: fwd_nc<8>(D, grid, st, F, em, Vs, M, Zp, N, G, gchunk); break;
+  }
+}
+
+struct BwdArgs {
+  const float *coef, *F, *em, *Lb, *mu, *Vs, *V;
+  float *gpart, *dFpart;
+  int64_t N; int G; int64_t cchunk; int D, S, sidx, first_s, first;
+};
+template <int NC, int RG>
+void bwd_nc(dim3 grid, hipStream_t st, const BwdArgs& a) {
+#define CA_BWD(DT)                                                                                                   \
+  hipLaunchKernelGGL((k_bwd<NC, DT, RG>), grid, dim3(CA_TB), 0, st, a.coef, a.F, a.em, a.Lb, a.mu, a.Vs, a.V, a.gpart, \
+                     a.dFpart, a.N, a.G, a.cchunk, a.D, a.S, a.sidx, a.first_s, a.first)
+  switch (a.D) {
+    case 0: CA_BWD(0); break;
+    case 1: CA_BWD(1); break;
+    case 2: CA_BWD(2); break;
+    default: CA_BWD(-1); break;
+  }
+#undef CA_BWD
+}
+template <int RG>
+void bwd_rg(int nc, dim3 grid, hipStream_t st, const BwdArgs& a) {
+  switch (nc) {
+    case 1: bwd_nc<1, RG>(grid, st, a); break;
+    case 2: bwd_nc<2, RG>(grid, st, a); break;
+    case 3: bwd_nc<3, RG>(grid, st, a); break;
+    case 4: bwd_nc<4, RG>(grid, st, a); break;
+    case 5: bwd_nc<5, RG>(grid, st, a); break;
+    case 6: bwd_nc<6, RG>(grid, st, a); break;
+    case 7: bwd_nc<7, RG>(grid, st, a); break;
+    default: bwd_nc<8, RG>(grid, st, a); break;
+  }
+}
+void launch_bwd(int RG, int nc, dim3 grid, hipStream_t st, const BwdArgs& a) {
+  if (RG == 1) bwd_rg<1>(nc, grid, st, a);
+  else bwd_rg<4>(nc, grid, st, a);
+}
+
+template <typename YT>
+void ypass_t(ca_engine* h, int koff, int kk, dim3 grid) {
+  const YT* Y = (const YT*)h->Y;
+#define CA_YP(KK)                                                                                                        \
+  hipLaunchKernelGGL((k_ypass<YT, KK>), grid, dim3(CA_TB), 0, h->stream, Y, h->F, h->D, h->V, koff, h->YWpart, h->YTpart, \
+                     h->N, h->G, h->Gp, h->nseg, h->nrb, h->TR, h->K)
+  switch (kk) {
+    case 1: CA_YP(1); break;
+    case 2: CA_YP(2); break;
+    case 3: CA_YP(3); break;
+    default: CA_YP(4); break;
+  }
+#undef CA_YP
+}
+
+// ---- host matrix helpers ------------------------------------------------------------------
+// element (r, c) of an R x Cn host matrix in the problem's layout
+inline int64_t hidx(int layout, int64_t r, int64_t c, int64_t R, int64_t Cn) {
+  return layout == CA_COL_MAJOR ? c * R + r : r * Cn + c;
+}
+
+int upload_f(ca_engine* h, float* dst, const std::vector<float>& v) {
+  if (v.empty()) return CA_OK;
+  HIPCK(h, hipMemcpyAsync(dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  HIPCK(h, hipStreamSynchronize(h->stream));
+  return CA_OK;
+}
+int upload_d(ca_engine* h, double* dst, const std::vector<double>& v) {
+  if (v.empty()) return CA_OK;
+  HIPCK(h, hipMemcpyAsync(dst, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIPCK(h, hipStreamSynchronize(h->stream));
+  return CA_OK;
+}
+int download_f(ca_engine* h, std::vector<float>& v, const float* src, int64_t n) {
+  v.resize((size_t)n);
+  if (n == 0) return CA_OK;
+  HIPCK(h, hipMemcpyAsync(v.data(), src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  HIPCK(h, hipStreamSynchronize(h->stream));
+  return CA_OK;
+}
+
+// ---- derived state that depends on the parameters only (not on eps) -------------------------
+int refresh_derived(ca_engine* h) {
+  if (h->D > 0) {
+    LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_vprep, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->V, h->Vs, h->vmm_part, h->G, h->D));
+    LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_vmm_final, dim3(1), dim3(64), 0, h->stream, h->vmm_part, h->vmm, h->ngblk, h->D));
+    LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_etamax, dim3(cdiv(h->N, CA_TB)), dim3(CA_TB), 0, h->stream, h->F, h->vmm, h->etamax2, h->N, h->D));
+  }
+  h->ycache_valid = false;
+  return CA_OK;
+}
+
+// Y.W and Y^T.psi for the current parameters (once per parameter state)
+int ensure_ycache(ca_engine* h) {
+  if (h->ycache_valid || h->K == 0) { h->ycache_valid = true; return CA_OK; }
+  const int64_t tasks = (int64_t)h->nrb * h->nseg;
+  dim3 grid(cdiv(tasks, CA_TB / 64));
+  for (int koff = 0; koff < h->K; koff += 4) {
+    const int kk = std::min(4, h->K - koff);
+    CACK(prof_begin(h, CA_KERNEL_YPASS));
+    if (h->ystore == CA_YSTORE_U8) ypass_t<uint8_t>(h, koff, kk, grid);
+    else if (h->ystore == CA_YSTORE_U16) ypass_t<uint16_t>(h, koff, kk, grid);
+    else ypass_t<float>(h, koff, kk, grid);
+    HIPCK(h, hipGetLastError());
+    CACK(prof_end(h));
+  }
+  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_yt_reduce, dim3(cdiv((int64_t)h->G * h->K, CA_TB)), dim3(CA_TB), 0, h->stream,
+                                                h->YTpart, h->ytpsi, h->G, h->Gp, h->K, h->nrb));
+  h->ycache_valid = true;
+  return CA_OK;
+}
+
+int allreduce(ca_engine* h, double* buf, int64_t n) {
+  if (h->opt.world <= 1) return CA_OK;
+  if (!h->comm) { h->err = "world > 1 but ca_comm_init() was not called"; return CA_ERR_STATE; }
+  int rc = g_rccl.AllReduce(buf, buf, (size_t)n, kNcclFloat64, kNcclSum, h->comm, h->stream);
+  if (rc != 0) {
+    h->err = std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+    return CA_ERR_COMM;
+  }
+  return CA_OK;
+}
+
+// One evaluation of the model for the eps of device slot `eps_slot`.
+//   mode CA_MODE_ELBO : forward only, ELBO -> elbo_dst        (`sess$run(elbo)`)
+//   mode CA_MODE_GINIT: forward only, overwrite the q(z) logits (`gamma_init`)
+//   mode CA_MODE_TRAIN: forward + backward (+ Adam when apply)  (`sess$run(train)`)
+int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_dst) {
+  const float* eps = h->eps_dev + eps_slot * (int64_t)h->S * h->G;
+  const int N256 = cdiv(h->N, CA_TB);
+  CACK(ensure_ycache(h));
+  LAUNCH(h, CA_KERNEL_OTHER,
+         hipLaunchKernelGGL(k_gene_pre, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->loc, h->ls, eps, h->colsum, h->Lb, h->V,
+                            h->D, h->K, h->YtX, h->mu32, h->Mb, h->gene_part, h->G, h->S, h->nchunk));
+  for (int s = 0; s < h->S; ++s)
+    for (int ch = 0; ch < h->nchunk; ++ch) {
+      const int nc = std::min(CA_CW, h->C - ch * CA_CW);
+      const float* M = h->Mb + ((int64_t)s * h->nchunk + ch) * h->G * CA_CW;
+      // Zpart [S][gsplit][nchunk][N][8]: the kernel strides its split index by N*8, so pass per-(s,ch) bases
+      // laid out as [s][ch][split][N][8]
+      float* Zp = h->Zpart + (((int64_t)s * h->nchunk + ch) * h->gsplit) * h->N * CA_CW;
+      LAUNCH(h, CA_KERNEL_FWD, launch_fwd(nc, h->D, dim3(N256, h->gsplit), h->stream, h->F, h->etamax2, h->Vs, M, Zp, h->N, h->G, h->gchunk));
+    }
+  LAUNCH(h, CA_KERNEL_CELL,
+         hipLaunchKernelGGL(k_cell, dim3(N256), dim3(CA_TB), 0, h->stream, h->Zpart, h->A, h->cn, h->s64, h->etamax2, h->glogit,
+                            h->alpha_u, h->F, h->YWpart, h->YW, h->coef, h->dgl, h->scratch, h->cell_part, h->N, h->C, h->S, h->D,
+                            h->K, h->gsplit, h->nchunk, h->nseg, mode));
+  if (mode == CA_MODE_GINIT) return CA_OK;
+  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_reduce_part, dim3(1), dim3(CA_TB), 0, h->stream, h->cell_part, h->red, h->ncblk, 3 + h->C));
+  float lr_t = 0.f;
+  if (mode == CA_MODE_TRAIN) {
+    for (int s = 0; s < h->S; ++s)
+      for (int ch = 0; ch < h->nchunk; ++ch) {
+        BwdArgs a;
+        a.coef = h->coef + ((int64_t)s * h->nchunk + ch) * h->N * CA_CW;
+        a.F = h->F; a.em = h->etamax2;
+        a.Lb = h->Lb + (int64_t)ch * h->G * CA_CW;
+        a.mu = h->mu32 + (int64_t)s * h->G;
+        a.Vs = h->Vs; a.V = h->V; a.gpart = h->gpart; a.dFpart = h->dFpart;
+        a.N = h->N; a.G = h->G; a.cchunk = h->cchunk; a.D = h->D; a.S = h->S; a.sidx = s;
+        a.first_s = (ch == 0); a.first = (s == 0 && ch == 0);
+        const int nc = std::min(CA_CW, h->C - ch * CA_CW);
+        LAUNCH(h, CA_KERNEL_BWD, launch_bwd(h->RG, nc, dim3(cdiv(h->ntile, CA_TB / 64), h->csplit), h->stream, a));
+      }
+    const int W_ = h->S + h->D;
+    LAUNCH(h, CA_KERNEL_OTHER,
+           hipLaunchKernelGGL(k_gene_reduce, dim3(cdiv((int64_t)h->G * (W_ + h->K), CA_TB)), dim3(CA_TB), 0, h->stream, h->gpart,
+                              h->ytpsi, h->red + h->off_g, h->red + h->off_y, h->G, W_, h->csplit, h->K));
+    CACK(allreduce(h, h->red, h->red_n));
+    if (apply) {
+      // lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t), float32 like TF's _prepare()/_apply_dense
+      lr_t = (float)h->opt.learning_rate * sqrtf(1.f - h->b2p) / (1.f - h->b1p);
+    }
+    LAUNCH(h, CA_KERNEL_OTHER,
+           hipLaunchKernelGGL(k_final_gene, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->red + h->off_g, h->red + h->off_y, eps,
+                              h->colsum, h->YtX, h->vchi, h->loc, h->ls, h->V, h->m_loc, h->v_loc, h->m_ls, h->v_ls, h->m_V, h->v_V,
+                              h->g_loc, h->g_ls, h->g_V, h->G, h->S, h->D, h->K, apply, lr_t, (float)h->opt.beta1, (float)h->opt.beta2,
+                              (float)h->opt.adam_eps));
+  } else {
+    CACK(allreduce(h, h->red, 3 + h->C));
+  }
+  LAUNCH(h, CA_KERNEL_OTHER,
+         hipLaunchKernelGGL(k_final_small, dim3(1), dim3(CA_TB), 0, h->stream, h->red, h->gene_part, h->ngblk, h->vchi, h->alpha_u,
+                            h->m_v, h->v_v, h->m_a, h->v_a, h->g_v, h->g_a, elbo_dst, h->terms_dev, h->G, h->C, h->K,
+                            (mode == CA_MODE_TRAIN && apply) ? 1 : 0, lr_t, (float)h->opt.beta1, (float)h->opt.beta2,
+                            (float)h->opt.adam_eps));
+  if (mode == CA_MODE_TRAIN) {
+    LAUNCH(h, CA_KERNEL_OTHER,
+           hipLaunchKernelGGL(k_adam_cell, dim3(N256), dim3(CA_TB), 0, h->stream, h->F, h->YW, h->dFpart, h->glogit, h->dgl, h->m_psi,
+                              h->v_psi, h->m_gl, h->v_gl, h->g_psi, h->N, h->C, h->D, h->K, h->ntile, apply, lr_t,
+                              (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps));
+    if (apply) {
+      h->b1p *= (float)h->opt.beta1;
+      h->b2p *= (float)h->opt.beta2;
+      CACK(refresh_derived(h));
+    }
+  }
+  return CA_OK;
+}
+
+int ensure_eps_cap(ca_engine* h, int64_t draws) {
+  if (draws <= h->eps_cap) return CA_OK;
+  float* p = nullptr;
+  HIPCK(h, hipMalloc((void**)&p, (size_t)draws * h->S * h->G * sizeof(float)));
+  if (h->eps_dev) {
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    HIPCK(h, hipFree(h->eps_dev));
+    h->dev_bytes -= h->eps_cap * (int64_t)h->S * h->G * 4;
+  }
+  h->eps_dev = p;
+  h->eps_cap = draws;
+  h->dev_bytes += draws * (int64_t)h->S * h->G * 4;
+  return CA_OK;
+}
+int ensure_elbo_cap(ca_engine* h, int64_t n) {
+  if (n <= h->elbo_cap) return CA_OK;
+  double* p = nullptr;
+  HIPCK(h, hipMalloc((void**)&p, (size_t)n * sizeof(double)));
+  if (h->elbo_dev) {
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    HIPCK(h, hipFree(h->elbo_dev));
+  }
+  h->elbo_dev = p;
+  h->elbo_cap = n;
+  return CA_OK;
+}
+
+// put `n_draws` draws on the device: from the caller's stream, or generated (built-in Philox stream)
+int stage_eps(ca_engine* h, const float* eps_stream, int64_t have, int64_t need) {
+  const int64_t per = (int64_t)h->S * h->G;
+  CACK(ensure_eps_cap(h, std::max<int64_t>(need, 1)));
+  if (eps_stream) {
+    if (have < need) {
+      h->err = "eps stream too short: need " + std::to_string(need) + " draws, got " + std::to_string(have);
+      return CA_ERR_INVALID;
+    }
+    HIPCK(h, hipMemcpyAsync(h->eps_dev, eps_stream, (size_t)need * per * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+  } else {
+    std::vector<float> buf((size_t)need * per);
+    for (int64_t d = 0; d < need; ++d) ca_philox::normal_draw(h->opt.seed, h->draw + d, per, buf.data() + d * per);
+    h->draw += need;
+    HIPCK(h, hipMemcpyAsync(h->eps_dev, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+  }
+  return CA_OK;
+}
+
+int read_doubles(ca_engine* h, const double* dev, double* out, int n) {
+  HIPCK(h, hipMemcpyAsync(h->host_pinned, dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCK(h, hipStreamSynchronize(h->stream));
+  for (int i = 0; i < n; ++i) out[i] = h->host_pinned[i];
+  return CA_OK;
+}
+
+template <typename ST>
+int scan_and_convert(ca_engine* h, const ST* src_dev, int64_t sn, int64_t sg) {
+  double* maxv = nullptr;
+  int* flags = nullptr;
+  HIPCK(h, hipMalloc((void**)&maxv, 16));
+  flags = (int*)(maxv + 1);
+  HIPCK(h, hipMemsetAsync(maxv, 0, 16, h->stream));
+  const int64_t total = h->N * (int64_t)h->G;
+  hipLaunchKernelGGL((k_scan_y<ST>), dim3(std::min<int64_t>(4096, cdiv(total, CA_TB))), dim3(CA_TB), 0, h->stream, src_dev, total, maxv, flags);
+  HIPCK(h, hipGetLastError());
+  double hm[2];
+  HIPCK(h, hipMemcpyAsync(hm, maxv, 16, hipMemcpyDeviceToHost, h->stream));
+  HIPCK(h, hipStreamSynchronize(h->stream));
+  const double mx = hm[0];
+  int fl;
+  memcpy(&fl, &hm[1], sizeof(int));
+  if (fl & 2) { hipFree(maxv); h->err = "count matrix has negative or NaN entries"; return CA_ERR_INVALID; }
+  int store = h->opt.y_storage;
+  if (store == CA_YSTORE_AUTO) {
+    if (fl & 1) store = CA_YSTORE_F32;
+    else if (mx <= 255.0) store = CA_YSTORE_U8;
+    else if (mx <= 65535.0) store = CA_YSTORE_U16;
+    else store = CA_YSTORE_F32;
+  }
+  if ((store == CA_YSTORE_U8 && ((fl & 1) || mx > 255.0)) || (store == CA_YSTORE_U16 && ((fl & 1) || mx > 65535.0))) {
+    hipFree(maxv);
+    h->err = "requested y_storage cannot hold the counts (max " + std::to_string(mx) + ")";
+    return CA_ERR_INVALID;
+  }
+  h->ystore = store;
+  h->ybytes = store == CA_YSTORE_U8 ? 1 : store == CA_YSTORE_U16 ? 2 : 4;
+  h->VEC = 16 / h->ybytes;
+  const int segw = 64 * h->VEC;
+  h->nseg = cdiv(h->G, segw);
+  h->Gp = h->nseg * segw;
+  h->y_dev_bytes = h->N * (int64_t)h->Gp * h->ybytes;
+  uint8_t* yb = nullptr;
+  CACK(dalloc(h, &yb, h->y_dev_bytes));
+  h->Y = yb;
+  HIPCK(h, hipMemsetAsync(maxv, 0, 16, h->stream));
+  const int64_t tot = h->N * (int64_t)h->Gp;
+  dim3 grid(cdiv(tot, CA_TB));
+  if (store == CA_YSTORE_U8) hipLaunchKernelGGL((k_convert_y<ST, uint8_t>), grid, dim3(CA_TB), 0, h->stream, src_dev, (uint8_t*)h->Y, h->N, h->G, h->Gp, sn, sg, flags);
+  else if (store == CA_YSTORE_U16) hipLaunchKernelGGL((k_convert_y<ST, uint16_t>), grid, dim3(CA_TB), 0, h->stream, src_dev, (uint16_t*)h->Y, h->N, h->G, h->Gp, sn, sg, flags);
+  else hipLaunchKernelGGL((k_convert_y<ST, float>), grid, dim3(CA_TB), 0, h->stream, src_dev, (float*)h->Y, h->N, h->G, h->Gp, sn, sg, flags);
+  HIPCK(h, hipGetLastError());
+  HIPCK(h, hipMemcpyAsync(hm, maxv, 16, hipMemcpyDeviceToHost, h->stream));
+  HIPCK(h, hipStreamSynchronize(h->stream));
+  memcpy(&fl, &hm[1], sizeof(int));
+  hipFree(maxv);
+  if (fl & 1) { h->err = "counts are not exactly representable in the on-device storage type"; return CA_ERR_INVALID; }
+  return CA_OK;
+}
+
+int upload_y(ca_engine* h, const ca_problem* p) {
+  const int64_t total = h->N * (int64_t)h->G;
+  size_t esz = p->y_dtype == CA_F64 ? 8 : (p->y_dtype == CA_F32 || p->y_dtype == CA_I32) ? 4 : p->y_dtype == CA_U16 ? 2 : 1;
+  const void* src = p->Y;
+  void* staging = nullptr;
+  if (!p->y_on_device) {
+    HIPCK(h, hipMalloc(&staging, (size_t)total * esz));
+    HIPCK(h, hipMemcpy(staging, p->Y, (size_t)total * esz, hipMemcpyHostToDevice));
+    src = staging;
+  }
+  const int64_t sn = p->layout == CA_COL_MAJOR ? 1 : h->G;
+  const int64_t sg = p->layout == CA_COL_MAJOR ? h->N : 1;
+  int rc;
+  switch (p->y_dtype) {
+    case CA_F64: rc = scan_and_convert<double>(h, (const double*)src, sn, sg); break;
+    case CA_F32: rc = scan_and_convert<float>(h, (const float*)src, sn, sg); break;
+    case CA_I32: rc = scan_and_convert<int32_t>(h, (const int32_t*)src, sn, sg); break;
+    case CA_U16: rc = scan_and_convert<uint16_t>(h, (const uint16_t*)src, sn, sg); break;
+    case CA_U8: rc = scan_and_convert<uint8_t>(h, (const uint8_t*)src, sn, sg); break;
+    default: h->err = "unknown y_dtype"; rc = CA_ERR_INVALID;
+  }
+  if (staging) hipFree(staging);
+  return rc;
+}
+
+template <typename YT>
+void launch_prep(ca_engine* h, const double* logL, const double* extra) {
+  hipLaunchKernelGGL((k_prep_cells<YT>), dim3((unsigned)h->N), dim3(CA_TB), 0, h->stream, (const YT*)h->Y, logL, extra, h->A, h->cn,
+                     h->s64, h->s32, h->N, h->G, h->Gp, h->C);
+}
+
+int create_impl(ca_engine* h, const ca_problem* p) {
+  const int N = (int)h->N; (void)N;
+  HIPCK(h, hipSetDevice(h->device));
+  hipDeviceProp_t prop;
+  HIPCK(h, hipGetDeviceProperties(&prop, h->device));
+  h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  HIPCK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIPCK(h, hipHostMalloc((void**)&h->host_pinned, 64 * sizeof(double)));
+  CACK(upload_y(h, p));
+  const int G = h->G, C = h->C, K = h->K, P = h->P, S = h->S, D = h->D;
+  const int64_t Nn = h->N;
+  h->nchunk = cdiv(C, CA_CW);
+  h->ngblk = cdiv(G, CA_TB);
+  h->ncblk = cdiv(Nn, CA_TB);
+  // ---- sweep decomposition
+  const int target_blocks = 8 * h->n_cu;
+  h->gsplit = std::max(1, std::min(cdiv(target_blocks, h->ncblk), std::max(1, G / 64)));
+  h->gchunk = cdiv(G, h->gsplit);
+  h->gsplit = cdiv(G, h->gchunk);
+  h->RG = G >= 1024 ? 4 : 1;
+  h->ntile = cdiv(G, 64 * h->RG);
+  const int gblocks = cdiv(h->ntile, CA_TB / 64);
+  h->csplit = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(target_blocks, gblocks), std::max<int64_t>(1, Nn / 64)));
+  h->cchunk = (Nn + h->csplit - 1) / h->csplit;
+  h->csplit = cdiv(Nn, h->cchunk);
+  h->TR = 128;
+  h->nrb = cdiv(Nn, h->TR);
+  while ((int64_t)h->nrb * h->nseg < 8 * h->n_cu && h->TR > 16) { h->TR /= 2; h->nrb = cdiv(Nn, h->TR); }
+  // ---- constants
+  std::vector<double> Lrm((size_t)G * C), logL((size_t)G * C);
+  std::vector<float> Lb((size_t)h->nchunk * G * CA_CW, 0.f);
+  for (int g = 0; g < G; ++g)
+    for (int c = 0; c < C; ++c) {
+      const double v = p->L[hidx(p->layout, g, c, G, C)];
+      Lrm[(size_t)g * C + c] = v;
+      logL[(size_t)g * C + c] = std::log(v);
+      Lb[((size_t)(c / CA_CW) * G + g) * CA_CW + (c % CA_CW)] = (float)v;
+    }
+  CACK(dalloc(h, &h->Lb, (int64_t)Lb.size()));
+  CACK(upload_f(h, h->Lb, Lb));
+  double* logL_dev = nullptr; double* extra_dev = nullptr;
+  HIPCK(h, hipMalloc((void**)&logL_dev, logL.size() * sizeof(double)));
+  HIPCK(h, hipMemcpy(logL_dev, logL.data(), logL.size() * sizeof(double), hipMemcpyHostToDevice));
+  if (p->extra_loglik) {
+    std::vector<double> ex((size_t)Nn * C);
+    for (int64_t n = 0; n < Nn; ++n)
+      for (int c = 0; c < C; ++c) ex[(size_t)n * C + c] = p->extra_loglik[hidx(p->layout, n, c, Nn, C)];
+    HIPCK(h, hipMalloc((void**)&extra_dev, ex.size() * sizeof(double)));
+    HIPCK(h, hipMemcpy(extra_dev, ex.data(), ex.size() * sizeof(double), hipMemcpyHostToDevice));
+  }
+  CACK(dalloc(h, &h->A, Nn * C));
+  CACK(dalloc(h, &h->cn, Nn));
+  CACK(dalloc(h, &h->s64, Nn));
+  CACK(dalloc(h, &h->s32, Nn));
+  CACK(dalloc(h, &h->colsum, G));
+  if (h->ystore == CA_YSTORE_U8) launch_prep<uint8_t>(h, logL_dev, extra_dev);
+  else if (h->ystore == CA_YSTORE_U16) launch_prep<uint16_t>(h, logL_dev, extra_dev);
+  else launch_prep<float>(h, logL_dev, extra_dev);
+  HIPCK(h, hipGetLastError());
+  HIPCK(h, hipStreamSynchronize(h->stream));
+  hipFree(logL_dev);
+  if (extra_dev) hipFree(extra_dev);
+  // ---- variables (:240-272)
+  CACK(dalloc(h, &h->F, Nn * std::max(D, 1)));
+  CACK(dalloc(h, &h->m_psi, Nn * std::max(K, 1)));
+  CACK(dalloc(h, &h->v_psi, Nn * std::max(K, 1)));
+  CACK(dalloc(h, &h->g_psi, Nn * std::max(K, 1)));
+  CACK(dalloc(h, &h->glogit, Nn * C));
+  CACK(dalloc(h, &h->m_gl, Nn * C));
+  CACK(dalloc(h, &h->v_gl, Nn * C));
+  CACK(dalloc(h, &h->dgl, Nn * C));
+  CACK(dalloc(h, &h->V, (int64_t)G * std::max(D, 1)));
+  CACK(dalloc(h, &h->m_V, (int64_t)G * std::max(D, 1)));
+  CACK(dalloc(h, &h->v_V, (int64_t)G * std::max(D, 1)));
+  CACK(dalloc(h, &h->g_V, (int64_t)G * std::max(D, 1)));
+  CACK(dalloc(h, &h->Vs, (int64_t)G * std::max(D, 1)));
+  CACK(dalloc(h, &h->loc, G)); CACK(dalloc(h, &h->ls, G));
+  CACK(dalloc(h, &h->m_loc, G)); CACK(dalloc(h, &h->v_loc, G));
+  CACK(dalloc(h, &h->m_ls, G)); CACK(dalloc(h, &h->v_ls, G));
+  CACK(dalloc(h, &h->g_loc, G)); CACK(dalloc(h, &h->g_ls, G));
+  CACK(dalloc(h, &h->vchi, std::max(K, 1))); CACK(dalloc(h, &h->m_v, std::max(K, 1))); CACK(dalloc(h, &h->v_v, std::max(K, 1)));
+  CACK(dalloc(h, &h->g_v, std::max(K, 1)));
+  CACK(dalloc(h, &h->alpha_u, C)); CACK(dalloc(h, &h->m_a, C)); CACK(dalloc(h, &h->v_a, C)); CACK(dalloc(h, &h->g_a, C));
+  {
+    std::vector<float> Fh((size_t)Nn * std::max(D, 1), 0.f);
+    if (D > 0) {
+      for (int64_t n = 0; n < Nn; ++n) {
+        for (int k = 0; k < K; ++k) Fh[(size_t)n * D + k] = (float)p->psi0[hidx(p->layout, n, k, Nn, K)];
+        for (int q = 0; q < P; ++q) Fh[(size_t)n * D + K + q] = (float)p->X[hidx(p->layout, n, q, Nn, P)];
+      }
+    }
+    CACK(upload_f(h, h->F, Fh));
+    std::vector<float> l0((size_t)G);
+    for (int g = 0; g < G; ++g) l0[g] = (float)p->loc0[g];
+    CACK(upload_f(h, h->loc, l0));
+  }
+  // ---- pass buffers
+  CACK(dalloc(h, &h->mu32, (int64_t)S * G));
+  CACK(dalloc(h, &h->Mb, (int64_t)S * h->nchunk * G * CA_CW));
+  CACK(dalloc(h, &h->vmm, 2 * std::max(D, 1)));
+  CACK(dalloc(h, &h->vmm_part, (int64_t)h->ngblk * 2 * std::max(D, 1)));
+  CACK(dalloc(h, &h->etamax2, Nn));
+  CACK(dalloc(h, &h->gene_part, (int64_t)h->ngblk * (3 + K)));
+  CACK(dalloc(h, &h->Zpart, (int64_t)S * h->gsplit * h->nchunk * Nn * CA_CW));
+  CACK(dalloc(h, &h->coef, (int64_t)S * h->nchunk * Nn * CA_CW));
+  CACK(dalloc(h, &h->scratch, Nn * C));
+  CACK(dalloc(h, &h->cell_part, (int64_t)h->ncblk * (3 + C)));
+  CACK(dalloc(h, &h->gpart, (int64_t)h->csplit * G * (S + D)));
+  CACK(dalloc(h, &h->dFpart, (int64_t)h->ntile * Nn * std::max(D, 1)));
+  CACK(dalloc(h, &h->YWpart, (int64_t)h->nseg * Nn * std::max(K, 1)));
+  CACK(dalloc(h, &h->YTpart, (int64_t)h->nrb * h->Gp * std::max(K, 1)));
+  CACK(dalloc(h, &h->YW, Nn * std::max(K, 1)));
+  CACK(dalloc(h, &h->ytpsi, (int64_t)G * std::max(K, 1)));
+  h->off_g = 3 + C;
+  h->off_y = h->off_g + (int64_t)G * (S + D);
+  h->red_n = h->off_y + (int64_t)G * K;
+  CACK(dalloc(h, &h->red, h->red_n));
+  CACK(dalloc(h, &h->terms_dev, 4));
+  CACK(ensure_elbo_cap(h, 64));
+  CACK(ensure_eps_cap(h, 1));
+  // ---- column sums and Y^T X via the streaming kernel with all-ones factors (exact for integer counts:
+  //      every per-strip partial is an integer < 2^24, the cross-strip sum is fp64)
+  {
+    // colsum: run ypass with K' = 1, psi == 1, W == 0 on temporary factor buffers
+    const int cols = 1 + ((K > 0) ? P : 0);
+    std::vector<double> cs((size_t)G, 0.0), ytx((size_t)G * std::max(P, 1), 0.0);
+    float *Ft = nullptr, *Vt = nullptr, *YWp = nullptr, *YTp = nullptr; double* yt = nullptr;
+    HIPCK(h, hipMalloc((void**)&Ft, (size_t)Nn * sizeof(float)));
+    HIPCK(h, hipMalloc((void**)&Vt, (size_t)G * sizeof(float)));
+    HIPCK(h, hipMalloc((void**)&YWp, (size_t)h->nseg * Nn * sizeof(float)));
+    HIPCK(h, hipMalloc((void**)&YTp, (size_t)h->nrb * h->Gp * sizeof(float)));
+    HIPCK(h, hipMalloc((void**)&yt, (size_t)G * sizeof(double)));
+    HIPCK(h, hipMemsetAsync(Vt, 0, (size_t)G * sizeof(float), h->stream));
+    std::vector<float> col((size_t)Nn);
+    for (int j = 0; j < cols; ++j) {
+      for (int64_t n = 0; n < Nn; ++n) col[n] = j == 0 ? 1.f : (float)p->X[hidx(p->layout, n, j - 1, Nn, P)];
+      HIPCK(h, hipMemcpyAsync(Ft, col.data(), (size_t)Nn * sizeof(float), hipMemcpyHostToDevice, h->stream));
+      const int64_t tasks = (int64_t)h->nrb * h->nseg;
+      dim3 grid(cdiv(tasks, CA_TB / 64));
+      if (h->ystore == CA_YSTORE_U8)
+        hipLaunchKernelGGL((k_ypass<uint8_t, 1>), grid, dim3(CA_TB), 0, h->stream, (const uint8_t*)h->Y, Ft, 1, Vt, 0, YWp, YTp, Nn, G, h->Gp, h->nseg, h->nrb, h->TR, 1);
+      else if (h->ystore == CA_YSTORE_U16)
+        hipLaunchKernelGGL((k_ypass<uint16_t, 1>), grid, dim3(CA_TB), 0, h->stream, (const uint16_t*)h->Y, Ft, 1, Vt, 0, YWp, YTp, Nn, G, h->Gp, h->nseg, h->nrb, h->TR, 1);
+      else
+        hipLaunchKernelGGL((k_ypass<float, 1>), grid, dim3(CA_TB), 0, h->stream, (const float*)h->Y, Ft, 1, Vt, 0, YWp, YTp, Nn, G, h->Gp, h->nseg, h->nrb, h->TR, 1);
+      HIPCK(h, hipGetLastError());
+      hipLaunchKernelGGL(k_yt_reduce, dim3(cdiv(G, CA_TB)), dim3(CA_TB), 0, h->stream, YTp, yt, G, h->Gp, 1, h->nrb);
+      std::vector<double> tmp((size_t)G);
+      HIPCK(h, hipMemcpyAsync(tmp.data(), yt, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIPCK(h, hipStreamSynchronize(h->stream));
+      if (j == 0) cs = tmp;
+      else for (int g = 0; g < G; ++g) ytx[(size_t)g * P + (j - 1)] = tmp[g];
+    }
+    hipFree(Ft); hipFree(Vt); hipFree(YWp); hipFree(YTp); hipFree(yt);
+    CACK(upload_d(h, h->colsum, cs));
+    CACK(dalloc(h, &h->YtX, (int64_t)G * std::max(P, 1)));
+    CACK(upload_d(h, h->YtX, ytx));
+  }
+  h->b1p = (float)h->opt.beta1;
+  h->b2p = (float)h->opt.beta2;
+  CACK(refresh_derived(h));
+  HIPCK(h, hipStreamSynchronize(h->stream));
+  return CA_OK;
+}
+
+struct ParamRef {
+  float* f = nullptr; double* d = nullptr;
+  int64_t rows = 0, cols = 0, stride = 0, off = 0;  // logical rows x cols; device element (r,c) at r*stride + off + c
+  int xform = 0;  // 0 none, 1 softplus, 2 row softmax, 3 exp, 4 softmax (vector)
+  bool matrix = false;
+};
+
+bool find_param(ca_engine* h, const std::string& n, bool grad, ParamRef& r) {
+  const int64_t N = h->N; const int G = h->G, C = h->C, K = h->K, P = h->P, D = h->D;
+  if (n == "loc" || n == "mu") { r.f = grad ? h->g_loc : h->loc; r.rows = G; r.cols = 1; r.stride = 1; r.xform = (n == "mu") ? 1 : 0; return !(grad && n == "mu"); }
+  if (n == "ls") { r.f = grad ? h->g_ls : h->ls; r.rows = G; r.cols = 1; r.stride = 1; return true; }
+  if (n == "gamma_logits" || n == "clone_probs") { r.f = grad ? h->dgl : h->glogit; r.rows = N; r.cols = C; r.stride = C; r.matrix = true; r.xform = (n == "clone_probs") ? 2 : 0; return !(grad && n == "clone_probs"); }
+  if (n == "alpha_unconstr" || n == "alpha") { r.f = grad ? h->g_a : h->alpha_u; r.rows = C; r.cols = 1; r.stride = 1; r.xform = (n == "alpha") ? 4 : 0; return !(grad && n == "alpha"); }
+  if (n == "v" || n == "chi") { r.f = grad ? h->g_v : h->vchi; r.rows = K; r.cols = 1; r.stride = 1; r.xform = (n == "chi") ? 3 : 0; return !(grad && n == "chi"); }
+  if (n == "psi") { r.f = grad ? h->g_psi : h->F; r.rows = N; r.cols = K; r.stride = grad ? K : D; r.matrix = true; return true; }
+  if (n == "W") { r.f = grad ? h->g_V : h->V; r.rows = G; r.cols = K; r.stride = D; r.matrix = true; return true; }
+  if (n == "beta") { r.f = grad ? h->g_V : h->V; r.rows = G; r.cols = (D > 0) ? P : 0; r.stride = D; r.off = K; r.matrix = true; return true; }
+  if (n == "s" && !grad) { r.d = h->s64; r.rows = N; r.cols = 1; r.stride = 1; return true; }
+  return false;
+}
+
+}  // namespace
+
+// =============================================================================== C ABI
+extern "C" {
+
+int ca_abi_version(void) { return CA_ABI_VERSION; }
+
+int ca_default_options(ca_options* o) {
+  if (!o) return CA_ERR_INVALID;
+  memset(o, 0, sizeof(*o));
+  o->learning_rate = 0.1;
+  o->beta1 = 0.9; o->beta2 = 0.999; o->adam_eps = 1e-8;
+  o->seed = 0x5eed5eedull;
+  o->device = 0; o->y_storage = CA_YSTORE_AUTO; o->rank = 0; o->world = 1; o->profile = 0;
+  return CA_OK;
+}
+
+const char* ca_last_error(ca_handle h) { return h ? h->err.c_str() : g_last_error.c_str(); }
+
+int ca_create(const ca_problem* p, const ca_options* o, ca_handle* out) {
+  g_last_error.clear();
+  if (!p || !out) { g_last_error = "null argument"; return CA_ERR_INVALID; }
+  *out = nullptr;
+  ca_options opt;
+  if (o) opt = *o; else ca_default_options(&opt);
+  auto bad = [&](const char* m) { g_last_error = m; return CA_ERR_INVALID; };
+  if (p->N <= 0 || p->G <= 0 || p->C <= 0) return bad("N, G and C must be positive");
+  if (p->C > 256) return bad("C > 256 clones not supported");
+  if (p->K < 0 || p->P < 0 || p->S < 1) return bad("K >= 0, P >= 0, S >= 1 required");
+  const int D = p->K > 0 ? p->K + p->P : 0;
+  if (D > 8) return bad("K + P > 8 not supported");
+  if (!p->Y || !p->L || !p->loc0) return bad("Y, L and loc0 are required");
+  if (p->K > 0 && !p->psi0) return bad("psi0 is required when K > 0");
+  if (p->P > 0 && !p->X) return bad("X is required when P > 0");
+  if (opt.world < 1 || opt.rank < 0 || opt.rank >= opt.world) return bad("bad rank/world");
+  ca_engine* h = new ca_engine();
+  h->N = p->N; h->G = p->G; h->C = p->C; h->K = p->K; h->P = p->P; h->S = p->S; h->D = D;
+  h->layout = p->layout; h->opt = opt; h->device = opt.device;
+  int rc = create_impl(h, p);
+  if (rc != CA_OK) {
+    g_last_error = h->err;
+    ca_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return CA_OK;
+}
+
+int ca_destroy(ca_handle h) {
+  if (!h) return CA_OK;
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->comm) g_rccl.CommDestroy(h->comm);
+  for (auto& e : h->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  for (void* q : h->allocs) hipFree(q);
+  if (h->eps_dev) hipFree(h->eps_dev);
+  if (h->elbo_dev) hipFree(h->elbo_dev);
+  if (h->host_pinned) hipHostFree(h->host_pinned);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return CA_OK;
+}
+
+int ca_get_info(ca_handle h, ca_info* i) {
+  if (!h || !i) return CA_ERR_INVALID;
+  memset(i, 0, sizeof(*i));
+  i->N = h->N; i->G = h->G; i->C = h->C; i->K = h->K; i->P = h->P; i->S = h->S;
+  i->y_storage = h->ystore; i->y_bytes_per_elem = h->ybytes; i->y_device_bytes = h->y_dev_bytes; i->device_bytes = h->dev_bytes;
+  i->gsplit = h->gsplit; i->csplit = h->csplit; i->n_cu = h->n_cu;
+  return CA_OK;
+}
+
+int ca_synchronize(ca_handle h) {
+  if (!h) return CA_ERR_INVALID;
+  HIPCK(h, hipSetDevice(h->device));
+  HIPCK(h, hipStreamSynchronize(h->stream));
+  return CA_OK;
+}
+
+int ca_comm_unique_id(char id[128]) {
+  if (!g_rccl.load()) { g_last_error = g_rccl.err; return CA_ERR_COMM; }
+  ca_nccl_uid u;
+  int rc = g_rccl.GetUniqueId(&u);
+  if (rc != 0) { g_last_error = "ncclGetUniqueId failed"; return CA_ERR_COMM; }
+  memcpy(id, u.internal, 128);
+  return CA_OK;
+}
+
+int ca_comm_init(ca_handle h, const char id[128]) {
+  if (!h || !id) return CA_ERR_INVALID;
+  if (!g_rccl.load()) { h->err = g_rccl.err; return CA_ERR_COMM; }
+  HIPCK(h, hipSetDevice(h->device));
+  ca_nccl_uid u;
+  memcpy(u.internal, id, 128);
+  int rc = g_rccl.CommInitRank(&h->comm, h->opt.world, u, h->opt.rank);
+  if (rc != 0) {
+    h->err = std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+    h->comm = nullptr;
+    return CA_ERR_COMM;
+  }
+  // the per-gene count totals are sums over ALL cells: reduce once at setup
+  CACK(allreduce(h, h->colsum, h->G));
+  if (h->P > 0 && h->K > 0) CACK(allreduce(h, h->YtX, (int64_t)h->G * h->P));
+  HIPCK(h, hipStreamSynchronize(h->stream));
+  return CA_OK;
+}
+
+static int stage_one(ca_handle h, const float* eps) { return stage_eps(h, eps, 1, 1); }
+
+int ca_gamma_init(ca_handle h, const float* eps) {
+  if (!h) return CA_ERR_INVALID;
+  HIPCK(h, hipSetDevice(h->device));
+  CACK(stage_one(h, eps));
+  CACK(run_pass(h, 0, CA_MODE_GINIT, 0, nullptr));
+  HIPCK(h, hipStreamSynchronize(h->stream));
+  return CA_OK;
+}
+
+int ca_elbo(ca_handle h, const float* eps, double* elbo) {
+  if (!h || !elbo) return CA_ERR_INVALID;
+  HIPCK(h, hipSetDevice(h->device));
+  CACK(stage_one(h, eps));
+  CACK(run_pass(h, 0, CA_MODE_ELBO, 0, h->elbo_dev));
+  return read_doubles(h, h->elbo_dev, elbo, 1);
+}
+
+int ca_elbo_terms(ca_handle h, const float* eps, double terms[3]) {
+  if (!h || !terms) return CA_ERR_INVALID;
+  HIPCK(h, hipSetDevice(h->device));
+  CACK(stage_one(h, eps));
+  CACK(run_pass(h, 0, CA_MODE_ELBO, 0, h->elbo_dev));
+  return read_doubles(h, h->terms_dev, terms, 3);
+}
+
+int ca_step(ca_handle h, const float* eps) {
+  if (!h) return CA_ERR_INVALID;
+  HIPCK(h, hipSetDevice(h->device));
+  CACK(stage_one(h, eps));
+  CACK(run_pass(h, 0, CA_MODE_TRAIN, 1, h->elbo_dev));
+  HIPCK(h, hipStreamSynchronize(h->stream));
+  return CA_OK;
+}
+
+int ca_gradients(ca_handle h, const float* eps, double* elbo) {
+  if (!h) return CA_ERR_INVALID;
+  HIPCK(h, hipSetDevice(h->device));
+  CACK(stage_one(h, eps));
+  CACK(run_pass(h, 0, CA_MODE_TRAIN, 0, h->elbo_dev));
+  double e;
+  CACK(read_doubles(h, h->elbo_dev, &e, 1));
+  if (elbo) *elbo = e;
+  return CA_OK;
+}
+
+int ca_run(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_stream, int64_t n_draws, double* trace, int32_t* n_elbo) {
+  if (!h || !trace || !n_elbo || max_iter < 0) return CA_ERR_INVALID;
+  HIPCK(h, hipSetDevice(h->device));
+  const int64_t need = 2 + 2 * (int64_t)max_iter;
+  CACK(stage_eps(h, eps_stream, n_draws, need));
+  CACK(ensure_elbo_cap(h, 1 + (int64_t)max_iter));
+  *n_elbo = 0;
+  CACK(run_pass(h, 0, CA_MODE_GINIT, 0, nullptr));                      // :368-369
+  CACK(run_pass(h, 1, CA_MODE_ELBO, 0, h->elbo_dev));                   // :372
+  double val;
+  CACK(read_doubles(h, h->elbo_dev, &val, 1));
+  trace[0] = val; *n_elbo = 1;
+  if (std::isnan(val)) { h->err = "Initial elbo is NA"; return CA_ERR_NAN; }   // :374-376
+  double diffs[10];
+  for (double& d : diffs) d = 1e3;                                      // :379
+  for (int i = 1; i <= max_iter; ++i) {
+    CACK(run_pass(h, 2 * (int64_t)i, CA_MODE_TRAIN, 1, nullptr));       // :401
+    CACK(run_pass(h, 2 * (int64_t)i + 1, CA_MODE_ELBO, 0, h->elbo_dev + i));   // :403
+    double nv;
+    CACK(read_doubles(h, h->elbo_dev + i, &nv, 1));
+    const double diff = (nv - val) / std::fabs(val);
+    for (int j = 0; j < 9; ++j) diffs[j] = diffs[j + 1];
+    diffs[9] = diff;
+    trace[i] = nv; *n_elbo = i + 1;
+    val = nv;
+    double mean = 0.0;
+    for (double d : diffs) mean += std::fabs(d);
+    mean /= 10.0;
+    if (std::isnan(mean)) { h->err = "missing value where TRUE/FALSE needed"; return CA_ERR_NAN; }  // R's if (NA) at :414
+    if (mean < rel_tol) break;                                          // :414-415
+  }
+  return CA_OK;
+}
+
+int ca_iterate(ca_handle h, int32_t n_iter, const float* eps_stream, int64_t n_draws, double* last_elbo) {
+  if (!h || n_iter < 0) return CA_ERR_INVALID;
+  HIPCK(h, hipSetDevice(h->device));
+  CACK(stage_eps(h, eps_stream, n_draws, 2 * (int64_t)n_iter));
+  CACK(ensure_elbo_cap(h, std::max(1, n_iter)));
+  for (int i = 0; i < n_iter; ++i) {
+    CACK(run_pass(h, 2 * (int64_t)i, CA_MODE_TRAIN, 1, nullptr));
+    CACK(run_pass(h, 2 * (int64_t)i + 1, CA_MODE_ELBO, 0, h->elbo_dev + i));
+  }
+  if (last_elbo && n_iter > 0) return read_doubles(h, h->elbo_dev + (n_iter - 1), last_elbo, 1);
+  HIPCK(h, hipStreamSynchronize(h->stream));
+  return CA_OK;
+}
+
+int ca_final_elbo(ca_handle h, int32_t n_rep, const float* eps_stream, int64_t n_draws, double* values, double* mean, double* sd) {
+  if (!h || n_rep < 1) return CA_ERR_INVALID;
+  HIPCK(h, hipSetDevice(h->device));
+  CACK(stage_eps(h, eps_stream, n_draws, n_rep));
+  CACK(ensure_elbo_cap(h, n_rep));
+  for (int i = 0; i < n_rep; ++i) CACK(run_pass(h, i, CA_MODE_ELBO, 0, h->elbo_dev + i));
+  std::vector<double> v((size_t)n_rep);
+  HIPCK(h, hipMemcpyAsync(v.data(), h->elbo_dev, (size_t)n_rep * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCK(h, hipStreamSynchronize(h->stream));
+  double m = 0.0;
+  for (double x : v) m += x;
+  m /= n_rep;
+  double ss = 0.0;
+  for (double x : v) ss += (x - m) * (x - m);
+  if (values) memcpy(values, v.data(), (size_t)n_rep * sizeof(double));
+  if (mean) *mean = m;
+  if (sd) *sd = n_rep > 1 ? std::sqrt(ss / (n_rep - 1)) : NAN;
+  return CA_OK;
+}
+
+static int get_generic(ca_handle h, const char* name, double* out, bool grad) {
+  if (!h || !name || !out) return CA_ERR_INVALID;
+  HIPCK(h, hipSetDevice(h->device));
+  ParamRef r;
+  if (!find_param(h, name, grad, r)) { h->err = std::string("unknown parameter name: ") + name; return CA_ERR_INVALID; }
+  if (r.rows * r.cols == 0) return CA_OK;
+  if (r.d) {
+    HIPCK(h, hipMemcpyAsync(out, r.d, (size_t)r.rows * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return CA_OK;
+  }
+  std::vector<float> buf;
+  CACK(download_f(h, buf, r.f, r.rows * std::max<int64_t>(r.stride, 1)));
+  std::vector<double> row((size_t)std::max<int64_t>(r.cols, 1));
+  if (r.xform == 4) {  // softmax over a vector
+    double mx = -INFINITY, se = 0.0;
+    for (int64_t i = 0; i < r.rows; ++i) mx = std::max(mx, (double)buf[i]);
+    for (int64_t i = 0; i < r.rows; ++i) se += std::exp((double)buf[i] - mx);
+    for (int64_t i = 0; i < r.rows; ++i) out[i] = std::exp((double)buf[i] - mx - std::log(se));
+    return CA_OK;
+  }
+  for (int64_t i = 0; i < r.rows; ++i) {
+    for (int64_t c = 0; c < r.cols; ++c) row[c] = (double)buf[i * r.stride + r.off + c];
+    if (r.xform == 1) for (auto& x : row) x = x > 0 ? x + std::log1p(std::exp(-x)) : std::log1p(std::exp(x));
+    if (r.xform == 3) for (auto& x : row) x = std::exp(x);
+    if (r.xform == 2) {
+      double mx = -INFINITY, se = 0.0;
+      for (int64_t c = 0; c < r.cols; ++c) mx = std::max(mx, row[c]);
+      for (int64_t c = 0; c < r.cols; ++c) se += std::exp(row[c] - mx);
+      const double lse = mx + std::log(se);
+      for (int64_t c = 0; c < r.cols; ++c) row[c] = std::exp(row[c] - lse);
+    }
+    for (int64_t c = 0; c < r.cols; ++c) out[r.matrix ? hidx(h->layout, i, c, r.rows, r.cols) : i] = row[c];
+  }
+  return CA_OK;
+}
+
+int ca_get_param(ca_handle h, const char* name, double* out) { return get_generic(h, name, out, false); }
+int ca_get_gradient(ca_handle h, const char* name, double* out) { return get_generic(h, name, out, true); }
+
+int ca_set_param(ca_handle h, const char* name, const double* in) {
+  if (!h || !name || !in) return CA_ERR_INVALID;
+  HIPCK(h, hipSetDevice(h->device));
+  ParamRef r;
+  if (!find_param(h, name, false, r) || r.xform != 0 || r.d) { h->err = std::string("cannot set parameter: ") + name; return CA_ERR_INVALID; }
+  if (r.rows * r.cols == 0) return CA_OK;
+  std::vector<float> buf;
+  CACK(download_f(h, buf, r.f, r.rows * std::max<int64_t>(r.stride, 1)));
+  for (int64_t i = 0; i < r.rows; ++i)
+    for (int64_t c = 0; c < r.cols; ++c)
+      buf[i * r.stride + r.off + c] = (float)in[r.matrix ? hidx(h->layout, i, c, r.rows, r.cols) : i];
+  CACK(upload_f(h, r.f, buf));
+  CACK(refresh_derived(h));
+  HIPCK(h, hipStreamSynchronize(h->stream));
+  return CA_OK;
+}
+
+int ca_get_kernel_times(ca_handle h, double ms[CA_KERNEL_COUNT], int64_t launches[CA_KERNEL_COUNT]) {
+  if (!h) return CA_ERR_INVALID;
+  HIPCK(h, hipSetDevice(h->device));
+  CACK(prof_flush(h));
+  for (int i = 0; i < CA_KERNEL_COUNT; ++i) {
+    if (ms) ms[i] = h->k_ms[i];
+    if (launches) launches[i] = h->k_n[i];
+  }
+  return CA_OK;
+}
+
+int ca_reset_kernel_times(ca_handle h) {
+  if (!h) return CA_ERR_INVALID;
+  CACK(prof_flush(h));
+  for (int i = 0; i < CA_KERNEL_COUNT; ++i) { h->k_ms[i] = 0; h->k_n[i] = 0; }
+  return CA_OK;
+}
+
+int ca_eps_draw(uint64_t seed, uint64_t draw, int64_t n, float* out) {
+  if (!out || n < 0) return CA_ERR_INVALID;
+  ca_philox::normal_draw(seed, draw, n, out);
+  return CA_OK;
+}
+
+}  // extern "C"

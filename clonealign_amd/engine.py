@@ -1,0 +1,323 @@
+"""ctypes binding of ``libclonealign_hip.so`` (C ABI: ``include/clonealign_hip.h``).
+
+This is the product path: there is NO CPU fallback.  Importing works anywhere (so the
+symbol table can be checked without a GPU); constructing a :class:`HipEngine` fails loudly
+when the library is missing or no MI355X is visible.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libclonealign_hip.so")
+
+CA_OK = 0
+CA_ERR_NAN = 4
+CA_F64, CA_F32, CA_I32, CA_U16, CA_U8 = 0, 1, 2, 3, 4
+CA_ROW_MAJOR, CA_COL_MAJOR = 0, 1
+YSTORE = {"auto": 0, "f32": 1, "u16": 2, "u8": 3}
+YSTORE_NAME = {v: k for k, v in YSTORE.items()}
+KERNEL_NAMES = ("fwd", "bwd", "ypass", "cell", "other")
+
+EXPORTS = (
+    "ca_abi_version", "ca_default_options", "ca_create", "ca_destroy", "ca_last_error", "ca_get_info",
+    "ca_synchronize", "ca_comm_unique_id", "ca_comm_init", "ca_gamma_init", "ca_elbo", "ca_elbo_terms",
+    "ca_step", "ca_gradients", "ca_run", "ca_iterate", "ca_final_elbo", "ca_get_param", "ca_set_param",
+    "ca_get_gradient", "ca_get_kernel_times", "ca_reset_kernel_times", "ca_eps_draw",
+)
+
+
+class CaProblem(C.Structure):
+    _fields_ = [("N", C.c_int64), ("G", C.c_int32), ("C", C.c_int32), ("K", C.c_int32), ("P", C.c_int32),
+                ("S", C.c_int32), ("layout", C.c_int32), ("y_dtype", C.c_int32), ("y_on_device", C.c_int32),
+                ("Y", C.c_void_p), ("L", C.c_void_p), ("psi0", C.c_void_p), ("loc0", C.c_void_p),
+                ("X", C.c_void_p), ("extra_loglik", C.c_void_p)]
+
+
+class CaOptions(C.Structure):
+    _fields_ = [("learning_rate", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
+                ("adam_eps", C.c_double), ("seed", C.c_uint64), ("device", C.c_int32),
+                ("y_storage", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32), ("profile", C.c_int32),
+                ("reserved", C.c_int32 * 7)]
+
+
+class CaInfo(C.Structure):
+    _fields_ = [("N", C.c_int64), ("G", C.c_int32), ("C", C.c_int32), ("K", C.c_int32), ("P", C.c_int32),
+                ("S", C.c_int32), ("y_storage", C.c_int32), ("y_bytes_per_elem", C.c_int32),
+                ("y_device_bytes", C.c_int64), ("device_bytes", C.c_int64), ("gsplit", C.c_int32),
+                ("csplit", C.c_int32), ("n_cu", C.c_int32), ("reserved", C.c_int32 * 8)]
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen the engine; raises (never falls back) when it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            f"{p} not found: build the HIP engine first (python -c 'import __graft_entry__ as g; g.build()' "
+            "or make -C clonealign_amd/csrc). clonealign_amd has no CPU fallback.")
+    lib = C.CDLL(p)
+    lib.ca_last_error.restype = C.c_char_p
+    lib.ca_last_error.argtypes = [C.c_void_p]
+    for name in EXPORTS:
+        if name != "ca_last_error":
+            getattr(lib, name).restype = C.c_int
+    lib.ca_create.argtypes = [C.POINTER(CaProblem), C.POINTER(CaOptions), C.POINTER(C.c_void_p)]
+    lib.ca_destroy.argtypes = [C.c_void_p]
+    lib.ca_get_info.argtypes = [C.c_void_p, C.POINTER(CaInfo)]
+    lib.ca_synchronize.argtypes = [C.c_void_p]
+    lib.ca_comm_unique_id.argtypes = [C.c_char_p]
+    lib.ca_comm_init.argtypes = [C.c_void_p, C.c_char_p]
+    lib.ca_gamma_init.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ca_elbo.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+    lib.ca_elbo_terms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+    lib.ca_step.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ca_gradients.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
+    lib.ca_run.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_int64, C.c_void_p,
+                           C.POINTER(C.c_int32)]
+    lib.ca_iterate.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_double)]
+    lib.ca_final_elbo.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
+                                  C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.ca_get_param.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+    lib.ca_set_param.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+    lib.ca_get_gradient.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+    lib.ca_get_kernel_times.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ca_reset_kernel_times.argtypes = [C.c_void_p]
+    lib.ca_eps_draw.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+class EngineError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"clonealign_hip error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+_Y_DTYPES = {np.dtype(np.float64): CA_F64, np.dtype(np.float32): CA_F32, np.dtype(np.int32): CA_I32,
+             np.dtype(np.uint16): CA_U16, np.dtype(np.uint8): CA_U8}
+
+
+def comm_unique_id():
+    lib = load_library()
+    buf = C.create_string_buffer(128)
+    rc = lib.ca_comm_unique_id(buf)
+    if rc != CA_OK:
+        raise EngineError(rc, (lib.ca_last_error(None) or b"").decode())
+    return bytes(buf.raw)
+
+
+class HipEngine:
+    """One fit on one MI355X: same constructor/method protocol as the oracle models."""
+
+    VAR_NAMES = ("W", "v", "psi", "beta", "alpha_unconstr", "loc", "ls", "gamma_logits")
+
+    def __init__(self, Y, L, psi0, loc0, K, S=1, X=None, extra_loglik=None, learning_rate=0.1,
+                 device=0, y_storage="auto", seed=0x5EED5EED, rank=0, world=1, profile=False,
+                 y_device_ptr=None, y_device_dtype=None, shape=None, comm_id=None):
+        self.lib = load_library()
+        self.h = C.c_void_p()
+        if y_device_ptr is not None:
+            N, G = shape
+            y_dt = _Y_DTYPES[np.dtype(y_device_dtype)]
+            y_ptr = C.c_void_p(int(y_device_ptr))
+            self._keep = []
+        else:
+            Y = np.asarray(Y)
+            if Y.dtype not in _Y_DTYPES:
+                Y = Y.astype(np.float64)
+            Y = np.ascontiguousarray(Y)
+            N, G = Y.shape
+            y_dt = _Y_DTYPES[Y.dtype]
+            y_ptr = Y.ctypes.data_as(C.c_void_p)
+            self._keep = [Y]
+        L = np.ascontiguousarray(np.asarray(L, dtype=np.float64))
+        self.N, self.G, self.C = int(N), int(G), int(L.shape[1])
+        self.K, self.S = int(K), int(S)
+        loc0 = np.ascontiguousarray(np.asarray(loc0, dtype=np.float64))
+        psi0 = np.ascontiguousarray(np.asarray(psi0, dtype=np.float64).reshape(self.N, self.K))
+        Xc = None if X is None else np.ascontiguousarray(np.asarray(X, dtype=np.float64).reshape(self.N, -1))
+        self.P = 0 if Xc is None else Xc.shape[1]
+        ex = None if extra_loglik is None else np.ascontiguousarray(np.asarray(extra_loglik, dtype=np.float64))
+        if L.shape[0] != self.G or loc0.shape[0] != self.G:
+            raise ValueError("L / loc0 do not match the number of genes")
+        self._keep += [L, loc0, psi0, Xc, ex]
+        ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
+        prob = CaProblem(N=self.N, G=self.G, C=self.C, K=self.K, P=self.P, S=self.S, layout=CA_ROW_MAJOR,
+                         y_dtype=y_dt, y_on_device=int(y_device_ptr is not None), Y=y_ptr, L=ptr(L),
+                         psi0=ptr(psi0) if self.K > 0 else None, loc0=ptr(loc0), X=ptr(Xc), extra_loglik=ptr(ex))
+        opt = CaOptions()
+        self.lib.ca_default_options(C.byref(opt))
+        opt.learning_rate = float(learning_rate)
+        opt.device = int(device)
+        opt.y_storage = YSTORE[y_storage] if isinstance(y_storage, str) else int(y_storage)
+        opt.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        opt.rank, opt.world, opt.profile = int(rank), int(world), int(bool(profile))
+        rc = self.lib.ca_create(C.byref(prob), C.byref(opt), C.byref(self.h))
+        if rc != CA_OK:
+            msg = (self.lib.ca_last_error(None) or b"").decode()
+            self.h = C.c_void_p()
+            raise EngineError(rc, msg)
+        if world > 1:
+            if comm_id is None:
+                raise ValueError("world > 1 needs comm_id (bytes from comm_unique_id(), broadcast from rank 0)")
+            self._ck(self.lib.ca_comm_init(self.h, comm_id))
+
+    # -------------------------------------------------------------- plumbing
+    def _ck(self, rc):
+        if rc != CA_OK:
+            raise EngineError(rc, (self.lib.ca_last_error(self.h) or b"").decode())
+
+    def _eps(self, eps):
+        if eps is None:
+            return None, None
+        e = np.ascontiguousarray(np.asarray(eps, dtype=np.float32)).reshape(-1)
+        if e.size != self.S * self.G:
+            raise ValueError("eps must have S*G elements")
+        return e, e.ctypes.data_as(C.c_void_p)
+
+    def _stream(self, eps_stream, need):
+        """eps_stream: None (built-in), ndarray [draws,S,G], or an object with .block(n)."""
+        if eps_stream is None:
+            return None, None, 0
+        if hasattr(eps_stream, "block"):
+            arr = eps_stream.block(need)
+        else:
+            arr = np.asarray(eps_stream, dtype=np.float32)
+        arr = np.ascontiguousarray(arr, dtype=np.float32).reshape(-1, self.S * self.G)
+        return arr, arr.ctypes.data_as(C.c_void_p), arr.shape[0]
+
+    def info(self):
+        i = CaInfo()
+        self._ck(self.lib.ca_get_info(self.h, C.byref(i)))
+        return {f[0]: getattr(i, f[0]) for f in CaInfo._fields_ if f[0] != "reserved"} | {
+            "y_storage_name": YSTORE_NAME[i.y_storage]}
+
+    # -------------------------------------------------------------- sess$run equivalents
+    def gamma_init(self, eps):
+        _k, p = self._eps(eps)
+        self._ck(self.lib.ca_gamma_init(self.h, p))
+
+    def elbo(self, eps):
+        _k, p = self._eps(eps)
+        out = C.c_double()
+        self._ck(self.lib.ca_elbo(self.h, p, C.byref(out)))
+        return out.value
+
+    def elbo_terms(self, eps):
+        _k, p = self._eps(eps)
+        out = (C.c_double * 3)()
+        self._ck(self.lib.ca_elbo_terms(self.h, p, out))
+        return tuple(out)
+
+    def step(self, eps):
+        _k, p = self._eps(eps)
+        self._ck(self.lib.ca_step(self.h, p))
+
+    def gradients(self, eps):
+        _k, p = self._eps(eps)
+        out = C.c_double()
+        self._ck(self.lib.ca_gradients(self.h, p, C.byref(out)))
+        return {n: self._get(self.lib.ca_get_gradient, n) for n in self.VAR_NAMES}, out.value
+
+    def run(self, eps_stream, max_iter, rel_tol):
+        """Whole loop of R/inference-tflow.R:368-417 in one call; returns the ELBO trace."""
+        need = 2 + 2 * int(max_iter)
+        start = getattr(eps_stream, "draw", None)
+        _k, p, n = self._stream(eps_stream, need)
+        trace = np.zeros(int(max_iter) + 1, dtype=np.float64)
+        cnt = C.c_int32()
+        rc = self.lib.ca_run(self.h, int(max_iter), float(rel_tol), p, n, trace.ctypes.data_as(C.c_void_p),
+                             C.byref(cnt))
+        if rc == CA_ERR_NAN:
+            raise FloatingPointError((self.lib.ca_last_error(self.h) or b"").decode())
+        self._ck(rc)
+        if start is not None:      # a stream object advances only by what the loop consumed
+            eps_stream.draw = start + 2 * cnt.value
+        return trace[:cnt.value].copy()
+
+    def iterate(self, n_iter, eps_stream=None, want_elbo=True):
+        _k, p, n = self._stream(eps_stream, 2 * int(n_iter))
+        out = C.c_double()
+        self._ck(self.lib.ca_iterate(self.h, int(n_iter), p, n, C.byref(out) if want_elbo else None))
+        return out.value
+
+    def final_elbo(self, eps_stream, n_rep=20):
+        _k, p, n = self._stream(eps_stream, int(n_rep))
+        vals = np.zeros(int(n_rep), dtype=np.float64)
+        self._ck(self.lib.ca_final_elbo(self.h, int(n_rep), p, n, vals.ctypes.data_as(C.c_void_p), None, None))
+        return vals
+
+    def synchronize(self):
+        self._ck(self.lib.ca_synchronize(self.h))
+
+    # -------------------------------------------------------------- fetch / poke
+    def _shape(self, name):
+        N, G, Cn, K, P = self.N, self.G, self.C, self.K, self.P
+        return {"mu": (G,), "loc": (G,), "ls": (G,), "clone_probs": (N, Cn), "gamma_logits": (N, Cn), "s": (N,),
+                "alpha": (Cn,), "alpha_unconstr": (Cn,), "beta": (G, P), "psi": (N, K), "W": (G, K),
+                "chi": (K,), "v": (K,)}[name]
+
+    def _get(self, fn, name):
+        out = np.zeros(self._shape(name), dtype=np.float64)
+        if out.size:
+            self._ck(fn(self.h, name.encode(), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def get(self, name):
+        return self._get(self.lib.ca_get_param, name)
+
+    def set(self, name, value):
+        v = np.ascontiguousarray(np.asarray(value, dtype=np.float64).reshape(self._shape(name)))
+        if v.size:
+            self._ck(self.lib.ca_set_param(self.h, name.encode(), v.ctypes.data_as(C.c_void_p)))
+
+    def get_params(self):
+        """R/inference-tflow.R:424-434."""
+        out = {n: self.get(n) for n in ("mu", "clone_probs", "s", "alpha")}
+        if self.P > 0:
+            out["beta"] = self.get("beta")
+        if self.K > 0:
+            for n in ("psi", "W", "chi"):
+                out[n] = self.get(n)
+        return out
+
+    def get_state(self):
+        return {n: self.get(n) for n in self.VAR_NAMES}
+
+    def kernel_times(self, reset=False):
+        ms = (C.c_double * 5)()
+        cnt = (C.c_int64 * 5)()
+        self._ck(self.lib.ca_get_kernel_times(self.h, ms, cnt))
+        if reset:
+            self._ck(self.lib.ca_reset_kernel_times(self.h))
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(KERNEL_NAMES)}
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.lib.ca_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def eps_draw(seed, draw, n):
+    """The library's built-in eps stream (host side), for checking against rng.normal_draw."""
+    lib = load_library()
+    out = np.zeros(int(n), dtype=np.float32)
+    rc = lib.ca_eps_draw(int(seed), int(draw), int(n), out.ctypes.data_as(C.c_void_p))
+    if rc != CA_OK:
+        raise EngineError(rc, "ca_eps_draw")
+    return out

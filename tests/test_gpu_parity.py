@@ -1,0 +1,137 @@
+"""GPU parity: the HIP engine (through the C ABI) against the float64 fused oracle.
+
+Tolerances: the engine holds variables in float32 and accumulates the N*G*C contraction in
+float32 FMA chains (exact-f32 products, fp64 cross-block sums); ELBO terms and gradients are
+compared at 2e-5 relative to the largest magnitude of the compared array, parameters after
+Adam steps at 1e-4 (north_star: "ELBO/ML parameters within 1e-4 relative").
+"""
+import numpy as np
+import pytest
+
+from tests._cases import eps_for, make_case, perturbed_state
+
+pytestmark = pytest.mark.gpu
+
+CASES = {
+    "k1": dict(N=300, G=130, C=3, K=1),
+    "k0": dict(N=257, G=70, C=4, K=0),
+    "k2p1s2x": dict(N=200, G=90, C=4, K=2, P=1, S=2, extra=True),
+    "k0p1": dict(N=100, G=40, C=3, K=0, P=1),
+    "c11": dict(N=150, G=64, C=11, K=1),
+    "mid": dict(N=3000, G=1500, C=6, K=1),
+}
+
+
+def _mk(name, **eng_kw):
+    from clonealign_amd.engine import HipEngine
+    from oracle.fused_numpy import FusedModel
+    case = make_case(seed=hash(name) % 1000, **CASES[name])
+    return case, HipEngine(**case, **eng_kw), FusedModel(**case, dtype="float32")
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    if a.size == 0:
+        return 0.0
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_elbo_and_gradients_match_oracle(name):
+    case, eng, ora = _mk(name)
+    try:
+        st = perturbed_state({n: getattr(ora, n).shape for n in ora.VAR_NAMES})
+        for n, v in st.items():
+            setattr(ora, n, v.astype(ora.pdt))
+            eng.set(n, v)
+        eps = eps_for(ora.S, ora.G, 7)
+        te, to = eng.elbo_terms(eps), ora.elbo_terms(eps)
+        for a, b in zip(te, to):
+            assert abs(a - b) <= 2e-5 * max(abs(b), 1.0), (te, to)
+        assert abs(eng.elbo(eps) - ora.elbo(eps)) <= 2e-5 * abs(ora.elbo(eps))
+        ge, ee = eng.gradients(eps)
+        go, eo = ora.gradients(eps)
+        assert abs(ee - eo) <= 2e-5 * abs(eo)
+        for n in ora.VAR_NAMES:
+            assert _rel(ge[n], go[n]) < 2e-5, (n, _rel(ge[n], go[n]))
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("name", ["k1", "k2p1s2x", "c11"])
+def test_gamma_init_and_steps_match_oracle(name):
+    case, eng, ora = _mk(name)
+    try:
+        e0 = eps_for(ora.S, ora.G, 11)
+        eng.gamma_init(e0)
+        ora.gamma_init(e0)
+        assert _rel(eng.get("gamma_logits"), ora.gamma_logits) < 1e-5
+        for i in range(10):
+            e = eps_for(ora.S, ora.G, 100 + i)
+            eng.step(e)
+            ora.step(e)
+        e = eps_for(ora.S, ora.G, 999)
+        assert abs(eng.elbo(e) - ora.elbo(e)) <= 1e-4 * abs(ora.elbo(e))
+        so, se = ora.get_state(), eng.get_state()
+        for n in ora.VAR_NAMES:
+            assert _rel(se[n], so[n]) < 1e-4, (n, _rel(se[n], so[n]))
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("store", ["u8", "u16", "f32"])
+def test_storage_widths_agree(store):
+    case, eng, ora = _mk("k1", y_storage=store)
+    try:
+        assert eng.info()["y_storage_name"] == store
+        eps = eps_for(1, ora.G, 3)
+        st = perturbed_state({n: getattr(ora, n).shape for n in ora.VAR_NAMES})
+        for n, v in st.items():
+            setattr(ora, n, v.astype(ora.pdt))
+            eng.set(n, v)
+        assert abs(eng.elbo(eps) - ora.elbo(eps)) <= 2e-5 * abs(ora.elbo(eps))
+        ge, _ = eng.gradients(eps)
+        go, _ = ora.gradients(eps)
+        for n in ("W", "psi"):
+            assert _rel(ge[n], go[n]) < 2e-5
+    finally:
+        eng.close()
+
+
+def test_non_integer_counts_use_f32_and_col_major_boundary():
+    from clonealign_amd.engine import HipEngine
+    from oracle.fused_numpy import FusedModel
+    case = make_case(120, 50, 3, 1, seed=5)
+    case["Y"] = case["Y"] * 0.5
+    eng, ora = HipEngine(**case), FusedModel(**case, dtype="float32")
+    try:
+        assert eng.info()["y_storage_name"] == "f32"
+        eps = eps_for(1, 50, 1)
+        assert abs(eng.elbo(eps) - ora.elbo(eps)) <= 2e-5 * abs(ora.elbo(eps))
+    finally:
+        eng.close()
+
+
+def test_example_sce_full_fit_matches_oracle():
+    """Config 1 of BASELINE.json: clonealign() on example_sce, 200 iterations, shared eps stream."""
+    import os
+    import clonealign_amd as ca
+    from oracle.fused_numpy import FusedModel
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "example_sce.npz"))
+    Y, L = d["Y"].astype(np.float64), d["L"].astype(np.float64)
+    kw = dict(seed=12345, verbose=False, clone_names=list(d["clones"]))
+    fit_g = ca.clonealign(Y, L, **kw)
+    fit_o = ca.clonealign(Y, L, engine=FusedModel, engine_opts=dict(dtype="float32"), **kw)
+    eg, eo = fit_g["convergence_info"]["elbo"], fit_o["convergence_info"]["elbo"]
+    assert len(eg) == len(eo) == 201
+    assert np.abs(eg - eo).max() <= 1e-4 * np.abs(eo).max()
+    assert abs(fit_g["convergence_info"]["final_elbo"] - fit_o["convergence_info"]["final_elbo"]) <= 1e-4 * abs(
+        fit_o["convergence_info"]["final_elbo"])
+    pg, po = fit_g["ml_params"], fit_o["ml_params"]
+    for k in ("mu", "alpha", "psi", "W", "chi", "clone_probs"):
+        assert _rel(pg[k], po[k]) < 1e-4, k
+    # labels identical except where the oracle itself sits within 1e-3 of the 0.95 threshold
+    mx = po["clone_probs"].max(1)
+    robust = np.abs(mx - 0.95) > 1e-3
+    assert np.array_equal(fit_g["clone"][robust], fit_o["clone"][robust])
+    assert robust.sum() >= 190
