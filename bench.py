@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""ELBO iterations/sec of the clonealign VI hot path on MI355X (BASELINE.json metric).
+
+One "step" = one iteration of the reference's loop (R/inference-tflow.R:401,403): a train
+pass (forward + backward + Adam, fresh eps) followed by a monitor pass (forward, fresh eps).
+Workload at N=1: BASELINE.json configs[2] -- synthetic 100k cells x 5k genes x 8 clones
+(the configuration the metric is quoted on).  With N>1 GPUs the SAME 100k cells are sharded
+across the ranks (configs[3]: strong scaling) with one RCCL all-reduce of the per-gene
+gradient sums per train pass.
+
+  python bench.py --gpus 1 --steps 50 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
+
+
+def algorithmic_work(kernel, N, G, C, K):
+    """Per-launch algorithmic work of each kernel class."""
+    if kernel == "ypass":     # one pass over Y: Y.W and Y^T.psi; canonical 4 B/elem + outputs
+        return "hbm", N * G * 4.0 + (N + G) * K * 4.0 * 2
+    if kernel == "fwd":       # eta 2K, Z 2C, +1 (exp not counted)
+        return "mfma", N * G * (2.0 * C + 2.0 * K + 1.0)
+    if kernel == "bwd":       # eta 2K, t 2C, dM/dmu 2C-equivalent, deta 1, dpsi 2K, dW 2K
+        return "mfma", N * G * (4.0 * C + 6.0 * K + 1.0)
+    return "hbm", 0.0
+
+
+def cpu_baseline(Yh, L, psi0, loc0, K, N_full, budget_s=20.0):
+    """Oracle (kind 'port') timed on the host cores on a bounded cell sample of the same workload."""
+    try:
+        from oracle import c_port
+        return c_port.time_baseline(Yh, L, psi0, loc0, K, N_full, budget_s)
+    except Exception:  # C port unavailable: numpy restatement
+        pass
+    from oracle.fused_numpy import FusedModel
+    n = Yh.shape[0]
+    m = FusedModel(Yh, L, psi0[:n], loc0, K, 1, dtype="float32")
+    rng = np.random.default_rng(0)
+    G = Yh.shape[1]
+    e = lambda: rng.normal(size=(1, G)).astype(np.float32)  # noqa: E731
+    m.gamma_init(e())
+    m.step(e()); m.elbo(e())
+    t0 = time.perf_counter()
+    it = 0
+    while True:
+        m.step(e()); m.elbo(e())
+        it += 1
+        if time.perf_counter() - t0 > budget_s or it >= 50:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": it / dt * n / N_full, "unit": "iterations/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"numpy float64 fused oracle, first {n} of {N_full} cells x {G} genes, {it} iterations, "
+                      f"rate scaled by {n}/{N_full}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--cells", type=int, default=100_000)
+    ap.add_argument("--genes", type=int, default=5_000)
+    ap.add_argument("--clones", type=int, default=8)
+    ap.add_argument("--latent", type=int, default=1)
+    ap.add_argument("--y-storage", default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-cells", type=int, default=4096)
+    ap.add_argument("--seed", type=int, default=20243)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import torch
+    import torch.distributed as dist
+    from clonealign_amd import synth
+    from clonealign_amd.engine import HipEngine, comm_unique_id
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only; data path = RCCL in the engine
+
+    N, G, C, K = args.cells, args.genes, args.clones, args.latent
+    lo = (N * rank) // world
+    hi = (N * (rank + 1)) // world
+    Yd, aux = synth.make_problem_torch(N, G, C, seed=args.seed, rows=(lo, hi), device=f"cuda:{local_rank}")
+    n_loc = hi - lo
+    # data-driven loc0 (R/inference-tflow.R:220-235,262) from GLOBAL column means; psi0 ~ N(0,1)
+    rm = Yd.sum(1, keepdim=True).to(torch.float64) / G
+    colacc = torch.zeros(G, dtype=torch.float64, device=Yd.device)
+    for b0 in range(0, n_loc, 8192):
+        colacc += (Yd[b0:b0 + 8192].to(torch.float64) / rm[b0:b0 + 8192]).sum(0)
+    colacc = colacc.cpu()
+    if world > 1:
+        dist.all_reduce(colacc)
+    from clonealign_amd.hostprep import safe_inverse_softplus
+    loc0 = safe_inverse_softplus(np.maximum(colacc.numpy() / N, 1e-6))
+    psi0 = np.random.default_rng(args.seed + 1).normal(size=(N, K))[lo:hi]
+    torch.cuda.synchronize()
+
+    comm_id = None
+    if world > 1:
+        box = [comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        comm_id = box[0]
+    eng = HipEngine(None, aux["L"], psi0, loc0, K, 1, y_device_ptr=Yd.data_ptr(), y_device_dtype=np.int32,
+                    shape=(n_loc, G), device=local_rank, y_storage=args.y_storage, rank=rank, world=world,
+                    comm_id=comm_id, profile=0)
+    info = eng.info()
+    Ysample = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        Ysample = Yd[:args.cpu_sample_cells].cpu().numpy()
+    del Yd
+    torch.cuda.empty_cache()
+
+    rng = np.random.default_rng(args.seed + 2 + 0)   # same eps on every rank
+    eps0 = rng.normal(size=(1, G)).astype(np.float32)
+    eng.gamma_init(eps0)
+    # --- warmup (+ find the dominant kernel class with all classes timed)
+    eng.set_profile(0x1F)
+    eps_w = rng.normal(size=(2 * max(args.warmup, 1), 1, G)).astype(np.float32)
+    eng.iterate(max(args.warmup, 1), eps_w)
+    kt = eng.kernel_times(reset=True)
+    dominant = max(("fwd", "bwd", "ypass"), key=lambda k: kt[k][0])
+    kid = {"fwd": 0, "bwd": 1, "ypass": 2}[dominant]
+    eng.set_profile(1 << kid)
+    eps_t = rng.normal(size=(2 * args.steps, 1, G)).astype(np.float32)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        eng.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    last = eng.iterate(args.steps, eps_t)
+    eng.synchronize()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0])
+    kt_timed = eng.kernel_times(reset=True)
+    if not np.isfinite(last):
+        raise SystemExit(f"non-finite ELBO after the timed steps: {last}")
+
+    if rank == 0:
+        ms, launches = kt_timed[dominant]
+        per_launch_s = ms / max(launches, 1) * 1e-3
+        bound, work = algorithmic_work(dominant, n_loc, G, C, K)
+        if bound == "hbm":
+            achieved, peak, unit = work / per_launch_s / 1e9, PEAK_HBM_GBS, "GB/s"
+        else:
+            achieved, peak, unit = work / per_launch_s / 1e12, PEAK_F32_TFLOPS, "TFLOP/s"
+        out = {
+            "metric": "ELBO iterations/sec", "value": args.steps / dt, "unit": "iterations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"synthetic {N} cells x {G} genes x {C} clones, K={K}, S=1, cell-sharded over "
+                                   f"{world} GPU(s) (BASELINE.json configs[{2 if world == 1 else 3}])",
+                       "cells": N, "genes": G, "clones": C, "K": K, "mc_samples": 1, "learning_rate": 0.1,
+                       "y_storage": info["y_storage_name"], "y_bytes_per_elem": info["y_bytes_per_elem"],
+                       "parallelism": f"cells/{world}" if world > 1 else "single"},
+            "roofline": {"bound": bound, "kernel": dominant, "achieved": achieved, "peak": peak, "unit": unit,
+                         "frac": achieved / peak, "traffic": None,
+                         "launch_ms": per_launch_s * 1e3, "launches": int(launches)},
+            "kernel_ms_per_iter_warmup": {k: v[0] / max(args.warmup, 1) for k, v in kt.items()},
+            "final_elbo": last,
+        }
+        if Ysample is not None:
+            out["cpu_baseline"] = cpu_baseline(Ysample, aux["L"], psi0, loc0, K, N)
+        print(json.dumps(out), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -107,7 +107,7 @@ struct ca_engine {
   // ---- comm
   ca_nccl_comm comm = nullptr;
   // ---- profiling
-  std::vector<EvPair> ev_pool; size_t ev_used = 0;
+  std::vector<EvPair> ev_pool; size_t ev_used = 0; bool prof_open = false;
   double k_ms[CA_KERNEL_COUNT] = {0}; int64_t k_n[CA_KERNEL_COUNT] = {0};
   int n_cu = 256;
 };
@@ -160,7 +160,8 @@ int prof_flush(ca_engine* h) {
   return CA_OK;
 }
 int prof_begin(ca_engine* h, int kid) {
-  if (!h->opt.profile) return CA_OK;
+  h->prof_open = false;
+  if (!((h->opt.profile >> kid) & 1)) return CA_OK;
   if (h->ev_used == h->ev_pool.size()) {
     if (h->ev_pool.size() < 2048) {
       EvPair p; p.kid = kid;
@@ -173,10 +174,12 @@ int prof_begin(ca_engine* h, int kid) {
   }
   h->ev_pool[h->ev_used].kid = kid;
   HIPCK(h, hipEventRecord(h->ev_pool[h->ev_used].a, h->stream));
+  h->prof_open = true;
   return CA_OK;
 }
 int prof_end(ca_engine* h) {
-  if (!h->opt.profile) return CA_OK;
+  if (!h->prof_open) return CA_OK;
+  h->prof_open = false;
   HIPCK(h, hipEventRecord(h->ev_pool[h->ev_used].b, h->stream));
   h->ev_used++;
   return CA_OK;
@@ -1032,6 +1035,13 @@ int ca_reset_kernel_times(ca_handle h) {
   if (!h) return CA_ERR_INVALID;
   CACK(prof_flush(h));
   for (int i = 0; i < CA_KERNEL_COUNT; ++i) { h->k_ms[i] = 0; h->k_n[i] = 0; }
+  return CA_OK;
+}
+
+int ca_set_profile(ca_handle h, int32_t mask) {
+  if (!h) return CA_ERR_INVALID;
+  CACK(prof_flush(h));
+  h->opt.profile = mask;
   return CA_OK;
 }
 

@@ -24,7 +24,7 @@ EXPORTS = (
     "ca_abi_version", "ca_default_options", "ca_create", "ca_destroy", "ca_last_error", "ca_get_info",
     "ca_synchronize", "ca_comm_unique_id", "ca_comm_init", "ca_gamma_init", "ca_elbo", "ca_elbo_terms",
     "ca_step", "ca_gradients", "ca_run", "ca_iterate", "ca_final_elbo", "ca_get_param", "ca_set_param",
-    "ca_get_gradient", "ca_get_kernel_times", "ca_reset_kernel_times", "ca_eps_draw",
+    "ca_get_gradient", "ca_get_kernel_times", "ca_reset_kernel_times", "ca_set_profile", "ca_eps_draw",
 )
 
 
@@ -89,6 +89,7 @@ def load_library(path=None):
     lib.ca_get_gradient.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
     lib.ca_get_kernel_times.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ca_reset_kernel_times.argtypes = [C.c_void_p]
+    lib.ca_set_profile.argtypes = [C.c_void_p, C.c_int32]
     lib.ca_eps_draw.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p]
     if path is None:
         _lib = lib
@@ -160,7 +161,8 @@ class HipEngine:
         opt.device = int(device)
         opt.y_storage = YSTORE[y_storage] if isinstance(y_storage, str) else int(y_storage)
         opt.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
-        opt.rank, opt.world, opt.profile = int(rank), int(world), int(bool(profile))
+        opt.rank, opt.world = int(rank), int(world)
+        opt.profile = 0x1F if profile is True else int(profile)
         rc = self.lib.ca_create(C.byref(prob), C.byref(opt), C.byref(self.h))
         if rc != CA_OK:
             msg = (self.lib.ca_last_error(None) or b"").decode()
@@ -300,6 +302,9 @@ class HipEngine:
         if reset:
             self._ck(self.lib.ca_reset_kernel_times(self.h))
         return {k: (ms[i], cnt[i]) for i, k in enumerate(KERNEL_NAMES)}
+
+    def set_profile(self, mask):
+        self._ck(self.lib.ca_set_profile(self.h, int(mask)))
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:

@@ -71,7 +71,7 @@ typedef struct ca_options {
   int32_t device;                   /* HIP device ordinal */
   int32_t y_storage;                /* ca_ystore: on-device width of the count matrix */
   int32_t rank, world;              /* cell-sharded data parallel: shard `rank` of `world` */
-  int32_t profile;                  /* nonzero: time kernels with HIP events (ca_get_kernel_times) */
+  int32_t profile;                  /* bitmask over ca_kernel_id: time those kernel classes with HIP events */
   int32_t reserved[7];
 } ca_options;
 
@@ -148,9 +148,10 @@ int ca_set_param(ca_handle h, const char* name, const double* in);
 /* after ca_gradients(): d ELBO / d variable, raw-variable names as in ca_set_param */
 int ca_get_gradient(ca_handle h, const char* name, double* out);
 
-/* profile != 0: accumulated HIP-event time per kernel class since the last reset */
+/* accumulated HIP-event time per profiled kernel class since the last reset; ca_set_profile changes the mask */
 int ca_get_kernel_times(ca_handle h, double ms[CA_KERNEL_COUNT], int64_t launches[CA_KERNEL_COUNT]);
 int ca_reset_kernel_times(ca_handle h);
+int ca_set_profile(ca_handle h, int32_t mask);
 
 /* built-in eps stream (Philox4x32-10 + Box-Muller), host side: out[n] for draw `draw` */
 int ca_eps_draw(uint64_t seed, uint64_t draw, int64_t n, float* out);
