@@ -135,3 +135,52 @@ def test_example_sce_full_fit_matches_oracle():
     robust = np.abs(mx - 0.95) > 1e-3
     assert np.array_equal(fit_g["clone"][robust], fit_o["clone"][robust])
     assert robust.sum() >= 190
+
+
+@pytest.mark.parametrize("name,n_iter", [("cfg1", 200), ("tiny_k0", 12), ("tiny_full", 12)])
+def test_engine_replays_golden_vectors(name, n_iter):
+    """Committed goldens (literal float64 autodiff oracle, explicit eps stream) through the C ABI."""
+    from clonealign_amd.api import clone_assignment
+    from clonealign_amd.engine import HipEngine
+    from tests import _golden
+    g = _golden.load(name)
+    eng = HipEngine(**_golden.case_of(name, g))
+    try:
+        trace, final = _golden.replay(eng, g, n_iter)
+        assert np.abs(trace - g["elbo_trace"]).max() <= 1e-4 * np.abs(g["elbo_trace"]).max()
+        assert np.abs(final - g["final_elbos"]).max() <= 1e-4 * np.abs(g["final_elbos"]).max()
+        p = eng.get_params()
+        for k, v in p.items():
+            assert _rel(v, g["param_" + k]) < 1e-4, k
+        if name == "cfg1":
+            lab = clone_assignment(p["clone_probs"], ["A", "B", "C"])
+            mx = g["param_clone_probs"].max(1)
+            robust = np.abs(mx - 0.95) > 1e-3
+            assert np.array_equal(lab[robust], g["clone"][robust]) and robust.sum() >= 190
+    finally:
+        eng.close()
+
+
+def test_ca_run_equals_call_by_call_loop_and_builtin_stream():
+    """ca_run() (whole loop in the library) == the R-style loop over ca_step/ca_elbo; the built-in
+    Philox stream (eps = NULL) equals the same stream injected from clonealign_amd.rng."""
+    from clonealign_amd.engine import HipEngine
+    from clonealign_amd.inference import run_vi_loop
+    from clonealign_amd.rng import EpsStream
+    case = make_case(seed=21, **CASES["k1"])
+    a, b, c = HipEngine(**case, seed=4242), HipEngine(**case), HipEngine(**case)
+    try:
+        t_builtin = a.run(None, 15, 1e-9)
+        t_inject = b.run(EpsStream(4242, 1, b.G), 15, 1e-9)
+        t_loop = np.array(run_vi_loop(c, EpsStream(4242, 1, c.G), 15, 1e-9))
+        assert np.array_equal(t_builtin, t_inject)
+        assert np.array_equal(t_inject, t_loop)
+        assert len(t_loop) == 16
+        # early stop: a loose tolerance stops after the 10-long window fills (R/inference-tflow.R:379,414)
+        d = HipEngine(**case)
+        es = EpsStream(1, 1, d.G)
+        t = d.run(es, 100, 1.0)
+        assert len(t) == 11 and es.draw == 22
+        d.close()
+    finally:
+        a.close(); b.close(); c.close()

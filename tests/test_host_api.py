@@ -1,0 +1,174 @@
+"""Host-side mirror of the reference API, driven on CPU with the oracle standing in for the engine.
+
+The first two tests are line-by-line translations of the reference's own
+tests/testthat/test_clonealign.R:4-39 and :42-66.
+"""
+import warnings
+
+import numpy as np
+import pytest
+
+import clonealign_amd as ca
+from clonealign_amd import hostprep
+from clonealign_amd.api import ClonealignFit
+from oracle.fused_numpy import FusedModel
+from tests import _golden
+
+ORACLE = dict(engine=FusedModel, engine_opts=dict(dtype="float32"))
+
+
+@pytest.fixture(scope="module")
+def example():
+    return _golden.example()
+
+
+def _cal(example, **kw):
+    Y, L, clones, genes, cells = example
+    sce = {"assays": {"counts": Y.T}, "rownames": genes}      # SingleCellExperiment stand-in: genes x cells
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return ca.clonealign(sce, L, clone_names=clones, verbose=False, **ORACLE, **kw)
+
+
+def test_clonealign_returns_a_valid_object(example):          # test_clonealign.R:4-39
+    Y, L, clones, genes, cells = example
+    N, G, C = Y.shape[0], Y.shape[1], 3
+    cal = _cal(example, max_iter=5, seed=1)
+    assert isinstance(cal, ClonealignFit)
+    assert len(cal["clone"]) == N
+    assert set(np.unique(cal["clone"])) <= set(clones) | {"unassigned"}
+    assert cal["ml_params"]["clone_probs"].shape == (N, C)
+    assert len(cal["retained_genes"]) == len(cal["ml_params"]["mu"]) <= G
+    assert {"clone_probs", "mu", "s"} <= set(cal["ml_params"])
+    assert {"clone", "convergence_info", "retained_genes", "correlations", "ml_params"} <= set(cal)
+    assert list(cal["ml_params"]) == ["mu", "clone_probs", "s", "alpha", "psi", "W", "chi"]   # :469-470
+    assert list(cal["convergence_info"]) == ["final_elbo", "sd_final_elbo", "elbo"]           # :463
+    assert len(cal["convergence_info"]["elbo"]) == 6
+    assert "A clonealign_fit for 200 cells, 100 genes, and 3 clones" in repr(cal)
+
+
+def test_seed_setting_works_correctly(example):               # test_clonealign.R:42-66
+    cal1 = _cal(example, max_iter=5, seed=12345)
+    cal2 = _cal(example, max_iter=5, seed=12345)
+    assert cal1["convergence_info"]["final_elbo"] == cal2["convergence_info"]["final_elbo"]
+    cal3 = _cal(example, max_iter=5, seed=54321)
+    assert cal1["convergence_info"]["final_elbo"] != cal3["convergence_info"]["final_elbo"]
+
+
+def test_vignette_known_answer_soft(example):
+    """docs/introduction_to_clonealign.html:746-819,908 (package 1.99.2): after preprocessing 6 cells x
+    66 genes remain, all cells -> clone A with prob ~0.999, final ELBOs -562.6 ... -562.9.  The rendered
+    run is from an older model version, so only MC-noise-level agreement is asserted."""
+    Y, L, clones, genes, cells = example
+    pp = ca.preprocess_for_clonealign(Y, L, gene_names=genes, cell_names=cells)
+    assert pp["gene_expression_data"].shape == (6, 67)
+    assert list(pp["retained_cells"]) == ["cell_21", "cell_58", "cell_81", "cell_117", "cell_118", "cell_184"]
+    fit = ca.clonealign(pp["gene_expression_data"], pp["copy_number_data"], clone_names=clones, verbose=False,
+                        seed=0, **ORACLE)
+    assert len(fit["ml_params"]["mu"]) == 66                   # "Removing 1 genes with low counts"
+    assert list(fit["clone"]) == ["A"] * 6
+    assert fit["ml_params"]["clone_probs"][:, 0].min() > 0.99
+    assert abs(fit["convergence_info"]["final_elbo"] - (-562.75)) < 10.0
+
+
+def test_run_clonealign_picks_best_elbo(example):
+    Y, L, clones, genes, cells = example
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        best = ca.run_clonealign(Y[:60], L, initial_shrinks=(0, 5), n_repeats=2, print_elbos=False, seed=3,
+                                 max_iter=3, verbose=False, clone_names=clones, **ORACLE)
+    info = best["multirun_info"]
+    assert len(info["elbos"]) == 4 and len(info["clone_prevalences_at_different_shrinks"]) == 4
+    assert best["convergence_info"]["final_elbo"] == info["elbos"].max()
+
+
+def test_softplus_helpers_and_saturate():
+    x = np.array([1e-3, 0.5, 3.0, 40.0])
+    np.testing.assert_allclose(hostprep.softplus(hostprep.safe_inverse_softplus(x)), x, rtol=1e-12)
+    np.testing.assert_allclose(hostprep.safe_inverse_softplus(x[:3]), hostprep.inverse_softplus(x[:3]), rtol=1e-9)
+    with pytest.raises(ValueError, match="Inverse softplus only takes positive values"):
+        hostprep.safe_inverse_softplus(np.array([1.0, -0.1]))
+    assert hostprep.saturate(np.array([[1, 7], [6, 9]]), 6).tolist() == [[1, 6], [6, 6]]
+
+
+def test_pca_init_matches_prcomp_definition(example):
+    Y = example[0]
+    pcs = hostprep.pca_init(Y, 2, None)
+    X = np.log2(Y + 1)
+    Xs = (X - X.mean(0)) / X.std(0, ddof=1)
+    u, s, vt = np.linalg.svd(Xs, full_matrices=False)
+    ref = u[:, :2] * s[:2]
+    ref = ref / ref.std(0, ddof=1)
+    for k in range(2):
+        assert min(np.abs(pcs[:, k] - ref[:, k]).max(), np.abs(pcs[:, k] + ref[:, k]).max()) < 1e-9
+    np.testing.assert_allclose(pcs.std(0, ddof=1), 1.0, rtol=1e-12)
+    big = hostprep._top_eigvecs(Xs, 1)[:, 0]
+    assert min(np.abs(big - vt[0]).max(), np.abs(big + vt[0]).max()) < 1e-6
+
+
+def test_clone_assignment_threshold_and_ties():
+    g = np.array([[0.96, 0.04, 0.0], [0.5, 0.5, 0.0], [0.0, 0.949, 0.051], [0.0, 0.95, 0.05]])
+    assert list(ca.clone_assignment(g, ["A", "B", "C"])) == ["A", "unassigned", "unassigned", "B"]
+    assert list(ca.clone_assignment(g, ["A", "B", "C"], 0.5)) == ["A", "A", "B", "B"]
+
+
+def test_compute_correlations_matches_numpy():
+    rng = np.random.default_rng(0)
+    Y = rng.poisson(3, size=(40, 6)).astype(float)
+    Y[:, 5] = 2.0                                             # constant gene -> NA in R
+    L = rng.integers(1, 4, size=(6, 3)).astype(float)
+    clones = np.array(["A", "B", "C", "unassigned"], dtype=object)[rng.integers(0, 4, 40)]
+    cor = ca.compute_correlations(Y, L, clones, ["A", "B", "C"])
+    keep = clones != "unassigned"
+    idx = np.array([["A", "B", "C"].index(c) for c in clones[keep]])
+    for i in range(5):
+        x = L[i, idx]
+        if x.std() > 0:
+            assert abs(cor[i] - np.corrcoef(x, Y[keep, i])[0, 1]) < 1e-12
+    assert np.isnan(cor[5])
+
+
+def test_error_behaviour_mirrors_reference(example):
+    Y, L, clones, *_ = example
+    with pytest.raises(ValueError, match="same number of genes"):
+        ca.clonealign(Y, L[:50], **ORACLE)
+    Yz = Y.copy()
+    Yz[3] = 0
+    with pytest.raises(ValueError, match="Some cells have no counts mapping"):
+        ca.clonealign(Yz, L, verbose=False, **ORACLE)
+    with pytest.raises(TypeError, match="must be SingleCellExperiment"):
+        ca.clonealign([1, 2, 3], L)
+    with pytest.raises(NotImplementedError):
+        ca.clonealign(Y, L, dtype="float64", verbose=False, **ORACLE)
+
+
+def test_covariates_and_allele_term_run(example):
+    Y, L, clones, *_ = example
+    rng = np.random.default_rng(1)
+    n = 50
+    x = rng.normal(size=n)
+    V = 7
+    clone_allele = rng.integers(1, 4, size=(V, 3)).astype(float)
+    cov = rng.integers(0, 9, size=(n, V)).astype(float)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fit = ca.clonealign(Y[:n], L, x=x, clone_allele=clone_allele, cov=cov, ref=cov, max_iter=3, verbose=False,
+                            seed=2, **ORACLE)
+    assert fit["ml_params"]["beta"].shape[1] == 1
+    assert list(fit["ml_params"]) == ["mu", "clone_probs", "s", "alpha", "beta", "psi", "W", "chi"]
+    assert fit["clone_probs_from_snv"].shape == (n, 3)
+    np.testing.assert_allclose(fit["clone_probs_from_snv"].sum(1), 1.0)
+
+
+def test_product_path_refuses_to_run_without_the_hip_engine(example):
+    """No engine= override => the HIP engine; on a box without a GPU that must be a loud failure."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("GPU present")
+    except ImportError:
+        pass
+    from clonealign_amd.engine import EngineError
+    Y, L, *_ = example
+    with pytest.raises((EngineError, RuntimeError)):
+        ca.clonealign(Y[:20], L, max_iter=1, verbose=False)
