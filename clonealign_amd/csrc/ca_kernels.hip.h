@@ -228,14 +228,26 @@ __global__ void __launch_bounds__(CA_TB) k_ypass(const YT* __restrict__ Y, const
     for (int k = 0; k < KK; ++k) YTpart[((int64_t)rb * Gp + col0 + j) * K + koff + k] = acc[j][k];
 }
 
-// sum the per-row-block partials of Y^T.psi in fixed order (fp64)
-__global__ void k_yt_reduce(const float* __restrict__ YTpart, double* __restrict__ ytpsi, int G, int Gp, int K, int nrb) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= G * K) return;
-  const int g = i / K, k = i - g * K;
-  double a = 0.0;
-  for (int rb = 0; rb < nrb; ++rb) a += (double)YTpart[((int64_t)rb * Gp + g) * K + k];
-  ytpsi[i] = a;
+// Column sums of a [rows][ld] float slab in fp64 and in a fixed order: out[c] = sum_r part[r*ld + c].
+// Used for every cross-block reduction of per-gene partials (Y^T.psi strips, backward-sweep cell
+// splits).  Block = 64 columns x 4 row lanes (256-byte coalesced row reads), LDS combine.
+__global__ void __launch_bounds__(CA_TB) k_colsum(const float* __restrict__ part, double* __restrict__ out, int rows,
+                                                  int64_t ld, int cols) {
+  __shared__ double sm[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx;
+  double a0 = 0.0, a1 = 0.0;
+  if (c < cols) {
+    int r = ty;
+    for (; r + 4 < rows; r += 8) {
+      a0 += (double)part[(int64_t)r * ld + c];
+      a1 += (double)part[(int64_t)(r + 4) * ld + c];
+    }
+    if (r < rows) a0 += (double)part[(int64_t)r * ld + c];
+  }
+  sm[ty][tx] = a0 + a1;
+  __syncthreads();
+  if (ty == 0 && c < cols) out[c] = ((sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]));
 }
 
 // ------------------------------------------------------------------ per-gene preparation of one pass
@@ -609,6 +621,104 @@ __global__ void __launch_bounds__(CA_TB) k_cell(const float* __restrict__ Zpart 
   }
 }
 
+// Same epilogue with CP (a power of two, C <= CP <= 64) lanes per cell: one lane per (cell, clone),
+// softmax / log-sum-exp reductions by xor-shuffles inside the lane group.  CA_TB / CP cells per block.
+template <int CP>
+__global__ void __launch_bounds__(CA_TB) k_cell_par(const float* __restrict__ Zpart, const double* __restrict__ A,
+                                                    const double* __restrict__ cn, const double* __restrict__ s64,
+                                                    const float* __restrict__ etamax2, float* __restrict__ glogit,
+                                                    const float* __restrict__ alpha_u, const float* __restrict__ F,
+                                                    const float* __restrict__ YWpart, float* __restrict__ YW,
+                                                    float* __restrict__ coef, float* __restrict__ dgl,
+                                                    double* __restrict__ cell_part, int64_t N, int C, int S, int D, int K,
+                                                    int gsplit, int nchunk, int nseg, int mode) {
+  __shared__ double sm[CA_TB];
+  __shared__ double la[64];
+  constexpr int CPB = CA_TB / CP;  // cells per block
+  if (threadIdx.x == 0) {
+    double mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmax(mx, (double)alpha_u[c]);
+    double se = 0.0;
+    for (int c = 0; c < C; ++c) se += exp((double)alpha_u[c] - mx);
+    const double lse = mx + log(se);
+    for (int c = 0; c < C; ++c) la[c] = (double)alpha_u[c] - lse;
+  }
+  __syncthreads();
+  const int c = threadIdx.x % CP;
+  const int64_t n = (int64_t)blockIdx.x * CPB + threadIdx.x / CP;
+  const bool okn = n < N, ok = okn && c < C;
+  const int64_t nn = okn ? n : N - 1;
+  const int cc_ = c < C ? c : C - 1;
+  const double gl = ok ? (double)glogit[nn * C + cc_] : -INFINITY;
+  auto gmax = [](double v) {
+#pragma unroll
+    for (int o = CP / 2; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, CP));
+    return v;
+  };
+  auto gsum = [](double v) {
+#pragma unroll
+    for (int o = CP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, CP);
+    return v;
+  };
+  const double mx = gmax(gl);
+  const double lse = mx + log(gsum(ok ? exp(gl - mx) : 0.0));
+  const double lg = gl - lse;
+  const double gam = ok ? exp(lg) : 0.0;
+  const double sn = s64[nn];
+  const double em = (D > 0) ? (double)etamax2[nn] * CA_LN2 : 0.0;
+  const int ch = cc_ / CA_CW, cc = cc_ % CA_CW;
+  double lzsum = 0.0;
+  for (int s = 0; s < S; ++s) {
+    double Z = 0.0;
+    for (int sp = 0; sp < gsplit; ++sp) Z += (double)Zpart[((((int64_t)s * nchunk + ch) * gsplit + sp) * N + nn) * CA_CW + cc];
+    lzsum += log(Z) + em;
+    if (mode == CA_MODE_TRAIN && ok) coef[(((int64_t)s * nchunk + ch) * N + nn) * CA_CW + cc] = (float)(-gam * sn / ((double)S * Z));
+  }
+  const double Anc = A[nn * C + cc_];
+  if (mode == CA_MODE_GINIT) {
+    const double ll = ok ? (double)S * Anc - sn * lzsum : -INFINITY;   // sum over samples, no log_alpha (:338)
+    const double m2 = gmax(ll);
+    const double l2 = m2 + log(gsum(ok ? exp(ll - m2) : 0.0));
+    if (ok) glogit[nn * C + cc_] = (float)(ll - l2);
+    return;
+  }
+  const double llp = Anc - sn * lzsum / (double)S;
+  const double f = llp + la[cc_] - lg;
+  const bool live = ok && gam != 0.0;
+  const double fbar = gsum(live ? gam * f : 0.0);
+  if (mode == CA_MODE_TRAIN && ok) dgl[nn * C + cc_] = live ? (float)(gam * (f - fbar)) : 0.f;
+  double ee = live ? gam * llp : 0.0, pr = live ? gam * la[cc_] : 0.0, q = live ? gam * lg : 0.0;
+  if (okn && c == 0) {
+    ee += cn[nn];
+    for (int k = 0; k < K; ++k) {
+      double yw = 0.0;
+      for (int sg = 0; sg < nseg; ++sg) yw += (double)YWpart[((int64_t)sg * N + nn) * K + k];
+      YW[nn * K + k] = (float)yw;
+      const double ps = (double)F[nn * D + k];
+      ee += ps * yw;
+      pr += -0.5 * ps * ps - 0.5 * CA_LOG2PI;
+    }
+  }
+  const int W_ = 3 + C;
+  const double r0 = ca_block_sum(ee, sm);
+  const double r1 = ca_block_sum(pr, sm);
+  const double r2 = ca_block_sum(q, sm);
+  if (threadIdx.x == 0) {
+    cell_part[(int64_t)blockIdx.x * W_ + 0] = r0;
+    cell_part[(int64_t)blockIdx.x * W_ + 1] = r1;
+    cell_part[(int64_t)blockIdx.x * W_ + 2] = r2;
+  }
+  // per-clone sums of gamma over the block's cells, fixed order
+  __syncthreads();
+  sm[threadIdx.x] = gam;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    double a = 0.0;
+    for (int i = 0; i < CPB; ++i) a += sm[i * CP + threadIdx.x];
+    cell_part[(int64_t)blockIdx.x * W_ + 3 + threadIdx.x] = a;
+  }
+}
+
 // fixed-order reduction of block partials: out[j] = sum_b part[b][j]  (one block)
 __global__ void __launch_bounds__(CA_TB) k_reduce_part(const double* __restrict__ part, double* __restrict__ out, int nblk, int W_) {
   __shared__ double sm[CA_TB];
@@ -617,21 +727,6 @@ __global__ void __launch_bounds__(CA_TB) k_reduce_part(const double* __restrict_
     for (int b = threadIdx.x; b < nblk; b += CA_TB) a += part[(int64_t)b * W_ + j];
     const double r = ca_block_sum(a, sm);
     if (threadIdx.x == 0) out[j] = r;
-  }
-}
-
-// per-gene sums of the backward sweep over the cell splits (fp64, fixed order), then the local Y^T.psi
-//   red_g[g][j], j < S+D  <- sum_split gpart[split][g][j];   red_y[g][k] <- ytpsi[g][k]
-__global__ void k_gene_reduce(const float* __restrict__ gpart, const double* __restrict__ ytpsi, double* __restrict__ red_g,
-                              double* __restrict__ red_y, int G, int W_, int csplit, int K) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t ng = (int64_t)G * W_;
-  if (i < ng) {
-    double a = 0.0;
-    for (int sp = 0; sp < csplit; ++sp) a += (double)gpart[(int64_t)sp * ng + i];
-    red_g[i] = a;
-  } else if (i < ng + (int64_t)G * K) {
-    red_y[i - ng] = ytpsi[i - ng];
   }
 }
 

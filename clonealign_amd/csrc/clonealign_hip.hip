@@ -321,8 +321,9 @@ int ensure_ycache(ca_engine* h) {
     HIPCK(h, hipGetLastError());
     CACK(prof_end(h));
   }
-  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_yt_reduce, dim3(cdiv((int64_t)h->G * h->K, CA_TB)), dim3(CA_TB), 0, h->stream,
-                                                h->YTpart, h->ytpsi, h->G, h->Gp, h->K, h->nrb));
+  // YTpart is [nrb][Gp*K]: column sums over the row blocks; ytpsi is laid out [Gp][K] (first G rows used)
+  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->Gp * h->K, 64)), dim3(CA_TB), 0, h->stream,
+                                                h->YTpart, h->ytpsi, h->nrb, (int64_t)h->Gp * h->K, h->Gp * h->K));
   h->ycache_valid = true;
   return CA_OK;
 }
@@ -358,10 +359,31 @@ int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_d
       float* Zp = h->Zpart + (((int64_t)s * h->nchunk + ch) * h->gsplit) * h->N * CA_CW;
       LAUNCH(h, CA_KERNEL_FWD, launch_fwd(nc, h->D, dim3(N256, h->gsplit), h->stream, h->F, h->etamax2, h->Vs, M, Zp, h->N, h->G, h->gchunk));
     }
-  LAUNCH(h, CA_KERNEL_CELL,
-         hipLaunchKernelGGL(k_cell, dim3(N256), dim3(CA_TB), 0, h->stream, h->Zpart, h->A, h->cn, h->s64, h->etamax2, h->glogit,
-                            h->alpha_u, h->F, h->YWpart, h->YW, h->coef, h->dgl, h->scratch, h->cell_part, h->N, h->C, h->S, h->D,
-                            h->K, h->gsplit, h->nchunk, h->nseg, mode));
+  if (h->C <= 64) {
+    int CP = 1;
+    while (CP < h->C) CP <<= 1;
+    dim3 grid(h->ncblk);
+#define CA_CELL(CPV)                                                                                                          \
+  LAUNCH(h, CA_KERNEL_CELL,                                                                                                   \
+         hipLaunchKernelGGL((k_cell_par<CPV>), grid, dim3(CA_TB), 0, h->stream, h->Zpart, h->A, h->cn, h->s64, h->etamax2,    \
+                            h->glogit, h->alpha_u, h->F, h->YWpart, h->YW, h->coef, h->dgl, h->cell_part, h->N, h->C, h->S,  \
+                            h->D, h->K, h->gsplit, h->nchunk, h->nseg, mode))
+    switch (CP) {
+      case 1: CA_CELL(1); break;
+      case 2: CA_CELL(2); break;
+      case 4: CA_CELL(4); break;
+      case 8: CA_CELL(8); break;
+      case 16: CA_CELL(16); break;
+      case 32: CA_CELL(32); break;
+      default: CA_CELL(64); break;
+    }
+#undef CA_CELL
+  } else {
+    LAUNCH(h, CA_KERNEL_CELL,
+           hipLaunchKernelGGL(k_cell, dim3(h->ncblk), dim3(CA_TB), 0, h->stream, h->Zpart, h->A, h->cn, h->s64, h->etamax2, h->glogit,
+                              h->alpha_u, h->F, h->YWpart, h->YW, h->coef, h->dgl, h->scratch, h->cell_part, h->N, h->C, h->S, h->D,
+                              h->K, h->gsplit, h->nchunk, h->nseg, mode));
+  }
   if (mode == CA_MODE_GINIT) return CA_OK;
   LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_reduce_part, dim3(1), dim3(CA_TB), 0, h->stream, h->cell_part, h->red, h->ncblk, 3 + h->C));
   float lr_t = 0.f;
@@ -381,8 +403,10 @@ int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_d
       }
     const int W_ = h->S + h->D;
     LAUNCH(h, CA_KERNEL_OTHER,
-           hipLaunchKernelGGL(k_gene_reduce, dim3(cdiv((int64_t)h->G * (W_ + h->K), CA_TB)), dim3(CA_TB), 0, h->stream, h->gpart,
-                              h->ytpsi, h->red + h->off_g, h->red + h->off_y, h->G, W_, h->csplit, h->K));
+           hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->G * W_, 64)), dim3(CA_TB), 0, h->stream, h->gpart,
+                              h->red + h->off_g, h->csplit, (int64_t)h->G * W_, h->G * W_));
+    if (h->K > 0)
+      HIPCK(h, hipMemcpyAsync(h->red + h->off_y, h->ytpsi, (size_t)h->G * h->K * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     CACK(allreduce(h, h->red, h->red_n));
     if (apply) {
       // lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t), float32 like TF's _prepare()/_apply_dense
@@ -568,10 +592,16 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   const int64_t Nn = h->N;
   h->nchunk = cdiv(C, CA_CW);
   h->ngblk = cdiv(G, CA_TB);
-  h->ncblk = cdiv(Nn, CA_TB);
+  {
+    int CP = 1;
+    while (CP < C) CP <<= 1;
+    h->ncblk = (C <= 64) ? cdiv(Nn, CA_TB / CP) : cdiv(Nn, CA_TB);   // k_cell_par: CA_TB / CP cells per block
+  }
+  const int n256 = cdiv(Nn, CA_TB);
   // ---- sweep decomposition
   const int target_blocks = 8 * h->n_cu;
-  h->gsplit = std::max(1, std::min(cdiv(target_blocks, h->ncblk), std::max(1, G / 64)));
+  // one full round of resident blocks (8 x 256 threads per CU) when the cell blocks alone do not fill the chip
+  h->gsplit = std::max(1, std::min(target_blocks / std::max(n256, 1), std::max(1, G / 64)));
   h->gchunk = cdiv(G, h->gsplit);
   h->gsplit = cdiv(G, h->gchunk);
   h->RG = G >= 1024 ? 4 : 1;
@@ -667,7 +697,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   CACK(dalloc(h, &h->YWpart, (int64_t)h->nseg * Nn * std::max(K, 1)));
   CACK(dalloc(h, &h->YTpart, (int64_t)h->nrb * h->Gp * std::max(K, 1)));
   CACK(dalloc(h, &h->YW, Nn * std::max(K, 1)));
-  CACK(dalloc(h, &h->ytpsi, (int64_t)G * std::max(K, 1)));
+  CACK(dalloc(h, &h->ytpsi, (int64_t)h->Gp * std::max(K, 1)));
   h->off_g = 3 + C;
   h->off_y = h->off_g + (int64_t)G * (S + D);
   h->red_n = h->off_y + (int64_t)G * K;
@@ -686,7 +716,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     HIPCK(h, hipMalloc((void**)&Vt, (size_t)G * sizeof(float)));
     HIPCK(h, hipMalloc((void**)&YWp, (size_t)h->nseg * Nn * sizeof(float)));
     HIPCK(h, hipMalloc((void**)&YTp, (size_t)h->nrb * h->Gp * sizeof(float)));
-    HIPCK(h, hipMalloc((void**)&yt, (size_t)G * sizeof(double)));
+    HIPCK(h, hipMalloc((void**)&yt, (size_t)h->Gp * sizeof(double)));
     HIPCK(h, hipMemsetAsync(Vt, 0, (size_t)G * sizeof(float), h->stream));
     std::vector<float> col((size_t)Nn);
     for (int j = 0; j < cols; ++j) {
@@ -701,7 +731,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
       else
         hipLaunchKernelGGL((k_ypass<float, 1>), grid, dim3(CA_TB), 0, h->stream, (const float*)h->Y, Ft, 1, Vt, 0, YWp, YTp, Nn, G, h->Gp, h->nseg, h->nrb, h->TR, 1);
       HIPCK(h, hipGetLastError());
-      hipLaunchKernelGGL(k_yt_reduce, dim3(cdiv(G, CA_TB)), dim3(CA_TB), 0, h->stream, YTp, yt, G, h->Gp, 1, h->nrb);
+      hipLaunchKernelGGL(k_colsum, dim3(cdiv(h->Gp, 64)), dim3(CA_TB), 0, h->stream, YTp, yt, h->nrb, (int64_t)h->Gp, h->Gp);
       std::vector<double> tmp((size_t)G);
       HIPCK(h, hipMemcpyAsync(tmp.data(), yt, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, h->stream));
       HIPCK(h, hipStreamSynchronize(h->stream));
