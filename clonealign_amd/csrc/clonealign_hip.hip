@@ -102,10 +102,11 @@ struct ca_engine {
   double* red = nullptr; int64_t red_n = 0, off_g = 0, off_y = 0;
   double* elbo_dev = nullptr; int64_t elbo_cap = 0; double* terms_dev = nullptr;
   double* host_pinned = nullptr;  // 8 doubles
-  bool ycache_valid = false;
+  bool ycache_valid = false, sums_global = false;
   uint64_t draw = 0;  // built-in stream position
   // ---- comm
   ca_nccl_comm comm = nullptr;
+  ca_host_allreduce_fn host_ar = nullptr; void* host_ar_user = nullptr; double* host_ar_buf = nullptr; int64_t host_ar_cap = 0;
   // ---- profiling
   std::vector<EvPair> ev_pool; size_t ev_used = 0; bool prof_open = false;
   double k_ms[CA_KERNEL_COUNT] = {0}; int64_t k_n[CA_KERNEL_COUNT] = {0};
@@ -329,13 +330,35 @@ int ensure_ycache(ca_engine* h) {
 }
 
 int allreduce(ca_engine* h, double* buf, int64_t n) {
-  if (h->opt.world <= 1) return CA_OK;
-  if (!h->comm) { h->err = "world > 1 but ca_comm_init() was not called"; return CA_ERR_STATE; }
+  if (h->opt.world <= 1 && !h->comm && !h->host_ar) return CA_OK;   // a 1-rank communicator still reduces (tests)
+  if (h->host_ar) {
+    if (n > h->host_ar_cap) {
+      if (h->host_ar_buf) HIPCK(h, hipHostFree(h->host_ar_buf));
+      HIPCK(h, hipHostMalloc((void**)&h->host_ar_buf, (size_t)n * sizeof(double)));
+      h->host_ar_cap = n;
+    }
+    HIPCK(h, hipMemcpyAsync(h->host_ar_buf, buf, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    if (h->host_ar(h->host_ar_user, h->host_ar_buf, n) != 0) { h->err = "host all-reduce callback failed"; return CA_ERR_COMM; }
+    HIPCK(h, hipMemcpyAsync(buf, h->host_ar_buf, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    return CA_OK;
+  }
+  if (!h->comm) { h->err = "world > 1 but neither ca_comm_init() nor ca_set_host_allreduce() was called"; return CA_ERR_STATE; }
   int rc = g_rccl.AllReduce(buf, buf, (size_t)n, kNcclFloat64, kNcclSum, h->comm, h->stream);
   if (rc != 0) {
     h->err = std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
     return CA_ERR_COMM;
   }
+  return CA_OK;
+}
+
+// the per-gene count totals are sums over ALL cells: reduced once, when the transport is set
+int setup_global_sums(ca_engine* h) {
+  if (h->sums_global) return CA_OK;
+  CACK(allreduce(h, h->colsum, h->G));
+  if (h->P > 0 && h->K > 0) CACK(allreduce(h, h->YtX, (int64_t)h->G * h->P));
+  HIPCK(h, hipStreamSynchronize(h->stream));
+  h->sums_global = true;
   return CA_OK;
 }
 
@@ -829,6 +852,7 @@ int ca_destroy(ca_handle h) {
   if (h->eps_dev) hipFree(h->eps_dev);
   if (h->elbo_dev) hipFree(h->elbo_dev);
   if (h->host_pinned) hipHostFree(h->host_pinned);
+  if (h->host_ar_buf) hipHostFree(h->host_ar_buf);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
   return CA_OK;
@@ -871,11 +895,15 @@ int ca_comm_init(ca_handle h, const char id[128]) {
     h->comm = nullptr;
     return CA_ERR_COMM;
   }
-  // the per-gene count totals are sums over ALL cells: reduce once at setup
-  CACK(allreduce(h, h->colsum, h->G));
-  if (h->P > 0 && h->K > 0) CACK(allreduce(h, h->YtX, (int64_t)h->G * h->P));
-  HIPCK(h, hipStreamSynchronize(h->stream));
-  return CA_OK;
+  return setup_global_sums(h);
+}
+
+int ca_set_host_allreduce(ca_handle h, ca_host_allreduce_fn fn, void* user) {
+  if (!h || !fn) return CA_ERR_INVALID;
+  HIPCK(h, hipSetDevice(h->device));
+  h->host_ar = fn;
+  h->host_ar_user = user;
+  return setup_global_sums(h);
 }
 
 static int stage_one(ca_handle h, const float* eps) { return stage_eps(h, eps, 1, 1); }

@@ -22,7 +22,7 @@ KERNEL_NAMES = ("fwd", "bwd", "ypass", "cell", "other")
 
 EXPORTS = (
     "ca_abi_version", "ca_default_options", "ca_create", "ca_destroy", "ca_last_error", "ca_get_info",
-    "ca_synchronize", "ca_comm_unique_id", "ca_comm_init", "ca_gamma_init", "ca_elbo", "ca_elbo_terms",
+    "ca_synchronize", "ca_comm_unique_id", "ca_comm_init", "ca_set_host_allreduce", "ca_gamma_init", "ca_elbo", "ca_elbo_terms",
     "ca_step", "ca_gradients", "ca_run", "ca_iterate", "ca_final_elbo", "ca_get_param", "ca_set_param",
     "ca_get_gradient", "ca_get_kernel_times", "ca_reset_kernel_times", "ca_set_profile", "ca_eps_draw",
 )
@@ -49,6 +49,8 @@ class CaInfo(C.Structure):
                 ("csplit", C.c_int32), ("n_cu", C.c_int32), ("reserved", C.c_int32 * 8)]
 
 
+HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)
+
 _lib = None
 
 
@@ -74,6 +76,7 @@ def load_library(path=None):
     lib.ca_synchronize.argtypes = [C.c_void_p]
     lib.ca_comm_unique_id.argtypes = [C.c_char_p]
     lib.ca_comm_init.argtypes = [C.c_void_p, C.c_char_p]
+    lib.ca_set_host_allreduce.argtypes = [C.c_void_p, HOST_ALLREDUCE_FN, C.c_void_p]
     lib.ca_gamma_init.argtypes = [C.c_void_p, C.c_void_p]
     lib.ca_elbo.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
     lib.ca_elbo_terms.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
@@ -123,7 +126,7 @@ class HipEngine:
 
     def __init__(self, Y, L, psi0, loc0, K, S=1, X=None, extra_loglik=None, learning_rate=0.1,
                  device=0, y_storage="auto", seed=0x5EED5EED, rank=0, world=1, profile=False,
-                 y_device_ptr=None, y_device_dtype=None, shape=None, comm_id=None):
+                 y_device_ptr=None, y_device_dtype=None, shape=None, comm_id=None, host_allreduce=None):
         self.lib = load_library()
         self.h = C.c_void_p()
         if y_device_ptr is not None:
@@ -169,9 +172,23 @@ class HipEngine:
             self.h = C.c_void_p()
             raise EngineError(rc, msg)
         if world > 1:
-            if comm_id is None:
-                raise ValueError("world > 1 needs comm_id (bytes from comm_unique_id(), broadcast from rank 0)")
-            self._ck(self.lib.ca_comm_init(self.h, comm_id))
+            if host_allreduce is not None:
+                # host_allreduce(np.ndarray float64 view) must sum the array in place over all ranks
+                def _cb(_user, buf, n, _f=host_allreduce):
+                    try:
+                        _f(np.ctypeslib.as_array(buf, shape=(n,)))
+                        return 0
+                    except Exception:          # never unwind through C
+                        import traceback
+                        traceback.print_exc()
+                        return 1
+                self._cb = HOST_ALLREDUCE_FN(_cb)
+                self._ck(self.lib.ca_set_host_allreduce(self.h, self._cb, None))
+            elif comm_id is not None:
+                self._ck(self.lib.ca_comm_init(self.h, comm_id))
+            else:
+                raise ValueError("world > 1 needs comm_id (bytes from comm_unique_id(), broadcast from rank 0) "
+                                 "or host_allreduce")
 
     # -------------------------------------------------------------- plumbing
     def _ck(self, rc):

@@ -113,6 +113,11 @@ int ca_synchronize(ca_handle h);
  * Rank 0 calls ca_comm_unique_id() and distributes the 128 bytes out of band. */
 int ca_comm_unique_id(char id[128]);
 int ca_comm_init(ca_handle h, const char id[128]);
+/* Alternative transport for world > 1 (MPI, gloo, tests): the engine hands the summand buffer to the
+ * host callback, which must replace buf[0..n) by its sum over all ranks (same order on every rank)
+ * and return 0.  Slower than RCCL (one device<->host round trip per reduction); same results. */
+typedef int (*ca_host_allreduce_fn)(void* user, double* buf, int64_t n);
+int ca_set_host_allreduce(ca_handle h, ca_host_allreduce_fn fn, void* user);
 
 /* `sess$run(gamma_init)` + `sess$run(init_gamma)`   (:338-342,368-369) */
 int ca_gamma_init(ca_handle h, const float* eps);

@@ -66,10 +66,23 @@ class FusedModel:
         self.loc = np.asarray(loc0, dtype=np.float64).astype(p)
         self.ls = np.zeros(self.G, p)
         self.gamma_logits = np.zeros((self.N, self.C), p)
+        # cell-sharded evaluation: `allreduce(vec)` must return the sum of `vec` over all
+        # shards.  It is applied at exactly the points where the HIP engine all-reduces.
+        self.allreduce = None
         self.lr, self.b1, self.b2, self.adam_eps = learning_rate, 0.9, 0.999, 1e-8
         self.b1p, self.b2p = p(self.b1), p(self.b2)
         self.m = {n: np.zeros_like(getattr(self, n)) for n in self.VAR_NAMES}
         self.vv = {n: np.zeros_like(getattr(self, n)) for n in self.VAR_NAMES}
+
+    def set_allreduce(self, fn):
+        """Switch to sharded mode: this model holds a shard of the cells; per-gene count totals become global."""
+        self.allreduce = fn
+        self.colsum = fn(self.colsum.copy())
+        if self.YtX.size:
+            self.YtX = fn(self.YtX.reshape(-1).copy()).reshape(self.YtX.shape)
+
+    def _ar(self, v):
+        return v if self.allreduce is None else self.allreduce(np.ascontiguousarray(v, dtype=np.float64))
 
     def _A_blocked(self):
         with np.errstate(divide="ignore"):
@@ -120,31 +133,34 @@ class FusedModel:
         if self.extra is not None:
             llp = llp + self.extra
         logmu = np.log(mu)
+        # ---- per-cell summands: local to a shard, all-reduced as one 3-vector
         T = 0.0
+        psi_prior = 0.0
         if self.D > 0:
             YW = self.Y @ V[:, :self.K]
             T = float((F[:, :self.K] * YW).sum())
-            if self.P > 0:
-                T += float((V[:, self.K:] * self.YtX).sum())
             c["YW"] = YW
-        EE_p_y = (float(self.cn.sum()) + float((self.colsum[None, :] * logmu).sum()) / S + T
-                  + float((gamma * llp).sum()))
+            psi = self.psi.astype(np.float64)
+            psi_prior = float((-0.5 * psi ** 2 - 0.5 * LOG2PI).sum())
+        ent = float(np.where(gamma == 0, 0.0, gamma * log_gamma).sum())
+        loc3 = self._ar(np.array([float(self.cn.sum()) + T + float((gamma * llp).sum()),
+                                  float((gamma * log_alpha[None, :]).sum()) + psi_prior, ent]))
+        # ---- global summands (replicated parameters; identical on every shard)
+        EE_p_y = loc3[0] + float((self.colsum[None, :] * logmu).sum()) / S
+        if self.D > 0 and self.P > 0:
+            EE_p_y += float((V[:, self.K:] * self.YtX).sum())
         xa = np.exp(log_alpha) + 1e-3
         dirichlet = float(((1.0 / C - 1.0) * np.log(xa)).sum()) - (C * gammaln(1.0 / C) - gammaln(1.0))
-        E_log_p_p = float((gamma * log_alpha[None, :]).sum()) \
-            + float((-0.5 * logmu ** 2 - 0.5 * LOG2PI).sum()) / S + dirichlet
+        E_log_p_p = loc3[1] + float((-0.5 * logmu ** 2 - 0.5 * LOG2PI).sum()) / S + dirichlet
         if self.K > 0:
             W = self.W.astype(np.float64)
             v = self.v.astype(np.float64)
             chi = np.exp(v)
             E_log_p_p += float((-0.5 * W ** 2 * chi[None, :] + 0.5 * v[None, :] - 0.5 * LOG2PI).sum())
             E_log_p_p += float((v - chi).sum())
-            psi = self.psi.astype(np.float64)
-            E_log_p_p += float((-0.5 * psi ** 2 - 0.5 * LOG2PI).sum())
         ls = self.ls.astype(np.float64)
         qlp = -0.5 * eps ** 2 - ls[None, :] - 0.5 * LOG2PI + softplus(-x)
-        ent = float(np.where(gamma == 0, 0.0, gamma * log_gamma).sum())
-        E_log_q = float(qlp.mean(0).sum()) + ent
+        E_log_q = float(qlp.mean(0).sum()) + loc3[2]
         c.update(gamma=gamma, log_gamma=log_gamma, log_alpha=log_alpha, llp=llp, logmu=logmu)
         return EE_p_y, E_log_p_p, E_log_q
 
@@ -185,6 +201,15 @@ class FusedModel:
             if self.D > 0:
                 dF[sl] = deta @ V
                 dV += deta.T @ F[sl]
+        YtPsi = self.Y.T @ self.psi.astype(np.float64) if K > 0 else np.zeros((G, 0))
+        sg = gamma.sum(0)
+        if self.allreduce is not None:          # one all-reduce per train pass: [dmu | dV | Y^T psi | sum gamma]
+            pk = self._ar(np.concatenate([dmu.ravel(), dV.ravel(), YtPsi.ravel(), sg]))
+            o = 0
+            dmu = pk[o:o + dmu.size].reshape(dmu.shape); o += dmu.size
+            dV = pk[o:o + dV.size].reshape(dV.shape); o += dV.size
+            YtPsi = pk[o:o + YtPsi.size].reshape(YtPsi.shape); o += YtPsi.size
+            sg = pk[o:o + C]
         g = {}
         # q(mu) parameters
         dmu_tot = self.colsum[None, :] / (S * mu) + dmu - logmu / (S * mu)
@@ -199,7 +224,6 @@ class FusedModel:
             v = self.v.astype(np.float64)
             chi = np.exp(v)
             psi = self.psi.astype(np.float64)
-            YtPsi = self.Y.T @ psi
             g["W"] = YtPsi + dV[:, :K] - W * chi[None, :]
             g["v"] = -0.5 * chi * (W ** 2).sum(0) + 0.5 * G + 1.0 - chi
             g["psi"] = c["YW"] + dF[:, :K] - psi
@@ -217,7 +241,6 @@ class FusedModel:
         g["gamma_logits"] = gamma * (f - fbar)
         # alpha
         alpha = np.exp(log_alpha)
-        sg = gamma.sum(0)
         # d/d log_alpha_c of [sum gamma log_alpha + dirichlet(alpha + 1e-3)], then through log_softmax
         dla = sg + (1.0 / C - 1.0) * alpha / (alpha + 1e-3)
         g["alpha_unconstr"] = dla - alpha * dla.sum()

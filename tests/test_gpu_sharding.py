@@ -1,0 +1,92 @@
+"""The engine's cell-sharded path on ONE GPU: two handles (rank 0/1 of world 2) on two host threads, joined
+by the host all-reduce hook of the C ABI (ca_set_host_allreduce).  Everything but the RCCL transport itself
+is the code the 8-GPU bench runs; the result must match a single-handle fit of all cells."""
+import threading
+
+import numpy as np
+import pytest
+
+from clonealign_amd.sharding import cell_range
+from tests._cases import eps_for, make_case
+
+pytestmark = pytest.mark.gpu
+
+
+class _HostAllreduce:
+    def __init__(self, world):
+        self.world = world
+        self.bar = threading.Barrier(world)
+        self.slots = [None] * world
+        self.sizes = []
+
+    def make(self, rank):
+        def fn(buf):
+            self.slots[rank] = buf.copy()
+            self.bar.wait()
+            tot = self.slots[0].copy()
+            for r in range(1, self.world):
+                tot += self.slots[r]
+            self.bar.wait()
+            buf[:] = tot
+            if rank == 0:
+                self.sizes.append(len(buf))
+        return fn
+
+
+@pytest.mark.parametrize("kw", [dict(N=301, G=140, C=3, K=1), dict(N=260, G=90, C=4, K=2, P=1, S=2, extra=True)])
+def test_two_shards_on_one_gpu_match_single_handle(kw):
+    from clonealign_amd.engine import HipEngine
+    case = make_case(seed=9, **kw)
+    N, G, S = case["Y"].shape[0], case["Y"].shape[1], case["S"]
+    n_iter = 8
+
+    def drive(eng):
+        eng.gamma_init(eps_for(S, G, 0))
+        tr = [eng.elbo(eps_for(S, G, 1))]
+        for i in range(1, n_iter + 1):
+            eng.step(eps_for(S, G, 2 * i))
+            tr.append(eng.elbo(eps_for(S, G, 2 * i + 1)))
+        return np.array(tr), eng.get_state()
+
+    ref = HipEngine(**case)
+    tr_ref, st_ref = drive(ref)
+    ref.close()
+
+    ar = _HostAllreduce(2)
+    out = [None, None]
+
+    def worker(rank):
+        lo, hi = cell_range(N, rank, 2)
+        shard = dict(case)
+        for k in ("Y", "psi0", "X", "extra_loglik"):
+            if shard.get(k) is not None:
+                shard[k] = shard[k][lo:hi]
+        eng = HipEngine(**shard, rank=rank, world=2, host_allreduce=ar.make(rank))
+        out[rank] = drive(eng) + ((lo, hi),)
+        eng.close()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for r in range(2):
+        tr, st, (lo, hi) = out[r]
+        assert np.abs(tr - tr_ref).max() <= 2e-6 * np.abs(tr_ref).max()
+        for n in ("W", "v", "beta", "alpha_unconstr", "loc", "ls"):
+            assert np.abs(st[n] - st_ref[n]).max(initial=0) <= 2e-5 * max(np.abs(st_ref[n]).max(initial=0), 1e-30), n
+            assert np.array_equal(st[n], out[0][1][n])          # replicas stay bit-identical
+        for n in ("psi", "gamma_logits"):
+            assert np.abs(st[n] - st_ref[n][lo:hi]).max(initial=0) <= 2e-5 * max(np.abs(st_ref[n]).max(initial=0), 1e-30), n
+
+
+def test_rccl_communicator_of_one_rank_runs():
+    """ncclCommInitRank with one rank on the visible GPU: the RCCL code path (dlopen, init, all-reduce, destroy)."""
+    from clonealign_amd.engine import HipEngine, comm_unique_id
+    case = make_case(seed=2, N=200, G=64, C=3, K=1)
+    a = HipEngine(**case)
+    ea = a.elbo(eps_for(1, 64, 3))
+    a.close()
+    b = HipEngine(**case, rank=0, world=1)
+    b._ck(b.lib.ca_comm_init(b.h, comm_unique_id()))   # 1-rank communicator: every pass now goes through ncclAllReduce
+    eb = b.elbo(eps_for(1, 64, 3))
+    b.close()
+    assert ea == eb

@@ -1,0 +1,98 @@
+"""world_size-2 gloo tests (CPU): the cell-sharded evaluation -- what is local, what is replicated, what is
+all-reduced and where -- reproduces the single-process fit.  The oracle stands in for the engine (the HIP
+engine implements the same plan and is checked against a single-GPU run in test_gpu_sharding.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from clonealign_amd.sharding import cell_range, reduce_plan
+from oracle.fused_numpy import FusedModel
+from tests._cases import eps_for, make_case
+
+CASES = {"k1": dict(N=61, G=23, C=3, K=1), "k2p1s2": dict(N=50, G=19, C=4, K=2, P=1, S=2, extra=True),
+         "k0": dict(N=40, G=17, C=3, K=0)}
+N_ITER = 6
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(model, S, G):
+    model.gamma_init(eps_for(S, G, 0))
+    trace = [model.elbo(eps_for(S, G, 1))]
+    for i in range(1, N_ITER + 1):
+        model.step(eps_for(S, G, 2 * i))
+        trace.append(model.elbo(eps_for(S, G, 2 * i + 1)))
+    return np.array(trace)
+
+
+def _worker(rank, world, port, name, outdir):
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    case = make_case(seed=5, **CASES[name])
+    N = case["Y"].shape[0]
+    lo, hi = cell_range(N, rank, world)
+    shard = dict(case)
+    for k in ("Y", "psi0", "X", "extra_loglik"):
+        if shard.get(k) is not None:
+            shard[k] = shard[k][lo:hi]
+    m = FusedModel(**shard)
+    sizes = []
+
+    def allreduce(v):
+        t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64).copy())
+        dist.all_reduce(t)
+        sizes.append(t.numel())
+        return t.numpy()
+
+    m.set_allreduce(allreduce)
+    trace = _run(m, m.S, m.G)
+    st = m.get_state()
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), trace=trace, lo=lo, hi=hi, sizes=np.array(sizes), **st)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_two_rank_sharded_fit_equals_single_process(name, tmp_path):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, name, str(tmp_path)), nprocs=2, join=True)
+    case = make_case(seed=5, **CASES[name])
+    ref = FusedModel(**case)
+    tr = _run(ref, ref.S, ref.G)
+    sr = ref.get_state()
+    r = [np.load(tmp_path / f"rank{i}.npz") for i in range(2)]
+    for i in range(2):
+        np.testing.assert_allclose(r[i]["trace"], tr, rtol=1e-10)          # every rank sees the global ELBO
+        for n in ("W", "v", "beta", "alpha_unconstr", "loc", "ls"):          # replicated variables
+            np.testing.assert_allclose(r[i][n], sr[n], rtol=1e-7, atol=1e-9)
+            np.testing.assert_array_equal(r[i][n], r[0][n])                  # bit-identical across ranks
+        lo, hi = int(r[i]["lo"]), int(r[i]["hi"])
+        for n in ("psi", "gamma_logits"):                                    # cell-local variables
+            np.testing.assert_allclose(r[i][n], sr[n][lo:hi], rtol=1e-7, atol=1e-8)
+    # the train-pass payload is what sharding.reduce_plan says the engine reduces
+    plan = reduce_plan(ref.G, ref.C, ref.K, ref.P, ref.S)
+    assert int(r[0]["sizes"].max()) == plan["total"] - 3
+
+
+def test_cell_range_partitions_exactly():
+    for N in (1, 7, 100, 100_000):
+        for W in (1, 2, 3, 8):
+            if W > N:
+                continue
+            rs = [cell_range(N, r, W) for r in range(W)]
+            assert rs[0][0] == 0 and rs[-1][1] == N
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(W - 1))
+            sz = [b - a for a, b in rs]
+            assert max(sz) - min(sz) <= 1
+    with pytest.raises(ValueError):
+        cell_range(10, 2, 2)
