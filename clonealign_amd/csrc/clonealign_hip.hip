@@ -196,14 +196,16 @@ int prof_end(ca_engine* h) {
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ---- template dispatch of the sweeps -------------------------------------------------------
+constexpr int kFwdR = 2;  // cells per lane of the forward sweep
 template <int NC>
 void fwd_nc(int D, dim3 grid, hipStream_t st, const float* F, const float* em, const float* Vs, const float* M, float* Zp,
             int64_t N, int G, int gchunk) {
+  const size_t lds = (size_t)gchunk * (CA_CW + (D > 0 ? D : 0)) * sizeof(float);
   switch (D) {
-    case 0: hipLaunchKernelGGL((k_fwd<NC, 0>), grid, dim3(CA_TB), 0, st, F, em, Vs, M, Zp, N, G, gchunk, D); break;
-    case 1: hipLaunchKernelGGL((k_fwd<NC, 1>), grid, dim3(CA_TB), 0, st, F, em, Vs, M, Zp, N, G, gchunk, D); break;
-    case 2: hipLaunchKernelGGL((k_fwd<NC, 2>), grid, dim3(CA_TB), 0, st, F, em, Vs, M, Zp, N, G, gchunk, D); break;
-    default: hipLaunchKernelGGL((k_fwd<NC, -1>), grid, dim3(CA_TB), 0, st, F, em, Vs, M, Zp, N, G, gchunk, D); break;
+    case 0: hipLaunchKernelGGL((k_fwd_lds<NC, 0, kFwdR>), grid, dim3(CA_TB), lds, st, F, em, Vs, M, Zp, N, G, gchunk, D); break;
+    case 1: hipLaunchKernelGGL((k_fwd_lds<NC, 1, kFwdR>), grid, dim3(CA_TB), lds, st, F, em, Vs, M, Zp, N, G, gchunk, D); break;
+    case 2: hipLaunchKernelGGL((k_fwd_lds<NC, 2, kFwdR>), grid, dim3(CA_TB), lds, st, F, em, Vs, M, Zp, N, G, gchunk, D); break;
+    default: hipLaunchKernelGGL((k_fwd_lds<NC, -1, kFwdR>), grid, dim3(CA_TB), lds, st, F, em, Vs, M, Zp, N, G, gchunk, D); break;
   }
 }
 void launch_fwd(int nc, int D, dim3 grid, hipStream_t st, const float* F, const float* em, const float* Vs, const float* M,
@@ -324,7 +326,7 @@ int ensure_ycache(ca_engine* h) {
   }
   // YTpart is [nrb][Gp*K]: column sums over the row blocks; ytpsi is laid out [Gp][K] (first G rows used)
   LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->Gp * h->K, 64)), dim3(CA_TB), 0, h->stream,
-                                                h->YTpart, h->ytpsi, h->nrb, (int64_t)h->Gp * h->K, h->Gp * h->K));
+                                                h->YTpart, h->red + h->off_y, h->nrb, (int64_t)h->Gp * h->K, h->Gp * h->K));
   h->ycache_valid = true;
   return CA_OK;
 }
@@ -380,7 +382,7 @@ int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_d
       // Zpart [S][gsplit][nchunk][N][8]: the kernel strides its split index by N*8, so pass per-(s,ch) bases
       // laid out as [s][ch][split][N][8]
       float* Zp = h->Zpart + (((int64_t)s * h->nchunk + ch) * h->gsplit) * h->N * CA_CW;
-      LAUNCH(h, CA_KERNEL_FWD, launch_fwd(nc, h->D, dim3(N256, h->gsplit), h->stream, h->F, h->etamax2, h->Vs, M, Zp, h->N, h->G, h->gchunk));
+      LAUNCH(h, CA_KERNEL_FWD, launch_fwd(nc, h->D, dim3(cdiv(h->N, CA_TB * kFwdR), h->gsplit), h->stream, h->F, h->etamax2, h->Vs, M, Zp, h->N, h->G, h->gchunk));
     }
   if (h->C <= 64) {
     int CP = 1;
@@ -408,7 +410,7 @@ int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_d
                               h->K, h->gsplit, h->nchunk, h->nseg, mode));
   }
   if (mode == CA_MODE_GINIT) return CA_OK;
-  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_reduce_part, dim3(1), dim3(CA_TB), 0, h->stream, h->cell_part, h->red, h->ncblk, 3 + h->C));
+  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_reduce_part, dim3(3 + h->C), dim3(CA_TB), 0, h->stream, h->cell_part, h->red, h->ncblk, 3 + h->C));
   float lr_t = 0.f;
   if (mode == CA_MODE_TRAIN) {
     for (int s = 0; s < h->S; ++s)
@@ -428,9 +430,8 @@ int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_d
     LAUNCH(h, CA_KERNEL_OTHER,
            hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->G * W_, 64)), dim3(CA_TB), 0, h->stream, h->gpart,
                               h->red + h->off_g, h->csplit, (int64_t)h->G * W_, h->G * W_));
-    if (h->K > 0)
-      HIPCK(h, hipMemcpyAsync(h->red + h->off_y, h->ytpsi, (size_t)h->G * h->K * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     CACK(allreduce(h, h->red, h->red_n));
+    if (h->opt.world > 1 || h->comm || h->host_ar) h->ycache_valid = false;   // red_y now holds the GLOBAL sum
     if (apply) {
       // lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t), float32 like TF's _prepare()/_apply_dense
       lr_t = (float)h->opt.learning_rate * sqrtf(1.f - h->b2p) / (1.f - h->b1p);
@@ -618,24 +619,29 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   {
     int CP = 1;
     while (CP < C) CP <<= 1;
-    h->ncblk = (C <= 64) ? cdiv(Nn, CA_TB / CP) : cdiv(Nn, CA_TB);   // k_cell_par: CA_TB / CP cells per block
+    h->ncblk = (C <= 64) ? std::min(cdiv(Nn, CA_TB / CP), 16 * 256) : cdiv(Nn, CA_TB);   // k_cell_par: grid-stride over groups of CA_TB / CP cells
   }
   const int n256 = cdiv(Nn, CA_TB);
   // ---- sweep decomposition
   const int target_blocks = 8 * h->n_cu;
   // one full round of resident blocks (8 x 256 threads per CU) when the cell blocks alone do not fill the chip
-  h->gsplit = std::max(1, std::min(target_blocks / std::max(n256, 1), std::max(1, G / 64)));
+  const int nfb = cdiv(Nn, CA_TB * kFwdR);
+  h->gsplit = std::max(1, std::min(target_blocks / std::max(nfb, 1), std::max(1, G / 64)));
+  h->gsplit = std::max(h->gsplit, cdiv(G, 1024));      // LDS slice: at most 1024 genes x (8 + D) floats = 64 KB
+  if (const char* e = getenv("CA_GSPLIT")) h->gsplit = std::max(std::max(1, atoi(e)), cdiv(G, 1024));   // tuning override
   h->gchunk = cdiv(G, h->gsplit);
   h->gsplit = cdiv(G, h->gchunk);
   h->RG = G >= 1024 ? 4 : 1;
   h->ntile = cdiv(G, 64 * h->RG);
   const int gblocks = cdiv(h->ntile, CA_TB / 64);
   h->csplit = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(target_blocks, gblocks), std::max<int64_t>(1, Nn / 64)));
+  if (const char* e = getenv("CA_CSPLIT")) h->csplit = std::max(1, atoi(e));   // tuning override
   h->cchunk = (Nn + h->csplit - 1) / h->csplit;
   h->csplit = cdiv(Nn, h->cchunk);
   h->TR = 128;
+  if (const char* e = getenv("CA_TR")) h->TR = std::max(1, atoi(e));   // tuning override
   h->nrb = cdiv(Nn, h->TR);
-  while ((int64_t)h->nrb * h->nseg < 8 * h->n_cu && h->TR > 16) { h->TR /= 2; h->nrb = cdiv(Nn, h->TR); }
+  while (!getenv("CA_TR") && (int64_t)h->nrb * h->nseg < 8 * h->n_cu && h->TR > 16) { h->TR /= 2; h->nrb = cdiv(Nn, h->TR); }
   // ---- constants
   std::vector<double> Lrm((size_t)G * C), logL((size_t)G * C);
   std::vector<float> Lb((size_t)h->nchunk * G * CA_CW, 0.f);
@@ -724,7 +730,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   h->off_g = 3 + C;
   h->off_y = h->off_g + (int64_t)G * (S + D);
   h->red_n = h->off_y + (int64_t)G * K;
-  CACK(dalloc(h, &h->red, h->red_n));
+  CACK(dalloc(h, &h->red, h->off_y + (int64_t)h->Gp * std::max(K, 1)));   // Y^T psi lands here directly ([Gp][K] rows, first G reduced)
   CACK(dalloc(h, &h->terms_dev, 4));
   CACK(ensure_elbo_cap(h, 64));
   CACK(ensure_eps_cap(h, 1));
