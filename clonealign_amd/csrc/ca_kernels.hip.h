@@ -57,15 +57,13 @@ __device__ __forceinline__ double ca_sigmoid_d(double x) { return 1.0 / (1.0 + e
 template <typename YT> struct YVec;
 template <> struct YVec<float> {
   static constexpr int VEC = 4;
-  __device__ static void load(const float* p, float (&y)[4]) {
-    const float4 v = *reinterpret_cast<const float4*>(p);
-    y[0] = v.x; y[1] = v.y; y[2] = v.z; y[3] = v.w;
+  __device__ static void decode(const uint4 v, float (&y)[4]) {
+    y[0] = __uint_as_float(v.x); y[1] = __uint_as_float(v.y); y[2] = __uint_as_float(v.z); y[3] = __uint_as_float(v.w);
   }
 };
 template <> struct YVec<uint16_t> {
   static constexpr int VEC = 8;
-  __device__ static void load(const uint16_t* p, float (&y)[8]) {
-    const uint4 v = *reinterpret_cast<const uint4*>(p);
+  __device__ static void decode(const uint4 v, float (&y)[8]) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -76,8 +74,7 @@ template <> struct YVec<uint16_t> {
 };
 template <> struct YVec<uint8_t> {
   static constexpr int VEC = 16;
-  __device__ static void load(const uint8_t* p, float (&y)[16]) {
-    const uint4 v = *reinterpret_cast<const uint4*>(p);
+  __device__ static void decode(const uint4 v, float (&y)[16]) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -108,19 +105,88 @@ __global__ void k_convert_y(const ST* __restrict__ src, YT* __restrict__ dst, in
   dst[i] = out;
 }
 
+// u8 storage with an overflow list: the dense byte holds min(y, 255); the (rare) excess y - 255 goes to a
+// COO list (appended in arbitrary order here, sorted on the host afterwards so that every later sum over it
+// has a fixed order).
+template <typename ST>
+__global__ void k_convert_y_u8ovf(const ST* __restrict__ src, uint8_t* __restrict__ dst, int64_t N, int G, int Gp, int64_t sn,
+                                  int64_t sg, unsigned long long* __restrict__ counter, int* __restrict__ orow,
+                                  int* __restrict__ ocol, float* __restrict__ oval) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * (int64_t)Gp) return;
+  const int64_t n = i / Gp;
+  const int g = (int)(i - n * Gp);
+  uint8_t out = 0;
+  if (g < G) {
+    const double v = (double)src[n * sn + (int64_t)g * sg];
+    if (v > 255.0) {
+      out = 255;
+      const unsigned long long k = atomicAdd(counter, 1ull);
+      orow[k] = (int)n; ocol[k] = g; oval[k] = (float)(v - 255.0);
+    } else {
+      out = (uint8_t)v;
+    }
+  }
+  dst[i] = out;
+}
+
+// overflow-list contributions to the Y stream products, one thread per cell (CSR order) / per gene (CSC order)
+__global__ void k_ovf_rows(const int64_t* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
+                           const float* __restrict__ V, int Dstride, float* __restrict__ YWextra /*[N][K]*/, int64_t N, int K) {
+  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  for (int k = 0; k < K; ++k) {
+    float a = 0.f;
+    for (int64_t e = rowptr[n]; e < rowptr[n + 1]; ++e) a = fmaf(val[e], V[(int64_t)col[e] * Dstride + k], a);
+    YWextra[n * K + k] = a;
+  }
+}
+// Gene side of the overflow list.  The excess entries concentrate in a few highly expressed genes (one entry
+// per cell there), so each gene's CSC range is cut into chunks of <= 256 entries: one wave per chunk
+// (k_ovf_chunks), then one thread per gene adds its chunk sums in order (k_ovf_cols).
+__global__ void __launch_bounds__(CA_TB) k_ovf_chunks(const int64_t* __restrict__ chunk_start, const int* __restrict__ row,
+                                                      const float* __restrict__ val, const float* __restrict__ F, int Dstride,
+                                                      float* __restrict__ csum /*[nchunk][K]*/, int nchunk, int K) {
+  const int lane = threadIdx.x & 63;
+  const int ch = blockIdx.x * (CA_TB / 64) + (threadIdx.x >> 6);
+  if (ch >= nchunk) return;
+  const int64_t e0 = chunk_start[ch], e1 = chunk_start[ch + 1];
+  for (int k = 0; k < K; ++k) {
+    float a = 0.f;
+    for (int64_t e = e0 + lane; e < e1; e += 64) a = fmaf(val[e], F[(int64_t)row[e] * Dstride + k], a);
+    const float tot = ca_wave_sum_lane63(a);
+    if (lane == 63) csum[(int64_t)ch * K + k] = tot;
+  }
+}
+__global__ void k_ovf_cols(const int* __restrict__ col_chunk_ptr, const float* __restrict__ csum,
+                           float* __restrict__ YTextra /*[Gp][K]*/, int Gp, int G, int K) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= Gp) return;
+  for (int k = 0; k < K; ++k) {
+    float a = 0.f;
+    if (g < G)
+      for (int c = col_chunk_ptr[g]; c < col_chunk_ptr[g + 1]; ++c) a += csum[(int64_t)c * K + k];
+    YTextra[(int64_t)g * K + k] = a;
+  }
+}
+
 // max / integrality scan used to choose the storage width (flags bit0: non-integer, bit1: negative/NaN)
 template <typename ST>
-__global__ void k_scan_y(const ST* __restrict__ src, int64_t total, double* __restrict__ maxv, int* __restrict__ flags) {
+__global__ void k_scan_y(const ST* __restrict__ src, int64_t total, double* __restrict__ maxv, int* __restrict__ flags,
+                         unsigned long long* __restrict__ n_over255) {
   __shared__ double sm[CA_TB];
   double m = 0.0;
   int f = 0;
+  unsigned long long over = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const double v = (double)src[i];
     if (!(v >= 0.0)) f |= 2;
     if (v != floor(v)) f |= 1;
+    if (v > 255.0) ++over;
     m = v > m ? v : m;
   }
   if (f) atomicOr(flags, f);
+  if (over) atomicAdd(n_over255, over);
   sm[threadIdx.x] = m;
   __syncthreads();
   for (int s = CA_TB / 2; s > 0; s >>= 1) {
@@ -141,7 +207,8 @@ __global__ void __launch_bounds__(CA_TB) k_prep_cells(const YT* __restrict__ Y, 
                                                       const double* __restrict__ extra /*[N][C] or null*/,
                                                       double* __restrict__ A, double* __restrict__ cn,
                                                       double* __restrict__ s64, float* __restrict__ s32, int64_t N, int G,
-                                                      int Gp, int C) {
+                                                      int Gp, int C, const int64_t* __restrict__ orowptr,
+                                                      const int* __restrict__ ocol, const float* __restrict__ oval) {
   __shared__ double sm[CA_TB];
   const int64_t n = blockIdx.x;
   const YT* row = Y + n * (int64_t)Gp;
@@ -151,6 +218,13 @@ __global__ void __launch_bounds__(CA_TB) k_prep_cells(const YT* __restrict__ Y, 
     ssum += y;
     if (y > 1.0) lg += lgamma(y + 1.0);
     else if (y > 0.0 && y < 1.0) lg += lgamma(y + 1.0);
+  }
+  // entries stored as 255 + overflow: add the excess and swap lgamma(256) for lgamma(256 + excess)
+  const int64_t oe0 = orowptr ? orowptr[n] : 0, oe1 = orowptr ? orowptr[n + 1] : 0;
+  for (int64_t e = oe0 + threadIdx.x; e < oe1; e += CA_TB) {
+    const double x = (double)oval[e];
+    ssum += x;
+    lg += lgamma(256.0 + x) - lgamma(256.0);
   }
   const double st = ca_block_sum(ssum, sm);
   const double lt = ca_block_sum(lg, sm);
@@ -165,6 +239,7 @@ __global__ void __launch_bounds__(CA_TB) k_prep_cells(const YT* __restrict__ Y, 
       const double y = (double)row[g];
       if (y != 0.0) a += y * logL[(int64_t)g * C + c];  // xlogy: 0*log(0) := 0, y>0 & L=0 -> -inf
     }
+    for (int64_t e = oe0 + threadIdx.x; e < oe1; e += CA_TB) a += (double)oval[e] * logL[(int64_t)ocol[e] * C + c];
     const double at = ca_block_sum(a, sm);
     if (threadIdx.x == 0) A[n * C + c] = at + (extra ? extra[n * C + c] : 0.0);
   }
@@ -199,27 +274,53 @@ __global__ void __launch_bounds__(CA_TB) k_ypass(const YT* __restrict__ Y, const
   const int64_t r0 = rb * TR;
   const int64_t r1 = (r0 + TR < N) ? r0 + TR : N;
   const YT* base = Y + col0;
-#pragma unroll 4
-  for (int64_t r = r0; r < r1; ++r) {
-    float y[VEC];
-    YVec<YT>::load(base + r * Gp, y);
-    float p[KK], ps[KK];
+  constexpr int U = 4;  // rows in flight per wave: U independent 16-byte loads issued before any is consumed
+  // Row totals are parked one per lane (row r -> lane (r - r0) & 63) and written 64 at a time: a per-row
+  // store from lane 63 would sit in the same in-order vmcnt queue as the loads and serialise the stream.
+  float keep[KK];
 #pragma unroll
-    for (int k = 0; k < KK; ++k) {
-      p[k] = 0.f;
-      ps[k] = F[r * Dstride + koff + k];  // wave-uniform -> scalar load
+  for (int k = 0; k < KK; ++k) keep[k] = 0.f;
+  for (int64_t rr = r0; rr < r1; rr += U) {
+    uint4 raw[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = (rr + u < r1) ? rr + u : r1 - 1;   // tail rows re-read the last row (contribution masked below)
+      raw[u] = *reinterpret_cast<const uint4*>(base + r * Gp);
     }
 #pragma unroll
-    for (int j = 0; j < VEC; ++j)
+    for (int u = 0; u < U; ++u) {
+      const int64_t r = rr + u;
+      if (r < r1) {   // wave-uniform
+        float y[VEC];
+        YVec<YT>::decode(raw[u], y);
+        float p[KK], ps[KK];
 #pragma unroll
-      for (int k = 0; k < KK; ++k) {
-        p[k] = fmaf(y[j], w[j][k], p[k]);
-        acc[j][k] = fmaf(y[j], ps[k], acc[j][k]);
+        for (int k = 0; k < KK; ++k) {
+          p[k] = 0.f;
+          ps[k] = F[r * Dstride + koff + k];  // wave-uniform -> scalar load
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j)
+#pragma unroll
+          for (int k = 0; k < KK; ++k) {
+            p[k] = fmaf(y[j], w[j][k], p[k]);
+            acc[j][k] = fmaf(y[j], ps[k], acc[j][k]);
+          }
+        const int slot = (int)(r - r0) & 63;
+#pragma unroll
+        for (int k = 0; k < KK; ++k) {
+          const float tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ca_wave_sum_lane63(p[k])), 63));
+          keep[k] = (lane == slot) ? tot : keep[k];
+        }
       }
+    }
+    const int64_t done = ((rr + U < r1) ? rr + U : r1) - r0;   // rows finished so far in this strip
+    if ((done & 63) == 0 || rr + U >= r1) {                   // wave-uniform flush of the last (up to 64) rows
+      const int64_t fb = r0 + ((done - 1) & ~(int64_t)63);
+      if (fb + lane < r0 + done) {
 #pragma unroll
-    for (int k = 0; k < KK; ++k) {
-      const float tot = ca_wave_sum_lane63(p[k]);
-      if (lane == 63) YWpart[((int64_t)sg * N + r) * K + koff + k] = tot;
+        for (int k = 0; k < KK; ++k) YWpart[((int64_t)sg * N + fb + lane) * K + koff + k] = keep[k];
+      }
     }
   }
 #pragma unroll
@@ -230,24 +331,30 @@ __global__ void __launch_bounds__(CA_TB) k_ypass(const YT* __restrict__ Y, const
 
 // Column sums of a [rows][ld] float slab in fp64 and in a fixed order: out[c] = sum_r part[r*ld + c].
 // Used for every cross-block reduction of per-gene partials (Y^T.psi strips, backward-sweep cell
-// splits).  Block = 64 columns x 4 row lanes (256-byte coalesced row reads), LDS combine.
-__global__ void __launch_bounds__(CA_TB) k_colsum(const float* __restrict__ part, double* __restrict__ out, int rows,
-                                                  int64_t ld, int cols) {
-  __shared__ double sm[4][64];
+// splits).  Block = 64 columns x 16 row lanes (256-byte coalesced row reads), LDS tree combine.
+__global__ void __launch_bounds__(1024) k_colsum(const float* __restrict__ part, double* __restrict__ out, int rows,
+                                                 int64_t ld, int cols) {
+  constexpr int RL = 16;   // row lanes per column: block = 64 columns x 16 row lanes
+  __shared__ double sm[RL][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
   double a0 = 0.0, a1 = 0.0;
   if (c < cols) {
     int r = ty;
-    for (; r + 4 < rows; r += 8) {
+    for (; r + RL < rows; r += 2 * RL) {
       a0 += (double)part[(int64_t)r * ld + c];
-      a1 += (double)part[(int64_t)(r + 4) * ld + c];
+      a1 += (double)part[(int64_t)(r + RL) * ld + c];
     }
     if (r < rows) a0 += (double)part[(int64_t)r * ld + c];
   }
   sm[ty][tx] = a0 + a1;
   __syncthreads();
-  if (ty == 0 && c < cols) out[c] = ((sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]));
+#pragma unroll
+  for (int s = RL / 2; s > 0; s >>= 1) {
+    if (ty < s) sm[ty][tx] += sm[ty + s][tx];
+    __syncthreads();
+  }
+  if (ty == 0 && c < cols) out[c] = sm[0][tx];
 }
 
 // ------------------------------------------------------------------ per-gene preparation of one pass
@@ -508,6 +615,9 @@ __global__ void __launch_bounds__(CA_TB) k_bwd(const float* __restrict__ coef /*
   }
   const int64_t n0 = (int64_t)blockIdx.y * cchunk;
   const int64_t n1 = (n0 + cchunk < N) ? n0 + cchunk : N;
+  float keepF[DM];
+#pragma unroll
+  for (int d = 0; d < DM; ++d) keepF[d] = 0.f;
   for (int64_t n = n0; n < n1; ++n) {
     float cf[NC], f[DM];
 #pragma unroll
@@ -539,14 +649,23 @@ __global__ void __launch_bounds__(CA_TB) k_bwd(const float* __restrict__ coef /*
         dsum[d] = fmaf(deta, v[r][d], dsum[d]);
       }
     }
+    const int slot = (int)(n - n0) & 63;
 #pragma unroll
     for (int d = 0; d < DM; ++d) {
       if (d < Dn) {
-        const float tot = ca_wave_sum_lane63(dsum[d]);
-        if (lane == 63) {
-          float* p = dFpart + ((int64_t)tile * N + n) * Dn + d;
-          *p = first ? tot : (*p + tot);
-        }
+        const float tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ca_wave_sum_lane63(dsum[d])), 63));
+        keepF[d] = (lane == slot) ? tot : keepF[d];
+      }
+    }
+    if (slot == 63 || n + 1 == n1) {   // wave-uniform: write the last (up to 64) cells' totals, one cell per lane
+      const int64_t fb = n - slot;
+      if (fb + lane <= n) {
+#pragma unroll
+        for (int d = 0; d < DM; ++d)
+          if (d < Dn) {
+            float* p = dFpart + ((int64_t)tile * N + fb + lane) * Dn + d;
+            *p = first ? keepF[d] : (*p + keepF[d]);
+          }
       }
     }
   }
@@ -726,9 +845,11 @@ __global__ void __launch_bounds__(CA_TB) k_cell_par(const float* __restrict__ Zp
     const int cc_ = c < C ? c : C - 1;
     const double gl = ok ? (double)glogit[nn * C + cc_] : -INFINITY;
     const double mx = gmax(gl);
-    const double lse = mx + log(gsum(ok ? exp(gl - mx) : 0.0));
+    const double ex = ok ? exp(gl - mx) : 0.0;
+    const double se = gsum(ex);
+    const double lse = mx + log(se);
     const double lg = gl - lse;
-    const double gam = ok ? exp(lg) : 0.0;
+    const double gam = ok ? ex / se : 0.0;
     const double sn = s64[nn];
     const double em = (D > 0) ? (double)etamax2[nn] * CA_LN2 : 0.0;
     const int ch = cc_ / CA_CW, cc = cc_ % CA_CW;
@@ -813,9 +934,12 @@ __global__ void __launch_bounds__(CA_TB) k_final_gene(const double* __restrict__
                                                       float* __restrict__ m_loc, float* __restrict__ v_loc, float* __restrict__ m_ls,
                                                       float* __restrict__ v_ls, float* __restrict__ m_V, float* __restrict__ v_V,
                                                       float* __restrict__ g_loc, float* __restrict__ g_ls, float* __restrict__ g_V,
+                                                      float* __restrict__ Vs, float* __restrict__ vmm_part,
                                                       int G, int S, int D, int K, int apply, float lr_t, float b1, float b2, float aeps) {
+  __shared__ float smin[CA_TB], smax[CA_TB];
   const int g = blockIdx.x * CA_TB + threadIdx.x;
-  if (g >= G) return;
+  const bool ok = g < G;
+  if (ok) {
   const double l = (double)loc[g], lsd = (double)ls[g], sd = exp(lsd), cs = colsum[g];
   const int W_ = S + D;
   double gl = 0.0, gs = 0.0;
@@ -850,6 +974,31 @@ __global__ void __launch_bounds__(CA_TB) k_final_gene(const double* __restrict__
       V[(int64_t)g * D + d] = th; m_V[(int64_t)g * D + d] = m; v_V[(int64_t)g * D + d] = v;
     }
   }
+  }
+  if (!apply) return;
+  // the updated loadings in log2 units and their per-block range (k_vprep fused in; same arithmetic)
+  for (int d = 0; d < D; ++d) {
+    float v = 0.f;
+    if (ok) {
+      v = V[(int64_t)g * D + d] * CA_LOG2E_F;
+      Vs[(int64_t)g * D + d] = v;
+    }
+    __syncthreads();
+    smin[threadIdx.x] = ok ? v : INFINITY;
+    smax[threadIdx.x] = ok ? v : -INFINITY;
+    __syncthreads();
+    for (int s = CA_TB / 2; s > 0; s >>= 1) {
+      if (threadIdx.x < s) {
+        smin[threadIdx.x] = fminf(smin[threadIdx.x], smin[threadIdx.x + s]);
+        smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + s]);
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      vmm_part[((int64_t)blockIdx.x * 2 + 0) * D + d] = smin[0];
+      vmm_part[((int64_t)blockIdx.x * 2 + 1) * D + d] = smax[0];
+    }
+  }
 }
 
 // ------------------------------------------------------------------ ELBO assembly + the O(K + C) variables
@@ -860,7 +1009,10 @@ __global__ void __launch_bounds__(CA_TB) k_final_small(const double* __restrict_
                                                        float* __restrict__ m_v, float* __restrict__ v_v, float* __restrict__ m_a,
                                                        float* __restrict__ v_a, float* __restrict__ g_v, float* __restrict__ g_a,
                                                        double* __restrict__ elbo_out, double* __restrict__ terms_out, int G, int C, int K,
-                                                       int apply, float lr_t, float b1, float b2, float aeps) {
+                                                       int apply, float lr_t, float b1, float b2, float aeps,
+                                                       const double* __restrict__ cell_part, int ncblk, double* __restrict__ red_w,
+                                                       const float* __restrict__ vmm_part, float* __restrict__ vmm, int D,
+                                                       double dir_const) {
   __shared__ double sm[CA_TB];
   __shared__ double gs[3 + 16];
   const int W_ = 3 + K;
@@ -870,49 +1022,103 @@ __global__ void __launch_bounds__(CA_TB) k_final_small(const double* __restrict_
     const double r = ca_block_sum(a, sm);
     if (threadIdx.x == 0) gs[j] = r;
   }
+  // range of the updated V' over the gene blocks (k_vmm_final folded in)
+  if (apply && vmm_part && (int)threadIdx.x < D) {
+    const int d = threadIdx.x;
+    float mn = INFINITY, mx2 = -INFINITY;
+    for (int b = 0; b < ngblk; ++b) {
+      mn = fminf(mn, vmm_part[((int64_t)b * 2 + 0) * D + d]);
+      mx2 = fmaxf(mx2, vmm_part[((int64_t)b * 2 + 1) * D + d]);
+    }
+    vmm[d] = mn;
+    vmm[D + d] = mx2;
+  }
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  // log alpha and the Dirichlet(1/C) log-pdf evaluated at alpha + 1e-3 (:324, argument not renormalised)
-  double mx = -INFINITY;
-  for (int c = 0; c < C; ++c) mx = fmax(mx, (double)alpha_u[c]);
-  double se = 0.0;
-  for (int c = 0; c < C; ++c) se += exp((double)alpha_u[c] - mx);
-  const double lse = mx + log(se);
+  if (threadIdx.x >= 64) return;
+  // One lane per clone (and per latent dimension): the fp64 exp/log chains of this kernel are long, so they
+  // run side by side in wave 0 and meet through xor-shuffles.  (C <= 64 here; larger C takes the loop form.)
+  const int c = threadIdx.x;
   const double conc = 1.0 / (double)C;
-  double dir = -((double)C * lgamma(conc) - lgamma(1.0));
-  double dla_sum = 0.0;
-  for (int c = 0; c < C; ++c) {
-    const double al = exp((double)alpha_u[c] - lse);
-    dir += (conc - 1.0) * log(al + 1e-3);
-    dla_sum += red[3 + c] + (conc - 1.0) * al / (al + 1e-3);
+  auto wsum = [](double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+  auto wmax = [](double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+  };
+  double dir_sum, dla_c = 0.0, al_c = 0.0, dla_sum;
+  if (C <= 64) {
+    const double au = c < C ? (double)alpha_u[c] : -INFINITY;
+    const double mx = wmax(au);
+    const double se = wsum(c < C ? exp(au - mx) : 0.0);
+    const double lse = mx + log(se);
+    al_c = c < C ? exp(au - lse) : 0.0;
+    dla_c = c < C ? red[3 + c] + (conc - 1.0) * al_c / (al_c + 1e-3) : 0.0;
+    dir_sum = wsum(c < C ? (conc - 1.0) * log(al_c + 1e-3) : 0.0);   // Dirichlet(1/C) log-pdf at alpha + 1e-3 (:324)
+    dla_sum = wsum(dla_c);
+  } else {
+    double mx = -INFINITY, se = 0.0;
+    for (int j = 0; j < C; ++j) mx = fmax(mx, (double)alpha_u[j]);
+    for (int j = 0; j < C; ++j) se += exp((double)alpha_u[j] - mx);
+    const double lse = mx + log(se);
+    dir_sum = 0.0; dla_sum = 0.0;
+    for (int j = 0; j < C; ++j) {
+      const double al = exp((double)alpha_u[j] - lse);
+      dir_sum += (conc - 1.0) * log(al + 1e-3);
+      dla_sum += red[3 + j] + (conc - 1.0) * al / (al + 1e-3);
+    }
   }
-  double EE = red[0] + gs[0];
-  double Ep = red[1] + gs[1] + dir;
-  double Eq = red[2] + gs[2];
-  for (int k = 0; k < K; ++k) {
-    const double v = (double)vchi[k], chi = exp(v);
-    Ep += -0.5 * chi * gs[3 + k] + (double)G * (0.5 * v - 0.5 * CA_LOG2PI) + (v - chi);
-    const double gv = -0.5 * chi * gs[3 + k] + 0.5 * (double)G + 1.0 - chi;
-    g_v[k] = (float)gv;
+  // chi terms: lane k < K
+  double ep_k = 0.0;
+  if (c < K) {
+    const double v = (double)vchi[c], chi = exp(v);
+    ep_k = -0.5 * chi * gs[3 + c] + (double)G * (0.5 * v - 0.5 * CA_LOG2PI) + (v - chi);
+    const double gv = -0.5 * chi * gs[3 + c] + 0.5 * (double)G + 1.0 - chi;
+    g_v[c] = (float)gv;
     if (apply) {
-      float th = vchi[k], m = m_v[k], vv = v_v[k];
+      float th = vchi[c], m = m_v[c], vv = v_v[c];
       ca_adam(th, m, vv, -(float)gv, lr_t, b1, b2, aeps);
-      vchi[k] = th; m_v[k] = m; v_v[k] = vv;
+      vchi[c] = th; m_v[c] = m; v_v[c] = vv;
     }
   }
-  if (elbo_out) *elbo_out = EE + Ep - Eq;
-  if (terms_out) { terms_out[0] = EE; terms_out[1] = Ep; terms_out[2] = Eq; }
-  for (int c = 0; c < C; ++c) {
-    const double al = exp((double)alpha_u[c] - lse);
-    const double dla = red[3 + c] + (conc - 1.0) * al / (al + 1e-3);
-    g_a[c] = (float)(dla - al * dla_sum);
+  const double ep_chi = wsum(ep_k);
+  if (c == 0) {
+    const double EE = red[0] + gs[0];
+    const double Ep = red[1] + gs[1] + dir_const + dir_sum + ep_chi;
+    const double Eq = red[2] + gs[2];
+    if (elbo_out) *elbo_out = EE + Ep - Eq;
+    if (terms_out) { terms_out[0] = EE; terms_out[1] = Ep; terms_out[2] = Eq; }
   }
-  if (apply)
-    for (int c = 0; c < C; ++c) {
-      float th = alpha_u[c], m = m_a[c], vv = v_a[c];
-      ca_adam(th, m, vv, -g_a[c], lr_t, b1, b2, aeps);
-      alpha_u[c] = th; m_a[c] = m; v_a[c] = vv;
+  if (C <= 64) {
+    if (c < C) {
+      const float ga = (float)(dla_c - al_c * dla_sum);
+      g_a[c] = ga;
+      if (apply) {
+        float th = alpha_u[c], m = m_a[c], vv = v_a[c];
+        ca_adam(th, m, vv, -ga, lr_t, b1, b2, aeps);
+        alpha_u[c] = th; m_a[c] = m; v_a[c] = vv;
+      }
     }
+  } else if (c == 0) {
+    double mx = -INFINITY, se = 0.0;
+    for (int j = 0; j < C; ++j) mx = fmax(mx, (double)alpha_u[j]);
+    for (int j = 0; j < C; ++j) se += exp((double)alpha_u[j] - mx);
+    const double lse = mx + log(se);
+    for (int j = 0; j < C; ++j) {
+      const double al = exp((double)alpha_u[j] - lse);
+      const double dla = red[3 + j] + (conc - 1.0) * al / (al + 1e-3);
+      g_a[j] = (float)(dla - al * dla_sum);
+    }
+    if (apply)
+      for (int j = 0; j < C; ++j) {
+        float th = alpha_u[j], m = m_a[j], vv = v_a[j];
+        ca_adam(th, m, vv, -g_a[j], lr_t, b1, b2, aeps);
+        alpha_u[j] = th; m_a[j] = m; v_a[j] = vv;
+      }
+  }
 }
 
 // ------------------------------------------------------------------ per-cell variables: psi and the q(z) logits
@@ -920,7 +1126,8 @@ __global__ void __launch_bounds__(CA_TB) k_adam_cell(float* __restrict__ F, cons
                                                      float* __restrict__ glogit, const float* __restrict__ dgl,
                                                      float* __restrict__ m_psi, float* __restrict__ v_psi, float* __restrict__ m_gl,
                                                      float* __restrict__ v_gl, float* __restrict__ g_psi, int64_t N, int C, int D, int K,
-                                                     int ntile, int apply, float lr_t, float b1, float b2, float aeps) {
+                                                     int ntile, int apply, float lr_t, float b1, float b2, float aeps,
+                                                     const float* __restrict__ vmm, float* __restrict__ etamax2) {
   const int64_t n = (int64_t)blockIdx.x * CA_TB + threadIdx.x;
   if (n >= N) return;
   for (int k = 0; k < K; ++k) {
@@ -940,4 +1147,12 @@ __global__ void __launch_bounds__(CA_TB) k_adam_cell(float* __restrict__ F, cons
       ca_adam(th, m, v, -dgl[n * C + c], lr_t, b1, b2, aeps);
       glogit[n * C + c] = th; m_gl[n * C + c] = m; v_gl[n * C + c] = v;
     }
+  if (apply && D > 0) {   // exponent bound for the updated psi and V' (k_etamax folded in)
+    float e = 0.f;
+    for (int d = 0; d < D; ++d) {
+      const float f = F[n * D + d];
+      e += fmaxf(f * vmm[d], f * vmm[D + d]);
+    }
+    etamax2[n] = e;
+  }
 }

@@ -77,6 +77,12 @@ struct ca_engine {
   int ystore = 0, ybytes = 0, VEC = 0, Gp = 0, nseg = 0, TR = 0, nrb = 0;
   void* Y = nullptr;
   int64_t y_dev_bytes = 0;
+  // overflow list of the u8 storage (entries > 255), CSR (by cell) and CSC (by gene) orders, host copy kept for setup
+  int64_t n_ovf = 0;
+  int64_t *ovf_rowptr = nullptr, *ovf_chunk_start = nullptr; int* ovf_col_chunk_ptr = nullptr; float* ovf_csum = nullptr; int n_ovf_chunk = 0;
+  int *ovf_col = nullptr, *ovf_row2 = nullptr;
+  float *ovf_val = nullptr, *ovf_val2 = nullptr;
+  std::vector<int> h_orow, h_ocol; std::vector<float> h_oval;
   // ---- constants
   float* Lb = nullptr;       // [nchunk][G][8]
   double *A = nullptr, *cn = nullptr, *s64 = nullptr, *colsum = nullptr, *YtX = nullptr;
@@ -88,6 +94,7 @@ struct ca_engine {
   float *loc = nullptr, *ls = nullptr, *m_loc = nullptr, *v_loc = nullptr, *m_ls = nullptr, *v_ls = nullptr;
   float *vchi = nullptr, *m_v = nullptr, *v_v = nullptr;            // [K]
   float *alpha_u = nullptr, *m_a = nullptr, *v_a = nullptr;         // [C]
+  double dir_const = 0.0;
   float b1p = 0.f, b2p = 0.f;  // running beta powers, float32 like TF's beta*_power variables
   // ---- gradients (d ELBO / d var)
   float *g_loc = nullptr, *g_ls = nullptr, *g_V = nullptr, *g_v = nullptr, *g_a = nullptr, *g_psi = nullptr, *dgl = nullptr;
@@ -324,9 +331,17 @@ int ensure_ycache(ca_engine* h) {
     HIPCK(h, hipGetLastError());
     CACK(prof_end(h));
   }
-  // YTpart is [nrb][Gp*K]: column sums over the row blocks; ytpsi is laid out [Gp][K] (first G rows used)
-  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->Gp * h->K, 64)), dim3(CA_TB), 0, h->stream,
-                                                h->YTpart, h->red + h->off_y, h->nrb, (int64_t)h->Gp * h->K, h->Gp * h->K));
+  if (h->n_ovf > 0) {   // entries above 255: one extra "segment" of YW and one extra "row block" of Y^T psi
+    LAUNCH(h, CA_KERNEL_YPASS, hipLaunchKernelGGL(k_ovf_rows, dim3(cdiv(h->N, CA_TB)), dim3(CA_TB), 0, h->stream, h->ovf_rowptr, h->ovf_col,
+                                                  h->ovf_val, h->V, h->D, h->YWpart + (int64_t)h->nseg * h->N * h->K, h->N, h->K));
+    LAUNCH(h, CA_KERNEL_YPASS, hipLaunchKernelGGL(k_ovf_chunks, dim3(cdiv(h->n_ovf_chunk, CA_TB / 64)), dim3(CA_TB), 0, h->stream,
+                                                  h->ovf_chunk_start, h->ovf_row2, h->ovf_val2, h->F, h->D, h->ovf_csum, h->n_ovf_chunk, h->K));
+    LAUNCH(h, CA_KERNEL_YPASS, hipLaunchKernelGGL(k_ovf_cols, dim3(cdiv(h->Gp, CA_TB)), dim3(CA_TB), 0, h->stream, h->ovf_col_chunk_ptr,
+                                                  h->ovf_csum, h->YTpart + (int64_t)h->nrb * h->Gp * h->K, h->Gp, h->G, h->K));
+  }
+  // YTpart is [nrb (+1)][Gp*K]: column sums over the row blocks; ytpsi is laid out [Gp][K] (first G rows used)
+  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->Gp * h->K, 64)), dim3(1024), 0, h->stream,
+                                                h->YTpart, h->red + h->off_y, h->nrb + (h->n_ovf > 0 ? 1 : 0), (int64_t)h->Gp * h->K, h->Gp * h->K));
   h->ycache_valid = true;
   return CA_OK;
 }
@@ -392,7 +407,7 @@ int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_d
   LAUNCH(h, CA_KERNEL_CELL,                                                                                                   \
          hipLaunchKernelGGL((k_cell_par<CPV>), grid, dim3(CA_TB), 0, h->stream, h->Zpart, h->A, h->cn, h->s64, h->etamax2,    \
                             h->glogit, h->alpha_u, h->F, h->YWpart, h->YW, h->coef, h->dgl, h->cell_part, h->N, h->C, h->S,  \
-                            h->D, h->K, h->gsplit, h->nchunk, h->nseg, mode))
+                            h->D, h->K, h->gsplit, h->nchunk, h->nseg + (h->n_ovf > 0 ? 1 : 0), mode))
     switch (CP) {
       case 1: CA_CELL(1); break;
       case 2: CA_CELL(2); break;
@@ -407,7 +422,7 @@ int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_d
     LAUNCH(h, CA_KERNEL_CELL,
            hipLaunchKernelGGL(k_cell, dim3(h->ncblk), dim3(CA_TB), 0, h->stream, h->Zpart, h->A, h->cn, h->s64, h->etamax2, h->glogit,
                               h->alpha_u, h->F, h->YWpart, h->YW, h->coef, h->dgl, h->scratch, h->cell_part, h->N, h->C, h->S, h->D,
-                              h->K, h->gsplit, h->nchunk, h->nseg, mode));
+                              h->K, h->gsplit, h->nchunk, h->nseg + (h->n_ovf > 0 ? 1 : 0), mode));
   }
   if (mode == CA_MODE_GINIT) return CA_OK;
   LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_reduce_part, dim3(3 + h->C), dim3(CA_TB), 0, h->stream, h->cell_part, h->red, h->ncblk, 3 + h->C));
@@ -428,7 +443,7 @@ int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_d
       }
     const int W_ = h->S + h->D;
     LAUNCH(h, CA_KERNEL_OTHER,
-           hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->G * W_, 64)), dim3(CA_TB), 0, h->stream, h->gpart,
+           hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->G * W_, 64)), dim3(1024), 0, h->stream, h->gpart,
                               h->red + h->off_g, h->csplit, (int64_t)h->G * W_, h->G * W_));
     CACK(allreduce(h, h->red, h->red_n));
     if (h->opt.world > 1 || h->comm || h->host_ar) h->ycache_valid = false;   // red_y now holds the GLOBAL sum
@@ -439,7 +454,7 @@ int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_d
     LAUNCH(h, CA_KERNEL_OTHER,
            hipLaunchKernelGGL(k_final_gene, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->red + h->off_g, h->red + h->off_y, eps,
                               h->colsum, h->YtX, h->vchi, h->loc, h->ls, h->V, h->m_loc, h->v_loc, h->m_ls, h->v_ls, h->m_V, h->v_V,
-                              h->g_loc, h->g_ls, h->g_V, h->G, h->S, h->D, h->K, apply, lr_t, (float)h->opt.beta1, (float)h->opt.beta2,
+                              h->g_loc, h->g_ls, h->g_V, h->Vs, h->vmm_part, h->G, h->S, h->D, h->K, apply, lr_t, (float)h->opt.beta1, (float)h->opt.beta2,
                               (float)h->opt.adam_eps));
   } else {
     CACK(allreduce(h, h->red, 3 + h->C));
@@ -448,16 +463,17 @@ int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_d
          hipLaunchKernelGGL(k_final_small, dim3(1), dim3(CA_TB), 0, h->stream, h->red, h->gene_part, h->ngblk, h->vchi, h->alpha_u,
                             h->m_v, h->v_v, h->m_a, h->v_a, h->g_v, h->g_a, elbo_dst, h->terms_dev, h->G, h->C, h->K,
                             (mode == CA_MODE_TRAIN && apply) ? 1 : 0, lr_t, (float)h->opt.beta1, (float)h->opt.beta2,
-                            (float)h->opt.adam_eps));
+                            (float)h->opt.adam_eps, (const double*)nullptr, h->ncblk, h->red,
+                            h->vmm_part, h->vmm, h->D, h->dir_const));
   if (mode == CA_MODE_TRAIN) {
     LAUNCH(h, CA_KERNEL_OTHER,
            hipLaunchKernelGGL(k_adam_cell, dim3(N256), dim3(CA_TB), 0, h->stream, h->F, h->YW, h->dFpart, h->glogit, h->dgl, h->m_psi,
                               h->v_psi, h->m_gl, h->v_gl, h->g_psi, h->N, h->C, h->D, h->K, h->ntile, apply, lr_t,
-                              (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps));
+                              (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, h->vmm, h->etamax2));
     if (apply) {
       h->b1p *= (float)h->opt.beta1;
       h->b2p *= (float)h->opt.beta2;
-      CACK(refresh_derived(h));
+      h->ycache_valid = false;   // V', its range and etamax2 were refreshed inside the step's own kernels
     }
   }
   return CA_OK;
@@ -522,27 +538,34 @@ template <typename ST>
 int scan_and_convert(ca_engine* h, const ST* src_dev, int64_t sn, int64_t sg) {
   double* maxv = nullptr;
   int* flags = nullptr;
-  HIPCK(h, hipMalloc((void**)&maxv, 16));
+  HIPCK(h, hipMalloc((void**)&maxv, 32));
   flags = (int*)(maxv + 1);
-  HIPCK(h, hipMemsetAsync(maxv, 0, 16, h->stream));
+  unsigned long long* cnt = (unsigned long long*)(maxv + 2);
+  HIPCK(h, hipMemsetAsync(maxv, 0, 32, h->stream));
   const int64_t total = h->N * (int64_t)h->G;
-  hipLaunchKernelGGL((k_scan_y<ST>), dim3(std::min<int64_t>(4096, cdiv(total, CA_TB))), dim3(CA_TB), 0, h->stream, src_dev, total, maxv, flags);
+  hipLaunchKernelGGL((k_scan_y<ST>), dim3(std::min<int64_t>(4096, cdiv(total, CA_TB))), dim3(CA_TB), 0, h->stream, src_dev, total, maxv, flags, cnt);
   HIPCK(h, hipGetLastError());
-  double hm[2];
-  HIPCK(h, hipMemcpyAsync(hm, maxv, 16, hipMemcpyDeviceToHost, h->stream));
+  double hm[4];
+  HIPCK(h, hipMemcpyAsync(hm, maxv, 32, hipMemcpyDeviceToHost, h->stream));
   HIPCK(h, hipStreamSynchronize(h->stream));
   const double mx = hm[0];
   int fl;
   memcpy(&fl, &hm[1], sizeof(int));
+  unsigned long long n255;
+  memcpy(&n255, &hm[2], sizeof(n255));
   if (fl & 2) { hipFree(maxv); h->err = "count matrix has negative or NaN entries"; return CA_ERR_INVALID; }
   int store = h->opt.y_storage;
+  const bool integral = !(fl & 1);
+  // u8 also serves matrices with a few entries above 255 (at most 1 in 64, each < 2^24): those keep 255 in
+  // the dense byte and their excess in a sorted overflow list
+  const bool u8_ok = integral && mx < 16777216.0 && (int64_t)n255 * 64 <= total;
   if (store == CA_YSTORE_AUTO) {
-    if (fl & 1) store = CA_YSTORE_F32;
-    else if (mx <= 255.0) store = CA_YSTORE_U8;
+    if (!integral) store = CA_YSTORE_F32;
+    else if (u8_ok) store = CA_YSTORE_U8;
     else if (mx <= 65535.0) store = CA_YSTORE_U16;
     else store = CA_YSTORE_F32;
   }
-  if ((store == CA_YSTORE_U8 && ((fl & 1) || mx > 255.0)) || (store == CA_YSTORE_U16 && ((fl & 1) || mx > 65535.0))) {
+  if ((store == CA_YSTORE_U8 && !(integral && mx < 16777216.0)) || (store == CA_YSTORE_U16 && (!integral || mx > 65535.0))) {
     hipFree(maxv);
     h->err = "requested y_storage cannot hold the counts (max " + std::to_string(mx) + ")";
     return CA_ERR_INVALID;
@@ -557,9 +580,65 @@ int scan_and_convert(ca_engine* h, const ST* src_dev, int64_t sn, int64_t sg) {
   uint8_t* yb = nullptr;
   CACK(dalloc(h, &yb, h->y_dev_bytes));
   h->Y = yb;
-  HIPCK(h, hipMemsetAsync(maxv, 0, 16, h->stream));
+  HIPCK(h, hipMemsetAsync(maxv, 0, 32, h->stream));
   const int64_t tot = h->N * (int64_t)h->Gp;
   dim3 grid(cdiv(tot, CA_TB));
+  if (store == CA_YSTORE_U8 && n255 > 0) {
+    h->n_ovf = (int64_t)n255;
+    int *orow = nullptr, *ocol = nullptr; float* oval = nullptr;
+    HIPCK(h, hipMalloc((void**)&orow, n255 * sizeof(int)));
+    HIPCK(h, hipMalloc((void**)&ocol, n255 * sizeof(int)));
+    HIPCK(h, hipMalloc((void**)&oval, n255 * sizeof(float)));
+    hipLaunchKernelGGL((k_convert_y_u8ovf<ST>), grid, dim3(CA_TB), 0, h->stream, src_dev, (uint8_t*)h->Y, h->N, h->G, h->Gp, sn, sg, cnt, orow, ocol, oval);
+    HIPCK(h, hipGetLastError());
+    h->h_orow.resize(n255); h->h_ocol.resize(n255); h->h_oval.resize(n255);
+    HIPCK(h, hipMemcpyAsync(h->h_orow.data(), orow, n255 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipMemcpyAsync(h->h_ocol.data(), ocol, n255 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipMemcpyAsync(h->h_oval.data(), oval, n255 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    hipFree(orow); hipFree(ocol); hipFree(oval); hipFree(maxv);
+    // fixed order: sort by (cell, gene) for the CSR copy and by (gene, cell) for the CSC copy
+    const int64_t nz = (int64_t)n255;
+    std::vector<int64_t> idx(nz);
+    for (int64_t i = 0; i < nz; ++i) idx[i] = i;
+    std::sort(idx.begin(), idx.end(), [&](int64_t a, int64_t b) {
+      return h->h_orow[a] != h->h_orow[b] ? h->h_orow[a] < h->h_orow[b] : h->h_ocol[a] < h->h_ocol[b]; });
+    std::vector<int> r1(nz), c1(nz); std::vector<float> v1(nz);
+    for (int64_t i = 0; i < nz; ++i) { r1[i] = h->h_orow[idx[i]]; c1[i] = h->h_ocol[idx[i]]; v1[i] = h->h_oval[idx[i]]; }
+    h->h_orow = r1; h->h_ocol = c1; h->h_oval = v1;
+    std::vector<int64_t> rowptr(h->N + 1, 0), colptr(h->G + 1, 0);
+    for (int64_t i = 0; i < nz; ++i) { rowptr[r1[i] + 1]++; colptr[c1[i] + 1]++; }
+    for (int64_t i = 0; i < h->N; ++i) rowptr[i + 1] += rowptr[i];
+    for (int g = 0; g < h->G; ++g) colptr[g + 1] += colptr[g];
+    std::vector<int> r2(nz); std::vector<float> v2(nz);
+    {
+      std::vector<int64_t> fill(colptr.begin(), colptr.end() - 1);
+      for (int64_t i = 0; i < nz; ++i) { const int64_t q = fill[c1[i]]++; r2[q] = r1[i]; v2[q] = v1[i]; }   // rows ascending within a gene
+    }
+    // chunks of <= 256 entries inside each gene's CSC range
+    std::vector<int64_t> chunk_start; std::vector<int> col_chunk_ptr(h->G + 1, 0);
+    for (int g = 0; g < h->G; ++g) {
+      col_chunk_ptr[g] = (int)chunk_start.size();
+      for (int64_t e = colptr[g]; e < colptr[g + 1]; e += 256) chunk_start.push_back(e);
+    }
+    col_chunk_ptr[h->G] = (int)chunk_start.size();
+    h->n_ovf_chunk = (int)chunk_start.size();
+    chunk_start.push_back(nz);
+    CACK(dalloc(h, &h->ovf_rowptr, h->N + 1));
+    CACK(dalloc(h, &h->ovf_chunk_start, (int64_t)chunk_start.size()));
+    CACK(dalloc(h, &h->ovf_col_chunk_ptr, h->G + 1));
+    CACK(dalloc(h, &h->ovf_csum, (int64_t)h->n_ovf_chunk * std::max(h->K, 1)));
+    HIPCK(h, hipMemcpy(h->ovf_chunk_start, chunk_start.data(), chunk_start.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIPCK(h, hipMemcpy(h->ovf_col_chunk_ptr, col_chunk_ptr.data(), col_chunk_ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+    CACK(dalloc(h, &h->ovf_col, nz)); CACK(dalloc(h, &h->ovf_row2, nz));
+    CACK(dalloc(h, &h->ovf_val, nz)); CACK(dalloc(h, &h->ovf_val2, nz));
+    HIPCK(h, hipMemcpy(h->ovf_rowptr, rowptr.data(), rowptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+    HIPCK(h, hipMemcpy(h->ovf_col, c1.data(), nz * sizeof(int), hipMemcpyHostToDevice));
+    HIPCK(h, hipMemcpy(h->ovf_row2, r2.data(), nz * sizeof(int), hipMemcpyHostToDevice));
+    HIPCK(h, hipMemcpy(h->ovf_val, v1.data(), nz * sizeof(float), hipMemcpyHostToDevice));
+    HIPCK(h, hipMemcpy(h->ovf_val2, v2.data(), nz * sizeof(float), hipMemcpyHostToDevice));
+    return CA_OK;
+  }
   if (store == CA_YSTORE_U8) hipLaunchKernelGGL((k_convert_y<ST, uint8_t>), grid, dim3(CA_TB), 0, h->stream, src_dev, (uint8_t*)h->Y, h->N, h->G, h->Gp, sn, sg, flags);
   else if (store == CA_YSTORE_U16) hipLaunchKernelGGL((k_convert_y<ST, uint16_t>), grid, dim3(CA_TB), 0, h->stream, src_dev, (uint16_t*)h->Y, h->N, h->G, h->Gp, sn, sg, flags);
   else hipLaunchKernelGGL((k_convert_y<ST, float>), grid, dim3(CA_TB), 0, h->stream, src_dev, (float*)h->Y, h->N, h->G, h->Gp, sn, sg, flags);
@@ -600,7 +679,7 @@ int upload_y(ca_engine* h, const ca_problem* p) {
 template <typename YT>
 void launch_prep(ca_engine* h, const double* logL, const double* extra) {
   hipLaunchKernelGGL((k_prep_cells<YT>), dim3((unsigned)h->N), dim3(CA_TB), 0, h->stream, (const YT*)h->Y, logL, extra, h->A, h->cn,
-                     h->s64, h->s32, h->N, h->G, h->Gp, h->C);
+                     h->s64, h->s32, h->N, h->G, h->Gp, h->C, h->ovf_rowptr, h->ovf_col, h->ovf_val);
 }
 
 int create_impl(ca_engine* h, const ca_problem* p) {
@@ -621,7 +700,6 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     while (CP < C) CP <<= 1;
     h->ncblk = (C <= 64) ? std::min(cdiv(Nn, CA_TB / CP), 16 * 256) : cdiv(Nn, CA_TB);   // k_cell_par: grid-stride over groups of CA_TB / CP cells
   }
-  const int n256 = cdiv(Nn, CA_TB);
   // ---- sweep decomposition
   const int target_blocks = 8 * h->n_cu;
   // one full round of resident blocks (8 x 256 threads per CU) when the cell blocks alone do not fill the chip
@@ -723,8 +801,8 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   CACK(dalloc(h, &h->cell_part, (int64_t)h->ncblk * (3 + C)));
   CACK(dalloc(h, &h->gpart, (int64_t)h->csplit * G * (S + D)));
   CACK(dalloc(h, &h->dFpart, (int64_t)h->ntile * Nn * std::max(D, 1)));
-  CACK(dalloc(h, &h->YWpart, (int64_t)h->nseg * Nn * std::max(K, 1)));
-  CACK(dalloc(h, &h->YTpart, (int64_t)h->nrb * h->Gp * std::max(K, 1)));
+  CACK(dalloc(h, &h->YWpart, (int64_t)(h->nseg + 1) * Nn * std::max(K, 1)));
+  CACK(dalloc(h, &h->YTpart, (int64_t)(h->nrb + 1) * h->Gp * std::max(K, 1)));
   CACK(dalloc(h, &h->YW, Nn * std::max(K, 1)));
   CACK(dalloc(h, &h->ytpsi, (int64_t)h->Gp * std::max(K, 1)));
   h->off_g = 3 + C;
@@ -760,10 +838,12 @@ int create_impl(ca_engine* h, const ca_problem* p) {
       else
         hipLaunchKernelGGL((k_ypass<float, 1>), grid, dim3(CA_TB), 0, h->stream, (const float*)h->Y, Ft, 1, Vt, 0, YWp, YTp, Nn, G, h->Gp, h->nseg, h->nrb, h->TR, 1);
       HIPCK(h, hipGetLastError());
-      hipLaunchKernelGGL(k_colsum, dim3(cdiv(h->Gp, 64)), dim3(CA_TB), 0, h->stream, YTp, yt, h->nrb, (int64_t)h->Gp, h->Gp);
+      hipLaunchKernelGGL(k_colsum, dim3(cdiv(h->Gp, 64)), dim3(1024), 0, h->stream, YTp, yt, h->nrb, (int64_t)h->Gp, h->Gp);
       std::vector<double> tmp((size_t)G);
       HIPCK(h, hipMemcpyAsync(tmp.data(), yt, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, h->stream));
       HIPCK(h, hipStreamSynchronize(h->stream));
+      for (int64_t e = 0; e < h->n_ovf; ++e)   // overflow list, fixed (cell, gene) order
+        tmp[h->h_ocol[e]] += (double)h->h_oval[e] * (double)col[h->h_orow[e]];
       if (j == 0) cs = tmp;
       else for (int g = 0; g < G; ++g) ytx[(size_t)g * P + (j - 1)] = tmp[g];
     }
@@ -772,6 +852,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     CACK(dalloc(h, &h->YtX, (int64_t)G * std::max(P, 1)));
     CACK(upload_d(h, h->YtX, ytx));
   }
+  h->dir_const = -((double)C * std::lgamma(1.0 / (double)C) - std::lgamma(1.0));
   h->b1p = (float)h->opt.beta1;
   h->b2p = (float)h->opt.beta2;
   CACK(refresh_derived(h));

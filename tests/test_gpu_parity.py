@@ -184,3 +184,41 @@ def test_ca_run_equals_call_by_call_loop_and_builtin_stream():
         d.close()
     finally:
         a.close(); b.close(); c.close()
+
+
+@pytest.mark.parametrize("name", ["k1", "k2p1s2x"])
+def test_u8_storage_with_overflow_list(name):
+    """Counts above 255 in a mostly-small matrix: dense u8 (capped at 255) + sorted overflow list."""
+    from clonealign_amd.engine import HipEngine
+    from oracle.fused_numpy import FusedModel
+    case = make_case(seed=31, **CASES[name])
+    Y = case["Y"]
+    rng = np.random.default_rng(0)
+    for _ in range(12):
+        Y[rng.integers(0, Y.shape[0]), rng.integers(0, Y.shape[1])] = float(rng.integers(256, 5000))
+    Y[3, 5], Y[3, 6], Y[200 % Y.shape[0], 5] = 256.0, 70000.0, 300.0
+    eng, ora = HipEngine(**case), FusedModel(**case, dtype="float32")
+    try:
+        info = eng.info()
+        assert info["y_storage_name"] == "u8" and info["y_bytes_per_elem"] == 1
+        np.testing.assert_array_equal(eng.get("s"), ora.s)
+        st = perturbed_state({n: getattr(ora, n).shape for n in ora.VAR_NAMES})
+        for n, v in st.items():
+            setattr(ora, n, v.astype(ora.pdt))
+            eng.set(n, v)
+        eps = eps_for(ora.S, ora.G, 4)
+        for a, b in zip(eng.elbo_terms(eps), ora.elbo_terms(eps)):
+            assert abs(a - b) <= 2e-5 * max(abs(b), 1.0)
+        ge, _ = eng.gradients(eps)
+        go, _ = ora.gradients(eps)
+        for n in ora.VAR_NAMES:
+            assert _rel(ge[n], go[n]) < 2e-5, n
+        for i in range(3):
+            e = eps_for(ora.S, ora.G, 40 + i)
+            eng.step(e)
+            ora.step(e)
+        so, se = ora.get_state(), eng.get_state()
+        for n in ora.VAR_NAMES:
+            assert _rel(se[n], so[n]) < 1e-4, n
+    finally:
+        eng.close()

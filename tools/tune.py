@@ -1,16 +1,14 @@
-"""Tuning sweep over the decomposition env overrides (CA_GSPLIT / CA_CSPLIT / CA_TR); prints per-kernel ms/iter."""
+"""Tuning sweep over the decomposition env overrides (CA_GSPLIT / CA_CSPLIT / CA_TR); prints per-kernel us/iter."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-def run(env):
+def run(env, extra=()):
     e = dict(os.environ); e.update({k: str(v) for k, v in env.items()})
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline"],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", *extra],
                          env=e, capture_output=True, text=True).stdout.strip().splitlines()[-1]
     d = json.loads(out)
     k = d["kernel_ms_per_iter_warmup"]
-    print(env, f"{d['value']:.0f} it/s", {n: round(v * 1e3) for n, v in k.items()}, flush=True)
-for cs in (256, 320, 358, 410, 512, 716, 1024):
-    run({"CA_CSPLIT": cs})
-for gs in (4, 5, 8, 10, 16, 20):
-    run({"CA_GSPLIT": gs})
-for tr in (32, 64, 128, 256):
-    run({"CA_TR": tr})
+    print(env, extra, f"{d['value']:.0f} it/s", d["config"]["y_storage"], {n: round(v * 1e3) for n, v in k.items()}, flush=True)
+if __name__ == "__main__":
+    for tr in (32, 64, 128, 256):
+        run({"CA_TR": tr})
+    run({}, ("--y-storage", "u16"))
