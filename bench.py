@@ -27,12 +27,17 @@ PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
 
 
-def algorithmic_work(kernel, N, G, C, K):
+def algorithmic_work(kernel, N, G, C, K, fused=False, steps=1):
     """Per-launch algorithmic work of each kernel class."""
     if kernel == "ypass":     # one pass over Y: Y.W and Y^T.psi; canonical 4 B/elem + outputs
         return "hbm", N * G * 4.0 + (N + G) * K * 4.0 * 2
     if kernel == "fwd":       # eta 2K, Z 2C, +1 (exp not counted)
-        return "mfma", N * G * (2.0 * C + 2.0 * K + 1.0)
+        plain = N * G * (2.0 * C + 2.0 * K + 1.0)
+        if not fused:
+            return "mfma", plain
+        # fused two-eps sweep: 2C columns share one eta/exp; per timed call: steps-1 fused launches + 2 plain ones
+        two = N * G * (4.0 * C + 2.0 * K + 1.0)
+        return "mfma", ((steps - 1) * two + 2 * plain) / (steps + 1)
     if kernel == "bwd":       # eta 2K, t 2C, dM/dmu 2C-equivalent, deta 1, dpsi 2K, dW 2K
         return "mfma", N * G * (4.0 * C + 6.0 * K + 1.0)
     return "hbm", 0.0
@@ -171,7 +176,7 @@ def main():
     if rank == 0:
         ms, launches = kt_timed[dominant]
         per_launch_s = ms / max(launches, 1) * 1e-3
-        bound, work = algorithmic_work(dominant, n_loc, G, C, K)
+        bound, work = algorithmic_work(dominant, n_loc, G, C, K, bool(info.get("fused_sweep")), args.steps)
         if bound == "hbm":
             achieved, peak, unit = work / per_launch_s / 1e9, PEAK_HBM_GBS, "GB/s"
         else:
@@ -185,6 +190,7 @@ def main():
                                    f"{world} GPU(s) (BASELINE.json configs[{2 if world == 1 else 3}])",
                        "cells": N, "genes": G, "clones": C, "K": K, "mc_samples": 1, "learning_rate": 0.1,
                        "y_storage": info["y_storage_name"], "y_bytes_per_elem": info["y_bytes_per_elem"],
+                       "fused_sweep": bool(info.get("fused_sweep")),
                        "parallelism": f"cells/{world}" if world > 1 else "single"},
             "roofline": {"bound": bound, "kernel": dominant, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": None,

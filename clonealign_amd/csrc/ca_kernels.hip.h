@@ -280,12 +280,22 @@ __global__ void __launch_bounds__(CA_TB) k_ypass(const YT* __restrict__ Y, const
   float keep[KK];
 #pragma unroll
   for (int k = 0; k < KK; ++k) keep[k] = 0.f;
+  uint4 nxt[U];   // software pipeline: the next U rows are requested before the current U are consumed
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t r = (r0 + u < r1) ? r0 + u : r1 - 1;
+    nxt[u] = *reinterpret_cast<const uint4*>(base + r * Gp);
+  }
   for (int64_t rr = r0; rr < r1; rr += U) {
     uint4 raw[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int64_t r = (rr + u < r1) ? rr + u : r1 - 1;   // tail rows re-read the last row (contribution masked below)
-      raw[u] = *reinterpret_cast<const uint4*>(base + r * Gp);
+    for (int u = 0; u < U; ++u) raw[u] = nxt[u];
+    if (rr + U < r1) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t r = (rr + U + u < r1) ? rr + U + u : r1 - 1;   // tail rows re-read the last row (masked below)
+        nxt[u] = *reinterpret_cast<const uint4*>(base + r * Gp);
+      }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -368,8 +378,8 @@ __global__ void __launch_bounds__(CA_TB) k_gene_pre(const float* __restrict__ lo
                                                     const float* __restrict__ eps /*[S][G]*/,
                                                     const double* __restrict__ colsum, const float* __restrict__ Lb /*[nchunk][G][8]*/,
                                                     const float* __restrict__ V, int D, int K, const double* __restrict__ YtX,
-                                                    float* __restrict__ mu32 /*[S][G]*/, float* __restrict__ Mb /*[S][nchunk][G][8]*/,
-                                                    double* __restrict__ gene_part, int G, int S, int nchunk) {
+                                                    float* __restrict__ mu32 /*[S][G]*/, float* __restrict__ Mb /*[S][nchunk][G][mrow]*/,
+                                                    double* __restrict__ gene_part, int G, int S, int nchunk, int mrow, int mcol, int ncol) {
   __shared__ double sm[CA_TB];
   const int g = blockIdx.x * CA_TB + threadIdx.x;
   const bool ok = g < G;
@@ -385,13 +395,11 @@ __global__ void __launch_bounds__(CA_TB) k_gene_pre(const float* __restrict__ lo
       const float muf = (float)mu;
       mu32[(int64_t)s * G + g] = muf;
       for (int ch = 0; ch < nchunk; ++ch) {
-        const float4* lp = reinterpret_cast<const float4*>(Lb + ((int64_t)ch * G + g) * CA_CW);
-        float4 a = lp[0], b = lp[1];
-        a.x *= muf; a.y *= muf; a.z *= muf; a.w *= muf;
-        b.x *= muf; b.y *= muf; b.z *= muf; b.w *= muf;
-        float4* mp = reinterpret_cast<float4*>(Mb + (((int64_t)s * nchunk + ch) * G + g) * CA_CW);
-        mp[0] = a;
-        mp[1] = b;
+        // row stride mrow / column offset mcol / ncol columns: 8/0/8 normally; the fused two-eps sweep packs
+        // [mu_A L | mu_B L] into one row
+        const float* lp = Lb + ((int64_t)ch * G + g) * CA_CW;
+        float* mp = Mb + (((int64_t)s * nchunk + ch) * G + g) * mrow + mcol;
+        for (int c = 0; c < ncol; ++c) mp[c] = lp[c] * muf;
       }
       t0 += cs * lm;
       t1 += -0.5 * lm * lm - 0.5 * CA_LOG2PI;
@@ -517,20 +525,20 @@ __global__ void __launch_bounds__(CA_TB) k_fwd(const float* __restrict__ F, cons
 // LDS-staged variant (the one launched): the block copies its gene slice of M (and V') into LDS once and
 // every lane sweeps it for R cells -- broadcast ds_read_b128 instead of per-wave scalar loads, R independent
 // exp chains per lane.  Measured 132-137 us vs 158 us for k_fwd at 100k x 5k x 8 (tools/fwd_lab.hip).
-template <int NC, int D, int R>
+template <int NC, int D, int R, int CWS = CA_CW>
 __global__ void __launch_bounds__(CA_TB) k_fwd_lds(const float* __restrict__ F, const float* __restrict__ etamax2,
-                                                   const float* __restrict__ Vs, const float* __restrict__ M /*[G][8]*/,
-                                                   float* __restrict__ Zpart /*[gsplit][N][8]*/, int64_t N, int G,
+                                                   const float* __restrict__ Vs, const float* __restrict__ M /*[G][CWS]*/,
+                                                   float* __restrict__ Zpart /*[gsplit][N][CWS]*/, int64_t N, int G,
                                                    int gchunk, int Drt) {
   constexpr int DM = (D < 0) ? 8 : (D > 0 ? D : 1);
   const int Dn = (D < 0) ? Drt : D;
-  extern __shared__ float ca_lds[];  // [gchunk][8] M slice, then [gchunk][Dn] V' slice
+  extern __shared__ float ca_lds[];  // [gchunk][CWS] M slice, then [gchunk][Dn] V' slice
   const int g0 = blockIdx.y * gchunk;
   const int ng = ((g0 + gchunk < G) ? g0 + gchunk : G) - g0;
   float4* l4 = reinterpret_cast<float4*>(ca_lds);
-  const float4* m4 = reinterpret_cast<const float4*>(M + (int64_t)g0 * CA_CW);
-  for (int i = threadIdx.x; i < ng * 2; i += CA_TB) l4[i] = m4[i];
-  float* lv = ca_lds + (int64_t)gchunk * CA_CW;
+  const float4* m4 = reinterpret_cast<const float4*>(M + (int64_t)g0 * CWS);
+  for (int i = threadIdx.x; i < ng * (CWS / 4); i += CA_TB) l4[i] = m4[i];
+  float* lv = ca_lds + (int64_t)gchunk * CWS;
   for (int i = threadIdx.x; i < ng * Dn; i += CA_TB) lv[i] = Vs[(int64_t)g0 * Dn + i];
   __syncthreads();
   const int64_t nb = (int64_t)blockIdx.x * CA_TB * R + threadIdx.x;
@@ -547,8 +555,12 @@ __global__ void __launch_bounds__(CA_TB) k_fwd_lds(const float* __restrict__ F, 
   }
 #pragma unroll 4
   for (int g = 0; g < ng; ++g) {
-    const float4 a = l4[2 * g], b = l4[2 * g + 1];
-    const float m[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    float m[CWS];
+#pragma unroll
+    for (int j = 0; j < CWS / 4; ++j) {
+      const float4 a = l4[(CWS / 4) * g + j];
+      m[4 * j] = a.x; m[4 * j + 1] = a.y; m[4 * j + 2] = a.z; m[4 * j + 3] = a.w;
+    }
     float v[DM];
 #pragma unroll
     for (int d = 0; d < DM; ++d) v[d] = (d < Dn) ? lv[g * Dn + d] : 0.f;
@@ -569,7 +581,7 @@ __global__ void __launch_bounds__(CA_TB) k_fwd_lds(const float* __restrict__ F, 
   for (int r = 0; r < R; ++r) {
     const int64_t n = nb + r * CA_TB;
     if (n < N) {
-      float* zp = Zpart + ((int64_t)blockIdx.y * N + n) * CA_CW;
+      float* zp = Zpart + ((int64_t)blockIdx.y * N + n) * CWS;
 #pragma unroll
       for (int c = 0; c < NC; ++c) zp[c] = z[r][c];
     }
@@ -898,6 +910,105 @@ __global__ void __launch_bounds__(CA_TB) k_cell_par(const float* __restrict__ Zp
     cell_part[(int64_t)blockIdx.x * W_ + 2] = r2;
   }
   // per-clone sums of gamma over the block's cells, fixed order
+  __syncthreads();
+  sm[threadIdx.x] = gsumc;
+  __syncthreads();
+  if (threadIdx.x < C) {
+    double a = 0.0;
+    for (int i = 0; i < CPB; ++i) a += sm[i * CP + threadIdx.x];
+    cell_part[(int64_t)blockIdx.x * W_ + 3 + threadIdx.x] = a;
+  }
+}
+
+// Cell epilogue of the FUSED sweep: one forward sweep produced Z for two eps draws of the same parameter
+// state -- group A (columns [0,C): the monitor pass, `sess$run(elbo)` :403) and group B (columns [C,2C): the
+// forward half of the NEXT train pass, :401).  gamma, log gamma, log alpha, psi.(YW) are shared; A yields the
+// ELBO partials, B yields coef and d ELBO / d logits for the backward sweep.  S == 1, C <= 8.
+template <int CP>
+__global__ void __launch_bounds__(CA_TB) k_cell_fused(const float* __restrict__ Zpart /*[gsplit][N][zrow]*/, int zrow,
+                                                      const double* __restrict__ A, const double* __restrict__ cn,
+                                                      const double* __restrict__ s64, const float* __restrict__ etamax2,
+                                                      const float* __restrict__ glogit, const float* __restrict__ alpha_u,
+                                                      const float* __restrict__ F, const float* __restrict__ YWpart,
+                                                      float* __restrict__ YW, float* __restrict__ coef /*[N][8]*/,
+                                                      float* __restrict__ dgl, double* __restrict__ cell_part, int64_t N, int C,
+                                                      int D, int K, int gsplit, int nseg) {
+  __shared__ double sm[CA_TB];
+  __shared__ double la[64];
+  constexpr int CPB = CA_TB / CP;
+  if (threadIdx.x == 0) {
+    double mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmax(mx, (double)alpha_u[c]);
+    double se = 0.0;
+    for (int c = 0; c < C; ++c) se += exp((double)alpha_u[c] - mx);
+    const double lse = mx + log(se);
+    for (int c = 0; c < C; ++c) la[c] = (double)alpha_u[c] - lse;
+  }
+  __syncthreads();
+  const int c = threadIdx.x % CP;
+  auto gmax = [](double v) {
+#pragma unroll
+    for (int o = CP / 2; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, CP));
+    return v;
+  };
+  auto gsum = [](double v) {
+#pragma unroll
+    for (int o = CP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, CP);
+    return v;
+  };
+  double ee = 0.0, pr = 0.0, q = 0.0, gsumc = 0.0;
+  const int64_t ngroups = (N + CPB - 1) / CPB;
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t n = grp * CPB + threadIdx.x / CP;
+    const bool okn = n < N, ok = okn && c < C;
+    const int64_t nn = okn ? n : N - 1;
+    const int cc = c < C ? c : C - 1;
+    const double gl = ok ? (double)glogit[nn * C + cc] : -INFINITY;
+    const double mx = gmax(gl);
+    const double ex = ok ? exp(gl - mx) : 0.0;
+    const double se = gsum(ex);
+    const double lse = mx + log(se);
+    const double lg = gl - lse;
+    const double gam = ok ? ex / se : 0.0;
+    const double sn = s64[nn];
+    const double em = (D > 0) ? (double)etamax2[nn] * CA_LN2 : 0.0;
+    double ZA = 0.0, ZB = 0.0;
+    for (int sp = 0; sp < gsplit; ++sp) {
+      const float* zp = Zpart + ((int64_t)sp * N + nn) * zrow;
+      ZA += (double)zp[cc];
+      ZB += (double)zp[C + cc];
+    }
+    const double Anc = A[nn * C + cc];
+    const double llpA = Anc - sn * (log(ZA) + em);
+    const double llpB = Anc - sn * (log(ZB) + em);
+    if (ok) coef[nn * CA_CW + cc] = (float)(-gam * sn / ZB);
+    const double fB = llpB + la[cc] - lg;
+    const bool live = ok && gam != 0.0;
+    const double fbarB = gsum(live ? gam * fB : 0.0);
+    if (ok) dgl[nn * C + cc] = live ? (float)(gam * (fB - fbarB)) : 0.f;
+    if (live) { ee += gam * llpA; pr += gam * la[cc]; q += gam * lg; }
+    gsumc += gam;
+    if (okn && c == 0) {
+      ee += cn[nn];
+      for (int k = 0; k < K; ++k) {
+        double yw = 0.0;
+        for (int sg = 0; sg < nseg; ++sg) yw += (double)YWpart[((int64_t)sg * N + nn) * K + k];
+        YW[nn * K + k] = (float)yw;
+        const double ps = (double)F[nn * D + k];
+        ee += ps * yw;
+        pr += -0.5 * ps * ps - 0.5 * CA_LOG2PI;
+      }
+    }
+  }
+  const int W_ = 3 + C;
+  const double r0 = ca_block_sum(ee, sm);
+  const double r1 = ca_block_sum(pr, sm);
+  const double r2 = ca_block_sum(q, sm);
+  if (threadIdx.x == 0) {
+    cell_part[(int64_t)blockIdx.x * W_ + 0] = r0;
+    cell_part[(int64_t)blockIdx.x * W_ + 1] = r1;
+    cell_part[(int64_t)blockIdx.x * W_ + 2] = r2;
+  }
   __syncthreads();
   sm[threadIdx.x] = gsumc;
   __syncthreads();

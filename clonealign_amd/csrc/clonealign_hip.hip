@@ -70,6 +70,8 @@ struct ca_engine {
   ca_options opt{};
   int device = 0;
   hipStream_t stream = nullptr;
+  // second stream: the Y pass of the next parameter state runs beside the monitor pass's forward sweep
+  hipStream_t stream2 = nullptr; hipEvent_t ev_params = nullptr, ev_ydone = nullptr; bool y_pending = false, async_y = true;
   std::string err;
   std::vector<void*> allocs;
   int64_t dev_bytes = 0;
@@ -110,6 +112,9 @@ struct ca_engine {
   double* elbo_dev = nullptr; int64_t elbo_cap = 0; double* terms_dev = nullptr;
   double* host_pinned = nullptr;  // 8 doubles
   bool ycache_valid = false, sums_global = false;
+  // fused two-eps sweep (monitor pass of iteration i + forward half of train pass i+1, same parameters)
+  bool fused_ok = false, look_valid = false; int64_t look_slot = 0; int frow = 8;
+  float *Mb2 = nullptr, *mu32B = nullptr, *Zpart2 = nullptr; double* gene_partB = nullptr;
   uint64_t draw = 0;  // built-in stream position
   // ---- comm
   ca_nccl_comm comm = nullptr;
@@ -158,6 +163,7 @@ int dalloc(ca_engine* h, T** p, int64_t n) {
 int prof_flush(ca_engine* h) {
   if (h->ev_used == 0) return CA_OK;
   HIPCK(h, hipStreamSynchronize(h->stream));
+  if (h->stream2) HIPCK(h, hipStreamSynchronize(h->stream2));
   for (size_t i = 0; i < h->ev_used; ++i) {
     float ms = 0.f;
     HIPCK(h, hipEventElapsedTime(&ms, h->ev_pool[i].a, h->ev_pool[i].b));
@@ -226,6 +232,29 @@ void launch_fwd(int nc, int D, dim3 grid, hipStream_t st, const float* F, const 
     case 6: fwd_nc<6>(D, grid, st, F, em, Vs, M, Zp, N, G, gchunk); break;
     case 7: fwd_nc<7>(D, grid, st, F, em, Vs, M, Zp, N, G, gchunk); break;
     default: fwd_nc<8>(D, grid, st, F, em, Vs, M, Zp, N, G, gchunk); break;
+  }
+}
+
+template <int NC>
+void fwd16_nc(int D, dim3 grid, hipStream_t st, const float* F, const float* em, const float* Vs, const float* M, float* Zp,
+              int64_t N, int G, int gchunk) {
+  const size_t lds = (size_t)gchunk * (16 + (D > 0 ? D : 0)) * sizeof(float);
+  switch (D) {
+    case 0: hipLaunchKernelGGL((k_fwd_lds<NC, 0, kFwdR, 16>), grid, dim3(CA_TB), lds, st, F, em, Vs, M, Zp, N, G, gchunk, D); break;
+    case 1: hipLaunchKernelGGL((k_fwd_lds<NC, 1, kFwdR, 16>), grid, dim3(CA_TB), lds, st, F, em, Vs, M, Zp, N, G, gchunk, D); break;
+    case 2: hipLaunchKernelGGL((k_fwd_lds<NC, 2, kFwdR, 16>), grid, dim3(CA_TB), lds, st, F, em, Vs, M, Zp, N, G, gchunk, D); break;
+    default: hipLaunchKernelGGL((k_fwd_lds<NC, -1, kFwdR, 16>), grid, dim3(CA_TB), lds, st, F, em, Vs, M, Zp, N, G, gchunk, D); break;
+  }
+}
+// forward sweep over 2*C columns [A | B] of a fused two-eps pass; row stride 8 when 2C <= 8, else 16
+void launch_fwd_fused(int C, int D, dim3 grid, hipStream_t st, const float* F, const float* em, const float* Vs, const float* M,
+                      float* Zp, int64_t N, int G, int gchunk) {
+  switch (2 * C) {
+    case 10: fwd16_nc<10>(D, grid, st, F, em, Vs, M, Zp, N, G, gchunk); break;
+    case 12: fwd16_nc<12>(D, grid, st, F, em, Vs, M, Zp, N, G, gchunk); break;
+    case 14: fwd16_nc<14>(D, grid, st, F, em, Vs, M, Zp, N, G, gchunk); break;
+    case 16: fwd16_nc<16>(D, grid, st, F, em, Vs, M, Zp, N, G, gchunk); break;
+    default: launch_fwd(2 * C, D, grid, st, F, em, Vs, M, Zp, N, G, gchunk); break;   // 2, 4, 6, 8 columns
   }
 }
 
@@ -308,12 +337,14 @@ int download_f(ca_engine* h, std::vector<float>& v, const float* src, int64_t n)
 
 // ---- derived state that depends on the parameters only (not on eps) -------------------------
 int refresh_derived(ca_engine* h) {
+  if (h->y_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ydone, 0)); h->y_pending = false; }
   if (h->D > 0) {
     LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_vprep, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->V, h->Vs, h->vmm_part, h->G, h->D));
     LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_vmm_final, dim3(1), dim3(64), 0, h->stream, h->vmm_part, h->vmm, h->ngblk, h->D));
     LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_etamax, dim3(cdiv(h->N, CA_TB)), dim3(CA_TB), 0, h->stream, h->F, h->vmm, h->etamax2, h->N, h->D));
   }
   h->ycache_valid = false;
+  h->look_valid = false;
   return CA_OK;
 }
 
@@ -379,17 +410,78 @@ int setup_global_sums(ca_engine* h) {
   return CA_OK;
 }
 
+// Backward half of a train pass.  Needs: coef / dgl from the cell epilogue, mu of the same eps, red[0..3+C) cell sums.
+// cell_sums_global: red[0..3+C) was already all-reduced by the monitor pass that produced it (fused path).
+int train_tail(ca_engine* h, const float* eps, const float* mu32, int apply, double* elbo_dst, bool cell_sums_global) {
+  const int N256 = cdiv(h->N, CA_TB);
+  float lr_t = 0.f;
+  for (int s = 0; s < h->S; ++s)
+    for (int ch = 0; ch < h->nchunk; ++ch) {
+      BwdArgs a;
+      a.coef = h->coef + ((int64_t)s * h->nchunk + ch) * h->N * CA_CW;
+      a.F = h->F; a.em = h->etamax2;
+      a.Lb = h->Lb + (int64_t)ch * h->G * CA_CW;
+      a.mu = mu32 + (int64_t)s * h->G;
+      a.Vs = h->Vs; a.V = h->V; a.gpart = h->gpart; a.dFpart = h->dFpart;
+      a.N = h->N; a.G = h->G; a.cchunk = h->cchunk; a.D = h->D; a.S = h->S; a.sidx = s;
+      a.first_s = (ch == 0); a.first = (s == 0 && ch == 0);
+      const int nc = std::min(CA_CW, h->C - ch * CA_CW);
+      LAUNCH(h, CA_KERNEL_BWD, launch_bwd(h->RG, nc, dim3(cdiv(h->ntile, CA_TB / 64), h->csplit), h->stream, a));
+    }
+  const int W_ = h->S + h->D;
+  LAUNCH(h, CA_KERNEL_OTHER,
+         hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->G * W_, 64)), dim3(1024), 0, h->stream, h->gpart,
+                            h->red + h->off_g, h->csplit, (int64_t)h->G * W_, h->G * W_));
+  if (cell_sums_global) CACK(allreduce(h, h->red + h->off_g, h->red_n - h->off_g));
+  else CACK(allreduce(h, h->red, h->red_n));
+  if (h->opt.world > 1 || h->comm || h->host_ar) h->ycache_valid = false;   // red_y now holds the GLOBAL sum
+  if (apply) {
+    // lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t), float32 like TF's _prepare()/_apply_dense
+    lr_t = (float)h->opt.learning_rate * sqrtf(1.f - h->b2p) / (1.f - h->b1p);
+  }
+  LAUNCH(h, CA_KERNEL_OTHER,
+         hipLaunchKernelGGL(k_final_gene, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->red + h->off_g, h->red + h->off_y, eps,
+                            h->colsum, h->YtX, h->vchi, h->loc, h->ls, h->V, h->m_loc, h->v_loc, h->m_ls, h->v_ls, h->m_V, h->v_V,
+                            h->g_loc, h->g_ls, h->g_V, h->Vs, h->vmm_part, h->G, h->S, h->D, h->K, apply, lr_t, (float)h->opt.beta1, (float)h->opt.beta2,
+                            (float)h->opt.adam_eps));
+  LAUNCH(h, CA_KERNEL_OTHER,
+         hipLaunchKernelGGL(k_final_small, dim3(1), dim3(CA_TB), 0, h->stream, h->red, h->gene_part, h->ngblk, h->vchi, h->alpha_u,
+                            h->m_v, h->v_v, h->m_a, h->v_a, h->g_v, h->g_a, elbo_dst, h->terms_dev, h->G, h->C, h->K, apply ? 1 : 0, lr_t,
+                            (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, (const double*)nullptr, h->ncblk, h->red,
+                            h->vmm_part, h->vmm, h->D, h->dir_const));
+  LAUNCH(h, CA_KERNEL_OTHER,
+         hipLaunchKernelGGL(k_adam_cell, dim3(N256), dim3(CA_TB), 0, h->stream, h->F, h->YW, h->dFpart, h->glogit, h->dgl, h->m_psi,
+                            h->v_psi, h->m_gl, h->v_gl, h->g_psi, h->N, h->C, h->D, h->K, h->ntile, apply, lr_t,
+                            (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, h->vmm, h->etamax2));
+  if (apply) {
+    h->b1p *= (float)h->opt.beta1;
+    h->b2p *= (float)h->opt.beta2;
+    h->ycache_valid = false;   // V', its range and etamax2 were refreshed inside the step's own kernels
+    h->look_valid = false;
+    if (h->async_y && h->K > 0) {   // start the Y pass for the new parameters on the side stream right away
+      HIPCK(h, hipEventRecord(h->ev_params, h->stream));
+      HIPCK(h, hipStreamWaitEvent(h->stream2, h->ev_params, 0));
+      std::swap(h->stream, h->stream2);
+      const int rc = ensure_ycache(h);
+      std::swap(h->stream, h->stream2);
+      CACK(rc);
+      HIPCK(h, hipEventRecord(h->ev_ydone, h->stream2));
+      h->y_pending = true;
+    }
+  }
+  return CA_OK;
+}
+
 // One evaluation of the model for the eps of device slot `eps_slot`.
 //   mode CA_MODE_ELBO : forward only, ELBO -> elbo_dst        (`sess$run(elbo)`)
 //   mode CA_MODE_GINIT: forward only, overwrite the q(z) logits (`gamma_init`)
 //   mode CA_MODE_TRAIN: forward + backward (+ Adam when apply)  (`sess$run(train)`)
 int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_dst) {
   const float* eps = h->eps_dev + eps_slot * (int64_t)h->S * h->G;
-  const int N256 = cdiv(h->N, CA_TB);
   CACK(ensure_ycache(h));
   LAUNCH(h, CA_KERNEL_OTHER,
          hipLaunchKernelGGL(k_gene_pre, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->loc, h->ls, eps, h->colsum, h->Lb, h->V,
-                            h->D, h->K, h->YtX, h->mu32, h->Mb, h->gene_part, h->G, h->S, h->nchunk));
+                            h->D, h->K, h->YtX, h->mu32, h->Mb, h->gene_part, h->G, h->S, h->nchunk, CA_CW, 0, CA_CW));
   for (int s = 0; s < h->S; ++s)
     for (int ch = 0; ch < h->nchunk; ++ch) {
       const int nc = std::min(CA_CW, h->C - ch * CA_CW);
@@ -399,6 +491,10 @@ int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_d
       float* Zp = h->Zpart + (((int64_t)s * h->nchunk + ch) * h->gsplit) * h->N * CA_CW;
       LAUNCH(h, CA_KERNEL_FWD, launch_fwd(nc, h->D, dim3(cdiv(h->N, CA_TB * kFwdR), h->gsplit), h->stream, h->F, h->etamax2, h->Vs, M, Zp, h->N, h->G, h->gchunk));
     }
+  if (h->y_pending) {   // the cell epilogue is the first consumer of YW / Y^T psi
+    HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ydone, 0));
+    h->y_pending = false;
+  }
   if (h->C <= 64) {
     int CP = 1;
     while (CP < h->C) CP <<= 1;
@@ -426,57 +522,79 @@ int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_d
   }
   if (mode == CA_MODE_GINIT) return CA_OK;
   LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_reduce_part, dim3(3 + h->C), dim3(CA_TB), 0, h->stream, h->cell_part, h->red, h->ncblk, 3 + h->C));
-  float lr_t = 0.f;
-  if (mode == CA_MODE_TRAIN) {
-    for (int s = 0; s < h->S; ++s)
-      for (int ch = 0; ch < h->nchunk; ++ch) {
-        BwdArgs a;
-        a.coef = h->coef + ((int64_t)s * h->nchunk + ch) * h->N * CA_CW;
-        a.F = h->F; a.em = h->etamax2;
-        a.Lb = h->Lb + (int64_t)ch * h->G * CA_CW;
-        a.mu = h->mu32 + (int64_t)s * h->G;
-        a.Vs = h->Vs; a.V = h->V; a.gpart = h->gpart; a.dFpart = h->dFpart;
-        a.N = h->N; a.G = h->G; a.cchunk = h->cchunk; a.D = h->D; a.S = h->S; a.sidx = s;
-        a.first_s = (ch == 0); a.first = (s == 0 && ch == 0);
-        const int nc = std::min(CA_CW, h->C - ch * CA_CW);
-        LAUNCH(h, CA_KERNEL_BWD, launch_bwd(h->RG, nc, dim3(cdiv(h->ntile, CA_TB / 64), h->csplit), h->stream, a));
-      }
-    const int W_ = h->S + h->D;
-    LAUNCH(h, CA_KERNEL_OTHER,
-           hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->G * W_, 64)), dim3(1024), 0, h->stream, h->gpart,
-                              h->red + h->off_g, h->csplit, (int64_t)h->G * W_, h->G * W_));
-    CACK(allreduce(h, h->red, h->red_n));
-    if (h->opt.world > 1 || h->comm || h->host_ar) h->ycache_valid = false;   // red_y now holds the GLOBAL sum
-    if (apply) {
-      // lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t), float32 like TF's _prepare()/_apply_dense
-      lr_t = (float)h->opt.learning_rate * sqrtf(1.f - h->b2p) / (1.f - h->b1p);
-    }
-    LAUNCH(h, CA_KERNEL_OTHER,
-           hipLaunchKernelGGL(k_final_gene, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->red + h->off_g, h->red + h->off_y, eps,
-                              h->colsum, h->YtX, h->vchi, h->loc, h->ls, h->V, h->m_loc, h->v_loc, h->m_ls, h->v_ls, h->m_V, h->v_V,
-                              h->g_loc, h->g_ls, h->g_V, h->Vs, h->vmm_part, h->G, h->S, h->D, h->K, apply, lr_t, (float)h->opt.beta1, (float)h->opt.beta2,
-                              (float)h->opt.adam_eps));
-  } else {
-    CACK(allreduce(h, h->red, 3 + h->C));
-  }
+  if (mode == CA_MODE_TRAIN) return train_tail(h, eps, h->mu32, apply, elbo_dst, false);
+  CACK(allreduce(h, h->red, 3 + h->C));
   LAUNCH(h, CA_KERNEL_OTHER,
          hipLaunchKernelGGL(k_final_small, dim3(1), dim3(CA_TB), 0, h->stream, h->red, h->gene_part, h->ngblk, h->vchi, h->alpha_u,
-                            h->m_v, h->v_v, h->m_a, h->v_a, h->g_v, h->g_a, elbo_dst, h->terms_dev, h->G, h->C, h->K,
-                            (mode == CA_MODE_TRAIN && apply) ? 1 : 0, lr_t, (float)h->opt.beta1, (float)h->opt.beta2,
-                            (float)h->opt.adam_eps, (const double*)nullptr, h->ncblk, h->red,
+                            h->m_v, h->v_v, h->m_a, h->v_a, h->g_v, h->g_a, elbo_dst, h->terms_dev, h->G, h->C, h->K, 0, 0.f,
+                            (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, (const double*)nullptr, h->ncblk, h->red,
                             h->vmm_part, h->vmm, h->D, h->dir_const));
-  if (mode == CA_MODE_TRAIN) {
-    LAUNCH(h, CA_KERNEL_OTHER,
-           hipLaunchKernelGGL(k_adam_cell, dim3(N256), dim3(CA_TB), 0, h->stream, h->F, h->YW, h->dFpart, h->glogit, h->dgl, h->m_psi,
-                              h->v_psi, h->m_gl, h->v_gl, h->g_psi, h->N, h->C, h->D, h->K, h->ntile, apply, lr_t,
-                              (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, h->vmm, h->etamax2));
-    if (apply) {
-      h->b1p *= (float)h->opt.beta1;
-      h->b2p *= (float)h->opt.beta2;
-      h->ycache_valid = false;   // V', its range and etamax2 were refreshed inside the step's own kernels
-    }
-  }
   return CA_OK;
+}
+
+// Monitor pass for eps slot A fused with the forward half of the NEXT train pass (eps slot B): one sweep,
+// one exp per (cell, gene) for both (same parameters, R/inference-tflow.R:401,403 of consecutive iterations).
+int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst) {
+  const float* epsA = h->eps_dev + slotA * (int64_t)h->G;
+  const float* epsB = h->eps_dev + slotB * (int64_t)h->G;
+  CACK(ensure_ycache(h));
+  LAUNCH(h, CA_KERNEL_OTHER,
+         hipLaunchKernelGGL(k_gene_pre, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->loc, h->ls, epsA, h->colsum, h->Lb, h->V,
+                            h->D, h->K, h->YtX, h->mu32, h->Mb2, h->gene_part, h->G, 1, 1, h->frow, 0, h->C));
+  LAUNCH(h, CA_KERNEL_OTHER,
+         hipLaunchKernelGGL(k_gene_pre, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->loc, h->ls, epsB, h->colsum, h->Lb, h->V,
+                            h->D, h->K, h->YtX, h->mu32B, h->Mb2, h->gene_partB, h->G, 1, 1, h->frow, h->C, h->C));
+  LAUNCH(h, CA_KERNEL_FWD, launch_fwd_fused(h->C, h->D, dim3(cdiv(h->N, CA_TB * kFwdR), h->gsplit), h->stream, h->F, h->etamax2,
+                                            h->Vs, h->Mb2, h->Zpart2, h->N, h->G, h->gchunk));
+  if (h->y_pending) {
+    HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ydone, 0));
+    h->y_pending = false;
+  }
+  {
+    int CP = 1;
+    while (CP < h->C) CP <<= 1;
+    dim3 grid(h->ncblk);
+#define CA_CELLF(CPV)                                                                                                        \
+  LAUNCH(h, CA_KERNEL_CELL,                                                                                                  \
+         hipLaunchKernelGGL((k_cell_fused<CPV>), grid, dim3(CA_TB), 0, h->stream, h->Zpart2, h->frow, h->A, h->cn, h->s64,   \
+                            h->etamax2, h->glogit, h->alpha_u, h->F, h->YWpart, h->YW, h->coef, h->dgl, h->cell_part, h->N,  \
+                            h->C, h->D, h->K, h->gsplit, h->nseg + (h->n_ovf > 0 ? 1 : 0)))
+    switch (CP) {
+      case 1: CA_CELLF(1); break;
+      case 2: CA_CELLF(2); break;
+      case 4: CA_CELLF(4); break;
+      default: CA_CELLF(8); break;
+    }
+#undef CA_CELLF
+  }
+  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_reduce_part, dim3(3 + h->C), dim3(CA_TB), 0, h->stream, h->cell_part, h->red, h->ncblk, 3 + h->C));
+  CACK(allreduce(h, h->red, 3 + h->C));
+  LAUNCH(h, CA_KERNEL_OTHER,
+         hipLaunchKernelGGL(k_final_small, dim3(1), dim3(CA_TB), 0, h->stream, h->red, h->gene_part, h->ngblk, h->vchi, h->alpha_u,
+                            h->m_v, h->v_v, h->m_a, h->v_a, h->g_v, h->g_a, elbo_dst, h->terms_dev, h->G, h->C, h->K, 0, 0.f,
+                            (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, (const double*)nullptr, h->ncblk, h->red,
+                            h->vmm_part, h->vmm, h->D, h->dir_const));
+  h->look_valid = true;
+  h->look_slot = slotB;
+  return CA_OK;
+}
+
+// Train pass whose forward half was already done by fused_pass(.., slotB): backward sweep + Adam.
+int train_from_lookahead(ca_engine* h, int64_t slot) {
+  if (!h->look_valid || h->look_slot != slot) { h->err = "internal: no look-ahead forward for this eps slot"; return CA_ERR_STATE; }
+  h->look_valid = false;
+  return train_tail(h, h->eps_dev + slot * (int64_t)h->G, h->mu32B, 1, nullptr, true);
+}
+
+// monitor pass on eps slot m; with next >= 0 (and the fused path available) also the forward half of the train
+// pass on slot `next`, which train_pass() then completes
+int monitor_pass(ca_engine* h, int64_t m, int64_t next, double* elbo_dst) {
+  if (h->fused_ok && next >= 0) return fused_pass(h, m, next, elbo_dst);
+  return run_pass(h, m, CA_MODE_ELBO, 0, elbo_dst);
+}
+int train_pass(ca_engine* h, int64_t slot) {
+  if (h->look_valid && h->look_slot == slot) return train_from_lookahead(h, slot);
+  return run_pass(h, slot, CA_MODE_TRAIN, 1, nullptr);
 }
 
 int ensure_eps_cap(ca_engine* h, int64_t draws) {
@@ -509,6 +627,7 @@ int ensure_elbo_cap(ca_engine* h, int64_t n) {
 // put `n_draws` draws on the device: from the caller's stream, or generated (built-in Philox stream)
 int stage_eps(ca_engine* h, const float* eps_stream, int64_t have, int64_t need) {
   const int64_t per = (int64_t)h->S * h->G;
+  h->look_valid = false;   // the staged eps slots are about to change
   CACK(ensure_eps_cap(h, std::max<int64_t>(need, 1)));
   if (eps_stream) {
     if (have < need) {
@@ -689,6 +808,10 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   HIPCK(h, hipGetDeviceProperties(&prop, h->device));
   h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIPCK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  HIPCK(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+  HIPCK(h, hipEventCreateWithFlags(&h->ev_params, hipEventDisableTiming));
+  HIPCK(h, hipEventCreateWithFlags(&h->ev_ydone, hipEventDisableTiming));
+  if (const char* e = getenv("CA_ASYNC_Y")) h->async_y = atoi(e) != 0;
   HIPCK(h, hipHostMalloc((void**)&h->host_pinned, 64 * sizeof(double)));
   CACK(upload_y(h, p));
   const int G = h->G, C = h->C, K = h->K, P = h->P, S = h->S, D = h->D;
@@ -791,6 +914,14 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   // ---- pass buffers
   CACK(dalloc(h, &h->mu32, (int64_t)S * G));
   CACK(dalloc(h, &h->Mb, (int64_t)S * h->nchunk * G * CA_CW));
+  h->fused_ok = (S == 1 && C <= CA_CW) && !(getenv("CA_FUSED") && atoi(getenv("CA_FUSED")) == 0);
+  if (h->fused_ok) {
+    h->frow = (2 * C <= 8) ? 8 : 16;
+    CACK(dalloc(h, &h->Mb2, (int64_t)G * h->frow));
+    CACK(dalloc(h, &h->mu32B, G));
+    CACK(dalloc(h, &h->gene_partB, (int64_t)h->ngblk * (3 + K)));
+    CACK(dalloc(h, &h->Zpart2, (int64_t)h->gsplit * Nn * h->frow));
+  }
   CACK(dalloc(h, &h->vmm, 2 * std::max(D, 1)));
   CACK(dalloc(h, &h->vmm_part, (int64_t)h->ngblk * 2 * std::max(D, 1)));
   CACK(dalloc(h, &h->etamax2, Nn));
@@ -933,6 +1064,9 @@ int ca_destroy(ca_handle h) {
   if (!h) return CA_OK;
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
+  if (h->ev_params) hipEventDestroy(h->ev_params);
+  if (h->ev_ydone) hipEventDestroy(h->ev_ydone);
   if (h->comm) g_rccl.CommDestroy(h->comm);
   for (auto& e : h->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   for (void* q : h->allocs) hipFree(q);
@@ -950,7 +1084,7 @@ int ca_get_info(ca_handle h, ca_info* i) {
   memset(i, 0, sizeof(*i));
   i->N = h->N; i->G = h->G; i->C = h->C; i->K = h->K; i->P = h->P; i->S = h->S;
   i->y_storage = h->ystore; i->y_bytes_per_elem = h->ybytes; i->y_device_bytes = h->y_dev_bytes; i->device_bytes = h->dev_bytes;
-  i->gsplit = h->gsplit; i->csplit = h->csplit; i->n_cu = h->n_cu;
+  i->gsplit = h->gsplit; i->csplit = h->csplit; i->n_cu = h->n_cu; i->fused_sweep = h->fused_ok ? 1 : 0;
   return CA_OK;
 }
 
@@ -1048,7 +1182,7 @@ int ca_run(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_strea
   CACK(ensure_elbo_cap(h, 1 + (int64_t)max_iter));
   *n_elbo = 0;
   CACK(run_pass(h, 0, CA_MODE_GINIT, 0, nullptr));                      // :368-369
-  CACK(run_pass(h, 1, CA_MODE_ELBO, 0, h->elbo_dev));                   // :372
+  CACK(monitor_pass(h, 1, max_iter >= 1 ? 2 : -1, h->elbo_dev));        // :372 (+ forward half of the first train pass)
   double val;
   CACK(read_doubles(h, h->elbo_dev, &val, 1));
   trace[0] = val; *n_elbo = 1;
@@ -1056,8 +1190,8 @@ int ca_run(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_strea
   double diffs[10];
   for (double& d : diffs) d = 1e3;                                      // :379
   for (int i = 1; i <= max_iter; ++i) {
-    CACK(run_pass(h, 2 * (int64_t)i, CA_MODE_TRAIN, 1, nullptr));       // :401
-    CACK(run_pass(h, 2 * (int64_t)i + 1, CA_MODE_ELBO, 0, h->elbo_dev + i));   // :403
+    CACK(train_pass(h, 2 * (int64_t)i));                                // :401
+    CACK(monitor_pass(h, 2 * (int64_t)i + 1, i < max_iter ? 2 * (int64_t)i + 2 : -1, h->elbo_dev + i));   // :403
     double nv;
     CACK(read_doubles(h, h->elbo_dev + i, &nv, 1));
     const double diff = (nv - val) / std::fabs(val);
@@ -1080,8 +1214,8 @@ int ca_iterate(ca_handle h, int32_t n_iter, const float* eps_stream, int64_t n_d
   CACK(stage_eps(h, eps_stream, n_draws, 2 * (int64_t)n_iter));
   CACK(ensure_elbo_cap(h, std::max(1, n_iter)));
   for (int i = 0; i < n_iter; ++i) {
-    CACK(run_pass(h, 2 * (int64_t)i, CA_MODE_TRAIN, 1, nullptr));
-    CACK(run_pass(h, 2 * (int64_t)i + 1, CA_MODE_ELBO, 0, h->elbo_dev + i));
+    CACK(train_pass(h, 2 * (int64_t)i));
+    CACK(monitor_pass(h, 2 * (int64_t)i + 1, i + 1 < n_iter ? 2 * (int64_t)i + 2 : -1, h->elbo_dev + i));
   }
   if (last_elbo && n_iter > 0) return read_doubles(h, h->elbo_dev + (n_iter - 1), last_elbo, 1);
   HIPCK(h, hipStreamSynchronize(h->stream));

@@ -84,7 +84,8 @@ typedef struct ca_info {
   int64_t device_bytes;      /* total device allocation of this handle */
   int32_t gsplit, csplit;    /* gene / cell splits of the forward / backward sweeps */
   int32_t n_cu;
-  int32_t reserved[8];
+  int32_t fused_sweep;       /* 1: ca_run/ca_iterate fuse monitor pass i with the forward half of train pass i+1 */
+  int32_t reserved[7];
 } ca_info;
 
 /* kernel classes reported by ca_get_kernel_times() */

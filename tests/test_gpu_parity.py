@@ -174,7 +174,9 @@ def test_ca_run_equals_call_by_call_loop_and_builtin_stream():
         t_inject = b.run(EpsStream(4242, 1, b.G), 15, 1e-9)
         t_loop = np.array(run_vi_loop(c, EpsStream(4242, 1, c.G), 15, 1e-9))
         assert np.array_equal(t_builtin, t_inject)
-        assert np.array_equal(t_inject, t_loop)
+        # ca_run takes the fused two-eps sweep (monitor i + forward of train i+1), the call-by-call loop the plain
+        # passes: same arithmetic, fp64 contraction may differ in the last bit
+        np.testing.assert_allclose(t_inject, t_loop, rtol=1e-13)
         assert len(t_loop) == 16
         # early stop: a loose tolerance stops after the 10-long window fills (R/inference-tflow.R:379,414)
         d = HipEngine(**case)

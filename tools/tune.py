@@ -1,14 +1,14 @@
-"""Tuning sweep over the decomposition env overrides (CA_GSPLIT / CA_CSPLIT / CA_TR); prints per-kernel us/iter."""
+"""A/B sweep over engine env overrides; prints it/s and per-kernel us/iter (profiled warm-up)."""
 import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def run(env, extra=()):
     e = dict(os.environ); e.update({k: str(v) for k, v in env.items()})
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", *extra],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "5", "--no-cpu-baseline", *extra],
                          env=e, capture_output=True, text=True).stdout.strip().splitlines()[-1]
     d = json.loads(out)
     k = d["kernel_ms_per_iter_warmup"]
     print(env, extra, f"{d['value']:.0f} it/s", d["config"]["y_storage"], {n: round(v * 1e3) for n, v in k.items()}, flush=True)
 if __name__ == "__main__":
-    for tr in (32, 64, 128, 256):
-        run({"CA_TR": tr})
-    run({}, ("--y-storage", "u16"))
+    import ast
+    for arg in sys.argv[1:]:
+        run(ast.literal_eval(arg))
