@@ -291,6 +291,7 @@ void bwd_rg(int nc, dim3 grid, hipStream_t st, const BwdArgs& a) {
 }
 void launch_bwd(int RG, int nc, dim3 grid, hipStream_t st, const BwdArgs& a) {
   if (RG == 1) bwd_rg<1>(nc, grid, st, a);
+  else if (RG == 8) bwd_rg<8>(nc, grid, st, a);
   else bwd_rg<4>(nc, grid, st, a);
 }
 
@@ -832,7 +833,9 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   if (const char* e = getenv("CA_GSPLIT")) h->gsplit = std::max(std::max(1, atoi(e)), cdiv(G, 1024));   // tuning override
   h->gchunk = cdiv(G, h->gsplit);
   h->gsplit = cdiv(G, h->gchunk);
-  h->RG = G >= 1024 ? 4 : 1;
+  // genes per lane of the backward sweep: more genes amortise the per-cell wave reduction (tools/bwd_lab2.hip)
+  h->RG = G >= 1024 ? 4 : 1;   // RG = 8 measured equal in the engine (272 vs 276 us): kept selectable, not default
+  if (const char* e = getenv("CA_RG")) { const int r = atoi(e); if (r == 1 || r == 4 || r == 8) h->RG = r; }
   h->ntile = cdiv(G, 64 * h->RG);
   const int gblocks = cdiv(h->ntile, CA_TB / 64);
   h->csplit = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(target_blocks, gblocks), std::max<int64_t>(1, Nn / 64)));
