@@ -701,6 +701,128 @@ __global__ void __launch_bounds__(CA_TB) k_bwd(const float* __restrict__ coef /*
   }
 }
 
+// ------------------------------------------------------------------ backward sweep on the matrix cores
+// t_ng = sum_c coef_nc L_gc as ONE v_mfma_f32_16x16x32_bf16 per 16 genes x 16 cells: coef is split into three bf16
+// parts by the cell epilogue (K = 3 parts x 8 clones = 24 of 32), copy numbers that are bf16-exact (integers up to
+// 256: the normal case) make every product exact, accumulation is fp32 -- same result as the fp32 VALU chain up to
+// summation order (tools/bwd_lab3.hip: 4e-8 relative).  Rows = genes, columns = cells, so a lane owns ONE cell per
+// batch: d/dF needs a 4-lane-group sum per batch, the per-gene sums stay in-lane over the whole cell slice.
+// On gfx950 every VALU instruction costs 4 cycles per wave64, packed or not (tools/valu_lab.hip), hence the explicit
+// 2-wide math.  Used when D == 1, C <= 8 and L is bf16-exact; k_bwd is the general fallback.
+typedef __bf16 ca_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float ca_f32x4 __attribute__((ext_vector_type(4)));
+typedef float ca_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned short ca_bf16_rn(float f) {
+  unsigned u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+// three bf16 parts of a float: x = p1 + p2 + p3 up to 2^-24 relative
+__device__ __forceinline__ void ca_split3(float x, unsigned short& p1, unsigned short& p2, unsigned short& p3) {
+  p1 = ca_bf16_rn(x); x -= __uint_as_float((unsigned)p1 << 16);
+  p2 = ca_bf16_rn(x); x -= __uint_as_float((unsigned)p2 << 16);
+  p3 = ca_bf16_rn(x);
+}
+
+template <int TL>
+__global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __restrict__ cq /*[N16][4][8] bf16 parts of coef*/,
+                                                    const float* __restrict__ F /*[N16]*/, const float* __restrict__ etamax2 /*[N16]*/,
+                                                    const float* __restrict__ Lb /*[G][8]*/, const float* __restrict__ mu,
+                                                    const float* __restrict__ Vs, const float* __restrict__ V,
+                                                    float* __restrict__ gpart /*[csplit][G][S+1]*/, float* __restrict__ dFpart /*[nwt][N]*/,
+                                                    int64_t N, int G, int64_t cchunk, int S, int sidx, int first_s, int first) {
+  const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+  const int wtile = blockIdx.x * (CA_TB / 64) + (threadIdx.x >> 6);
+  const int gbase = wtile * TL * 16;
+  if (gbase >= G) return;
+  ca_bf16x8 Lf[TL];
+  ca_f32x2 vs[TL][2], mv[TL][2], accU[TL][2], accUF[TL][2];
+#pragma unroll
+  for (int m = 0; m < TL; ++m) {
+    {  // MFMA A operand: lane (row j, k-group q) holds L[gene gbase+16m+j][0..8), once per coef part (q < 3)
+      const int g = gbase + 16 * m + j;
+      const bool ok = g < G;
+      const int gg = ok ? g : G - 1;
+      unsigned short b[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) b[c] = (ok && q < 3) ? ca_bf16_rn(Lb[(int64_t)gg * CA_CW + c]) : 0;
+      const uint4 raw = {(unsigned)b[0] | ((unsigned)b[1] << 16), (unsigned)b[2] | ((unsigned)b[3] << 16),
+                         (unsigned)b[4] | ((unsigned)b[5] << 16), (unsigned)b[6] | ((unsigned)b[7] << 16)};
+      Lf[m] = __builtin_bit_cast(ca_bf16x8, raw);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {  // this lane's output rows: genes gbase + 16m + 4q + {2h, 2h+1}
+      float a[2], b[2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        const int g = gbase + 16 * m + 4 * q + 2 * h + x;
+        const bool ok = g < G;
+        const int gg = ok ? g : G - 1;
+        a[x] = ok ? Vs[gg] : 0.f;
+        b[x] = ok ? mu[gg] * V[gg] : 0.f;
+      }
+      vs[m][h] = (ca_f32x2){a[0], a[1]};
+      mv[m][h] = (ca_f32x2){b[0], b[1]};
+      accU[m][h] = (ca_f32x2){0.f, 0.f};
+      accUF[m][h] = (ca_f32x2){0.f, 0.f};
+    }
+  }
+  const int64_t n0 = (int64_t)blockIdx.y * cchunk;
+  const int64_t n1 = (n0 + cchunk < N) ? n0 + cchunk : N;
+  for (int64_t b0 = n0; b0 < n1; b0 += 16) {
+    // MFMA B operand: lane (column j, k-group q) holds part q of coef[cell b0+j][0..8): 16 bytes, 1 KiB per wave
+    const uint4 craw = *reinterpret_cast<const uint4*>(cq + ((b0 + j) * 4 + q) * 8);
+    const ca_bf16x8 Cf = __builtin_bit_cast(ca_bf16x8, craw);
+    const float fc = F[b0 + j], ec = etamax2[b0 + j];   // padded to a multiple of 16 cells
+    ca_f32x2 dF = {0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < TL; ++m) {
+      ca_f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Lf[m], Cf, t, 0, 0, 0);   // t[r]: gene gbase+16m+4q+r, cell b0+j
+      const ca_f32x2 t2[2] = {{t[0], t[1]}, {t[2], t[3]}};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const ca_f32x2 eta = vs[m][h] * fc - ec;
+        const ca_f32x2 ex = {__builtin_amdgcn_exp2f(eta.x), __builtin_amdgcn_exp2f(eta.y)};
+        const ca_f32x2 u = ex * t2[h];
+        accU[m][h] += u;
+        accUF[m][h] = u * fc + accUF[m][h];
+        dF = u * mv[m][h] + dF;
+      }
+    }
+    float d = dF.x + dF.y;
+    d += __shfl_xor(d, 16);
+    d += __shfl_xor(d, 32);
+    const int64_t n = b0 + j;
+    if (q == 0 && n < n1) {
+      float* p = dFpart + (int64_t)wtile * N + n;
+      *p = first ? d : (*p + d);
+    }
+  }
+  const int W_ = S + 1;
+#pragma unroll
+  for (int m = 0; m < TL; ++m)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      // sum over the 16 cell lanes of the row; lanes j = 0,1 write genes 2h, 2h+1 of the lane group
+      float a0 = accU[m][h].x, a1 = accU[m][h].y, b0_ = accUF[m][h].x, b1 = accUF[m][h].y;
+      a0 += ca_dpp_pull<0xB1, 0xF>(a0); a0 += ca_dpp_pull<0x4E, 0xF>(a0); a0 += ca_dpp_pull<0x141, 0xF>(a0); a0 += ca_dpp_pull<0x140, 0xF>(a0);
+      a1 += ca_dpp_pull<0xB1, 0xF>(a1); a1 += ca_dpp_pull<0x4E, 0xF>(a1); a1 += ca_dpp_pull<0x141, 0xF>(a1); a1 += ca_dpp_pull<0x140, 0xF>(a1);
+      b0_ += ca_dpp_pull<0xB1, 0xF>(b0_); b0_ += ca_dpp_pull<0x4E, 0xF>(b0_); b0_ += ca_dpp_pull<0x141, 0xF>(b0_); b0_ += ca_dpp_pull<0x140, 0xF>(b0_);
+      b1 += ca_dpp_pull<0xB1, 0xF>(b1); b1 += ca_dpp_pull<0x4E, 0xF>(b1); b1 += ca_dpp_pull<0x141, 0xF>(b1); b1 += ca_dpp_pull<0x140, 0xF>(b1);
+      if (j < 2) {
+        const int g = gbase + 16 * m + 4 * q + 2 * h + j;
+        if (g < G) {
+          float* gp = gpart + ((int64_t)blockIdx.y * G + g) * W_;
+          const float su = j ? a1 : a0, suf = mu[g] * (j ? b1 : b0_);
+          gp[sidx] = first_s ? su : gp[sidx] + su;
+          gp[S] = first ? suf : gp[S] + suf;
+        }
+      }
+    }
+}
+
 // ------------------------------------------------------------------ per-cell epilogue
 // Everything of R/inference-tflow.R:294-308,322,327,332-333,338-342 that is per cell, in fp64:
 // log-lik ll'_nc = A_nc - s_n mean_s log Z_snc, gamma = softmax(logits), the cell's ELBO
@@ -827,7 +949,8 @@ __global__ void __launch_bounds__(CA_TB) k_cell_par(const float* __restrict__ Zp
                                                     const float* __restrict__ YWpart, float* __restrict__ YW,
                                                     float* __restrict__ coef, float* __restrict__ dgl,
                                                     double* __restrict__ cell_part, int64_t N, int C, int S, int D, int K,
-                                                    int gsplit, int nchunk, int nseg, int mode) {
+                                                    int gsplit, int nchunk, int nseg, int mode,
+                                                    unsigned short* __restrict__ coefq, int64_t N16) {
   __shared__ double sm[CA_TB];
   __shared__ double la[64];
   constexpr int CPB = CA_TB / CP;  // cells per block
@@ -873,7 +996,16 @@ __global__ void __launch_bounds__(CA_TB) k_cell_par(const float* __restrict__ Zp
       double Z = 0.0;
       for (int sp = 0; sp < gsplit; ++sp) Z += (double)Zpart[((((int64_t)s * nchunk + ch) * gsplit + sp) * N + nn) * CA_CW + cc];
       lzsum += log(Z) + em;
-      if (mode == CA_MODE_TRAIN && ok) coef[(((int64_t)s * nchunk + ch) * N + nn) * CA_CW + cc] = (float)(-gam * sn / ((double)S * Z));
+      if (mode == CA_MODE_TRAIN && ok) {
+        const float cfv = (float)(-gam * sn / ((double)S * Z));
+        coef[(((int64_t)s * nchunk + ch) * N + nn) * CA_CW + cc] = cfv;
+        if (coefq) {   // three bf16 parts for the matrix-core backward sweep (nchunk == 1)
+          unsigned short p1, p2, p3;
+          ca_split3(cfv, p1, p2, p3);
+          unsigned short* qp = coefq + (((int64_t)s * N16 + nn) * 4) * 8 + cc;
+          qp[0] = p1; qp[8] = p2; qp[16] = p3;
+        }
+      }
     }
     const double Anc = A[nn * C + cc_];
     if (mode == CA_MODE_GINIT) {
@@ -935,7 +1067,7 @@ __global__ void __launch_bounds__(CA_TB) k_cell_fused(const float* __restrict__ 
                                                       const float* __restrict__ F, const float* __restrict__ YWpart,
                                                       float* __restrict__ YW, float* __restrict__ coef /*[N][8]*/,
                                                       float* __restrict__ dgl, double* __restrict__ cell_part, int64_t N, int C,
-                                                      int D, int K, int gsplit, int nseg) {
+                                                      int D, int K, int gsplit, int nseg, unsigned short* __restrict__ coefq) {
   __shared__ double sm[CA_TB];
   __shared__ double la[64];
   constexpr int CPB = CA_TB / CP;
@@ -984,7 +1116,16 @@ __global__ void __launch_bounds__(CA_TB) k_cell_fused(const float* __restrict__ 
     const double Anc = A[nn * C + cc];
     const double llpA = Anc - sn * (log(ZA) + em);
     const double llpB = Anc - sn * (log(ZB) + em);
-    if (ok) coef[nn * CA_CW + cc] = (float)(-gam * sn / ZB);
+    if (ok) {
+      const float cfv = (float)(-gam * sn / ZB);
+      coef[nn * CA_CW + cc] = cfv;
+      if (coefq) {
+        unsigned short p1, p2, p3;
+        ca_split3(cfv, p1, p2, p3);
+        unsigned short* qp = coefq + (nn * 4) * 8 + cc;
+        qp[0] = p1; qp[8] = p2; qp[16] = p3;
+      }
+    }
     const double fB = llpB + la[cc] - lg;
     const bool live = ok && gam != 0.0;
     const double fbarB = gsum(live ? gam * fB : 0.0);

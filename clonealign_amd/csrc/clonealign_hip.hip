@@ -115,6 +115,8 @@ struct ca_engine {
   // fused two-eps sweep (monitor pass of iteration i + forward half of train pass i+1, same parameters)
   bool fused_ok = false, look_valid = false; int64_t look_slot = 0; int frow = 8;
   float *Mb2 = nullptr, *mu32B = nullptr, *Zpart2 = nullptr; double* gene_partB = nullptr;
+  // matrix-core backward sweep (k_bwd_mfma): bf16 parts of coef, its own cell split
+  bool bwd_mfma = false; unsigned short* coefq = nullptr; int64_t N16 = 0, cchunk_m = 0; int csplit_m = 1, nwt = 0;
   uint64_t draw = 0;  // built-in stream position
   // ---- comm
   ca_nccl_comm comm = nullptr;
@@ -416,23 +418,35 @@ int setup_global_sums(ca_engine* h) {
 int train_tail(ca_engine* h, const float* eps, const float* mu32, int apply, double* elbo_dst, bool cell_sums_global) {
   const int N256 = cdiv(h->N, CA_TB);
   float lr_t = 0.f;
-  for (int s = 0; s < h->S; ++s)
-    for (int ch = 0; ch < h->nchunk; ++ch) {
-      BwdArgs a;
-      a.coef = h->coef + ((int64_t)s * h->nchunk + ch) * h->N * CA_CW;
-      a.F = h->F; a.em = h->etamax2;
-      a.Lb = h->Lb + (int64_t)ch * h->G * CA_CW;
-      a.mu = mu32 + (int64_t)s * h->G;
-      a.Vs = h->Vs; a.V = h->V; a.gpart = h->gpart; a.dFpart = h->dFpart;
-      a.N = h->N; a.G = h->G; a.cchunk = h->cchunk; a.D = h->D; a.S = h->S; a.sidx = s;
-      a.first_s = (ch == 0); a.first = (s == 0 && ch == 0);
-      const int nc = std::min(CA_CW, h->C - ch * CA_CW);
-      LAUNCH(h, CA_KERNEL_BWD, launch_bwd(h->RG, nc, dim3(cdiv(h->ntile, CA_TB / 64), h->csplit), h->stream, a));
-    }
   const int W_ = h->S + h->D;
-  LAUNCH(h, CA_KERNEL_OTHER,
-         hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->G * W_, 64)), dim3(1024), 0, h->stream, h->gpart,
-                            h->red + h->off_g, h->csplit, (int64_t)h->G * W_, h->G * W_));
+  if (h->bwd_mfma) {
+    constexpr int TL = 4;
+    for (int s = 0; s < h->S; ++s)
+      LAUNCH(h, CA_KERNEL_BWD,
+             hipLaunchKernelGGL((k_bwd_mfma<TL>), dim3(cdiv(h->nwt, CA_TB / 64), h->csplit_m), dim3(CA_TB), 0, h->stream,
+                                h->coefq + (int64_t)s * h->N16 * 32, h->F, h->etamax2, h->Lb, mu32 + (int64_t)s * h->G, h->Vs, h->V,
+                                h->gpart, h->dFpart, h->N, h->G, h->cchunk_m, h->S, s, 1, s == 0 ? 1 : 0));
+    LAUNCH(h, CA_KERNEL_OTHER,
+           hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->G * W_, 64)), dim3(1024), 0, h->stream, h->gpart,
+                              h->red + h->off_g, h->csplit_m, (int64_t)h->G * W_, h->G * W_));
+  } else {
+    for (int s = 0; s < h->S; ++s)
+      for (int ch = 0; ch < h->nchunk; ++ch) {
+        BwdArgs a;
+        a.coef = h->coef + ((int64_t)s * h->nchunk + ch) * h->N * CA_CW;
+        a.F = h->F; a.em = h->etamax2;
+        a.Lb = h->Lb + (int64_t)ch * h->G * CA_CW;
+        a.mu = mu32 + (int64_t)s * h->G;
+        a.Vs = h->Vs; a.V = h->V; a.gpart = h->gpart; a.dFpart = h->dFpart;
+        a.N = h->N; a.G = h->G; a.cchunk = h->cchunk; a.D = h->D; a.S = h->S; a.sidx = s;
+        a.first_s = (ch == 0); a.first = (s == 0 && ch == 0);
+        const int nc = std::min(CA_CW, h->C - ch * CA_CW);
+        LAUNCH(h, CA_KERNEL_BWD, launch_bwd(h->RG, nc, dim3(cdiv(h->ntile, CA_TB / 64), h->csplit), h->stream, a));
+      }
+    LAUNCH(h, CA_KERNEL_OTHER,
+           hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->G * W_, 64)), dim3(1024), 0, h->stream, h->gpart,
+                              h->red + h->off_g, h->csplit, (int64_t)h->G * W_, h->G * W_));
+  }
   if (cell_sums_global) CACK(allreduce(h, h->red + h->off_g, h->red_n - h->off_g));
   else CACK(allreduce(h, h->red, h->red_n));
   if (h->opt.world > 1 || h->comm || h->host_ar) h->ycache_valid = false;   // red_y now holds the GLOBAL sum
@@ -452,7 +466,7 @@ int train_tail(ca_engine* h, const float* eps, const float* mu32, int apply, dou
                             h->vmm_part, h->vmm, h->D, h->dir_const));
   LAUNCH(h, CA_KERNEL_OTHER,
          hipLaunchKernelGGL(k_adam_cell, dim3(N256), dim3(CA_TB), 0, h->stream, h->F, h->YW, h->dFpart, h->glogit, h->dgl, h->m_psi,
-                            h->v_psi, h->m_gl, h->v_gl, h->g_psi, h->N, h->C, h->D, h->K, h->ntile, apply, lr_t,
+                            h->v_psi, h->m_gl, h->v_gl, h->g_psi, h->N, h->C, h->D, h->K, h->bwd_mfma ? h->nwt : h->ntile, apply, lr_t,
                             (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, h->vmm, h->etamax2));
   if (apply) {
     h->b1p *= (float)h->opt.beta1;
@@ -504,7 +518,7 @@ int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_d
   LAUNCH(h, CA_KERNEL_CELL,                                                                                                   \
          hipLaunchKernelGGL((k_cell_par<CPV>), grid, dim3(CA_TB), 0, h->stream, h->Zpart, h->A, h->cn, h->s64, h->etamax2,    \
                             h->glogit, h->alpha_u, h->F, h->YWpart, h->YW, h->coef, h->dgl, h->cell_part, h->N, h->C, h->S,  \
-                            h->D, h->K, h->gsplit, h->nchunk, h->nseg + (h->n_ovf > 0 ? 1 : 0), mode))
+                            h->D, h->K, h->gsplit, h->nchunk, h->nseg + (h->n_ovf > 0 ? 1 : 0), mode, h->bwd_mfma ? h->coefq : nullptr, h->N16))
     switch (CP) {
       case 1: CA_CELL(1); break;
       case 2: CA_CELL(2); break;
@@ -559,7 +573,7 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst) {
   LAUNCH(h, CA_KERNEL_CELL,                                                                                                  \
          hipLaunchKernelGGL((k_cell_fused<CPV>), grid, dim3(CA_TB), 0, h->stream, h->Zpart2, h->frow, h->A, h->cn, h->s64,   \
                             h->etamax2, h->glogit, h->alpha_u, h->F, h->YWpart, h->YW, h->coef, h->dgl, h->cell_part, h->N,  \
-                            h->C, h->D, h->K, h->gsplit, h->nseg + (h->n_ovf > 0 ? 1 : 0)))
+                            h->C, h->D, h->K, h->gsplit, h->nseg + (h->n_ovf > 0 ? 1 : 0), h->bwd_mfma ? h->coefq : nullptr))
     switch (CP) {
       case 1: CA_CELLF(1); break;
       case 2: CA_CELLF(2); break;
@@ -881,7 +895,27 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   hipFree(logL_dev);
   if (extra_dev) hipFree(extra_dev);
   // ---- variables (:240-272)
-  CACK(dalloc(h, &h->F, Nn * std::max(D, 1)));
+  // matrix-core backward sweep: needs D == 1, one clone chunk and bf16-exact copy numbers (integers up to 256)
+  {
+    bool exact = true;
+    for (double v : Lrm) {
+      const float f = (float)v;
+      uint32_t u; memcpy(&u, &f, 4);
+      if ((double)f != v || (u & 0xFFFFu) != 0) { exact = false; break; }
+    }
+    h->bwd_mfma = exact && D == 1 && h->nchunk == 1 && !(getenv("CA_BWD_MFMA") && atoi(getenv("CA_BWD_MFMA")) == 0);
+    h->N16 = (Nn + 15) / 16 * 16;
+    if (h->bwd_mfma) {
+      h->nwt = cdiv(G, 4 * 16);
+      const int xb = cdiv(h->nwt, CA_TB / 64);
+      h->csplit_m = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(target_blocks, xb), std::max<int64_t>(1, Nn / 256)));
+      if (const char* e = getenv("CA_CSPLIT_M")) h->csplit_m = std::max(1, atoi(e));
+      h->cchunk_m = ((Nn + h->csplit_m - 1) / h->csplit_m + 15) / 16 * 16;
+      h->csplit_m = cdiv(Nn, h->cchunk_m);
+      CACK(dalloc(h, &h->coefq, (int64_t)S * h->N16 * 32));
+    }
+  }
+  CACK(dalloc(h, &h->F, h->N16 * std::max(D, 1)));
   CACK(dalloc(h, &h->m_psi, Nn * std::max(K, 1)));
   CACK(dalloc(h, &h->v_psi, Nn * std::max(K, 1)));
   CACK(dalloc(h, &h->g_psi, Nn * std::max(K, 1)));
@@ -927,14 +961,14 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   }
   CACK(dalloc(h, &h->vmm, 2 * std::max(D, 1)));
   CACK(dalloc(h, &h->vmm_part, (int64_t)h->ngblk * 2 * std::max(D, 1)));
-  CACK(dalloc(h, &h->etamax2, Nn));
+  CACK(dalloc(h, &h->etamax2, h->N16));
   CACK(dalloc(h, &h->gene_part, (int64_t)h->ngblk * (3 + K)));
   CACK(dalloc(h, &h->Zpart, (int64_t)S * h->gsplit * h->nchunk * Nn * CA_CW));
   CACK(dalloc(h, &h->coef, (int64_t)S * h->nchunk * Nn * CA_CW));
   CACK(dalloc(h, &h->scratch, Nn * C));
   CACK(dalloc(h, &h->cell_part, (int64_t)h->ncblk * (3 + C)));
-  CACK(dalloc(h, &h->gpart, (int64_t)h->csplit * G * (S + D)));
-  CACK(dalloc(h, &h->dFpart, (int64_t)h->ntile * Nn * std::max(D, 1)));
+  CACK(dalloc(h, &h->gpart, (int64_t)std::max(h->csplit, h->csplit_m) * G * (S + D)));
+  CACK(dalloc(h, &h->dFpart, (int64_t)std::max(h->ntile, h->nwt) * Nn * std::max(D, 1)));
   CACK(dalloc(h, &h->YWpart, (int64_t)(h->nseg + 1) * Nn * std::max(K, 1)));
   CACK(dalloc(h, &h->YTpart, (int64_t)(h->nrb + 1) * h->Gp * std::max(K, 1)));
   CACK(dalloc(h, &h->YW, Nn * std::max(K, 1)));

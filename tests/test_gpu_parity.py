@@ -224,3 +224,30 @@ def test_u8_storage_with_overflow_list(name):
             assert _rel(se[n], so[n]) < 1e-4, n
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("variant", ["mfma_default", "valu_forced", "non_integer_L"])
+def test_backward_sweep_variants_agree_with_oracle(variant, monkeypatch):
+    """k_bwd_mfma (bf16 x 3 split on the matrix cores; integer copy numbers, D == 1, C <= 8) and the fp32 VALU
+    fallback k_bwd (forced by env, or automatically when L is not bf16-exact) against the oracle."""
+    from clonealign_amd.engine import HipEngine
+    from oracle.fused_numpy import FusedModel
+    case = make_case(seed=77, N=700, G=1100, C=5, K=1)
+    if variant == "valu_forced":
+        monkeypatch.setenv("CA_BWD_MFMA", "0")
+    if variant == "non_integer_L":
+        case["L"] = case["L"] + 0.3
+    eng, ora = HipEngine(**case), FusedModel(**case, dtype="float32")
+    try:
+        st = perturbed_state({n: getattr(ora, n).shape for n in ora.VAR_NAMES})
+        for n, v in st.items():
+            setattr(ora, n, v.astype(ora.pdt))
+            eng.set(n, v)
+        eps = eps_for(1, ora.G, 12)
+        ge, ee = eng.gradients(eps)
+        go, eo = ora.gradients(eps)
+        assert abs(ee - eo) <= 2e-5 * abs(eo)
+        for n in ora.VAR_NAMES:
+            assert _rel(ge[n], go[n]) < 2e-5, (variant, n, _rel(ge[n], go[n]))
+    finally:
+        eng.close()
