@@ -425,6 +425,55 @@ __global__ void __launch_bounds__(CA_TB) k_gene_pre(const float* __restrict__ lo
   }
 }
 
+// Fused two-eps variant (S == 1, one clone chunk): both draws A (monitor pass) and B (next train pass) in one
+// launch; M row = [mu_A L (C cols) | mu_B L (C cols)], per-draw mu and gene partials kept apart.
+__global__ void __launch_bounds__(CA_TB) k_gene_pre_fused(const float* __restrict__ loc, const float* __restrict__ ls,
+                                                          const float* __restrict__ epsA, const float* __restrict__ epsB,
+                                                          const double* __restrict__ colsum, const float* __restrict__ Lb,
+                                                          const float* __restrict__ V, int D, int K, const double* __restrict__ YtX,
+                                                          float* __restrict__ muA, float* __restrict__ muB, float* __restrict__ Mb,
+                                                          double* __restrict__ gene_partA, double* __restrict__ gene_partB, int G,
+                                                          int mrow, int C) {
+  __shared__ double sm[CA_TB];
+  const int g = blockIdx.x * CA_TB + threadIdx.x;
+  const bool ok = g < G;
+  double t[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+  if (ok) {
+    const double l = (double)loc[g], lsd = (double)ls[g], sd = exp(lsd), cs = colsum[g];
+    double bx = 0.0;
+    for (int p = K; p < D; ++p) bx += (double)V[(int64_t)g * D + p] * YtX[(int64_t)g * (D - K) + (p - K)];
+    const float* lp = Lb + (int64_t)g * CA_CW;
+    for (int w = 0; w < 2; ++w) {
+      const double e = (double)(w ? epsB : epsA)[g];
+      const double x = l + sd * e;
+      const double mu = ca_softplus_d(x), lm = log(mu);
+      const float muf = (float)mu;
+      (w ? muB : muA)[g] = muf;
+      float* mp = Mb + (int64_t)g * mrow + w * C;
+      for (int c = 0; c < C; ++c) mp[c] = lp[c] * muf;
+      t[w][0] = cs * lm + bx;
+      t[w][1] = -0.5 * lm * lm - 0.5 * CA_LOG2PI;
+      t[w][2] = -0.5 * e * e - lsd - 0.5 * CA_LOG2PI + (mu - x);
+    }
+  }
+  const int W_ = 3 + K;
+  for (int w = 0; w < 2; ++w) {
+    double* gp = (w ? gene_partB : gene_partA) + (int64_t)blockIdx.x * W_;
+    for (int i = 0; i < 3; ++i) {
+      const double r = ca_block_sum(t[w][i], sm);
+      if (threadIdx.x == 0) gp[i] = r;
+    }
+  }
+  for (int k = 0; k < K; ++k) {
+    const double wv = ok ? (double)V[(int64_t)g * D + k] : 0.0;
+    const double wsum = ca_block_sum(wv * wv, sm);
+    if (threadIdx.x == 0) {
+      gene_partA[(int64_t)blockIdx.x * W_ + 3 + k] = wsum;
+      gene_partB[(int64_t)blockIdx.x * W_ + 3 + k] = wsum;
+    }
+  }
+}
+
 // Vs = V * log2(e) and per-block min/max of each column (for the per-cell exponent bound)
 __global__ void __launch_bounds__(CA_TB) k_vprep(const float* __restrict__ V, float* __restrict__ Vs,
                                                  float* __restrict__ vmm_part /*[nblk][2][D]*/, int G, int D) {
@@ -730,12 +779,14 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
                                                     const float* __restrict__ F /*[N16]*/, const float* __restrict__ etamax2 /*[N16]*/,
                                                     const float* __restrict__ Lb /*[G][8]*/, const float* __restrict__ mu,
                                                     const float* __restrict__ Vs, const float* __restrict__ V,
-                                                    float* __restrict__ gpart /*[csplit][G][S+1]*/, float* __restrict__ dFpart /*[nwt][N]*/,
+                                                    float* __restrict__ gpart /*[csplit][G][S+1]*/, float* __restrict__ dFpart /*[gridDim.x][N]*/,
                                                     int64_t N, int G, int64_t cchunk, int S, int sidx, int first_s, int first) {
+  extern __shared__ float ca_lds[];   // [4 waves][cchunk]: per-wave d/dF of the block's cell slice, summed at the end
   const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
-  const int wtile = blockIdx.x * (CA_TB / 64) + (threadIdx.x >> 6);
+  const int wv = threadIdx.x >> 6;
+  const int wtile = blockIdx.x * (CA_TB / 64) + wv;
   const int gbase = wtile * TL * 16;
-  if (gbase >= G) return;
+  const bool active = gbase < G;
   ca_bf16x8 Lf[TL];
   ca_f32x2 vs[TL][2], mv[TL][2], accU[TL][2], accUF[TL][2];
 #pragma unroll
@@ -770,7 +821,10 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
   }
   const int64_t n0 = (int64_t)blockIdx.y * cchunk;
   const int64_t n1 = (n0 + cchunk < N) ? n0 + cchunk : N;
-  for (int64_t b0 = n0; b0 < n1; b0 += 16) {
+  float* myd = ca_lds + (int64_t)wv * cchunk;
+  if (!active)
+    for (int64_t i = lane; i < n1 - n0; i += 64) myd[i] = 0.f;
+  for (int64_t b0 = n0; active && b0 < n1; b0 += 16) {
     // MFMA B operand: lane (column j, k-group q) holds part q of coef[cell b0+j][0..8): 16 bytes, 1 KiB per wave
     const uint4 craw = *reinterpret_cast<const uint4*>(cq + ((b0 + j) * 4 + q) * 8);
     const ca_bf16x8 Cf = __builtin_bit_cast(ca_bf16x8, craw);
@@ -795,11 +849,15 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
     d += __shfl_xor(d, 16);
     d += __shfl_xor(d, 32);
     const int64_t n = b0 + j;
-    if (q == 0 && n < n1) {
-      float* p = dFpart + (int64_t)wtile * N + n;
-      *p = first ? d : (*p + d);
-    }
+    if (q == 0 && n < n1) myd[n - n0] = d;
   }
+  __syncthreads();
+  for (int64_t i = threadIdx.x; i < n1 - n0; i += CA_TB) {
+    const float d = (ca_lds[i] + ca_lds[cchunk + i]) + (ca_lds[2 * cchunk + i] + ca_lds[3 * cchunk + i]);
+    float* p = dFpart + (int64_t)blockIdx.x * N + n0 + i;
+    *p = first ? d : (*p + d);
+  }
+  if (!active) return;
   const int W_ = S + 1;
 #pragma unroll
   for (int m = 0; m < TL; ++m)

@@ -423,7 +423,7 @@ int train_tail(ca_engine* h, const float* eps, const float* mu32, int apply, dou
     constexpr int TL = 4;
     for (int s = 0; s < h->S; ++s)
       LAUNCH(h, CA_KERNEL_BWD,
-             hipLaunchKernelGGL((k_bwd_mfma<TL>), dim3(cdiv(h->nwt, CA_TB / 64), h->csplit_m), dim3(CA_TB), 0, h->stream,
+             hipLaunchKernelGGL((k_bwd_mfma<TL>), dim3(cdiv(h->nwt, CA_TB / 64), h->csplit_m), dim3(CA_TB), (size_t)h->cchunk_m * 4 * sizeof(float), h->stream,
                                 h->coefq + (int64_t)s * h->N16 * 32, h->F, h->etamax2, h->Lb, mu32 + (int64_t)s * h->G, h->Vs, h->V,
                                 h->gpart, h->dFpart, h->N, h->G, h->cchunk_m, h->S, s, 1, s == 0 ? 1 : 0));
     LAUNCH(h, CA_KERNEL_OTHER,
@@ -466,7 +466,7 @@ int train_tail(ca_engine* h, const float* eps, const float* mu32, int apply, dou
                             h->vmm_part, h->vmm, h->D, h->dir_const));
   LAUNCH(h, CA_KERNEL_OTHER,
          hipLaunchKernelGGL(k_adam_cell, dim3(N256), dim3(CA_TB), 0, h->stream, h->F, h->YW, h->dFpart, h->glogit, h->dgl, h->m_psi,
-                            h->v_psi, h->m_gl, h->v_gl, h->g_psi, h->N, h->C, h->D, h->K, h->bwd_mfma ? h->nwt : h->ntile, apply, lr_t,
+                            h->v_psi, h->m_gl, h->v_gl, h->g_psi, h->N, h->C, h->D, h->K, h->bwd_mfma ? cdiv(h->nwt, CA_TB / 64) : h->ntile, apply, lr_t,
                             (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, h->vmm, h->etamax2));
   if (apply) {
     h->b1p *= (float)h->opt.beta1;
@@ -554,11 +554,8 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst) {
   const float* epsB = h->eps_dev + slotB * (int64_t)h->G;
   CACK(ensure_ycache(h));
   LAUNCH(h, CA_KERNEL_OTHER,
-         hipLaunchKernelGGL(k_gene_pre, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->loc, h->ls, epsA, h->colsum, h->Lb, h->V,
-                            h->D, h->K, h->YtX, h->mu32, h->Mb2, h->gene_part, h->G, 1, 1, h->frow, 0, h->C));
-  LAUNCH(h, CA_KERNEL_OTHER,
-         hipLaunchKernelGGL(k_gene_pre, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->loc, h->ls, epsB, h->colsum, h->Lb, h->V,
-                            h->D, h->K, h->YtX, h->mu32B, h->Mb2, h->gene_partB, h->G, 1, 1, h->frow, h->C, h->C));
+         hipLaunchKernelGGL(k_gene_pre_fused, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->loc, h->ls, epsA, epsB, h->colsum, h->Lb,
+                            h->V, h->D, h->K, h->YtX, h->mu32, h->mu32B, h->Mb2, h->gene_part, h->gene_partB, h->G, h->frow, h->C));
   LAUNCH(h, CA_KERNEL_FWD, launch_fwd_fused(h->C, h->D, dim3(cdiv(h->N, CA_TB * kFwdR), h->gsplit), h->stream, h->F, h->etamax2,
                                             h->Vs, h->Mb2, h->Zpart2, h->N, h->G, h->gchunk));
   if (h->y_pending) {
@@ -910,6 +907,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
       const int xb = cdiv(h->nwt, CA_TB / 64);
       h->csplit_m = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(target_blocks, xb), std::max<int64_t>(1, Nn / 256)));
       if (const char* e = getenv("CA_CSPLIT_M")) h->csplit_m = std::max(1, atoi(e));
+      h->csplit_m = (int)std::max<int64_t>(h->csplit_m, (Nn + 4079) / 4080);   // LDS: 4 waves x cchunk floats <= 64 KB
       h->cchunk_m = ((Nn + h->csplit_m - 1) / h->csplit_m + 15) / 16 * 16;
       h->csplit_m = cdiv(Nn, h->cchunk_m);
       CACK(dalloc(h, &h->coefq, (int64_t)S * h->N16 * 32));
