@@ -839,7 +839,9 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   const int target_blocks = 8 * h->n_cu;
   // one full round of resident blocks (8 x 256 threads per CU) when the cell blocks alone do not fill the chip
   const int nfb = cdiv(Nn, CA_TB * kFwdR);
-  h->gsplit = std::max(1, std::min(target_blocks / std::max(nfb, 1), std::max(1, G / 64)));
+  // enough blocks for ~one resident round, but never more than 16 gene slices: every slice adds an N x 16 float
+  // partial that the cell epilogue has to read back (at 12.5k cells 78 slices cost 2x the sweep itself)
+  h->gsplit = std::max(1, std::min(std::min(target_blocks / std::max(nfb, 1), 16), std::max(1, G / 64)));
   h->gsplit = std::max(h->gsplit, cdiv(G, 1024));      // LDS slice: at most 1024 genes x (8 + D) floats = 64 KB
   if (const char* e = getenv("CA_GSPLIT")) h->gsplit = std::max(std::max(1, atoi(e)), cdiv(G, 1024));   // tuning override
   h->gchunk = cdiv(G, h->gsplit);
@@ -856,7 +858,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   h->TR = 128;
   if (const char* e = getenv("CA_TR")) h->TR = std::max(1, atoi(e));   // tuning override
   h->nrb = cdiv(Nn, h->TR);
-  while (!getenv("CA_TR") && (int64_t)h->nrb * h->nseg < 8 * h->n_cu && h->TR > 16) { h->TR /= 2; h->nrb = cdiv(Nn, h->TR); }
+  while (!getenv("CA_TR") && (int64_t)h->nrb * h->nseg < 4 * h->n_cu && h->TR > 32) { h->TR /= 2; h->nrb = cdiv(Nn, h->TR); }
   // ---- constants
   std::vector<double> Lrm((size_t)G * C), logL((size_t)G * C);
   std::vector<float> Lb((size_t)h->nchunk * G * CA_CW, 0.f);

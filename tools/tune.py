@@ -3,12 +3,16 @@ import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def run(env, extra=()):
     e = dict(os.environ); e.update({k: str(v) for k, v in env.items()})
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "40", "--warmup", "5", "--no-cpu-baseline", *extra],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "5", "--no-cpu-baseline", *extra],
                          env=e, capture_output=True, text=True).stdout.strip().splitlines()[-1]
     d = json.loads(out)
     k = d["kernel_ms_per_iter_warmup"]
     print(env, extra, f"{d['value']:.0f} it/s", d["config"]["y_storage"], {n: round(v * 1e3) for n, v in k.items()}, flush=True)
 if __name__ == "__main__":
     import ast
+    extra = ()
     for arg in sys.argv[1:]:
-        run(ast.literal_eval(arg))
+        if arg.startswith("--"):
+            extra = tuple(arg.split("="))
+            continue
+        run(ast.literal_eval(arg), extra)
