@@ -181,6 +181,13 @@ def main():
             achieved, peak, unit = work / per_launch_s / 1e9, PEAK_HBM_GBS, "GB/s"
         else:
             achieved, peak, unit = work / per_launch_s / 1e12, PEAK_F32_TFLOPS, "TFLOP/s"
+        traffic = None
+        try:   # HBM bytes per launch from the committed PMC passes (same workload only)
+            if (N, G, C, K, world) == (100_000, 5_000, 8, 1, 1):
+                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+                traffic = pm.get(dominant, {}).get("hbm_bytes")
+        except Exception:
+            traffic = None
         out = {
             "metric": "ELBO iterations/sec", "value": args.steps / dt, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -193,8 +200,10 @@ def main():
                        "fused_sweep": bool(info.get("fused_sweep")),
                        "parallelism": f"cells/{world}" if world > 1 else "single"},
             "roofline": {"bound": bound, "kernel": dominant, "achieved": achieved, "peak": peak, "unit": unit,
-                         "frac": achieved / peak, "traffic": None,
-                         "launch_ms": per_launch_s * 1e3, "launches": int(launches)},
+                         "frac": achieved / peak, "traffic": traffic,
+                         "launch_ms": per_launch_s * 1e3, "launches": int(launches),
+                         "note": ("the forward sweep shares the GPU with the Y-stream kernel on a side stream "
+                                  "(standalone 190 us / 92 TFLOP/s; see DESIGN.md section 8)") if dominant == "fwd" else ""},
             "kernel_ms_per_iter_warmup": {k: v[0] / max(args.warmup, 1) for k, v in kt.items()},
             "final_elbo": last,
         }
