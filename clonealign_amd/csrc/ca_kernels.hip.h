@@ -945,12 +945,12 @@ __global__ void __launch_bounds__(CA_TB) k_cell(const float* __restrict__ Zpart 
       }
       const double llp = A[n * C + c] - sn * lzsum / (double)S;
       const double f = llp + la[c] - lg;
-      if (gam != 0.0) {
-        ee += gam * llp;
-        pr += gam * la[c];
+      ee += gam * llp;            // unguarded like :308 (0 * -inf = NaN for an impossible clone)
+      pr += gam * la[c];
+      if (gam != 0.0) {           // `tf$where(gamma == 0, 0, ...)` of :333
         q += gam * lg;
         fbar += gam * f;
-      }
+      } else if (!isfinite(llp)) fbar += gam * f;
       if (mode == CA_MODE_TRAIN) scratch[n * C + c] = f;
     }
     if (mode == CA_MODE_TRAIN) {
@@ -1075,10 +1075,15 @@ __global__ void __launch_bounds__(CA_TB) k_cell_par(const float* __restrict__ Zp
     }
     const double llp = Anc - sn * lzsum / (double)S;
     const double f = llp + la[cc_] - lg;
+    // Only the entropy term is guarded (`tf$where(gamma == 0, 0, ...)`, :333).  gamma * ll' is not (:308): an
+    // impossible clone (L = 0 where y > 0 => ll' = -inf, gamma = 0) gives 0 * -inf = NaN, the reference's
+    // "Initial elbo is NA".  For finite ll' a gamma that underflowed to 0 contributes exactly 0 either way.
     const bool live = ok && gam != 0.0;
-    const double fbar = gsum(live ? gam * f : 0.0);
-    if (mode == CA_MODE_TRAIN && ok) dgl[nn * C + cc_] = live ? (float)(gam * (f - fbar)) : 0.f;
-    if (live) { ee += gam * llp; pr += gam * la[cc_]; q += gam * lg; }
+    const double gf = (live || (ok && !isfinite(llp))) ? gam * f : 0.0;
+    const double fbar = gsum(gf);
+    if (mode == CA_MODE_TRAIN && ok) dgl[nn * C + cc_] = (float)(live || !isfinite(llp) ? gam * (f - fbar) : 0.0);
+    if (ok) { ee += gam * llp; pr += gam * la[cc_]; }
+    if (live) q += gam * lg;
     gsumc += gam;
     if (okn && c == 0) {
       ee += cn[nn];
@@ -1185,10 +1190,12 @@ __global__ void __launch_bounds__(CA_TB) k_cell_fused(const float* __restrict__ 
       }
     }
     const double fB = llpB + la[cc] - lg;
-    const bool live = ok && gam != 0.0;
-    const double fbarB = gsum(live ? gam * fB : 0.0);
-    if (ok) dgl[nn * C + cc] = live ? (float)(gam * (fB - fbarB)) : 0.f;
-    if (live) { ee += gam * llpA; pr += gam * la[cc]; q += gam * lg; }
+    const bool live = ok && gam != 0.0;   // see k_cell_par: only the entropy term is guarded against gamma == 0
+    const double gfB = (live || (ok && !isfinite(llpB))) ? gam * fB : 0.0;
+    const double fbarB = gsum(gfB);
+    if (ok) dgl[nn * C + cc] = (float)(live || !isfinite(llpB) ? gam * (fB - fbarB) : 0.0);
+    if (ok) { ee += gam * llpA; pr += gam * la[cc]; }
+    if (live) q += gam * lg;
     gsumc += gam;
     if (okn && c == 0) {
       ee += cn[nn];

@@ -1,0 +1,185 @@
+"""GPU parity at the benchmark shapes: cfg-2 against the C oracle, and size-independent properties of the
+engine at the full 100k x 5k x 8 configuration (BASELINE.json configs[1..2])."""
+import numpy as np
+import pytest
+
+from tests._cases import eps_for
+
+pytestmark = pytest.mark.gpu
+
+
+def _synth(N, G, C, seed=20243, device_counts=False):
+    import torch
+    from clonealign_amd import synth
+    from clonealign_amd.hostprep import safe_inverse_softplus
+    Yd, aux = synth.make_problem_torch(N, G, C, seed=seed, device="cuda:0")
+    rm = Yd.sum(1, keepdim=True).to(torch.float64) / G
+    col = torch.zeros(G, dtype=torch.float64, device=Yd.device)
+    for b0 in range(0, N, 8192):
+        col += (Yd[b0:b0 + 8192].to(torch.float64) / rm[b0:b0 + 8192]).sum(0)
+    loc0 = safe_inverse_softplus(np.maximum(col.cpu().numpy() / N, 1e-6))
+    psi0 = np.random.default_rng(seed + 1).normal(size=(N, 1))
+    return Yd, aux["L"], psi0, loc0
+
+
+def test_cfg2_iterations_match_c_oracle():
+    """10k cells x 2k genes x 4 clones: gamma init + 4 iterations, engine vs the C/OpenMP float64 oracle."""
+    from clonealign_amd.engine import HipEngine
+    from oracle.c_port import CPortModel
+    N, G, C = 10_000, 2_000, 4
+    Yd, L, psi0, loc0 = _synth(N, G, C)
+    Y = Yd.cpu().numpy().astype(np.float64)
+    eng = HipEngine(Y, L, psi0, loc0, 1)
+    ora = CPortModel(Y, L, psi0, loc0, 1, dtype="float32")
+    try:
+        eng.gamma_init(eps_for(1, G, 0)); ora.gamma_init(eps_for(1, G, 0))
+        for i in range(1, 5):
+            eng.step(eps_for(1, G, 2 * i)); ora.step(eps_for(1, G, 2 * i))
+            a, b = eng.elbo(eps_for(1, G, 2 * i + 1)), ora.elbo(eps_for(1, G, 2 * i + 1))
+            assert abs(a - b) <= 1e-6 * abs(b), (i, a, b)
+        se, so = eng.get_state(), ora.get_state()
+        for n in ("W", "v", "psi", "alpha_unconstr", "loc", "ls", "gamma_logits"):
+            err = np.abs(se[n] - so[n]).max() / max(np.abs(so[n]).max(), 1e-30)
+            assert err < 1e-4, (n, err)
+        # clone calls: identical wherever the oracle is not within 1e-3 of the 0.95 threshold
+        pe, po = eng.get("clone_probs"), ora.get_params()["clone_probs"]
+        robust = np.abs(po.max(1) - 0.95) > 1e-3
+        assert np.array_equal(pe.argmax(1)[robust], po.argmax(1)[robust])
+        assert np.array_equal((pe.max(1) >= 0.95)[robust], (po.max(1) >= 0.95)[robust])
+    finally:
+        eng.close(); ora.close()
+
+
+@pytest.fixture(scope="module")
+def full():
+    """The bench workload: 100k x 5k x 8 generated on the GPU, handed over as a device pointer."""
+    from clonealign_amd.engine import HipEngine
+    N, G, C = 100_000, 5_000, 8
+    Yd, L, psi0, loc0 = _synth(N, G, C)
+
+    def make(rows=None, **kw):
+        lo, hi = rows or (0, N)
+        sub = Yd[lo:hi].contiguous()
+        e = HipEngine(None, L, psi0[lo:hi], loc0, 1, y_device_ptr=sub.data_ptr(), y_device_dtype=np.int32,
+                      shape=(hi - lo, G), **kw)
+        del sub
+        return e
+    return dict(N=N, G=G, C=C, make=make, Yd=Yd)
+
+
+def _drive(eng, G, n_iter):
+    eng.gamma_init(eps_for(1, G, 0))
+    tr = [eng.elbo(eps_for(1, G, 1))]
+    for i in range(1, n_iter + 1):
+        eng.step(eps_for(1, G, 2 * i))
+        tr.append(eng.elbo(eps_for(1, G, 2 * i + 1)))
+    return np.array(tr)
+
+
+def test_full_size_run_is_bit_reproducible_and_storage_is_u8(full):
+    a, b = full["make"](), full["make"]()
+    try:
+        assert a.info()["y_storage_name"] == "u8"
+        s = a.get("s")
+        assert np.array_equal(s, full["Yd"].sum(1).cpu().numpy().astype(np.float64))   # exact row sums incl. overflow list
+        ta, tb = _drive(a, full["G"], 3), _drive(b, full["G"], 3)
+        assert np.array_equal(ta, tb)
+        assert np.all(np.isfinite(ta)) and ta[-1] > ta[0]
+        # ca_iterate (fused two-eps sweeps, side stream) replays to the same bits
+        eps = np.stack([eps_for(1, full["G"], 100 + i) for i in range(8)])
+        ea, eb = a.iterate(4, eps), b.iterate(4, eps)
+        assert ea == eb
+    finally:
+        a.close(); b.close()
+
+
+def test_full_size_gradient_matches_finite_difference_of_the_elbo(full):
+    """Backward sweep vs forward sweep at 100k x 5k x 8: directional derivative along the gradient itself."""
+    eng = full["make"]()
+    try:
+        G = full["G"]
+        eng.gamma_init(eps_for(1, G, 0))
+        eng.step(eps_for(1, G, 2)); eng.step(eps_for(1, G, 4))
+        eps = eps_for(1, G, 9)
+        g, e0 = eng.gradients(eps)
+        for name, h in (("loc", 2e-4), ("W", 2e-4), ("psi", 2e-4)):
+            d = g[name] / np.abs(g[name]).max()
+            x0 = eng.get(name)
+            eng.set(name, x0 + h * d); ep = eng.elbo(eps)
+            eng.set(name, x0 - h * d); em = eng.elbo(eps)
+            eng.set(name, x0)
+            fd = (ep - em) / (2 * h)
+            an = float((g[name] * d).sum())
+            assert abs(fd - an) <= 2e-2 * abs(an), (name, fd, an)
+    finally:
+        eng.close()
+
+
+def test_full_size_two_shards_equal_one_engine(full):
+    """Cell sharding at full size (two handles on one GPU joined by the host all-reduce hook)."""
+    import threading
+    from clonealign_amd.sharding import cell_range
+    from tests.test_gpu_sharding import _HostAllreduce
+    N, G = full["N"], full["G"]
+    ref = full["make"]()
+    tr_ref = _drive(ref, G, 2)
+    st_ref = {n: ref.get(n) for n in ("loc", "W", "alpha_unconstr")}
+    ref.close()
+    ar = _HostAllreduce(2)
+    out = [None, None]
+
+    def worker(r):
+        eng = full["make"](rows=cell_range(N, r, 2), rank=r, world=2, host_allreduce=ar.make(r))
+        out[r] = (_drive(eng, G, 2), {n: eng.get(n) for n in ("loc", "W", "alpha_unconstr")})
+        eng.close()
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    for r in range(2):
+        assert np.abs(out[r][0] - tr_ref).max() <= 1e-7 * np.abs(tr_ref).max()
+        for n, v in st_ref.items():
+            assert np.abs(out[r][1][n] - v).max() <= 1e-4 * max(np.abs(v).max(), 1e-30), n
+            assert np.array_equal(out[r][1][n], out[0][1][n])
+
+
+def test_edge_shapes_and_invalid_inputs():
+    from clonealign_amd.engine import EngineError, HipEngine
+    from oracle.fused_numpy import FusedModel
+    rng = np.random.default_rng(3)
+    shapes = [dict(N=1, G=7, C=2, K=1), dict(N=5, G=1, C=3, K=1), dict(N=33, G=65, C=1, K=1),
+              dict(N=257, G=1025, C=8, K=1), dict(N=17, G=40, C=3, K=0), dict(N=64, G=64, C=8, K=2)]
+    for kw in shapes:
+        N, G, C, K = kw["N"], kw["G"], kw["C"], kw["K"]
+        L = rng.integers(1, 5, size=(G, C)).astype(np.float64)
+        Y = rng.poisson(2.0, size=(N, G)).astype(np.float64)
+        Y[:, 0] += 1
+        if G > 3:
+            Y[:, 3] = 0                                   # an all-zero gene is legal at the C ABI
+        case = dict(Y=Y, L=L, psi0=rng.normal(size=(N, K)), loc0=rng.normal(size=G) + 1, K=K, S=1)
+        eng, ora = HipEngine(**case), FusedModel(**case, dtype="float32")
+        try:
+            e = eps_for(1, G, 1)
+            eng.gamma_init(e); ora.gamma_init(e)
+            a, b = eng.elbo(e), ora.elbo(e)
+            assert abs(a - b) <= 1e-5 * max(abs(b), 1.0), (kw, a, b)
+            ge, _ = eng.gradients(e)
+            go, _ = ora.gradients(e)
+            for n in ora.VAR_NAMES:
+                if go[n].size:   # absolute floor: in these degenerate shapes several gradients vanish identically
+                    assert np.abs(ge[n] - go[n]).max() <= 2e-5 * max(np.abs(go[n]).max(), 1.0), (kw, n)
+            eng.step(e)          # (Adam turns noise-level gradients into lr-sized steps, so only finiteness is checked after)
+            assert np.isfinite(eng.elbo(e))
+        finally:
+            eng.close()
+    base = dict(L=np.ones((4, 2)), psi0=np.zeros((3, 1)), loc0=np.ones(4), K=1)
+    for bad in (np.full((3, 4), -1.0), np.full((3, 4), np.nan), np.full((3, 4), 2.0 ** 25 + 1.0)):   # negative, NaN, not exactly representable on the device
+        with pytest.raises(EngineError):
+            HipEngine(Y=bad, **base)
+    with pytest.raises(EngineError):
+        HipEngine(Y=np.full((3, 4), 300.5), y_storage="u8", **base)
+    zero_L = HipEngine(Y=np.ones((3, 4)), L=np.array([[1, 0], [1, 1], [2, 1], [1, 2.0]]), psi0=np.zeros((3, 1)), loc0=np.ones(4), K=1)
+    try:   # L = 0 with y > 0: -inf log-lik -> NaN ELBO, the reference's "Initial elbo is NA"
+        with pytest.raises(FloatingPointError, match="Initial elbo is NA"):
+            zero_L.run(None, 2, 1e-6)
+    finally:
+        zero_L.close()
