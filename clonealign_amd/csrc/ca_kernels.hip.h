@@ -86,6 +86,16 @@ template <> struct YVec<uint8_t> {
   }
 };
 
+// value transforms of the count stream (template parameter TF of k_ypass / runtime tf of the overflow kernels):
+//   0 identity (the VI loop), 1 log2(y + 1), 2 log2(y + 1)^2   (PCA initialisation, R/inference-tflow.R:204)
+template <int TF>
+__device__ __forceinline__ float ca_ytf(float y) {
+  if (TF == 0) return y;
+  const float x = __builtin_amdgcn_logf(y + 1.f);   // v_log_f32 = log2
+  return TF == 1 ? x : x * x;
+}
+__device__ __forceinline__ float ca_ytf_rt(float y, int tf) { return tf == 0 ? ca_ytf<0>(y) : tf == 1 ? ca_ytf<1>(y) : ca_ytf<2>(y); }
+
 // ------------------------------------------------------------------ upload / conversion
 // src is N x G in either layout and any ca_dtype; dst is row-major [N][Gp] of YT, zero padded.
 template <typename ST, typename YT>
@@ -132,12 +142,16 @@ __global__ void k_convert_y_u8ovf(const ST* __restrict__ src, uint8_t* __restric
 
 // overflow-list contributions to the Y stream products, one thread per cell (CSR order) / per gene (CSC order)
 __global__ void k_ovf_rows(const int64_t* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
-                           const float* __restrict__ V, int Dstride, float* __restrict__ YWextra /*[N][K]*/, int64_t N, int K) {
+                           const float* __restrict__ V, int Dstride, float* __restrict__ YWextra /*[N][K]*/, int64_t N, int K,
+                           int tf) {
   const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
   for (int k = 0; k < K; ++k) {
     float a = 0.f;
-    for (int64_t e = rowptr[n]; e < rowptr[n + 1]; ++e) a = fmaf(val[e], V[(int64_t)col[e] * Dstride + k], a);
+    for (int64_t e = rowptr[n]; e < rowptr[n + 1]; ++e) {
+      const float dv = tf == 0 ? val[e] : ca_ytf_rt(255.f + val[e], tf) - ca_ytf_rt(255.f, tf);   // T(y) - T(255)
+      a = fmaf(dv, V[(int64_t)col[e] * Dstride + k], a);
+    }
     YWextra[n * K + k] = a;
   }
 }
@@ -146,14 +160,17 @@ __global__ void k_ovf_rows(const int64_t* __restrict__ rowptr, const int* __rest
 // (k_ovf_chunks), then one thread per gene adds its chunk sums in order (k_ovf_cols).
 __global__ void __launch_bounds__(CA_TB) k_ovf_chunks(const int64_t* __restrict__ chunk_start, const int* __restrict__ row,
                                                       const float* __restrict__ val, const float* __restrict__ F, int Dstride,
-                                                      float* __restrict__ csum /*[nchunk][K]*/, int nchunk, int K) {
+                                                      float* __restrict__ csum /*[nchunk][K]*/, int nchunk, int K, int tf) {
   const int lane = threadIdx.x & 63;
   const int ch = blockIdx.x * (CA_TB / 64) + (threadIdx.x >> 6);
   if (ch >= nchunk) return;
   const int64_t e0 = chunk_start[ch], e1 = chunk_start[ch + 1];
   for (int k = 0; k < K; ++k) {
     float a = 0.f;
-    for (int64_t e = e0 + lane; e < e1; e += 64) a = fmaf(val[e], F[(int64_t)row[e] * Dstride + k], a);
+    for (int64_t e = e0 + lane; e < e1; e += 64) {
+      const float dv = tf == 0 ? val[e] : ca_ytf_rt(255.f + val[e], tf) - ca_ytf_rt(255.f, tf);
+      a = fmaf(dv, F[(int64_t)row[e] * Dstride + k], a);
+    }
     const float tot = ca_wave_sum_lane63(a);
     if (lane == 63) csum[(int64_t)ch * K + k] = tot;
   }
@@ -251,7 +268,7 @@ __global__ void __launch_bounds__(CA_TB) k_prep_cells(const YT* __restrict__ Y, 
 // in registers, per-row partial reduced across the wave with DPP.
 //   YWpart[seg][n][k]  = sum over the strip's genes of y_ng W_gk          (summed over seg later)
 //   YTpart[rb][g][k]   = sum over the strip's cells of y_ng psi_nk        (summed over rb later)
-template <typename YT, int KK>
+template <typename YT, int KK, int TF = 0>
 __global__ void __launch_bounds__(CA_TB) k_ypass(const YT* __restrict__ Y, const float* __restrict__ F, int Dstride,
                                                  const float* __restrict__ V, int koff, float* __restrict__ YWpart,
                                                  float* __restrict__ YTpart, int64_t N, int G, int Gp, int nseg,
@@ -303,6 +320,10 @@ __global__ void __launch_bounds__(CA_TB) k_ypass(const YT* __restrict__ Y, const
       if (r < r1) {   // wave-uniform
         float y[VEC];
         YVec<YT>::decode(raw[u], y);
+        if (TF != 0) {
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) y[j] = ca_ytf<TF>(y[j]);
+        }
         float p[KK], ps[KK];
 #pragma unroll
         for (int k = 0; k < KK; ++k) {
@@ -365,6 +386,17 @@ __global__ void __launch_bounds__(1024) k_colsum(const float* __restrict__ part,
     __syncthreads();
   }
   if (ty == 0 && c < cols) out[c] = sm[0][tx];
+}
+
+// PCA init: scores of one pass, A[n][k] = sum_seg YWpart[seg][n][k] - c[k]
+__global__ void k_pca_rows(const float* __restrict__ YWpart, const double* __restrict__ c, float* __restrict__ A, int64_t N, int q,
+                           int nseg) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * q) return;
+  const int k = (int)(i % q);
+  double a = 0.0;
+  for (int sg = 0; sg < nseg; ++sg) a += (double)YWpart[(int64_t)sg * N * q + i];
+  A[i] = (float)(a - c[k]);
 }
 
 // ------------------------------------------------------------------ per-gene preparation of one pass

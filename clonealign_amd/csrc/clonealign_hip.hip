@@ -367,9 +367,9 @@ int ensure_ycache(ca_engine* h) {
   }
   if (h->n_ovf > 0) {   // entries above 255: one extra "segment" of YW and one extra "row block" of Y^T psi
     LAUNCH(h, CA_KERNEL_YPASS, hipLaunchKernelGGL(k_ovf_rows, dim3(cdiv(h->N, CA_TB)), dim3(CA_TB), 0, h->stream, h->ovf_rowptr, h->ovf_col,
-                                                  h->ovf_val, h->V, h->D, h->YWpart + (int64_t)h->nseg * h->N * h->K, h->N, h->K));
+                                                  h->ovf_val, h->V, h->D, h->YWpart + (int64_t)h->nseg * h->N * h->K, h->N, h->K, 0));
     LAUNCH(h, CA_KERNEL_YPASS, hipLaunchKernelGGL(k_ovf_chunks, dim3(cdiv(h->n_ovf_chunk, CA_TB / 64)), dim3(CA_TB), 0, h->stream,
-                                                  h->ovf_chunk_start, h->ovf_row2, h->ovf_val2, h->F, h->D, h->ovf_csum, h->n_ovf_chunk, h->K));
+                                                  h->ovf_chunk_start, h->ovf_row2, h->ovf_val2, h->F, h->D, h->ovf_csum, h->n_ovf_chunk, h->K, 0));
     LAUNCH(h, CA_KERNEL_YPASS, hipLaunchKernelGGL(k_ovf_cols, dim3(cdiv(h->Gp, CA_TB)), dim3(CA_TB), 0, h->stream, h->ovf_col_chunk_ptr,
                                                   h->ovf_csum, h->YTpart + (int64_t)h->nrb * h->Gp * h->K, h->Gp, h->G, h->K));
   }
@@ -378,6 +378,101 @@ int ensure_ycache(ca_engine* h) {
                                                 h->YTpart, h->red + h->off_y, h->nrb + (h->n_ovf > 0 ? 1 : 0), (int64_t)h->Gp * h->K, h->Gp * h->K));
   h->ycache_valid = true;
   return CA_OK;
+}
+
+// Transformed pass over Y with explicit factor buffers (PCA init): row products Y'.Vp -> YWp, column products Y'^T.Fp -> YTp
+template <typename YT, int TF>
+void ypass_tf_t(ca_engine* h, const float* Fp, const float* Vp, int q, int koff, int kk, float* YWp, float* YTp, dim3 grid) {
+  const YT* Y = (const YT*)h->Y;
+#define CA_YPT(KK)                                                                                                    \
+  hipLaunchKernelGGL((k_ypass<YT, KK, TF>), grid, dim3(CA_TB), 0, h->stream, Y, Fp, q, Vp, koff, YWp, YTp, h->N, h->G, \
+                     h->Gp, h->nseg, h->nrb, h->TR, q)
+  switch (kk) {
+    case 1: CA_YPT(1); break;
+    case 2: CA_YPT(2); break;
+    case 3: CA_YPT(3); break;
+    default: CA_YPT(4); break;
+  }
+#undef CA_YPT
+}
+template <int TF>
+int ypass_tf(ca_engine* h, const float* Fp, const float* Vp, int q, float* YWp, float* YTp, float* csum) {
+  const int64_t tasks = (int64_t)h->nrb * h->nseg;
+  dim3 grid(cdiv(tasks, CA_TB / 64));
+  for (int koff = 0; koff < q; koff += 4) {
+    const int kk = std::min(4, q - koff);
+    if (h->ystore == CA_YSTORE_U8) ypass_tf_t<uint8_t, TF>(h, Fp, Vp, q, koff, kk, YWp, YTp, grid);
+    else if (h->ystore == CA_YSTORE_U16) ypass_tf_t<uint16_t, TF>(h, Fp, Vp, q, koff, kk, YWp, YTp, grid);
+    else ypass_tf_t<float, TF>(h, Fp, Vp, q, koff, kk, YWp, YTp, grid);
+    HIPCK(h, hipGetLastError());
+  }
+  if (h->n_ovf > 0) {
+    hipLaunchKernelGGL(k_ovf_rows, dim3(cdiv(h->N, CA_TB)), dim3(CA_TB), 0, h->stream, h->ovf_rowptr, h->ovf_col, h->ovf_val, Vp, q,
+                       YWp + (int64_t)h->nseg * h->N * q, h->N, q, TF);
+    hipLaunchKernelGGL(k_ovf_chunks, dim3(cdiv(h->n_ovf_chunk, CA_TB / 64)), dim3(CA_TB), 0, h->stream, h->ovf_chunk_start, h->ovf_row2,
+                       h->ovf_val2, Fp, q, csum, h->n_ovf_chunk, q, TF);
+    hipLaunchKernelGGL(k_ovf_cols, dim3(cdiv(h->Gp, CA_TB)), dim3(CA_TB), 0, h->stream, h->ovf_col_chunk_ptr, csum,
+                       YTp + (int64_t)h->nrb * h->Gp * q, h->Gp, h->G, q);
+    HIPCK(h, hipGetLastError());
+  }
+  return CA_OK;
+}
+
+// modified Gram-Schmidt (twice) on the columns of Q [G][q] (row-major), double precision
+void orthonormalize(std::vector<double>& Q, int G, int q) {
+  for (int rep = 0; rep < 2; ++rep)
+    for (int k = 0; k < q; ++k) {
+      for (int j = 0; j < k; ++j) {
+        double d = 0.0;
+        for (int g = 0; g < G; ++g) d += Q[(size_t)g * q + k] * Q[(size_t)g * q + j];
+        for (int g = 0; g < G; ++g) Q[(size_t)g * q + k] -= d * Q[(size_t)g * q + j];
+      }
+      double nn = 0.0;
+      for (int g = 0; g < G; ++g) nn += Q[(size_t)g * q + k] * Q[(size_t)g * q + k];
+      nn = std::sqrt(nn);
+      if (nn < 1e-300) nn = 1.0;
+      for (int g = 0; g < G; ++g) Q[(size_t)g * q + k] /= nn;
+    }
+}
+// cyclic Jacobi eigen-decomposition of a symmetric q x q matrix; eigenvalues descending, eigenvectors in columns of W
+void sym_eig(std::vector<double> T, int q, std::vector<double>& lam, std::vector<double>& W) {
+  W.assign((size_t)q * q, 0.0);
+  for (int i = 0; i < q; ++i) W[(size_t)i * q + i] = 1.0;
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0;
+    for (int i = 0; i < q; ++i) for (int j = i + 1; j < q; ++j) off += T[(size_t)i * q + j] * T[(size_t)i * q + j];
+    if (off < 1e-30) break;
+    for (int p_ = 0; p_ < q; ++p_)
+      for (int r = p_ + 1; r < q; ++r) {
+        const double apr = T[(size_t)p_ * q + r];
+        if (std::fabs(apr) < 1e-300) continue;
+        const double th = (T[(size_t)r * q + r] - T[(size_t)p_ * q + p_]) / (2.0 * apr);
+        const double t = (th >= 0 ? 1.0 : -1.0) / (std::fabs(th) + std::sqrt(th * th + 1.0));
+        const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+        for (int k = 0; k < q; ++k) {
+          const double a = T[(size_t)k * q + p_], b = T[(size_t)k * q + r];
+          T[(size_t)k * q + p_] = c * a - sn * b; T[(size_t)k * q + r] = sn * a + c * b;
+        }
+        for (int k = 0; k < q; ++k) {
+          const double a = T[(size_t)p_ * q + k], b = T[(size_t)r * q + k];
+          T[(size_t)p_ * q + k] = c * a - sn * b; T[(size_t)r * q + k] = sn * a + c * b;
+        }
+        for (int k = 0; k < q; ++k) {
+          const double a = W[(size_t)k * q + p_], b = W[(size_t)k * q + r];
+          W[(size_t)k * q + p_] = c * a - sn * b; W[(size_t)k * q + r] = sn * a + c * b;
+        }
+      }
+  }
+  std::vector<int> idx(q);
+  for (int i = 0; i < q; ++i) idx[i] = i;
+  std::sort(idx.begin(), idx.end(), [&](int a, int b) { return T[(size_t)a * q + a] > T[(size_t)b * q + b]; });
+  lam.resize(q);
+  std::vector<double> W2((size_t)q * q);
+  for (int j = 0; j < q; ++j) {
+    lam[j] = T[(size_t)idx[j] * q + idx[j]];
+    for (int k = 0; k < q; ++k) W2[(size_t)k * q + j] = W[(size_t)k * q + idx[j]];
+  }
+  W = W2;
 }
 
 int allreduce(ca_engine* h, double* buf, int64_t n) {
@@ -1277,6 +1372,158 @@ int ca_final_elbo(ca_handle h, int32_t n_rep, const float* eps_stream, int64_t n
   if (mean) *mean = m;
   if (sd) *sd = n_rep > 1 ? std::sqrt(ss / (n_rep - 1)) : NAN;
   return CA_OK;
+}
+
+// host-side all-reduce of a small double vector through the engine's transport (device scratch round trip)
+static int allreduce_host_vec(ca_engine* h, std::vector<double>& v, double* dev_scratch) {
+  if (h->opt.world <= 1 && !h->comm && !h->host_ar) return CA_OK;
+  HIPCK(h, hipMemcpyAsync(dev_scratch, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  CACK(allreduce(h, dev_scratch, (int64_t)v.size()));
+  HIPCK(h, hipMemcpyAsync(v.data(), dev_scratch, v.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIPCK(h, hipStreamSynchronize(h->stream));
+  return CA_OK;
+}
+
+int ca_init_psi_pca(ca_handle h, const double* noise, int32_t n_iter, uint64_t seed, double* pcs_out) {
+  if (!h) return CA_ERR_INVALID;
+  if (h->K == 0) return CA_OK;
+  HIPCK(h, hipSetDevice(h->device));
+  if (h->y_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ydone, 0)); h->y_pending = false; }
+  const int64_t N = h->N; const int G = h->G, Gp = h->Gp, K = h->K;
+  const int q = std::min(std::min(K + 4, 12), G);
+  if (n_iter <= 0) n_iter = 40;
+  float *Fp = nullptr, *Vp = nullptr, *YWp = nullptr, *YTp = nullptr, *csum = nullptr; double *ytd = nullptr, *cdev = nullptr;
+  auto cleanup = [&]() { hipFree(Fp); hipFree(Vp); hipFree(YWp); hipFree(YTp); hipFree(csum); hipFree(ytd); hipFree(cdev); };
+#define PCK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->err = std::string(#call) + ": " + hipGetErrorString(e_); cleanup(); return CA_ERR_HIP; } } while (0)
+  PCK(hipMalloc((void**)&Fp, (size_t)N * q * sizeof(float)));
+  PCK(hipMalloc((void**)&Vp, (size_t)Gp * q * sizeof(float)));
+  PCK(hipMalloc((void**)&YWp, (size_t)(h->nseg + 1) * N * q * sizeof(float)));
+  PCK(hipMalloc((void**)&YTp, (size_t)(h->nrb + 1) * Gp * q * sizeof(float)));
+  PCK(hipMalloc((void**)&csum, (size_t)std::max(h->n_ovf_chunk, 1) * q * sizeof(float)));
+  PCK(hipMalloc((void**)&ytd, (size_t)std::max<int64_t>((int64_t)Gp * q, 2 * (int64_t)Gp + q * q + 4 * q + 8) * sizeof(double)));
+  PCK(hipMalloc((void**)&cdev, (size_t)q * sizeof(double)));
+  const int nrb_tot = h->nrb + (h->n_ovf > 0 ? 1 : 0), nseg_tot = h->nseg + (h->n_ovf > 0 ? 1 : 0);
+  auto colsum_to_host = [&](int qq, std::vector<double>& out) -> int {
+    hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)Gp * qq, 64)), dim3(1024), 0, h->stream, YTp, ytd, nrb_tot, (int64_t)Gp * qq, Gp * qq);
+    out.resize((size_t)G * qq);
+    HIPCK(h, hipMemcpyAsync(out.data(), ytd, (size_t)G * qq * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return CA_OK;
+  };
+  int rc = CA_OK;
+  // ---- column means and standard deviations of x = log2(y + 1)
+  std::vector<double> sx, sxx, ntot(1, (double)N);
+  {
+    std::vector<float> ones((size_t)N, 1.f);
+    PCK(hipMemcpyAsync(Fp, ones.data(), (size_t)N * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    PCK(hipMemsetAsync(Vp, 0, (size_t)Gp * sizeof(float), h->stream));
+    if ((rc = ypass_tf<1>(h, Fp, Vp, 1, YWp, YTp, csum)) != CA_OK || (rc = colsum_to_host(1, sx)) != CA_OK) { cleanup(); return rc; }
+    if ((rc = ypass_tf<2>(h, Fp, Vp, 1, YWp, YTp, csum)) != CA_OK || (rc = colsum_to_host(1, sxx)) != CA_OK) { cleanup(); return rc; }
+    std::vector<double> pack((size_t)2 * G + 1);
+    for (int g = 0; g < G; ++g) { pack[g] = sx[g]; pack[G + g] = sxx[g]; }
+    pack[2 * G] = (double)N;
+    if ((rc = allreduce_host_vec(h, pack, ytd)) != CA_OK) { cleanup(); return rc; }
+    for (int g = 0; g < G; ++g) { sx[g] = pack[g]; sxx[g] = pack[G + g]; }
+    ntot[0] = pack[2 * G];
+  }
+  const double Nt = ntot[0];
+  std::vector<double> mean(G), sd(G);
+  for (int g = 0; g < G; ++g) {
+    mean[g] = sx[g] / Nt;
+    const double var = (sxx[g] - Nt * mean[g] * mean[g]) / (Nt - 1.0);
+    sd[g] = std::sqrt(var);
+    if (!(var > 1e-12 * std::max(1.0, mean[g] * mean[g]))) {
+      h->err = "cannot rescale a constant/zero column to unit variance";   // prcomp(scale. = TRUE) on a constant gene
+      cleanup();
+      return CA_ERR_INVALID;
+    }
+  }
+  // ---- blocked subspace iteration on Xs^T Xs
+  std::vector<double> Q((size_t)G * q);
+  {
+    std::vector<float> r((size_t)G * q);
+    ca_philox::normal_draw(seed ^ 0x9E3779B97F4A7C15ull, 0, (int64_t)G * q, r.data());
+    for (size_t i = 0; i < Q.size(); ++i) Q[i] = r[i];
+    orthonormalize(Q, G, q);
+  }
+  std::vector<float> vp((size_t)Gp * q, 0.f);
+  std::vector<double> c(q), B;
+  auto rows_pass = [&]() -> int {   // A = Xs Q  ->  Fp
+    for (int k = 0; k < q; ++k) c[k] = 0.0;
+    for (int g = 0; g < G; ++g)
+      for (int k = 0; k < q; ++k) {
+        const double w = Q[(size_t)g * q + k] / sd[g];
+        vp[(size_t)g * q + k] = (float)w;
+        c[k] += mean[g] * w;
+      }
+    HIPCK(h, hipMemcpyAsync(Vp, vp.data(), vp.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipMemcpyAsync(cdev, c.data(), q * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CACK(ypass_tf<1>(h, Fp, Vp, q, YWp, YTp, csum));
+    hipLaunchKernelGGL(k_pca_rows, dim3(cdiv(N * q, CA_TB)), dim3(CA_TB), 0, h->stream, YWp, cdev, Fp, N, q, nseg_tot);
+    HIPCK(h, hipGetLastError());
+    return CA_OK;
+  };
+  for (int it = 0; it < n_iter && rc == CA_OK; ++it) {
+    if ((rc = rows_pass()) != CA_OK) break;
+    if ((rc = ypass_tf<1>(h, Fp, Vp, q, YWp, YTp, csum)) != CA_OK) break;   // B = Xs^T A (column products)
+    if ((rc = colsum_to_host(q, B)) != CA_OK) break;
+    if ((rc = allreduce_host_vec(h, B, ytd)) != CA_OK) break;
+    for (int g = 0; g < G; ++g)
+      for (int k = 0; k < q; ++k) Q[(size_t)g * q + k] = B[(size_t)g * q + k] / sd[g];
+    orthonormalize(Q, G, q);
+  }
+  if (rc != CA_OK) { cleanup(); return rc; }
+  // ---- Rayleigh-Ritz on the converged subspace
+  if ((rc = rows_pass()) != CA_OK) { cleanup(); return rc; }
+  std::vector<float> Af((size_t)N * q);
+  PCK(hipMemcpyAsync(Af.data(), Fp, Af.size() * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+  PCK(hipStreamSynchronize(h->stream));
+  std::vector<double> T((size_t)q * q, 0.0);
+  for (int64_t n = 0; n < N; ++n)
+    for (int a = 0; a < q; ++a)
+      for (int b = a; b < q; ++b) T[(size_t)a * q + b] += (double)Af[(size_t)n * q + a] * (double)Af[(size_t)n * q + b];
+  for (int a = 0; a < q; ++a) for (int b = 0; b < a; ++b) T[(size_t)a * q + b] = T[(size_t)b * q + a];
+  if ((rc = allreduce_host_vec(h, T, ytd)) != CA_OK) { cleanup(); return rc; }
+  std::vector<double> lam, W;
+  sym_eig(T, q, lam, W);
+  std::vector<double> sgn(K, 1.0);
+  for (int k = 0; k < K; ++k) {   // sign: loading of largest magnitude positive
+    double best = 0.0, val = 1.0;
+    for (int g = 0; g < G; ++g) {
+      double vgk = 0.0;
+      for (int j = 0; j < q; ++j) vgk += Q[(size_t)g * q + j] * W[(size_t)j * q + k];
+      if (std::fabs(vgk) > best) { best = std::fabs(vgk); val = vgk; }
+    }
+    sgn[k] = val < 0 ? -1.0 : 1.0;
+  }
+  std::vector<double> sc((size_t)N * K), stat((size_t)2 * K, 0.0);
+  for (int64_t n = 0; n < N; ++n)
+    for (int k = 0; k < K; ++k) {
+      double v = 0.0;
+      for (int j = 0; j < q; ++j) v += (double)Af[(size_t)n * q + j] * W[(size_t)j * q + k];
+      v *= sgn[k];
+      sc[(size_t)n * K + k] = v;
+      stat[k] += v; stat[K + k] += v * v;
+    }
+  if ((rc = allreduce_host_vec(h, stat, ytd)) != CA_OK) { cleanup(); return rc; }
+  std::vector<float> Fh;
+  if ((rc = download_f(h, Fh, h->F, N * std::max(h->D, 1))) != CA_OK) { cleanup(); return rc; }
+  for (int k = 0; k < K; ++k) {
+    const double mu_ = stat[k] / Nt, sdk = std::sqrt((stat[K + k] - Nt * mu_ * mu_) / (Nt - 1.0));   // scale(pcs)
+    for (int64_t n = 0; n < N; ++n) {
+      double v = (sc[(size_t)n * K + k] - mu_) / sdk;
+      if (noise) v += noise[hidx(h->layout, n, k, N, K)];
+      if (pcs_out) pcs_out[hidx(h->layout, n, k, N, K)] = v;
+      Fh[(size_t)n * h->D + k] = (float)v;
+    }
+  }
+  rc = upload_f(h, h->F, Fh);
+  cleanup();
+  if (rc != CA_OK) return rc;
+  CACK(refresh_derived(h));
+  HIPCK(h, hipStreamSynchronize(h->stream));
+  return CA_OK;
+#undef PCK
 }
 
 static int get_generic(ca_handle h, const char* name, double* out, bool grad) {

@@ -23,7 +23,7 @@ KERNEL_NAMES = ("fwd", "bwd", "ypass", "cell", "other")
 EXPORTS = (
     "ca_abi_version", "ca_default_options", "ca_create", "ca_destroy", "ca_last_error", "ca_get_info",
     "ca_synchronize", "ca_comm_unique_id", "ca_comm_init", "ca_set_host_allreduce", "ca_gamma_init", "ca_elbo", "ca_elbo_terms",
-    "ca_step", "ca_gradients", "ca_run", "ca_iterate", "ca_final_elbo", "ca_get_param", "ca_set_param",
+    "ca_step", "ca_gradients", "ca_run", "ca_iterate", "ca_final_elbo", "ca_init_psi_pca", "ca_get_param", "ca_set_param",
     "ca_get_gradient", "ca_get_kernel_times", "ca_reset_kernel_times", "ca_set_profile", "ca_eps_draw",
 )
 
@@ -87,6 +87,7 @@ def load_library(path=None):
     lib.ca_iterate.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_double)]
     lib.ca_final_elbo.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
                                   C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.ca_init_psi_pca.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p]
     lib.ca_get_param.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
     lib.ca_set_param.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
     lib.ca_get_gradient.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
@@ -274,6 +275,15 @@ class HipEngine:
         vals = np.zeros(int(n_rep), dtype=np.float64)
         self._ck(self.lib.ca_final_elbo(self.h, int(n_rep), p, n, vals.ctypes.data_as(C.c_void_p), None, None))
         return vals
+
+    def pca_init(self, noise=None, n_iter=40, seed=0):
+        """psi <- scale(first K PCs of standardised log2(Y+1)) + noise, computed on the device (R/inference-tflow.R:204-208)."""
+        out = np.zeros((self.N, self.K), dtype=np.float64)
+        nz = None if noise is None else np.ascontiguousarray(np.asarray(noise, dtype=np.float64).reshape(self.N, self.K))
+        if self.K > 0:
+            self._ck(self.lib.ca_init_psi_pca(self.h, None if nz is None else nz.ctypes.data_as(C.c_void_p), int(n_iter),
+                                              int(seed) & 0xFFFFFFFFFFFFFFFF, out.ctypes.data_as(C.c_void_p)))
+        return out
 
     def synchronize(self):
         self._ck(self.lib.ca_synchronize(self.h))

@@ -78,13 +78,15 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
                     fix_alpha=False, dtype="float32", saturate=True, saturation_threshold=6,
                     K=1, mc_samples=1, verbose=True, initial_shrink=5, data_init_mu=True,
                     *, gene_names=None, seed=None, engine=None, engine_opts=None,
-                    psi_noise=None, eps_stream=None):
+                    psi_noise=None, eps_stream=None, psi_init="auto"):
     """EM/VI inference on the MI355X engine.  Arguments as R/inference-tflow.R:71-89.
 
     Keyword-only extras (no reference counterpart): ``seed`` (replaces R's ``set.seed``
     state feeding ``rnorm`` at :208 and ``get_next_seed`` at :269), ``gene_names``
     (``colnames(Y_dat)``), ``engine`` (engine class; default the HIP engine),
-    ``psi_noise`` / ``eps_stream`` to inject the two noise sources explicitly.
+    ``psi_noise`` / ``eps_stream`` to inject the two noise sources explicitly, ``psi_init`` in
+    {"auto", "host", "device"}: where the PCA initialisation of :204-208 runs ("auto": on the device, by
+    subspace iteration over the resident count matrix, once N*G exceeds 4e6; exact SVD on the host below that).
     """
     log = (lambda m: print(m)) if verbose else (lambda m: None)
     log("Constructing HIP engine")                               # :102-104 ("Constructing tensorflow graph")
@@ -137,7 +139,11 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
     # initialisation (:204-235)
     if psi_noise is None:
         psi_noise = rng.normal(0.0, 0.05, size=(K, N)).T if K > 0 else np.zeros((N, 0))  # column-major fill
-    pcs = hostprep.pca_init(Y_dat, K, psi_noise)
+    Engine = engine if engine is not None else _default_engine_factory()
+    if psi_init not in ("auto", "host", "device"):
+        raise ValueError("psi_init must be 'auto', 'host' or 'device'")
+    device_pca = K > 0 and hasattr(Engine, "pca_init") and (psi_init == "device" or (psi_init == "auto" and N * G > 4_000_000))
+    pcs = np.zeros((N, K)) if device_pca else hostprep.pca_init(Y_dat, K, psi_noise)
     s_init = Y_dat.sum(1)
     if np.any(s_init == 0):
         raise ValueError("Some cells have no counts mapping")          # :212-214
@@ -148,10 +154,13 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
         eps_seed = int(rng.integers(1, 2**31 - 1))                      # get_next_seed(), :49-51
         eps_stream = EpsStream(eps_seed, S, G)
 
-    Engine = engine if engine is not None else _default_engine_factory()
     eng = Engine(Y_dat, L_dat, pcs, loc0, K, S, X=x, extra_loglik=extra,
                  learning_rate=learning_rate, **(engine_opts or {}))
     try:
+        if device_pca:
+            if np.any(np.asarray(Y_dat).std(0) == 0):    # prcomp(scale = TRUE) refuses constant genes
+                raise ValueError("cannot rescale a constant/zero column to unit variance")
+            eng.pca_init(psi_noise, seed=int(rng.integers(0, 2**31 - 1)))
         log("Optimizing ELBO")
         if hasattr(eng, "run"):
             elbos = eng.run(eps_stream, max_iter, rel_tol)

@@ -144,6 +144,13 @@ int ca_iterate(ca_handle h, int32_t n_iter, const float* eps_stream, int64_t n_d
 int ca_final_elbo(ca_handle h, int32_t n_rep, const float* eps_stream, int64_t n_draws, double* values,
                   double* mean, double* sd);
 
+/* psi initialisation on the device (R/inference-tflow.R:204-208): the first K principal components of the standardised
+ * log2(Y + 1) matrix (prcomp(center = TRUE, scale = TRUE)), each scaled to unit variance (scale()), plus `noise`
+ * (N x K in the problem's layout, the reference's rnorm(.., 0, 0.05), or NULL).  Blocked subspace iteration on the resident
+ * count matrix (two passes over Y per iteration, K + 4 vectors); component signs are fixed by making the loading of largest
+ * magnitude positive (prcomp's own signs are LAPACK's and arbitrary).  Overwrites psi; pcs_out (N x K) may be NULL. */
+int ca_init_psi_pca(ca_handle h, const double* noise, int32_t n_iter, uint64_t seed, double* pcs_out);
+
 /* Fetch (:424-434).  name in {"mu","clone_probs","s","alpha","beta","psi","W","chi"} (the
  * reference's ml_params) or a raw variable {"loc","ls","gamma_logits","alpha_unconstr","v"}.
  * Output is float64 in the problem's layout; sizes: mu/loc/ls G, clone_probs/gamma_logits

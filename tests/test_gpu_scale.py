@@ -183,3 +183,59 @@ def test_edge_shapes_and_invalid_inputs():
             zero_L.run(None, 2, 1e-6)
     finally:
         zero_L.close()
+
+
+def test_device_pca_init_matches_prcomp_up_to_sign():
+    """psi initialisation on the device vs the host SVD (hostprep.pca_init = prcomp + scale)."""
+    from clonealign_amd import hostprep
+    from clonealign_amd.engine import HipEngine
+    from tests import _golden
+    Y, L, *_ = _golden.example()
+    for K in (1, 2):
+        eng = HipEngine(Y, L, np.zeros((200, K)), np.ones(100), K)
+        try:
+            dev = eng.pca_init(None, n_iter=60, seed=1)
+            ref = hostprep.pca_init(Y, K, None)
+            for k in range(K):
+                err = min(np.abs(dev[:, k] - ref[:, k]).max(), np.abs(dev[:, k] + ref[:, k]).max())
+                assert err < 2e-3, (K, k, err)      # fp32 streaming sums + v_log_f32 vs float64 SVD
+            np.testing.assert_allclose(dev.std(0, ddof=1), 1.0, rtol=1e-6)
+            np.testing.assert_allclose(eng.get("psi"), dev, rtol=0, atol=1e-6)
+        finally:
+            eng.close()
+    # counts above 255 (overflow list) and a larger matrix: compare with the host subspace iteration
+    rng = np.random.default_rng(5)
+    Yb = rng.poisson(rng.lognormal(0, 1.5, size=600)[None, :] * rng.lognormal(0, 0.4, size=(3000, 1))).astype(np.float64)
+    Yb[:, 0] += 1 + rng.integers(0, 3, size=3000)
+    Yb[::7, 5] += 400
+    Lb = rng.integers(1, 5, size=(600, 3)).astype(np.float64)
+    eng = HipEngine(Yb, Lb, np.zeros((3000, 1)), np.ones(600), 1)
+    try:
+        assert eng.info()["y_storage_name"] == "u8"
+        dev = eng.pca_init(None, n_iter=60, seed=2)[:, 0]
+        ref = hostprep.pca_init(Yb, 1, None)[:, 0]
+        assert min(np.abs(dev - ref).max(), np.abs(dev + ref).max()) < 5e-3
+        with pytest.raises(Exception):
+            Yc = Yb.copy(); Yc[:, 9] = 3.0
+            e2 = HipEngine(Yc, Lb, np.zeros((3000, 1)), np.ones(600), 1)
+            try:
+                e2.pca_init(None)
+            finally:
+                e2.close()
+    finally:
+        eng.close()
+
+
+def test_clonealign_end_to_end_with_device_pca():
+    import clonealign_amd as ca
+    from tests import _golden
+    Y, L, clones, *_ = _golden.example()
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = ca.clonealign(Y, L, max_iter=20, verbose=False, seed=3, clone_names=clones, engine_opts=None)
+        from clonealign_amd.inference import inference_tflow
+        b = inference_tflow(Y, L, max_iter=20, rel_tol=1e-6, verbose=False, seed=3, K=1, psi_init="device")
+    assert len(b["convergence_info"]["elbo"]) == 21 and np.isfinite(b["convergence_info"]["final_elbo"])
+    # same data, same seeds, host vs device PCA init: ELBO after 20 iterations agrees to MC noise
+    assert abs(a["convergence_info"]["final_elbo"] - b["convergence_info"]["final_elbo"]) < 60.0
