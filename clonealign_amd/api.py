@@ -78,6 +78,29 @@ def compute_correlations(Y, L, clones, clone_names):
     return out
 
 
+def correlations_from_sums(T, Syy, L, clone_counts):
+    """Pearson r per gene from the device-side sums (ca_clone_gene_sums): x = copy number of the assigned clone,
+    y = counts, over assigned cells.  Equals compute_correlations() (R's scale() does not change r)."""
+    T = np.asarray(T, dtype=np.float64)
+    L = np.asarray(L, dtype=np.float64)
+    nc = np.asarray(clone_counts, dtype=np.float64)
+    n = nc.sum()
+    out = np.full(T.shape[0], np.nan)
+    if n < 2:
+        return out
+    Sx, Sxx = L @ nc, (L ** 2) @ nc
+    Sy, Sxy = T.sum(1), (L * T).sum(1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        vx = n * Sxx - Sx ** 2
+        vy = n * np.asarray(Syy, dtype=np.float64) - Sy ** 2
+        den = np.sqrt(vx * vy)
+        r = (n * Sxy - Sx * Sy) / den
+    # constant x or y (R: NA with a warning); guard against round-off making a zero variance slightly positive
+    ok = (vx > 1e-9 * np.maximum(n * Sxx, 1.0)) & (vy > 1e-9 * np.maximum(n * np.asarray(Syy), 1.0))
+    out[ok] = r[ok]
+    return out
+
+
 def _parse_expression(gene_expression_data):
     """R/clonealign.R:207-222.  Returns (Y[cells,genes], gene_names or None)."""
     g = gene_expression_data
@@ -139,19 +162,34 @@ def clonealign(gene_expression_data, copy_number_data, max_iter=200, rel_tol=1e-
     if gene_names is None:
         gene_names = _default_gene_names(G)
     # NB the reference forwards ``ref = cov`` (R/clonealign.R:271); kept for drop-in behaviour
+    def _post(eng, rlist):
+        # device-side sums for compute_correlations: no second pass over Y on the host
+        if not hasattr(eng, "clone_gene_sums"):
+            return None
+        labels = clone_assignment(rlist["clone_probs"], clone_names, clone_call_probability)
+        lut = {c: i for i, c in enumerate(clone_names)}
+        idx = np.array([lut.get(c, -1) for c in labels], dtype=np.int32)
+        T, Syy = eng.clone_gene_sums(idx)
+        return dict(T=T, Syy=Syy, counts=np.bincount(idx[idx >= 0], minlength=C))
+
     res = inference_tflow(Y, L, max_iter=max_iter, rel_tol=rel_tol, learning_rate=learning_rate,
                           gene_filter_threshold=gene_filter_threshold, x=x,
                           clone_allele=clone_allele, cov=cov, ref=cov, fix_alpha=fix_alpha,
                           dtype=dtype, saturate=saturate, saturation_threshold=saturation_threshold,
                           K=K, mc_samples=mc_samples, verbose=verbose, initial_shrink=initial_shrink,
                           data_init_mu=data_init_mu, gene_names=gene_names, seed=seed,
-                          engine=engine, engine_opts=engine_opts)
+                          engine=engine, engine_opts=engine_opts, post=_post)
     res = ClonealignFit(res)
     res["clone"] = clone_assignment(res["ml_params"]["clone_probs"], clone_names,
                                     clone_call_probability)          # :283
     res["clone_names"] = list(clone_names)                           # colnames(clone_probs), :286
-    keep = np.array([g in set(res["retained_genes"]) for g in gene_names])
-    res["correlations"] = compute_correlations(Y[:, keep], L[keep, :], res["clone"], clone_names)  # :292-294
+    keepset = set(res["retained_genes"])
+    keep = np.array([g in keepset for g in gene_names])
+    post = res.pop("post", None)
+    if post is not None:
+        res["correlations"] = correlations_from_sums(post["T"], post["Syy"], L[keep, :], post["counts"])   # :292-294
+    else:
+        res["correlations"] = compute_correlations(Y[:, keep], L[keep, :], res["clone"], clone_names)      # :292-294
     cor = res["correlations"]
     if np.any(~np.isnan(cor)):
         if np.nanquantile(cor, 0.25) < 0:                            # :296-300

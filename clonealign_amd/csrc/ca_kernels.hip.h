@@ -87,14 +87,18 @@ template <> struct YVec<uint8_t> {
 };
 
 // value transforms of the count stream (template parameter TF of k_ypass / runtime tf of the overflow kernels):
-//   0 identity (the VI loop), 1 log2(y + 1), 2 log2(y + 1)^2   (PCA initialisation, R/inference-tflow.R:204)
+//   0 identity (the VI loop), 1 log2(y + 1), 2 log2(y + 1)^2   (PCA initialisation, R/inference-tflow.R:204),
+//   3 y^2 (post-hoc gene/copy-number correlations, R/clonealign.R:318-334)
 template <int TF>
 __device__ __forceinline__ float ca_ytf(float y) {
   if (TF == 0) return y;
+  if (TF == 3) return y * y;
   const float x = __builtin_amdgcn_logf(y + 1.f);   // v_log_f32 = log2
   return TF == 1 ? x : x * x;
 }
-__device__ __forceinline__ float ca_ytf_rt(float y, int tf) { return tf == 0 ? ca_ytf<0>(y) : tf == 1 ? ca_ytf<1>(y) : ca_ytf<2>(y); }
+__device__ __forceinline__ float ca_ytf_rt(float y, int tf) {
+  return tf == 0 ? ca_ytf<0>(y) : tf == 1 ? ca_ytf<1>(y) : tf == 2 ? ca_ytf<2>(y) : ca_ytf<3>(y);
+}
 
 // ------------------------------------------------------------------ upload / conversion
 // src is N x G in either layout and any ca_dtype; dst is row-major [N][Gp] of YT, zero padded.

@@ -1526,6 +1526,60 @@ int ca_init_psi_pca(ca_handle h, const double* noise, int32_t n_iter, uint64_t s
 #undef PCK
 }
 
+int ca_clone_gene_sums(ca_handle h, const int32_t* clone_of_cell, double* Tout, double* Syy) {
+  if (!h || !clone_of_cell || !Tout || !Syy) return CA_ERR_INVALID;
+  HIPCK(h, hipSetDevice(h->device));
+  if (h->y_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ydone, 0)); h->y_pending = false; }
+  const int64_t N = h->N; const int G = h->G, Gp = h->Gp, C = h->C;
+  float *Fp = nullptr, *Vp = nullptr, *YWp = nullptr, *YTp = nullptr, *csum = nullptr; double* ytd = nullptr;
+  auto cleanup = [&]() { hipFree(Fp); hipFree(Vp); hipFree(YWp); hipFree(YTp); hipFree(csum); hipFree(ytd); };
+#define PCK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { h->err = std::string(#call) + ": " + hipGetErrorString(e_); cleanup(); return CA_ERR_HIP; } } while (0)
+  PCK(hipMalloc((void**)&Fp, (size_t)N * C * sizeof(float)));
+  PCK(hipMalloc((void**)&Vp, (size_t)Gp * C * sizeof(float)));
+  PCK(hipMalloc((void**)&YWp, (size_t)(h->nseg + 1) * N * C * sizeof(float)));
+  PCK(hipMalloc((void**)&YTp, (size_t)(h->nrb + 1) * Gp * C * sizeof(float)));
+  PCK(hipMalloc((void**)&csum, (size_t)std::max(h->n_ovf_chunk, 1) * C * sizeof(float)));
+  PCK(hipMalloc((void**)&ytd, (size_t)Gp * C * sizeof(double)));
+  PCK(hipMemsetAsync(Vp, 0, (size_t)Gp * C * sizeof(float), h->stream));
+  const int nrb_tot = h->nrb + (h->n_ovf > 0 ? 1 : 0);
+  std::vector<float> ind((size_t)N * C, 0.f), asg((size_t)N, 0.f);
+  for (int64_t n = 0; n < N; ++n) {
+    const int c = clone_of_cell[n];
+    if (c >= C) { h->err = "clone index out of range"; cleanup(); return CA_ERR_INVALID; }
+    if (c >= 0) { ind[(size_t)n * C + c] = 1.f; asg[n] = 1.f; }
+  }
+  int rc;
+  std::vector<double> out;
+  // T = Y^T I  (strip partials are exact integers below 2^24 for integer counts; the cross-strip sum is fp64)
+  PCK(hipMemcpyAsync(Fp, ind.data(), ind.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  if ((rc = ypass_tf<0>(h, Fp, Vp, C, YWp, YTp, csum)) != CA_OK) { cleanup(); return rc; }
+  hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)Gp * C, 64)), dim3(1024), 0, h->stream, YTp, ytd, nrb_tot, (int64_t)Gp * C, Gp * C);
+  out.resize((size_t)G * C);
+  PCK(hipMemcpyAsync(out.data(), ytd, out.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  PCK(hipStreamSynchronize(h->stream));
+  for (int g = 0; g < G; ++g)
+    for (int c = 0; c < C; ++c) Tout[hidx(h->layout, g, c, G, C)] = out[(size_t)g * C + c];
+  // Syy = (Y^2)^T 1_assigned
+  PCK(hipMemcpyAsync(Fp, asg.data(), asg.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
+  if ((rc = ypass_tf<3>(h, Fp, Vp, 1, YWp, YTp, csum)) != CA_OK) { cleanup(); return rc; }
+  hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)Gp, 64)), dim3(1024), 0, h->stream, YTp, ytd, nrb_tot, (int64_t)Gp, Gp);
+  PCK(hipMemcpyAsync(Syy, ytd, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  PCK(hipStreamSynchronize(h->stream));
+  cleanup();
+  if (h->opt.world > 1 || h->comm || h->host_ar) {   // sharded: totals over all cells
+    std::vector<double> pack((size_t)G * C + G);
+    for (int g = 0; g < G; ++g) { for (int c = 0; c < C; ++c) pack[(size_t)g * C + c] = out[(size_t)g * C + c]; pack[(size_t)G * C + g] = Syy[g]; }
+    double* scratch = nullptr;
+    HIPCK(h, hipMalloc((void**)&scratch, pack.size() * sizeof(double)));
+    rc = allreduce_host_vec(h, pack, scratch);
+    hipFree(scratch);
+    if (rc != CA_OK) return rc;
+    for (int g = 0; g < G; ++g) { for (int c = 0; c < C; ++c) Tout[hidx(h->layout, g, c, G, C)] = pack[(size_t)g * C + c]; Syy[g] = pack[(size_t)G * C + g]; }
+  }
+  return CA_OK;
+#undef PCK
+}
+
 static int get_generic(ca_handle h, const char* name, double* out, bool grad) {
   if (!h || !name || !out) return CA_ERR_INVALID;
   HIPCK(h, hipSetDevice(h->device));

@@ -23,7 +23,7 @@ KERNEL_NAMES = ("fwd", "bwd", "ypass", "cell", "other")
 EXPORTS = (
     "ca_abi_version", "ca_default_options", "ca_create", "ca_destroy", "ca_last_error", "ca_get_info",
     "ca_synchronize", "ca_comm_unique_id", "ca_comm_init", "ca_set_host_allreduce", "ca_gamma_init", "ca_elbo", "ca_elbo_terms",
-    "ca_step", "ca_gradients", "ca_run", "ca_iterate", "ca_final_elbo", "ca_init_psi_pca", "ca_get_param", "ca_set_param",
+    "ca_step", "ca_gradients", "ca_run", "ca_iterate", "ca_final_elbo", "ca_init_psi_pca", "ca_clone_gene_sums", "ca_get_param", "ca_set_param",
     "ca_get_gradient", "ca_get_kernel_times", "ca_reset_kernel_times", "ca_set_profile", "ca_eps_draw",
 )
 
@@ -88,6 +88,7 @@ def load_library(path=None):
     lib.ca_final_elbo.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
                                   C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.ca_init_psi_pca.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p]
+    lib.ca_clone_gene_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ca_get_param.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
     lib.ca_set_param.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
     lib.ca_get_gradient.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
@@ -284,6 +285,15 @@ class HipEngine:
             self._ck(self.lib.ca_init_psi_pca(self.h, None if nz is None else nz.ctypes.data_as(C.c_void_p), int(n_iter),
                                               int(seed) & 0xFFFFFFFFFFFFFFFF, out.ctypes.data_as(C.c_void_p)))
         return out
+
+    def clone_gene_sums(self, clone_idx):
+        """(T[G,C], Syy[G]): per-gene count sums by assigned clone and sums of squares over assigned cells (-1 = unassigned)."""
+        ci = np.ascontiguousarray(np.asarray(clone_idx, dtype=np.int32).reshape(self.N))
+        T = np.zeros((self.G, self.C), dtype=np.float64)
+        Syy = np.zeros(self.G, dtype=np.float64)
+        self._ck(self.lib.ca_clone_gene_sums(self.h, ci.ctypes.data_as(C.c_void_p), T.ctypes.data_as(C.c_void_p),
+                                             Syy.ctypes.data_as(C.c_void_p)))
+        return T, Syy
 
     def synchronize(self):
         self._ck(self.lib.ca_synchronize(self.h))

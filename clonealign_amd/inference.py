@@ -78,7 +78,7 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
                     fix_alpha=False, dtype="float32", saturate=True, saturation_threshold=6,
                     K=1, mc_samples=1, verbose=True, initial_shrink=5, data_init_mu=True,
                     *, gene_names=None, seed=None, engine=None, engine_opts=None,
-                    psi_noise=None, eps_stream=None, psi_init="auto"):
+                    psi_noise=None, eps_stream=None, psi_init="auto", post=None):
     """EM/VI inference on the MI355X engine.  Arguments as R/inference-tflow.R:71-89.
 
     Keyword-only extras (no reference counterpart): ``seed`` (replaces R's ``set.seed``
@@ -86,7 +86,9 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
     (``colnames(Y_dat)``), ``engine`` (engine class; default the HIP engine),
     ``psi_noise`` / ``eps_stream`` to inject the two noise sources explicitly, ``psi_init`` in
     {"auto", "host", "device"}: where the PCA initialisation of :204-208 runs ("auto": on the device, by
-    subspace iteration over the resident count matrix, once N*G exceeds 4e6; exact SVD on the host below that).
+    subspace iteration over the resident count matrix, once N*G exceeds 4e6; exact SVD on the host below that);
+    ``post(engine, ml_params)`` runs before the engine is closed (clonealign() uses it for the device-side
+    correlation sums) and its result is returned under ``"post"``.
     """
     log = (lambda m: print(m)) if verbose else (lambda m: None)
     log("Constructing HIP engine")                               # :102-104 ("Constructing tensorflow graph")
@@ -168,6 +170,7 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
             elbos = run_vi_loop(eng, eps_stream, max_iter, rel_tol, verbose)
         log("\nELBO converged or reached max iterations")
         rlist = eng.get_params()                                        # :424-434
+        post_out = post(eng, rlist) if post is not None else None
         log("Computing final ELBO")
         if hasattr(eng, "final_elbo"):
             final = eng.final_elbo(eps_stream, N_FINAL_ELBO)
@@ -195,4 +198,5 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
         "convergence_info": convergence_info,
         "retained_genes": retained_genes,
         "clone_probs_from_snv": clone_probs_from_snv,
+        **({"post": post_out} if post is not None else {}),
     }

@@ -151,6 +151,13 @@ int ca_final_elbo(ca_handle h, int32_t n_rep, const float* eps_stream, int64_t n
  * magnitude positive (prcomp's own signs are LAPACK's and arbitrary).  Overwrites psi; pcs_out (N x K) may be NULL. */
 int ca_init_psi_pca(ca_handle h, const double* noise, int32_t n_iter, uint64_t seed, double* pcs_out);
 
+/* Per-gene sums behind compute_correlations() (R/clonealign.R:318-334), one pass over the resident counts instead of
+ * shipping Y back: clone_of_cell[n] in [0, C) or -1 ("unassigned", dropped at :319-320).
+ *   T[g][c] = sum over cells assigned to clone c of y_ng      (G x C, problem layout)
+ *   Syy[g]  = sum over assigned cells of y_ng^2
+ * Pearson's r of (copy number of the assigned clone, counts) follows from T, Syy and the clone sizes on the host. */
+int ca_clone_gene_sums(ca_handle h, const int32_t* clone_of_cell, double* T, double* Syy);
+
 /* Fetch (:424-434).  name in {"mu","clone_probs","s","alpha","beta","psi","W","chi"} (the
  * reference's ml_params) or a raw variable {"loc","ls","gamma_logits","alpha_unconstr","v"}.
  * Output is float64 in the problem's layout; sizes: mu/loc/ls G, clone_probs/gamma_logits

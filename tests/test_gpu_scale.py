@@ -239,3 +239,30 @@ def test_clonealign_end_to_end_with_device_pca():
     assert len(b["convergence_info"]["elbo"]) == 21 and np.isfinite(b["convergence_info"]["final_elbo"])
     # same data, same seeds, host vs device PCA init: ELBO after 20 iterations agrees to MC noise
     assert abs(a["convergence_info"]["final_elbo"] - b["convergence_info"]["final_elbo"]) < 60.0
+
+
+def test_device_correlation_sums_match_host_compute_correlations():
+    """clonealign()'s correlations from the engine's per-clone gene sums == the host formula."""
+    import warnings
+    import clonealign_amd as ca
+    from clonealign_amd.engine import HipEngine
+    from tests import _golden
+    Y, L, clones, *_ = _golden.example()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        fit = ca.clonealign(Y, L, max_iter=30, verbose=False, seed=5, clone_names=clones)
+    host = ca.compute_correlations(Y, L, fit["clone"], clones)
+    np.testing.assert_allclose(fit["correlations"], host, rtol=1e-9, atol=1e-12, equal_nan=True)
+    # raw sums incl. entries above 255
+    rng = np.random.default_rng(1)
+    Yb = rng.poisson(4, size=(500, 300)).astype(np.float64)
+    Yb[::5, 3] += 1000
+    Lb = rng.integers(1, 5, size=(300, 4)).astype(np.float64)
+    idx = rng.integers(-1, 4, size=500)
+    eng = HipEngine(Yb, Lb, np.zeros((500, 1)), np.ones(300), 1)
+    try:
+        T, Syy = eng.clone_gene_sums(idx)
+        np.testing.assert_array_equal(T, np.stack([Yb[idx == c].sum(0) for c in range(4)], 1))
+        np.testing.assert_allclose(Syy, (Yb[idx >= 0] ** 2).sum(0), rtol=1e-6)
+    finally:
+        eng.close()

@@ -172,3 +172,20 @@ def test_product_path_refuses_to_run_without_the_hip_engine(example):
     Y, L, *_ = example
     with pytest.raises((EngineError, RuntimeError)):
         ca.clonealign(Y[:20], L, max_iter=1, verbose=False)
+
+
+def test_correlations_from_sums_equals_direct_computation():
+    from clonealign_amd.api import correlations_from_sums
+    rng = np.random.default_rng(4)
+    Y = rng.poisson(3, size=(60, 9)).astype(float)
+    Y[:, 8] = 5.0
+    L = rng.integers(1, 4, size=(9, 3)).astype(float)
+    L[7] = 2.0                                              # same copy number in every clone -> NA
+    idx = rng.integers(-1, 3, size=60)
+    clones = np.array(["A", "B", "C", "unassigned"], dtype=object)[idx]
+    direct = ca.compute_correlations(Y, L, clones, ["A", "B", "C"])
+    T = np.stack([Y[idx == c].sum(0) for c in range(3)], 1)
+    Syy = (Y[idx >= 0] ** 2).sum(0)
+    viasums = correlations_from_sums(T, Syy, L, np.bincount(idx[idx >= 0], minlength=3))
+    np.testing.assert_allclose(viasums[:7], direct[:7], rtol=1e-10)
+    assert np.isnan(viasums[7]) and np.isnan(viasums[8]) and np.isnan(direct[8])
