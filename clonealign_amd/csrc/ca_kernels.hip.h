@@ -284,13 +284,18 @@ __global__ void __launch_bounds__(CA_TB) k_ypass(const YT* __restrict__ Y, const
   const int sg = (int)(task - rb * nseg);
   if (rb >= nrb) return;
   const int col0 = sg * 64 * VEC + lane * VEC;
-  float w[VEC][KK], acc[VEC][KK];
+  // 2-wide packed accumulation (v_pk_fma_f32): every VALU instruction costs 4 cycles per wave64 on gfx950, packed or not
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  constexpr int VH = VEC / 2;
+  f2 w[VH][KK], acc[VH][KK];
 #pragma unroll
-  for (int j = 0; j < VEC; ++j)
+  for (int j = 0; j < VH; ++j)
 #pragma unroll
     for (int k = 0; k < KK; ++k) {
-      w[j][k] = (col0 + j < G) ? V[(int64_t)(col0 + j) * Dstride + koff + k] : 0.f;
-      acc[j][k] = 0.f;
+      const float w0 = (col0 + 2 * j < G) ? V[(int64_t)(col0 + 2 * j) * Dstride + koff + k] : 0.f;
+      const float w1 = (col0 + 2 * j + 1 < G) ? V[(int64_t)(col0 + 2 * j + 1) * Dstride + koff + k] : 0.f;
+      w[j][k] = (f2){w0, w1};
+      acc[j][k] = (f2){0.f, 0.f};
     }
   const int64_t r0 = rb * TR;
   const int64_t r1 = (r0 + TR < N) ? r0 + TR : N;
@@ -328,23 +333,26 @@ __global__ void __launch_bounds__(CA_TB) k_ypass(const YT* __restrict__ Y, const
 #pragma unroll
           for (int j = 0; j < VEC; ++j) y[j] = ca_ytf<TF>(y[j]);
         }
-        float p[KK], ps[KK];
+        f2 p[KK];
+        float ps[KK];
 #pragma unroll
         for (int k = 0; k < KK; ++k) {
-          p[k] = 0.f;
+          p[k] = (f2){0.f, 0.f};
           ps[k] = F[r * Dstride + koff + k];  // wave-uniform -> scalar load
         }
 #pragma unroll
-        for (int j = 0; j < VEC; ++j)
+        for (int j = 0; j < VH; ++j) {
+          const f2 y2 = {y[2 * j], y[2 * j + 1]};
 #pragma unroll
           for (int k = 0; k < KK; ++k) {
-            p[k] = fmaf(y[j], w[j][k], p[k]);
-            acc[j][k] = fmaf(y[j], ps[k], acc[j][k]);
+            p[k] = y2 * w[j][k] + p[k];
+            acc[j][k] = y2 * ps[k] + acc[j][k];
           }
+        }
         const int slot = (int)(r - r0) & 63;
 #pragma unroll
         for (int k = 0; k < KK; ++k) {
-          const float tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ca_wave_sum_lane63(p[k])), 63));
+          const float tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ca_wave_sum_lane63(p[k].x + p[k].y)), 63));
           keep[k] = (lane == slot) ? tot : keep[k];
         }
       }
@@ -359,9 +367,12 @@ __global__ void __launch_bounds__(CA_TB) k_ypass(const YT* __restrict__ Y, const
     }
   }
 #pragma unroll
-  for (int j = 0; j < VEC; ++j)
+  for (int j = 0; j < VH; ++j)
 #pragma unroll
-    for (int k = 0; k < KK; ++k) YTpart[((int64_t)rb * Gp + col0 + j) * K + koff + k] = acc[j][k];
+    for (int k = 0; k < KK; ++k) {
+      YTpart[((int64_t)rb * Gp + col0 + 2 * j) * K + koff + k] = acc[j][k].x;
+      YTpart[((int64_t)rb * Gp + col0 + 2 * j + 1) * K + koff + k] = acc[j][k].y;
+    }
 }
 
 // Column sums of a [rows][ld] float slab in fp64 and in a fixed order: out[c] = sum_r part[r*ld + c].

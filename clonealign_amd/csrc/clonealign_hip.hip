@@ -211,7 +211,7 @@ int prof_end(ca_engine* h) {
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 // ---- template dispatch of the sweeps -------------------------------------------------------
-constexpr int kFwdR = 2;  // cells per lane of the forward sweep
+constexpr int kFwdR = 2;  // cells per lane of the forward sweep (R = 4 measured 5 % slower with 16 columns)
 template <int NC>
 void fwd_nc(int D, dim3 grid, hipStream_t st, const float* F, const float* em, const float* Vs, const float* M, float* Zp,
             int64_t N, int G, int gchunk) {
