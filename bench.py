@@ -88,6 +88,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "CLONEALIGN_BENCH_DEVICE" in os.environ:   # plumbing test on a 1-GPU box: every rank on the same device
+        local_rank = int(os.environ["CLONEALIGN_BENCH_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -123,14 +125,46 @@ def main():
     psi0 = np.random.default_rng(args.seed + 1).normal(size=(N, K))[lo:hi]
     torch.cuda.synchronize()
 
-    comm_id = None
-    if world > 1:
-        box = [comm_unique_id() if rank == 0 else None]
+    def make_engine(**kw):
+        return HipEngine(None, aux["L"], psi0, loc0, K, 1, y_device_ptr=Yd.data_ptr(), y_device_dtype=np.int32,
+                         shape=(n_loc, G), device=local_rank, y_storage=args.y_storage, rank=rank, world=world, profile=0, **kw)
+
+    collective = "none"
+    if world == 1:
+        eng = make_engine()
+    else:
+        # data path: RCCL all-reduce inside the engine (xGMI).  If the communicator cannot be brought up on EVERY rank,
+        # all ranks fall back together to the host hook over gloo (slower, same results) rather than dying.
+        ok = 1
+        eng = None
+        try:
+            box = [comm_unique_id() if rank == 0 else None]
+        except Exception as e:  # noqa: BLE001
+            box, ok = [None], 0
+            print(f"[rank {rank}] RCCL unavailable: {e}", file=sys.stderr, flush=True)
         dist.broadcast_object_list(box, src=0)
-        comm_id = box[0]
-    eng = HipEngine(None, aux["L"], psi0, loc0, K, 1, y_device_ptr=Yd.data_ptr(), y_device_dtype=np.int32,
-                    shape=(n_loc, G), device=local_rank, y_storage=args.y_storage, rank=rank, world=world,
-                    comm_id=comm_id, profile=0)
+        if box[0] is None:
+            ok = 0
+        if ok:
+            try:
+                eng = make_engine(comm_id=box[0])
+            except Exception as e:  # noqa: BLE001
+                ok = 0
+                print(f"[rank {rank}] RCCL communicator init failed: {e}", file=sys.stderr, flush=True)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 1:
+            collective = "rccl"
+        else:
+            if eng is not None:
+                eng.close()
+
+            def gloo_sum(buf):
+                t = torch.from_numpy(buf.copy())
+                dist.all_reduce(t)
+                buf[:] = t.numpy()
+            eng = make_engine(host_allreduce=gloo_sum)
+            collective = "gloo-host-fallback"
     info = eng.info()
     Ysample = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -207,7 +241,7 @@ def main():
                        "cells": N, "genes": G, "clones": C, "K": K, "mc_samples": 1, "learning_rate": 0.1,
                        "y_storage": info["y_storage_name"], "y_bytes_per_elem": info["y_bytes_per_elem"],
                        "fused_sweep": bool(info.get("fused_sweep")),
-                       "parallelism": f"cells/{world}" if world > 1 else "single"},
+                       "parallelism": f"cells/{world}" if world > 1 else "single", "collective": collective},
             "roofline": {"bound": bound, "kernel": dominant, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": traffic,
                          "launch_ms": per_launch_s * 1e3, "launches": int(launches),
