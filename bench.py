@@ -240,7 +240,8 @@ def main():
                                    f"{world} GPU(s) (BASELINE.json configs[{2 if world == 1 else 3}])",
                        "cells": N, "genes": G, "clones": C, "K": K, "mc_samples": 1, "learning_rate": 0.1,
                        "y_storage": info["y_storage_name"], "y_bytes_per_elem": info["y_bytes_per_elem"],
-                       "fused_sweep": bool(info.get("fused_sweep")),
+                       "fused_sweep": bool(info.get("fused_sweep")), "fwd_mfma": bool(info.get("fwd_mfma")),
+                       "bwd_mfma": bool(info.get("bwd_mfma")),
                        "parallelism": f"cells/{world}" if world > 1 else "single", "collective": collective},
             "roofline": {"bound": bound, "kernel": dominant, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": traffic,

@@ -50,6 +50,11 @@ __device__ __forceinline__ double ca_block_sum(double v, double* sm) {
   return sm[0];
 }
 
+__device__ __forceinline__ unsigned short ca_bf16_rn(float f) {
+  unsigned u = __float_as_uint(f);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
 __device__ __forceinline__ double ca_softplus_d(double x) { return x > 0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
 __device__ __forceinline__ double ca_sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
 
@@ -473,14 +478,15 @@ __global__ void __launch_bounds__(CA_TB) k_gene_pre(const float* __restrict__ lo
 }
 
 // Fused two-eps variant (S == 1, one clone chunk): both draws A (monitor pass) and B (next train pass) in one
-// launch; M row = [mu_A L (C cols) | mu_B L (C cols)], per-draw mu and gene partials kept apart.
+// launch; M row = [mu_A L (C cols) | mu_B L (C cols)], per-draw mu and gene partials kept apart.  With Mq the row
+// goes out as two bf16 parts in the operand layout of the matrix-core sweep instead (k_fwd_mfma).
 __global__ void __launch_bounds__(CA_TB) k_gene_pre_fused(const float* __restrict__ loc, const float* __restrict__ ls,
                                                           const float* __restrict__ epsA, const float* __restrict__ epsB,
                                                           const double* __restrict__ colsum, const float* __restrict__ Lb,
                                                           const float* __restrict__ V, int D, int K, const double* __restrict__ YtX,
                                                           float* __restrict__ muA, float* __restrict__ muB, float* __restrict__ Mb,
                                                           double* __restrict__ gene_partA, double* __restrict__ gene_partB, int G,
-                                                          int mrow, int C) {
+                                                          int mrow, int C, unsigned short* __restrict__ Mq) {
   __shared__ double sm[CA_TB];
   const int g = blockIdx.x * CA_TB + threadIdx.x;
   const bool ok = g < G;
@@ -496,8 +502,18 @@ __global__ void __launch_bounds__(CA_TB) k_gene_pre_fused(const float* __restric
       const double mu = ca_softplus_d(x), lm = log(mu);
       const float muf = (float)mu;
       (w ? muB : muA)[g] = muf;
-      float* mp = Mb + (int64_t)g * mrow + w * C;
-      for (int c = 0; c < C; ++c) mp[c] = lp[c] * muf;
+      if (Mq) {   // two bf16 parts in the B-operand layout of k_fwd_mfma: [g / 32][part][16 (g % 32) / 8 + column][g % 8]
+        unsigned short* mq = Mq + ((int64_t)(g >> 5) * 128 + 16 * ((g & 31) >> 3) + w * C) * 8 + (g & 7);
+        for (int c = 0; c < C; ++c) {
+          const float x = lp[c] * muf;
+          const unsigned short p1 = ca_bf16_rn(x);
+          mq[c * 8] = p1;
+          mq[(64 + c) * 8] = ca_bf16_rn(x - __uint_as_float((unsigned)p1 << 16));
+        }
+      } else {
+        float* mp = Mb + (int64_t)g * mrow + w * C;
+        for (int c = 0; c < C; ++c) mp[c] = lp[c] * muf;
+      }
       t[w][0] = cs * lm + bx;
       t[w][1] = -0.5 * lm * lm - 0.5 * CA_LOG2PI;
       t[w][2] = -0.5 * e * e - lsd - 0.5 * CA_LOG2PI + (mu - x);
@@ -684,6 +700,142 @@ __global__ void __launch_bounds__(CA_TB) k_fwd_lds(const float* __restrict__ F, 
   }
 }
 
+// ------------------------------------------------------------------ forward sweep on the matrix cores
+// Z = E.M for the 16 columns of the fused two-eps pass as bf16 MFMAs with fp32 accumulation:
+//   rows = 16 cells, k = 32 genes, columns = [mu_A L | mu_B L | 0]   (v_mfma_f32_16x16x32_bf16)
+// A lane owns ONE cell and 8 consecutive genes of the k-step (the A-operand layout), so it generates its 8 E values,
+// rounds them to bf16 (hi, v_cvt_pk_bf16_f32), takes the exact remainder e - hi with v_dot2c_f32_bf16 and rounds
+// that too (lo): E = hi + lo up to 2^-18.  M arrives pre-split the same way (Mq, written by k_gene_pre_fused in the
+// B-operand layout) and Z += lo.M1 + hi.M2 + hi.M1 -- the dropped terms are <= 3 x 2^-18 relative per product with
+// random sign; measured against float64 the result is as accurate as the fp32 VALU chain (tools/fwd_mfma_lab.hip:
+// rms 1.4e-7 vs 1.3e-7).  The gene slice of a block streams through LDS in double-buffered chunks of KC k-steps, so
+// few slices suffice (fewer Z partials for the cell epilogue to re-read).  Issue-bound: 20 VALU + 8 v_exp_f32 +
+// 3 MFMA per 8 genes x 16 columns per lane (tools/inst_lab.hip: 220 cycles per wave and k-step-tile) against
+// 8 + 8 v_exp + 64 for the VALU kernel.  D in {1, 2}; k_fwd_lds is the general fallback.
+typedef __bf16 ca_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 ca_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float ca_f32x4 __attribute__((ext_vector_type(4)));
+typedef float ca_f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned ca_pk_bf16(float a, float b) {   // v_cvt_pk_bf16_f32, round to nearest even
+  const ca_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, ca_bf16x2));
+}
+
+constexpr int CA_FM_TL = 4;   // 16-cell tiles per wave  -> 256 cells per block
+constexpr int CA_FM_KC = 4;   // k-steps (of 32 genes) per LDS chunk
+
+template <int D>
+__global__ void __launch_bounds__(CA_TB) k_fwd_mfma(const float* __restrict__ F, const float* __restrict__ etamax2,
+                                                    const float* __restrict__ Vs /*[G][D]*/,
+                                                    const unsigned short* __restrict__ Mq /*[nk][2][64][8] bf16*/,
+                                                    float* __restrict__ Zpart /*[fsplit][N][16]*/, int64_t N, int G, int kchunk,
+                                                    int nk) {
+  constexpr int TL = CA_FM_TL, KC = CA_FM_KC;
+  constexpr int NB = KC * 128;            // uint4 of B per chunk (2 parts x 64 lanes per k-step)
+  constexpr int NV = KC * 32 * D;         // floats of V' per chunk, [ks][d][32]
+  constexpr int BUF = NB + NV / 4;        // uint4 per buffer
+  constexpr int NLD = NB / CA_TB;
+  static_assert(NB % CA_TB == 0 && NV <= CA_TB, "chunk shape");
+  __shared__ uint4 lds[2 * BUF];
+  const int k0 = blockIdx.y * kchunk;
+  const int nks = min(nk, k0 + kchunk) - k0;
+  const int nch = (nks + KC - 1) / KC;
+  const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4, wv = threadIdx.x >> 6;
+  const int64_t cell0 = ((int64_t)blockIdx.x * (CA_TB / 64) + wv) * (TL * 16);
+  uint4 st[NLD];
+  float sv = 0.f;
+  auto gload = [&](int c) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = threadIdx.x + CA_TB * i;   // [ks][part][lane]
+      const int kk = k0 + c * KC + (idx >> 7);
+      st[i] = (kk < k0 + nks) ? reinterpret_cast<const uint4*>(Mq)[(int64_t)kk * 128 + (idx & 127)] : (uint4){0u, 0u, 0u, 0u};
+    }
+    if (threadIdx.x < NV) {
+      const int ks = threadIdx.x / (32 * D), rem = threadIdx.x % (32 * D), d = rem / 32, gi = rem % 32;
+      const int kk = k0 + c * KC + ks, g = kk * 32 + gi;
+      sv = (kk < k0 + nks && g < G) ? Vs[(int64_t)g * D + d] : 0.f;
+    }
+  };
+  auto lstore = [&](int b) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) lds[b * BUF + threadIdx.x + CA_TB * i] = st[i];
+    if (threadIdx.x < NV) reinterpret_cast<float*>(lds + b * BUF + NB)[threadIdx.x] = sv;
+  };
+  float f[TL][D], em[TL];
+  ca_f32x4 acc[TL];
+#pragma unroll
+  for (int t = 0; t < TL; ++t) {
+    const int64_t n = cell0 + 16 * t + j;
+    const int64_t nn = n < N ? n : N - 1;
+#pragma unroll
+    for (int d = 0; d < D; ++d) f[t][d] = F[nn * D + d];
+    em[t] = etamax2[nn];
+    acc[t] = (ca_f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  // (-1, 0) and (0, -1) as bf16 pairs for v_dot2c_f32_bf16; kept out of the compiler's sight, which would turn them
+  // into the fp32 inline constant -1.0 (wrong half of the pair)
+  unsigned m0, m1;
+  asm volatile("s_mov_b32 %0, 0x0000bf80" : "=s"(m0));
+  asm volatile("s_mov_b32 %0, 0xbf800000" : "=s"(m1));
+  const ca_bf16x2 neg_lo = __builtin_bit_cast(ca_bf16x2, m0), neg_hi = __builtin_bit_cast(ca_bf16x2, m1);
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int c = 0; c < nch; ++c) {
+    const int b = c & 1;
+    if (c + 1 < nch) gload(c + 1);
+    const uint4* lb = lds + b * BUF;
+    const float4* lv4 = reinterpret_cast<const float4*>(lds + b * BUF + NB);
+#pragma unroll 2
+    for (int ks = 0; ks < KC; ++ks) {
+      const uint4 b1r = lb[ks * 128 + lane], b2r = lb[ks * 128 + 64 + lane];
+      const ca_bf16x8 B1 = __builtin_bit_cast(ca_bf16x8, b1r), B2 = __builtin_bit_cast(ca_bf16x8, b2r);
+      ca_f32x2 v2[D][4];   // V'_d of this lane's 8 genes
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const float4 va = lv4[(ks * D + d) * 8 + 2 * q], vb = lv4[(ks * D + d) * 8 + 2 * q + 1];
+        v2[d][0] = (ca_f32x2){va.x, va.y}; v2[d][1] = (ca_f32x2){va.z, va.w};
+        v2[d][2] = (ca_f32x2){vb.x, vb.y}; v2[d][3] = (ca_f32x2){vb.z, vb.w};
+      }
+#pragma unroll
+      for (int t = 0; t < TL; ++t) {
+        unsigned hi[4], lo[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          ca_f32x2 eta = v2[0][p] * f[t][0] - em[t];
+#pragma unroll
+          for (int d = 1; d < D; ++d) eta = v2[d][p] * f[t][d] + eta;
+          const float e0 = __builtin_amdgcn_exp2f(eta.x), e1 = __builtin_amdgcn_exp2f(eta.y);
+          hi[p] = ca_pk_bf16(e0, e1);
+          const ca_bf16x2 hb = __builtin_bit_cast(ca_bf16x2, hi[p]);
+          const float r0 = __builtin_amdgcn_fdot2_f32_bf16(hb, neg_lo, e0, false);   // e0 - hi.lo, exact
+          const float r1 = __builtin_amdgcn_fdot2_f32_bf16(hb, neg_hi, e1, false);
+          lo[p] = ca_pk_bf16(r0, r1);
+        }
+        const ca_bf16x8 A1 = __builtin_bit_cast(ca_bf16x8, ((uint4){hi[0], hi[1], hi[2], hi[3]}));
+        const ca_bf16x8 A2 = __builtin_bit_cast(ca_bf16x8, ((uint4){lo[0], lo[1], lo[2], lo[3]}));
+        ca_f32x4 a = acc[t];
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2, B1, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B2, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B1, a, 0, 0, 0);
+        acc[t] = a;
+      }
+    }
+    if (c + 1 < nch) lstore(b ^ 1);
+    __syncthreads();
+  }
+  // accumulator layout: lane (column j, rows 4q .. 4q+3 of the tile)
+#pragma unroll
+  for (int t = 0; t < TL; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t n = cell0 + 16 * t + 4 * q + r;
+      if (n < N) Zpart[((int64_t)blockIdx.y * N + n) * 16 + j] = acc[t][r];
+    }
+}
+
 // ------------------------------------------------------------------ backward sweep
 // Reverse mode of Z = E.M given coef = dELBO/dZ.  lane = gene (RG genes per lane), loop over a
 // slice of cells whose coef/F/etamax are wave-uniform (scalar loads).  Ablations (tools/bwd_lab2.hip, 100k x 5k x 8,
@@ -805,15 +957,7 @@ __global__ void __launch_bounds__(CA_TB) k_bwd(const float* __restrict__ coef /*
 // batch: d/dF needs a 4-lane-group sum per batch, the per-gene sums stay in-lane over the whole cell slice.
 // On gfx950 every VALU instruction costs 4 cycles per wave64, packed or not (tools/valu_lab.hip), hence the explicit
 // 2-wide math.  Used when D == 1, C <= 8 and L is bf16-exact; k_bwd is the general fallback.
-typedef __bf16 ca_bf16x8 __attribute__((ext_vector_type(8)));
-typedef float ca_f32x4 __attribute__((ext_vector_type(4)));
-typedef float ca_f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ unsigned short ca_bf16_rn(float f) {
-  unsigned u = __float_as_uint(f);
-  u += 0x7FFFu + ((u >> 16) & 1u);
-  return (unsigned short)(u >> 16);
-}
 // three bf16 parts of a float: x = p1 + p2 + p3 up to 2^-24 relative
 __device__ __forceinline__ void ca_split3(float x, unsigned short& p1, unsigned short& p2, unsigned short& p3) {
   p1 = ca_bf16_rn(x); x -= __uint_as_float((unsigned)p1 << 16);
@@ -871,11 +1015,24 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
   float* myd = ca_lds + (int64_t)wv * cchunk;
   if (!active)
     for (int64_t i = lane; i < n1 - n0; i += 64) myd[i] = 0.f;
+  // MFMA B operand: lane (column j, k-group q) holds part q of coef[cell b0+j][0..8): 16 bytes, 1 KiB per wave.
+  // The next batch's operands are fetched while the current one is in the pipes (cell arrays padded to 16).
+  uint4 craw_n = {0u, 0u, 0u, 0u};
+  float fc_n = 0.f, ec_n = 0.f;
+  if (active && n0 < n1) {
+    craw_n = *reinterpret_cast<const uint4*>(cq + ((n0 + j) * 4 + q) * 8);
+    fc_n = F[n0 + j];
+    ec_n = etamax2[n0 + j];
+  }
   for (int64_t b0 = n0; active && b0 < n1; b0 += 16) {
-    // MFMA B operand: lane (column j, k-group q) holds part q of coef[cell b0+j][0..8): 16 bytes, 1 KiB per wave
-    const uint4 craw = *reinterpret_cast<const uint4*>(cq + ((b0 + j) * 4 + q) * 8);
+    const uint4 craw = craw_n;
+    const float fc = fc_n, ec = ec_n;
+    if (b0 + 16 < n1) {
+      craw_n = *reinterpret_cast<const uint4*>(cq + ((b0 + 16 + j) * 4 + q) * 8);
+      fc_n = F[b0 + 16 + j];
+      ec_n = etamax2[b0 + 16 + j];
+    }
     const ca_bf16x8 Cf = __builtin_bit_cast(ca_bf16x8, craw);
-    const float fc = F[b0 + j], ec = etamax2[b0 + j];   // padded to a multiple of 16 cells
     ca_f32x2 dF = {0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < TL; ++m) {

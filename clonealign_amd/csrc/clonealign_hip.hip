@@ -115,6 +115,8 @@ struct ca_engine {
   // fused two-eps sweep (monitor pass of iteration i + forward half of train pass i+1, same parameters)
   bool fused_ok = false, look_valid = false; int64_t look_slot = 0; int frow = 8;
   float *Mb2 = nullptr, *mu32B = nullptr, *Zpart2 = nullptr; double* gene_partB = nullptr;
+  bool y_defer = false;
+  bool fwd_mfma = false; int fsplit = 1, fkchunk = 1, nk32 = 1; unsigned short* Mq = nullptr;   // matrix-core forward sweep
   // matrix-core backward sweep (k_bwd_mfma): bf16 parts of coef, its own cell split
   bool bwd_mfma = false; unsigned short* coefq = nullptr; int64_t N16 = 0, cchunk_m = 0; int csplit_m = 1, nwt = 0;
   uint64_t draw = 0;  // built-in stream position
@@ -209,6 +211,21 @@ int prof_end(ca_engine* h) {
   } while (0)
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Split count s in [1, smax] for a grid of xb * s equal blocks on `slots` resident block slots: fewest rounds per unit
+// of work (a grid just past a multiple of the slots runs a nearly empty last round), every extra split charged
+// `penalty` (its partial results are written and re-read).  Ties go to the smaller split.
+inline int pick_split(int64_t xb, int64_t slots, int smax, double penalty) {
+  int best = 1;
+  double best_score = -1e30;
+  for (int s = 1; s <= smax; ++s) {
+    const int64_t B = xb * s;
+    const int64_t rounds = (B + slots - 1) / slots;
+    const double score = (double)B / (double)(rounds * slots) - penalty * s;
+    if (score > best_score + 1e-9) { best_score = score; best = s; }
+  }
+  return best;
+}
 
 // ---- template dispatch of the sweeps -------------------------------------------------------
 constexpr int kFwdR = 2;  // cells per lane of the forward sweep (R = 4 measured 5 % slower with 16 columns)
@@ -341,6 +358,7 @@ int download_f(ca_engine* h, std::vector<float>& v, const float* src, int64_t n)
 // ---- derived state that depends on the parameters only (not on eps) -------------------------
 int refresh_derived(ca_engine* h) {
   if (h->y_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ydone, 0)); h->y_pending = false; }
+  h->y_defer = false;   // a deferred side-stream Y pass would not be ordered after this parameter change: redo it in line
   if (h->D > 0) {
     LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_vprep, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->V, h->Vs, h->vmm_part, h->G, h->D));
     LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_vmm_final, dim3(1), dim3(64), 0, h->stream, h->vmm_part, h->vmm, h->ngblk, h->D));
@@ -353,6 +371,17 @@ int refresh_derived(ca_engine* h) {
 
 // Y.W and Y^T.psi for the current parameters (once per parameter state)
 int ensure_ycache(ca_engine* h) {
+  if (h->y_defer) {   // deferred side-stream start (train_tail): ordered after the parameter update by ev_params
+    h->y_defer = false;
+    HIPCK(h, hipStreamWaitEvent(h->stream2, h->ev_params, 0));
+    std::swap(h->stream, h->stream2);
+    const int rc = ensure_ycache(h);
+    std::swap(h->stream, h->stream2);
+    CACK(rc);
+    HIPCK(h, hipEventRecord(h->ev_ydone, h->stream2));
+    h->y_pending = true;
+    return CA_OK;
+  }
   if (h->ycache_valid || h->K == 0) { h->ycache_valid = true; return CA_OK; }
   const int64_t tasks = (int64_t)h->nrb * h->nseg;
   dim3 grid(cdiv(tasks, CA_TB / 64));
@@ -568,15 +597,11 @@ int train_tail(ca_engine* h, const float* eps, const float* mu32, int apply, dou
     h->b2p *= (float)h->opt.beta2;
     h->ycache_valid = false;   // V', its range and etamax2 were refreshed inside the step's own kernels
     h->look_valid = false;
-    if (h->async_y && h->K > 0) {   // start the Y pass for the new parameters on the side stream right away
+    if (h->async_y && h->K > 0) {
+      // the Y pass for the new parameters goes to the side stream; its launches are issued by the next pass AFTER that
+      // pass's per-gene kernel, so the main stream is not left waiting for the host to get through them
       HIPCK(h, hipEventRecord(h->ev_params, h->stream));
-      HIPCK(h, hipStreamWaitEvent(h->stream2, h->ev_params, 0));
-      std::swap(h->stream, h->stream2);
-      const int rc = ensure_ycache(h);
-      std::swap(h->stream, h->stream2);
-      CACK(rc);
-      HIPCK(h, hipEventRecord(h->ev_ydone, h->stream2));
-      h->y_pending = true;
+      h->y_defer = true;
     }
   }
   return CA_OK;
@@ -588,10 +613,10 @@ int train_tail(ca_engine* h, const float* eps, const float* mu32, int apply, dou
 //   mode CA_MODE_TRAIN: forward + backward (+ Adam when apply)  (`sess$run(train)`)
 int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_dst) {
   const float* eps = h->eps_dev + eps_slot * (int64_t)h->S * h->G;
-  CACK(ensure_ycache(h));
   LAUNCH(h, CA_KERNEL_OTHER,
          hipLaunchKernelGGL(k_gene_pre, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->loc, h->ls, eps, h->colsum, h->Lb, h->V,
                             h->D, h->K, h->YtX, h->mu32, h->Mb, h->gene_part, h->G, h->S, h->nchunk, CA_CW, 0, CA_CW));
+  CACK(ensure_ycache(h));
   for (int s = 0; s < h->S; ++s)
     for (int ch = 0; ch < h->nchunk; ++ch) {
       const int nc = std::min(CA_CW, h->C - ch * CA_CW);
@@ -647,12 +672,23 @@ int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_d
 int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst) {
   const float* epsA = h->eps_dev + slotA * (int64_t)h->G;
   const float* epsB = h->eps_dev + slotB * (int64_t)h->G;
-  CACK(ensure_ycache(h));
   LAUNCH(h, CA_KERNEL_OTHER,
          hipLaunchKernelGGL(k_gene_pre_fused, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->loc, h->ls, epsA, epsB, h->colsum, h->Lb,
-                            h->V, h->D, h->K, h->YtX, h->mu32, h->mu32B, h->Mb2, h->gene_part, h->gene_partB, h->G, h->frow, h->C));
-  LAUNCH(h, CA_KERNEL_FWD, launch_fwd_fused(h->C, h->D, dim3(cdiv(h->N, CA_TB * kFwdR), h->gsplit), h->stream, h->F, h->etamax2,
-                                            h->Vs, h->Mb2, h->Zpart2, h->N, h->G, h->gchunk));
+                            h->V, h->D, h->K, h->YtX, h->mu32, h->mu32B, h->Mb2, h->gene_part, h->gene_partB, h->G, h->frow, h->C,
+                            h->fwd_mfma ? h->Mq : nullptr));
+  CACK(ensure_ycache(h));
+  if (h->fwd_mfma) {
+    const dim3 grid(cdiv(h->N, (CA_TB / 64) * CA_FM_TL * 16), h->fsplit);
+    if (h->D == 1)
+      LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_mfma<1>), grid, dim3(CA_TB), 0, h->stream, h->F, h->etamax2, h->Vs, h->Mq,
+                                                  h->Zpart2, h->N, h->G, h->fkchunk, h->nk32));
+    else
+      LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_mfma<2>), grid, dim3(CA_TB), 0, h->stream, h->F, h->etamax2, h->Vs, h->Mq,
+                                                  h->Zpart2, h->N, h->G, h->fkchunk, h->nk32));
+  } else {
+    LAUNCH(h, CA_KERNEL_FWD, launch_fwd_fused(h->C, h->D, dim3(cdiv(h->N, CA_TB * kFwdR), h->gsplit), h->stream, h->F, h->etamax2,
+                                              h->Vs, h->Mb2, h->Zpart2, h->N, h->G, h->gchunk));
+  }
   if (h->y_pending) {
     HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ydone, 0));
     h->y_pending = false;
@@ -665,7 +701,8 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst) {
   LAUNCH(h, CA_KERNEL_CELL,                                                                                                  \
          hipLaunchKernelGGL((k_cell_fused<CPV>), grid, dim3(CA_TB), 0, h->stream, h->Zpart2, h->frow, h->A, h->cn, h->s64,   \
                             h->etamax2, h->glogit, h->alpha_u, h->F, h->YWpart, h->YW, h->coef, h->dgl, h->cell_part, h->N,  \
-                            h->C, h->D, h->K, h->gsplit, h->nseg + (h->n_ovf > 0 ? 1 : 0), h->bwd_mfma ? h->coefq : nullptr))
+                            h->C, h->D, h->K, h->fwd_mfma ? h->fsplit : h->gsplit, h->nseg + (h->n_ovf > 0 ? 1 : 0),              \
+                            h->bwd_mfma ? h->coefq : nullptr))
     switch (CP) {
       case 1: CA_CELLF(1); break;
       case 2: CA_CELLF(2); break;
@@ -1002,7 +1039,16 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     if (h->bwd_mfma) {
       h->nwt = cdiv(G, 4 * 16);
       const int xb = cdiv(h->nwt, CA_TB / 64);
-      h->csplit_m = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(target_blocks, xb), std::max<int64_t>(1, Nn / 256)));
+      {
+        // resident blocks per CU from the compiler's register count (LDS, 16 B per cell of the slice, is not the limit
+        // at the slice lengths this produces); one or two full rounds instead of "about 8 blocks per CU"
+        int per_cu = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_bwd_mfma<4>, CA_TB, 16 * 1024) != hipSuccess || per_cu < 1)
+          per_cu = 4;
+        (void)hipGetLastError();
+        const int smax = (int)std::max<int64_t>(1, std::min<int64_t>(Nn / 256, cdiv(2 * (int64_t)per_cu * h->n_cu, xb)));
+        h->csplit_m = pick_split(xb, (int64_t)per_cu * h->n_cu, smax, 1e-4);
+      }
       if (const char* e = getenv("CA_CSPLIT_M")) h->csplit_m = std::max(1, atoi(e));
       h->csplit_m = (int)std::max<int64_t>(h->csplit_m, (Nn + 4079) / 4080);   // LDS: 4 waves x cchunk floats <= 64 KB
       h->cchunk_m = ((Nn + h->csplit_m - 1) / h->csplit_m + 15) / 16 * 16;
@@ -1049,11 +1095,37 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   h->fused_ok = (S == 1 && C <= CA_CW) && !(getenv("CA_FUSED") && atoi(getenv("CA_FUSED")) == 0);
   if (h->fused_ok) {
     h->frow = (2 * C <= 8) ? 8 : 16;
-    CACK(dalloc(h, &h->Mb2, (int64_t)G * h->frow));
+    // matrix-core forward sweep (k_fwd_mfma): D in {1, 2}; few gene slices, streamed through LDS
+    h->fwd_mfma = (D == 1 || D == 2) && !(getenv("CA_FWD_MFMA") && atoi(getenv("CA_FWD_MFMA")) == 0);
+    int zsplit = h->gsplit;
+    if (h->fwd_mfma) {
+      h->frow = 16;
+      h->nk32 = cdiv(G, 32);
+      const int cblocks = cdiv(Nn, (CA_TB / 64) * CA_FM_TL * 16);
+      {
+        int per_cu = 4;
+        const void* fn = (D == 1) ? (const void*)k_fwd_mfma<1> : (const void*)k_fwd_mfma<2>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, CA_TB, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        (void)hipGetLastError();
+        // every gene slice adds an N x 16 float partial (written here, re-read by the cell epilogue): ~2 % of the sweep
+        h->fsplit = pick_split(cblocks, (int64_t)per_cu * h->n_cu, std::max(1, std::min(16, h->nk32 / CA_FM_KC)), 0.02);
+      }
+      if (const char* e = getenv("CA_FSPLIT")) h->fsplit = std::max(1, std::min(atoi(e), h->nk32));
+      h->fkchunk = cdiv(h->nk32, h->fsplit);
+      h->fsplit = cdiv(h->nk32, h->fkchunk);
+      zsplit = h->fsplit;
+      CACK(dalloc(h, &h->Mq, (int64_t)h->nk32 * 2 * 64 * 8));   // zero-filled: padding genes and columns stay 0
+    } else {
+      CACK(dalloc(h, &h->Mb2, (int64_t)G * h->frow));
+    }
     CACK(dalloc(h, &h->mu32B, G));
     CACK(dalloc(h, &h->gene_partB, (int64_t)h->ngblk * (3 + K)));
-    CACK(dalloc(h, &h->Zpart2, (int64_t)h->gsplit * Nn * h->frow));
+    CACK(dalloc(h, &h->Zpart2, (int64_t)zsplit * Nn * h->frow));
   }
+  if (getenv("CA_VERBOSE"))
+    fprintf(stderr, "[clonealign_hip] N=%lld G=%d C=%d D=%d n_cu=%d gsplit=%d gchunk=%d csplit=%d fused=%d fwd_mfma=%d fsplit=%d fkchunk=%d "
+            "bwd_mfma=%d csplit_m=%d cchunk_m=%lld nwt=%d\n", (long long)Nn, G, C, D, h->n_cu, h->gsplit, h->gchunk, h->csplit,
+            (int)h->fused_ok, (int)h->fwd_mfma, h->fsplit, h->fkchunk, (int)h->bwd_mfma, h->csplit_m, (long long)h->cchunk_m, h->nwt);
   CACK(dalloc(h, &h->vmm, 2 * std::max(D, 1)));
   CACK(dalloc(h, &h->vmm_part, (int64_t)h->ngblk * 2 * std::max(D, 1)));
   CACK(dalloc(h, &h->etamax2, h->N16));
@@ -1217,6 +1289,7 @@ int ca_get_info(ca_handle h, ca_info* i) {
   i->N = h->N; i->G = h->G; i->C = h->C; i->K = h->K; i->P = h->P; i->S = h->S;
   i->y_storage = h->ystore; i->y_bytes_per_elem = h->ybytes; i->y_device_bytes = h->y_dev_bytes; i->device_bytes = h->dev_bytes;
   i->gsplit = h->gsplit; i->csplit = h->csplit; i->n_cu = h->n_cu; i->fused_sweep = h->fused_ok ? 1 : 0;
+  i->fwd_mfma = (h->fused_ok && h->fwd_mfma) ? 1 : 0; i->bwd_mfma = h->bwd_mfma ? 1 : 0; i->fsplit = h->fsplit;
   return CA_OK;
 }
 

@@ -46,7 +46,8 @@ class CaInfo(C.Structure):
     _fields_ = [("N", C.c_int64), ("G", C.c_int32), ("C", C.c_int32), ("K", C.c_int32), ("P", C.c_int32),
                 ("S", C.c_int32), ("y_storage", C.c_int32), ("y_bytes_per_elem", C.c_int32),
                 ("y_device_bytes", C.c_int64), ("device_bytes", C.c_int64), ("gsplit", C.c_int32),
-                ("csplit", C.c_int32), ("n_cu", C.c_int32), ("fused_sweep", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("csplit", C.c_int32), ("n_cu", C.c_int32), ("fused_sweep", C.c_int32), ("fwd_mfma", C.c_int32),
+                ("bwd_mfma", C.c_int32), ("fsplit", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)

@@ -85,7 +85,10 @@ typedef struct ca_info {
   int32_t gsplit, csplit;    /* gene / cell splits of the forward / backward sweeps */
   int32_t n_cu;
   int32_t fused_sweep;       /* 1: ca_run/ca_iterate fuse monitor pass i with the forward half of train pass i+1 */
-  int32_t reserved[7];
+  int32_t fwd_mfma;          /* 1: the fused sweep's forward contraction runs on the matrix cores (k_fwd_mfma) */
+  int32_t bwd_mfma;          /* 1: the backward sweep's t = coef.L contraction runs on the matrix cores (k_bwd_mfma) */
+  int32_t fsplit;            /* gene slices of the matrix-core forward sweep */
+  int32_t reserved[4];
 } ca_info;
 
 /* kernel classes reported by ca_get_kernel_times() */

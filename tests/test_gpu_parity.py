@@ -5,6 +5,8 @@ float32 FMA chains (exact-f32 products, fp64 cross-block sums); ELBO terms and g
 compared at 2e-5 relative to the largest magnitude of the compared array, parameters after
 Adam steps at 1e-4 (north_star: "ELBO/ML parameters within 1e-4 relative").
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -169,14 +171,23 @@ def test_ca_run_equals_call_by_call_loop_and_builtin_stream():
     from clonealign_amd.rng import EpsStream
     case = make_case(seed=21, **CASES["k1"])
     a, b, c = HipEngine(**case, seed=4242), HipEngine(**case), HipEngine(**case)
+    os.environ["CA_FWD_MFMA"] = "0"
+    try:
+        b0 = HipEngine(**case)
+    finally:
+        del os.environ["CA_FWD_MFMA"]
     try:
         t_builtin = a.run(None, 15, 1e-9)
         t_inject = b.run(EpsStream(4242, 1, b.G), 15, 1e-9)
         t_loop = np.array(run_vi_loop(c, EpsStream(4242, 1, c.G), 15, 1e-9))
         assert np.array_equal(t_builtin, t_inject)
         # ca_run takes the fused two-eps sweep (monitor i + forward of train i+1), the call-by-call loop the plain
-        # passes: same arithmetic, fp64 contraction may differ in the last bit
-        np.testing.assert_allclose(t_inject, t_loop, rtol=1e-13)
+        # passes.  With the VALU forward kernel both do the same fp32 arithmetic (fp64 contraction may differ in the
+        # last bit); the matrix-core forward of the fused sweep (bf16-split products, fp32 accumulation) differs from
+        # the fp32 FMA chain at the fp32 rounding level
+        t_valu = b0.run(EpsStream(4242, 1, b0.G), 15, 1e-9)
+        np.testing.assert_allclose(t_valu, t_loop, rtol=1e-13)
+        np.testing.assert_allclose(t_inject, t_loop, rtol=2e-6)
         assert len(t_loop) == 16
         # early stop: a loose tolerance stops after the 10-long window fills (R/inference-tflow.R:379,414)
         d = HipEngine(**case)
@@ -185,7 +196,7 @@ def test_ca_run_equals_call_by_call_loop_and_builtin_stream():
         assert len(t) == 11 and es.draw == 22
         d.close()
     finally:
-        a.close(); b.close(); c.close()
+        a.close(); b.close(); c.close(); b0.close()
 
 
 @pytest.mark.parametrize("name", ["k1", "k2p1s2x"])
@@ -249,5 +260,46 @@ def test_backward_sweep_variants_agree_with_oracle(variant, monkeypatch):
         assert abs(ee - eo) <= 2e-5 * abs(eo)
         for n in ora.VAR_NAMES:
             assert _rel(ge[n], go[n]) < 2e-5, (variant, n, _rel(ge[n], go[n]))
+    finally:
+        eng.close()
+
+
+FUSED_SHAPES = {
+    "d1_c5": dict(N=700, G=1100, C=5, K=1),
+    "d1_c8_ragged": dict(N=333, G=95, C=8, K=1),          # G not a multiple of 32, N not a multiple of 256
+    "d2_k1p1": dict(N=520, G=300, C=6, K=1, P=1),
+    "d2_k2": dict(N=257, G=161, C=2, K=2),
+    "d3_fallback": dict(N=200, G=90, C=4, K=2, P=1),       # D = 3: the VALU sweep is the only one
+}
+
+
+@pytest.mark.parametrize("fwd", ["mfma", "valu"])
+@pytest.mark.parametrize("shape", list(FUSED_SHAPES))
+def test_fused_sweep_forward_variants_agree_with_oracle(shape, fwd, monkeypatch):
+    """ca_iterate takes the fused two-eps sweep (monitor pass i + forward half of train pass i+1 from one exp per
+    (cell, gene)); its forward contraction runs on the matrix cores (k_fwd_mfma, D in {1, 2}) or on the VALU
+    (CA_FWD_MFMA=0, and always for D >= 3).  Both against the oracle's call-by-call loop."""
+    from clonealign_amd.engine import HipEngine
+    from oracle.fused_numpy import FusedModel
+    if fwd == "valu":
+        monkeypatch.setenv("CA_FWD_MFMA", "0")
+    case = make_case(seed=5, **FUSED_SHAPES[shape])
+    eng, ora = HipEngine(**case), FusedModel(**case, dtype="float32")
+    try:
+        assert eng.info()["fwd_mfma"] == int(fwd == "mfma" and ora.D in (1, 2))
+        st = perturbed_state({n: getattr(ora, n).shape for n in ora.VAR_NAMES}, amp=0.2)
+        for n, v in st.items():
+            setattr(ora, n, v.astype(ora.pdt))
+            eng.set(n, v)
+        n_iter = 4
+        eps = np.stack([eps_for(1, ora.G, 100 + i) for i in range(2 * n_iter)])
+        last = eng.iterate(n_iter, eps)
+        for i in range(n_iter):
+            ora.step(eps[2 * i])
+            e = ora.elbo(eps[2 * i + 1])
+        assert abs(last - e) <= 2e-5 * abs(e)
+        p = eng.get_state()
+        for n in ora.VAR_NAMES:
+            assert _rel(p[n], getattr(ora, n)) < 1e-4, (shape, fwd, n, _rel(p[n], getattr(ora, n)))
     finally:
         eng.close()

@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(256) bwd_mfma3(const unsigned short* __restric
 
 // v4: operands swapped (rows = genes, columns = cells): each lane owns ONE cell per batch, so d/dF needs only a
 // 4-lane-group sum per batch; the per-gene sums stay in-lane for the whole cell slice and are row-reduced once.
-template <int TL, bool PF>
+template <int TL, bool PF, int ABL = 0>
 __global__ void __launch_bounds__(256) bwd_mfma4(const unsigned short* __restrict__ cq, const float* __restrict__ F,
                                                  const float* __restrict__ em2, const float* __restrict__ Lb,
                                                  const float* __restrict__ mu, const float* __restrict__ Vs, const float* __restrict__ V,
@@ -324,18 +324,22 @@ __global__ void __launch_bounds__(256) bwd_mfma4(const unsigned short* __restric
 #pragma unroll
     for (int m = 0; m < TL; ++m) {
       f32x4 t = {0.f, 0.f, 0.f, 0.f};
-      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Lf[m], Cf, t, 0, 0, 0);   // t[r]: gene gbase+16m+4q+r, cell b0+j
+      if (ABL == 2) { t[0] = __uint_as_float(craw.x); t[1] = __uint_as_float(craw.y); t[2] = __uint_as_float(craw.z); t[3] = __uint_as_float(craw.w); }
+      else t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Lf[m], Cf, t, 0, 0, 0);   // t[r]: gene gbase+16m+4q+r, cell b0+j
       const f32x2 t2[2] = {{t[0], t[1]}, {t[2], t[3]}};
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const f32x2 eta = vs[m][h] * fc - ec;
-        const f32x2 ex = {__builtin_amdgcn_exp2f(eta.x), __builtin_amdgcn_exp2f(eta.y)};
+        const f32x2 ex = ABL == 1 ? eta : (f32x2){__builtin_amdgcn_exp2f(eta.x), __builtin_amdgcn_exp2f(eta.y)};
         const f32x2 u = ex * t2[h];
+        if (ABL != 4) {
         accU[m][h] += u;
         accUF[m][h] = u * fc + accUF[m][h];
-        dF = u * mv[m][h] + dF;
+        } else accU[m][h] = u;
+        if (ABL != 3) dF = u * mv[m][h] + dF; else dF = u;
       }
     }
+    if (ABL == 3) { if (dF.x == 123.f) dFpart[b0] = dF.y; continue; }
     if (!PF && b0 + 16 < n1) {
       craw = *reinterpret_cast<const uint4*>(cq + ((b0 + 16 + j) * 4 + q) * 8);
       f = F[b0 + 16 + j]; em = em2[b0 + 16 + j];
@@ -351,6 +355,183 @@ __global__ void __launch_bounds__(256) bwd_mfma4(const unsigned short* __restric
     for (int h = 0; h < 2; ++h) {
       const float a0 = row16_sum(accU[m][h].x), a1 = row16_sum(accU[m][h].y);
       const float b0_ = row16_sum(accUF[m][h].x), b1 = row16_sum(accUF[m][h].y);
+      if (j < 2) {
+        const int g = gbase + 16 * m + 4 * q + 2 * h + j;
+        if (g < G) { float* gp = gpart + ((long)blockIdx.y * G + g) * 2; gp[0] = j ? a1 : a0; gp[1] = mu[g] * (j ? b1 : b0_); }
+      }
+    }
+}
+// v5: MFMAs of batch b+1 issued before the VALU work of batch b (results parked in 16 VGPRs), operands two batches ahead
+template <int TL, int TAIL>
+__global__ void __launch_bounds__(256) bwd_mfma5(const unsigned short* __restrict__ cq, const float* __restrict__ F,
+                                                 const float* __restrict__ em2, const float* __restrict__ Lb,
+                                                 const float* __restrict__ mu, const float* __restrict__ Vs, const float* __restrict__ V,
+                                                 float* __restrict__ gpart, float* __restrict__ dFpart, long N, int G, long cchunk) {
+  const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+  const int wtile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int gbase = wtile * TL * 16;
+  if (gbase >= G) return;
+  bf16x8 Lf[TL];
+  f32x2 vs[TL][2], mv[TL][2], accU[TL][2], accUF[TL][2];
+#pragma unroll
+  for (int m = 0; m < TL; ++m) {
+    {
+      const int g = gbase + 16 * m + j; const bool ok = g < G; const int gg = ok ? g : G - 1;
+      unsigned short b[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) b[c] = (ok && q < 3) ? bf16_rn(Lb[(long)gg * 8 + c]) : 0;
+      uint4 raw = {(unsigned)b[0] | ((unsigned)b[1] << 16), (unsigned)b[2] | ((unsigned)b[3] << 16),
+                   (unsigned)b[4] | ((unsigned)b[5] << 16), (unsigned)b[6] | ((unsigned)b[7] << 16)};
+      Lf[m] = __builtin_bit_cast(bf16x8, raw);
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float a[2], b[2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) {
+        const int g = gbase + 16 * m + 4 * q + 2 * h + x; const bool ok = g < G; const int gg = ok ? g : G - 1;
+        a[x] = ok ? Vs[gg] : 0.f; b[x] = ok ? mu[gg] * V[gg] : 0.f;
+      }
+      vs[m][h] = (f32x2){a[0], a[1]}; mv[m][h] = (f32x2){b[0], b[1]};
+      accU[m][h] = (f32x2){0.f, 0.f}; accUF[m][h] = (f32x2){0.f, 0.f};
+    }
+  }
+  const long n0 = (long)blockIdx.y * cchunk, n1 = std::min(n0 + cchunk, N);
+  auto ldc = [&](long b0) { return *reinterpret_cast<const uint4*>(cq + ((b0 + j) * 4 + q) * 8); };
+  f32x4 t[TL];
+  {
+    const bf16x8 Cf = __builtin_bit_cast(bf16x8, ldc(n0));
+#pragma unroll
+    for (int m = 0; m < TL; ++m) t[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Lf[m], Cf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+  }
+  float f = F[n0 + j], em = em2[n0 + j];
+  uint4 craw = (n0 + 16 < n1) ? ldc(n0 + 16) : (uint4){0, 0, 0, 0};
+  for (long b0 = n0; b0 < n1; b0 += 16) {
+    const float fc = f, ec = em;
+    f32x4 tc[TL];
+#pragma unroll
+    for (int m = 0; m < TL; ++m) tc[m] = t[m];
+    const bf16x8 Cf = __builtin_bit_cast(bf16x8, craw);
+    if (b0 + 16 < n1) {
+#pragma unroll
+      for (int m = 0; m < TL; ++m) t[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Lf[m], Cf, (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+      f = F[b0 + 16 + j]; em = em2[b0 + 16 + j];
+    }
+    if (b0 + 32 < n1) craw = ldc(b0 + 32);
+    f32x2 dF = {0.f, 0.f};
+#pragma unroll
+    for (int m = 0; m < TL; ++m) {
+      const f32x2 t2[2] = {{tc[m][0], tc[m][1]}, {tc[m][2], tc[m][3]}};
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const f32x2 eta = vs[m][h] * fc - ec;
+        const f32x2 ex = {__builtin_amdgcn_exp2f(eta.x), __builtin_amdgcn_exp2f(eta.y)};
+        const f32x2 u = ex * t2[h];
+        accU[m][h] += u;
+        accUF[m][h] = u * fc + accUF[m][h];
+        dF = u * mv[m][h] + dF;
+      }
+    }
+    float d = dF.x + dF.y;
+    if (TAIL == 0) {
+      d += __shfl_xor(d, 16); d += __shfl_xor(d, 32);
+      const long n = b0 + j;
+      if (q == 0 && n < n1) dFpart[(long)wtile * N + n] = d;
+    } else if (TAIL == 1) {   // DPP row_bcast-free: two v_permlane-like swaps via ds_swizzle are not available across 16; use readlane-free adds
+      d += __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, d), 0));   // placeholder cost probe
+      const long n = b0 + j;
+      if (q == 0 && n < n1) dFpart[(long)wtile * N + n] = d;
+    } else {                  // no cross-lane sum: every k-group writes its own partial (4x the d/dF partial traffic)
+      const long n = b0 + j;
+      if (n < n1) dFpart[((long)wtile * 4 + q) * N + n] = d;
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < TL; ++m)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float a0 = row16_sum(accU[m][h].x), a1 = row16_sum(accU[m][h].y);
+      const float b0_ = row16_sum(accUF[m][h].x), b1 = row16_sum(accUF[m][h].y);
+      if (j < 2) {
+        const int g = gbase + 16 * m + 4 * q + 2 * h + j;
+        if (g < G) { float* gp = gpart + ((long)blockIdx.y * G + g) * 2; gp[0] = j ? a1 : a0; gp[1] = mu[g] * (j ? b1 : b0_); }
+      }
+    }
+}
+__device__ unsigned long long g_stamp[4096 * 2];
+__device__ unsigned long long g_abs[4096 * 2];
+// v6: v4 with scalar (non-packed) f32 math: VOP2 v_mul/v_add/v_fmac issue at 2 cycles per wave64 with >= 2 waves per SIMD
+// and do not pay the packed-op penalty beside MFMAs
+template <int TL>
+__global__ void __launch_bounds__(256) bwd_mfma6(const unsigned short* __restrict__ cq, const float* __restrict__ F,
+                                                 const float* __restrict__ em2, const float* __restrict__ Lb,
+                                                 const float* __restrict__ mu, const float* __restrict__ Vs, const float* __restrict__ V,
+                                                 float* __restrict__ gpart, float* __restrict__ dFpart, long N, int G, long cchunk) {
+  const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+  const int wtile = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int gbase = wtile * TL * 16;
+  if (gbase >= G) return;
+  bf16x8 Lf[TL];
+  float vs[TL][4], mv[TL][4], accU[TL][4], accUF[TL][4];
+#pragma unroll
+  for (int m = 0; m < TL; ++m) {
+    {
+      const int g = gbase + 16 * m + j; const bool ok = g < G; const int gg = ok ? g : G - 1;
+      unsigned short b[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) b[c] = (ok && q < 3) ? bf16_rn(Lb[(long)gg * 8 + c]) : 0;
+      uint4 raw = {(unsigned)b[0] | ((unsigned)b[1] << 16), (unsigned)b[2] | ((unsigned)b[3] << 16),
+                   (unsigned)b[4] | ((unsigned)b[5] << 16), (unsigned)b[6] | ((unsigned)b[7] << 16)};
+      Lf[m] = __builtin_bit_cast(bf16x8, raw);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int g = gbase + 16 * m + 4 * q + r; const bool ok = g < G; const int gg = ok ? g : G - 1;
+      vs[m][r] = ok ? Vs[gg] : 0.f; mv[m][r] = ok ? mu[gg] * V[gg] : 0.f;
+      accU[m][r] = 0.f; accUF[m][r] = 0.f;
+    }
+  }
+  const long n0 = (long)blockIdx.y * cchunk, n1 = std::min(n0 + cchunk, N);
+  uint4 craw = *reinterpret_cast<const uint4*>(cq + ((n0 + j) * 4 + q) * 8);
+  float f = F[n0 + j], em = em2[n0 + j];
+  const unsigned long long st0 = __builtin_amdgcn_s_memtime(), sr0 = __builtin_amdgcn_s_memrealtime();
+  for (long b0 = n0; b0 < n1; b0 += 16) {
+    const bf16x8 Cf = __builtin_bit_cast(bf16x8, craw);
+    const float fc = f, ec = em;
+    if (b0 + 16 < n1) {
+      craw = *reinterpret_cast<const uint4*>(cq + ((b0 + 16 + j) * 4 + q) * 8);
+      f = F[b0 + 16 + j]; em = em2[b0 + 16 + j];
+    }
+    float dF = 0.f;
+#pragma unroll
+    for (int m = 0; m < TL; ++m) {
+      f32x4 t = {0.f, 0.f, 0.f, 0.f};
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Lf[m], Cf, t, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float ex = __builtin_amdgcn_exp2f(fmaf(vs[m][r], fc, -ec));
+        const float u = ex * t[r];
+        accU[m][r] += u;
+        accUF[m][r] = fmaf(u, fc, accUF[m][r]);
+        dF = fmaf(u, mv[m][r], dF);
+      }
+    }
+    float d = dF;
+    d += __shfl_xor(d, 16); d += __shfl_xor(d, 32);
+    const long n = b0 + j;
+    if (q == 0 && n < n1) dFpart[(long)wtile * N + n] = d;
+  }
+  {
+    const unsigned long long st1 = __builtin_amdgcn_s_memtime(), sr1 = __builtin_amdgcn_s_memrealtime();
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    if (threadIdx.x == 0 && bid < 4096) { g_stamp[2 * bid] = st1 - st0; g_stamp[2 * bid + 1] = sr1 - sr0; g_abs[2 * bid] = sr0; g_abs[2 * bid + 1] = sr1; }
+  }
+#pragma unroll
+  for (int m = 0; m < TL; ++m)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float a0 = row16_sum(accU[m][2 * h]), a1 = row16_sum(accU[m][2 * h + 1]);
+      const float b0_ = row16_sum(accUF[m][2 * h]), b1 = row16_sum(accUF[m][2 * h + 1]);
       if (j < 2) {
         const int g = gbase + 16 * m + 4 * q + 2 * h + j;
         if (g < G) { float* gp = gpart + ((long)blockIdx.y * G + g) * 2; gp[0] = j ? a1 : a0; gp[1] = mu[g] * (j ? b1 : b0_); }
@@ -426,6 +607,43 @@ int main() {
       hipLaunchKernelGGL((bwd_mfma4<TL, PF>), grid, dim3(256), 0, 0, dq, dF, dem, dL, dmu, dVs, dV, dg, ddF, N, G, cchunk);   \
       CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError()); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (it) best = std::min(best, ms); } \
     char nm[64]; snprintf(nm, 64, "MFMA v4 transposed TL=%d pf=%d", TL, (int)PF); check(nwt, cs, nm, best); }
-  RUNM4(4, true, 50); RUNM4(4, true, 100); RUNM4(4, false, 100); RUNM4(4, true, 200); RUNM4(8, true, 50); RUNM4(8, true, 100); RUNM4(8, false, 100); RUNM4(2, true, 50); RUNM4(2, true, 100); RUNM4(6, true, 100);
+  RUNM4(4, true, 51); RUNM4(4, true, 100);
+#define RUNM4A(TL, PF, AB, csplit_req)                                                                                     \
+  { long cchunk = (N + (csplit_req) - 1) / (csplit_req); cchunk = (cchunk + 15) / 16 * 16; int cs = (int)((N + cchunk - 1) / cchunk); \
+    const int nwt = (G + TL * 16 - 1) / (TL * 16); dim3 grid((nwt + 3) / 4, cs); float best = 1e9;                       \
+    for (int it = 0; it < 4; ++it) { CK(hipMemset(ddF, 0, (size_t)nwt * N * 4)); CK(hipEventRecord(e0));                  \
+      hipLaunchKernelGGL((bwd_mfma4<TL, PF, AB>), grid, dim3(256), 0, 0, dq, dF, dem, dL, dmu, dVs, dV, dg, ddF, N, G, cchunk);   \
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError()); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (it) best = std::min(best, ms); } \
+    char nm[64]; snprintf(nm, 64, "v4 TL=%d abl=%d", TL, AB); check(nwt, cs, nm, best); }
+  RUNM4(2, true, 51); RUNM4(2, true, 102); RUNM4(8, true, 51); RUNM4(8, true, 26); RUNM4(3, true, 51); RUNM4(6, true, 51);
+#define RUNM5(TL, TAILV, csplit_req)                                                                                     \
+  { long cchunk = (N + (csplit_req) - 1) / (csplit_req); cchunk = (cchunk + 15) / 16 * 16; int cs = (int)((N + cchunk - 1) / cchunk); \
+    const int nwt = (G + TL * 16 - 1) / (TL * 16); dim3 grid((nwt + 3) / 4, cs); float best = 1e9;                       \
+    for (int it = 0; it < 4; ++it) { CK(hipMemset(ddF, 0, (size_t)nwt * N * 4)); CK(hipEventRecord(e0));                  \
+      hipLaunchKernelGGL((bwd_mfma5<TL, TAILV>), grid, dim3(256), 0, 0, dq, dF, dem, dL, dmu, dVs, dV, dg, ddF, N, G, cchunk);   \
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError()); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (it) best = std::min(best, ms); } \
+    char nm[64]; snprintf(nm, 64, "v5 pipelined TL=%d tail=%d", TL, TAILV); check(nwt, cs, nm, best); }
+#define RUNM6(TL, csplit_req)                                                                                     \
+  { long cchunk = (N + (csplit_req) - 1) / (csplit_req); cchunk = (cchunk + 15) / 16 * 16; int cs = (int)((N + cchunk - 1) / cchunk); \
+    const int nwt = (G + TL * 16 - 1) / (TL * 16); dim3 grid((nwt + 3) / 4, cs); float best = 1e9;                       \
+    for (int it = 0; it < 4; ++it) { CK(hipMemset(ddF, 0, (size_t)nwt * N * 4)); CK(hipEventRecord(e0));                  \
+      hipLaunchKernelGGL((bwd_mfma6<TL>), grid, dim3(256), 0, 0, dq, dF, dem, dL, dmu, dVs, dV, dg, ddF, N, G, cchunk);   \
+      CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipGetLastError()); float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (it) best = std::min(best, ms); } \
+    char nm[64]; snprintf(nm, 64, "v6 scalar TL=%d", TL); check(nwt, cs, nm, best); \
+    { std::vector<unsigned long long> st(4096 * 2); CK(hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamp), st.size() * 8)); \
+      const int nb = std::min(4096, (int)(grid.x * grid.y)); std::vector<double> ck, cyc; for (int i = 0; i < nb; ++i) if (st[2*i+1] > 0) { ck.push_back((double)st[2*i] / (double)st[2*i+1] * 100.0); cyc.push_back((double)st[2*i]); } \
+      std::sort(ck.begin(), ck.end()); std::sort(cyc.begin(), cyc.end()); \
+      { std::vector<unsigned long long> ab(4096 * 2); CK(hipMemcpyFromSymbol(ab.data(), HIP_SYMBOL(g_abs), ab.size() * 8)); \
+        unsigned long long t0 = ~0ull, t1 = 0; for (int i = 0; i < nb; ++i) { t0 = std::min(t0, ab[2*i]); t1 = std::max(t1, ab[2*i+1]); } \
+        int late = 0; double mid = 0; for (int i = 0; i < nb; ++i) { if (ab[2*i] - t0 > 2000) ++late; } \
+        int maxc = 0; for (int i = 0; i < nb; i += 7) { int c = 0; for (int k = 0; k < nb; ++k) if (ab[2*k] <= ab[2*i] && ab[2*k+1] > ab[2*i]) ++c; maxc = std::max(maxc, c); } \
+        { std::vector<double> du; for (int i = 0; i < nb; ++i) du.push_back((ab[2*i+1] - ab[2*i]) / 100.0); std::vector<double> sd = du; std::sort(sd.begin(), sd.end()); \
+          printf("   loop us: p5 %.0f p25 %.0f p50 %.0f p75 %.0f p95 %.0f max %.0f;", sd[nb/20], sd[nb/4], sd[nb/2], sd[3*nb/4], sd[19*nb/20], sd[nb-1]); \
+          double xs[8] = {0}; int xc[8] = {0}; for (int i = 0; i < nb; ++i) { xs[i % 8] += du[i]; xc[i % 8]++; } printf(" mean by bid%%8:"); for (int x = 0; x < 8; ++x) printf(" %.0f", xs[x] / xc[x]); \
+          const int gx = (int)grid.x; double bs[64] = {0}; int bc[64] = {0}; for (int i = 0; i < nb; ++i) { bs[(i % gx) % 64] += du[i]; bc[(i % gx) % 64]++; } printf("\n   mean by blockIdx.x:"); for (int x = 0; x < gx && x < 64; ++x) printf(" %.0f", bs[x] / bc[x]); printf("\n"); } \
+        printf("   blocks %d: span %.1f us, %d blocks started > 20 us after the first, max concurrent blocks %d\n", nb, (t1 - t0) / 100.0, late, maxc); (void)mid; } \
+      printf("   in-kernel clock median %.0f MHz (min %.0f max %.0f), loop cycles median %.0f, batches per wave %ld -> %.0f cycles per batch per wave\n", ck[ck.size()/2], ck.front(), ck.back(), cyc[cyc.size()/2], (long)(cchunk / 16), cyc[cyc.size()/2] / (cchunk / 16)); } }
+  RUNM6(4, 51); RUNM6(4, 100); RUNM6(2, 51); RUNM6(8, 51); RUNM6(6, 51);
+  RUNM4A(4, true, 1, 51); RUNM4A(4, true, 2, 51); RUNM4A(4, true, 3, 51); RUNM4A(4, true, 4, 51);
   return 0;
 }
