@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "ca_kernels.hip.h"
@@ -116,6 +117,8 @@ struct ca_engine {
   bool fused_ok = false, look_valid = false; int64_t look_slot = 0; int frow = 8;
   float *Mb2 = nullptr, *mu32B = nullptr, *Zpart2 = nullptr; double* gene_partB = nullptr;
   bool y_defer = false;
+  hipStream_t stream3 = nullptr; hipEvent_t ev_elbo = nullptr;   // ELBO read-back beside the speculative backward sweep (ca_run)
+  bool bwd_ready = false; int64_t bwd_slot = -1;
   bool fwd_mfma = false; int fsplit = 1, fkchunk = 1, nk32 = 1; unsigned short* Mq = nullptr;   // matrix-core forward sweep
   // matrix-core backward sweep (k_bwd_mfma): bf16 parts of coef, its own cell split
   bool bwd_mfma = false; unsigned short* coefq = nullptr; int64_t N16 = 0, cchunk_m = 0; int csplit_m = 1, nwt = 0;
@@ -539,9 +542,9 @@ int setup_global_sums(ca_engine* h) {
 
 // Backward half of a train pass.  Needs: coef / dgl from the cell epilogue, mu of the same eps, red[0..3+C) cell sums.
 // cell_sums_global: red[0..3+C) was already all-reduced by the monitor pass that produced it (fused path).
-int train_tail(ca_engine* h, const float* eps, const float* mu32, int apply, double* elbo_dst, bool cell_sums_global) {
-  const int N256 = cdiv(h->N, CA_TB);
-  float lr_t = 0.f;
+// backward half of a train pass: the sweep, the column sums of its partials and the cross-shard reduction.  Changes no
+// variable, so ca_run may issue it before it knows whether the loop goes on (train_bwd_speculative).
+int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
   const int W_ = h->S + h->D;
   if (h->bwd_mfma) {
     constexpr int TL = 4;
@@ -574,6 +577,13 @@ int train_tail(ca_engine* h, const float* eps, const float* mu32, int apply, dou
   if (cell_sums_global) CACK(allreduce(h, h->red + h->off_g, h->red_n - h->off_g));
   else CACK(allreduce(h, h->red, h->red_n));
   if (h->opt.world > 1 || h->comm || h->host_ar) h->ycache_valid = false;   // red_y now holds the GLOBAL sum
+  return CA_OK;
+}
+
+// update half: per-gene / per-cell gradients from the reduced sums, Adam when `apply`
+int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
+  const int N256 = cdiv(h->N, CA_TB);
+  float lr_t = 0.f;
   if (apply) {
     // lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t), float32 like TF's _prepare()/_apply_dense
     lr_t = (float)h->opt.learning_rate * sqrtf(1.f - h->b2p) / (1.f - h->b1p);
@@ -605,6 +615,11 @@ int train_tail(ca_engine* h, const float* eps, const float* mu32, int apply, dou
     }
   }
   return CA_OK;
+}
+
+int train_tail(ca_engine* h, const float* eps, const float* mu32, int apply, double* elbo_dst, bool cell_sums_global) {
+  CACK(train_bwd(h, mu32, cell_sums_global));
+  return train_update(h, eps, apply, elbo_dst);
 }
 
 // One evaluation of the model for the eps of device slot `eps_slot`.
@@ -720,6 +735,7 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst) {
                             h->vmm_part, h->vmm, h->D, h->dir_const));
   h->look_valid = true;
   h->look_slot = slotB;
+  h->bwd_ready = false;
   return CA_OK;
 }
 
@@ -727,7 +743,30 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst) {
 int train_from_lookahead(ca_engine* h, int64_t slot) {
   if (!h->look_valid || h->look_slot != slot) { h->err = "internal: no look-ahead forward for this eps slot"; return CA_ERR_STATE; }
   h->look_valid = false;
-  return train_tail(h, h->eps_dev + slot * (int64_t)h->G, h->mu32B, 1, nullptr, true);
+  const bool have_bwd = h->bwd_ready && h->bwd_slot == slot;
+  h->bwd_ready = false;
+  if (!have_bwd) CACK(train_bwd(h, h->mu32B, true));
+  return train_update(h, h->eps_dev + slot * (int64_t)h->G, 1, nullptr);
+}
+
+// ca_run: issue the backward half of the NEXT train pass (its forward half came with the monitor pass just queued)
+// before the host reads that monitor pass's ELBO, so the read-back and the stop test run beside the sweep instead of
+// draining the GPU every iteration.  If the loop stops, the sweep's scratch results are simply never used.
+int train_bwd_speculative(ca_engine* h) {
+  if (!h->look_valid) return CA_OK;
+  CACK(train_bwd(h, h->mu32B, true));
+  h->bwd_ready = true;
+  h->bwd_slot = h->look_slot;
+  return CA_OK;
+}
+// ELBO values written by kernels already queued on the main stream at the time of `ev_elbo`, read without waiting
+// for anything queued after it
+int read_doubles_at_event(ca_engine* h, const double* dev, double* out, int n) {
+  HIPCK(h, hipStreamWaitEvent(h->stream3, h->ev_elbo, 0));
+  HIPCK(h, hipMemcpyAsync(h->host_pinned, dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream3));
+  HIPCK(h, hipStreamSynchronize(h->stream3));
+  for (int i = 0; i < n; ++i) out[i] = h->host_pinned[i];
+  return CA_OK;
 }
 
 // monitor pass on eps slot m; with next >= 0 (and the fused path available) also the forward half of the train
@@ -782,7 +821,19 @@ int stage_eps(ca_engine* h, const float* eps_stream, int64_t have, int64_t need)
     HIPCK(h, hipStreamSynchronize(h->stream));
   } else {
     std::vector<float> buf((size_t)need * per);
-    for (int64_t d = 0; d < need; ++d) ca_philox::normal_draw(h->opt.seed, h->draw + d, per, buf.data() + d * per);
+    // counter-based stream: draws are independent, so a long run's worth (2 + 2 max_iter draws) is generated by a few
+    // host threads -- same values whatever the thread count
+    const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(need, 16), (int64_t)std::thread::hardware_concurrency()));
+    if (nt > 1 && need * per >= (1 << 16)) {
+      std::vector<std::thread> pool;
+      const uint64_t seed = h->opt.seed, base = h->draw;
+      float* out = buf.data();
+      for (int64_t t = 0; t < nt; ++t)
+        pool.emplace_back([=]() { for (int64_t d = t; d < need; d += nt) ca_philox::normal_draw(seed, base + d, per, out + d * per); });
+      for (auto& th : pool) th.join();
+    } else {
+      for (int64_t d = 0; d < need; ++d) ca_philox::normal_draw(h->opt.seed, h->draw + d, per, buf.data() + d * per);
+    }
     h->draw += need;
     HIPCK(h, hipMemcpyAsync(h->eps_dev, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
@@ -952,9 +1003,13 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   HIPCK(h, hipGetDeviceProperties(&prop, h->device));
   h->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   HIPCK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  // (a low-priority side stream, or s_setprio 3 in the sweep, only moves the Y stream's time out from under the sweep:
+  //  measured 2090 -> 2100 and 2090 -> 1730 it/s; the cell epilogue waits for it either way)
   HIPCK(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
   HIPCK(h, hipEventCreateWithFlags(&h->ev_params, hipEventDisableTiming));
   HIPCK(h, hipEventCreateWithFlags(&h->ev_ydone, hipEventDisableTiming));
+  HIPCK(h, hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
+  HIPCK(h, hipEventCreateWithFlags(&h->ev_elbo, hipEventDisableTiming));
   if (const char* e = getenv("CA_ASYNC_Y")) h->async_y = atoi(e) != 0;
   HIPCK(h, hipHostMalloc((void**)&h->host_pinned, 64 * sizeof(double)));
   CACK(upload_y(h, p));
@@ -1269,6 +1324,8 @@ int ca_destroy(ca_handle h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
+  if (h->stream3) { hipStreamSynchronize(h->stream3); hipStreamDestroy(h->stream3); }
+  if (h->ev_elbo) hipEventDestroy(h->ev_elbo);
   if (h->ev_params) hipEventDestroy(h->ev_params);
   if (h->ev_ydone) hipEventDestroy(h->ev_ydone);
   if (h->comm) g_rccl.CommDestroy(h->comm);
@@ -1389,7 +1446,9 @@ int ca_run(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_strea
   CACK(run_pass(h, 0, CA_MODE_GINIT, 0, nullptr));                      // :368-369
   CACK(monitor_pass(h, 1, max_iter >= 1 ? 2 : -1, h->elbo_dev));        // :372 (+ forward half of the first train pass)
   double val;
-  CACK(read_doubles(h, h->elbo_dev, &val, 1));
+  HIPCK(h, hipEventRecord(h->ev_elbo, h->stream));
+  CACK(train_bwd_speculative(h));
+  CACK(read_doubles_at_event(h, h->elbo_dev, &val, 1));
   trace[0] = val; *n_elbo = 1;
   if (std::isnan(val)) { h->err = "Initial elbo is NA"; return CA_ERR_NAN; }   // :374-376
   double diffs[10];
@@ -1398,7 +1457,9 @@ int ca_run(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_strea
     CACK(train_pass(h, 2 * (int64_t)i));                                // :401
     CACK(monitor_pass(h, 2 * (int64_t)i + 1, i < max_iter ? 2 * (int64_t)i + 2 : -1, h->elbo_dev + i));   // :403
     double nv;
-    CACK(read_doubles(h, h->elbo_dev + i, &nv, 1));
+    HIPCK(h, hipEventRecord(h->ev_elbo, h->stream));
+    CACK(train_bwd_speculative(h));     // backward half of train pass i+1 runs while the host looks at ELBO i
+    CACK(read_doubles_at_event(h, h->elbo_dev + i, &nv, 1));
     const double diff = (nv - val) / std::fabs(val);
     for (int j = 0; j < 9; ++j) diffs[j] = diffs[j + 1];
     diffs[9] = diff;
