@@ -949,6 +949,157 @@ __global__ void __launch_bounds__(CA_TB) k_bwd(const float* __restrict__ coef /*
   }
 }
 
+// TF1 Adam (tf.train.AdamOptimizer, R/inference-tflow.R:345): epsilon outside the bias correction
+__device__ __forceinline__ void ca_adam(float& th, float& m, float& v, float g, float lr_t, float b1, float b2, float eps) {
+  m = b1 * m + (1.f - b1) * g;
+  v = b2 * v + (1.f - b2) * g * g;
+  th = th - lr_t * m / (sqrtf(v) + eps);
+}
+
+// ------------------------------------------------------------------ ELBO assembly + the O(K + C) variables
+// red[0..2] cell sums (all-reduced when sharded), red[3..3+C) sum_n gamma_nc; gene_part block partials.
+// Uses W^2 sums taken BEFORE this step's Adam update of W (k_gene_pre), as autodiff does.
+// One 256-thread block runs the body: as its own launch (k_final_small), or as an extra block of a kernel it does not
+// depend on -- the monitor pass's ELBO assembly rides on the backward sweep, the train pass's chi / alpha update on
+// the per-cell Adam kernel -- so the fp64 exp/log chains of this single wave are off the critical path.
+struct ca_small_args {
+  int enabled;
+  double* red; const double* gene_part; int ngblk;
+  float *vchi, *alpha_u, *m_v, *v_v, *m_a, *v_a, *g_v, *g_a;
+  double *elbo_out, *terms_out;
+  int G, C, K, apply;
+  float lr_t, b1, b2, aeps;
+  const float* vmm_part; float* vmm; int D;
+  double dir_const;
+  const double* cell_part; int ncblk;   // when set: first reduce the cell epilogue's block partials into red[0 .. 3 + C)
+  double* host_out; unsigned long long* host_flag; unsigned long long host_seq;   // ELBO mirrored into pinned host memory (ca_run)
+};
+
+__device__ __forceinline__ void ca_final_small_body(const ca_small_args& sa) {
+  __shared__ double sm[CA_TB];
+  __shared__ double gs[3 + 16];
+  if (sa.cell_part) {   // k_reduce_part folded in (same fixed order: strided partial sums, then the block tree)
+    const int Wc = 3 + sa.C;
+    for (int j = 0; j < Wc; ++j) {
+      double acc = 0.0;
+      for (int b = threadIdx.x; b < sa.ncblk; b += CA_TB) acc += sa.cell_part[(int64_t)b * Wc + j];
+      const double r = ca_block_sum(acc, sm);
+      if (threadIdx.x == 0) sa.red[j] = r;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  const int W_ = 3 + sa.K;
+  for (int j = 0; j < W_; ++j) {
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < sa.ngblk; b += CA_TB) acc += sa.gene_part[(int64_t)b * W_ + j];
+    const double r = ca_block_sum(acc, sm);
+    if (threadIdx.x == 0) gs[j] = r;
+  }
+  // range of the updated V' over the gene blocks (k_vmm_final folded in)
+  if (sa.apply && sa.vmm_part && (int)threadIdx.x < sa.D) {
+    const int d = threadIdx.x;
+    float mn = INFINITY, mx2 = -INFINITY;
+    for (int b = 0; b < sa.ngblk; ++b) {
+      mn = fminf(mn, sa.vmm_part[((int64_t)b * 2 + 0) * sa.D + d]);
+      mx2 = fmaxf(mx2, sa.vmm_part[((int64_t)b * 2 + 1) * sa.D + d]);
+    }
+    sa.vmm[d] = mn;
+    sa.vmm[sa.D + d] = mx2;
+  }
+  __syncthreads();
+  if (threadIdx.x >= 64) return;
+  // One lane per clone (and per latent dimension): the fp64 exp/log chains of this kernel are long, so they
+  // run side by side in wave 0 and meet through xor-shuffles.  (C <= 64 here; larger C takes the loop form.)
+  const int c = threadIdx.x;
+  const double conc = 1.0 / (double)sa.C;
+  auto wsum = [](double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+  auto wmax = [](double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
+    return v;
+  };
+  double dir_sum, dla_c = 0.0, al_c = 0.0, dla_sum;
+  if (sa.C <= 64) {
+    const double au = c < sa.C ? (double)sa.alpha_u[c] : -INFINITY;
+    const double mx = wmax(au);
+    const double se = wsum(c < sa.C ? exp(au - mx) : 0.0);
+    const double lse = mx + log(se);
+    al_c = c < sa.C ? exp(au - lse) : 0.0;
+    dla_c = c < sa.C ? sa.red[3 + c] + (conc - 1.0) * al_c / (al_c + 1e-3) : 0.0;
+    dir_sum = wsum(c < sa.C ? (conc - 1.0) * log(al_c + 1e-3) : 0.0);   // Dirichlet(1/C) log-pdf at alpha + 1e-3 (:324)
+    dla_sum = wsum(dla_c);
+  } else {
+    double mx = -INFINITY, se = 0.0;
+    for (int j = 0; j < sa.C; ++j) mx = fmax(mx, (double)sa.alpha_u[j]);
+    for (int j = 0; j < sa.C; ++j) se += exp((double)sa.alpha_u[j] - mx);
+    const double lse = mx + log(se);
+    dir_sum = 0.0; dla_sum = 0.0;
+    for (int j = 0; j < sa.C; ++j) {
+      const double al = exp((double)sa.alpha_u[j] - lse);
+      dir_sum += (conc - 1.0) * log(al + 1e-3);
+      dla_sum += sa.red[3 + j] + (conc - 1.0) * al / (al + 1e-3);
+    }
+  }
+  // chi terms: lane k < K
+  double ep_k = 0.0;
+  if (c < sa.K) {
+    const double v = (double)sa.vchi[c], chi = exp(v);
+    ep_k = -0.5 * chi * gs[3 + c] + (double)sa.G * (0.5 * v - 0.5 * CA_LOG2PI) + (v - chi);
+    const double gv = -0.5 * chi * gs[3 + c] + 0.5 * (double)sa.G + 1.0 - chi;
+    sa.g_v[c] = (float)gv;
+    if (sa.apply) {
+      float th = sa.vchi[c], m = sa.m_v[c], vv = sa.v_v[c];
+      ca_adam(th, m, vv, -(float)gv, sa.lr_t, sa.b1, sa.b2, sa.aeps);
+      sa.vchi[c] = th; sa.m_v[c] = m; sa.v_v[c] = vv;
+    }
+  }
+  const double ep_chi = wsum(ep_k);
+  if (c == 0) {
+    const double EE = sa.red[0] + gs[0];
+    const double Ep = sa.red[1] + gs[1] + sa.dir_const + dir_sum + ep_chi;
+    const double Eq = sa.red[2] + gs[2];
+    if (sa.elbo_out) *sa.elbo_out = EE + Ep - Eq;
+    if (sa.terms_out) { sa.terms_out[0] = EE; sa.terms_out[1] = Ep; sa.terms_out[2] = Eq; }
+    if (sa.host_out) {   // the host loop of ca_run polls the flag instead of draining the stream
+      *sa.host_out = EE + Ep - Eq;
+      __threadfence_system();
+      __hip_atomic_store(sa.host_flag, sa.host_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  if (sa.C <= 64) {
+    if (c < sa.C) {
+      const float ga = (float)(dla_c - al_c * dla_sum);
+      sa.g_a[c] = ga;
+      if (sa.apply) {
+        float th = sa.alpha_u[c], m = sa.m_a[c], vv = sa.v_a[c];
+        ca_adam(th, m, vv, -ga, sa.lr_t, sa.b1, sa.b2, sa.aeps);
+        sa.alpha_u[c] = th; sa.m_a[c] = m; sa.v_a[c] = vv;
+      }
+    }
+  } else if (c == 0) {
+    double mx = -INFINITY, se = 0.0;
+    for (int j = 0; j < sa.C; ++j) mx = fmax(mx, (double)sa.alpha_u[j]);
+    for (int j = 0; j < sa.C; ++j) se += exp((double)sa.alpha_u[j] - mx);
+    const double lse = mx + log(se);
+    for (int j = 0; j < sa.C; ++j) {
+      const double al = exp((double)sa.alpha_u[j] - lse);
+      const double dla = sa.red[3 + j] + (conc - 1.0) * al / (al + 1e-3);
+      sa.g_a[j] = (float)(dla - al * dla_sum);
+    }
+    if (sa.apply)
+      for (int j = 0; j < sa.C; ++j) {
+        float th = sa.alpha_u[j], m = sa.m_a[j], vv = sa.v_a[j];
+        ca_adam(th, m, vv, -sa.g_a[j], sa.lr_t, sa.b1, sa.b2, sa.aeps);
+        sa.alpha_u[j] = th; sa.m_a[j] = m; sa.v_a[j] = vv;
+      }
+  }
+}
+
 // ------------------------------------------------------------------ backward sweep on the matrix cores
 // t_ng = sum_c coef_nc L_gc as ONE v_mfma_f32_16x16x32_bf16 per 16 genes x 16 cells: coef is split into three bf16
 // parts by the cell epilogue (K = 3 parts x 8 clones = 24 of 32), copy numbers that are bf16-exact (integers up to
@@ -971,8 +1122,13 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
                                                     const float* __restrict__ Lb /*[G][8]*/, const float* __restrict__ mu,
                                                     const float* __restrict__ Vs, const float* __restrict__ V,
                                                     float* __restrict__ gpart /*[csplit][G][S+1]*/, float* __restrict__ dFpart /*[gridDim.x][N]*/,
-                                                    int64_t N, int G, int64_t cchunk, int S, int sidx, int first_s, int first) {
+                                                    int64_t N, int G, int64_t cchunk, int S, int sidx, int first_s, int first,
+                                                    ca_small_args tail, int xblocks) {
   extern __shared__ float ca_lds[];   // [4 waves][cchunk]: per-wave d/dF of the block's cell slice, summed at the end
+  if ((int)blockIdx.x >= xblocks) {   // the extra block column: its first block assembles the previous pass's ELBO
+    if (blockIdx.y == 0 && tail.enabled) ca_final_small_body(tail);
+    return;
+  }
   const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
   const int wv = threadIdx.x >> 6;
   const int wtile = blockIdx.x * (CA_TB / 64) + wv;
@@ -982,15 +1138,21 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
   ca_f32x2 vs[TL][2], mv[TL][2], accU[TL][2], accUF[TL][2];
 #pragma unroll
   for (int m = 0; m < TL; ++m) {
-    {  // MFMA A operand: lane (row j, k-group q) holds L[gene gbase+16m+j][0..8), once per coef part (q < 3)
+    {  // MFMA A operand: lane (row j, k-group q) holds L[gene gbase+16m+j][0..8), once per coef part (q < 3).
+       // All prologue loads are unconditional on a clamped index and masked afterwards: guarded loads compile to one
+       // branch + wait each and ran back to back (13 us per block, tools/bwd_lab3.hip)
       const int g = gbase + 16 * m + j;
-      const bool ok = g < G;
-      const int gg = ok ? g : G - 1;
+      const bool ok = g < G && q < 3;
+      const int gg = g < G ? g : G - 1;
+      const float4 r0 = *reinterpret_cast<const float4*>(Lb + (int64_t)gg * CA_CW);
+      const float4 r1 = *reinterpret_cast<const float4*>(Lb + (int64_t)gg * CA_CW + 4);
+      const float lr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
       unsigned short b[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) b[c] = (ok && q < 3) ? ca_bf16_rn(Lb[(int64_t)gg * CA_CW + c]) : 0;
-      const uint4 raw = {(unsigned)b[0] | ((unsigned)b[1] << 16), (unsigned)b[2] | ((unsigned)b[3] << 16),
-                         (unsigned)b[4] | ((unsigned)b[5] << 16), (unsigned)b[6] | ((unsigned)b[7] << 16)};
+      for (int c = 0; c < 8; ++c) b[c] = ca_bf16_rn(lr[c]);
+      const unsigned msk = ok ? 0xFFFFFFFFu : 0u;
+      const uint4 raw = {((unsigned)b[0] | ((unsigned)b[1] << 16)) & msk, ((unsigned)b[2] | ((unsigned)b[3] << 16)) & msk,
+                         ((unsigned)b[4] | ((unsigned)b[5] << 16)) & msk, ((unsigned)b[6] | ((unsigned)b[7] << 16)) & msk};
       Lf[m] = __builtin_bit_cast(ca_bf16x8, raw);
     }
 #pragma unroll
@@ -1001,8 +1163,9 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
         const int g = gbase + 16 * m + 4 * q + 2 * h + x;
         const bool ok = g < G;
         const int gg = ok ? g : G - 1;
-        a[x] = ok ? Vs[gg] : 0.f;
-        b[x] = ok ? mu[gg] * V[gg] : 0.f;
+        const float vsv = Vs[gg], muv = mu[gg], vv = V[gg];
+        a[x] = ok ? vsv : 0.f;
+        b[x] = ok ? muv * vv : 0.f;
       }
       vs[m][h] = (ca_f32x2){a[0], a[1]};
       mv[m][h] = (ca_f32x2){b[0], b[1]};
@@ -1442,13 +1605,6 @@ __global__ void __launch_bounds__(CA_TB) k_reduce_part(const double* __restrict_
   if (threadIdx.x == 0) out[j] = r;
 }
 
-// TF1 Adam (tf.train.AdamOptimizer, R/inference-tflow.R:345): epsilon outside the bias correction
-__device__ __forceinline__ void ca_adam(float& th, float& m, float& v, float g, float lr_t, float b1, float b2, float eps) {
-  m = b1 * m + (1.f - b1) * g;
-  v = b2 * v + (1.f - b2) * g * g;
-  th = th - lr_t * m / (sqrtf(v) + eps);
-}
-
 // ------------------------------------------------------------------ per-gene gradients + Adam
 // d ELBO / d loc, ls (through mu = softplus(loc + exp(ls) eps)), W, beta; minimises -ELBO.
 __global__ void __launch_bounds__(CA_TB) k_final_gene(const double* __restrict__ red_g /*[G][S+D]*/, const double* __restrict__ red_y /*[G][K]*/,
@@ -1525,125 +1681,8 @@ __global__ void __launch_bounds__(CA_TB) k_final_gene(const double* __restrict__
   }
 }
 
-// ------------------------------------------------------------------ ELBO assembly + the O(K + C) variables
-// red[0..2] cell sums (all-reduced when sharded), red[3..3+C) sum_n gamma_nc; gene_part block partials.
-// Uses W^2 sums taken BEFORE this step's Adam update of W (k_gene_pre), as autodiff does.
-__global__ void __launch_bounds__(CA_TB) k_final_small(const double* __restrict__ red, const double* __restrict__ gene_part, int ngblk,
-                                                       float* __restrict__ vchi, float* __restrict__ alpha_u,
-                                                       float* __restrict__ m_v, float* __restrict__ v_v, float* __restrict__ m_a,
-                                                       float* __restrict__ v_a, float* __restrict__ g_v, float* __restrict__ g_a,
-                                                       double* __restrict__ elbo_out, double* __restrict__ terms_out, int G, int C, int K,
-                                                       int apply, float lr_t, float b1, float b2, float aeps,
-                                                       const double* __restrict__ cell_part, int ncblk, double* __restrict__ red_w,
-                                                       const float* __restrict__ vmm_part, float* __restrict__ vmm, int D,
-                                                       double dir_const) {
-  __shared__ double sm[CA_TB];
-  __shared__ double gs[3 + 16];
-  const int W_ = 3 + K;
-  for (int j = 0; j < W_; ++j) {
-    double a = 0.0;
-    for (int b = threadIdx.x; b < ngblk; b += CA_TB) a += gene_part[(int64_t)b * W_ + j];
-    const double r = ca_block_sum(a, sm);
-    if (threadIdx.x == 0) gs[j] = r;
-  }
-  // range of the updated V' over the gene blocks (k_vmm_final folded in)
-  if (apply && vmm_part && (int)threadIdx.x < D) {
-    const int d = threadIdx.x;
-    float mn = INFINITY, mx2 = -INFINITY;
-    for (int b = 0; b < ngblk; ++b) {
-      mn = fminf(mn, vmm_part[((int64_t)b * 2 + 0) * D + d]);
-      mx2 = fmaxf(mx2, vmm_part[((int64_t)b * 2 + 1) * D + d]);
-    }
-    vmm[d] = mn;
-    vmm[D + d] = mx2;
-  }
-  __syncthreads();
-  if (threadIdx.x >= 64) return;
-  // One lane per clone (and per latent dimension): the fp64 exp/log chains of this kernel are long, so they
-  // run side by side in wave 0 and meet through xor-shuffles.  (C <= 64 here; larger C takes the loop form.)
-  const int c = threadIdx.x;
-  const double conc = 1.0 / (double)C;
-  auto wsum = [](double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-  };
-  auto wmax = [](double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64));
-    return v;
-  };
-  double dir_sum, dla_c = 0.0, al_c = 0.0, dla_sum;
-  if (C <= 64) {
-    const double au = c < C ? (double)alpha_u[c] : -INFINITY;
-    const double mx = wmax(au);
-    const double se = wsum(c < C ? exp(au - mx) : 0.0);
-    const double lse = mx + log(se);
-    al_c = c < C ? exp(au - lse) : 0.0;
-    dla_c = c < C ? red[3 + c] + (conc - 1.0) * al_c / (al_c + 1e-3) : 0.0;
-    dir_sum = wsum(c < C ? (conc - 1.0) * log(al_c + 1e-3) : 0.0);   // Dirichlet(1/C) log-pdf at alpha + 1e-3 (:324)
-    dla_sum = wsum(dla_c);
-  } else {
-    double mx = -INFINITY, se = 0.0;
-    for (int j = 0; j < C; ++j) mx = fmax(mx, (double)alpha_u[j]);
-    for (int j = 0; j < C; ++j) se += exp((double)alpha_u[j] - mx);
-    const double lse = mx + log(se);
-    dir_sum = 0.0; dla_sum = 0.0;
-    for (int j = 0; j < C; ++j) {
-      const double al = exp((double)alpha_u[j] - lse);
-      dir_sum += (conc - 1.0) * log(al + 1e-3);
-      dla_sum += red[3 + j] + (conc - 1.0) * al / (al + 1e-3);
-    }
-  }
-  // chi terms: lane k < K
-  double ep_k = 0.0;
-  if (c < K) {
-    const double v = (double)vchi[c], chi = exp(v);
-    ep_k = -0.5 * chi * gs[3 + c] + (double)G * (0.5 * v - 0.5 * CA_LOG2PI) + (v - chi);
-    const double gv = -0.5 * chi * gs[3 + c] + 0.5 * (double)G + 1.0 - chi;
-    g_v[c] = (float)gv;
-    if (apply) {
-      float th = vchi[c], m = m_v[c], vv = v_v[c];
-      ca_adam(th, m, vv, -(float)gv, lr_t, b1, b2, aeps);
-      vchi[c] = th; m_v[c] = m; v_v[c] = vv;
-    }
-  }
-  const double ep_chi = wsum(ep_k);
-  if (c == 0) {
-    const double EE = red[0] + gs[0];
-    const double Ep = red[1] + gs[1] + dir_const + dir_sum + ep_chi;
-    const double Eq = red[2] + gs[2];
-    if (elbo_out) *elbo_out = EE + Ep - Eq;
-    if (terms_out) { terms_out[0] = EE; terms_out[1] = Ep; terms_out[2] = Eq; }
-  }
-  if (C <= 64) {
-    if (c < C) {
-      const float ga = (float)(dla_c - al_c * dla_sum);
-      g_a[c] = ga;
-      if (apply) {
-        float th = alpha_u[c], m = m_a[c], vv = v_a[c];
-        ca_adam(th, m, vv, -ga, lr_t, b1, b2, aeps);
-        alpha_u[c] = th; m_a[c] = m; v_a[c] = vv;
-      }
-    }
-  } else if (c == 0) {
-    double mx = -INFINITY, se = 0.0;
-    for (int j = 0; j < C; ++j) mx = fmax(mx, (double)alpha_u[j]);
-    for (int j = 0; j < C; ++j) se += exp((double)alpha_u[j] - mx);
-    const double lse = mx + log(se);
-    for (int j = 0; j < C; ++j) {
-      const double al = exp((double)alpha_u[j] - lse);
-      const double dla = red[3 + j] + (conc - 1.0) * al / (al + 1e-3);
-      g_a[j] = (float)(dla - al * dla_sum);
-    }
-    if (apply)
-      for (int j = 0; j < C; ++j) {
-        float th = alpha_u[j], m = m_a[j], vv = v_a[j];
-        ca_adam(th, m, vv, -g_a[j], lr_t, b1, b2, aeps);
-        alpha_u[j] = th; m_a[j] = m; v_a[j] = vv;
-      }
-  }
-}
+// ------------------------------------------------------------------ ELBO assembly + the O(K + C) variables (body: ca_final_small_body above)
+__global__ void __launch_bounds__(CA_TB) k_final_small(ca_small_args a) { ca_final_small_body(a); }
 
 // ------------------------------------------------------------------ per-cell variables: psi and the q(z) logits
 __global__ void __launch_bounds__(CA_TB) k_adam_cell(float* __restrict__ F, const float* __restrict__ YW, const float* __restrict__ dFpart,
@@ -1651,7 +1690,25 @@ __global__ void __launch_bounds__(CA_TB) k_adam_cell(float* __restrict__ F, cons
                                                      float* __restrict__ m_psi, float* __restrict__ v_psi, float* __restrict__ m_gl,
                                                      float* __restrict__ v_gl, float* __restrict__ g_psi, int64_t N, int C, int D, int K,
                                                      int ntile, int apply, float lr_t, float b1, float b2, float aeps,
-                                                     const float* __restrict__ vmm, float* __restrict__ etamax2) {
+                                                     const float* __restrict__ vmm_part, int ngblk, float* __restrict__ etamax2,
+                                                     ca_small_args tail, int cblocks) {
+  if ((int)blockIdx.x >= cblocks) {   // the extra block: chi / alpha gradients and Adam, the range of V' (ca_final_small_body)
+    if (tail.enabled) ca_final_small_body(tail);
+    return;
+  }
+  // range of the updated V' over the gene blocks, per block (k_vmm_final folded in: same min / max as the extra block's)
+  __shared__ float vmm[2 * 8];
+  if (apply && D > 0 && D <= 8 && (int)threadIdx.x < D) {
+    const int d = threadIdx.x;
+    float mn = INFINITY, mx = -INFINITY;
+    for (int b = 0; b < ngblk; ++b) {
+      mn = fminf(mn, vmm_part[((int64_t)b * 2 + 0) * D + d]);
+      mx = fmaxf(mx, vmm_part[((int64_t)b * 2 + 1) * D + d]);
+    }
+    vmm[d] = mn;
+    vmm[D + d] = mx;
+  }
+  __syncthreads();
   const int64_t n = (int64_t)blockIdx.x * CA_TB + threadIdx.x;
   if (n >= N) return;
   for (int k = 0; k < K; ++k) {

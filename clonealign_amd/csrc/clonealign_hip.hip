@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -119,6 +120,10 @@ struct ca_engine {
   bool y_defer = false;
   hipStream_t stream3 = nullptr; hipEvent_t ev_elbo = nullptr;   // ELBO read-back beside the speculative backward sweep (ca_run)
   bool bwd_ready = false; int64_t bwd_slot = -1;
+  ca_small_args mon_tail;          // pending ELBO assembly of a fused monitor pass: rides on the next backward sweep
+  bool tail_fuse = true;
+  double* host_dev = nullptr;      // device view of host_pinned
+  unsigned long long host_seq = 0, host_seq_next = 0;
   bool fwd_mfma = false; int fsplit = 1, fkchunk = 1, nk32 = 1; unsigned short* Mq = nullptr;   // matrix-core forward sweep
   // matrix-core backward sweep (k_bwd_mfma): bf16 parts of coef, its own cell split
   bool bwd_mfma = false; unsigned short* coefq = nullptr; int64_t N16 = 0, cchunk_m = 0; int csplit_m = 1, nwt = 0;
@@ -542,21 +547,57 @@ int setup_global_sums(ca_engine* h) {
 
 // Backward half of a train pass.  Needs: coef / dgl from the cell epilogue, mu of the same eps, red[0..3+C) cell sums.
 // cell_sums_global: red[0..3+C) was already all-reduced by the monitor pass that produced it (fused path).
+
+// arguments of the O(K + C) body (ca_final_small_body): monitor form (apply = 0, ELBO out) or train form
+ca_small_args small_args(ca_engine* h, const double* gene_part, int apply, float lr_t, double* elbo_dst, bool reduce_cells) {
+  ca_small_args a;
+  a.enabled = 1;
+  a.red = h->red; a.gene_part = gene_part; a.ngblk = h->ngblk;
+  a.vchi = h->vchi; a.alpha_u = h->alpha_u; a.m_v = h->m_v; a.v_v = h->v_v; a.m_a = h->m_a; a.v_a = h->v_a; a.g_v = h->g_v; a.g_a = h->g_a;
+  a.elbo_out = elbo_dst; a.terms_out = h->terms_dev;
+  a.G = h->G; a.C = h->C; a.K = h->K; a.apply = apply;
+  a.lr_t = lr_t; a.b1 = (float)h->opt.beta1; a.b2 = (float)h->opt.beta2; a.aeps = (float)h->opt.adam_eps;
+  a.vmm_part = h->vmm_part; a.vmm = h->vmm; a.D = h->D;
+  a.dir_const = h->dir_const;
+  a.cell_part = reduce_cells ? h->cell_part : nullptr; a.ncblk = h->ncblk;
+  a.host_out = nullptr; a.host_flag = nullptr; a.host_seq = 0;
+  if (!apply && elbo_dst && h->host_seq_next && h->host_dev) {   // monitor pass inside ca_run: mirror the ELBO to the host
+    a.host_out = h->host_dev + 32;
+    a.host_flag = reinterpret_cast<unsigned long long*>(h->host_dev + 33);
+    a.host_seq = h->host_seq_next;
+    h->host_seq_next = 0;
+  }
+  return a;
+}
+// a fused monitor pass leaves its ELBO assembly for the next backward sweep; if none is coming, run it now
+int flush_mon_tail(ca_engine* h) {
+  if (!h->mon_tail.enabled) return CA_OK;
+  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_final_small, dim3(1), dim3(CA_TB), 0, h->stream, h->mon_tail));
+  h->mon_tail.enabled = 0;
+  return CA_OK;
+}
+inline ca_small_args no_small_args() { ca_small_args a; memset(&a, 0, sizeof(a)); return a; }
+
 // backward half of a train pass: the sweep, the column sums of its partials and the cross-shard reduction.  Changes no
 // variable, so ca_run may issue it before it knows whether the loop goes on (train_bwd_speculative).
 int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
   const int W_ = h->S + h->D;
   if (h->bwd_mfma) {
     constexpr int TL = 4;
+    const int xb = cdiv(h->nwt, CA_TB / 64);
     for (int s = 0; s < h->S; ++s)
       LAUNCH(h, CA_KERNEL_BWD,
-             hipLaunchKernelGGL((k_bwd_mfma<TL>), dim3(cdiv(h->nwt, CA_TB / 64), h->csplit_m), dim3(CA_TB), (size_t)h->cchunk_m * 4 * sizeof(float), h->stream,
+             hipLaunchKernelGGL((k_bwd_mfma<TL>), dim3(xb + ((s == 0 && h->mon_tail.enabled) ? 1 : 0), h->csplit_m), dim3(CA_TB),
+                                (size_t)h->cchunk_m * 4 * sizeof(float), h->stream,
                                 h->coefq + (int64_t)s * h->N16 * 32, h->F, h->etamax2, h->Lb, mu32 + (int64_t)s * h->G, h->Vs, h->V,
-                                h->gpart, h->dFpart, h->N, h->G, h->cchunk_m, h->S, s, 1, s == 0 ? 1 : 0));
+                                h->gpart, h->dFpart, h->N, h->G, h->cchunk_m, h->S, s, 1, s == 0 ? 1 : 0,
+                                s == 0 ? h->mon_tail : no_small_args(), xb));
+    h->mon_tail.enabled = 0;
     LAUNCH(h, CA_KERNEL_OTHER,
            hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->G * W_, 64)), dim3(1024), 0, h->stream, h->gpart,
                               h->red + h->off_g, h->csplit_m, (int64_t)h->G * W_, h->G * W_));
   } else {
+    CACK(flush_mon_tail(h));
     for (int s = 0; s < h->S; ++s)
       for (int ch = 0; ch < h->nchunk; ++ch) {
         BwdArgs a;
@@ -593,15 +634,12 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
                             h->colsum, h->YtX, h->vchi, h->loc, h->ls, h->V, h->m_loc, h->v_loc, h->m_ls, h->v_ls, h->m_V, h->v_V,
                             h->g_loc, h->g_ls, h->g_V, h->Vs, h->vmm_part, h->G, h->S, h->D, h->K, apply, lr_t, (float)h->opt.beta1, (float)h->opt.beta2,
                             (float)h->opt.adam_eps));
+  // the O(K + C) update rides on the per-cell kernel as one extra block (ca_final_small_body)
   LAUNCH(h, CA_KERNEL_OTHER,
-         hipLaunchKernelGGL(k_final_small, dim3(1), dim3(CA_TB), 0, h->stream, h->red, h->gene_part, h->ngblk, h->vchi, h->alpha_u,
-                            h->m_v, h->v_v, h->m_a, h->v_a, h->g_v, h->g_a, elbo_dst, h->terms_dev, h->G, h->C, h->K, apply ? 1 : 0, lr_t,
-                            (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, (const double*)nullptr, h->ncblk, h->red,
-                            h->vmm_part, h->vmm, h->D, h->dir_const));
-  LAUNCH(h, CA_KERNEL_OTHER,
-         hipLaunchKernelGGL(k_adam_cell, dim3(N256), dim3(CA_TB), 0, h->stream, h->F, h->YW, h->dFpart, h->glogit, h->dgl, h->m_psi,
+         hipLaunchKernelGGL(k_adam_cell, dim3(N256 + 1), dim3(CA_TB), 0, h->stream, h->F, h->YW, h->dFpart, h->glogit, h->dgl, h->m_psi,
                             h->v_psi, h->m_gl, h->v_gl, h->g_psi, h->N, h->C, h->D, h->K, h->bwd_mfma ? cdiv(h->nwt, CA_TB / 64) : h->ntile, apply, lr_t,
-                            (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, h->vmm, h->etamax2));
+                            (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, h->vmm_part, h->ngblk, h->etamax2,
+                            small_args(h, h->gene_part, apply ? 1 : 0, lr_t, elbo_dst, false), N256));
   if (apply) {
     h->b1p *= (float)h->opt.beta1;
     h->b2p *= (float)h->opt.beta2;
@@ -628,6 +666,7 @@ int train_tail(ca_engine* h, const float* eps, const float* mu32, int apply, dou
 //   mode CA_MODE_TRAIN: forward + backward (+ Adam when apply)  (`sess$run(train)`)
 int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_dst) {
   const float* eps = h->eps_dev + eps_slot * (int64_t)h->S * h->G;
+  CACK(flush_mon_tail(h));
   LAUNCH(h, CA_KERNEL_OTHER,
          hipLaunchKernelGGL(k_gene_pre, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->loc, h->ls, eps, h->colsum, h->Lb, h->V,
                             h->D, h->K, h->YtX, h->mu32, h->Mb, h->gene_part, h->G, h->S, h->nchunk, CA_CW, 0, CA_CW));
@@ -674,11 +713,8 @@ int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_d
   LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_reduce_part, dim3(3 + h->C), dim3(CA_TB), 0, h->stream, h->cell_part, h->red, h->ncblk, 3 + h->C));
   if (mode == CA_MODE_TRAIN) return train_tail(h, eps, h->mu32, apply, elbo_dst, false);
   CACK(allreduce(h, h->red, 3 + h->C));
-  LAUNCH(h, CA_KERNEL_OTHER,
-         hipLaunchKernelGGL(k_final_small, dim3(1), dim3(CA_TB), 0, h->stream, h->red, h->gene_part, h->ngblk, h->vchi, h->alpha_u,
-                            h->m_v, h->v_v, h->m_a, h->v_a, h->g_v, h->g_a, elbo_dst, h->terms_dev, h->G, h->C, h->K, 0, 0.f,
-                            (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, (const double*)nullptr, h->ncblk, h->red,
-                            h->vmm_part, h->vmm, h->D, h->dir_const));
+  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_final_small, dim3(1), dim3(CA_TB), 0, h->stream,
+                                                small_args(h, h->gene_part, 0, 0.f, elbo_dst, false)));
   return CA_OK;
 }
 
@@ -726,13 +762,16 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst) {
     }
 #undef CA_CELLF
   }
-  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_reduce_part, dim3(3 + h->C), dim3(CA_TB), 0, h->stream, h->cell_part, h->red, h->ncblk, 3 + h->C));
-  CACK(allreduce(h, h->red, 3 + h->C));
-  LAUNCH(h, CA_KERNEL_OTHER,
-         hipLaunchKernelGGL(k_final_small, dim3(1), dim3(CA_TB), 0, h->stream, h->red, h->gene_part, h->ngblk, h->vchi, h->alpha_u,
-                            h->m_v, h->v_v, h->m_a, h->v_a, h->g_v, h->g_a, elbo_dst, h->terms_dev, h->G, h->C, h->K, 0, 0.f,
-                            (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, (const double*)nullptr, h->ncblk, h->red,
-                            h->vmm_part, h->vmm, h->D, h->dir_const));
+  if (h->tail_fuse && h->bwd_mfma && h->opt.world <= 1 && !h->comm && !h->host_ar) {
+    // unsharded: the reduction of the cell partials and the ELBO assembly ride on the backward sweep of the train pass
+    // that completes this look-ahead (one extra block of k_bwd_mfma), not on the critical path
+    h->mon_tail = small_args(h, h->gene_part, 0, 0.f, elbo_dst, true);
+  } else {
+    LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_reduce_part, dim3(3 + h->C), dim3(CA_TB), 0, h->stream, h->cell_part, h->red, h->ncblk, 3 + h->C));
+    CACK(allreduce(h, h->red, 3 + h->C));
+    LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_final_small, dim3(1), dim3(CA_TB), 0, h->stream,
+                                                  small_args(h, h->gene_part, 0, 0.f, elbo_dst, false)));
+  }
   h->look_valid = true;
   h->look_slot = slotB;
   h->bwd_ready = false;
@@ -759,13 +798,27 @@ int train_bwd_speculative(ca_engine* h) {
   h->bwd_slot = h->look_slot;
   return CA_OK;
 }
-// ELBO values written by kernels already queued on the main stream at the time of `ev_elbo`, read without waiting
-// for anything queued after it
-int read_doubles_at_event(ca_engine* h, const double* dev, double* out, int n) {
-  HIPCK(h, hipStreamWaitEvent(h->stream3, h->ev_elbo, 0));
-  HIPCK(h, hipMemcpyAsync(h->host_pinned, dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream3));
-  HIPCK(h, hipStreamSynchronize(h->stream3));
-  for (int i = 0; i < n; ++i) out[i] = h->host_pinned[i];
+int read_doubles(ca_engine* h, const double* dev, double* out, int n);
+// ca_run: the monitor pass's O(K + C) body mirrors its ELBO into pinned host memory and raises a sequence flag
+// (ca_small_args::host_*); the host spins on the flag instead of draining a stream, so whatever was queued behind
+// the monitor pass (the speculative backward sweep) keeps the GPU busy.  Falls back to a plain read-back when the
+// stream runs dry without the flag (mirror unavailable) and surfaces stream errors.
+int wait_host_elbo(ca_engine* h, unsigned long long seq, const double* dev, double* out) {
+  if (!h->host_dev) return read_doubles(h, dev, out, 1);
+  volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(h->host_pinned + 33);
+  unsigned spins = 0;
+  while (*flag != seq) {
+    if ((++spins & 0x3FFu) == 0) {
+      const hipError_t q = hipStreamQuery(h->stream);
+      if (q == hipSuccess) {
+        if (*flag == seq) break;
+        return read_doubles(h, dev, out, 1);
+      }
+      if (q != hipErrorNotReady) HIPCK(h, q);
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  *out = *reinterpret_cast<volatile double*>(h->host_pinned + 32);
   return CA_OK;
 }
 
@@ -1012,6 +1065,10 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   HIPCK(h, hipEventCreateWithFlags(&h->ev_elbo, hipEventDisableTiming));
   if (const char* e = getenv("CA_ASYNC_Y")) h->async_y = atoi(e) != 0;
   HIPCK(h, hipHostMalloc((void**)&h->host_pinned, 64 * sizeof(double)));
+  memset(h->host_pinned, 0, 64 * sizeof(double));
+  if (hipHostGetDevicePointer((void**)&h->host_dev, h->host_pinned, 0) != hipSuccess) { h->host_dev = nullptr; (void)hipGetLastError(); }
+  h->mon_tail = no_small_args();
+  if (const char* e = getenv("CA_TAIL_FUSE")) h->tail_fuse = atoi(e) != 0;
   CACK(upload_y(h, p));
   const int G = h->G, C = h->C, K = h->K, P = h->P, S = h->S, D = h->D;
   const int64_t Nn = h->N;
@@ -1444,22 +1501,24 @@ int ca_run(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_strea
   CACK(ensure_elbo_cap(h, 1 + (int64_t)max_iter));
   *n_elbo = 0;
   CACK(run_pass(h, 0, CA_MODE_GINIT, 0, nullptr));                      // :368-369
+  h->host_seq_next = ++h->host_seq;
   CACK(monitor_pass(h, 1, max_iter >= 1 ? 2 : -1, h->elbo_dev));        // :372 (+ forward half of the first train pass)
   double val;
-  HIPCK(h, hipEventRecord(h->ev_elbo, h->stream));
   CACK(train_bwd_speculative(h));
-  CACK(read_doubles_at_event(h, h->elbo_dev, &val, 1));
+  CACK(flush_mon_tail(h));
+  CACK(wait_host_elbo(h, h->host_seq, h->elbo_dev, &val));
   trace[0] = val; *n_elbo = 1;
   if (std::isnan(val)) { h->err = "Initial elbo is NA"; return CA_ERR_NAN; }   // :374-376
   double diffs[10];
   for (double& d : diffs) d = 1e3;                                      // :379
   for (int i = 1; i <= max_iter; ++i) {
     CACK(train_pass(h, 2 * (int64_t)i));                                // :401
+    h->host_seq_next = ++h->host_seq;
     CACK(monitor_pass(h, 2 * (int64_t)i + 1, i < max_iter ? 2 * (int64_t)i + 2 : -1, h->elbo_dev + i));   // :403
     double nv;
-    HIPCK(h, hipEventRecord(h->ev_elbo, h->stream));
     CACK(train_bwd_speculative(h));     // backward half of train pass i+1 runs while the host looks at ELBO i
-    CACK(read_doubles_at_event(h, h->elbo_dev + i, &nv, 1));
+    CACK(flush_mon_tail(h));
+    CACK(wait_host_elbo(h, h->host_seq, h->elbo_dev + i, &nv));
     const double diff = (nv - val) / std::fabs(val);
     for (int j = 0; j < 9; ++j) diffs[j] = diffs[j + 1];
     diffs[9] = diff;
@@ -1483,6 +1542,7 @@ int ca_iterate(ca_handle h, int32_t n_iter, const float* eps_stream, int64_t n_d
     CACK(train_pass(h, 2 * (int64_t)i));
     CACK(monitor_pass(h, 2 * (int64_t)i + 1, i + 1 < n_iter ? 2 * (int64_t)i + 2 : -1, h->elbo_dev + i));
   }
+  CACK(flush_mon_tail(h));
   if (last_elbo && n_iter > 0) return read_doubles(h, h->elbo_dev + (n_iter - 1), last_elbo, 1);
   HIPCK(h, hipStreamSynchronize(h->stream));
   return CA_OK;

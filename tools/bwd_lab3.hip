@@ -460,6 +460,7 @@ __global__ void __launch_bounds__(256) bwd_mfma5(const unsigned short* __restric
 }
 __device__ unsigned long long g_stamp[4096 * 2];
 __device__ unsigned long long g_abs[4096 * 2];
+__device__ unsigned long long g_ent[4096 * 2];
 // v6: v4 with scalar (non-packed) f32 math: VOP2 v_mul/v_add/v_fmac issue at 2 cycles per wave64 with >= 2 waves per SIMD
 // and do not pay the packed-op penalty beside MFMAs
 template <int TL>
@@ -467,6 +468,7 @@ __global__ void __launch_bounds__(256) bwd_mfma6(const unsigned short* __restric
                                                  const float* __restrict__ em2, const float* __restrict__ Lb,
                                                  const float* __restrict__ mu, const float* __restrict__ Vs, const float* __restrict__ V,
                                                  float* __restrict__ gpart, float* __restrict__ dFpart, long N, int G, long cchunk) {
+  const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();
   const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
   const int wtile = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int gbase = wtile * TL * 16;
@@ -476,18 +478,22 @@ __global__ void __launch_bounds__(256) bwd_mfma6(const unsigned short* __restric
 #pragma unroll
   for (int m = 0; m < TL; ++m) {
     {
-      const int g = gbase + 16 * m + j; const bool ok = g < G; const int gg = ok ? g : G - 1;
+      const int g = gbase + 16 * m + j; const bool ok = g < G && q < 3; const int gg = g < G ? g : G - 1;
+      const float4 r0 = *reinterpret_cast<const float4*>(Lb + (long)gg * 8), r1 = *reinterpret_cast<const float4*>(Lb + (long)gg * 8 + 4);
+      const float lr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
       unsigned short b[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) b[c] = (ok && q < 3) ? bf16_rn(Lb[(long)gg * 8 + c]) : 0;
-      uint4 raw = {(unsigned)b[0] | ((unsigned)b[1] << 16), (unsigned)b[2] | ((unsigned)b[3] << 16),
-                   (unsigned)b[4] | ((unsigned)b[5] << 16), (unsigned)b[6] | ((unsigned)b[7] << 16)};
+      for (int c = 0; c < 8; ++c) b[c] = bf16_rn(lr[c]);
+      const unsigned msk = ok ? 0xFFFFFFFFu : 0u;
+      uint4 raw = {((unsigned)b[0] | ((unsigned)b[1] << 16)) & msk, ((unsigned)b[2] | ((unsigned)b[3] << 16)) & msk,
+                   ((unsigned)b[4] | ((unsigned)b[5] << 16)) & msk, ((unsigned)b[6] | ((unsigned)b[7] << 16)) & msk};
       Lf[m] = __builtin_bit_cast(bf16x8, raw);
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int g = gbase + 16 * m + 4 * q + r; const bool ok = g < G; const int gg = ok ? g : G - 1;
-      vs[m][r] = ok ? Vs[gg] : 0.f; mv[m][r] = ok ? mu[gg] * V[gg] : 0.f;
+      const float a_ = Vs[gg], b_ = mu[gg], c_ = V[gg];
+      vs[m][r] = ok ? a_ : 0.f; mv[m][r] = ok ? b_ * c_ : 0.f;
       accU[m][r] = 0.f; accUF[m][r] = 0.f;
     }
   }
@@ -524,7 +530,7 @@ __global__ void __launch_bounds__(256) bwd_mfma6(const unsigned short* __restric
   {
     const unsigned long long st1 = __builtin_amdgcn_s_memtime(), sr1 = __builtin_amdgcn_s_memrealtime();
     const int bid = blockIdx.y * gridDim.x + blockIdx.x;
-    if (threadIdx.x == 0 && bid < 4096) { g_stamp[2 * bid] = st1 - st0; g_stamp[2 * bid + 1] = sr1 - sr0; g_abs[2 * bid] = sr0; g_abs[2 * bid + 1] = sr1; }
+    if (threadIdx.x == 0 && bid < 4096) { g_stamp[2 * bid] = st1 - st0; g_stamp[2 * bid + 1] = sr1 - sr0; g_abs[2 * bid] = sr0; g_abs[2 * bid + 1] = sr1; g_ent[2 * bid] = t_entry; }
   }
 #pragma unroll
   for (int m = 0; m < TL; ++m)
@@ -537,6 +543,7 @@ __global__ void __launch_bounds__(256) bwd_mfma6(const unsigned short* __restric
         if (g < G) { float* gp = gpart + ((long)blockIdx.y * G + g) * 2; gp[0] = j ? a1 : a0; gp[1] = mu[g] * (j ? b1 : b0_); }
       }
     }
+  { const int bid = blockIdx.y * gridDim.x + blockIdx.x; if (threadIdx.x == 0 && bid < 4096) g_ent[2 * bid + 1] = __builtin_amdgcn_s_memrealtime(); }
 }
 int main() {
   long N = 100000; int G = 5000; const long N16 = (N + 15) / 16 * 16;
@@ -641,9 +648,14 @@ int main() {
           printf("   loop us: p5 %.0f p25 %.0f p50 %.0f p75 %.0f p95 %.0f max %.0f;", sd[nb/20], sd[nb/4], sd[nb/2], sd[3*nb/4], sd[19*nb/20], sd[nb-1]); \
           double xs[8] = {0}; int xc[8] = {0}; for (int i = 0; i < nb; ++i) { xs[i % 8] += du[i]; xc[i % 8]++; } printf(" mean by bid%%8:"); for (int x = 0; x < 8; ++x) printf(" %.0f", xs[x] / xc[x]); \
           const int gx = (int)grid.x; double bs[64] = {0}; int bc[64] = {0}; for (int i = 0; i < nb; ++i) { bs[(i % gx) % 64] += du[i]; bc[(i % gx) % 64]++; } printf("\n   mean by blockIdx.x:"); for (int x = 0; x < gx && x < 64; ++x) printf(" %.0f", bs[x] / bc[x]); printf("\n"); } \
+        { std::vector<unsigned long long> en(4096 * 2); CK(hipMemcpyFromSymbol(en.data(), HIP_SYMBOL(g_ent), en.size() * 8)); \
+          std::vector<double> pro, epi; for (int i = 0; i < nb; ++i) { pro.push_back((ab[2*i] - en[2*i]) / 100.0); epi.push_back((en[2*i+1] - ab[2*i+1]) / 100.0); } \
+          std::sort(pro.begin(), pro.end()); std::sort(epi.begin(), epi.end()); \
+          unsigned long long e0 = ~0ull, e1 = 0; for (int i = 0; i < nb; ++i) { e0 = std::min(e0, en[2*i]); e1 = std::max(e1, en[2*i+1]); } \
+          printf("   prologue us p50 %.1f p95 %.1f; epilogue us p50 %.1f p95 %.1f; first entry -> last exit %.1f us\n", pro[nb/2], pro[19*nb/20], epi[nb/2], epi[19*nb/20], (e1 - e0) / 100.0); } \
         printf("   blocks %d: span %.1f us, %d blocks started > 20 us after the first, max concurrent blocks %d\n", nb, (t1 - t0) / 100.0, late, maxc); (void)mid; } \
       printf("   in-kernel clock median %.0f MHz (min %.0f max %.0f), loop cycles median %.0f, batches per wave %ld -> %.0f cycles per batch per wave\n", ck[ck.size()/2], ck.front(), ck.back(), cyc[cyc.size()/2], (long)(cchunk / 16), cyc[cyc.size()/2] / (cchunk / 16)); } }
-  RUNM6(4, 51); RUNM6(4, 100); RUNM6(2, 51); RUNM6(8, 51); RUNM6(6, 51);
+  RUNM6(4, 51); RUNM6(4, 100); RUNM6(4, 204); RUNM6(4, 391);
   RUNM4A(4, true, 1, 51); RUNM4A(4, true, 2, 51); RUNM4A(4, true, 3, 51); RUNM4A(4, true, 4, 51);
   return 0;
 }
