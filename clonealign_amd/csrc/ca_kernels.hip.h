@@ -480,14 +480,13 @@ __global__ void __launch_bounds__(CA_TB) k_gene_pre(const float* __restrict__ lo
 // Fused two-eps variant (S == 1, one clone chunk): both draws A (monitor pass) and B (next train pass) in one
 // launch; M row = [mu_A L (C cols) | mu_B L (C cols)], per-draw mu and gene partials kept apart.  With Mq the row
 // goes out as two bf16 parts in the operand layout of the matrix-core sweep instead (k_fwd_mfma).
-__global__ void __launch_bounds__(CA_TB) k_gene_pre_fused(const float* __restrict__ loc, const float* __restrict__ ls,
+__device__ __forceinline__ void ca_gene_pre_fused_body(const float* __restrict__ loc, const float* __restrict__ ls,
                                                           const float* __restrict__ epsA, const float* __restrict__ epsB,
                                                           const double* __restrict__ colsum, const float* __restrict__ Lb,
                                                           const float* __restrict__ V, int D, int K, const double* __restrict__ YtX,
                                                           float* __restrict__ muA, float* __restrict__ muB, float* __restrict__ Mb,
                                                           double* __restrict__ gene_partA, double* __restrict__ gene_partB, int G,
-                                                          int mrow, int C, unsigned short* __restrict__ Mq) {
-  __shared__ double sm[CA_TB];
+                                                          int mrow, int C, unsigned short* __restrict__ Mq, double* sm) {
   const int g = blockIdx.x * CA_TB + threadIdx.x;
   const bool ok = g < G;
   double t[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
@@ -535,6 +534,17 @@ __global__ void __launch_bounds__(CA_TB) k_gene_pre_fused(const float* __restric
       gene_partB[(int64_t)blockIdx.x * W_ + 3 + k] = wsum;
     }
   }
+}
+
+__global__ void __launch_bounds__(CA_TB) k_gene_pre_fused(const float* __restrict__ loc, const float* __restrict__ ls,
+                                                          const float* __restrict__ epsA, const float* __restrict__ epsB,
+                                                          const double* __restrict__ colsum, const float* __restrict__ Lb,
+                                                          const float* __restrict__ V, int D, int K, const double* __restrict__ YtX,
+                                                          float* __restrict__ muA, float* __restrict__ muB, float* __restrict__ Mb,
+                                                          double* __restrict__ gene_partA, double* __restrict__ gene_partB, int G,
+                                                          int mrow, int C, unsigned short* __restrict__ Mq) {
+  __shared__ double sm[CA_TB];
+  ca_gene_pre_fused_body(loc, ls, epsA, epsB, colsum, Lb, V, D, K, YtX, muA, muB, Mb, gene_partA, gene_partB, G, mrow, C, Mq, sm);
 }
 
 // Vs = V * log2(e) and per-block min/max of each column (for the per-cell exponent bound)
@@ -1607,7 +1617,7 @@ __global__ void __launch_bounds__(CA_TB) k_reduce_part(const double* __restrict_
 
 // ------------------------------------------------------------------ per-gene gradients + Adam
 // d ELBO / d loc, ls (through mu = softplus(loc + exp(ls) eps)), W, beta; minimises -ELBO.
-__global__ void __launch_bounds__(CA_TB) k_final_gene(const double* __restrict__ red_g /*[G][S+D]*/, const double* __restrict__ red_y /*[G][K]*/,
+__device__ __forceinline__ void ca_final_gene_body(const double* __restrict__ red_g /*[G][S+D]*/, const double* __restrict__ red_y /*[G][K]*/,
                                                       const float* __restrict__ eps, const double* __restrict__ colsum,
                                                       const double* __restrict__ YtX, const float* __restrict__ vchi,
                                                       float* __restrict__ loc, float* __restrict__ ls, float* __restrict__ V,
@@ -1615,19 +1625,19 @@ __global__ void __launch_bounds__(CA_TB) k_final_gene(const double* __restrict__
                                                       float* __restrict__ v_ls, float* __restrict__ m_V, float* __restrict__ v_V,
                                                       float* __restrict__ g_loc, float* __restrict__ g_ls, float* __restrict__ g_V,
                                                       float* __restrict__ Vs, float* __restrict__ vmm_part,
-                                                      int G, int S, int D, int K, int apply, float lr_t, float b1, float b2, float aeps) {
-  __shared__ float smin[CA_TB], smax[CA_TB];
+                                                      int G, int S, int D, int K, int apply, float lr_t, float b1, float b2, float aeps, float* smin, float* smax) {
   const int g = blockIdx.x * CA_TB + threadIdx.x;
   const bool ok = g < G;
   if (ok) {
   const double l = (double)loc[g], lsd = (double)ls[g], sd = exp(lsd), cs = colsum[g];
   const int W_ = S + D;
+  const double* rg = red_g + (int64_t)g * W_;
   double gl = 0.0, gs = 0.0;
   for (int s = 0; s < S; ++s) {
     const double e = (double)eps[(int64_t)s * G + g];
     const double x = l + sd * e;
     const double mu = ca_softplus_d(x), lm = log(mu), sig = ca_sigmoid_d(x);
-    const double dmu = cs / ((double)S * mu) + red_g[(int64_t)g * W_ + s] - lm / ((double)S * mu);
+    const double dmu = cs / ((double)S * mu) + rg[s] - lm / ((double)S * mu);
     const double dx = dmu * sig + (1.0 - sig) / (double)S;
     gl += dx;
     gs += dx * e * sd;
@@ -1644,7 +1654,7 @@ __global__ void __launch_bounds__(CA_TB) k_final_gene(const double* __restrict__
     ls[g] = th; m_ls[g] = m; v_ls[g] = v;
   }
   for (int d = 0; d < D; ++d) {
-    double gv = red_g[(int64_t)g * W_ + S + d];
+    double gv = rg[S + d];
     if (d < K) gv += red_y[(int64_t)g * K + d] - exp((double)vchi[d]) * (double)V[(int64_t)g * D + d];
     else gv += YtX[(int64_t)g * (D - K) + (d - K)];
     g_V[(int64_t)g * D + d] = (float)gv;
@@ -1679,6 +1689,20 @@ __global__ void __launch_bounds__(CA_TB) k_final_gene(const double* __restrict__
       vmm_part[((int64_t)blockIdx.x * 2 + 1) * D + d] = smax[0];
     }
   }
+}
+
+__global__ void __launch_bounds__(CA_TB) k_final_gene(const double* __restrict__ red_g /*[G][S+D]*/, const double* __restrict__ red_y /*[G][K]*/,
+                                                      const float* __restrict__ eps, const double* __restrict__ colsum,
+                                                      const double* __restrict__ YtX, const float* __restrict__ vchi,
+                                                      float* __restrict__ loc, float* __restrict__ ls, float* __restrict__ V,
+                                                      float* __restrict__ m_loc, float* __restrict__ v_loc, float* __restrict__ m_ls,
+                                                      float* __restrict__ v_ls, float* __restrict__ m_V, float* __restrict__ v_V,
+                                                      float* __restrict__ g_loc, float* __restrict__ g_ls, float* __restrict__ g_V,
+                                                      float* __restrict__ Vs, float* __restrict__ vmm_part,
+                                                      int G, int S, int D, int K, int apply, float lr_t, float b1, float b2, float aeps) {
+  __shared__ float smin[CA_TB], smax[CA_TB];
+  ca_final_gene_body(red_g, red_y, eps, colsum, YtX, vchi, loc, ls, V, m_loc, v_loc, m_ls, v_ls, m_V, v_V, g_loc, g_ls, g_V, Vs, vmm_part, G, S, D, K,
+                     apply, lr_t, b1, b2, aeps, smin, smax);
 }
 
 // ------------------------------------------------------------------ ELBO assembly + the O(K + C) variables (body: ca_final_small_body above)

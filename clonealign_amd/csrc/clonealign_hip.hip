@@ -593,6 +593,8 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
                                 h->gpart, h->dFpart, h->N, h->G, h->cchunk_m, h->S, s, 1, s == 0 ? 1 : 0,
                                 s == 0 ? h->mon_tail : no_small_args(), xb));
     h->mon_tail.enabled = 0;
+    // (summing the sweep's partials inside k_final_gene instead -- one thread per gene, csplit_m loads in a row -- was
+    //  slower than this parallel launch: 2219 -> 2190 it/s)
     LAUNCH(h, CA_KERNEL_OTHER,
            hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->G * W_, 64)), dim3(1024), 0, h->stream, h->gpart,
                               h->red + h->off_g, h->csplit_m, (int64_t)h->G * W_, h->G * W_));
@@ -629,11 +631,11 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
     // lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t), float32 like TF's _prepare()/_apply_dense
     lr_t = (float)h->opt.learning_rate * sqrtf(1.f - h->b2p) / (1.f - h->b1p);
   }
-  LAUNCH(h, CA_KERNEL_OTHER,
-         hipLaunchKernelGGL(k_final_gene, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->red + h->off_g, h->red + h->off_y, eps,
-                            h->colsum, h->YtX, h->vchi, h->loc, h->ls, h->V, h->m_loc, h->v_loc, h->m_ls, h->v_ls, h->m_V, h->v_V,
-                            h->g_loc, h->g_ls, h->g_V, h->Vs, h->vmm_part, h->G, h->S, h->D, h->K, apply, lr_t, (float)h->opt.beta1, (float)h->opt.beta2,
-                            (float)h->opt.adam_eps));
+    LAUNCH(h, CA_KERNEL_OTHER,
+           hipLaunchKernelGGL(k_final_gene, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->red + h->off_g, h->red + h->off_y, eps,
+                              h->colsum, h->YtX, h->vchi, h->loc, h->ls, h->V, h->m_loc, h->v_loc, h->m_ls, h->v_ls, h->m_V, h->v_V,
+                              h->g_loc, h->g_ls, h->g_V, h->Vs, h->vmm_part, h->G, h->S, h->D, h->K, apply, lr_t, (float)h->opt.beta1, (float)h->opt.beta2,
+                              (float)h->opt.adam_eps));
   // the O(K + C) update rides on the per-cell kernel as one extra block (ca_final_small_body)
   LAUNCH(h, CA_KERNEL_OTHER,
          hipLaunchKernelGGL(k_adam_cell, dim3(N256 + 1), dim3(CA_TB), 0, h->stream, h->F, h->YW, h->dFpart, h->glogit, h->dgl, h->m_psi,
@@ -647,7 +649,9 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
     h->look_valid = false;
     if (h->async_y && h->K > 0) {
       // the Y pass for the new parameters goes to the side stream; its launches are issued by the next pass AFTER that
-      // pass's per-gene kernel, so the main stream is not left waiting for the host to get through them
+      // pass's per-gene kernel, so the main stream is not left waiting for the host to get through them.  That per-gene
+      // kernel (14 us on the main stream) is also the Y stream's head start: folding it into the train tail so that the
+      // forward sweep and the Y stream start together cost 18 % (2219 -> 1825 it/s; the sweep's blocks take the CUs first)
       HIPCK(h, hipEventRecord(h->ev_params, h->stream));
       h->y_defer = true;
     }
