@@ -150,10 +150,10 @@ __global__ void k_convert_y_u8ovf(const ST* __restrict__ src, uint8_t* __restric
 }
 
 // overflow-list contributions to the Y stream products, one thread per cell (CSR order) / per gene (CSC order)
-__global__ void k_ovf_rows(const int64_t* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
-                           const float* __restrict__ V, int Dstride, float* __restrict__ YWextra /*[N][K]*/, int64_t N, int K,
-                           int tf) {
-  const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void ca_ovf_rows_body(int blk, const int64_t* __restrict__ rowptr, const int* __restrict__ col,
+                                                 const float* __restrict__ val, const float* __restrict__ V, int Dstride,
+                                                 float* __restrict__ YWextra /*[N][K]*/, int64_t N, int K, int tf) {
+  const int64_t n = (int64_t)blk * blockDim.x + threadIdx.x;
   if (n >= N) return;
   for (int k = 0; k < K; ++k) {
     float a = 0.f;
@@ -164,14 +164,19 @@ __global__ void k_ovf_rows(const int64_t* __restrict__ rowptr, const int* __rest
     YWextra[n * K + k] = a;
   }
 }
+__global__ void k_ovf_rows(const int64_t* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ val,
+                           const float* __restrict__ V, int Dstride, float* __restrict__ YWextra /*[N][K]*/, int64_t N, int K,
+                           int tf) {
+  ca_ovf_rows_body(blockIdx.x, rowptr, col, val, V, Dstride, YWextra, N, K, tf);
+}
 // Gene side of the overflow list.  The excess entries concentrate in a few highly expressed genes (one entry
 // per cell there), so each gene's CSC range is cut into chunks of <= 256 entries: one wave per chunk
 // (k_ovf_chunks), then one thread per gene adds its chunk sums in order (k_ovf_cols).
-__global__ void __launch_bounds__(CA_TB) k_ovf_chunks(const int64_t* __restrict__ chunk_start, const int* __restrict__ row,
-                                                      const float* __restrict__ val, const float* __restrict__ F, int Dstride,
-                                                      float* __restrict__ csum /*[nchunk][K]*/, int nchunk, int K, int tf) {
+__device__ __forceinline__ void ca_ovf_chunks_body(int blk, const int64_t* __restrict__ chunk_start, const int* __restrict__ row,
+                                                   const float* __restrict__ val, const float* __restrict__ F, int Dstride,
+                                                   float* __restrict__ csum /*[nchunk][K]*/, int nchunk, int K, int tf) {
   const int lane = threadIdx.x & 63;
-  const int ch = blockIdx.x * (CA_TB / 64) + (threadIdx.x >> 6);
+  const int ch = blk * (CA_TB / 64) + (threadIdx.x >> 6);
   if (ch >= nchunk) return;
   const int64_t e0 = chunk_start[ch], e1 = chunk_start[ch + 1];
   for (int k = 0; k < K; ++k) {
@@ -184,6 +189,18 @@ __global__ void __launch_bounds__(CA_TB) k_ovf_chunks(const int64_t* __restrict_
     if (lane == 63) csum[(int64_t)ch * K + k] = tot;
   }
 }
+__global__ void __launch_bounds__(CA_TB) k_ovf_chunks(const int64_t* __restrict__ chunk_start, const int* __restrict__ row,
+                                                      const float* __restrict__ val, const float* __restrict__ F, int Dstride,
+                                                      float* __restrict__ csum /*[nchunk][K]*/, int nchunk, int K, int tf) {
+  ca_ovf_chunks_body(blockIdx.x, chunk_start, row, val, F, Dstride, csum, nchunk, K, tf);
+}
+// the overflow list's two per-entry kernels as extra blocks of the Y stream launch (k_ypass): they depend on nothing
+// the stream computes, and as launches of their own they were 2 x 5 us of pure latency on the side stream
+struct ca_ovf_args {
+  int nb_rows, nb_chunks;   // extra blocks after the stream's own (0 = none)
+  const int64_t* rowptr; const int* col; const float* val; float* YWextra;
+  const int64_t* chunk_start; const int* row2; const float* val2; float* csum; int nchunk;
+};
 __global__ void k_ovf_cols(const int* __restrict__ col_chunk_ptr, const float* __restrict__ csum,
                            float* __restrict__ YTextra /*[Gp][K]*/, int Gp, int G, int K) {
   const int g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -281,8 +298,14 @@ template <typename YT, int KK, int TF = 0>
 __global__ void __launch_bounds__(CA_TB) k_ypass(const YT* __restrict__ Y, const float* __restrict__ F, int Dstride,
                                                  const float* __restrict__ V, int koff, float* __restrict__ YWpart,
                                                  float* __restrict__ YTpart, int64_t N, int G, int Gp, int nseg,
-                                                 int nrb, int TR, int K) {
+                                                 int nrb, int TR, int K, ca_ovf_args ovf, int nb_main) {
   constexpr int VEC = YVec<YT>::VEC;
+  if ((int)blockIdx.x >= nb_main) {   // overflow-list blocks (identity transform only: the VI loop)
+    const int b = blockIdx.x - nb_main;
+    if (b < ovf.nb_rows) ca_ovf_rows_body(b, ovf.rowptr, ovf.col, ovf.val, V, Dstride, ovf.YWextra, N, K, 0);
+    else ca_ovf_chunks_body(b - ovf.nb_rows, ovf.chunk_start, ovf.row2, ovf.val2, F, Dstride, ovf.csum, ovf.nchunk, K, 0);
+    return;
+  }
   const int lane = threadIdx.x & 63;
   const int64_t task = (int64_t)blockIdx.x * (CA_TB / 64) + (threadIdx.x >> 6);
   const int64_t rb = task / nseg;
@@ -384,7 +407,8 @@ __global__ void __launch_bounds__(CA_TB) k_ypass(const YT* __restrict__ Y, const
 // Used for every cross-block reduction of per-gene partials (Y^T.psi strips, backward-sweep cell
 // splits).  Block = 64 columns x 16 row lanes (256-byte coalesced row reads), LDS tree combine.
 __global__ void __launch_bounds__(1024) k_colsum(const float* __restrict__ part, double* __restrict__ out, int rows,
-                                                 int64_t ld, int cols) {
+                                                 int64_t ld, int cols, const int* __restrict__ col_chunk_ptr = nullptr,
+                                                 const float* __restrict__ csum = nullptr, int K = 1, int G = 0) {
   constexpr int RL = 16;   // row lanes per column: block = 64 columns x 16 row lanes
   __shared__ double sm[RL][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
@@ -397,6 +421,11 @@ __global__ void __launch_bounds__(1024) k_colsum(const float* __restrict__ part,
       a1 += (double)part[(int64_t)(r + RL) * ld + c];
     }
     if (r < rows) a0 += (double)part[(int64_t)r * ld + c];
+    if (csum && ty == 0) {   // gene side of the overflow list (k_ovf_cols folded in): column c = gene * K + k
+      const int g = c / K, k = c - g * K;
+      if (g < G)
+        for (int ch = col_chunk_ptr[g]; ch < col_chunk_ptr[g + 1]; ++ch) a1 += (double)csum[(int64_t)ch * K + k];
+    }
   }
   sm[ty][tx] = a0 + a1;
   __syncthreads();

@@ -323,11 +323,13 @@ void launch_bwd(int RG, int nc, dim3 grid, hipStream_t st, const BwdArgs& a) {
 }
 
 template <typename YT>
-void ypass_t(ca_engine* h, int koff, int kk, dim3 grid) {
+void ypass_t(ca_engine* h, int koff, int kk, dim3 grid, const ca_ovf_args& ovf) {
   const YT* Y = (const YT*)h->Y;
+  const int nb_main = grid.x;
+  grid.x += ovf.nb_rows + ovf.nb_chunks;
 #define CA_YP(KK)                                                                                                        \
   hipLaunchKernelGGL((k_ypass<YT, KK>), grid, dim3(CA_TB), 0, h->stream, Y, h->F, h->D, h->V, koff, h->YWpart, h->YTpart, \
-                     h->N, h->G, h->Gp, h->nseg, h->nrb, h->TR, h->K)
+                     h->N, h->G, h->Gp, h->nseg, h->nrb, h->TR, h->K, ovf, nb_main)
   switch (kk) {
     case 1: CA_YP(1); break;
     case 2: CA_YP(2); break;
@@ -393,26 +395,32 @@ int ensure_ycache(ca_engine* h) {
   if (h->ycache_valid || h->K == 0) { h->ycache_valid = true; return CA_OK; }
   const int64_t tasks = (int64_t)h->nrb * h->nseg;
   dim3 grid(cdiv(tasks, CA_TB / 64));
+  // entries above 255: one extra "segment" of YW and one extra term of Y^T psi; their per-entry work rides on the
+  // first stream launch, the per-gene sums on the column-sum launch
+  ca_ovf_args ovf;
+  memset(&ovf, 0, sizeof(ovf));
+  if (h->n_ovf > 0) {
+    ovf.nb_rows = cdiv(h->N, CA_TB); ovf.nb_chunks = cdiv(h->n_ovf_chunk, CA_TB / 64);
+    ovf.rowptr = h->ovf_rowptr; ovf.col = h->ovf_col; ovf.val = h->ovf_val; ovf.YWextra = h->YWpart + (int64_t)h->nseg * h->N * h->K;
+    ovf.chunk_start = h->ovf_chunk_start; ovf.row2 = h->ovf_row2; ovf.val2 = h->ovf_val2; ovf.csum = h->ovf_csum; ovf.nchunk = h->n_ovf_chunk;
+  }
+  ca_ovf_args none;
+  memset(&none, 0, sizeof(none));
   for (int koff = 0; koff < h->K; koff += 4) {
     const int kk = std::min(4, h->K - koff);
     CACK(prof_begin(h, CA_KERNEL_YPASS));
-    if (h->ystore == CA_YSTORE_U8) ypass_t<uint8_t>(h, koff, kk, grid);
-    else if (h->ystore == CA_YSTORE_U16) ypass_t<uint16_t>(h, koff, kk, grid);
-    else ypass_t<float>(h, koff, kk, grid);
+    const ca_ovf_args& o = koff == 0 ? ovf : none;
+    if (h->ystore == CA_YSTORE_U8) ypass_t<uint8_t>(h, koff, kk, grid, o);
+    else if (h->ystore == CA_YSTORE_U16) ypass_t<uint16_t>(h, koff, kk, grid, o);
+    else ypass_t<float>(h, koff, kk, grid, o);
     HIPCK(h, hipGetLastError());
     CACK(prof_end(h));
   }
-  if (h->n_ovf > 0) {   // entries above 255: one extra "segment" of YW and one extra "row block" of Y^T psi
-    LAUNCH(h, CA_KERNEL_YPASS, hipLaunchKernelGGL(k_ovf_rows, dim3(cdiv(h->N, CA_TB)), dim3(CA_TB), 0, h->stream, h->ovf_rowptr, h->ovf_col,
-                                                  h->ovf_val, h->V, h->D, h->YWpart + (int64_t)h->nseg * h->N * h->K, h->N, h->K, 0));
-    LAUNCH(h, CA_KERNEL_YPASS, hipLaunchKernelGGL(k_ovf_chunks, dim3(cdiv(h->n_ovf_chunk, CA_TB / 64)), dim3(CA_TB), 0, h->stream,
-                                                  h->ovf_chunk_start, h->ovf_row2, h->ovf_val2, h->F, h->D, h->ovf_csum, h->n_ovf_chunk, h->K, 0));
-    LAUNCH(h, CA_KERNEL_YPASS, hipLaunchKernelGGL(k_ovf_cols, dim3(cdiv(h->Gp, CA_TB)), dim3(CA_TB), 0, h->stream, h->ovf_col_chunk_ptr,
-                                                  h->ovf_csum, h->YTpart + (int64_t)h->nrb * h->Gp * h->K, h->Gp, h->G, h->K));
-  }
-  // YTpart is [nrb (+1)][Gp*K]: column sums over the row blocks; ytpsi is laid out [Gp][K] (first G rows used)
+  // YTpart is [nrb][Gp*K]: column sums over the row blocks (+ the overflow list's chunk sums per gene); ytpsi is laid
+  // out [Gp][K] (first G rows used)
   LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->Gp * h->K, 64)), dim3(1024), 0, h->stream,
-                                                h->YTpart, h->red + h->off_y, h->nrb + (h->n_ovf > 0 ? 1 : 0), (int64_t)h->Gp * h->K, h->Gp * h->K));
+                                                h->YTpart, h->red + h->off_y, h->nrb, (int64_t)h->Gp * h->K, h->Gp * h->K,
+                                                h->n_ovf > 0 ? h->ovf_col_chunk_ptr : nullptr, h->n_ovf > 0 ? h->ovf_csum : nullptr, h->K, h->G));
   h->ycache_valid = true;
   return CA_OK;
 }
@@ -421,9 +429,11 @@ int ensure_ycache(ca_engine* h) {
 template <typename YT, int TF>
 void ypass_tf_t(ca_engine* h, const float* Fp, const float* Vp, int q, int koff, int kk, float* YWp, float* YTp, dim3 grid) {
   const YT* Y = (const YT*)h->Y;
+  ca_ovf_args no_ovf;
+  memset(&no_ovf, 0, sizeof(no_ovf));
 #define CA_YPT(KK)                                                                                                    \
   hipLaunchKernelGGL((k_ypass<YT, KK, TF>), grid, dim3(CA_TB), 0, h->stream, Y, Fp, q, Vp, koff, YWp, YTp, h->N, h->G, \
-                     h->Gp, h->nseg, h->nrb, h->TR, q)
+                     h->Gp, h->nseg, h->nrb, h->TR, q, no_ovf, (int)grid.x)
   switch (kk) {
     case 1: CA_YPT(1); break;
     case 2: CA_YPT(2); break;
@@ -1282,12 +1292,14 @@ int create_impl(ca_engine* h, const ca_problem* p) {
       HIPCK(h, hipMemcpyAsync(Ft, col.data(), (size_t)Nn * sizeof(float), hipMemcpyHostToDevice, h->stream));
       const int64_t tasks = (int64_t)h->nrb * h->nseg;
       dim3 grid(cdiv(tasks, CA_TB / 64));
+      ca_ovf_args no_ovf;
+      memset(&no_ovf, 0, sizeof(no_ovf));
       if (h->ystore == CA_YSTORE_U8)
-        hipLaunchKernelGGL((k_ypass<uint8_t, 1>), grid, dim3(CA_TB), 0, h->stream, (const uint8_t*)h->Y, Ft, 1, Vt, 0, YWp, YTp, Nn, G, h->Gp, h->nseg, h->nrb, h->TR, 1);
+        hipLaunchKernelGGL((k_ypass<uint8_t, 1>), grid, dim3(CA_TB), 0, h->stream, (const uint8_t*)h->Y, Ft, 1, Vt, 0, YWp, YTp, Nn, G, h->Gp, h->nseg, h->nrb, h->TR, 1, no_ovf, (int)grid.x);
       else if (h->ystore == CA_YSTORE_U16)
-        hipLaunchKernelGGL((k_ypass<uint16_t, 1>), grid, dim3(CA_TB), 0, h->stream, (const uint16_t*)h->Y, Ft, 1, Vt, 0, YWp, YTp, Nn, G, h->Gp, h->nseg, h->nrb, h->TR, 1);
+        hipLaunchKernelGGL((k_ypass<uint16_t, 1>), grid, dim3(CA_TB), 0, h->stream, (const uint16_t*)h->Y, Ft, 1, Vt, 0, YWp, YTp, Nn, G, h->Gp, h->nseg, h->nrb, h->TR, 1, no_ovf, (int)grid.x);
       else
-        hipLaunchKernelGGL((k_ypass<float, 1>), grid, dim3(CA_TB), 0, h->stream, (const float*)h->Y, Ft, 1, Vt, 0, YWp, YTp, Nn, G, h->Gp, h->nseg, h->nrb, h->TR, 1);
+        hipLaunchKernelGGL((k_ypass<float, 1>), grid, dim3(CA_TB), 0, h->stream, (const float*)h->Y, Ft, 1, Vt, 0, YWp, YTp, Nn, G, h->Gp, h->nseg, h->nrb, h->TR, 1, no_ovf, (int)grid.x);
       HIPCK(h, hipGetLastError());
       hipLaunchKernelGGL(k_colsum, dim3(cdiv(h->Gp, 64)), dim3(1024), 0, h->stream, YTp, yt, h->nrb, (int64_t)h->Gp, h->Gp);
       std::vector<double> tmp((size_t)G);
