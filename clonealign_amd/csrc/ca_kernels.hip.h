@@ -1012,42 +1012,11 @@ struct ca_small_args {
   double dir_const;
   const double* cell_part; int ncblk;   // when set: first reduce the cell epilogue's block partials into red[0 .. 3 + C)
   double* host_out; unsigned long long* host_flag; unsigned long long host_seq;   // ELBO mirrored into pinned host memory (ca_run)
+  int reduce_only;          // stop after the cell-partial reduction (sharded: the sums are all-reduced before the ELBO assembly)
 };
 
-__device__ __forceinline__ void ca_final_small_body(const ca_small_args& sa) {
-  __shared__ double sm[CA_TB];
-  __shared__ double gs[3 + 16];
-  if (sa.cell_part) {   // k_reduce_part folded in (same fixed order: strided partial sums, then the block tree)
-    const int Wc = 3 + sa.C;
-    for (int j = 0; j < Wc; ++j) {
-      double acc = 0.0;
-      for (int b = threadIdx.x; b < sa.ncblk; b += CA_TB) acc += sa.cell_part[(int64_t)b * Wc + j];
-      const double r = ca_block_sum(acc, sm);
-      if (threadIdx.x == 0) sa.red[j] = r;
-    }
-    __threadfence_block();
-    __syncthreads();
-  }
-  const int W_ = 3 + sa.K;
-  for (int j = 0; j < W_; ++j) {
-    double acc = 0.0;
-    for (int b = threadIdx.x; b < sa.ngblk; b += CA_TB) acc += sa.gene_part[(int64_t)b * W_ + j];
-    const double r = ca_block_sum(acc, sm);
-    if (threadIdx.x == 0) gs[j] = r;
-  }
-  // range of the updated V' over the gene blocks (k_vmm_final folded in)
-  if (sa.apply && sa.vmm_part && (int)threadIdx.x < sa.D) {
-    const int d = threadIdx.x;
-    float mn = INFINITY, mx2 = -INFINITY;
-    for (int b = 0; b < sa.ngblk; ++b) {
-      mn = fminf(mn, sa.vmm_part[((int64_t)b * 2 + 0) * sa.D + d]);
-      mx2 = fmaxf(mx2, sa.vmm_part[((int64_t)b * 2 + 1) * sa.D + d]);
-    }
-    sa.vmm[d] = mn;
-    sa.vmm[sa.D + d] = mx2;
-  }
-  __syncthreads();
-  if (threadIdx.x >= 64) return;
+// wave 0 of the O(K + C) body: one lane per clone / latent dimension
+__device__ __forceinline__ void ca_final_small_wave0(const ca_small_args& sa, const double* gs) {
   // One lane per clone (and per latent dimension): the fp64 exp/log chains of this kernel are long, so they
   // run side by side in wave 0 and meet through xor-shuffles.  (C <= 64 here; larger C takes the loop form.)
   const int c = threadIdx.x;
@@ -1137,6 +1106,43 @@ __device__ __forceinline__ void ca_final_small_body(const ca_small_args& sa) {
         sa.alpha_u[j] = th; sa.m_a[j] = m; sa.v_a[j] = vv;
       }
   }
+}
+
+__device__ __forceinline__ void ca_final_small_body(const ca_small_args& sa) {
+  __shared__ double sm[CA_TB];
+  __shared__ double gs[3 + 16];
+  if (sa.cell_part) {   // k_reduce_part folded in (same fixed order: strided partial sums, then the block tree)
+    const int Wc = 3 + sa.C;
+    for (int j = 0; j < Wc; ++j) {
+      double acc = 0.0;
+      for (int b = threadIdx.x; b < sa.ncblk; b += CA_TB) acc += sa.cell_part[(int64_t)b * Wc + j];
+      const double r = ca_block_sum(acc, sm);
+      if (threadIdx.x == 0) sa.red[j] = r;
+    }
+    __threadfence_block();
+    __syncthreads();
+  }
+  if (sa.reduce_only) return;   // (uniform) sharded runs: the ELBO is assembled after the all-reduce
+  const int W_ = 3 + sa.K;
+  for (int j = 0; j < W_; ++j) {
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < sa.ngblk; b += CA_TB) acc += sa.gene_part[(int64_t)b * W_ + j];
+    const double r = ca_block_sum(acc, sm);
+    if (threadIdx.x == 0) gs[j] = r;
+  }
+  // range of the updated V' over the gene blocks (k_vmm_final folded in)
+  if (sa.apply && sa.vmm_part && (int)threadIdx.x < sa.D) {
+    const int d = threadIdx.x;
+    float mn = INFINITY, mx2 = -INFINITY;
+    for (int b = 0; b < sa.ngblk; ++b) {
+      mn = fminf(mn, sa.vmm_part[((int64_t)b * 2 + 0) * sa.D + d]);
+      mx2 = fmaxf(mx2, sa.vmm_part[((int64_t)b * 2 + 1) * sa.D + d]);
+    }
+    sa.vmm[d] = mn;
+    sa.vmm[sa.D + d] = mx2;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) ca_final_small_wave0(sa, gs);
 }
 
 // ------------------------------------------------------------------ backward sweep on the matrix cores
@@ -1744,8 +1750,12 @@ __global__ void __launch_bounds__(CA_TB) k_adam_cell(float* __restrict__ F, cons
                                                      float* __restrict__ v_gl, float* __restrict__ g_psi, int64_t N, int C, int D, int K,
                                                      int ntile, int apply, float lr_t, float b1, float b2, float aeps,
                                                      const float* __restrict__ vmm_part, int ngblk, float* __restrict__ etamax2,
-                                                     ca_small_args tail, int cblocks) {
+                                                     ca_small_args mon, ca_small_args tail, int cblocks) {
   if ((int)blockIdx.x >= cblocks) {   // the extra block: chi / alpha gradients and Adam, the range of V' (ca_final_small_body)
+    if (mon.enabled) {                // sharded loop: a monitor pass's ELBO, assembled from the all-reduced sums BEFORE this update
+      ca_final_small_body(mon);
+      __syncthreads();
+    }
     if (tail.enabled) ca_final_small_body(tail);
     return;
   }

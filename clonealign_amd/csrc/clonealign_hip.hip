@@ -570,7 +570,7 @@ ca_small_args small_args(ca_engine* h, const double* gene_part, int apply, float
   a.vmm_part = h->vmm_part; a.vmm = h->vmm; a.D = h->D;
   a.dir_const = h->dir_const;
   a.cell_part = reduce_cells ? h->cell_part : nullptr; a.ncblk = h->ncblk;
-  a.host_out = nullptr; a.host_flag = nullptr; a.host_seq = 0;
+  a.host_out = nullptr; a.host_flag = nullptr; a.host_seq = 0; a.reduce_only = 0;
   if (!apply && elbo_dst && h->host_seq_next && h->host_dev) {   // monitor pass inside ca_run: mirror the ELBO to the host
     a.host_out = h->host_dev + 32;
     a.host_flag = reinterpret_cast<unsigned long long*>(h->host_dev + 33);
@@ -580,8 +580,15 @@ ca_small_args small_args(ca_engine* h, const double* gene_part, int apply, float
   return a;
 }
 // a fused monitor pass leaves its ELBO assembly for the next backward sweep; if none is coming, run it now
+int allreduce(ca_engine* h, double* buf, int64_t n);
+inline bool is_sharded(const ca_engine* h) { return h->opt.world > 1 || h->comm || h->host_ar; }
 int flush_mon_tail(ca_engine* h) {
   if (!h->mon_tail.enabled) return CA_OK;
+  if (is_sharded(h) && h->mon_tail.cell_part) {   // cell partials neither reduced nor all-reduced yet: the plain sequence
+    LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_reduce_part, dim3(3 + h->C), dim3(CA_TB), 0, h->stream, h->cell_part, h->red, h->ncblk, 3 + h->C));
+    CACK(allreduce(h, h->red, 3 + h->C));
+    h->mon_tail.cell_part = nullptr;
+  }
   LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_final_small, dim3(1), dim3(CA_TB), 0, h->stream, h->mon_tail));
   h->mon_tail.enabled = 0;
   return CA_OK;
@@ -592,17 +599,25 @@ inline ca_small_args no_small_args() { ca_small_args a; memset(&a, 0, sizeof(a))
 // variable, so ca_run may issue it before it knows whether the loop goes on (train_bwd_speculative).
 int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
   const int W_ = h->S + h->D;
+  bool merged = false;
   if (h->bwd_mfma) {
     constexpr int TL = 4;
     const int xb = cdiv(h->nwt, CA_TB / 64);
+    // a pending monitor-pass tail rides on the sweep: whole (unsharded), or only its cell-partial reduction (sharded:
+    // ONE all-reduce per iteration then carries the cell sums together with the gene sums, and the ELBO is assembled
+    // after it -- by the per-cell Adam kernel's extra block, or by ca_run's flush)
+    merged = is_sharded(h) && h->mon_tail.enabled && h->mon_tail.cell_part != nullptr;
+    ca_small_args bwd_tail = h->mon_tail;
+    if (merged) { bwd_tail.reduce_only = 1; bwd_tail.host_out = nullptr; }
     for (int s = 0; s < h->S; ++s)
       LAUNCH(h, CA_KERNEL_BWD,
              hipLaunchKernelGGL((k_bwd_mfma<TL>), dim3(xb + ((s == 0 && h->mon_tail.enabled) ? 1 : 0), h->csplit_m), dim3(CA_TB),
                                 (size_t)h->cchunk_m * 4 * sizeof(float), h->stream,
                                 h->coefq + (int64_t)s * h->N16 * 32, h->F, h->etamax2, h->Lb, mu32 + (int64_t)s * h->G, h->Vs, h->V,
                                 h->gpart, h->dFpart, h->N, h->G, h->cchunk_m, h->S, s, 1, s == 0 ? 1 : 0,
-                                s == 0 ? h->mon_tail : no_small_args(), xb));
-    h->mon_tail.enabled = 0;
+                                s == 0 ? bwd_tail : no_small_args(), xb));
+    if (merged) h->mon_tail.cell_part = nullptr;   // reduced by the extra block; all-reduced below with the gene sums
+    else h->mon_tail.enabled = 0;
     // (summing the sweep's partials inside k_final_gene instead -- one thread per gene, csplit_m loads in a row -- was
     //  slower than this parallel launch: 2219 -> 2190 it/s)
     LAUNCH(h, CA_KERNEL_OTHER,
@@ -627,7 +642,7 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
            hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->G * W_, 64)), dim3(1024), 0, h->stream, h->gpart,
                               h->red + h->off_g, h->csplit, (int64_t)h->G * W_, h->G * W_));
   }
-  if (cell_sums_global) CACK(allreduce(h, h->red + h->off_g, h->red_n - h->off_g));
+  if (cell_sums_global && !merged) CACK(allreduce(h, h->red + h->off_g, h->red_n - h->off_g));
   else CACK(allreduce(h, h->red, h->red_n));
   if (h->opt.world > 1 || h->comm || h->host_ar) h->ycache_valid = false;   // red_y now holds the GLOBAL sum
   return CA_OK;
@@ -646,12 +661,18 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
                               h->colsum, h->YtX, h->vchi, h->loc, h->ls, h->V, h->m_loc, h->v_loc, h->m_ls, h->v_ls, h->m_V, h->v_V,
                               h->g_loc, h->g_ls, h->g_V, h->Vs, h->vmm_part, h->G, h->S, h->D, h->K, apply, lr_t, (float)h->opt.beta1, (float)h->opt.beta2,
                               (float)h->opt.adam_eps));
-  // the O(K + C) update rides on the per-cell kernel as one extra block (ca_final_small_body)
+  // the O(K + C) update rides on the per-cell kernel as one extra block (ca_final_small_body); in a sharded loop a
+  // pending monitor-pass ELBO (sums all-reduced by train_bwd) is assembled by the same block first
+  ca_small_args mon = no_small_args();
+  if (h->mon_tail.enabled) {
+    if (h->mon_tail.cell_part) CACK(flush_mon_tail(h));   // not reduced (no backward sweep took it): the plain sequence
+    else { mon = h->mon_tail; h->mon_tail.enabled = 0; }
+  }
   LAUNCH(h, CA_KERNEL_OTHER,
          hipLaunchKernelGGL(k_adam_cell, dim3(N256 + 1), dim3(CA_TB), 0, h->stream, h->F, h->YW, h->dFpart, h->glogit, h->dgl, h->m_psi,
                             h->v_psi, h->m_gl, h->v_gl, h->g_psi, h->N, h->C, h->D, h->K, h->bwd_mfma ? cdiv(h->nwt, CA_TB / 64) : h->ntile, apply, lr_t,
                             (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, h->vmm_part, h->ngblk, h->etamax2,
-                            small_args(h, h->gene_part, apply ? 1 : 0, lr_t, elbo_dst, false), N256));
+                            mon, small_args(h, h->gene_part, apply ? 1 : 0, lr_t, elbo_dst, false), N256));
   if (apply) {
     h->b1p *= (float)h->opt.beta1;
     h->b2p *= (float)h->opt.beta2;
@@ -776,9 +797,10 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst) {
     }
 #undef CA_CELLF
   }
-  if (h->tail_fuse && h->bwd_mfma && h->opt.world <= 1 && !h->comm && !h->host_ar) {
-    // unsharded: the reduction of the cell partials and the ELBO assembly ride on the backward sweep of the train pass
-    // that completes this look-ahead (one extra block of k_bwd_mfma), not on the critical path
+  if (h->tail_fuse && h->bwd_mfma) {
+    // the reduction of the cell partials and the ELBO assembly ride on the backward sweep of the train pass that
+    // completes this look-ahead (one extra block of k_bwd_mfma), not on the critical path; sharded, only the
+    // reduction does and the ELBO follows that pass's single all-reduce (train_bwd)
     h->mon_tail = small_args(h, h->gene_part, 0, 0.f, elbo_dst, true);
   } else {
     LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_reduce_part, dim3(3 + h->C), dim3(CA_TB), 0, h->stream, h->cell_part, h->red, h->ncblk, 3 + h->C));

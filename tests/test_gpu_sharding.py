@@ -78,6 +78,77 @@ def test_two_shards_on_one_gpu_match_single_handle(kw):
             assert np.abs(st[n] - st_ref[n][lo:hi]).max(initial=0) <= 2e-5 * max(np.abs(st_ref[n]).max(initial=0), 1e-30), n
 
 
+@pytest.mark.parametrize("kw", [dict(N=301, G=140, C=3, K=1), dict(N=1300, G=700, C=8, K=1), dict(N=260, G=90, C=4, K=2, P=1)])
+def test_two_shards_whole_loop_matches_single_handle(kw):
+    """ca_run / ca_iterate (the fused two-eps sweep, what bench.py drives on N GPUs) on two shards through the host hook
+    against the single-handle loop: same ELBO trace, same parameters, replicas bit-identical, and the number of
+    collectives per iteration the design promises."""
+    from clonealign_amd.engine import HipEngine
+    from clonealign_amd.rng import EpsStream
+    case = make_case(seed=11, **kw)
+    N, G = case["Y"].shape[0], case["Y"].shape[1]
+    n_iter = 6
+
+    counts = {}
+
+    def drive(eng, ar=None, rank=None):
+        c0 = len(ar.sizes) if ar else 0
+        tr = eng.run(EpsStream(77, 1, G), n_iter, 1e-12)
+        c1 = len(ar.sizes) if ar else 0
+        last = eng.iterate(3, np.stack([eps_for(1, G, 500 + i) for i in range(6)]))
+        c2 = len(ar.sizes) if ar else 0
+        fin = eng.final_elbo(EpsStream(78, 1, G), 3)
+        if ar and rank == 0:
+            counts["run"], counts["iterate"], counts["mfma"] = c1 - c0, c2 - c1, eng.info()["bwd_mfma"]
+        return np.asarray(tr), last, np.asarray(fin), eng.get_state()
+
+    ref = HipEngine(**case)
+    tr_ref, last_ref, fin_ref, st_ref = drive(ref)
+    ref.close()
+
+    ar = _HostAllreduce(2)
+    out = [None, None]
+    err = []
+
+    def worker(rank):
+        try:
+            lo, hi = cell_range(N, rank, 2)
+            shard = dict(case)
+            for k in ("Y", "psi0", "X", "extra_loglik"):
+                if shard.get(k) is not None:
+                    shard[k] = shard[k][lo:hi]
+            eng = HipEngine(**shard, rank=rank, world=2, host_allreduce=ar.make(rank))
+            out[rank] = drive(eng, ar, rank) + ((lo, hi),)
+            eng.close()
+        except Exception as e:  # noqa: BLE001
+            err.append(e)
+            ar.bar.abort()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not err, err
+    # ONE collective per iteration in the loop: the monitor pass's cell sums travel with the next train pass's gene sums
+    # (ca_run: n_iter merged + the last, unfused monitor pass; ca_iterate(3): first train pass, 2 merged, last monitor pass)
+    # The general backward sweep (here K + P = 3) keeps the plain sequence: one collective per pass.
+    if counts.pop("mfma"):
+        assert counts == {"run": n_iter + 1, "iterate": 4}, counts
+    else:
+        assert counts == {"run": 2 * n_iter + 1, "iterate": 6}, counts
+    for r in range(2):
+        tr, last, fin, st, (lo, hi) = out[r]
+        assert len(tr) == n_iter + 1
+        assert np.abs(tr - tr_ref).max() <= 2e-6 * np.abs(tr_ref).max()
+        assert abs(last - last_ref) <= 2e-6 * abs(last_ref)
+        assert np.abs(fin - fin_ref).max() <= 2e-6 * np.abs(fin_ref).max()
+        assert np.array_equal(tr, out[0][0]) and last == out[0][1]      # every rank sees the same ELBOs
+        for n in ("W", "v", "beta", "alpha_unconstr", "loc", "ls"):
+            assert np.abs(st[n] - st_ref[n]).max(initial=0) <= 5e-5 * max(np.abs(st_ref[n]).max(initial=0), 1e-30), n
+            assert np.array_equal(st[n], out[0][3][n])
+        for n in ("psi", "gamma_logits"):
+            assert np.abs(st[n] - st_ref[n][lo:hi]).max(initial=0) <= 5e-5 * max(np.abs(st_ref[n]).max(initial=0), 1e-30), n
+
+
 def test_rccl_communicator_of_one_rank_runs():
     """ncclCommInitRank with one rank on the visible GPU: the RCCL code path (dlopen, init, all-reduce, destroy)."""
     from clonealign_amd.engine import HipEngine, comm_unique_id
