@@ -228,7 +228,12 @@ def main():
         try:   # HBM bytes per launch from the committed PMC passes (same workload only)
             if (N, G, C, K, world) == (100_000, 5_000, 8, 1, 1):
                 pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-                traffic = pm.get(dominant, {}).get("hbm_bytes")
+                key = dominant
+                if dominant == "fwd" and not info.get("fwd_mfma"):
+                    key = "fwd_valu"
+                if dominant == "bwd" and not info.get("bwd_mfma"):
+                    key = "bwd_valu"
+                traffic = pm.get(key, {}).get("hbm_bytes")
         except Exception:
             traffic = None
         out = {
@@ -246,8 +251,11 @@ def main():
             "roofline": {"bound": bound, "kernel": dominant, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": traffic,
                          "launch_ms": per_launch_s * 1e3, "launches": int(launches),
-                         "note": ("the forward sweep shares the GPU with the Y-stream kernel on a side stream "
-                                  "(standalone 190 us / 92 TFLOP/s; see DESIGN.md section 8)") if dominant == "fwd" else ""},
+                         "note": ("algorithmic fp32 flops of the fused two-eps sweep against the fp32 peak; the contraction "
+                                  "itself runs as bf16 hi/lo MFMAs (fp32-accurate), the kernel is bound by VALU issue "
+                                  "(v_exp_f32 + bf16 split: 88 us at 2.4 GHz, tools/inst_lab.hip) and shares the GPU with the "
+                                  "Y-stream kernel on a side stream (standalone 110 us; DESIGN.md sections 5 and 8)")
+                         if dominant == "fwd" else ""},
             "kernel_ms_per_iter_warmup": {k: v[0] / max(args.warmup, 1) for k, v in kt.items()},
             "final_elbo": last,
             "fit_wallclock": {"seconds": fit_s, "iterations": int(len(trace) - 1), "max_iter": 200, "rel_tol": 1e-6,
