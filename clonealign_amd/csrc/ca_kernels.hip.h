@@ -793,8 +793,10 @@ __global__ void __launch_bounds__(CA_TB) k_fwd_mfma(const float* __restrict__ F,
     }
     if (threadIdx.x < NV) {
       const int ks = threadIdx.x / (32 * D), rem = threadIdx.x % (32 * D), d = rem / 32, gi = rem % 32;
-      const int kk = k0 + c * KC + ks, g = kk * 32 + gi;
-      sv = (kk < k0 + nks && g < G) ? Vs[(int64_t)g * D + d] : 0.f;
+      // padding genes (M = 0 there) borrow the last real gene's loadings: their exponent then stays <= 0 like every
+      // real one (eta - etamax), where V' = 0 would give 2^(-etamax) -- inf x 0 for a cell with etamax < -128
+      const int kk = k0 + c * KC + ks, g = min(kk * 32 + gi, G - 1);
+      sv = Vs[(int64_t)g * D + d];
     }
   };
   auto lstore = [&](int b) {
@@ -1209,7 +1211,7 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
         const bool ok = g < G;
         const int gg = ok ? g : G - 1;
         const float vsv = Vs[gg], muv = mu[gg], vv = V[gg];
-        a[x] = ok ? vsv : 0.f;
+        a[x] = vsv;                  // rows past G keep a real gene's loading (exponent <= 0, never inf); their t is 0
         b[x] = ok ? muv * vv : 0.f;
       }
       vs[m][h] = (ca_f32x2){a[0], a[1]};

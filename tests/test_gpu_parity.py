@@ -303,3 +303,33 @@ def test_fused_sweep_forward_variants_agree_with_oracle(shape, fwd, monkeypatch)
             assert _rel(p[n], getattr(ora, n)) < 1e-4, (shape, fwd, n, _rel(p[n], getattr(ora, n)))
     finally:
         eng.close()
+
+
+def test_padding_genes_stay_finite_under_large_negative_exponents():
+    """G = 70 leaves 26 padding genes in the last 32-gene k-step of the matrix-core sweeps.  With every loading positive
+    and psi strongly negative the per-cell exponent bound etamax is far below -128: a padding gene evaluated at V' = 0
+    would be 2^(-etamax) = inf, times M = 0 = NaN.  The sweeps give them a real gene's loading instead."""
+    from clonealign_amd.engine import HipEngine
+    from oracle.fused_numpy import FusedModel
+    case = make_case(seed=3, N=200, G=70, C=4, K=1)
+    eng, ora = HipEngine(**case), FusedModel(**case, dtype="float32")
+    try:
+        st = perturbed_state({n: getattr(ora, n).shape for n in ora.VAR_NAMES}, amp=0.1)
+        st["W"] = np.full_like(st["W"], 3.0)
+        st["psi"] = np.full_like(st["psi"], -40.0)
+        st["psi"][::7] = 35.0                      # and some cells on the other side
+        for n, v in st.items():
+            setattr(ora, n, v.astype(ora.pdt))
+            eng.set(n, v)
+        eps = np.stack([eps_for(1, ora.G, 900 + i) for i in range(4)])
+        last = eng.iterate(2, eps)                 # fused sweep: k_fwd_mfma + k_bwd_mfma
+        for i in range(2):
+            ora.step(eps[2 * i])
+            e = ora.elbo(eps[2 * i + 1])
+        assert np.isfinite(last) and abs(last - e) <= 2e-5 * abs(e)
+        p = eng.get_state()
+        for n in ora.VAR_NAMES:
+            assert np.all(np.isfinite(p[n])), n
+            assert _rel(p[n], getattr(ora, n)) < 1e-4, (n, _rel(p[n], getattr(ora, n)))
+    finally:
+        eng.close()
