@@ -1295,6 +1295,57 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
     }
 }
 
+// ------------------------------------------------------------------ allele-specific term
+// R/allele-specific.R:17-58: the parameter-free [N, C] addend of the log-likelihood.  Per (variant, cell) two
+// log-probabilities of alt reads out of cov: p1 = logsumexp(log .5 + BB(.1, 1.9), log .5 + BB(1.9, .1)) for a clone
+// with allelic imbalance at the variant, p2 = BB(2, 2) for copy number 2; out[n, c] = sum_v (cn[v, c] == 2 ? p2 : p1)
+//                                                                                   = sum_v p1 + sum_v is2[v, c] (p2 - p1).
+// One block per cell, threads over variants (12 lgamma per pair: the binomial coefficient is shared by the three BB
+// terms, the beta-function constants are kernel arguments), p2 - p1 staged in LDS for the per-clone sums.
+__device__ __forceinline__ double ca_bb_tail(double k, double n, double a, double b, double cab) {
+  return lgamma(k + a) + lgamma(n - k + b) - lgamma(a + b + n) + cab;   // cab = lgamma(a + b) - lgamma(a) - lgamma(b)
+}
+__global__ void __launch_bounds__(CA_TB) k_allele_loglik(const double* __restrict__ cov, const double* __restrict__ ref, int64_t sn, int64_t sv,
+                                                         const unsigned char* __restrict__ is2 /*[V][C]*/, double* __restrict__ out,
+                                                         int64_t on, int64_t oc, int64_t N, int V, int C, int vtile, double c_low,
+                                                         double c_high, double c_two) {
+  extern __shared__ double ca_ldsd[];   // [vtile] p2 - p1 of the current variant tile
+  __shared__ double sm[CA_TB];
+  const int64_t n = blockIdx.x;
+  const double LOG_HALF = -0.69314718055994530942;
+  double s1 = 0.0;   // this thread's share of sum_v p1
+  for (int v0 = 0; v0 < V; v0 += vtile) {
+    const int nv = min(vtile, V - v0);
+    for (int i = threadIdx.x; i < nv; i += CA_TB) {
+      const double cv = cov[n * sn + (int64_t)(v0 + i) * sv], rf = ref[n * sn + (int64_t)(v0 + i) * sv];
+      const double k = cv - rf;   // alt = cov - ref (R/inference-tflow.R:173)
+      const double binom = lgamma(cv + 1.0) - lgamma(k + 1.0) - lgamma(cv - k + 1.0);
+      const double lo = LOG_HALF + binom + ca_bb_tail(k, cv, 0.1, 1.9, c_low);
+      const double hi = LOG_HALF + binom + ca_bb_tail(k, cv, 1.9, 0.1, c_high);
+      const double mx = fmax(lo, hi);
+      const double p1 = (mx == -INFINITY) ? -INFINITY : mx + log(exp(lo - mx) + exp(hi - mx));
+      const double p2 = binom + ca_bb_tail(k, cv, 2.0, 2.0, c_two);
+      s1 += p1;
+      ca_ldsd[i] = p2 - p1;
+    }
+    __syncthreads();
+    for (int c = 0; c < C; ++c) {
+      double a = 0.0;
+      for (int i = threadIdx.x; i < nv; i += CA_TB)
+        if (is2[(int64_t)(v0 + i) * C + c]) a += ca_ldsd[i];
+      const double r = ca_block_sum(a, sm);
+      if (threadIdx.x == 0) {
+        double* o = out + n * on + (int64_t)c * oc;
+        *o = (v0 == 0 ? 0.0 : *o) + r;
+      }
+    }
+    __syncthreads();
+  }
+  const double t1 = ca_block_sum(s1, sm);
+  if (threadIdx.x == 0)
+    for (int c = 0; c < C; ++c) out[n * on + (int64_t)c * oc] += t1;
+}
+
 // ------------------------------------------------------------------ per-cell epilogue
 // Everything of R/inference-tflow.R:294-308,322,327,332-333,338-342 that is per cell, in fp64:
 // log-lik ll'_nc = A_nc - s_n mean_s log Z_snc, gamma = softmax(logits), the cell's ELBO

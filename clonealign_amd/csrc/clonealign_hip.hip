@@ -1900,4 +1900,41 @@ int ca_eps_draw(uint64_t seed, uint64_t draw, int64_t n, float* out) {
   return CA_OK;
 }
 
+int ca_allele_loglik(int64_t N, int32_t V, int32_t C, int32_t layout, const double* clone_allele, const double* cov,
+                     const double* ref, int32_t device, double* out, char* err) {
+  auto fail = [&](int code, const std::string& m) { if (err) { strncpy(err, m.c_str(), 255); err[255] = 0; } return code; };
+  if (N < 1 || V < 1 || C < 1 || !clone_allele || !cov || !ref || !out) return fail(CA_ERR_INVALID, "ca_allele_loglik: bad arguments");
+  if (layout != CA_ROW_MAJOR && layout != CA_COL_MAJOR) return fail(CA_ERR_INVALID, "ca_allele_loglik: bad layout");
+  double *dcov = nullptr, *dref = nullptr, *dout = nullptr; unsigned char* dis2 = nullptr;
+  auto cleanup = [&]() { hipFree(dcov); hipFree(dref); hipFree(dout); hipFree(dis2); };
+#define ACK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { cleanup(); return fail(CA_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); } } while (0)
+  ACK(hipSetDevice(device));
+  std::vector<unsigned char> is2((size_t)V * C);
+  for (int v = 0; v < V; ++v)
+    for (int c = 0; c < C; ++c) is2[(size_t)v * C + c] = clone_allele[hidx(layout, v, c, V, C)] == 2.0 ? 1 : 0;
+  const size_t nv = (size_t)N * V;
+  ACK(hipMalloc((void**)&dcov, nv * sizeof(double)));
+  ACK(hipMalloc((void**)&dref, nv * sizeof(double)));
+  ACK(hipMalloc((void**)&dout, (size_t)N * C * sizeof(double)));
+  ACK(hipMalloc((void**)&dis2, is2.size()));
+  ACK(hipMemcpy(dcov, cov, nv * sizeof(double), hipMemcpyHostToDevice));
+  ACK(hipMemcpy(dref, ref, nv * sizeof(double), hipMemcpyHostToDevice));
+  ACK(hipMemcpy(dis2, is2.data(), is2.size(), hipMemcpyHostToDevice));
+  const int64_t sn = layout == CA_COL_MAJOR ? 1 : V, sv = layout == CA_COL_MAJOR ? N : 1;
+  const int64_t on = layout == CA_COL_MAJOR ? 1 : C, oc = layout == CA_COL_MAJOR ? N : 1;
+  const int vtile = std::min(V, 4096);
+  auto cab = [](double a, double b) { return std::lgamma(a + b) - std::lgamma(a) - std::lgamma(b); };
+  for (int64_t n0 = 0; n0 < N; n0 += 1 << 30) {   // grid.x limit
+    const int64_t nb = std::min<int64_t>(N - n0, (int64_t)1 << 30);
+    hipLaunchKernelGGL(k_allele_loglik, dim3((unsigned)nb), dim3(CA_TB), (size_t)vtile * sizeof(double), 0,
+                       dcov + n0 * sn, dref + n0 * sn, sn, sv, dis2, dout + n0 * on, on, oc, nb, (int)V, (int)C, vtile,
+                       cab(0.1, 1.9), cab(1.9, 0.1), cab(2.0, 2.0));
+    ACK(hipGetLastError());
+  }
+  ACK(hipMemcpy(out, dout, (size_t)N * C * sizeof(double), hipMemcpyDeviceToHost));
+#undef ACK
+  cleanup();
+  return CA_OK;
+}
+
 }  // extern "C"

@@ -24,7 +24,7 @@ EXPORTS = (
     "ca_abi_version", "ca_default_options", "ca_create", "ca_destroy", "ca_last_error", "ca_get_info",
     "ca_synchronize", "ca_comm_unique_id", "ca_comm_init", "ca_set_host_allreduce", "ca_gamma_init", "ca_elbo", "ca_elbo_terms",
     "ca_step", "ca_gradients", "ca_run", "ca_iterate", "ca_final_elbo", "ca_init_psi_pca", "ca_clone_gene_sums", "ca_get_param", "ca_set_param",
-    "ca_get_gradient", "ca_get_kernel_times", "ca_reset_kernel_times", "ca_set_profile", "ca_eps_draw",
+    "ca_get_gradient", "ca_get_kernel_times", "ca_reset_kernel_times", "ca_set_profile", "ca_eps_draw", "ca_allele_loglik",
 )
 
 
@@ -97,6 +97,8 @@ def load_library(path=None):
     lib.ca_reset_kernel_times.argtypes = [C.c_void_p]
     lib.ca_set_profile.argtypes = [C.c_void_p, C.c_int32]
     lib.ca_eps_draw.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p]
+    lib.ca_allele_loglik.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
+                                     C.c_void_p, C.c_char_p]
     if path is None:
         _lib = lib
     return lib
@@ -363,4 +365,24 @@ def eps_draw(seed, draw, n):
     rc = lib.ca_eps_draw(int(seed), int(draw), int(n), out.ctypes.data_as(C.c_void_p))
     if rc != CA_OK:
         raise EngineError(rc, "ca_eps_draw")
+    return out
+
+
+def allele_loglik(clone_allele, cov, ref, device=0):
+    """The allele-specific [N, C] addend of the log-likelihood on the device (ca_allele_loglik; R/allele-specific.R:17-58
+    with alt = cov - ref as at R/inference-tflow.R:173).  clone_allele [V, C]; cov, ref [N, V]."""
+    lib = load_library()
+    ca = np.ascontiguousarray(np.asarray(clone_allele, dtype=np.float64))
+    cv = np.ascontiguousarray(np.asarray(cov, dtype=np.float64))
+    rf = np.ascontiguousarray(np.asarray(ref, dtype=np.float64))
+    V, Cn = ca.shape
+    N = cv.shape[0]
+    if cv.shape != (N, V) or rf.shape != (N, V):
+        raise ValueError("cov and ref must be cells x variants, clone_allele variants x clones")
+    out = np.zeros((N, Cn), dtype=np.float64)
+    err = C.create_string_buffer(256)
+    rc = lib.ca_allele_loglik(N, V, Cn, CA_ROW_MAJOR, ca.ctypes.data_as(C.c_void_p), cv.ctypes.data_as(C.c_void_p),
+                              rf.ctypes.data_as(C.c_void_p), int(device), out.ctypes.data_as(C.c_void_p), err)
+    if rc != CA_OK:
+        raise EngineError(rc, err.value.decode() or "ca_allele_loglik")
     return out

@@ -78,7 +78,7 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
                     fix_alpha=False, dtype="float32", saturate=True, saturation_threshold=6,
                     K=1, mc_samples=1, verbose=True, initial_shrink=5, data_init_mu=True,
                     *, gene_names=None, seed=None, engine=None, engine_opts=None,
-                    psi_noise=None, eps_stream=None, psi_init="auto", post=None):
+                    psi_noise=None, eps_stream=None, psi_init="auto", post=None, allele_on="auto"):
     """EM/VI inference on the MI355X engine.  Arguments as R/inference-tflow.R:71-89.
 
     Keyword-only extras (no reference counterpart): ``seed`` (replaces R's ``set.seed``
@@ -87,6 +87,8 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
     ``psi_noise`` / ``eps_stream`` to inject the two noise sources explicitly, ``psi_init`` in
     {"auto", "host", "device"}: where the PCA initialisation of :204-208 runs ("auto": on the device, by
     subspace iteration over the resident count matrix, once N*G exceeds 4e6; exact SVD on the host below that);
+    ``allele_on`` in {"auto", "host", "device"}: where the parameter-free allele term of :166-187 is evaluated ("auto": on
+    the device, ca_allele_loglik, once cells x variants exceeds 2e5);
     ``post(engine, ml_params)`` runs before the engine is closed (clonealign() uses it for the device-side
     correlation sums) and its result is returned under ``"post"``.
     """
@@ -134,8 +136,13 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
         ref = np.asarray(ref, dtype=np.float64)
         V = clone_allele.shape[0]
         sanitize_allele_info(V, clone_allele, cov, ref, N, C)
-        alt = cov.T - ref.T
-        extra = construct_ai_likelihood(clone_allele, alt, cov.T)      # [N,C]
+        if allele_on in ("device", "auto") and engine is None and (allele_on == "device" or N * V > 200_000):
+            from .engine import allele_loglik                          # 12 lgamma per (variant, cell)
+            dev = int((engine_opts or {}).get("device", 0))
+            extra = allele_loglik(clone_allele, cov, ref, device=dev)  # [N,C]
+        else:
+            alt = cov.T - ref.T
+            extra = construct_ai_likelihood(clone_allele, alt, cov.T)  # [N,C]
         clone_probs_from_snv = np.exp(extra - logsumexp(extra, 1, keepdims=True))   # :436-440
     rng = np.random.default_rng(seed)
     # initialisation (:204-235)

@@ -179,6 +179,15 @@ int ca_set_profile(ca_handle h, int32_t mask);
 /* built-in eps stream (Philox4x32-10 + Box-Muller), host side: out[n] for draw `draw` */
 int ca_eps_draw(uint64_t seed, uint64_t draw, int64_t n, float* out);
 
+/* Allele-specific addend of the log-likelihood, needs no handle: replaces
+ * construct_ai_likelihood() + beta_binomial_log_prob() (R/allele-specific.R:17-58) as evaluated at
+ * R/inference-tflow.R:166-187 with alt = t(cov) - t(ref).  Host matrices in `layout` (ca_layout): clone_allele [V, C]
+ * copy number of each clone at each variant, cov / ref [N, V] coverage and reference read counts per cell; out [N, C]
+ * is what ca_problem.extra_loglik takes.  The term has no parameters, so it is computed once per fit.
+ * err (optional, >= 256 bytes) receives the message on failure. */
+int ca_allele_loglik(int64_t N, int32_t V, int32_t C, int32_t layout, const double* clone_allele, const double* cov,
+                     const double* ref, int32_t device, double* out, char* err);
+
 #ifdef __cplusplus
 }
 #endif
