@@ -294,6 +294,13 @@ __global__ void __launch_bounds__(CA_TB) k_prep_cells(const YT* __restrict__ Y, 
 // in registers, per-row partial reduced across the wave with DPP.
 //   YWpart[seg][n][k]  = sum over the strip's genes of y_ng W_gk          (summed over seg later)
 //   YTpart[rb][g][k]   = sum over the strip's cells of y_ng psi_nk        (summed over rb later)
+// Everything that is the same for the whole wave is kept in SGPRs on purpose (v_readfirstlane of the wave index): the
+// strip bounds, the row loop, the row base address (loads are `global_load_dwordx4 v, v_off, s[base]`), and the row's
+// psi, which is fetched once per strip into one VGPR per 64 rows and read back with v_readlane.  Before, the
+// compiler carried the row index in 64-bit vector registers (10 VALU per load address) and fetched psi with a
+// vector load per row whose s_waitcnt vmcnt(0) also drained the prefetched Y rows.  Rows are processed in two
+// alternating groups of U so the prefetch needs no register copies; row totals are parked one per lane with
+// v_writelane and stored 64 at a time (a per-row store would sit in the same in-order vmcnt queue as the loads).
 template <typename YT, int KK, int TF = 0>
 __global__ void __launch_bounds__(CA_TB) k_ypass(const YT* __restrict__ Y, const float* __restrict__ F, int Dstride,
                                                  const float* __restrict__ V, int koff, float* __restrict__ YWpart,
@@ -307,100 +314,98 @@ __global__ void __launch_bounds__(CA_TB) k_ypass(const YT* __restrict__ Y, const
     return;
   }
   const int lane = threadIdx.x & 63;
-  const int64_t task = (int64_t)blockIdx.x * (CA_TB / 64) + (threadIdx.x >> 6);
-  const int64_t rb = task / nseg;
-  const int sg = (int)(task - rb * nseg);
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int task = (int)blockIdx.x * (CA_TB / 64) + wave;   // wave-uniform from here on
+  const int rb = task / nseg;
+  const int sg = task - rb * nseg;
   if (rb >= nrb) return;
   const int col0 = sg * 64 * VEC + lane * VEC;
-  // 2-wide packed accumulation (v_pk_fma_f32): every VALU instruction costs 4 cycles per wave64 on gfx950, packed or not
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  constexpr int VH = VEC / 2;
-  f2 w[VH][KK], acc[VH][KK];
+  float w[VEC][KK], acc[VEC][KK];
 #pragma unroll
-  for (int j = 0; j < VH; ++j)
+  for (int j = 0; j < VEC; ++j)
 #pragma unroll
     for (int k = 0; k < KK; ++k) {
-      const float w0 = (col0 + 2 * j < G) ? V[(int64_t)(col0 + 2 * j) * Dstride + koff + k] : 0.f;
-      const float w1 = (col0 + 2 * j + 1 < G) ? V[(int64_t)(col0 + 2 * j + 1) * Dstride + koff + k] : 0.f;
-      w[j][k] = (f2){w0, w1};
-      acc[j][k] = (f2){0.f, 0.f};
+      const int g = col0 + j;
+      const float wv = V[(int64_t)(g < G ? g : G - 1) * Dstride + koff + k];   // unconditional load, masked after
+      w[j][k] = g < G ? wv : 0.f;
+      acc[j][k] = 0.f;
     }
-  const int64_t r0 = rb * TR;
-  const int64_t r1 = (r0 + TR < N) ? r0 + TR : N;
-  const YT* base = Y + col0;
-  constexpr int U = 4;  // rows in flight per wave: U independent 16-byte loads issued before any is consumed
-  // Row totals are parked one per lane (row r -> lane (r - r0) & 63) and written 64 at a time: a per-row
-  // store from lane 63 would sit in the same in-order vmcnt queue as the loads and serialise the stream.
+  const int64_t r0 = (int64_t)rb * TR;
+  const int nrows = (int)(((r0 + TR < N) ? r0 + TR : N) - r0);
+  // psi of the strip's rows: row i lives in lane i & 63 of psv[.][i >> 6]   (TR <= 128)
+  float psv[KK][2];
+#pragma unroll
+  for (int k = 0; k < KK; ++k)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+      const int i = lane + 64 * hh;
+      const int64_t r = r0 + (i < nrows ? i : nrows - 1);
+      psv[k][hh] = F[r * Dstride + koff + k];
+    }
+  const char* base = reinterpret_cast<const char*>(Y) + r0 * (int64_t)Gp * (int64_t)sizeof(YT);   // scalar
+  const int voff = col0 * (int)sizeof(YT);                                                          // per lane
+  const int64_t pitch = (int64_t)Gp * (int64_t)sizeof(YT);
+  constexpr int U = 4;   // rows per group; two groups alternate (2 x U 16-byte loads in flight per lane)
+  auto fetch = [&](uint4 (&buf)[U], int i0) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int i = (i0 + u < nrows) ? i0 + u : nrows - 1;   // tail rows re-read the last row (never consumed)
+      buf[u] = *reinterpret_cast<const uint4*>(base + (int64_t)i * pitch + voff);
+    }
+  };
   float keep[KK];
 #pragma unroll
   for (int k = 0; k < KK; ++k) keep[k] = 0.f;
-  uint4 nxt[U];   // software pipeline: the next U rows are requested before the current U are consumed
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int64_t r = (r0 + u < r1) ? r0 + u : r1 - 1;
-    nxt[u] = *reinterpret_cast<const uint4*>(base + r * Gp);
-  }
-  for (int64_t rr = r0; rr < r1; rr += U) {
-    uint4 raw[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) raw[u] = nxt[u];
-    if (rr + U < r1) {
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const int64_t r = (rr + U + u < r1) ? rr + U + u : r1 - 1;   // tail rows re-read the last row (masked below)
-        nxt[u] = *reinterpret_cast<const uint4*>(base + r * Gp);
-      }
-    }
+  auto consume = [&](const uint4 (&buf)[U], int i0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t r = rr + u;
-      if (r < r1) {   // wave-uniform
+      const int i = i0 + u;
+      if (i < nrows) {   // wave-uniform (scalar branch)
         float y[VEC];
-        YVec<YT>::decode(raw[u], y);
+        YVec<YT>::decode(buf[u], y);
         if (TF != 0) {
 #pragma unroll
           for (int j = 0; j < VEC; ++j) y[j] = ca_ytf<TF>(y[j]);
         }
-        f2 p[KK];
-        float ps[KK];
 #pragma unroll
         for (int k = 0; k < KK; ++k) {
-          p[k] = (f2){0.f, 0.f};
-          ps[k] = F[r * Dstride + koff + k];  // wave-uniform -> scalar load
-        }
+          const float ps = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, i < 64 ? psv[k][0] : psv[k][1]), i & 63));
+          float p0 = 0.f, p1 = 0.f;
 #pragma unroll
-        for (int j = 0; j < VH; ++j) {
-          const f2 y2 = {y[2 * j], y[2 * j + 1]};
-#pragma unroll
-          for (int k = 0; k < KK; ++k) {
-            p[k] = y2 * w[j][k] + p[k];
-            acc[j][k] = y2 * ps[k] + acc[j][k];
+          for (int j = 0; j < VEC; j += 2) {
+            p0 = fmaf(y[j], w[j][k], p0);
+            p1 = fmaf(y[j + 1], w[j + 1][k], p1);
+            acc[j][k] = fmaf(y[j], ps, acc[j][k]);
+            acc[j + 1][k] = fmaf(y[j + 1], ps, acc[j + 1][k]);
+          }
+          const int tot = __builtin_amdgcn_readlane(__builtin_bit_cast(int, ca_wave_sum_lane63(p0 + p1)), 63);
+          {   // keep[k] lane (i & 63) <- tot  (v_writelane_b32: value and lane select are both scalars, the select goes through m0)
+            const int slot = i & 63;
+            asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(keep[k]) : "s"(tot), "s"(slot) : "m0");
           }
         }
-        const int slot = (int)(r - r0) & 63;
+        if ((i & 63) == 63 || i == nrows - 1) {   // wave-uniform flush of the last (up to 64) row totals
+          const int fb = i & ~63;
+          if (fb + lane <= i) {
 #pragma unroll
-        for (int k = 0; k < KK; ++k) {
-          const float tot = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ca_wave_sum_lane63(p[k].x + p[k].y)), 63));
-          keep[k] = (lane == slot) ? tot : keep[k];
+            for (int k = 0; k < KK; ++k) YWpart[((int64_t)sg * N + r0 + fb + lane) * K + koff + k] = keep[k];
+          }
         }
       }
     }
-    const int64_t done = ((rr + U < r1) ? rr + U : r1) - r0;   // rows finished so far in this strip
-    if ((done & 63) == 0 || rr + U >= r1) {                   // wave-uniform flush of the last (up to 64) rows
-      const int64_t fb = r0 + ((done - 1) & ~(int64_t)63);
-      if (fb + lane < r0 + done) {
-#pragma unroll
-        for (int k = 0; k < KK; ++k) YWpart[((int64_t)sg * N + fb + lane) * K + koff + k] = keep[k];
-      }
-    }
+  };
+  uint4 bufA[U], bufB[U];
+  fetch(bufA, 0);
+  for (int i0 = 0; i0 < nrows; i0 += 2 * U) {
+    if (i0 + U < nrows) fetch(bufB, i0 + U);
+    consume(bufA, i0);
+    if (i0 + 2 * U < nrows) fetch(bufA, i0 + 2 * U);
+    if (i0 + U < nrows) consume(bufB, i0 + U);
   }
 #pragma unroll
-  for (int j = 0; j < VH; ++j)
+  for (int j = 0; j < VEC; ++j)
 #pragma unroll
-    for (int k = 0; k < KK; ++k) {
-      YTpart[((int64_t)rb * Gp + col0 + 2 * j) * K + koff + k] = acc[j][k].x;
-      YTpart[((int64_t)rb * Gp + col0 + 2 * j + 1) * K + koff + k] = acc[j][k].y;
-    }
+    for (int k = 0; k < KK; ++k) YTpart[((int64_t)rb * Gp + col0 + j) * K + koff + k] = acc[j][k];
 }
 
 // Column sums of a [rows][ld] float slab in fp64 and in a fixed order: out[c] = sum_r part[r*ld + c].

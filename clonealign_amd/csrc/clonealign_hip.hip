@@ -15,6 +15,7 @@
 #include <cstring>
 #include <string>
 #include <atomic>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -1136,7 +1137,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   h->cchunk = (Nn + h->csplit - 1) / h->csplit;
   h->csplit = cdiv(Nn, h->cchunk);
   h->TR = 128;
-  if (const char* e = getenv("CA_TR")) h->TR = std::max(1, atoi(e));   // tuning override
+  if (const char* e = getenv("CA_TR")) h->TR = std::min(128, std::max(1, atoi(e)));   // tuning override (k_ypass keeps psi of <= 128 rows)
   h->nrb = cdiv(Nn, h->TR);
   while (!getenv("CA_TR") && (int64_t)h->nrb * h->nseg < 4 * h->n_cu && h->TR > 32) { h->TR /= 2; h->nrb = cdiv(Nn, h->TR); }
   // ---- constants
@@ -1576,11 +1577,15 @@ int ca_iterate(ca_handle h, int32_t n_iter, const float* eps_stream, int64_t n_d
   HIPCK(h, hipSetDevice(h->device));
   CACK(stage_eps(h, eps_stream, n_draws, 2 * (int64_t)n_iter));
   CACK(ensure_elbo_cap(h, std::max(1, n_iter)));
+  const auto t_host0 = std::chrono::steady_clock::now();
   for (int i = 0; i < n_iter; ++i) {
     CACK(train_pass(h, 2 * (int64_t)i));
     CACK(monitor_pass(h, 2 * (int64_t)i + 1, i + 1 < n_iter ? 2 * (int64_t)i + 2 : -1, h->elbo_dev + i));
   }
   CACK(flush_mon_tail(h));
+  if (getenv("CA_VERBOSE") && n_iter > 0)
+    fprintf(stderr, "[clonealign_hip] ca_iterate: host enqueue %.1f us per iteration\n",
+            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host0).count() / n_iter);
   if (last_elbo && n_iter > 0) return read_doubles(h, h->elbo_dev + (n_iter - 1), last_elbo, 1);
   HIPCK(h, hipStreamSynchronize(h->stream));
   return CA_OK;
