@@ -1300,6 +1300,54 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
     }
 }
 
+// ------------------------------------------------------------------ preprocessing statistics
+// R/preprocess.R:93-147 needs two statistics of the RAW count matrix: colSums(Y) (per gene, all cells) and, after the
+// gene filters, rowSums(Y[, kept]) (per cell).  Both are single passes over the caller's matrix in its own dtype and
+// layout (element (n, g) at src[n * sn + g * sg]); sums are fp64 and taken in a fixed order.
+template <typename ST>
+__global__ void __launch_bounds__(CA_TB) k_pre_colsum(const ST* __restrict__ src, int64_t N, int G, int64_t sn, int64_t sg,
+                                                      int rows_per_block, double* __restrict__ part /*[gridDim.y][G]*/) {
+  const int g = blockIdx.x * CA_TB + threadIdx.x;
+  if (g >= G) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = (r0 + rows_per_block < N) ? r0 + rows_per_block : N;
+  double a = 0.0;
+  for (int64_t n = r0; n < r1; ++n) a += (double)src[n * sn + (int64_t)g * sg];
+  part[(int64_t)blockIdx.y * G + g] = a;
+}
+__global__ void __launch_bounds__(CA_TB) k_pre_colsum_final(const double* __restrict__ part, int nrb, int G, double* __restrict__ out) {
+  const int g = blockIdx.x * CA_TB + threadIdx.x;
+  if (g >= G) return;
+  double a = 0.0;
+  for (int r = 0; r < nrb; ++r) a += part[(int64_t)r * G + g];
+  out[g] = a;
+}
+// one wave per cell, lanes over genes (row-major input: coalesced); fixed-order DPP tree
+template <typename ST>
+__global__ void __launch_bounds__(CA_TB) k_pre_rowsum(const ST* __restrict__ src, const unsigned char* __restrict__ keep_gene, int64_t N,
+                                                      int G, int64_t sn, int64_t sg, double* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n = (int64_t)blockIdx.x * (CA_TB / 64) + (threadIdx.x >> 6);
+  if (n >= N) return;
+  double a = 0.0;
+  for (int g = lane; g < G; g += 64)
+    if (keep_gene[g]) a += (double)src[n * sn + (int64_t)g * sg];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+  if (lane == 0) out[n] = a;
+}
+// one thread per cell, loop over genes (column-major input: coalesced across cells)
+template <typename ST>
+__global__ void __launch_bounds__(CA_TB) k_pre_rowsum_cm(const ST* __restrict__ src, const unsigned char* __restrict__ keep_gene, int64_t N,
+                                                         int G, int64_t sn, int64_t sg, double* __restrict__ out) {
+  const int64_t n = (int64_t)blockIdx.x * CA_TB + threadIdx.x;
+  if (n >= N) return;
+  double a = 0.0;
+  for (int g = 0; g < G; ++g)
+    if (keep_gene[g]) a += (double)src[n * sn + (int64_t)g * sg];
+  out[n] = a;
+}
+
 // ------------------------------------------------------------------ allele-specific term
 // R/allele-specific.R:17-58: the parameter-free [N, C] addend of the log-likelihood.  Per (variant, cell) two
 // log-probabilities of alt reads out of cov: p1 = logsumexp(log .5 + BB(.1, 1.9), log .5 + BB(1.9, .1)) for a clone

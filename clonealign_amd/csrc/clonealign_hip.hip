@@ -1370,6 +1370,79 @@ bool find_param(ca_engine* h, const std::string& n, bool grad, ParamRef& r) {
 }  // namespace
 
 // =============================================================================== C ABI
+template <typename ST>
+static int preprocess_t(const ST* src, int64_t N, int G, int C, int layout, const double* L, const ca_preprocess_params& pp,
+                        uint8_t* keep_gene, uint8_t* keep_cell, double* gene_sums, double* cell_sums, std::string& msg) {
+  const int64_t sn = layout == CA_COL_MAJOR ? 1 : G, sg = layout == CA_COL_MAJOR ? N : 1;
+  double *part = nullptr, *dcol = nullptr, *drow = nullptr; unsigned char* dkeep = nullptr;
+  auto cleanup = [&]() { hipFree(part); hipFree(dcol); hipFree(drow); hipFree(dkeep); };
+#define PCK2(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { msg = std::string(#call) + ": " + hipGetErrorString(e_); cleanup(); return CA_ERR_HIP; } } while (0)
+  const int rpb = 1024, nrb = cdiv(N, rpb);
+  PCK2(hipMalloc((void**)&part, (size_t)nrb * G * sizeof(double)));
+  PCK2(hipMalloc((void**)&dcol, (size_t)G * sizeof(double)));
+  PCK2(hipMalloc((void**)&drow, (size_t)N * sizeof(double)));
+  PCK2(hipMalloc((void**)&dkeep, (size_t)G));
+  hipLaunchKernelGGL((k_pre_colsum<ST>), dim3(cdiv(G, CA_TB), nrb), dim3(CA_TB), 0, 0, src, N, G, sn, sg, rpb, part);
+  hipLaunchKernelGGL(k_pre_colsum_final, dim3(cdiv(G, CA_TB)), dim3(CA_TB), 0, 0, part, nrb, G, dcol);
+  PCK2(hipGetLastError());
+  std::vector<double> col((size_t)G);
+  PCK2(hipMemcpy(col.data(), dcol, (size_t)G * sizeof(double), hipMemcpyDeviceToHost));
+  // ---- O(G) decisions, in the reference's order
+  std::vector<uint8_t> kg((size_t)G, 1);
+  for (int g = 0; g < G; ++g) {                                                   // :114-116
+    double mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = std::max(mx, L[hidx(layout, g, c, G, C)]);
+    if (mx > pp.max_copy_number) kg[g] = 0;
+  }
+  for (int g = 0; g < G; ++g) if (kg[g] && !(col[g] > pp.min_counts_per_gene)) kg[g] = 0;   // :118-120
+  if (pp.remove_outlying_genes) {                                                 // :59-63, 123-128
+    std::vector<double> gm;
+    for (int g = 0; g < G; ++g) if (kg[g]) gm.push_back(col[g] / (double)N);
+    if (!gm.empty()) {
+      auto median = [](std::vector<double> v) {
+        std::sort(v.begin(), v.end());
+        const size_t n = v.size();
+        return n % 2 ? v[n / 2] : 0.5 * (v[n / 2 - 1] + v[n / 2]);
+      };
+      const double med = median(gm);
+      std::vector<double> dev(gm.size());
+      for (size_t i = 0; i < gm.size(); ++i) dev[i] = std::fabs(gm[i] - med);
+      const double md = 1.4826 * median(dev);
+      double mean = 0.0;
+      for (double v : gm) mean += v;
+      mean /= (double)gm.size();
+      const double thr = mean + pp.nmads * md;
+      for (int g = 0; g < G; ++g) if (kg[g] && col[g] / (double)N > thr) kg[g] = 0;
+    }
+  }
+  if (pp.remove_genes_same_copy_number && C >= 2) {                               // :131-135 (rowVars == 0)
+    for (int g = 0; g < G; ++g) {
+      if (!kg[g]) continue;
+      double m = 0.0;
+      for (int c = 0; c < C; ++c) m += L[hidx(layout, g, c, G, C)];
+      m /= C;
+      double v = 0.0;
+      for (int c = 0; c < C; ++c) { const double d = L[hidx(layout, g, c, G, C)] - m; v += d * d; }
+      if (v / (C - 1) == 0.0) kg[g] = 0;
+    }
+  }
+  PCK2(hipMemcpy(dkeep, kg.data(), (size_t)G, hipMemcpyHostToDevice));
+  if (layout == CA_COL_MAJOR)
+    hipLaunchKernelGGL((k_pre_rowsum_cm<ST>), dim3(cdiv(N, CA_TB)), dim3(CA_TB), 0, 0, src, dkeep, N, G, sn, sg, drow);
+  else
+    hipLaunchKernelGGL((k_pre_rowsum<ST>), dim3(cdiv(N, CA_TB / 64)), dim3(CA_TB), 0, 0, src, dkeep, N, G, sn, sg, drow);
+  PCK2(hipGetLastError());
+  std::vector<double> row((size_t)N);
+  PCK2(hipMemcpy(row.data(), drow, (size_t)N * sizeof(double), hipMemcpyDeviceToHost));
+  for (int64_t n = 0; n < N; ++n) keep_cell[n] = row[n] > pp.min_counts_per_cell ? 1 : 0;   // :138-139
+  memcpy(keep_gene, kg.data(), (size_t)G);
+  if (gene_sums) memcpy(gene_sums, col.data(), (size_t)G * sizeof(double));
+  if (cell_sums) memcpy(cell_sums, row.data(), (size_t)N * sizeof(double));
+#undef PCK2
+  cleanup();
+  return CA_OK;
+}
+
 extern "C" {
 
 int ca_abi_version(void) { return CA_ABI_VERSION; }
@@ -1940,6 +2013,35 @@ int ca_allele_loglik(int64_t N, int32_t V, int32_t C, int32_t layout, const doub
 #undef ACK
   cleanup();
   return CA_OK;
+}
+
+int ca_preprocess(int64_t N, int32_t G, int32_t C, int32_t layout, int32_t y_dtype, int32_t y_on_device, const void* Y,
+                  const double* L, const ca_preprocess_params* params, int32_t device, uint8_t* keep_gene,
+                  uint8_t* keep_cell, double* gene_sums, double* cell_sums, char* err) {
+  auto fail = [&](int code, const std::string& m) { if (err) { strncpy(err, m.c_str(), 255); err[255] = 0; } return code; };
+  if (N < 1 || G < 1 || C < 1 || !Y || !L || !params || !keep_gene || !keep_cell) return fail(CA_ERR_INVALID, "ca_preprocess: bad arguments");
+  if (layout != CA_ROW_MAJOR && layout != CA_COL_MAJOR) return fail(CA_ERR_INVALID, "ca_preprocess: bad layout");
+  if (hipSetDevice(device) != hipSuccess) return fail(CA_ERR_HIP, "ca_preprocess: hipSetDevice failed");
+  const size_t esz = y_dtype == CA_F64 ? 8 : (y_dtype == CA_F32 || y_dtype == CA_I32) ? 4 : y_dtype == CA_U16 ? 2 : 1;
+  const void* src = Y;
+  void* staging = nullptr;
+  if (!y_on_device) {
+    if (hipMalloc(&staging, (size_t)N * G * esz) != hipSuccess) return fail(CA_ERR_NOMEM, "ca_preprocess: device allocation of the count matrix failed");
+    if (hipMemcpy(staging, Y, (size_t)N * G * esz, hipMemcpyHostToDevice) != hipSuccess) { hipFree(staging); return fail(CA_ERR_HIP, "ca_preprocess: upload failed"); }
+    src = staging;
+  }
+  std::string msg;
+  int rc;
+  switch (y_dtype) {
+    case CA_F64: rc = preprocess_t<double>((const double*)src, N, G, C, layout, L, *params, keep_gene, keep_cell, gene_sums, cell_sums, msg); break;
+    case CA_F32: rc = preprocess_t<float>((const float*)src, N, G, C, layout, L, *params, keep_gene, keep_cell, gene_sums, cell_sums, msg); break;
+    case CA_I32: rc = preprocess_t<int32_t>((const int32_t*)src, N, G, C, layout, L, *params, keep_gene, keep_cell, gene_sums, cell_sums, msg); break;
+    case CA_U16: rc = preprocess_t<uint16_t>((const uint16_t*)src, N, G, C, layout, L, *params, keep_gene, keep_cell, gene_sums, cell_sums, msg); break;
+    case CA_U8: rc = preprocess_t<uint8_t>((const uint8_t*)src, N, G, C, layout, L, *params, keep_gene, keep_cell, gene_sums, cell_sums, msg); break;
+    default: rc = CA_ERR_INVALID; msg = "ca_preprocess: unknown y_dtype";
+  }
+  if (staging) hipFree(staging);
+  return rc == CA_OK ? CA_OK : fail(rc, msg);
 }
 
 }  // extern "C"

@@ -24,7 +24,7 @@ EXPORTS = (
     "ca_abi_version", "ca_default_options", "ca_create", "ca_destroy", "ca_last_error", "ca_get_info",
     "ca_synchronize", "ca_comm_unique_id", "ca_comm_init", "ca_set_host_allreduce", "ca_gamma_init", "ca_elbo", "ca_elbo_terms",
     "ca_step", "ca_gradients", "ca_run", "ca_iterate", "ca_final_elbo", "ca_init_psi_pca", "ca_clone_gene_sums", "ca_get_param", "ca_set_param",
-    "ca_get_gradient", "ca_get_kernel_times", "ca_reset_kernel_times", "ca_set_profile", "ca_eps_draw", "ca_allele_loglik",
+    "ca_get_gradient", "ca_get_kernel_times", "ca_reset_kernel_times", "ca_set_profile", "ca_eps_draw", "ca_allele_loglik", "ca_preprocess",
 )
 
 
@@ -48,6 +48,12 @@ class CaInfo(C.Structure):
                 ("y_device_bytes", C.c_int64), ("device_bytes", C.c_int64), ("gsplit", C.c_int32),
                 ("csplit", C.c_int32), ("n_cu", C.c_int32), ("fused_sweep", C.c_int32), ("fwd_mfma", C.c_int32),
                 ("bwd_mfma", C.c_int32), ("fsplit", C.c_int32), ("reserved", C.c_int32 * 4)]
+
+
+class CaPreprocessParams(C.Structure):
+    _fields_ = [("min_counts_per_gene", C.c_double), ("min_counts_per_cell", C.c_double),
+                ("remove_outlying_genes", C.c_int32), ("remove_genes_same_copy_number", C.c_int32),
+                ("nmads", C.c_double), ("max_copy_number", C.c_double)]
 
 
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)
@@ -97,6 +103,8 @@ def load_library(path=None):
     lib.ca_reset_kernel_times.argtypes = [C.c_void_p]
     lib.ca_set_profile.argtypes = [C.c_void_p, C.c_int32]
     lib.ca_eps_draw.argtypes = [C.c_uint64, C.c_uint64, C.c_int64, C.c_void_p]
+    lib.ca_preprocess.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                  C.POINTER(CaPreprocessParams), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p]
     lib.ca_allele_loglik.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                      C.c_void_p, C.c_char_p]
     if path is None:
@@ -386,3 +394,35 @@ def allele_loglik(clone_allele, cov, ref, device=0):
     if rc != CA_OK:
         raise EngineError(rc, err.value.decode() or "ca_allele_loglik")
     return out
+
+
+_NP_DTYPE = {np.dtype(np.float64): 0, np.dtype(np.float32): 1, np.dtype(np.int32): 2, np.dtype(np.uint16): 3, np.dtype(np.uint8): 4}
+
+
+def preprocess_masks(Y, L, min_counts_per_gene=20, min_counts_per_cell=100, remove_outlying_genes=True, nmads=10,
+                     max_copy_number=6, remove_genes_same_copy_number=True, device=0):
+    """Gene / cell retention masks of preprocess_for_clonealign() with the two O(N G) statistics taken on the device
+    (ca_preprocess; R/preprocess.R:93-147).  Y [N, G] in float64/float32/int32/uint16/uint8 (other dtypes are converted
+    to float64), L [G, C].  Returns (keep_gene bool[G], keep_cell bool[N], gene_sums[G], cell_sums[N])."""
+    lib = load_library()
+    Y = np.asarray(Y)
+    if Y.dtype not in _NP_DTYPE:
+        Y = Y.astype(np.float64)
+    Y = np.ascontiguousarray(Y)
+    L = np.ascontiguousarray(np.asarray(L, dtype=np.float64))
+    N, G = Y.shape
+    if L.shape[0] != G:
+        raise ValueError("copy_number_data must have same number of genes (rows) as gene_expression_data")
+    pp = CaPreprocessParams(float(min_counts_per_gene), float(min_counts_per_cell), int(bool(remove_outlying_genes)),
+                            int(bool(remove_genes_same_copy_number)), float(nmads), float(max_copy_number))
+    kg = np.zeros(G, dtype=np.uint8)
+    kc = np.zeros(N, dtype=np.uint8)
+    gs = np.zeros(G, dtype=np.float64)
+    cs = np.zeros(N, dtype=np.float64)
+    err = C.create_string_buffer(256)
+    rc = lib.ca_preprocess(N, G, L.shape[1], CA_ROW_MAJOR, _NP_DTYPE[Y.dtype], 0, Y.ctypes.data_as(C.c_void_p),
+                           L.ctypes.data_as(C.c_void_p), C.byref(pp), int(device), kg.ctypes.data_as(C.c_void_p),
+                           kc.ctypes.data_as(C.c_void_p), gs.ctypes.data_as(C.c_void_p), cs.ctypes.data_as(C.c_void_p), err)
+    if rc != CA_OK:
+        raise EngineError(rc, err.value.decode() or "ca_preprocess")
+    return kg.astype(bool), kc.astype(bool), gs, cs

@@ -1,8 +1,10 @@
 """``preprocess_for_clonealign`` -- host mirror of R/preprocess.R:93-147.
 
-One-shot O(N*G) filtering ahead of the fit.  Kept on the host for
-now; it is needed to reproduce the reference's only recorded numeric run (the vignette,
-docs/introduction_to_clonealign.html:746-819).
+One-shot O(N*G) filtering ahead of the fit.  The two O(N*G) statistics (colSums, then rowSums
+over the retained genes) can be taken on the device from the raw matrix (``on="device"``: ca_preprocess); the filtered
+matrices the reference returns are then cut on the host with the masks.  The host form is what reproduces the
+reference's only recorded numeric run (the vignette, docs/introduction_to_clonealign.html:746-819) and is the check
+of the device form.
 """
 import numpy as np
 
@@ -25,8 +27,10 @@ def get_outlying_genes(Y, nmads):
 def preprocess_for_clonealign(gene_expression_data, copy_number_data, min_counts_per_gene=20,
                               min_counts_per_cell=100, remove_outlying_genes=True, nmads=10,
                               max_copy_number=6, remove_genes_same_copy_number=True,
-                              gene_names=None, cell_names=None):
-    """Filter genes/cells exactly in the order of R/preprocess.R:114-139."""
+                              gene_names=None, cell_names=None, on="auto", device=0):
+    """Filter genes/cells exactly in the order of R/preprocess.R:114-139.
+
+    ``on`` in {"auto", "host", "device"}: where colSums / rowSums are taken ("auto": on the device above 2e7 elements)."""
     Y, gn = _parse_expression(gene_expression_data)
     L, _ = _parse_cnv(copy_number_data)
     G = Y.shape[1]
@@ -34,6 +38,18 @@ def preprocess_for_clonealign(gene_expression_data, copy_number_data, min_counts
         raise ValueError("copy_number_data must have same number of genes (rows) as gene_expression_data")
     genes = np.array(gene_names if gene_names is not None else (gn if gn is not None else np.arange(G)))
     cells = np.array(cell_names if cell_names is not None else np.arange(Y.shape[0]))
+    if on not in ("auto", "host", "device"):
+        raise ValueError("on must be 'auto', 'host' or 'device'")
+    if on == "device" or (on == "auto" and Y.size > 20_000_000):
+        from .engine import preprocess_masks
+        kg, kc, _gs, _cs = preprocess_masks(Y, L, min_counts_per_gene, min_counts_per_cell, remove_outlying_genes, nmads,
+                                            max_copy_number, remove_genes_same_copy_number, device=device)
+        return {
+            "gene_expression_data": Y[np.ix_(kc, kg)],
+            "copy_number_data": L[kg, :],
+            "retained_cells": cells[kc],
+            "retained_genes": genes[kg],
+        }
 
     def keep_genes(mask):
         nonlocal Y, L, genes

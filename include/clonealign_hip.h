@@ -188,6 +188,25 @@ int ca_eps_draw(uint64_t seed, uint64_t draw, int64_t n, float* out);
 int ca_allele_loglik(int64_t N, int32_t V, int32_t C, int32_t layout, const double* clone_allele, const double* cov,
                      const double* ref, int32_t device, double* out, char* err);
 
+/* Gene / cell filters of preprocess_for_clonealign() (R/preprocess.R:93-147), needs no handle.
+ * The two O(N G) statistics -- colSums(Y) and, after the gene filters, rowSums(Y[, kept]) -- are taken on the device
+ * from the caller's raw matrix (any ca_dtype, either layout, host or device pointer); the O(G) decisions follow the
+ * reference's order: copy number above max (:114-116), colSums <= min_counts_per_gene (:118-120), outlying gene means
+ * (mean + nmads * mad, :59-63,123-128), equal copy number in all clones (:131-135), rowSums <= min_counts_per_cell
+ * (:138-139).  Outputs: keep_gene [G], keep_cell [N] (1 = retained); gene_sums [G] / cell_sums [N] optional (may be NULL).
+ * The caller subsets Y, L and the names with the masks (the reference returns the filtered matrices). */
+typedef struct ca_preprocess_params {
+  double min_counts_per_gene;         /* 20   */
+  double min_counts_per_cell;         /* 100  */
+  int32_t remove_outlying_genes;      /* 1    */
+  int32_t remove_genes_same_copy_number; /* 1 */
+  double nmads;                       /* 10   */
+  double max_copy_number;             /* 6    */
+} ca_preprocess_params;
+int ca_preprocess(int64_t N, int32_t G, int32_t C, int32_t layout, int32_t y_dtype, int32_t y_on_device, const void* Y,
+                  const double* L, const ca_preprocess_params* params, int32_t device, uint8_t* keep_gene,
+                  uint8_t* keep_cell, double* gene_sums, double* cell_sums, char* err);
+
 #ifdef __cplusplus
 }
 #endif

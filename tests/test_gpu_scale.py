@@ -298,3 +298,38 @@ def test_inference_with_allele_term_device_equals_host():
     b = inference_tflow(case["Y"], case["L"], allele_on="device", **kw)
     np.testing.assert_allclose(a["convergence_info"]["elbo"], b["convergence_info"]["elbo"], rtol=1e-9)
     np.testing.assert_allclose(a["clone_probs_from_snv"], b["clone_probs_from_snv"], rtol=1e-10)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "int32", "uint16"])
+def test_preprocess_masks_on_device_match_host(dtype):
+    """ca_preprocess against the host mirror of R/preprocess.R:93-147 on data where every filter bites."""
+    from clonealign_amd.preprocess import preprocess_for_clonealign
+    rng = np.random.default_rng(12)
+    N, G, C = 700, 420, 4
+    mu = rng.lognormal(-1.0, 1.2, G)
+    mu[:3] *= 300.0                                    # outlying genes
+    Y = rng.poisson(mu[None, :] * rng.lognormal(0, 0.6, N)[:, None]).astype(dtype)
+    Y[:40] = 0                                         # cells without coverage
+    Y[:40, 5] = 1
+    L = rng.integers(1, 5, size=(G, C)).astype(np.float64)
+    L[10:20] = 2.0                                     # same copy number in all clones
+    L[30:34, 1] = 9.0                                  # above max_copy_number
+    Y[:, 50:60] = 0                                    # unexpressed genes
+    kw = dict(min_counts_per_gene=20, min_counts_per_cell=25, nmads=10)
+    host = preprocess_for_clonealign(Y.astype(np.float64), L, on="host", **kw)
+    dev = preprocess_for_clonealign(Y, L, on="device", **kw)
+    assert 0 < len(dev["retained_genes"]) < G and 0 < len(dev["retained_cells"]) < N
+    assert np.array_equal(host["retained_genes"], dev["retained_genes"])
+    assert np.array_equal(host["retained_cells"], dev["retained_cells"])
+    assert np.array_equal(host["gene_expression_data"], dev["gene_expression_data"].astype(np.float64))
+    assert np.array_equal(host["copy_number_data"], dev["copy_number_data"])
+
+
+def test_preprocess_example_sce_device_equals_host():
+    from clonealign_amd.preprocess import preprocess_for_clonealign
+    from tests import _golden
+    Y, L, *_ = _golden.example()
+    host = preprocess_for_clonealign(Y, L, on="host")
+    dev = preprocess_for_clonealign(Y, L, on="device")
+    assert np.array_equal(host["retained_genes"], dev["retained_genes"])
+    assert np.array_equal(host["retained_cells"], dev["retained_cells"])
