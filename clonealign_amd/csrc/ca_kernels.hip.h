@@ -36,18 +36,19 @@ __device__ __forceinline__ float ca_wave_sum_lane63(float v) {
   return v;
 }
 
-// deterministic block tree sum of doubles (blockDim.x == CA_TB); result valid in every thread
+// deterministic block sum of doubles (blockDim.x == CA_TB); result valid in every thread.  Xor-butterfly inside each
+// wave (no LDS, no barrier), then the CA_TB / 64 wave totals through LDS in wave order: 2 barriers instead of the
+// 10 of an LDS tree -- the per-gene / per-cell / O(K + C) kernels are chains of these.
 __device__ __forceinline__ double ca_block_sum(double v, double* sm) {
-  const int t = threadIdx.x;
-  __syncthreads();
-  sm[t] = v;
-  __syncthreads();
 #pragma unroll
-  for (int s = CA_TB / 2; s > 0; s >>= 1) {
-    if (t < s) sm[t] += sm[t + s];
-    __syncthreads();
-  }
-  return sm[0];
+  for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o, 64);
+  __syncthreads();   // sm may still be read from a previous call
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = sm[0];
+#pragma unroll
+  for (int w = 1; w < CA_TB / 64; ++w) r += sm[w];
+  return r;
 }
 
 __device__ __forceinline__ unsigned short ca_bf16_rn(float f) {
@@ -1399,6 +1400,30 @@ __global__ void __launch_bounds__(CA_TB) k_allele_loglik(const double* __restric
     for (int c = 0; c < C; ++c) out[n * on + (int64_t)c * oc] += t1;
 }
 
+// log_alpha = log_softmax(alpha_unconstr) (R/inference-tflow.R:255) into LDS, by wave 0: one lane per clone, the C
+// exponentials side by side (they were a serial chain on thread 0: ~2 us at the head of every cell-epilogue block)
+__device__ __forceinline__ void ca_log_softmax_alpha(const float* __restrict__ alpha_u, int C, double* la) {
+  if (threadIdx.x >= 64) return;
+  if (C <= 64) {
+    const int c = threadIdx.x;
+    const double au = c < C ? (double)alpha_u[c] : -INFINITY;
+    double mx = au;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) mx = fmax(mx, __shfl_xor(mx, o, 64));
+    double se = c < C ? exp(au - mx) : 0.0;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) se += __shfl_xor(se, o, 64);
+    if (c < C) la[c] = au - (mx + log(se));
+  } else if (threadIdx.x == 0) {
+    double mx = -INFINITY;
+    for (int c = 0; c < C; ++c) mx = fmax(mx, (double)alpha_u[c]);
+    double se = 0.0;
+    for (int c = 0; c < C; ++c) se += exp((double)alpha_u[c] - mx);
+    const double lse = mx + log(se);
+    for (int c = 0; c < C; ++c) la[c] = (double)alpha_u[c] - lse;
+  }
+}
+
 // ------------------------------------------------------------------ per-cell epilogue
 // Everything of R/inference-tflow.R:294-308,322,327,332-333,338-342 that is per cell, in fp64:
 // log-lik ll'_nc = A_nc - s_n mean_s log Z_snc, gamma = softmax(logits), the cell's ELBO
@@ -1421,14 +1446,7 @@ __global__ void __launch_bounds__(CA_TB) k_cell(const float* __restrict__ Zpart 
   __shared__ double sm[CA_TB];
   __shared__ double la[256];
   // log_alpha = log_softmax(alpha_unconstr) (:255); C is small
-  if (threadIdx.x == 0) {
-    double mx = -INFINITY;
-    for (int c = 0; c < C; ++c) mx = fmax(mx, (double)alpha_u[c]);
-    double se = 0.0;
-    for (int c = 0; c < C; ++c) se += exp((double)alpha_u[c] - mx);
-    const double lse = mx + log(se);
-    for (int c = 0; c < C; ++c) la[c] = (double)alpha_u[c] - lse;
-  }
+  ca_log_softmax_alpha(alpha_u, C, la);
   __syncthreads();
   const int64_t n = (int64_t)blockIdx.x * CA_TB + threadIdx.x;
   const bool ok = n < N;
@@ -1530,14 +1548,7 @@ __global__ void __launch_bounds__(CA_TB) k_cell_par(const float* __restrict__ Zp
   __shared__ double sm[CA_TB];
   __shared__ double la[64];
   constexpr int CPB = CA_TB / CP;  // cells per block
-  if (threadIdx.x == 0) {
-    double mx = -INFINITY;
-    for (int c = 0; c < C; ++c) mx = fmax(mx, (double)alpha_u[c]);
-    double se = 0.0;
-    for (int c = 0; c < C; ++c) se += exp((double)alpha_u[c] - mx);
-    const double lse = mx + log(se);
-    for (int c = 0; c < C; ++c) la[c] = (double)alpha_u[c] - lse;
-  }
+  ca_log_softmax_alpha(alpha_u, C, la);
   __syncthreads();
   const int c = threadIdx.x % CP;
   auto gmax = [](double v) {
@@ -1652,14 +1663,7 @@ __global__ void __launch_bounds__(CA_TB) k_cell_fused(const float* __restrict__ 
   __shared__ double sm[CA_TB];
   __shared__ double la[64];
   constexpr int CPB = CA_TB / CP;
-  if (threadIdx.x == 0) {
-    double mx = -INFINITY;
-    for (int c = 0; c < C; ++c) mx = fmax(mx, (double)alpha_u[c]);
-    double se = 0.0;
-    for (int c = 0; c < C; ++c) se += exp((double)alpha_u[c] - mx);
-    const double lse = mx + log(se);
-    for (int c = 0; c < C; ++c) la[c] = (double)alpha_u[c] - lse;
-  }
+  ca_log_softmax_alpha(alpha_u, C, la);
   __syncthreads();
   const int c = threadIdx.x % CP;
   auto gmax = [](double v) {
