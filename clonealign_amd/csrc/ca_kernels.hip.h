@@ -419,14 +419,16 @@ __global__ void __launch_bounds__(1024) k_colsum(const float* __restrict__ part,
   __shared__ double sm[RL][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + tx;
-  double a0 = 0.0, a1 = 0.0;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;   // four independent chains: the loads of a row lane overlap
   if (c < cols) {
     int r = ty;
-    for (; r + RL < rows; r += 2 * RL) {
-      a0 += (double)part[(int64_t)r * ld + c];
-      a1 += (double)part[(int64_t)(r + RL) * ld + c];
+    for (; r + 3 * RL < rows; r += 4 * RL) {
+      const float v0 = part[(int64_t)r * ld + c], v1 = part[(int64_t)(r + RL) * ld + c];
+      const float v2 = part[(int64_t)(r + 2 * RL) * ld + c], v3 = part[(int64_t)(r + 3 * RL) * ld + c];
+      a0 += (double)v0; a1 += (double)v1; a2 += (double)v2; a3 += (double)v3;
     }
-    if (r < rows) a0 += (double)part[(int64_t)r * ld + c];
+    for (; r < rows; r += RL) a0 += (double)part[(int64_t)r * ld + c];
+    a0 += a2; a1 += a3;
     if (csum && ty == 0) {   // gene side of the overflow list (k_ovf_cols folded in): column c = gene * K + k
       const int g = c / K, k = c - g * K;
       if (g < G)
