@@ -1162,7 +1162,7 @@ __device__ __forceinline__ void ca_final_small_body(const ca_small_args& sa) {
 // summation order (tools/bwd_lab3.hip: 4e-8 relative).  Rows = genes, columns = cells, so a lane owns ONE cell per
 // batch: d/dF needs a 4-lane-group sum per batch, the per-gene sums stay in-lane over the whole cell slice.
 // On gfx950 every VALU instruction costs 4 cycles per wave64, packed or not (tools/valu_lab.hip), hence the explicit
-// 2-wide math.  Used when D == 1, C <= 8 and L is bf16-exact; k_bwd is the general fallback.
+// 2-wide math.  Used when D is 1 or 2 (template DD), C <= 8 and L is bf16-exact; k_bwd is the general fallback.
 
 // three bf16 parts of a float: x = p1 + p2 + p3 up to 2^-24 relative
 __device__ __forceinline__ void ca_split3(float x, unsigned short& p1, unsigned short& p2, unsigned short& p3) {
@@ -1171,15 +1171,15 @@ __device__ __forceinline__ void ca_split3(float x, unsigned short& p1, unsigned 
   p3 = ca_bf16_rn(x);
 }
 
-template <int TL>
+template <int TL, int DD>
 __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __restrict__ cq /*[N16][4][8] bf16 parts of coef*/,
-                                                    const float* __restrict__ F /*[N16]*/, const float* __restrict__ etamax2 /*[N16]*/,
+                                                    const float* __restrict__ F /*[N16][DD]*/, const float* __restrict__ etamax2 /*[N16]*/,
                                                     const float* __restrict__ Lb /*[G][8]*/, const float* __restrict__ mu,
                                                     const float* __restrict__ Vs, const float* __restrict__ V,
-                                                    float* __restrict__ gpart /*[csplit][G][S+1]*/, float* __restrict__ dFpart /*[gridDim.x][N]*/,
+                                                    float* __restrict__ gpart /*[csplit][G][S+DD]*/, float* __restrict__ dFpart /*[gridDim.x][N][DD]*/,
                                                     int64_t N, int G, int64_t cchunk, int S, int sidx, int first_s, int first,
                                                     ca_small_args tail, int xblocks) {
-  extern __shared__ float ca_lds[];   // [4 waves][cchunk]: per-wave d/dF of the block's cell slice, summed at the end
+  extern __shared__ float ca_lds[];   // [4 waves][cchunk][DD]: per-wave d/dF of the block's cell slice, summed at the end
   if ((int)blockIdx.x >= xblocks) {   // the extra block column: its first block assembles the previous pass's ELBO
     if (blockIdx.y == 0 && tail.enabled) ca_final_small_body(tail);
     return;
@@ -1190,7 +1190,7 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
   const int gbase = wtile * TL * 16;
   const bool active = gbase < G;
   ca_bf16x8 Lf[TL];
-  ca_f32x2 vs[TL][2], mv[TL][2], accU[TL][2], accUF[TL][2];
+  ca_f32x2 vs[TL][2][DD], mv[TL][2][DD], accU[TL][2], accUF[TL][2][DD];
 #pragma unroll
   for (int m = 0; m < TL; ++m) {
     {  // MFMA A operand: lane (row j, k-group q) holds L[gene gbase+16m+j][0..8), once per coef part (q < 3).
@@ -1212,46 +1212,62 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {  // this lane's output rows: genes gbase + 16m + 4q + {2h, 2h+1}
-      float a[2], b[2];
+      float a[DD][2], b[DD][2];
 #pragma unroll
       for (int x = 0; x < 2; ++x) {
         const int g = gbase + 16 * m + 4 * q + 2 * h + x;
         const bool ok = g < G;
         const int gg = ok ? g : G - 1;
-        const float vsv = Vs[gg], muv = mu[gg], vv = V[gg];
-        a[x] = vsv;                  // rows past G keep a real gene's loading (exponent <= 0, never inf); their t is 0
-        b[x] = ok ? muv * vv : 0.f;
+        const float muv = mu[gg];
+#pragma unroll
+        for (int d = 0; d < DD; ++d) {
+          const float vsv = Vs[(int64_t)gg * DD + d], vv = V[(int64_t)gg * DD + d];
+          a[d][x] = vsv;             // rows past G keep a real gene's loading (exponent <= 0, never inf); their t is 0
+          b[d][x] = ok ? muv * vv : 0.f;
+        }
       }
-      vs[m][h] = (ca_f32x2){a[0], a[1]};
-      mv[m][h] = (ca_f32x2){b[0], b[1]};
       accU[m][h] = (ca_f32x2){0.f, 0.f};
-      accUF[m][h] = (ca_f32x2){0.f, 0.f};
+#pragma unroll
+      for (int d = 0; d < DD; ++d) {
+        vs[m][h][d] = (ca_f32x2){a[d][0], a[d][1]};
+        mv[m][h][d] = (ca_f32x2){b[d][0], b[d][1]};
+        accUF[m][h][d] = (ca_f32x2){0.f, 0.f};
+      }
     }
   }
   const int64_t n0 = (int64_t)blockIdx.y * cchunk;
   const int64_t n1 = (n0 + cchunk < N) ? n0 + cchunk : N;
-  float* myd = ca_lds + (int64_t)wv * cchunk;
+  float* myd = ca_lds + (int64_t)wv * cchunk * DD;
   if (!active)
-    for (int64_t i = lane; i < n1 - n0; i += 64) myd[i] = 0.f;
+    for (int64_t i = lane; i < (n1 - n0) * DD; i += 64) myd[i] = 0.f;
   // MFMA B operand: lane (column j, k-group q) holds part q of coef[cell b0+j][0..8): 16 bytes, 1 KiB per wave.
   // The next batch's operands are fetched while the current one is in the pipes (cell arrays padded to 16).
   uint4 craw_n = {0u, 0u, 0u, 0u};
-  float fc_n = 0.f, ec_n = 0.f;
+  float fc_n[DD], ec_n = 0.f;
+#pragma unroll
+  for (int d = 0; d < DD; ++d) fc_n[d] = 0.f;
   if (active && n0 < n1) {
     craw_n = *reinterpret_cast<const uint4*>(cq + ((n0 + j) * 4 + q) * 8);
-    fc_n = F[n0 + j];
+#pragma unroll
+    for (int d = 0; d < DD; ++d) fc_n[d] = F[(n0 + j) * DD + d];
     ec_n = etamax2[n0 + j];
   }
   for (int64_t b0 = n0; active && b0 < n1; b0 += 16) {
     const uint4 craw = craw_n;
-    const float fc = fc_n, ec = ec_n;
+    float fc[DD];
+#pragma unroll
+    for (int d = 0; d < DD; ++d) fc[d] = fc_n[d];
+    const float ec = ec_n;
     if (b0 + 16 < n1) {
       craw_n = *reinterpret_cast<const uint4*>(cq + ((b0 + 16 + j) * 4 + q) * 8);
-      fc_n = F[b0 + 16 + j];
+#pragma unroll
+      for (int d = 0; d < DD; ++d) fc_n[d] = F[(b0 + 16 + j) * DD + d];
       ec_n = etamax2[b0 + 16 + j];
     }
     const ca_bf16x8 Cf = __builtin_bit_cast(ca_bf16x8, craw);
-    ca_f32x2 dF = {0.f, 0.f};
+    ca_f32x2 dF[DD];
+#pragma unroll
+    for (int d = 0; d < DD; ++d) dF[d] = (ca_f32x2){0.f, 0.f};
 #pragma unroll
     for (int m = 0; m < TL; ++m) {
       ca_f32x4 t = {0.f, 0.f, 0.f, 0.f};
@@ -1259,45 +1275,61 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
       const ca_f32x2 t2[2] = {{t[0], t[1]}, {t[2], t[3]}};
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const ca_f32x2 eta = vs[m][h] * fc - ec;
+        ca_f32x2 eta = vs[m][h][0] * fc[0] - ec;
+#pragma unroll
+        for (int d = 1; d < DD; ++d) eta = vs[m][h][d] * fc[d] + eta;
         const ca_f32x2 ex = {__builtin_amdgcn_exp2f(eta.x), __builtin_amdgcn_exp2f(eta.y)};
         const ca_f32x2 u = ex * t2[h];
         accU[m][h] += u;
-        accUF[m][h] = u * fc + accUF[m][h];
-        dF = u * mv[m][h] + dF;
+#pragma unroll
+        for (int d = 0; d < DD; ++d) {
+          accUF[m][h][d] = u * fc[d] + accUF[m][h][d];
+          dF[d] = u * mv[m][h][d] + dF[d];
+        }
       }
     }
-    float d = dF.x + dF.y;
-    d += __shfl_xor(d, 16);
-    d += __shfl_xor(d, 32);
     const int64_t n = b0 + j;
-    if (q == 0 && n < n1) myd[n - n0] = d;
+#pragma unroll
+    for (int d = 0; d < DD; ++d) {
+      float dd = dF[d].x + dF[d].y;
+      dd += __shfl_xor(dd, 16);
+      dd += __shfl_xor(dd, 32);
+      if (q == 0 && n < n1) myd[(n - n0) * DD + d] = dd;
+    }
   }
   __syncthreads();
-  for (int64_t i = threadIdx.x; i < n1 - n0; i += CA_TB) {
-    const float d = (ca_lds[i] + ca_lds[cchunk + i]) + (ca_lds[2 * cchunk + i] + ca_lds[3 * cchunk + i]);
-    float* p = dFpart + (int64_t)blockIdx.x * N + n0 + i;
+  const int64_t wstride = cchunk * DD;
+  for (int64_t i = threadIdx.x; i < (n1 - n0) * DD; i += CA_TB) {
+    const float d = (ca_lds[i] + ca_lds[wstride + i]) + (ca_lds[2 * wstride + i] + ca_lds[3 * wstride + i]);
+    float* p = dFpart + ((int64_t)blockIdx.x * N + n0) * DD + i;
     *p = first ? d : (*p + d);
   }
   if (!active) return;
-  const int W_ = S + 1;
+  const int W_ = S + DD;
 #pragma unroll
   for (int m = 0; m < TL; ++m)
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       // sum over the 16 cell lanes of the row; lanes j = 0,1 write genes 2h, 2h+1 of the lane group
-      float a0 = accU[m][h].x, a1 = accU[m][h].y, b0_ = accUF[m][h].x, b1 = accUF[m][h].y;
-      a0 += ca_dpp_pull<0xB1, 0xF>(a0); a0 += ca_dpp_pull<0x4E, 0xF>(a0); a0 += ca_dpp_pull<0x141, 0xF>(a0); a0 += ca_dpp_pull<0x140, 0xF>(a0);
-      a1 += ca_dpp_pull<0xB1, 0xF>(a1); a1 += ca_dpp_pull<0x4E, 0xF>(a1); a1 += ca_dpp_pull<0x141, 0xF>(a1); a1 += ca_dpp_pull<0x140, 0xF>(a1);
-      b0_ += ca_dpp_pull<0xB1, 0xF>(b0_); b0_ += ca_dpp_pull<0x4E, 0xF>(b0_); b0_ += ca_dpp_pull<0x141, 0xF>(b0_); b0_ += ca_dpp_pull<0x140, 0xF>(b0_);
-      b1 += ca_dpp_pull<0xB1, 0xF>(b1); b1 += ca_dpp_pull<0x4E, 0xF>(b1); b1 += ca_dpp_pull<0x141, 0xF>(b1); b1 += ca_dpp_pull<0x140, 0xF>(b1);
+      auto row16 = [](float v) {
+        v += ca_dpp_pull<0xB1, 0xF>(v); v += ca_dpp_pull<0x4E, 0xF>(v); v += ca_dpp_pull<0x141, 0xF>(v); v += ca_dpp_pull<0x140, 0xF>(v);
+        return v;
+      };
+      const float a0 = row16(accU[m][h].x), a1 = row16(accU[m][h].y);
+      float bx[DD], by[DD];
+#pragma unroll
+      for (int d = 0; d < DD; ++d) { bx[d] = row16(accUF[m][h][d].x); by[d] = row16(accUF[m][h][d].y); }
       if (j < 2) {
         const int g = gbase + 16 * m + 4 * q + 2 * h + j;
         if (g < G) {
           float* gp = gpart + ((int64_t)blockIdx.y * G + g) * W_;
-          const float su = j ? a1 : a0, suf = mu[g] * (j ? b1 : b0_);
+          const float su = j ? a1 : a0;
           gp[sidx] = first_s ? su : gp[sidx] + su;
-          gp[S] = first ? suf : gp[S] + suf;
+#pragma unroll
+          for (int d = 0; d < DD; ++d) {
+            const float suf = mu[g] * (j ? by[d] : bx[d]);
+            gp[S + d] = first ? suf : gp[S + d] + suf;
+          }
         }
       }
     }

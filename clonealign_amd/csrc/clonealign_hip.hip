@@ -119,7 +119,6 @@ struct ca_engine {
   bool fused_ok = false, look_valid = false; int64_t look_slot = 0; int frow = 8;
   float *Mb2 = nullptr, *mu32B = nullptr, *Zpart2 = nullptr; double* gene_partB = nullptr;
   bool y_defer = false;
-  hipStream_t stream3 = nullptr; hipEvent_t ev_elbo = nullptr;   // ELBO read-back beside the speculative backward sweep (ca_run)
   bool bwd_ready = false; int64_t bwd_slot = -1;
   ca_small_args mon_tail;          // pending ELBO assembly of a fused monitor pass: rides on the next backward sweep
   bool tail_fuse = true;
@@ -610,13 +609,18 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
     merged = is_sharded(h) && h->mon_tail.enabled && h->mon_tail.cell_part != nullptr;
     ca_small_args bwd_tail = h->mon_tail;
     if (merged) { bwd_tail.reduce_only = 1; bwd_tail.host_out = nullptr; }
-    for (int s = 0; s < h->S; ++s)
-      LAUNCH(h, CA_KERNEL_BWD,
-             hipLaunchKernelGGL((k_bwd_mfma<TL>), dim3(xb + ((s == 0 && h->mon_tail.enabled) ? 1 : 0), h->csplit_m), dim3(CA_TB),
-                                (size_t)h->cchunk_m * 4 * sizeof(float), h->stream,
-                                h->coefq + (int64_t)s * h->N16 * 32, h->F, h->etamax2, h->Lb, mu32 + (int64_t)s * h->G, h->Vs, h->V,
-                                h->gpart, h->dFpart, h->N, h->G, h->cchunk_m, h->S, s, 1, s == 0 ? 1 : 0,
-                                s == 0 ? bwd_tail : no_small_args(), xb));
+#define CA_BWDM(DDV)                                                                                                              \
+  LAUNCH(h, CA_KERNEL_BWD,                                                                                                       \
+         hipLaunchKernelGGL((k_bwd_mfma<TL, DDV>), dim3(xb + ((s == 0 && h->mon_tail.enabled) ? 1 : 0), h->csplit_m), dim3(CA_TB), \
+                            (size_t)h->cchunk_m * 4 * DDV * sizeof(float), h->stream,                                             \
+                            h->coefq + (int64_t)s * h->N16 * 32, h->F, h->etamax2, h->Lb, mu32 + (int64_t)s * h->G, h->Vs, h->V,   \
+                            h->gpart, h->dFpart, h->N, h->G, h->cchunk_m, h->S, s, 1, s == 0 ? 1 : 0,                             \
+                            s == 0 ? bwd_tail : no_small_args(), xb))
+    for (int s = 0; s < h->S; ++s) {
+      if (h->D == 1) CA_BWDM(1);
+      else CA_BWDM(2);
+    }
+#undef CA_BWDM
     if (merged) h->mon_tail.cell_part = nullptr;   // reduced by the extra block; all-reduced below with the gene sums
     else h->mon_tail.enabled = 0;
     // (summing the sweep's partials inside k_final_gene instead -- one thread per gene, csplit_m loads in a row -- was
@@ -1098,8 +1102,6 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   HIPCK(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
   HIPCK(h, hipEventCreateWithFlags(&h->ev_params, hipEventDisableTiming));
   HIPCK(h, hipEventCreateWithFlags(&h->ev_ydone, hipEventDisableTiming));
-  HIPCK(h, hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
-  HIPCK(h, hipEventCreateWithFlags(&h->ev_elbo, hipEventDisableTiming));
   if (const char* e = getenv("CA_ASYNC_Y")) h->async_y = atoi(e) != 0;
   HIPCK(h, hipHostMalloc((void**)&h->host_pinned, 64 * sizeof(double)));
   memset(h->host_pinned, 0, 64 * sizeof(double));
@@ -1183,7 +1185,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
       uint32_t u; memcpy(&u, &f, 4);
       if ((double)f != v || (u & 0xFFFFu) != 0) { exact = false; break; }
     }
-    h->bwd_mfma = exact && D == 1 && h->nchunk == 1 && !(getenv("CA_BWD_MFMA") && atoi(getenv("CA_BWD_MFMA")) == 0);
+    h->bwd_mfma = exact && (D == 1 || D == 2) && h->nchunk == 1 && !(getenv("CA_BWD_MFMA") && atoi(getenv("CA_BWD_MFMA")) == 0);
     h->N16 = (Nn + 15) / 16 * 16;
     if (h->bwd_mfma) {
       h->nwt = cdiv(G, 4 * 16);
@@ -1192,14 +1194,15 @@ int create_impl(ca_engine* h, const ca_problem* p) {
         // resident blocks per CU from the compiler's register count (LDS, 16 B per cell of the slice, is not the limit
         // at the slice lengths this produces); one or two full rounds instead of "about 8 blocks per CU"
         int per_cu = 4;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_bwd_mfma<4>, CA_TB, 16 * 1024) != hipSuccess || per_cu < 1)
+        const void* bfn = D == 1 ? (const void*)k_bwd_mfma<4, 1> : (const void*)k_bwd_mfma<4, 2>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bfn, CA_TB, 16 * 1024) != hipSuccess || per_cu < 1)
           per_cu = 4;
         (void)hipGetLastError();
         const int smax = (int)std::max<int64_t>(1, std::min<int64_t>(Nn / 256, cdiv(2 * (int64_t)per_cu * h->n_cu, xb)));
         h->csplit_m = pick_split(xb, (int64_t)per_cu * h->n_cu, smax, 1e-4);
       }
       if (const char* e = getenv("CA_CSPLIT_M")) h->csplit_m = std::max(1, atoi(e));
-      h->csplit_m = (int)std::max<int64_t>(h->csplit_m, (Nn + 4079) / 4080);   // LDS: 4 waves x cchunk floats <= 64 KB
+      h->csplit_m = (int)std::max<int64_t>(h->csplit_m, (Nn * D + 4079) / 4080);   // LDS: 4 waves x cchunk x D floats <= 64 KB
       h->cchunk_m = ((Nn + h->csplit_m - 1) / h->csplit_m + 15) / 16 * 16;
       h->csplit_m = cdiv(Nn, h->cchunk_m);
       CACK(dalloc(h, &h->coefq, (int64_t)S * h->N16 * 32));
@@ -1493,8 +1496,6 @@ int ca_destroy(ca_handle h) {
   hipSetDevice(h->device);
   if (h->stream) hipStreamSynchronize(h->stream);
   if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
-  if (h->stream3) { hipStreamSynchronize(h->stream3); hipStreamDestroy(h->stream3); }
-  if (h->ev_elbo) hipEventDestroy(h->ev_elbo);
   if (h->ev_params) hipEventDestroy(h->ev_params);
   if (h->ev_ydone) hipEventDestroy(h->ev_ydone);
   if (h->comm) g_rccl.CommDestroy(h->comm);
