@@ -639,51 +639,10 @@ __global__ void k_etamax(const float* __restrict__ F, const float* __restrict__ 
 }
 
 // ------------------------------------------------------------------ forward sweep  Z = E . M
-// (R/inference-tflow.R:278-292 without materialising [S,G,C,N]).  lane = cell, loop over a
-// slice of genes; M_g[0..NC) and Vs_g[0..D) are wave-uniform and arrive through the scalar
-// cache (s_load), so the VALU does 1 fma (exponent) + v_exp_f32 + NC fma per (n,g).
-template <int NC, int D>
-__global__ void __launch_bounds__(CA_TB) k_fwd(const float* __restrict__ F, const float* __restrict__ etamax2,
-                                               const float* __restrict__ Vs, const float* __restrict__ M /*[G][8]*/,
-                                               float* __restrict__ Zpart /*[gsplit][N][8]*/, int64_t N, int G,
-                                               int gchunk, int Drt) {
-  constexpr int DM = (D < 0) ? 8 : (D > 0 ? D : 1);
-  const int Dn = (D < 0) ? Drt : D;
-  const int64_t n = (int64_t)blockIdx.x * CA_TB + threadIdx.x;
-  const int64_t nn = n < N ? n : N - 1;
-  const int g0 = blockIdx.y * gchunk;
-  const int g1 = (g0 + gchunk < G) ? g0 + gchunk : G;
-  float f[DM];
-#pragma unroll
-  for (int d = 0; d < DM; ++d) f[d] = (d < Dn) ? F[nn * Dn + d] : 0.f;
-  const float em = (Dn > 0) ? etamax2[nn] : 0.f;
-  float z[NC];
-#pragma unroll
-  for (int c = 0; c < NC; ++c) z[c] = 0.f;
-#pragma unroll 4
-  for (int g = g0; g < g1; ++g) {
-    float e = 1.f;
-    if (Dn > 0) {
-      float eta = -em;
-#pragma unroll
-      for (int d = 0; d < DM; ++d)
-        if (d < Dn) eta = fmaf(f[d], Vs[(int64_t)g * Dn + d], eta);
-      e = __builtin_amdgcn_exp2f(eta);
-    }
-    const float* mg = M + (int64_t)g * CA_CW;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) z[c] = fmaf(e, mg[c], z[c]);
-  }
-  if (n < N) {
-    float* zp = Zpart + ((int64_t)blockIdx.y * N + n) * CA_CW;
-#pragma unroll
-    for (int c = 0; c < NC; ++c) zp[c] = z[c];
-  }
-}
-
-// LDS-staged variant (the one launched): the block copies its gene slice of M (and V') into LDS once and
-// every lane sweeps it for R cells -- broadcast ds_read_b128 instead of per-wave scalar loads, R independent
-// exp chains per lane.  Measured 132-137 us vs 158 us for k_fwd at 100k x 5k x 8 (tools/fwd_lab.hip).
+// (R/inference-tflow.R:278-292 without materialising [S,G,C,N]).  VALU form: lane = R cells, loop over a slice of genes,
+// 1 fma (exponent) + v_exp_f32 + NC fma per (n,g).  A first version fetched M_g and V'_g through the scalar cache
+// (158 us); this one copies the block's gene slice of M (and V') into LDS once and every lane sweeps it -- broadcast
+// ds_read_b128, R independent exp chains per lane: 132-137 us at 100k x 5k x 8 (tools/fwd_lab.hip).
 template <int NC, int D, int R, int CWS = CA_CW>
 __global__ void __launch_bounds__(CA_TB) k_fwd_lds(const float* __restrict__ F, const float* __restrict__ etamax2,
                                                    const float* __restrict__ Vs, const float* __restrict__ M /*[G][CWS]*/,
@@ -1161,8 +1120,8 @@ __device__ __forceinline__ void ca_final_small_body(const ca_small_args& sa) {
 // 256: the normal case) make every product exact, accumulation is fp32 -- same result as the fp32 VALU chain up to
 // summation order (tools/bwd_lab3.hip: 4e-8 relative).  Rows = genes, columns = cells, so a lane owns ONE cell per
 // batch: d/dF needs a 4-lane-group sum per batch, the per-gene sums stay in-lane over the whole cell slice.
-// On gfx950 every VALU instruction costs 4 cycles per wave64, packed or not (tools/valu_lab.hip), hence the explicit
-// 2-wide math.  Used when D is 1 or 2 (template DD), C <= 8 and L is bf16-exact; k_bwd is the general fallback.
+// The per-element math is written 2-wide (v_pk_*): measured equal to the scalar form here (tools/bwd_lab3.hip v6: 151 vs 148 us).
+// Used when D is 1 or 2 (template DD), C <= 8 and L is bf16-exact; k_bwd is the general fallback.
 
 // three bf16 parts of a float: x = p1 + p2 + p3 up to 2^-24 relative
 __device__ __forceinline__ void ca_split3(float x, unsigned short& p1, unsigned short& p2, unsigned short& p3) {
