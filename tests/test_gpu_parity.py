@@ -333,3 +333,49 @@ def test_padding_genes_stay_finite_under_large_negative_exponents():
             assert _rel(p[n], getattr(ora, n)) < 1e-4, (n, _rel(p[n], getattr(ora, n)))
     finally:
         eng.close()
+
+
+def _random_shapes(n, seed=2024):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        K = int(rng.integers(0, 3))
+        out.append(dict(N=int(rng.integers(17, 2500)), G=int(rng.integers(33, 1300)), C=int(rng.integers(1, 9)), K=K,
+                        P=int(rng.integers(0, 2)) if K < 2 else 0, big=bool(rng.integers(0, 2))))
+    return out
+
+
+@pytest.mark.parametrize("shape", _random_shapes(14), ids=lambda s: "N{N}_G{G}_C{C}_K{K}_P{P}_{big}".format(**s))
+def test_random_shapes_whole_loop_matches_oracle(shape):
+    """Ragged sizes through every loop kernel (strip tails of the Y stream, partial 16-cell / 32-gene tiles of the matrix-core
+    sweeps, one or two exponent dimensions, the overflow list when counts exceed 255): ca_run + ca_iterate against the
+    oracle's call-by-call loop."""
+    from clonealign_amd.engine import HipEngine
+    from clonealign_amd.inference import run_vi_loop
+    from clonealign_amd.rng import EpsStream
+    from oracle.fused_numpy import FusedModel
+    kw = {k: v for k, v in shape.items() if k != "big"}
+    case = make_case(seed=shape["N"] + shape["G"], **kw)
+    if shape["big"]:                                  # a few counts above 255: u8 storage + overflow list
+        rng = np.random.default_rng(1)
+        idx = rng.integers(0, case["Y"].size, size=max(3, case["Y"].size // 5000))
+        case["Y"].reshape(-1)[idx] += rng.integers(200, 900, size=idx.size)
+    eng, ora = HipEngine(**case), FusedModel(**case, dtype="float32")
+    try:
+        G = ora.G
+        n_iter = 4
+        tr = np.asarray(eng.run(EpsStream(5, 1, G), n_iter, 1e-12))
+        to = np.asarray(run_vi_loop(ora, EpsStream(5, 1, G), n_iter, 1e-12))
+        assert tr.shape == to.shape and np.all(np.isfinite(tr))
+        assert np.abs(tr - to).max() <= 1e-4 * np.abs(to).max(), (tr, to)
+        eps = np.stack([eps_for(1, G, 300 + i) for i in range(4)])
+        last = eng.iterate(2, eps)
+        for i in range(2):
+            ora.step(eps[2 * i])
+            e = ora.elbo(eps[2 * i + 1])
+        assert abs(last - e) <= 1e-4 * abs(e)
+        p = eng.get_state()
+        for n in ora.VAR_NAMES:
+            assert _rel(p[n], getattr(ora, n)) < 1e-3, (n, _rel(p[n], getattr(ora, n)))
+    finally:
+        eng.close()
