@@ -982,6 +982,7 @@ struct ca_small_args {
   const double* cell_part; int ncblk;   // when set: first reduce the cell epilogue's block partials into red[0 .. 3 + C)
   double* host_out; unsigned long long* host_flag; unsigned long long host_seq;   // ELBO mirrored into pinned host memory (ca_run)
   int reduce_only;          // stop after the cell-partial reduction (sharded: the sums are all-reduced before the ELBO assembly)
+  const double* yw_part; int n_yw;      // with cell_part: block partials of sum_n psi_n.(YW)_n (k_yw_dot), added to red[0]
 };
 
 // wave 0 of the O(K + C) body: one lane per clone / latent dimension
@@ -1085,7 +1086,12 @@ __device__ __forceinline__ void ca_final_small_body(const ca_small_args& sa) {
     for (int j = 0; j < Wc; ++j) {
       double acc = 0.0;
       for (int b = threadIdx.x; b < sa.ncblk; b += CA_TB) acc += sa.cell_part[(int64_t)b * Wc + j];
-      const double r = ca_block_sum(acc, sm);
+      double r = ca_block_sum(acc, sm);
+      if (j == 0 && sa.yw_part) {   // the psi.(YW) term of EE_p_y, from the side stream's k_yw_dot
+        double ya = 0.0;
+        for (int b = threadIdx.x; b < sa.n_yw; b += CA_TB) ya += sa.yw_part[b];
+        r += ca_block_sum(ya, sm);
+      }
       if (threadIdx.x == 0) sa.red[j] = r;
     }
     __threadfence_block();
@@ -1139,8 +1145,8 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
                                                     int64_t N, int G, int64_t cchunk, int S, int sidx, int first_s, int first,
                                                     ca_small_args tail, int xblocks) {
   extern __shared__ float ca_lds[];   // [4 waves][cchunk][DD]: per-wave d/dF of the block's cell slice, summed at the end
-  if ((int)blockIdx.x >= xblocks) {   // the extra block column: its first block assembles the previous pass's ELBO
-    if (blockIdx.y == 0 && tail.enabled) ca_final_small_body(tail);
+  if ((int)blockIdx.x >= xblocks) {   // the extra block column: its first block assembles the pending monitor pass's ELBO
+    if (blockIdx.y == 0 && tail.enabled) ca_final_small_body(tail);   // (130 us of sweep to hide its fp64 chains under)
     return;
   }
   const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
@@ -1642,22 +1648,19 @@ __global__ void __launch_bounds__(CA_TB) k_cell_par(const float* __restrict__ Zp
 
 // Cell epilogue of the FUSED sweep: one forward sweep produced Z for two eps draws of the same parameter
 // state -- group A (columns [0,C): the monitor pass, `sess$run(elbo)` :403) and group B (columns [C,2C): the
-// forward half of the NEXT train pass, :401).  gamma, log gamma, log alpha, psi.(YW) are shared; A yields the
-// ELBO partials, B yields coef and d ELBO / d logits for the backward sweep.  S == 1, C <= 8.
+// forward half of the NEXT train pass, :401).  gamma, log gamma, log alpha are shared; A yields the ELBO partials,
+// B yields coef and d ELBO / d logits for the backward sweep.  S == 1, C <= 8.
+// The Y stream's products are NOT touched here (psi.(YW) of the ELBO and the YW row sums come from k_yw_dot on the
+// side stream), so this epilogue depends on the forward sweep only -- and can run inside it (k_fwd_cell).
+// ca_cell_fused_group: the math for CA_TB / CP cells, one lane per (cell, clone); ZA / ZB are this lane's two Z values.
+struct ca_cell_acc { double ee, pr, q, gsumc; };
+struct ca_cell_ptrs {
+  const double* A; const double* cn; const double* s64; const float* etamax2; const float* glogit; const float* F;
+  float* coef; float* dgl; unsigned short* coefq;
+};
 template <int CP>
-__global__ void __launch_bounds__(CA_TB) k_cell_fused(const float* __restrict__ Zpart /*[gsplit][N][zrow]*/, int zrow,
-                                                      const double* __restrict__ A, const double* __restrict__ cn,
-                                                      const double* __restrict__ s64, const float* __restrict__ etamax2,
-                                                      const float* __restrict__ glogit, const float* __restrict__ alpha_u,
-                                                      const float* __restrict__ F, const float* __restrict__ YWpart,
-                                                      float* __restrict__ YW, float* __restrict__ coef /*[N][8]*/,
-                                                      float* __restrict__ dgl, double* __restrict__ cell_part, int64_t N, int C,
-                                                      int D, int K, int gsplit, int nseg, unsigned short* __restrict__ coefq) {
-  __shared__ double sm[CA_TB];
-  __shared__ double la[64];
-  constexpr int CPB = CA_TB / CP;
-  ca_log_softmax_alpha(alpha_u, C, la);
-  __syncthreads();
+__device__ __forceinline__ void ca_cell_fused_group(const ca_cell_ptrs& p, const double* la, int64_t n, int64_t N, int C, int D, int K,
+                                                    double ZA, double ZB, ca_cell_acc& acc) {
   const int c = threadIdx.x % CP;
   auto gmax = [](double v) {
 #pragma unroll
@@ -1669,78 +1672,114 @@ __global__ void __launch_bounds__(CA_TB) k_cell_fused(const float* __restrict__ 
     for (int o = CP / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, CP);
     return v;
   };
-  double ee = 0.0, pr = 0.0, q = 0.0, gsumc = 0.0;
+  const bool okn = n < N, ok = okn && c < C;
+  const int64_t nn = okn ? n : N - 1;
+  const int cc = c < C ? c : C - 1;
+  const double gl = ok ? (double)p.glogit[nn * C + cc] : -INFINITY;
+  const double mx = gmax(gl);
+  const double ex = ok ? exp(gl - mx) : 0.0;
+  const double se = gsum(ex);
+  const double lse = mx + log(se);
+  const double lg = gl - lse;
+  const double gam = ok ? ex / se : 0.0;
+  const double sn = p.s64[nn];
+  const double em = (D > 0) ? (double)p.etamax2[nn] * CA_LN2 : 0.0;
+  const double Anc = p.A[nn * C + cc];
+  const double llpA = Anc - sn * (log(ZA) + em);
+  const double llpB = Anc - sn * (log(ZB) + em);
+  if (ok) {
+    const float cfv = (float)(-gam * sn / ZB);
+    p.coef[nn * CA_CW + cc] = cfv;
+    if (p.coefq) {
+      unsigned short p1, p2, p3;
+      ca_split3(cfv, p1, p2, p3);
+      unsigned short* qp = p.coefq + (nn * 4) * 8 + cc;
+      qp[0] = p1; qp[8] = p2; qp[16] = p3;
+    }
+  }
+  const double fB = llpB + la[cc] - lg;
+  const bool live = ok && gam != 0.0;   // see k_cell_par: only the entropy term is guarded against gamma == 0
+  const double gfB = (live || (ok && !isfinite(llpB))) ? gam * fB : 0.0;
+  const double fbarB = gsum(gfB);
+  if (ok) p.dgl[nn * C + cc] = (float)(live || !isfinite(llpB) ? gam * (fB - fbarB) : 0.0);
+  if (ok) { acc.ee += gam * llpA; acc.pr += gam * la[cc]; }
+  if (live) acc.q += gam * lg;
+  acc.gsumc += gam;
+  if (okn && c == 0) {
+    acc.ee += p.cn[nn];
+    for (int k = 0; k < K; ++k) {
+      const double ps = (double)p.F[nn * D + k];
+      acc.pr += -0.5 * ps * ps - 0.5 * CA_LOG2PI;
+    }
+  }
+}
+// block partials of the epilogue: cell_part[blk][0..2] and the per-clone gamma sums
+template <int CP>
+__device__ __forceinline__ void ca_cell_fused_finish(const ca_cell_acc& acc, double* sm, double* __restrict__ cell_part, int blk, int C) {
+  constexpr int CPB = CA_TB / CP;
+  const int W_ = 3 + C;
+  const double r0 = ca_block_sum(acc.ee, sm);
+  const double r1 = ca_block_sum(acc.pr, sm);
+  const double r2 = ca_block_sum(acc.q, sm);
+  if (threadIdx.x == 0) {
+    cell_part[(int64_t)blk * W_ + 0] = r0;
+    cell_part[(int64_t)blk * W_ + 1] = r1;
+    cell_part[(int64_t)blk * W_ + 2] = r2;
+  }
+  __syncthreads();
+  sm[threadIdx.x] = acc.gsumc;
+  __syncthreads();
+  if ((int)threadIdx.x < C) {
+    double a = 0.0;
+    for (int i = 0; i < CPB; ++i) a += sm[i * CP + threadIdx.x];
+    cell_part[(int64_t)blk * W_ + 3 + threadIdx.x] = a;
+  }
+}
+
+template <int CP>
+__global__ void __launch_bounds__(CA_TB) k_cell_fused(const float* __restrict__ Zpart /*[gsplit][N][zrow]*/, int zrow, ca_cell_ptrs p,
+                                                      const float* __restrict__ alpha_u, double* __restrict__ cell_part, int64_t N, int C,
+                                                      int D, int K, int gsplit) {
+  __shared__ double sm[CA_TB];
+  __shared__ double la[64];
+  constexpr int CPB = CA_TB / CP;
+  ca_log_softmax_alpha(alpha_u, C, la);
+  __syncthreads();
+  const int c = threadIdx.x % CP;
+  const int cc = c < C ? c : C - 1;
+  ca_cell_acc acc = {0.0, 0.0, 0.0, 0.0};
   const int64_t ngroups = (N + CPB - 1) / CPB;
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int64_t n = grp * CPB + threadIdx.x / CP;
-    const bool okn = n < N, ok = okn && c < C;
-    const int64_t nn = okn ? n : N - 1;
-    const int cc = c < C ? c : C - 1;
-    const double gl = ok ? (double)glogit[nn * C + cc] : -INFINITY;
-    const double mx = gmax(gl);
-    const double ex = ok ? exp(gl - mx) : 0.0;
-    const double se = gsum(ex);
-    const double lse = mx + log(se);
-    const double lg = gl - lse;
-    const double gam = ok ? ex / se : 0.0;
-    const double sn = s64[nn];
-    const double em = (D > 0) ? (double)etamax2[nn] * CA_LN2 : 0.0;
+    const int64_t nn = n < N ? n : N - 1;
     double ZA = 0.0, ZB = 0.0;
     for (int sp = 0; sp < gsplit; ++sp) {
       const float* zp = Zpart + ((int64_t)sp * N + nn) * zrow;
       ZA += (double)zp[cc];
       ZB += (double)zp[C + cc];
     }
-    const double Anc = A[nn * C + cc];
-    const double llpA = Anc - sn * (log(ZA) + em);
-    const double llpB = Anc - sn * (log(ZB) + em);
-    if (ok) {
-      const float cfv = (float)(-gam * sn / ZB);
-      coef[nn * CA_CW + cc] = cfv;
-      if (coefq) {
-        unsigned short p1, p2, p3;
-        ca_split3(cfv, p1, p2, p3);
-        unsigned short* qp = coefq + (nn * 4) * 8 + cc;
-        qp[0] = p1; qp[8] = p2; qp[16] = p3;
-      }
+    ca_cell_fused_group<CP>(p, la, n, N, C, D, K, ZA, ZB, acc);
+  }
+  ca_cell_fused_finish<CP>(acc, sm, cell_part, blockIdx.x, C);
+}
+
+// The Y stream's row products, finished on the side stream: YW[n][k] = sum over the gene strips (+ the overflow
+// list's extra strip) of YWpart, and this block's share of sum_n psi_n . (YW)_n, the one ELBO term that needs them
+// (part of EE_p_y; the O(K + C) body adds the block partials).  Same strip order as the sum in k_cell_par.
+__global__ void __launch_bounds__(CA_TB) k_yw_dot(const float* __restrict__ YWpart, int nseg, const float* __restrict__ F, int D, int K,
+                                                  int64_t N, float* __restrict__ YW, double* __restrict__ yw_part) {
+  __shared__ double sm[CA_TB];
+  const int64_t n = (int64_t)blockIdx.x * CA_TB + threadIdx.x;
+  double a = 0.0;
+  if (n < N)
+    for (int k = 0; k < K; ++k) {
+      double yw = 0.0;
+      for (int sg = 0; sg < nseg; ++sg) yw += (double)YWpart[((int64_t)sg * N + n) * K + k];
+      YW[n * K + k] = (float)yw;
+      a += (double)F[n * D + k] * yw;
     }
-    const double fB = llpB + la[cc] - lg;
-    const bool live = ok && gam != 0.0;   // see k_cell_par: only the entropy term is guarded against gamma == 0
-    const double gfB = (live || (ok && !isfinite(llpB))) ? gam * fB : 0.0;
-    const double fbarB = gsum(gfB);
-    if (ok) dgl[nn * C + cc] = (float)(live || !isfinite(llpB) ? gam * (fB - fbarB) : 0.0);
-    if (ok) { ee += gam * llpA; pr += gam * la[cc]; }
-    if (live) q += gam * lg;
-    gsumc += gam;
-    if (okn && c == 0) {
-      ee += cn[nn];
-      for (int k = 0; k < K; ++k) {
-        double yw = 0.0;
-        for (int sg = 0; sg < nseg; ++sg) yw += (double)YWpart[((int64_t)sg * N + nn) * K + k];
-        YW[nn * K + k] = (float)yw;
-        const double ps = (double)F[nn * D + k];
-        ee += ps * yw;
-        pr += -0.5 * ps * ps - 0.5 * CA_LOG2PI;
-      }
-    }
-  }
-  const int W_ = 3 + C;
-  const double r0 = ca_block_sum(ee, sm);
-  const double r1 = ca_block_sum(pr, sm);
-  const double r2 = ca_block_sum(q, sm);
-  if (threadIdx.x == 0) {
-    cell_part[(int64_t)blockIdx.x * W_ + 0] = r0;
-    cell_part[(int64_t)blockIdx.x * W_ + 1] = r1;
-    cell_part[(int64_t)blockIdx.x * W_ + 2] = r2;
-  }
-  __syncthreads();
-  sm[threadIdx.x] = gsumc;
-  __syncthreads();
-  if (threadIdx.x < C) {
-    double a = 0.0;
-    for (int i = 0; i < CPB; ++i) a += sm[i * CP + threadIdx.x];
-    cell_part[(int64_t)blockIdx.x * W_ + 3 + threadIdx.x] = a;
-  }
+  const double r = ca_block_sum(a, sm);
+  if (threadIdx.x == 0) yw_part[blockIdx.x] = r;
 }
 
 // fixed-order reduction of block partials: out[j] = sum_b part[b][j]; one block per column j
@@ -1837,7 +1876,11 @@ __global__ void __launch_bounds__(CA_TB) k_final_gene(const double* __restrict__
                                                       float* __restrict__ v_ls, float* __restrict__ m_V, float* __restrict__ v_V,
                                                       float* __restrict__ g_loc, float* __restrict__ g_ls, float* __restrict__ g_V,
                                                       float* __restrict__ Vs, float* __restrict__ vmm_part,
-                                                      int G, int S, int D, int K, int apply, float lr_t, float b1, float b2, float aeps) {
+                                                      int G, int S, int D, int K, int apply, float lr_t, float b1, float b2, float aeps, ca_small_args mon, int gblocks) {
+  if ((int)blockIdx.x >= gblocks) {   // the extra block: the pending monitor pass's ELBO (ca_final_small_body), beside the gene blocks
+    if (mon.enabled) ca_final_small_body(mon);
+    return;
+  }
   __shared__ float smin[CA_TB], smax[CA_TB];
   ca_final_gene_body(red_g, red_y, eps, colsum, YtX, vchi, loc, ls, V, m_loc, v_loc, m_ls, v_ls, m_V, v_V, g_loc, g_ls, g_V, Vs, vmm_part, G, S, D, K,
                      apply, lr_t, b1, b2, aeps, smin, smax);
@@ -1853,12 +1896,8 @@ __global__ void __launch_bounds__(CA_TB) k_adam_cell(float* __restrict__ F, cons
                                                      float* __restrict__ v_gl, float* __restrict__ g_psi, int64_t N, int C, int D, int K,
                                                      int ntile, int apply, float lr_t, float b1, float b2, float aeps,
                                                      const float* __restrict__ vmm_part, int ngblk, float* __restrict__ etamax2,
-                                                     ca_small_args mon, ca_small_args tail, int cblocks) {
+                                                     ca_small_args tail, int cblocks) {
   if ((int)blockIdx.x >= cblocks) {   // the extra block: chi / alpha gradients and Adam, the range of V' (ca_final_small_body)
-    if (mon.enabled) {                // sharded loop: a monitor pass's ELBO, assembled from the all-reduced sums BEFORE this update
-      ca_final_small_body(mon);
-      __syncthreads();
-    }
     if (tail.enabled) ca_final_small_body(tail);
     return;
   }

@@ -120,6 +120,7 @@ struct ca_engine {
   float *Mb2 = nullptr, *mu32B = nullptr, *Zpart2 = nullptr; double* gene_partB = nullptr;
   bool y_defer = false;
   bool bwd_ready = false; int64_t bwd_slot = -1;
+  double* yw_part = nullptr; int n_yw = 0;   // block partials of sum_n psi_n.(YW)_n (k_yw_dot)
   ca_small_args mon_tail;          // pending ELBO assembly of a fused monitor pass: rides on the next backward sweep
   bool tail_fuse = true;
   double* host_dev = nullptr;      // device view of host_pinned
@@ -421,6 +422,9 @@ int ensure_ycache(ca_engine* h) {
   LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->Gp * h->K, 64)), dim3(1024), 0, h->stream,
                                                 h->YTpart, h->red + h->off_y, h->nrb, (int64_t)h->Gp * h->K, h->Gp * h->K,
                                                 h->n_ovf > 0 ? h->ovf_col_chunk_ptr : nullptr, h->n_ovf > 0 ? h->ovf_csum : nullptr, h->K, h->G));
+  // row side: YW = sum of the strips, and the psi.(YW) partials of the ELBO (the fused loop's cell epilogue leaves both to this)
+  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_yw_dot, dim3(h->n_yw), dim3(CA_TB), 0, h->stream, h->YWpart,
+                                                h->nseg + (h->n_ovf > 0 ? 1 : 0), h->F, h->D, h->K, h->N, h->YW, h->yw_part));
   h->ycache_valid = true;
   return CA_OK;
 }
@@ -571,6 +575,7 @@ ca_small_args small_args(ca_engine* h, const double* gene_part, int apply, float
   a.dir_const = h->dir_const;
   a.cell_part = reduce_cells ? h->cell_part : nullptr; a.ncblk = h->ncblk;
   a.host_out = nullptr; a.host_flag = nullptr; a.host_seq = 0; a.reduce_only = 0;
+  a.yw_part = nullptr; a.n_yw = 0;
   if (!apply && elbo_dst && h->host_seq_next && h->host_dev) {   // monitor pass inside ca_run: mirror the ELBO to the host
     a.host_out = h->host_dev + 32;
     a.host_flag = reinterpret_cast<unsigned long long*>(h->host_dev + 33);
@@ -582,12 +587,24 @@ ca_small_args small_args(ca_engine* h, const double* gene_part, int apply, float
 // a fused monitor pass leaves its ELBO assembly for the next backward sweep; if none is coming, run it now
 int allreduce(ca_engine* h, double* buf, int64_t n);
 inline bool is_sharded(const ca_engine* h) { return h->opt.world > 1 || h->comm || h->host_ar; }
+// Reduce a pending monitor tail's cell partials (and psi.(YW) partials) for a sharded run: red[0 .. 3 + C) local sums,
+// ready for the all-reduce.  The Y stream (side stream) must have delivered the psi.(YW) partials first.
+int mon_tail_local_sums(ca_engine* h) {
+  if (!h->mon_tail.enabled || !h->mon_tail.cell_part) return CA_OK;
+  if (h->y_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ydone, 0)); h->y_pending = false; }
+  ca_small_args r = h->mon_tail;
+  r.reduce_only = 1; r.host_out = nullptr;
+  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_final_small, dim3(1), dim3(CA_TB), 0, h->stream, r));
+  h->mon_tail.cell_part = nullptr; h->mon_tail.yw_part = nullptr;
+  return CA_OK;
+}
+// a fused monitor pass leaves its ELBO assembly for the next train pass's per-gene kernel; if none is coming, run it now
 int flush_mon_tail(ca_engine* h) {
   if (!h->mon_tail.enabled) return CA_OK;
-  if (is_sharded(h) && h->mon_tail.cell_part) {   // cell partials neither reduced nor all-reduced yet: the plain sequence
-    LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_reduce_part, dim3(3 + h->C), dim3(CA_TB), 0, h->stream, h->cell_part, h->red, h->ncblk, 3 + h->C));
+  if (h->y_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ydone, 0)); h->y_pending = false; }
+  if (is_sharded(h) && h->mon_tail.cell_part) {   // local sums, then the (3 + C)-double all-reduce of a monitor pass
+    CACK(mon_tail_local_sums(h));
     CACK(allreduce(h, h->red, 3 + h->C));
-    h->mon_tail.cell_part = nullptr;
   }
   LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_final_small, dim3(1), dim3(CA_TB), 0, h->stream, h->mon_tail));
   h->mon_tail.enabled = 0;
@@ -603,26 +620,34 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
   if (h->bwd_mfma) {
     constexpr int TL = 4;
     const int xb = cdiv(h->nwt, CA_TB / 64);
-    // a pending monitor-pass tail rides on the sweep: whole (unsharded), or only its cell-partial reduction (sharded:
-    // ONE all-reduce per iteration then carries the cell sums together with the gene sums, and the ELBO is assembled
-    // after it -- by the per-cell Adam kernel's extra block, or by ca_run's flush)
-    merged = is_sharded(h) && h->mon_tail.enabled && h->mon_tail.cell_part != nullptr;
-    ca_small_args bwd_tail = h->mon_tail;
-    if (merged) { bwd_tail.reduce_only = 1; bwd_tail.host_out = nullptr; }
-#define CA_BWDM(DDV)                                                                                                              \
-  LAUNCH(h, CA_KERNEL_BWD,                                                                                                       \
-         hipLaunchKernelGGL((k_bwd_mfma<TL, DDV>), dim3(xb + ((s == 0 && h->mon_tail.enabled) ? 1 : 0), h->csplit_m), dim3(CA_TB), \
-                            (size_t)h->cchunk_m * 4 * DDV * sizeof(float), h->stream,                                             \
-                            h->coefq + (int64_t)s * h->N16 * 32, h->F, h->etamax2, h->Lb, mu32 + (int64_t)s * h->G, h->Vs, h->V,   \
-                            h->gpart, h->dFpart, h->N, h->G, h->cchunk_m, h->S, s, 1, s == 0 ? 1 : 0,                             \
+    // A pending monitor pass's tail rides on the sweep as one extra block (its fp64 chains hide under 130 us of sweep):
+    // whole when unsharded; sharded, only the local sums of the cell / psi.(YW) partials -- ONE all-reduce per iteration
+    // then carries them together with this pass's gene sums and the ELBO is assembled after it (k_final_gene's extra
+    // block, or ca_run's flush).  Both need the Y stream's psi.(YW) partials: the side stream is awaited here, one
+    // kernel later than the cell epilogue that used to need it.
+    ca_small_args bwd_tail = no_small_args();
+    if (h->mon_tail.enabled && h->mon_tail.cell_part) {
+      if (h->y_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ydone, 0)); h->y_pending = false; }
+      bwd_tail = h->mon_tail;
+      merged = is_sharded(h);
+      if (merged) { bwd_tail.reduce_only = 1; bwd_tail.host_out = nullptr; }
+    }
+#define CA_BWDM(DDV)                                                                                                        \
+  LAUNCH(h, CA_KERNEL_BWD,                                                                                                 \
+         hipLaunchKernelGGL((k_bwd_mfma<TL, DDV>), dim3(xb + ((s == 0 && bwd_tail.enabled) ? 1 : 0), h->csplit_m), dim3(CA_TB), \
+                            (size_t)h->cchunk_m * 4 * DDV * sizeof(float), h->stream,                                       \
+                            h->coefq + (int64_t)s * h->N16 * 32, h->F, h->etamax2, h->Lb, mu32 + (int64_t)s * h->G, h->Vs,  \
+                            h->V, h->gpart, h->dFpart, h->N, h->G, h->cchunk_m, h->S, s, 1, s == 0 ? 1 : 0,                 \
                             s == 0 ? bwd_tail : no_small_args(), xb))
     for (int s = 0; s < h->S; ++s) {
       if (h->D == 1) CA_BWDM(1);
       else CA_BWDM(2);
     }
 #undef CA_BWDM
-    if (merged) h->mon_tail.cell_part = nullptr;   // reduced by the extra block; all-reduced below with the gene sums
-    else h->mon_tail.enabled = 0;
+    if (bwd_tail.enabled) {
+      if (merged) { h->mon_tail.cell_part = nullptr; h->mon_tail.yw_part = nullptr; }   // local sums done; assembly still pending
+      else h->mon_tail.enabled = 0;
+    }
     // (summing the sweep's partials inside k_final_gene instead -- one thread per gene, csplit_m loads in a row -- was
     //  slower than this parallel launch: 2219 -> 2190 it/s)
     LAUNCH(h, CA_KERNEL_OTHER,
@@ -647,6 +672,10 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
            hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->G * W_, 64)), dim3(1024), 0, h->stream, h->gpart,
                               h->red + h->off_g, h->csplit, (int64_t)h->G * W_, h->G * W_));
   }
+  // the Y stream's results (Y^T psi in red_y, the psi.(YW) partials) are first needed from here on
+  if (h->y_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ydone, 0)); h->y_pending = false; }
+  // sharded loop: a pending monitor pass's cell sums travel with this pass's gene sums -- ONE all-reduce per iteration;
+  // the ELBO is assembled after it (k_final_gene's extra block, or ca_run's flush)
   if (cell_sums_global && !merged) CACK(allreduce(h, h->red + h->off_g, h->red_n - h->off_g));
   else CACK(allreduce(h, h->red, h->red_n));
   if (h->opt.world > 1 || h->comm || h->host_ar) h->ycache_valid = false;   // red_y now holds the GLOBAL sum
@@ -661,23 +690,21 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
     // lr_t = lr * sqrt(1 - beta2^t) / (1 - beta1^t), float32 like TF's _prepare()/_apply_dense
     lr_t = (float)h->opt.learning_rate * sqrtf(1.f - h->b2p) / (1.f - h->b1p);
   }
-    LAUNCH(h, CA_KERNEL_OTHER,
-           hipLaunchKernelGGL(k_final_gene, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->red + h->off_g, h->red + h->off_y, eps,
-                              h->colsum, h->YtX, h->vchi, h->loc, h->ls, h->V, h->m_loc, h->v_loc, h->m_ls, h->v_ls, h->m_V, h->v_V,
-                              h->g_loc, h->g_ls, h->g_V, h->Vs, h->vmm_part, h->G, h->S, h->D, h->K, apply, lr_t, (float)h->opt.beta1, (float)h->opt.beta2,
-                              (float)h->opt.adam_eps));
-  // the O(K + C) update rides on the per-cell kernel as one extra block (ca_final_small_body); in a sharded loop a
-  // pending monitor-pass ELBO (sums all-reduced by train_bwd) is assembled by the same block first
+  // A pending monitor pass's ELBO is assembled by one extra block of the per-gene kernel (ca_final_small_body: the
+  // reduction of the cell / psi.(YW) partials unless train_bwd did it for the all-reduce, then the assembly) BEFORE the
+  // O(K + C) update, which rides on the per-cell kernel the same way.
   ca_small_args mon = no_small_args();
-  if (h->mon_tail.enabled) {
-    if (h->mon_tail.cell_part) CACK(flush_mon_tail(h));   // not reduced (no backward sweep took it): the plain sequence
-    else { mon = h->mon_tail; h->mon_tail.enabled = 0; }
-  }
+  if (h->mon_tail.enabled) { mon = h->mon_tail; h->mon_tail.enabled = 0; }
+  LAUNCH(h, CA_KERNEL_OTHER,
+         hipLaunchKernelGGL(k_final_gene, dim3(h->ngblk + (mon.enabled ? 1 : 0)), dim3(CA_TB), 0, h->stream, h->red + h->off_g,
+                            h->red + h->off_y, eps, h->colsum, h->YtX, h->vchi, h->loc, h->ls, h->V, h->m_loc, h->v_loc, h->m_ls,
+                            h->v_ls, h->m_V, h->v_V, h->g_loc, h->g_ls, h->g_V, h->Vs, h->vmm_part, h->G, h->S, h->D, h->K, apply,
+                            lr_t, (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, mon, h->ngblk));
   LAUNCH(h, CA_KERNEL_OTHER,
          hipLaunchKernelGGL(k_adam_cell, dim3(N256 + 1), dim3(CA_TB), 0, h->stream, h->F, h->YW, h->dFpart, h->glogit, h->dgl, h->m_psi,
                             h->v_psi, h->m_gl, h->v_gl, h->g_psi, h->N, h->C, h->D, h->K, h->bwd_mfma ? cdiv(h->nwt, CA_TB / 64) : h->ntile, apply, lr_t,
                             (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, h->vmm_part, h->ngblk, h->etamax2,
-                            mon, small_args(h, h->gene_part, apply ? 1 : 0, lr_t, elbo_dst, false), N256));
+                            small_args(h, h->gene_part, apply ? 1 : 0, lr_t, elbo_dst, false), N256));
   if (apply) {
     h->b1p *= (float)h->opt.beta1;
     h->b2p *= (float)h->opt.beta2;
@@ -780,20 +807,18 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst) {
     LAUNCH(h, CA_KERNEL_FWD, launch_fwd_fused(h->C, h->D, dim3(cdiv(h->N, CA_TB * kFwdR), h->gsplit), h->stream, h->F, h->etamax2,
                                               h->Vs, h->Mb2, h->Zpart2, h->N, h->G, h->gchunk));
   }
-  if (h->y_pending) {
-    HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ydone, 0));
-    h->y_pending = false;
-  }
   {
+    // (no wait for the side stream here: this epilogue does not touch the Y stream's products -- k_yw_dot does)
     int CP = 1;
     while (CP < h->C) CP <<= 1;
     dim3 grid(h->ncblk);
-#define CA_CELLF(CPV)                                                                                                        \
-  LAUNCH(h, CA_KERNEL_CELL,                                                                                                  \
-         hipLaunchKernelGGL((k_cell_fused<CPV>), grid, dim3(CA_TB), 0, h->stream, h->Zpart2, h->frow, h->A, h->cn, h->s64,   \
-                            h->etamax2, h->glogit, h->alpha_u, h->F, h->YWpart, h->YW, h->coef, h->dgl, h->cell_part, h->N,  \
-                            h->C, h->D, h->K, h->fwd_mfma ? h->fsplit : h->gsplit, h->nseg + (h->n_ovf > 0 ? 1 : 0),              \
-                            h->bwd_mfma ? h->coefq : nullptr))
+    ca_cell_ptrs cp;
+    cp.A = h->A; cp.cn = h->cn; cp.s64 = h->s64; cp.etamax2 = h->etamax2; cp.glogit = h->glogit; cp.F = h->F;
+    cp.coef = h->coef; cp.dgl = h->dgl; cp.coefq = h->bwd_mfma ? h->coefq : nullptr;
+#define CA_CELLF(CPV)                                                                                                   \
+  LAUNCH(h, CA_KERNEL_CELL,                                                                                             \
+         hipLaunchKernelGGL((k_cell_fused<CPV>), grid, dim3(CA_TB), 0, h->stream, h->Zpart2, h->frow, cp, h->alpha_u,    \
+                            h->cell_part, h->N, h->C, h->D, h->K, h->fwd_mfma ? h->fsplit : h->gsplit))
     switch (CP) {
       case 1: CA_CELLF(1); break;
       case 2: CA_CELLF(2); break;
@@ -802,17 +827,13 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst) {
     }
 #undef CA_CELLF
   }
-  if (h->tail_fuse && h->bwd_mfma) {
-    // the reduction of the cell partials and the ELBO assembly ride on the backward sweep of the train pass that
-    // completes this look-ahead (one extra block of k_bwd_mfma), not on the critical path; sharded, only the
-    // reduction does and the ELBO follows that pass's single all-reduce (train_bwd)
-    h->mon_tail = small_args(h, h->gene_part, 0, 0.f, elbo_dst, true);
-  } else {
-    LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_reduce_part, dim3(3 + h->C), dim3(CA_TB), 0, h->stream, h->cell_part, h->red, h->ncblk, 3 + h->C));
-    CACK(allreduce(h, h->red, 3 + h->C));
-    LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_final_small, dim3(1), dim3(CA_TB), 0, h->stream,
-                                                  small_args(h, h->gene_part, 0, 0.f, elbo_dst, false)));
-  }
+  // The ELBO assembly (reduction of the cell partials and of k_yw_dot's psi.(YW) partials, then the O(K + C) body) is
+  // left pending: it rides on the per-gene kernel of the train pass that completes this look-ahead (train_update), after
+  // the single all-reduce of that pass when sharded (train_bwd); ca_run and the odd ends flush it (flush_mon_tail).
+  h->mon_tail = small_args(h, h->gene_part, 0, 0.f, elbo_dst, true);
+  h->mon_tail.ncblk = h->ncblk;
+  if (h->K > 0) { h->mon_tail.yw_part = h->yw_part; h->mon_tail.n_yw = h->n_yw; }
+  if (!h->tail_fuse) CACK(flush_mon_tail(h));
   h->look_valid = true;
   h->look_slot = slotB;
   h->bwd_ready = false;
@@ -1291,6 +1312,8 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   CACK(dalloc(h, &h->YWpart, (int64_t)(h->nseg + 1) * Nn * std::max(K, 1)));
   CACK(dalloc(h, &h->YTpart, (int64_t)(h->nrb + 1) * h->Gp * std::max(K, 1)));
   CACK(dalloc(h, &h->YW, Nn * std::max(K, 1)));
+  h->n_yw = cdiv(Nn, CA_TB);
+  CACK(dalloc(h, &h->yw_part, h->n_yw));
   CACK(dalloc(h, &h->ytpsi, (int64_t)h->Gp * std::max(K, 1)));
   h->off_g = 3 + C;
   h->off_y = h->off_g + (int64_t)G * (S + D);

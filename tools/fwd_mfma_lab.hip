@@ -394,6 +394,77 @@ __global__ void __launch_bounds__(256) fwd_mfma_s(const float* __restrict__ F, c
     }
 }
 
+// ---- in-block gene split: block = 16*TL cells, its 4 waves take every 4th k-step, B and V' straight from global (L2) with
+//      one k-step of prefetch, partial accumulators combined through LDS: complete Z per block, no partial slabs, no LDS staging
+template <int TL>
+__global__ void __launch_bounds__(256) fwd_mfma_g(const float* __restrict__ F, const float* __restrict__ em2, const float* __restrict__ Vs,
+                                                  const unsigned short* __restrict__ Mq /*[nk][3][64][8]*/, float* __restrict__ Zp, long N, int G,
+                                                  int nk) {
+  __shared__ f32x4 comb[4][TL][64];
+  const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4, wv = threadIdx.x >> 6;
+  const long cell0 = (long)blockIdx.x * (TL * 16);
+  float f[TL], em[TL];
+  f32x4 acc[TL];
+#pragma unroll
+  for (int t = 0; t < TL; ++t) {
+    const long n = cell0 + 16 * t + j; const long nn = n < N ? n : N - 1;
+    f[t] = F[nn]; em[t] = em2[nn];
+    acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  unsigned m0, m1;
+  asm volatile("s_mov_b32 %0, 0x0000bf80" : "=s"(m0));
+  asm volatile("s_mov_b32 %0, 0xbf800000" : "=s"(m1));
+  const uint4* Bq = reinterpret_cast<const uint4*>(Mq);
+  auto ldv = [&](int ks, float4& a, float4& b) {
+    const int g = ks * 32 + 8 * q;
+    const int g0 = min(g, G - 8 > 0 ? G - 8 : 0);   // lab: G multiple of 8
+    a = *reinterpret_cast<const float4*>(Vs + g0); b = *reinterpret_cast<const float4*>(Vs + g0 + 4);
+  };
+  int ks = wv;
+  uint4 b1n = {0,0,0,0}, b2n = {0,0,0,0}; float4 van = {0,0,0,0}, vbn = {0,0,0,0};
+  if (ks < nk) { b1n = Bq[((long)ks * 3 + 0) * 64 + lane]; b2n = Bq[((long)ks * 3 + 1) * 64 + lane]; ldv(ks, van, vbn); }
+  for (; ks < nk; ks += 4) {
+    const uint4 b1r = b1n, b2r = b2n; const float4 va = van, vb = vbn;
+    if (ks + 4 < nk) { b1n = Bq[((long)(ks + 4) * 3 + 0) * 64 + lane]; b2n = Bq[((long)(ks + 4) * 3 + 1) * 64 + lane]; ldv(ks + 4, van, vbn); }
+    const bf16x8 B1 = __builtin_bit_cast(bf16x8, b1r), B2 = __builtin_bit_cast(bf16x8, b2r);
+    const f32x2 v2[4] = {{va.x, va.y}, {va.z, va.w}, {vb.x, vb.y}, {vb.z, vb.w}};
+#pragma unroll
+    for (int t = 0; t < TL; ++t) {
+      unsigned hi[4], lo[4];
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const f32x2 eta = v2[p] * f[t] - em[t];
+        const float e0 = __builtin_amdgcn_exp2f(eta.x), e1 = __builtin_amdgcn_exp2f(eta.y);
+        hi[p] = pk_bf16(e0, e1);
+        const bf16x2 hb = __builtin_bit_cast(bf16x2, hi[p]);
+        const float r0 = __builtin_amdgcn_fdot2_f32_bf16(hb, __builtin_bit_cast(bf16x2, m0), e0, false);
+        const float r1 = __builtin_amdgcn_fdot2_f32_bf16(hb, __builtin_bit_cast(bf16x2, m1), e1, false);
+        lo[p] = pk_bf16(r0, r1);
+      }
+      const bf16x8 A1 = __builtin_bit_cast(bf16x8, ((uint4){hi[0], hi[1], hi[2], hi[3]}));
+      const bf16x8 A2 = __builtin_bit_cast(bf16x8, ((uint4){lo[0], lo[1], lo[2], lo[3]}));
+      f32x4 a = acc[t];
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2, B1, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B2, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B1, a, 0, 0, 0);
+      acc[t] = a;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TL; ++t) comb[wv][t][lane] = acc[t];
+  __syncthreads();
+  // thread -> (tile t, lane l): sum the 4 waves, write Z rows (cells 4q+r of the tile, column j)
+  for (int i = threadIdx.x; i < TL * 64; i += 256) {
+    const int t = i >> 6, l = i & 63, jj = l & 15, qq = l >> 4;
+    const f32x4 z = (comb[0][t][l] + comb[1][t][l]) + (comb[2][t][l] + comb[3][t][l]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long n = cell0 + 16 * t + 4 * qq + r;
+      if (n < N) Zp[n * NC + jj] = z[r];
+    }
+  }
+}
+
 int main(int argc, char** argv) {
   long N = argc > 1 ? atol(argv[1]) : 100000; int G = argc > 2 ? atoi(argv[2]) : 5000;
   std::vector<float> F(N), em(N), Vs(G), M((size_t)G * NC);
@@ -451,6 +522,12 @@ int main(int argc, char** argv) {
       const int gchunk = (G + gsplit - 1) / gsplit, gs = (G + gchunk - 1) / gchunk;
       TIME("valu lds R=2", gs, hipLaunchKernelGGL((fwd_valu<2>), dim3((unsigned)((N + 511) / 512), gs), dim3(256), (size_t)gchunk * 68, 0,
                                                    dF, dem, dVs, dM, dZ, N, G, gchunk));
+    }
+    {
+#define MFG(TLV) { char nm[64]; snprintf(nm, 64, "block-split TL=%d", TLV);                              \
+      TIME(nm, 1, hipLaunchKernelGGL((fwd_mfma_g<TLV>), dim3((unsigned)((N + 16 * TLV - 1) / (16 * TLV))), dim3(256), 0, 0, \
+                                      dF, dem, dVs, dMq, dZ, N, G, nk)); }
+      MFG(1); MFG(2); MFG(4); MFG(8);
     }
     for (int gsplit : {5, 8}) {
       const int kchunk = (nk + gsplit - 1) / gsplit, gs = (nk + kchunk - 1) / kchunk;
