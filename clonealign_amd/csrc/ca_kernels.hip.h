@@ -594,6 +594,8 @@ __global__ void __launch_bounds__(CA_TB) k_vprep(const float* __restrict__ V, fl
     if (g < G) {
       v = V[(int64_t)g * D + d] * CA_LOG2E_F;
       Vs[(int64_t)g * D + d] = v;
+      if (g == G - 1)   // pad to a multiple of 32 genes with the last gene's loading (k_fwd_cell reads whole k-steps)
+        for (int gp = G; gp < ((G + 31) / 32) * 32; ++gp) Vs[(int64_t)gp * D + d] = v;
     }
     __syncthreads();
     smin[threadIdx.x] = (g < G) ? v : INFINITY;
@@ -1782,6 +1784,109 @@ __global__ void __launch_bounds__(CA_TB) k_yw_dot(const float* __restrict__ YWpa
   if (threadIdx.x == 0) yw_part[blockIdx.x] = r;
 }
 
+// ------------------------------------------------------------------ forward sweep + cell epilogue in one kernel
+// The fused two-eps sweep with NO partial slabs: a block owns 64 cells for ALL genes, its four waves take every fourth
+// k-step (B operand and V' straight from L2 with one k-step of prefetch -- no LDS staging to share, each wave has its own
+// gene range), the four partial accumulators meet in LDS and the block goes straight on to the cell epilogue
+// (ca_cell_fused_group) for its 64 cells: no Z partials written or re-read (39 + 26 MB per pass at 100k cells), one
+// launch and one inter-kernel gap less.  Sweep alone 119 us against 108 us for k_fwd_mfma (tools/fwd_mfma_lab.hip,
+// "block-split"), paid back by the 42 us cell epilogue launch it replaces.  Vs must be padded to a multiple of 32 genes
+// (last gene replicated, see k_final_gene / k_vprep); Mq is zero there.
+template <int D, int CP>
+__global__ void __launch_bounds__(CA_TB) k_fwd_cell(const float* __restrict__ F, const float* __restrict__ etamax2,
+                                                    const float* __restrict__ Vs /*[nk * 32][D]*/,
+                                                    const unsigned short* __restrict__ Mq /*[nk][2][64][8] bf16*/, ca_cell_ptrs p,
+                                                    const float* __restrict__ alpha_u, double* __restrict__ cell_part, int64_t N,
+                                                    int C, int K, int nk) {
+  constexpr int TL = 4;                    // 16-cell tiles per block: 64 cells
+  __shared__ ca_f32x4 comb[4][TL][64];     // the four waves' partial accumulators
+  __shared__ double sm[CA_TB];
+  __shared__ double la[64];
+  ca_log_softmax_alpha(alpha_u, C, la);    // wave 0; visible to all after the barrier below
+  const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4, wv = threadIdx.x >> 6;
+  const int64_t cell0 = (int64_t)blockIdx.x * (TL * 16);
+  float f[TL][D], em[TL];
+  ca_f32x4 acc[TL];
+#pragma unroll
+  for (int t = 0; t < TL; ++t) {
+    const int64_t n = cell0 + 16 * t + j;
+    const int64_t nn = n < N ? n : N - 1;
+#pragma unroll
+    for (int d = 0; d < D; ++d) f[t][d] = F[nn * D + d];
+    em[t] = etamax2[nn];
+    acc[t] = (ca_f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  unsigned m0, m1;   // (-1, 0) and (0, -1) as bf16 pairs, see k_fwd_mfma
+  asm volatile("s_mov_b32 %0, 0x0000bf80" : "=s"(m0));
+  asm volatile("s_mov_b32 %0, 0xbf800000" : "=s"(m1));
+  const ca_bf16x2 neg_lo = __builtin_bit_cast(ca_bf16x2, m0), neg_hi = __builtin_bit_cast(ca_bf16x2, m1);
+  const uint4* Bq = reinterpret_cast<const uint4*>(Mq);
+  constexpr int NV4 = 2 * D;   // float4 per lane and k-step: V'[8 genes][D]
+  uint4 b1n = {0u, 0u, 0u, 0u}, b2n = {0u, 0u, 0u, 0u};
+  float4 vn[NV4];
+#pragma unroll
+  for (int i = 0; i < NV4; ++i) vn[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto fetch = [&](int ks) {
+    b1n = Bq[(int64_t)ks * 128 + lane];
+    b2n = Bq[(int64_t)ks * 128 + 64 + lane];
+    const float4* vp = reinterpret_cast<const float4*>(Vs + ((int64_t)ks * 32 + 8 * q) * D);
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) vn[i] = vp[i];
+  };
+  int ks = wv;
+  if (ks < nk) fetch(ks);
+  for (; ks < nk; ks += 4) {
+    const ca_bf16x8 B1 = __builtin_bit_cast(ca_bf16x8, b1n), B2 = __builtin_bit_cast(ca_bf16x8, b2n);
+    float vf[8 * D];
+#pragma unroll
+    for (int i = 0; i < NV4; ++i) { vf[4 * i] = vn[i].x; vf[4 * i + 1] = vn[i].y; vf[4 * i + 2] = vn[i].z; vf[4 * i + 3] = vn[i].w; }
+    if (ks + 4 < nk) fetch(ks + 4);
+#pragma unroll
+    for (int t = 0; t < TL; ++t) {
+      unsigned hi[4], lo[4];
+#pragma unroll
+      for (int pp = 0; pp < 4; ++pp) {
+        ca_f32x2 eta = (ca_f32x2){vf[(2 * pp) * D], vf[(2 * pp + 1) * D]} * f[t][0] - em[t];
+#pragma unroll
+        for (int d = 1; d < D; ++d) eta = (ca_f32x2){vf[(2 * pp) * D + d], vf[(2 * pp + 1) * D + d]} * f[t][d] + eta;
+        const float e0 = __builtin_amdgcn_exp2f(eta.x), e1 = __builtin_amdgcn_exp2f(eta.y);
+        hi[pp] = ca_pk_bf16(e0, e1);
+        const ca_bf16x2 hb = __builtin_bit_cast(ca_bf16x2, hi[pp]);
+        const float r0 = __builtin_amdgcn_fdot2_f32_bf16(hb, neg_lo, e0, false);
+        const float r1 = __builtin_amdgcn_fdot2_f32_bf16(hb, neg_hi, e1, false);
+        lo[pp] = ca_pk_bf16(r0, r1);
+      }
+      const ca_bf16x8 A1 = __builtin_bit_cast(ca_bf16x8, ((uint4){hi[0], hi[1], hi[2], hi[3]}));
+      const ca_bf16x8 A2 = __builtin_bit_cast(ca_bf16x8, ((uint4){lo[0], lo[1], lo[2], lo[3]}));
+      ca_f32x4 a = acc[t];
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2, B1, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B2, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B1, a, 0, 0, 0);
+      acc[t] = a;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TL; ++t) comb[wv][t][lane] = acc[t];
+  __syncthreads();
+  // ---- cell epilogue for the block's 64 cells; Z[cell][column] = sum over the four waves of comb[w][tile][16 q + column][r]
+  //      with cell = 16 tile + 4 q + r (accumulator layout of the 16x16 MFMA)
+  constexpr int CPB = CA_TB / CP;
+  const int c = threadIdx.x % CP;
+  const int cc = c < C ? c : C - 1;
+  ca_cell_acc cacc = {0.0, 0.0, 0.0, 0.0};
+  for (int g0 = 0; g0 < TL * 16; g0 += CPB) {
+    const int lc = g0 + (int)threadIdx.x / CP;       // local cell
+    const bool inb = lc < TL * 16;
+    const int lcc = inb ? lc : 0;
+    const int t = lcc >> 4, row = lcc & 15, qq = row >> 2, r = row & 3;
+    const int la_ = 16 * qq + cc, lb_ = 16 * qq + C + cc;
+    const double ZA = ((double)comb[0][t][la_][r] + (double)comb[1][t][la_][r]) + ((double)comb[2][t][la_][r] + (double)comb[3][t][la_][r]);
+    const double ZB = ((double)comb[0][t][lb_][r] + (double)comb[1][t][lb_][r]) + ((double)comb[2][t][lb_][r] + (double)comb[3][t][lb_][r]);
+    ca_cell_fused_group<CP>(p, la, inb ? cell0 + lc : N, N, C, D, K, ZA, ZB, cacc);
+  }
+  ca_cell_fused_finish<CP>(cacc, sm, cell_part, blockIdx.x, C);
+}
+
 // fixed-order reduction of block partials: out[j] = sum_b part[b][j]; one block per column j
 __global__ void __launch_bounds__(CA_TB) k_reduce_part(const double* __restrict__ part, double* __restrict__ out, int nblk, int W_) {
   __shared__ double sm[CA_TB];
@@ -1849,6 +1954,8 @@ __device__ __forceinline__ void ca_final_gene_body(const double* __restrict__ re
     if (ok) {
       v = V[(int64_t)g * D + d] * CA_LOG2E_F;
       Vs[(int64_t)g * D + d] = v;
+      if (g == G - 1)   // pad to a multiple of 32 genes with the last gene's loading (k_fwd_cell reads whole k-steps)
+        for (int gp = G; gp < ((G + 31) / 32) * 32; ++gp) Vs[(int64_t)gp * D + d] = v;
     }
     __syncthreads();
     smin[threadIdx.x] = ok ? v : INFINITY;

@@ -125,6 +125,7 @@ struct ca_engine {
   bool tail_fuse = true;
   double* host_dev = nullptr;      // device view of host_pinned
   unsigned long long host_seq = 0, host_seq_next = 0;
+  bool fwd_cell = false; int ncblk_f = 0;   // forward sweep + cell epilogue in one kernel (k_fwd_cell)
   bool fwd_mfma = false; int fsplit = 1, fkchunk = 1, nk32 = 1; unsigned short* Mq = nullptr;   // matrix-core forward sweep
   // matrix-core backward sweep (k_bwd_mfma): bf16 parts of coef, its own cell split
   bool bwd_mfma = false; unsigned short* coefq = nullptr; int64_t N16 = 0, cchunk_m = 0; int csplit_m = 1, nwt = 0;
@@ -795,6 +796,27 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst) {
                             h->V, h->D, h->K, h->YtX, h->mu32, h->mu32B, h->Mb2, h->gene_part, h->gene_partB, h->G, h->frow, h->C,
                             h->fwd_mfma ? h->Mq : nullptr));
   CACK(ensure_ycache(h));
+  ca_cell_ptrs cp;
+  cp.A = h->A; cp.cn = h->cn; cp.s64 = h->s64; cp.etamax2 = h->etamax2; cp.glogit = h->glogit; cp.F = h->F;
+  cp.coef = h->coef; cp.dgl = h->dgl; cp.coefq = h->bwd_mfma ? h->coefq : nullptr;
+  int CP = 1;
+  while (CP < h->C) CP <<= 1;
+  int cell_blocks = h->ncblk;
+  if (h->fwd_cell) {   // sweep + cell epilogue in one kernel: no Z partials, one launch
+    cell_blocks = h->ncblk_f;
+#define CA_FC(DV, CPV)                                                                                                       \
+  LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell<DV, CPV>), dim3(h->ncblk_f), dim3(CA_TB), 0, h->stream, h->F, h->etamax2, \
+                                              h->Vs, h->Mq, cp, h->alpha_u, h->cell_part, h->N, h->C, h->K, h->nk32))
+#define CA_FCD(CPV) do { if (h->D == 1) CA_FC(1, CPV); else CA_FC(2, CPV); } while (0)
+    switch (CP) {
+      case 1: CA_FCD(1); break;
+      case 2: CA_FCD(2); break;
+      case 4: CA_FCD(4); break;
+      default: CA_FCD(8); break;
+    }
+#undef CA_FCD
+#undef CA_FC
+  } else {
   if (h->fwd_mfma) {
     const dim3 grid(cdiv(h->N, (CA_TB / 64) * CA_FM_TL * 16), h->fsplit);
     if (h->D == 1)
@@ -809,12 +831,7 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst) {
   }
   {
     // (no wait for the side stream here: this epilogue does not touch the Y stream's products -- k_yw_dot does)
-    int CP = 1;
-    while (CP < h->C) CP <<= 1;
     dim3 grid(h->ncblk);
-    ca_cell_ptrs cp;
-    cp.A = h->A; cp.cn = h->cn; cp.s64 = h->s64; cp.etamax2 = h->etamax2; cp.glogit = h->glogit; cp.F = h->F;
-    cp.coef = h->coef; cp.dgl = h->dgl; cp.coefq = h->bwd_mfma ? h->coefq : nullptr;
 #define CA_CELLF(CPV)                                                                                                   \
   LAUNCH(h, CA_KERNEL_CELL,                                                                                             \
          hipLaunchKernelGGL((k_cell_fused<CPV>), grid, dim3(CA_TB), 0, h->stream, h->Zpart2, h->frow, cp, h->alpha_u,    \
@@ -827,11 +844,12 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst) {
     }
 #undef CA_CELLF
   }
+  }
   // The ELBO assembly (reduction of the cell partials and of k_yw_dot's psi.(YW) partials, then the O(K + C) body) is
   // left pending: it rides on the per-gene kernel of the train pass that completes this look-ahead (train_update), after
   // the single all-reduce of that pass when sharded (train_bwd); ca_run and the odd ends flush it (flush_mon_tail).
   h->mon_tail = small_args(h, h->gene_part, 0, 0.f, elbo_dst, true);
-  h->mon_tail.ncblk = h->ncblk;
+  h->mon_tail.ncblk = cell_blocks;
   if (h->K > 0) { h->mon_tail.yw_part = h->yw_part; h->mon_tail.n_yw = h->n_yw; }
   if (!h->tail_fuse) CACK(flush_mon_tail(h));
   h->look_valid = true;
@@ -1241,7 +1259,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   CACK(dalloc(h, &h->m_V, (int64_t)G * std::max(D, 1)));
   CACK(dalloc(h, &h->v_V, (int64_t)G * std::max(D, 1)));
   CACK(dalloc(h, &h->g_V, (int64_t)G * std::max(D, 1)));
-  CACK(dalloc(h, &h->Vs, (int64_t)G * std::max(D, 1)));
+  CACK(dalloc(h, &h->Vs, (int64_t)cdiv(G, 32) * 32 * std::max(D, 1)));   // padded to whole 32-gene k-steps (last gene replicated)
   CACK(dalloc(h, &h->loc, G)); CACK(dalloc(h, &h->ls, G));
   CACK(dalloc(h, &h->m_loc, G)); CACK(dalloc(h, &h->v_loc, G));
   CACK(dalloc(h, &h->m_ls, G)); CACK(dalloc(h, &h->v_ls, G));
@@ -1270,6 +1288,8 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     h->frow = (2 * C <= 8) ? 8 : 16;
     // matrix-core forward sweep (k_fwd_mfma): D in {1, 2}; few gene slices, streamed through LDS
     h->fwd_mfma = (D == 1 || D == 2) && !(getenv("CA_FWD_MFMA") && atoi(getenv("CA_FWD_MFMA")) == 0);
+    h->fwd_cell = h->fwd_mfma && h->tail_fuse && !(getenv("CA_FWD_CELL") && atoi(getenv("CA_FWD_CELL")) == 0);
+    h->ncblk_f = cdiv(Nn, 64);
     int zsplit = h->gsplit;
     if (h->fwd_mfma) {
       h->frow = 16;
@@ -1306,7 +1326,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   CACK(dalloc(h, &h->Zpart, (int64_t)S * h->gsplit * h->nchunk * Nn * CA_CW));
   CACK(dalloc(h, &h->coef, (int64_t)S * h->nchunk * Nn * CA_CW));
   CACK(dalloc(h, &h->scratch, Nn * C));
-  CACK(dalloc(h, &h->cell_part, (int64_t)h->ncblk * (3 + C)));
+  CACK(dalloc(h, &h->cell_part, (int64_t)std::max(h->ncblk, h->ncblk_f) * (3 + C)));
   CACK(dalloc(h, &h->gpart, (int64_t)std::max(h->csplit, h->csplit_m) * G * (S + D)));
   CACK(dalloc(h, &h->dFpart, (int64_t)std::max(h->ntile, h->nwt) * Nn * std::max(D, 1)));
   CACK(dalloc(h, &h->YWpart, (int64_t)(h->nseg + 1) * Nn * std::max(K, 1)));
@@ -1539,7 +1559,7 @@ int ca_get_info(ca_handle h, ca_info* i) {
   i->N = h->N; i->G = h->G; i->C = h->C; i->K = h->K; i->P = h->P; i->S = h->S;
   i->y_storage = h->ystore; i->y_bytes_per_elem = h->ybytes; i->y_device_bytes = h->y_dev_bytes; i->device_bytes = h->dev_bytes;
   i->gsplit = h->gsplit; i->csplit = h->csplit; i->n_cu = h->n_cu; i->fused_sweep = h->fused_ok ? 1 : 0;
-  i->fwd_mfma = (h->fused_ok && h->fwd_mfma) ? 1 : 0; i->bwd_mfma = h->bwd_mfma ? 1 : 0; i->fsplit = h->fsplit;
+  i->fwd_mfma = (h->fused_ok && h->fwd_mfma) ? 1 : 0; i->bwd_mfma = h->bwd_mfma ? 1 : 0; i->fsplit = h->fsplit; i->fwd_cell = (h->fused_ok && h->fwd_cell) ? 1 : 0;
   return CA_OK;
 }
 

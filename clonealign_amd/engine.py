@@ -47,7 +47,7 @@ class CaInfo(C.Structure):
                 ("S", C.c_int32), ("y_storage", C.c_int32), ("y_bytes_per_elem", C.c_int32),
                 ("y_device_bytes", C.c_int64), ("device_bytes", C.c_int64), ("gsplit", C.c_int32),
                 ("csplit", C.c_int32), ("n_cu", C.c_int32), ("fused_sweep", C.c_int32), ("fwd_mfma", C.c_int32),
-                ("bwd_mfma", C.c_int32), ("fsplit", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("bwd_mfma", C.c_int32), ("fsplit", C.c_int32), ("fwd_cell", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class CaPreprocessParams(C.Structure):

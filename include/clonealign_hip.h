@@ -88,7 +88,8 @@ typedef struct ca_info {
   int32_t fwd_mfma;          /* 1: the fused sweep's forward contraction runs on the matrix cores (k_fwd_mfma) */
   int32_t bwd_mfma;          /* 1: the backward sweep's t = coef.L contraction runs on the matrix cores (k_bwd_mfma) */
   int32_t fsplit;            /* gene slices of the matrix-core forward sweep */
-  int32_t reserved[4];
+  int32_t fwd_cell;          /* 1: forward sweep and cell epilogue of the fused pass are ONE kernel (k_fwd_cell) */
+  int32_t reserved[3];
 } ca_info;
 
 /* kernel classes reported by ca_get_kernel_times() */

@@ -273,20 +273,24 @@ FUSED_SHAPES = {
 }
 
 
-@pytest.mark.parametrize("fwd", ["mfma", "valu"])
+@pytest.mark.parametrize("fwd", ["cell", "mfma", "valu"])
 @pytest.mark.parametrize("shape", list(FUSED_SHAPES))
 def test_fused_sweep_forward_variants_agree_with_oracle(shape, fwd, monkeypatch):
     """ca_iterate takes the fused two-eps sweep (monitor pass i + forward half of train pass i+1 from one exp per
-    (cell, gene)); its forward contraction runs on the matrix cores (k_fwd_mfma, D in {1, 2}) or on the VALU
-    (CA_FWD_MFMA=0, and always for D >= 3).  Both against the oracle's call-by-call loop."""
+    (cell, gene)); its forward contraction runs on the matrix cores (D in {1, 2}) -- in one kernel with the cell
+    epilogue (k_fwd_cell, the default) or as k_fwd_mfma + k_cell_fused (CA_FWD_CELL=0) -- or on the VALU
+    (CA_FWD_MFMA=0, and always for D >= 3).  All against the oracle's call-by-call loop."""
     from clonealign_amd.engine import HipEngine
     from oracle.fused_numpy import FusedModel
+    if fwd == "mfma":
+        monkeypatch.setenv("CA_FWD_CELL", "0")
     if fwd == "valu":
         monkeypatch.setenv("CA_FWD_MFMA", "0")
     case = make_case(seed=5, **FUSED_SHAPES[shape])
     eng, ora = HipEngine(**case), FusedModel(**case, dtype="float32")
     try:
-        assert eng.info()["fwd_mfma"] == int(fwd == "mfma" and ora.D in (1, 2))
+        assert eng.info()["fwd_mfma"] == int(fwd in ("cell", "mfma") and ora.D in (1, 2))
+        assert eng.info()["fwd_cell"] == int(fwd == "cell" and ora.D in (1, 2))
         st = perturbed_state({n: getattr(ora, n).shape for n in ora.VAR_NAMES}, amp=0.2)
         for n, v in st.items():
             setattr(ora, n, v.astype(ora.pdt))
