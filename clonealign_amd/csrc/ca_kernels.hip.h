@@ -1785,21 +1785,21 @@ __global__ void __launch_bounds__(CA_TB) k_yw_dot(const float* __restrict__ YWpa
 }
 
 // ------------------------------------------------------------------ forward sweep + cell epilogue in one kernel
-// The fused two-eps sweep with NO partial slabs: a block owns 64 cells for ALL genes, its four waves take every fourth
+// The fused two-eps sweep with NO partial slabs: a block owns 16 * TL cells for ALL genes, its four waves take every fourth
 // k-step (B operand and V' straight from L2 with one k-step of prefetch -- no LDS staging to share, each wave has its own
 // gene range), the four partial accumulators meet in LDS and the block goes straight on to the cell epilogue
-// (ca_cell_fused_group) for its 64 cells: no Z partials written or re-read (39 + 26 MB per pass at 100k cells), one
+// (ca_cell_fused_group) for its cells: no Z partials written or re-read (39 + 26 MB per pass at 100k cells), one
 // launch and one inter-kernel gap less.  Sweep alone 119 us against 108 us for k_fwd_mfma (tools/fwd_mfma_lab.hip,
 // "block-split"), paid back by the 42 us cell epilogue launch it replaces.  Vs must be padded to a multiple of 32 genes
 // (last gene replicated, see k_final_gene / k_vprep); Mq is zero there.
-template <int D, int CP>
+template <int D, int TL>
 __global__ void __launch_bounds__(CA_TB) k_fwd_cell(const float* __restrict__ F, const float* __restrict__ etamax2,
                                                     const float* __restrict__ Vs /*[nk * 32][D]*/,
                                                     const unsigned short* __restrict__ Mq /*[nk][2][64][8] bf16*/, ca_cell_ptrs p,
                                                     const float* __restrict__ alpha_u, double* __restrict__ cell_part, int64_t N,
                                                     int C, int K, int nk) {
-  constexpr int TL = 4;                    // 16-cell tiles per block: 64 cells
-  __shared__ ca_f32x4 comb[4][TL][64];     // the four waves' partial accumulators
+  constexpr int CP = 8;                    // lanes per cell in the epilogue (C <= 8)
+  __shared__ ca_f32x4 comb[4][TL][64];     // the four waves' partial accumulators; the block owns 16 * TL cells
   __shared__ double sm[CA_TB];
   __shared__ double la[64];
   ca_log_softmax_alpha(alpha_u, C, la);    // wave 0; visible to all after the barrier below
@@ -1868,7 +1868,7 @@ __global__ void __launch_bounds__(CA_TB) k_fwd_cell(const float* __restrict__ F,
 #pragma unroll
   for (int t = 0; t < TL; ++t) comb[wv][t][lane] = acc[t];
   __syncthreads();
-  // ---- cell epilogue for the block's 64 cells; Z[cell][column] = sum over the four waves of comb[w][tile][16 q + column][r]
+  // ---- cell epilogue for the block's cells; Z[cell][column] = sum over the four waves of comb[w][tile][16 q + column][r]
   //      with cell = 16 tile + 4 q + r (accumulator layout of the 16x16 MFMA)
   constexpr int CPB = CA_TB / CP;
   const int c = threadIdx.x % CP;

@@ -125,7 +125,7 @@ struct ca_engine {
   bool tail_fuse = true;
   double* host_dev = nullptr;      // device view of host_pinned
   unsigned long long host_seq = 0, host_seq_next = 0;
-  bool fwd_cell = false; int ncblk_f = 0;   // forward sweep + cell epilogue in one kernel (k_fwd_cell)
+  bool fwd_cell = false; int ncblk_f = 0, fc_tl = 4;   // forward sweep + cell epilogue in one kernel (k_fwd_cell)
   bool fwd_mfma = false; int fsplit = 1, fkchunk = 1, nk32 = 1; unsigned short* Mq = nullptr;   // matrix-core forward sweep
   // matrix-core backward sweep (k_bwd_mfma): bf16 parts of coef, its own cell split
   bool bwd_mfma = false; unsigned short* coefq = nullptr; int64_t N16 = 0, cchunk_m = 0; int csplit_m = 1, nwt = 0;
@@ -804,14 +804,14 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst) {
   int cell_blocks = h->ncblk;
   if (h->fwd_cell) {   // sweep + cell epilogue in one kernel: no Z partials, one launch
     cell_blocks = h->ncblk_f;
-#define CA_FC(DV, CPV)                                                                                                       \
-  LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell<DV, CPV>), dim3(h->ncblk_f), dim3(CA_TB), 0, h->stream, h->F, h->etamax2, \
+#define CA_FC(DV, TLV)                                                                                                       \
+  LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell<DV, TLV>), dim3(h->ncblk_f), dim3(CA_TB), 0, h->stream, h->F, h->etamax2, \
                                               h->Vs, h->Mq, cp, h->alpha_u, h->cell_part, h->N, h->C, h->K, h->nk32))
-#define CA_FCD(CPV) do { if (h->D == 1) CA_FC(1, CPV); else CA_FC(2, CPV); } while (0)
-    switch (CP) {
-      case 1: CA_FCD(1); break;
-      case 2: CA_FCD(2); break;
+#define CA_FCD(TLV) do { if (h->D == 1) CA_FC(1, TLV); else CA_FC(2, TLV); } while (0)
+    switch (h->fc_tl) {
       case 4: CA_FCD(4); break;
+      case 5: CA_FCD(5); break;
+      case 6: CA_FCD(6); break;
       default: CA_FCD(8); break;
     }
 #undef CA_FCD
@@ -1289,7 +1289,23 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     // matrix-core forward sweep (k_fwd_mfma): D in {1, 2}; few gene slices, streamed through LDS
     h->fwd_mfma = (D == 1 || D == 2) && !(getenv("CA_FWD_MFMA") && atoi(getenv("CA_FWD_MFMA")) == 0);
     h->fwd_cell = h->fwd_mfma && h->tail_fuse && !(getenv("CA_FWD_CELL") && atoi(getenv("CA_FWD_CELL")) == 0);
-    h->ncblk_f = cdiv(Nn, 64);
+    {
+      // cells per block of k_fwd_cell: 16 * TL.  All blocks do the same work, so a grid just past the resident capacity
+      // runs a nearly empty second round (100k cells at TL = 4: 1563 blocks on 1536 slots); take the smallest tile that
+      // fits one round, else the largest (many rounds).
+      h->fc_tl = 8;
+      const int tls[4] = {4, 5, 6, 8};
+      const void* fns[2][4] = {{(const void*)k_fwd_cell<1, 4>, (const void*)k_fwd_cell<1, 5>, (const void*)k_fwd_cell<1, 6>, (const void*)k_fwd_cell<1, 8>},
+                               {(const void*)k_fwd_cell<2, 4>, (const void*)k_fwd_cell<2, 5>, (const void*)k_fwd_cell<2, 6>, (const void*)k_fwd_cell<2, 8>}};
+      for (int i = 0; i < 4 && h->fwd_cell; ++i) {
+        int per_cu = 4;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fns[D == 2 ? 1 : 0][i], CA_TB, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        (void)hipGetLastError();
+        if (cdiv(Nn, 16 * tls[i]) <= (int64_t)per_cu * h->n_cu) { h->fc_tl = tls[i]; break; }
+      }
+      if (const char* e = getenv("CA_FC_TL")) { const int t = atoi(e); if (t == 4 || t == 5 || t == 6 || t == 8) h->fc_tl = t; }
+      h->ncblk_f = cdiv(Nn, 16 * h->fc_tl);
+    }
     int zsplit = h->gsplit;
     if (h->fwd_mfma) {
       h->frow = 16;
