@@ -316,10 +316,12 @@ __global__ void __launch_bounds__(CA_TB) k_ypass(const YT* __restrict__ Y, const
   }
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int task = (int)blockIdx.x * (CA_TB / 64) + wave;   // wave-uniform from here on
-  const int rb = task / nseg;
-  const int sg = task - rb * nseg;
-  if (rb >= nrb) return;
+  // block = one gene segment x 4 consecutive row blocks (one per wave): the four column partials are combined in LDS at
+  // the end, so YTpart has one row per BLOCK (a quarter of the slab the column-sum kernel has to read back)
+  const int rg = (int)blockIdx.x / nseg;                    // wave-uniform from here on
+  const int sg = (int)blockIdx.x - rg * nseg;
+  const int rb = rg * (CA_TB / 64) + wave;
+  const bool live = rb < nrb;
   const int col0 = sg * 64 * VEC + lane * VEC;
   float w[VEC][KK], acc[VEC][KK];
 #pragma unroll
@@ -331,8 +333,8 @@ __global__ void __launch_bounds__(CA_TB) k_ypass(const YT* __restrict__ Y, const
       w[j][k] = g < G ? wv : 0.f;
       acc[j][k] = 0.f;
     }
-  const int64_t r0 = (int64_t)rb * TR;
-  const int nrows = (int)(((r0 + TR < N) ? r0 + TR : N) - r0);
+  const int64_t r0 = live ? (int64_t)rb * TR : 0;
+  const int nrows = live ? (int)(((r0 + TR < N) ? r0 + TR : N) - r0) : 0;
   // psi of the strip's rows: row i lives in lane i & 63 of psv[.][i >> 6]   (TR <= 128)
   float psv[KK][2];
 #pragma unroll
@@ -340,7 +342,7 @@ __global__ void __launch_bounds__(CA_TB) k_ypass(const YT* __restrict__ Y, const
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
       const int i = lane + 64 * hh;
-      const int64_t r = r0 + (i < nrows ? i : nrows - 1);
+      const int64_t r = r0 + (i < nrows ? i : (nrows > 0 ? nrows - 1 : 0));
       psv[k][hh] = F[r * Dstride + koff + k];
     }
   const char* base = reinterpret_cast<const char*>(Y) + r0 * (int64_t)Gp * (int64_t)sizeof(YT);   // scalar
@@ -396,17 +398,27 @@ __global__ void __launch_bounds__(CA_TB) k_ypass(const YT* __restrict__ Y, const
     }
   };
   uint4 bufA[U], bufB[U];
-  fetch(bufA, 0);
+  if (nrows > 0) fetch(bufA, 0);
   for (int i0 = 0; i0 < nrows; i0 += 2 * U) {
     if (i0 + U < nrows) fetch(bufB, i0 + U);
     consume(bufA, i0);
     if (i0 + 2 * U < nrows) fetch(bufA, i0 + 2 * U);
     if (i0 + U < nrows) consume(bufB, i0 + U);
   }
+  // combine the four waves' column partials (fixed order) and write the block's row of YTpart
+  __shared__ float ycomb[CA_TB / 64][64][VEC + 1];
 #pragma unroll
-  for (int j = 0; j < VEC; ++j)
+  for (int k = 0; k < KK; ++k) {
+    __syncthreads();
 #pragma unroll
-    for (int k = 0; k < KK; ++k) YTpart[((int64_t)rb * Gp + col0 + j) * K + koff + k] = acc[j][k];
+    for (int j = 0; j < VEC; ++j) ycomb[wave][lane][j] = acc[j][k];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * VEC; i += CA_TB) {
+      const int l = i / VEC, j = i - l * VEC;
+      const float v = (ycomb[0][l][j] + ycomb[1][l][j]) + (ycomb[2][l][j] + ycomb[3][l][j]);
+      YTpart[((int64_t)rg * Gp + sg * 64 * VEC + i) * K + koff + k] = v;
+    }
+  }
 }
 
 // Column sums of a [rows][ld] float slab in fp64 and in a fixed order: out[c] = sum_r part[r*ld + c].

@@ -79,7 +79,7 @@ struct ca_engine {
   std::vector<void*> allocs;
   int64_t dev_bytes = 0;
   // ---- count matrix
-  int ystore = 0, ybytes = 0, VEC = 0, Gp = 0, nseg = 0, TR = 0, nrb = 0;
+  int ystore = 0, ybytes = 0, VEC = 0, Gp = 0, nseg = 0, TR = 0, nrb = 0, nrg = 0;   // nrg: rows of YTpart = blocks of 4 row blocks
   void* Y = nullptr;
   int64_t y_dev_bytes = 0;
   // overflow list of the u8 storage (entries > 255), CSR (by cell) and CSC (by gene) orders, host copy kept for setup
@@ -395,8 +395,7 @@ int ensure_ycache(ca_engine* h) {
     return CA_OK;
   }
   if (h->ycache_valid || h->K == 0) { h->ycache_valid = true; return CA_OK; }
-  const int64_t tasks = (int64_t)h->nrb * h->nseg;
-  dim3 grid(cdiv(tasks, CA_TB / 64));
+  dim3 grid((unsigned)((int64_t)h->nrg * h->nseg));
   // entries above 255: one extra "segment" of YW and one extra term of Y^T psi; their per-entry work rides on the
   // first stream launch, the per-gene sums on the column-sum launch
   ca_ovf_args ovf;
@@ -421,7 +420,7 @@ int ensure_ycache(ca_engine* h) {
   // YTpart is [nrb][Gp*K]: column sums over the row blocks (+ the overflow list's chunk sums per gene); ytpsi is laid
   // out [Gp][K] (first G rows used)
   LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->Gp * h->K, 64)), dim3(1024), 0, h->stream,
-                                                h->YTpart, h->red + h->off_y, h->nrb, (int64_t)h->Gp * h->K, h->Gp * h->K,
+                                                h->YTpart, h->red + h->off_y, h->nrg, (int64_t)h->Gp * h->K, h->Gp * h->K,
                                                 h->n_ovf > 0 ? h->ovf_col_chunk_ptr : nullptr, h->n_ovf > 0 ? h->ovf_csum : nullptr, h->K, h->G));
   // row side: YW = sum of the strips, and the psi.(YW) partials of the ELBO (the fused loop's cell epilogue leaves both to this)
   LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_yw_dot, dim3(h->n_yw), dim3(CA_TB), 0, h->stream, h->YWpart,
@@ -449,8 +448,7 @@ void ypass_tf_t(ca_engine* h, const float* Fp, const float* Vp, int q, int koff,
 }
 template <int TF>
 int ypass_tf(ca_engine* h, const float* Fp, const float* Vp, int q, float* YWp, float* YTp, float* csum) {
-  const int64_t tasks = (int64_t)h->nrb * h->nseg;
-  dim3 grid(cdiv(tasks, CA_TB / 64));
+  dim3 grid((unsigned)((int64_t)h->nrg * h->nseg));
   for (int koff = 0; koff < q; koff += 4) {
     const int kk = std::min(4, q - koff);
     if (h->ystore == CA_YSTORE_U8) ypass_tf_t<uint8_t, TF>(h, Fp, Vp, q, koff, kk, YWp, YTp, grid);
@@ -464,7 +462,7 @@ int ypass_tf(ca_engine* h, const float* Fp, const float* Vp, int q, float* YWp, 
     hipLaunchKernelGGL(k_ovf_chunks, dim3(cdiv(h->n_ovf_chunk, CA_TB / 64)), dim3(CA_TB), 0, h->stream, h->ovf_chunk_start, h->ovf_row2,
                        h->ovf_val2, Fp, q, csum, h->n_ovf_chunk, q, TF);
     hipLaunchKernelGGL(k_ovf_cols, dim3(cdiv(h->Gp, CA_TB)), dim3(CA_TB), 0, h->stream, h->ovf_col_chunk_ptr, csum,
-                       YTp + (int64_t)h->nrb * h->Gp * q, h->Gp, h->G, q);
+                       YTp + (int64_t)h->nrg * h->Gp * q, h->Gp, h->G, q);
     HIPCK(h, hipGetLastError());
   }
   return CA_OK;
@@ -1181,6 +1179,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   if (const char* e = getenv("CA_TR")) h->TR = std::min(128, std::max(1, atoi(e)));   // tuning override (k_ypass keeps psi of <= 128 rows)
   h->nrb = cdiv(Nn, h->TR);
   while (!getenv("CA_TR") && (int64_t)h->nrb * h->nseg < 4 * h->n_cu && h->TR > 32) { h->TR /= 2; h->nrb = cdiv(Nn, h->TR); }
+  h->nrg = cdiv(h->nrb, CA_TB / 64);
   // ---- constants
   std::vector<double> Lrm((size_t)G * C), logL((size_t)G * C);
   std::vector<float> Lb((size_t)h->nchunk * G * CA_CW, 0.f);
@@ -1375,8 +1374,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     for (int j = 0; j < cols; ++j) {
       for (int64_t n = 0; n < Nn; ++n) col[n] = j == 0 ? 1.f : (float)p->X[hidx(p->layout, n, j - 1, Nn, P)];
       HIPCK(h, hipMemcpyAsync(Ft, col.data(), (size_t)Nn * sizeof(float), hipMemcpyHostToDevice, h->stream));
-      const int64_t tasks = (int64_t)h->nrb * h->nseg;
-      dim3 grid(cdiv(tasks, CA_TB / 64));
+      dim3 grid((unsigned)((int64_t)h->nrg * h->nseg));
       ca_ovf_args no_ovf;
       memset(&no_ovf, 0, sizeof(no_ovf));
       if (h->ystore == CA_YSTORE_U8)
@@ -1386,7 +1384,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
       else
         hipLaunchKernelGGL((k_ypass<float, 1>), grid, dim3(CA_TB), 0, h->stream, (const float*)h->Y, Ft, 1, Vt, 0, YWp, YTp, Nn, G, h->Gp, h->nseg, h->nrb, h->TR, 1, no_ovf, (int)grid.x);
       HIPCK(h, hipGetLastError());
-      hipLaunchKernelGGL(k_colsum, dim3(cdiv(h->Gp, 64)), dim3(1024), 0, h->stream, YTp, yt, h->nrb, (int64_t)h->Gp, h->Gp);
+      hipLaunchKernelGGL(k_colsum, dim3(cdiv(h->Gp, 64)), dim3(1024), 0, h->stream, YTp, yt, h->nrg, (int64_t)h->Gp, h->Gp);
       std::vector<double> tmp((size_t)G);
       HIPCK(h, hipMemcpyAsync(tmp.data(), yt, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, h->stream));
       HIPCK(h, hipStreamSynchronize(h->stream));
@@ -1772,7 +1770,7 @@ int ca_init_psi_pca(ca_handle h, const double* noise, int32_t n_iter, uint64_t s
   PCK(hipMalloc((void**)&csum, (size_t)std::max(h->n_ovf_chunk, 1) * q * sizeof(float)));
   PCK(hipMalloc((void**)&ytd, (size_t)std::max<int64_t>((int64_t)Gp * q, 2 * (int64_t)Gp + q * q + 4 * q + 8) * sizeof(double)));
   PCK(hipMalloc((void**)&cdev, (size_t)q * sizeof(double)));
-  const int nrb_tot = h->nrb + (h->n_ovf > 0 ? 1 : 0), nseg_tot = h->nseg + (h->n_ovf > 0 ? 1 : 0);
+  const int nrb_tot = h->nrg + (h->n_ovf > 0 ? 1 : 0), nseg_tot = h->nseg + (h->n_ovf > 0 ? 1 : 0);
   auto colsum_to_host = [&](int qq, std::vector<double>& out) -> int {
     hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)Gp * qq, 64)), dim3(1024), 0, h->stream, YTp, ytd, nrb_tot, (int64_t)Gp * qq, Gp * qq);
     out.resize((size_t)G * qq);
@@ -1911,7 +1909,7 @@ int ca_clone_gene_sums(ca_handle h, const int32_t* clone_of_cell, double* Tout, 
   PCK(hipMalloc((void**)&csum, (size_t)std::max(h->n_ovf_chunk, 1) * C * sizeof(float)));
   PCK(hipMalloc((void**)&ytd, (size_t)Gp * C * sizeof(double)));
   PCK(hipMemsetAsync(Vp, 0, (size_t)Gp * C * sizeof(float), h->stream));
-  const int nrb_tot = h->nrb + (h->n_ovf > 0 ? 1 : 0);
+  const int nrb_tot = h->nrg + (h->n_ovf > 0 ? 1 : 0);
   std::vector<float> ind((size_t)N * C, 0.f), asg((size_t)N, 0.f);
   for (int64_t n = 0; n < N; ++n) {
     const int c = clone_of_cell[n];
