@@ -383,3 +383,23 @@ def test_random_shapes_whole_loop_matches_oracle(shape):
             assert _rel(p[n], getattr(ora, n)) < 1e-3, (n, _rel(p[n], getattr(ora, n)))
     finally:
         eng.close()
+
+
+def test_same_seed_is_bitwise_reproducible():
+    """The reference's second test (tests/testthat/test_clonealign.R:61-64: two fits under the same set.seed are equal).
+    Here every reduction has a fixed order (no float atomics, partial slabs summed by index), two streams
+    notwithstanding: same seed => identical ELBO trace, parameters and final ELBOs, bit for bit."""
+    from clonealign_amd.engine import HipEngine
+    case = make_case(seed=4, N=5000, G=900, C=7, K=1)
+    outs = []
+    for _ in range(3):
+        e = HipEngine(**case, seed=99)
+        try:
+            tr = np.asarray(e.run(None, 20, 1e-12))
+            outs.append((tr, e.get_state(), np.asarray(e.final_elbo(None, 3))))
+        finally:
+            e.close()
+    for tr, st, fin in outs[1:]:
+        assert np.array_equal(tr, outs[0][0]) and np.array_equal(fin, outs[0][2])
+        for k, v in st.items():
+            assert np.array_equal(v, outs[0][1][k]), k
