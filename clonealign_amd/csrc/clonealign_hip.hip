@@ -1328,7 +1328,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     }
     CACK(dalloc(h, &h->mu32B, G));
     CACK(dalloc(h, &h->gene_partB, (int64_t)h->ngblk * (3 + K)));
-    CACK(dalloc(h, &h->Zpart2, (int64_t)zsplit * Nn * h->frow));
+    if (!h->fwd_cell) CACK(dalloc(h, &h->Zpart2, (int64_t)zsplit * Nn * h->frow));   // k_fwd_cell keeps Z in the block
   }
   if (getenv("CA_VERBOSE"))
     fprintf(stderr, "[clonealign_hip] N=%lld G=%d C=%d D=%d n_cu=%d gsplit=%d gchunk=%d csplit=%d fused=%d fwd_mfma=%d fsplit=%d fkchunk=%d "
