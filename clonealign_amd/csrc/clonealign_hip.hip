@@ -807,6 +807,7 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst) {
                                               h->Vs, h->Mq, cp, h->alpha_u, h->cell_part, h->N, h->C, h->K, h->nk32))
 #define CA_FCD(TLV) do { if (h->D == 1) CA_FC(1, TLV); else CA_FC(2, TLV); } while (0)
     switch (h->fc_tl) {
+      case 2: CA_FCD(2); break;
       case 4: CA_FCD(4); break;
       case 5: CA_FCD(5); break;
       case 6: CA_FCD(6); break;
@@ -1291,7 +1292,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     {
       // cells per block of k_fwd_cell: 16 * TL.  All blocks do the same work, so a grid just past the resident capacity
       // runs a nearly empty second round (100k cells at TL = 4: 1563 blocks on 1536 slots); take the smallest tile that
-      // fits one round, else the largest (many rounds).
+      // fits one round, else the largest (many rounds); 32-cell blocks below ~32k cells (+1-5 %).
       h->fc_tl = 8;
       const int tls[4] = {4, 5, 6, 8};
       const void* fns[2][4] = {{(const void*)k_fwd_cell<1, 4>, (const void*)k_fwd_cell<1, 5>, (const void*)k_fwd_cell<1, 6>, (const void*)k_fwd_cell<1, 8>},
@@ -1302,7 +1303,8 @@ int create_impl(ca_engine* h, const ca_problem* p) {
         (void)hipGetLastError();
         if (cdiv(Nn, 16 * tls[i]) <= (int64_t)per_cu * h->n_cu) { h->fc_tl = tls[i]; break; }
       }
-      if (const char* e = getenv("CA_FC_TL")) { const int t = atoi(e); if (t == 4 || t == 5 || t == 6 || t == 8) h->fc_tl = t; }
+      if (h->fwd_cell && cdiv(Nn, 64) < 2 * h->n_cu) h->fc_tl = 2;   // small shards: 64-cell blocks leave CUs with one block or none
+      if (const char* e = getenv("CA_FC_TL")) { const int t = atoi(e); if (t == 2 || t == 4 || t == 5 || t == 6 || t == 8) h->fc_tl = t; }
       h->ncblk_f = cdiv(Nn, 16 * h->fc_tl);
     }
     int zsplit = h->gsplit;
