@@ -78,7 +78,8 @@ def test_two_shards_on_one_gpu_match_single_handle(kw):
             assert np.abs(st[n] - st_ref[n][lo:hi]).max(initial=0) <= 2e-5 * max(np.abs(st_ref[n]).max(initial=0), 1e-30), n
 
 
-@pytest.mark.parametrize("kw", [dict(N=301, G=140, C=3, K=1), dict(N=1300, G=700, C=8, K=1), dict(N=260, G=90, C=4, K=2, P=1)])
+@pytest.mark.parametrize("kw", [dict(N=301, G=140, C=3, K=1), dict(N=1300, G=700, C=8, K=1), dict(N=260, G=90, C=4, K=2, P=1),
+                                dict(N=777, G=333, C=5, K=1, P=1), dict(N=515, G=97, C=2, K=2)])
 def test_two_shards_whole_loop_matches_single_handle(kw):
     """ca_run / ca_iterate (the fused two-eps sweep, what bench.py drives on N GPUs) on two shards through the host hook
     against the single-handle loop: same ELBO trace, same parameters, replicas bit-identical, and the number of
