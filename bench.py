@@ -236,6 +236,24 @@ def main():
                 traffic = pm.get(key, {}).get("hbm_bytes")
         except Exception:
             traffic = None
+        # the HBM-bound kernel of the iteration (SURVEY.md section 8d asks for both roofs): the Y stream, timed by HIP events on
+        # its own (side) stream during the warmup iterations, where every kernel class is timed
+        ystream = None
+        if K > 0 and kt["ypass"][1] > 0:
+            y_s = kt["ypass"][0] / kt["ypass"][1] * 1e-3
+            canon = n_loc * G * 4.0 + (n_loc + G) * K * 4.0 * 2
+            ytraffic = None
+            try:
+                if (N, G, C, K, world) == (100_000, 5_000, 8, 1, 1):
+                    ytraffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]["ypass"]["hbm_bytes"]
+            except Exception:
+                ytraffic = None
+            ystream = {"bound": "hbm", "kernel": "ypass", "achieved": canon / y_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                       "frac": canon / y_s / 1e9 / PEAK_HBM_GBS, "traffic": ytraffic, "launch_ms": y_s * 1e3,
+                       "stored_GBps": n_loc * G * float(info["y_bytes_per_elem"]) / y_s / 1e9,
+                       "note": "canonical 4 B per count (the reference feeds float32); the matrix is stored at "
+                               f"{info['y_bytes_per_elem']} B per count, so frac > 1 means fewer bytes moved than the canonical "
+                               "stream, not more than the memory system delivers (stored_GBps is the physical rate)"}
         out = {
             "metric": "ELBO iterations/sec", "value": args.steps / dt, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -257,6 +275,7 @@ def main():
                                   "Y-stream kernel on a side stream (standalone 110 us; DESIGN.md sections 5 and 8)")
                          if dominant == "fwd" else ""},
             "kernel_ms_per_iter_warmup": {k: v[0] / max(args.warmup, 1) for k, v in kt.items()},
+            "roofline_ystream": ystream,
             "final_elbo": last,
             "fit_wallclock": {"seconds": fit_s, "iterations": int(len(trace) - 1), "max_iter": 200, "rel_tol": 1e-6,
                               "final_elbo_mean": float(np.mean(finals)),
