@@ -1290,20 +1290,12 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     h->fwd_mfma = (D == 1 || D == 2) && !(getenv("CA_FWD_MFMA") && atoi(getenv("CA_FWD_MFMA")) == 0);
     h->fwd_cell = h->fwd_mfma && h->tail_fuse && !(getenv("CA_FWD_CELL") && atoi(getenv("CA_FWD_CELL")) == 0);
     {
-      // cells per block of k_fwd_cell: 16 * TL.  All blocks do the same work, so a grid just past the resident capacity
-      // runs a nearly empty second round (100k cells at TL = 4: 1563 blocks on 1536 slots); take the smallest tile that
-      // fits one round, else the largest (many rounds); 32-cell blocks below ~32k cells (+1-5 %).
-      h->fc_tl = 8;
-      const int tls[4] = {4, 5, 6, 8};
-      const void* fns[2][4] = {{(const void*)k_fwd_cell<1, 4>, (const void*)k_fwd_cell<1, 5>, (const void*)k_fwd_cell<1, 6>, (const void*)k_fwd_cell<1, 8>},
-                               {(const void*)k_fwd_cell<2, 4>, (const void*)k_fwd_cell<2, 5>, (const void*)k_fwd_cell<2, 6>, (const void*)k_fwd_cell<2, 8>}};
-      for (int i = 0; i < 4 && h->fwd_cell; ++i) {
-        int per_cu = 4;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fns[D == 2 ? 1 : 0][i], CA_TB, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-        (void)hipGetLastError();
-        // (about four blocks per CU measured best: 100k cells run 1.2 % faster at 96 cells per block than at 80)
-        const int64_t cap = std::min<int64_t>((int64_t)per_cu * h->n_cu, (int64_t)(4.2 * h->n_cu));
-        if (cdiv(Nn, 16 * tls[i]) <= cap) { h->fc_tl = tls[i]; break; }
+      // cells per block of k_fwd_cell: 16 * TL, chosen for about four blocks per CU -- measured, not derived: at 100k cells
+      // 96 cells per block (1042 blocks) beats 80 (1250) by 1.2 % and 64 (1563) by 5 %, although the occupancy API
+      // reports only three resident blocks per CU for it.
+      {
+        const int want = (int)std::ceil((double)Nn / (16.0 * 4.2 * h->n_cu));
+        h->fc_tl = want <= 4 ? 4 : want <= 5 ? 5 : 6;   // 128 cells per block never won (200k: 1346 vs 1363, 400k: 609 vs 638 it/s)
       }
       if (h->fwd_cell && cdiv(Nn, 64) < 2 * h->n_cu) h->fc_tl = 2;   // small shards: 64-cell blocks leave CUs with one block or none
       if (const char* e = getenv("CA_FC_TL")) { const int t = atoi(e); if (t == 2 || t == 4 || t == 5 || t == 6 || t == 8) h->fc_tl = t; }
@@ -1336,8 +1328,8 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   }
   if (getenv("CA_VERBOSE"))
     fprintf(stderr, "[clonealign_hip] N=%lld G=%d C=%d D=%d n_cu=%d gsplit=%d gchunk=%d csplit=%d fused=%d fwd_mfma=%d fsplit=%d fkchunk=%d "
-            "bwd_mfma=%d csplit_m=%d cchunk_m=%lld nwt=%d\n", (long long)Nn, G, C, D, h->n_cu, h->gsplit, h->gchunk, h->csplit,
-            (int)h->fused_ok, (int)h->fwd_mfma, h->fsplit, h->fkchunk, (int)h->bwd_mfma, h->csplit_m, (long long)h->cchunk_m, h->nwt);
+            "bwd_mfma=%d csplit_m=%d cchunk_m=%lld nwt=%d fwd_cell=%d fc_tl=%d\n", (long long)Nn, G, C, D, h->n_cu, h->gsplit, h->gchunk, h->csplit,
+            (int)h->fused_ok, (int)h->fwd_mfma, h->fsplit, h->fkchunk, (int)h->bwd_mfma, h->csplit_m, (long long)h->cchunk_m, h->nwt, (int)h->fwd_cell, h->fc_tl);
   CACK(dalloc(h, &h->vmm, 2 * std::max(D, 1)));
   CACK(dalloc(h, &h->vmm_part, (int64_t)h->ngblk * 2 * std::max(D, 1)));
   CACK(dalloc(h, &h->etamax2, h->N16));
