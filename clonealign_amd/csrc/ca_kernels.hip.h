@@ -384,7 +384,10 @@ __global__ void __launch_bounds__(CA_TB) k_ypass(const YT* __restrict__ Y, const
           const int tot = __builtin_amdgcn_readlane(__builtin_bit_cast(int, ca_wave_sum_lane63(p0 + p1)), 63);
           {   // keep[k] lane (i & 63) <- tot  (v_writelane_b32: value and lane select are both scalars, the select goes through m0)
             const int slot = i & 63;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // m0 is "reserved" to the allocator; this kernel has no other m0 user (no LDS-direct loads, no sendmsg)
             asm volatile("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(keep[k]) : "s"(tot), "s"(slot) : "m0");
+#pragma clang diagnostic pop
           }
         }
         if ((i & 63) == 63 || i == nrows - 1) {   // wave-uniform flush of the last (up to 64) row totals
