@@ -538,8 +538,8 @@ __device__ __forceinline__ void ca_gene_pre_fused_body(const float* __restrict__
                                                           const float* __restrict__ V, int D, int K, const double* __restrict__ YtX,
                                                           float* __restrict__ muA, float* __restrict__ muB, float* __restrict__ Mb,
                                                           double* __restrict__ gene_partA, double* __restrict__ gene_partB, int G,
-                                                          int mrow, int C, unsigned short* __restrict__ Mq, double* sm) {
-  const int g = blockIdx.x * CA_TB + threadIdx.x;
+                                                          int mrow, int C, unsigned short* __restrict__ Mq, double* sm, int blk) {
+  const int g = blk * CA_TB + threadIdx.x;
   const bool ok = g < G;
   double t[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
   if (ok) {
@@ -572,7 +572,7 @@ __device__ __forceinline__ void ca_gene_pre_fused_body(const float* __restrict__
   }
   const int W_ = 3 + K;
   for (int w = 0; w < 2; ++w) {
-    double* gp = (w ? gene_partB : gene_partA) + (int64_t)blockIdx.x * W_;
+    double* gp = (w ? gene_partB : gene_partA) + (int64_t)blk * W_;
     for (int i = 0; i < 3; ++i) {
       const double r = ca_block_sum(t[w][i], sm);
       if (threadIdx.x == 0) gp[i] = r;
@@ -582,8 +582,8 @@ __device__ __forceinline__ void ca_gene_pre_fused_body(const float* __restrict__
     const double wv = ok ? (double)V[(int64_t)g * D + k] : 0.0;
     const double wsum = ca_block_sum(wv * wv, sm);
     if (threadIdx.x == 0) {
-      gene_partA[(int64_t)blockIdx.x * W_ + 3 + k] = wsum;
-      gene_partB[(int64_t)blockIdx.x * W_ + 3 + k] = wsum;
+      gene_partA[(int64_t)blk * W_ + 3 + k] = wsum;
+      gene_partB[(int64_t)blk * W_ + 3 + k] = wsum;
     }
   }
 }
@@ -596,8 +596,23 @@ __global__ void __launch_bounds__(CA_TB) k_gene_pre_fused(const float* __restric
                                                           double* __restrict__ gene_partA, double* __restrict__ gene_partB, int G,
                                                           int mrow, int C, unsigned short* __restrict__ Mq) {
   __shared__ double sm[CA_TB];
-  ca_gene_pre_fused_body(loc, ls, epsA, epsB, colsum, Lb, V, D, K, YtX, muA, muB, Mb, gene_partA, gene_partB, G, mrow, C, Mq, sm);
+  ca_gene_pre_fused_body(loc, ls, epsA, epsB, colsum, Lb, V, D, K, YtX, muA, muB, Mb, gene_partA, gene_partB, G, mrow, C, Mq, sm, blockIdx.x);
 }
+// the same per-gene prologue for the NEXT (monitor, train) eps pair, as extra blocks of the per-cell kernel of a train pass
+// (k_adam_cell): the per-gene variables are final once k_final_gene has run, so the following fused pass starts at its sweep
+struct ca_pre_args {
+  int nblk;   // 0: none
+  const float* loc; const float* ls; const float* epsA; const float* epsB; const double* colsum; const float* Lb; const float* V;
+  const double* YtX; float* muA; float* muB; float* Mb; double* gene_partA; double* gene_partB; unsigned short* Mq;
+  int G, D, K, mrow, C;
+};
+// psi's gradient and Adam step, as extra blocks of the per-gene kernel (k_final_gene): psi is all the Y stream needs, so the
+// side stream can start on the next pass's Y kernel while the main stream is still updating the q(z) logits
+struct ca_psi_args {
+  int nblk;   // 0: none
+  float* F; const float* YW; const float* dFpart; float* m_psi; float* v_psi; float* g_psi;
+  int64_t N; int D, K, ntile;
+};
 
 // Vs = V * log2(e) and per-block min/max of each column (for the per-cell exponent bound)
 __global__ void __launch_bounds__(CA_TB) k_vprep(const float* __restrict__ V, float* __restrict__ Vs,
@@ -1914,6 +1929,22 @@ __global__ void __launch_bounds__(CA_TB) k_reduce_part(const double* __restrict_
 
 // ------------------------------------------------------------------ per-gene gradients + Adam
 // d ELBO / d loc, ls (through mu = softplus(loc + exp(ls) eps)), W, beta; minimises -ELBO.
+__device__ __forceinline__ void ca_psi_adam_body(const ca_psi_args& a, int blk, int apply, float lr_t, float b1, float b2, float aeps) {
+  const int64_t n = (int64_t)blk * CA_TB + threadIdx.x;
+  if (n >= a.N) return;
+  for (int k = 0; k < a.K; ++k) {
+    double dF = 0.0;
+    for (int t = 0; t < a.ntile; ++t) dF += (double)a.dFpart[((int64_t)t * a.N + n) * a.D + k];
+    const float gp = (float)((double)a.YW[n * a.K + k] + dF - (double)a.F[n * a.D + k]);
+    a.g_psi[n * a.K + k] = gp;
+    if (apply) {
+      float th = a.F[n * a.D + k], m = a.m_psi[n * a.K + k], v = a.v_psi[n * a.K + k];
+      ca_adam(th, m, v, -gp, lr_t, b1, b2, aeps);
+      a.F[n * a.D + k] = th; a.m_psi[n * a.K + k] = m; a.v_psi[n * a.K + k] = v;
+    }
+  }
+}
+
 __device__ __forceinline__ void ca_final_gene_body(const double* __restrict__ red_g /*[G][S+D]*/, const double* __restrict__ red_y /*[G][K]*/,
                                                       const float* __restrict__ eps, const double* __restrict__ colsum,
                                                       const double* __restrict__ YtX, const float* __restrict__ vchi,
@@ -1998,9 +2029,15 @@ __global__ void __launch_bounds__(CA_TB) k_final_gene(const double* __restrict__
                                                       float* __restrict__ v_ls, float* __restrict__ m_V, float* __restrict__ v_V,
                                                       float* __restrict__ g_loc, float* __restrict__ g_ls, float* __restrict__ g_V,
                                                       float* __restrict__ Vs, float* __restrict__ vmm_part,
-                                                      int G, int S, int D, int K, int apply, float lr_t, float b1, float b2, float aeps, ca_small_args mon, int gblocks) {
-  if ((int)blockIdx.x >= gblocks) {   // the extra block: the pending monitor pass's ELBO (ca_final_small_body), beside the gene blocks
-    if (mon.enabled) ca_final_small_body(mon);
+                                                      int G, int S, int D, int K, int apply, float lr_t, float b1, float b2, float aeps, ca_small_args mon, int gblocks,
+                                                      ca_psi_args psi) {
+  if ((int)blockIdx.x >= gblocks) {
+    int b = (int)blockIdx.x - gblocks;
+    if (mon.enabled) {   // one extra block: the pending monitor pass's ELBO (ca_final_small_body), beside the gene blocks
+      if (b == 0) { ca_final_small_body(mon); return; }
+      --b;
+    }
+    if (b < psi.nblk) ca_psi_adam_body(psi, b, apply, lr_t, b1, b2, aeps);
     return;
   }
   __shared__ float smin[CA_TB], smax[CA_TB];
@@ -2011,16 +2048,22 @@ __global__ void __launch_bounds__(CA_TB) k_final_gene(const double* __restrict__
 // ------------------------------------------------------------------ ELBO assembly + the O(K + C) variables (body: ca_final_small_body above)
 __global__ void __launch_bounds__(CA_TB) k_final_small(ca_small_args a) { ca_final_small_body(a); }
 
-// ------------------------------------------------------------------ per-cell variables: psi and the q(z) logits
-__global__ void __launch_bounds__(CA_TB) k_adam_cell(float* __restrict__ F, const float* __restrict__ YW, const float* __restrict__ dFpart,
-                                                     float* __restrict__ glogit, const float* __restrict__ dgl,
-                                                     float* __restrict__ m_psi, float* __restrict__ v_psi, float* __restrict__ m_gl,
-                                                     float* __restrict__ v_gl, float* __restrict__ g_psi, int64_t N, int C, int D, int K,
-                                                     int ntile, int apply, float lr_t, float b1, float b2, float aeps,
+// ------------------------------------------------------------------ per-cell variables: the q(z) logits and the exponent bound
+// (psi's own step runs as extra blocks of k_final_gene, see ca_psi_args)
+__global__ void __launch_bounds__(CA_TB) k_adam_cell(const float* __restrict__ F, float* __restrict__ glogit, const float* __restrict__ dgl,
+                                                     float* __restrict__ m_gl, float* __restrict__ v_gl, int64_t N, int C, int D,
+                                                     int apply, float lr_t, float b1, float b2, float aeps,
                                                      const float* __restrict__ vmm_part, int ngblk, float* __restrict__ etamax2,
-                                                     ca_small_args tail, int cblocks) {
-  if ((int)blockIdx.x >= cblocks) {   // the extra block: chi / alpha gradients and Adam, the range of V' (ca_final_small_body)
-    if (tail.enabled) ca_final_small_body(tail);
+                                                     ca_small_args tail, int cblocks, ca_pre_args pre) {
+  if ((int)blockIdx.x >= cblocks) {
+    const int b = (int)blockIdx.x - cblocks;
+    if (b == 0) {   // the extra block: chi / alpha gradients and Adam, the range of V' (ca_final_small_body)
+      if (tail.enabled) ca_final_small_body(tail);
+    } else if (b - 1 < pre.nblk) {   // the next eps pair's per-gene prologue (ca_pre_args)
+      __shared__ double smp[CA_TB];
+      ca_gene_pre_fused_body(pre.loc, pre.ls, pre.epsA, pre.epsB, pre.colsum, pre.Lb, pre.V, pre.D, pre.K, pre.YtX, pre.muA, pre.muB, pre.Mb,
+                             pre.gene_partA, pre.gene_partB, pre.G, pre.mrow, pre.C, pre.Mq, smp, b - 1);
+    }
     return;
   }
   // range of the updated V' over the gene blocks, per block (k_vmm_final folded in: same min / max as the extra block's)
@@ -2038,17 +2081,6 @@ __global__ void __launch_bounds__(CA_TB) k_adam_cell(float* __restrict__ F, cons
   __syncthreads();
   const int64_t n = (int64_t)blockIdx.x * CA_TB + threadIdx.x;
   if (n >= N) return;
-  for (int k = 0; k < K; ++k) {
-    double dF = 0.0;
-    for (int t = 0; t < ntile; ++t) dF += (double)dFpart[((int64_t)t * N + n) * D + k];
-    const float gp = (float)((double)YW[n * K + k] + dF - (double)F[n * D + k]);
-    g_psi[n * K + k] = gp;
-    if (apply) {
-      float th = F[n * D + k], m = m_psi[n * K + k], v = v_psi[n * K + k];
-      ca_adam(th, m, v, -gp, lr_t, b1, b2, aeps);
-      F[n * D + k] = th; m_psi[n * K + k] = m; v_psi[n * K + k] = v;
-    }
-  }
   if (apply)
     for (int c = 0; c < C; ++c) {
       float th = glogit[n * C + c], m = m_gl[n * C + c], v = v_gl[n * C + c];

@@ -119,6 +119,11 @@ struct ca_engine {
   bool fused_ok = false, look_valid = false; int64_t look_slot = 0; int frow = 8;
   float *Mb2 = nullptr, *mu32B = nullptr, *Zpart2 = nullptr; double* gene_partB = nullptr;
   bool y_defer = false;
+  // per-gene prologue of the next fused pass, computed ahead by the train pass before it (ca_pre_args): the loops announce
+  // the next (monitor, train) eps slots in hint_*, train_update fills the alternate partial buffers, fused_pass swaps them in
+  int64_t hint_A = -1, hint_B = -1, pre_A = -1, pre_B = -1;
+  bool pre_valid = false, pre_ok = true;
+  double *gene_part_alt = nullptr, *gene_partB_alt = nullptr;
   bool bwd_ready = false; int64_t bwd_slot = -1;
   double* yw_part = nullptr; int n_yw = 0;   // block partials of sum_n psi_n.(YW)_n (k_yw_dot)
   ca_small_args mon_tail;          // pending ELBO assembly of a fused monitor pass: rides on the next backward sweep
@@ -371,6 +376,7 @@ int download_f(ca_engine* h, std::vector<float>& v, const float* src, int64_t n)
 int refresh_derived(ca_engine* h) {
   if (h->y_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ydone, 0)); h->y_pending = false; }
   h->y_defer = false;   // a deferred side-stream Y pass would not be ordered after this parameter change: redo it in line
+  h->pre_valid = false;
   if (h->D > 0) {
     LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_vprep, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->V, h->Vs, h->vmm_part, h->G, h->D));
     LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_vmm_final, dim3(1), dim3(64), 0, h->stream, h->vmm_part, h->vmm, h->ngblk, h->D));
@@ -694,29 +700,50 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
   // O(K + C) update, which rides on the per-cell kernel the same way.
   ca_small_args mon = no_small_args();
   if (h->mon_tail.enabled) { mon = h->mon_tail; h->mon_tail.enabled = 0; }
+  // psi's own step: extra blocks of the per-gene kernel (it needs the sweep's dF partials and YW, nothing per-gene)
+  ca_psi_args psi;
+  memset(&psi, 0, sizeof(psi));
+  if (h->K > 0) {
+    psi.nblk = N256; psi.F = h->F; psi.YW = h->YW; psi.dFpart = h->dFpart; psi.m_psi = h->m_psi; psi.v_psi = h->v_psi; psi.g_psi = h->g_psi;
+    psi.N = h->N; psi.D = h->D; psi.K = h->K; psi.ntile = h->bwd_mfma ? cdiv(h->nwt, CA_TB / 64) : h->ntile;
+  }
+  h->pre_valid = false;
   LAUNCH(h, CA_KERNEL_OTHER,
-         hipLaunchKernelGGL(k_final_gene, dim3(h->ngblk + (mon.enabled ? 1 : 0)), dim3(CA_TB), 0, h->stream, h->red + h->off_g,
+         hipLaunchKernelGGL(k_final_gene, dim3(h->ngblk + (mon.enabled ? 1 : 0) + psi.nblk), dim3(CA_TB), 0, h->stream, h->red + h->off_g,
                             h->red + h->off_y, eps, h->colsum, h->YtX, h->vchi, h->loc, h->ls, h->V, h->m_loc, h->v_loc, h->m_ls,
                             h->v_ls, h->m_V, h->v_V, h->g_loc, h->g_ls, h->g_V, h->Vs, h->vmm_part, h->G, h->S, h->D, h->K, apply,
-                            lr_t, (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, mon, h->ngblk));
+                            lr_t, (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, mon, h->ngblk, psi));
+  if (apply && h->async_y && h->K > 0) {
+    // psi is final: the Y pass for the new parameters goes to the side stream from HERE (its launches are issued by the
+    // next pass, so the main stream is not left waiting for the host to get through them), and the per-cell kernel below
+    // (q(z) logits, exponent bound, the O(K + C) update and the next pass's per-gene prologue: 12-16 us) is its head
+    // start over the next forward sweep.  The Y stream needs one: letting the sweep and the Y kernel start together
+    // cost 18 % (2219 -> 1825 it/s; the sweep's blocks take the CUs first).
+    HIPCK(h, hipEventRecord(h->ev_params, h->stream));
+    h->y_defer = true;
+  }
+  // the next fused pass's per-gene prologue, when the loop has announced its eps slots: extra blocks of the per-cell kernel
+  ca_pre_args pre;
+  memset(&pre, 0, sizeof(pre));
+  if (apply && h->pre_ok && h->hint_A >= 0 && h->hint_B >= 0 && h->fused_ok && h->gene_part_alt) {
+    pre.nblk = h->ngblk;
+    pre.loc = h->loc; pre.ls = h->ls; pre.epsA = h->eps_dev + h->hint_A * (int64_t)h->G; pre.epsB = h->eps_dev + h->hint_B * (int64_t)h->G;
+    pre.colsum = h->colsum; pre.Lb = h->Lb; pre.V = h->V; pre.YtX = h->YtX; pre.muA = h->mu32; pre.muB = h->mu32B; pre.Mb = h->Mb2;
+    pre.gene_partA = h->gene_part_alt; pre.gene_partB = h->gene_partB_alt; pre.Mq = h->fwd_mfma ? h->Mq : nullptr;
+    pre.G = h->G; pre.D = h->D; pre.K = h->K; pre.mrow = h->frow; pre.C = h->C;
+  }
   LAUNCH(h, CA_KERNEL_OTHER,
-         hipLaunchKernelGGL(k_adam_cell, dim3(N256 + 1), dim3(CA_TB), 0, h->stream, h->F, h->YW, h->dFpart, h->glogit, h->dgl, h->m_psi,
-                            h->v_psi, h->m_gl, h->v_gl, h->g_psi, h->N, h->C, h->D, h->K, h->bwd_mfma ? cdiv(h->nwt, CA_TB / 64) : h->ntile, apply, lr_t,
-                            (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, h->vmm_part, h->ngblk, h->etamax2,
-                            small_args(h, h->gene_part, apply ? 1 : 0, lr_t, elbo_dst, false), N256));
+         hipLaunchKernelGGL(k_adam_cell, dim3(N256 + 1 + pre.nblk), dim3(CA_TB), 0, h->stream, h->F, h->glogit, h->dgl, h->m_gl, h->v_gl,
+                            h->N, h->C, h->D, apply, lr_t, (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps,
+                            h->vmm_part, h->ngblk, h->etamax2, small_args(h, h->gene_part, apply ? 1 : 0, lr_t, elbo_dst, false),
+                            N256, pre));
+  if (pre.nblk) { h->pre_valid = true; h->pre_A = h->hint_A; h->pre_B = h->hint_B; }
+  h->hint_A = h->hint_B = -1;
   if (apply) {
     h->b1p *= (float)h->opt.beta1;
     h->b2p *= (float)h->opt.beta2;
     h->ycache_valid = false;   // V', its range and etamax2 were refreshed inside the step's own kernels
     h->look_valid = false;
-    if (h->async_y && h->K > 0) {
-      // the Y pass for the new parameters goes to the side stream; its launches are issued by the next pass AFTER that
-      // pass's per-gene kernel, so the main stream is not left waiting for the host to get through them.  That per-gene
-      // kernel (14 us on the main stream) is also the Y stream's head start: folding it into the train tail so that the
-      // forward sweep and the Y stream start together cost 18 % (2219 -> 1825 it/s; the sweep's blocks take the CUs first)
-      HIPCK(h, hipEventRecord(h->ev_params, h->stream));
-      h->y_defer = true;
-    }
   }
   return CA_OK;
 }
@@ -733,6 +760,8 @@ int train_tail(ca_engine* h, const float* eps, const float* mu32, int apply, dou
 int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_dst) {
   const float* eps = h->eps_dev + eps_slot * (int64_t)h->S * h->G;
   CACK(flush_mon_tail(h));
+  if (mode != CA_MODE_TRAIN) h->hint_A = h->hint_B = -1;
+  h->pre_valid = false;   // this pass rewrites mu32 and the current per-gene partials
   LAUNCH(h, CA_KERNEL_OTHER,
          hipLaunchKernelGGL(k_gene_pre, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->loc, h->ls, eps, h->colsum, h->Lb, h->V,
                             h->D, h->K, h->YtX, h->mu32, h->Mb, h->gene_part, h->G, h->S, h->nchunk, CA_CW, 0, CA_CW));
@@ -789,10 +818,16 @@ int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_d
 int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst) {
   const float* epsA = h->eps_dev + slotA * (int64_t)h->G;
   const float* epsB = h->eps_dev + slotB * (int64_t)h->G;
-  LAUNCH(h, CA_KERNEL_OTHER,
-         hipLaunchKernelGGL(k_gene_pre_fused, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->loc, h->ls, epsA, epsB, h->colsum, h->Lb,
-                            h->V, h->D, h->K, h->YtX, h->mu32, h->mu32B, h->Mb2, h->gene_part, h->gene_partB, h->G, h->frow, h->C,
-                            h->fwd_mfma ? h->Mq : nullptr));
+  if (h->pre_valid && h->pre_A == slotA && h->pre_B == slotB) {   // the train pass before this one already ran the prologue
+    std::swap(h->gene_part, h->gene_part_alt);
+    std::swap(h->gene_partB, h->gene_partB_alt);
+  } else {
+    LAUNCH(h, CA_KERNEL_OTHER,
+           hipLaunchKernelGGL(k_gene_pre_fused, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->loc, h->ls, epsA, epsB, h->colsum, h->Lb,
+                              h->V, h->D, h->K, h->YtX, h->mu32, h->mu32B, h->Mb2, h->gene_part, h->gene_partB, h->G, h->frow, h->C,
+                              h->fwd_mfma ? h->Mq : nullptr));
+  }
+  h->pre_valid = false;
   CACK(ensure_ycache(h));
   ca_cell_ptrs cp;
   cp.A = h->A; cp.cn = h->cn; cp.s64 = h->s64; cp.etamax2 = h->etamax2; cp.glogit = h->glogit; cp.F = h->F;
@@ -1146,6 +1181,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   if (hipHostGetDevicePointer((void**)&h->host_dev, h->host_pinned, 0) != hipSuccess) { h->host_dev = nullptr; (void)hipGetLastError(); }
   h->mon_tail = no_small_args();
   if (const char* e = getenv("CA_TAIL_FUSE")) h->tail_fuse = atoi(e) != 0;
+  if (const char* e = getenv("CA_PRE")) h->pre_ok = atoi(e) != 0;
   CACK(upload_y(h, p));
   const int G = h->G, C = h->C, K = h->K, P = h->P, S = h->S, D = h->D;
   const int64_t Nn = h->N;
@@ -1324,6 +1360,8 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     }
     CACK(dalloc(h, &h->mu32B, G));
     CACK(dalloc(h, &h->gene_partB, (int64_t)h->ngblk * (3 + K)));
+    CACK(dalloc(h, &h->gene_part_alt, (int64_t)h->ngblk * (3 + K)));
+    CACK(dalloc(h, &h->gene_partB_alt, (int64_t)h->ngblk * (3 + K)));
     if (!h->fwd_cell) CACK(dalloc(h, &h->Zpart2, (int64_t)zsplit * Nn * h->frow));   // k_fwd_cell keeps Z in the block
   }
   if (getenv("CA_VERBOSE"))
@@ -1678,6 +1716,7 @@ int ca_run(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_strea
   double diffs[10];
   for (double& d : diffs) d = 1e3;                                      // :379
   for (int i = 1; i <= max_iter; ++i) {
+    h->hint_A = 2 * (int64_t)i + 1; h->hint_B = i < max_iter ? 2 * (int64_t)i + 2 : -1;
     CACK(train_pass(h, 2 * (int64_t)i));                                // :401
     h->host_seq_next = ++h->host_seq;
     CACK(monitor_pass(h, 2 * (int64_t)i + 1, i < max_iter ? 2 * (int64_t)i + 2 : -1, h->elbo_dev + i));   // :403
@@ -1706,6 +1745,7 @@ int ca_iterate(ca_handle h, int32_t n_iter, const float* eps_stream, int64_t n_d
   CACK(ensure_elbo_cap(h, std::max(1, n_iter)));
   const auto t_host0 = std::chrono::steady_clock::now();
   for (int i = 0; i < n_iter; ++i) {
+    h->hint_A = 2 * (int64_t)i + 1; h->hint_B = i + 1 < n_iter ? 2 * (int64_t)i + 2 : -1;
     CACK(train_pass(h, 2 * (int64_t)i));
     CACK(monitor_pass(h, 2 * (int64_t)i + 1, i + 1 < n_iter ? 2 * (int64_t)i + 2 : -1, h->elbo_dev + i));
   }
