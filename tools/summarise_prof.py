@@ -1,0 +1,52 @@
+"""Summarise one tools/prof_round.sh output directory into the files kept under profiles/.
+
+  python tools/summarise_prof.py gpurun_out/prof_v9 r01_v9
+
+writes profiles/<tag>_kernel_stats.csv (rocprofv3 --stats), <tag>_bench.json (the default bench line),
+<tag>_sq_counters.json (per-launch means of the SQ counters) and <tag>_pmc_hbm.json (HBM bytes per launch:
+FETCH_SIZE / WRITE_SIZE are in 64-byte units... see MI355X_MICROARCH.md: KiB units, FETCH_SIZE doubled on gfx950).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+src, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(root, "profiles")
+shutil.copy(glob.glob(os.path.join(src, "stats", "*kernel_stats.csv"))[0], os.path.join(out, f"{tag}_kernel_stats.csv"))
+line = [l for l in open(os.path.join(src, "bench_default.json")) if l.startswith("{")][-1]
+json.dump(json.loads(line), open(os.path.join(out, f"{tag}_bench.json"), "w"), indent=1)
+
+
+def per_kernel(path):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(path)):
+        name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+sq = per_kernel(glob.glob(os.path.join(src, "pmc_sq", "*counter_collection.csv"))[0])
+keep = {k: {c: sum(v) / len(v) for c, v in cs.items()} | {"launches": len(next(iter(cs.values())))}
+        for k, cs in sq.items() if k.startswith("k_")}
+json.dump({"_doc": f"SQ counters per launch (mean over the sampled launches), one rocprofv3 --pmc pass of `bench.py --steps 6 --warmup 2 "
+                   f"--no-cpu-baseline`, MI355X, 100k x 5k x 8, build {tag}. Quad-cycle units summed over waves (MI355X_MICROARCH.md).",
+           "kernels": keep}, open(os.path.join(out, f"{tag}_sq_counters.json"), "w"), indent=1)
+
+hbm = {}
+for which, sub, scale in (("fetch", "pmc_fetch", 2.0), ("write", "pmc_write", 1.0)):
+    for k, cs in per_kernel(glob.glob(os.path.join(src, sub, "*counter_collection.csv"))[0]).items():
+        if not k.startswith("k_"):
+            continue
+        for c, v in cs.items():
+            hbm.setdefault(k, {})[which + "_bytes"] = scale * 1024.0 * sum(v) / len(v)   # KiB units; FETCH_SIZE doubled on gfx950
+for k, d in hbm.items():
+    d["hbm_bytes"] = d.get("fetch_bytes", 0.0) + d.get("write_bytes", 0.0)
+json.dump({"_doc": f"HBM bytes per launch from separate FETCH_SIZE / WRITE_SIZE passes (KiB counters; FETCH_SIZE x2 on gfx950 as "
+                   f"MI355X_MICROARCH.md prescribes), build {tag}, same command as the SQ pass.", "kernels": hbm},
+          open(os.path.join(out, f"{tag}_pmc_hbm.json"), "w"), indent=1)
+print("wrote", sorted(f for f in os.listdir(out) if f.startswith(tag)))
