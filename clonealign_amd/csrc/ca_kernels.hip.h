@@ -289,6 +289,77 @@ __global__ void __launch_bounds__(CA_TB) k_prep_cells(const YT* __restrict__ Y, 
   }
 }
 
+// The same constants for 1-byte storage, the usual case: one WAVE per cell (16-byte loads, wave sums by shuffles, no
+// barriers in the cell loop), lgamma(y + 1) from a 256-entry table built once per block, log L gathered from L2 only for
+// the non-zero counts, grid-stride over cells.  13.0 -> 3.3 ms at 100k x 5k x 8 (the old form was a tenth of a 200-iteration fit).
+__global__ void __launch_bounds__(CA_TB) k_prep_cells_u8(const uint8_t* __restrict__ Y, const double* __restrict__ logL /*[G][C]*/,
+                                                         const double* __restrict__ extra /*[N][C] or null*/, double* __restrict__ A,
+                                                         double* __restrict__ cn, double* __restrict__ s64, float* __restrict__ s32,
+                                                         int64_t N, int G, int Gp, int C, const int64_t* __restrict__ orowptr,
+                                                         const int* __restrict__ ocol, const float* __restrict__ oval) {
+  __shared__ double lgt[CA_TB];   // CA_TB == 256: lgt[y] = lgamma(y + 1)
+  lgt[threadIdx.x] = lgamma((double)threadIdx.x + 1.0);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  auto wsum = [](double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+  };
+  for (int64_t n = (int64_t)blockIdx.x * (CA_TB / 64) + wv; n < N; n += (int64_t)gridDim.x * (CA_TB / 64)) {
+    const uint8_t* row = Y + n * (int64_t)Gp;
+    const int64_t oe0 = orowptr ? orowptr[n] : 0, oe1 = orowptr ? orowptr[n + 1] : 0;
+    for (int c0 = 0; c0 < C; c0 += 8) {   // eight clone columns per sweep of the row (one sweep when C <= 8)
+      const int nc = C - c0 < 8 ? C - c0 : 8;
+      double a[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+      double ssum = 0.0, lg = 0.0;
+      for (int g0 = lane * 16; g0 < G; g0 += 64 * 16) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(row + g0);   // rows are padded to whole 1 KiB strips (zeros)
+        const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const unsigned y = (w[j >> 2] >> (8 * (j & 3))) & 255u;
+          const int g = g0 + j;
+          if (y != 0u && g < G) {   // xlogy: 0 * log(0) := 0; y > 0 with L = 0 gives -inf like the reference
+            const double yd = (double)y;
+            ssum += yd;
+            lg += lgt[y];
+            const double* lp = logL + (int64_t)g * C + c0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+              if (c < nc) a[c] += yd * lp[c];
+          }
+        }
+      }
+      // entries stored as 255 + overflow: add the excess and swap lgamma(256) for lgamma(256 + excess)
+      for (int64_t e = oe0 + lane; e < oe1; e += 64) {
+        const double x = (double)oval[e];
+        ssum += x;
+        lg += lgamma(256.0 + x) - lgt[255];
+        const double* lp = logL + (int64_t)ocol[e] * C + c0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (c < nc) a[c] += x * lp[c];
+      }
+      if (c0 == 0) {
+        const double st = wsum(ssum), lt = wsum(lg);
+        if (lane == 0) {
+          s64[n] = st;
+          s32[n] = (float)st;
+          cn[n] = lgamma(st + 1.0) - lt;
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        if (c < nc) {
+          const double at = wsum(a[c]);
+          if (lane == 0) A[n * C + c0 + c] = at + (extra ? extra[n * C + c0 + c] : 0.0);
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------ Y stream: YW = Y.W and YtPsi = Y^T.psi
 // The only kernel that reads the count matrix inside the iteration loop (HBM-bound).  One wave
 // owns a strip of TR cells x (64*VEC) genes: 16-byte coalesced loads, per-lane column partials

@@ -1163,6 +1163,18 @@ void launch_prep(ca_engine* h, const double* logL, const double* extra) {
                      h->s64, h->s32, h->N, h->G, h->Gp, h->C, h->ovf_rowptr, h->ovf_col, h->ovf_val);
 }
 
+template <>
+void launch_prep<uint8_t>(ca_engine* h, const double* logL, const double* extra) {
+  if (getenv("CA_PREP_OLD")) {
+    hipLaunchKernelGGL((k_prep_cells<uint8_t>), dim3((unsigned)h->N), dim3(CA_TB), 0, h->stream, (const uint8_t*)h->Y, logL, extra, h->A,
+                       h->cn, h->s64, h->s32, h->N, h->G, h->Gp, h->C, h->ovf_rowptr, h->ovf_col, h->ovf_val);
+    return;
+  }
+  const int grid = (int)std::min<int64_t>(cdiv(h->N, CA_TB / 64), (int64_t)h->n_cu * 8);
+  hipLaunchKernelGGL(k_prep_cells_u8, dim3(grid), dim3(CA_TB), 0, h->stream, (const uint8_t*)h->Y, logL, extra, h->A, h->cn, h->s64,
+                     h->s32, h->N, h->G, h->Gp, h->C, h->ovf_rowptr, h->ovf_col, h->ovf_val);
+}
+
 int create_impl(ca_engine* h, const ca_problem* p) {
   const int N = (int)h->N; (void)N;
   HIPCK(h, hipSetDevice(h->device));
