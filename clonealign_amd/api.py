@@ -101,6 +101,12 @@ def correlations_from_sums(T, Syy, L, clone_counts):
     return out
 
 
+def _counts_array(a):
+    """The count matrix in its own dtype when the engine can upload it as it is (no float64 copy of N x G), else float64."""
+    a = np.asarray(a)
+    return a if a.dtype in (np.float64, np.float32, np.int32, np.uint16, np.uint8) else a.astype(np.float64)
+
+
 def _parse_expression(gene_expression_data):
     """R/clonealign.R:207-222.  Returns (Y[cells,genes], gene_names or None)."""
     g = gene_expression_data
@@ -115,11 +121,11 @@ def _parse_expression(gene_expression_data):
             names = [str(i) for i in counts.index]
         elif isinstance(g, dict) and "rownames" in g:
             names = list(g["rownames"])
-        return np.asarray(counts, dtype=np.float64).T, names
+        return _counts_array(counts).T, names
     if hasattr(g, "columns") and hasattr(g, "values"):               # pandas DataFrame cells x genes
-        return np.asarray(g.values, dtype=np.float64), [str(c) for c in g.columns]
+        return _counts_array(g.values), [str(c) for c in g.columns]
     if isinstance(g, np.ndarray) and g.ndim == 2:
-        return np.asarray(g, dtype=np.float64), None
+        return _counts_array(g), None
     raise TypeError("Input gene_expression_data must be SingleCellExperiment, SummarizedExperiment, or matrix")
 
 

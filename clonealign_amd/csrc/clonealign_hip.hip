@@ -1325,7 +1325,8 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     }
     CACK(upload_f(h, h->F, Fh));
     std::vector<float> l0((size_t)G);
-    for (int g = 0; g < G; ++g) l0[g] = (float)p->loc0[g];
+    if (p->loc0)   // else: filled below from the data (device form of mu_guess, R/inference-tflow.R:220-235)
+      for (int g = 0; g < G; ++g) l0[g] = (float)p->loc0[g];
     CACK(upload_f(h, h->loc, l0));
   }
   // ---- pass buffers
@@ -1408,6 +1409,16 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   {
     // colsum: run ypass with K' = 1, psi == 1, W == 0 on temporary factor buffers
     const int cols = 1 + ((K > 0) ? P : 0);
+    // loc0 == NULL: one more column with factor 1 / rowMeans(Y) gives mu_guess_g = mean_n(y_ng / mean_g' y_ng') (:220-235,
+    // data_init_mu = TRUE), and loc0 = safe_inverse_softplus(mu_guess) (:262, :6-11).  The weights go through float32 and
+    // the strip sums are fp32 (1e-7 relative on an initial value).
+    const int cols_all = cols + (p->loc0 ? 0 : 1);
+    std::vector<double> srow;
+    if (!p->loc0) {
+      srow.resize((size_t)Nn);
+      HIPCK(h, hipMemcpyAsync(srow.data(), h->s64, (size_t)Nn * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      HIPCK(h, hipStreamSynchronize(h->stream));
+    }
     std::vector<double> cs((size_t)G, 0.0), ytx((size_t)G * std::max(P, 1), 0.0);
     float *Ft = nullptr, *Vt = nullptr, *YWp = nullptr, *YTp = nullptr; double* yt = nullptr;
     HIPCK(h, hipMalloc((void**)&Ft, (size_t)Nn * sizeof(float)));
@@ -1417,8 +1428,9 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     HIPCK(h, hipMalloc((void**)&yt, (size_t)h->Gp * sizeof(double)));
     HIPCK(h, hipMemsetAsync(Vt, 0, (size_t)G * sizeof(float), h->stream));
     std::vector<float> col((size_t)Nn);
-    for (int j = 0; j < cols; ++j) {
-      for (int64_t n = 0; n < Nn; ++n) col[n] = j == 0 ? 1.f : (float)p->X[hidx(p->layout, n, j - 1, Nn, P)];
+    for (int j = 0; j < cols_all; ++j) {
+      if (j >= cols) for (int64_t n = 0; n < Nn; ++n) col[n] = (float)((double)G / srow[(size_t)n]);
+      else for (int64_t n = 0; n < Nn; ++n) col[n] = j == 0 ? 1.f : (float)p->X[hidx(p->layout, n, j - 1, Nn, P)];
       HIPCK(h, hipMemcpyAsync(Ft, col.data(), (size_t)Nn * sizeof(float), hipMemcpyHostToDevice, h->stream));
       dim3 grid((unsigned)((int64_t)h->nrg * h->nseg));
       ca_ovf_args no_ovf;
@@ -1436,7 +1448,14 @@ int create_impl(ca_engine* h, const ca_problem* p) {
       HIPCK(h, hipStreamSynchronize(h->stream));
       for (int64_t e = 0; e < h->n_ovf; ++e)   // overflow list, fixed (cell, gene) order
         tmp[h->h_ocol[e]] += (double)h->h_oval[e] * (double)col[h->h_orow[e]];
-      if (j == 0) cs = tmp;
+      if (j >= cols) {
+        std::vector<float> l0((size_t)G);
+        for (int g = 0; g < G; ++g) {
+          const double mu = tmp[g] / (double)Nn;
+          l0[g] = (float)(std::log(1.0 - std::exp(-std::fabs(mu))) + std::max(mu, 0.0));
+        }
+        CACK(upload_f(h, h->loc, l0));
+      } else if (j == 0) cs = tmp;
       else for (int g = 0; g < G; ++g) ytx[(size_t)g * P + (j - 1)] = tmp[g];
     }
     hipFree(Ft); hipFree(Vt); hipFree(YWp); hipFree(YTp); hipFree(yt);
@@ -1577,7 +1596,8 @@ int ca_create(const ca_problem* p, const ca_options* o, ca_handle* out) {
   if (p->K < 0 || p->P < 0 || p->S < 1) return bad("K >= 0, P >= 0, S >= 1 required");
   const int D = p->K > 0 ? p->K + p->P : 0;
   if (D > 8) return bad("K + P > 8 not supported");
-  if (!p->Y || !p->L || !p->loc0) return bad("Y, L and loc0 are required");
+  if (!p->Y || !p->L) return bad("Y and L are required");
+  if (!p->loc0 && opt.world > 1) return bad("loc0 = NULL (data-driven initialisation on the device) needs all cells: pass loc0 when world > 1");
   if (p->K > 0 && !p->psi0) return bad("psi0 is required when K > 0");
   if (p->P > 0 && !p->X) return bad("X is required when P > 0");
   if (opt.world < 1 || opt.rank < 0 || opt.rank >= opt.world) return bad("bad rank/world");

@@ -136,6 +136,7 @@ class HipEngine:
     """One fit on one MI355X: same constructor/method protocol as the oracle models."""
 
     VAR_NAMES = ("W", "v", "psi", "beta", "alpha_unconstr", "loc", "ls", "gamma_logits")
+    DEVICE_MU_INIT = True   # loc0=None: mu_guess / loc0 of R/inference-tflow.R:220-235,262 from the resident matrix
 
     def __init__(self, Y, L, psi0, loc0, K, S=1, X=None, extra_loglik=None, learning_rate=0.1,
                  device=0, y_storage="auto", seed=0x5EED5EED, rank=0, world=1, profile=False,
@@ -159,12 +160,12 @@ class HipEngine:
         L = np.ascontiguousarray(np.asarray(L, dtype=np.float64))
         self.N, self.G, self.C = int(N), int(G), int(L.shape[1])
         self.K, self.S = int(K), int(S)
-        loc0 = np.ascontiguousarray(np.asarray(loc0, dtype=np.float64))
+        loc0 = None if loc0 is None else np.ascontiguousarray(np.asarray(loc0, dtype=np.float64))
         psi0 = np.ascontiguousarray(np.asarray(psi0, dtype=np.float64).reshape(self.N, self.K))
         Xc = None if X is None else np.ascontiguousarray(np.asarray(X, dtype=np.float64).reshape(self.N, -1))
         self.P = 0 if Xc is None else Xc.shape[1]
         ex = None if extra_loglik is None else np.ascontiguousarray(np.asarray(extra_loglik, dtype=np.float64))
-        if L.shape[0] != self.G or loc0.shape[0] != self.G:
+        if L.shape[0] != self.G or (loc0 is not None and loc0.shape[0] != self.G):
             raise ValueError("L / loc0 do not match the number of genes")
         self._keep += [L, loc0, psi0, Xc, ex]
         ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731

@@ -36,9 +36,11 @@ def gene_filter(Y, L, gene_filter_threshold=0):
     """R/inference-tflow.R:117-124: drop genes with ``colSums(Y) <= threshold``.
 
     Returns (Y_kept, L_kept, keep_mask)."""
-    zero_gene_means = Y.sum(0) <= gene_filter_threshold
+    zero_gene_means = Y.sum(0, dtype=np.float64) <= gene_filter_threshold
     keep = ~zero_gene_means
-    return Y[:, keep], L[keep, :], keep
+    if keep.all():              # nothing to drop: no copy of the count matrix
+        return Y, L, keep
+    return np.ascontiguousarray(Y[:, keep]), L[keep, :], keep
 
 
 def r_scale(x):
@@ -90,13 +92,24 @@ def _top_eigvecs(Xs, K, iters=60, seed=0):
     return (Q @ Wt.T)[:, :K]
 
 
-def mu_guess(Y, data_init_mu=True):
-    """R/inference-tflow.R:220-235."""
+def mu_guess(Y, data_init_mu=True, row_sums=None):
+    """R/inference-tflow.R:220-235.  ``row_sums`` (rowSums(Y), float64) saves one pass over a large matrix."""
     G = Y.shape[1]
     if isinstance(data_init_mu, (bool, np.bool_)):
         if data_init_mu:
-            Yd = np.asarray(Y, dtype=np.float64)
-            return (Yd / Yd.mean(1, keepdims=True)).mean(0)
+            if Y.size <= 4_000_000:
+                Yd = np.asarray(Y, dtype=np.float64)
+                return (Yd / Yd.mean(1, keepdims=True)).mean(0)
+            # same quantity, mean_n(y_ng / mean_g' y_ng'), as row-block products in the matrix's own dtype: no N x G
+            # float64 temporaries (equal to the expression above up to the rounding of 1/mean, ~1e-16 relative)
+            N = Y.shape[0]
+            rs = np.asarray(row_sums, dtype=np.float64) if row_sums is not None else Y.sum(1, dtype=np.float64)
+            w = G / rs                                   # 1 / rowMeans(Y)
+            acc = np.zeros(G)
+            step = max(1, 8_000_000 // max(G, 1))
+            for i in range(0, N, step):
+                acc += w[i:i + step] @ np.asarray(Y[i:i + step], dtype=np.float64)
+            return acc / N
         return np.ones(G)
     v = np.asarray(data_init_mu, dtype=np.float64)
     if v.dtype.kind in "fiu" and v.size > 0:

@@ -100,7 +100,9 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
         raise NotImplementedError(
             "dtype='float64': the reference graph cannot be built for float64 "
             "(R/inference-tflow.R:323 divides a float64 tensor by tf$to_float(S)); only float32 is supported")
-    Y_dat = np.asarray(Y_dat, dtype=np.float64)
+    Y_dat = np.asarray(Y_dat)
+    if Y_dat.dtype not in (np.float64, np.float32, np.int32, np.uint16, np.uint8):   # dtypes the engine uploads as they are
+        Y_dat = Y_dat.astype(np.float64)
     L_dat = np.asarray(L_dat, dtype=np.float64)
     Y_dat, L_dat, keep = hostprep.gene_filter(Y_dat, L_dat, gene_filter_threshold)   # :117-124
     log(f"Removing {int((~keep).sum())} genes with low counts")
@@ -153,11 +155,15 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
         raise ValueError("psi_init must be 'auto', 'host' or 'device'")
     device_pca = K > 0 and hasattr(Engine, "pca_init") and (psi_init == "device" or (psi_init == "auto" and N * G > 4_000_000))
     pcs = np.zeros((N, K)) if device_pca else hostprep.pca_init(Y_dat, K, psi_noise)
-    s_init = Y_dat.sum(1)
+    s_init = Y_dat.sum(1, dtype=np.float64)
     if np.any(s_init == 0):
         raise ValueError("Some cells have no counts mapping")          # :212-214
-    mu_g = hostprep.mu_guess(Y_dat, data_init_mu)
-    loc0 = hostprep.safe_inverse_softplus(mu_g)                         # :262
+    if (isinstance(data_init_mu, (bool, np.bool_)) and bool(data_init_mu) and N * G > 4_000_000 and getattr(Engine, "DEVICE_MU_INIT", False)
+            and int((engine_opts or {}).get("world", 1)) == 1):
+        loc0 = None      # the engine takes mu_guess (:220-235) and loc0 (:262) from the resident matrix: no host pass
+    else:
+        mu_g = hostprep.mu_guess(Y_dat, data_init_mu, row_sums=s_init)
+        loc0 = hostprep.safe_inverse_softplus(mu_g)                     # :262
     S = int(mc_samples)
     if eps_stream is None:
         eps_seed = int(rng.integers(1, 2**31 - 1))                      # get_next_seed(), :49-51
@@ -167,7 +173,7 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
                  learning_rate=learning_rate, **(engine_opts or {}))
     try:
         if device_pca:
-            if np.any(np.asarray(Y_dat).std(0) == 0):    # prcomp(scale = TRUE) refuses constant genes
+            if np.any(Y_dat.min(0) == Y_dat.max(0)):     # prcomp(scale = TRUE) refuses constant genes (sd == 0)
                 raise ValueError("cannot rescale a constant/zero column to unit variance")
             eng.pca_init(psi_noise, seed=int(rng.integers(0, 2**31 - 1)))
         log("Optimizing ELBO")

@@ -59,7 +59,8 @@ typedef struct ca_problem {
   const void* Y;       /* N x G counts (:190,355) */
   const double* L;     /* G x C copy number (:191) */
   const double* psi0;  /* N x K  (:204-208, `pcs`)   -- may be NULL when K == 0 */
-  const double* loc0;  /* G      (:262, safe_inverse_softplus(mu_guess)) */
+  const double* loc0;  /* G      (:262, safe_inverse_softplus(mu_guess)); NULL = the data_init_mu = TRUE guess of :220-235
+                          computed from the resident matrix (single-shard problems only) */
   const double* X;     /* N x P covariates or NULL (:147-153) */
   const double* extra_loglik; /* N x C additive log-lik (allele term, :302-304) or NULL */
 } ca_problem;

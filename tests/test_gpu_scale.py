@@ -333,3 +333,52 @@ def test_preprocess_example_sce_device_equals_host():
     dev = preprocess_for_clonealign(Y, L, on="device")
     assert np.array_equal(host["retained_genes"], dev["retained_genes"])
     assert np.array_equal(host["retained_cells"], dev["retained_cells"])
+
+
+@pytest.mark.parametrize("dtype,big", [(np.float64, False), (np.int32, False), (np.int32, True)])
+def test_device_mu_init_matches_host_mu_guess(dtype, big):
+    """loc0 = NULL at the C ABI: mu_guess (R/inference-tflow.R:220-235) and loc0 = safe_inverse_softplus(mu_guess) (:262)
+    from the resident count matrix -- including counts above 255, which live in the overflow list -- vs the host formula."""
+    from clonealign_amd import hostprep
+    from clonealign_amd.engine import EngineError, HipEngine
+    rng = np.random.default_rng(12)
+    N, G, C = (3000, 700, 4) if big else (300, 130, 3)
+    Y = rng.poisson(rng.lognormal(-0.5, 1.3, G)[None, :] * rng.uniform(0.5, 2.0, N)[:, None])
+    Y[:, 0] += 1
+    Y[rng.integers(0, N, 12), rng.integers(0, G, 12)] += 400          # a few entries for the overflow list
+    Y = Y.astype(dtype)
+    L = rng.integers(1, 5, size=(G, C)).astype(np.float64)
+    want = hostprep.safe_inverse_softplus(hostprep.mu_guess(np.asarray(Y, dtype=np.float64), True))
+    eng = HipEngine(Y=Y, L=L, psi0=rng.normal(size=(N, 1)), loc0=None, K=1)
+    try:
+        assert eng.info()["y_storage_name"] == "u8"
+        got = eng.get("loc")
+        assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max()
+        e = eps_for(1, G, 2)
+        eng.gamma_init(e)
+        assert np.isfinite(eng.elbo(e))
+    finally:
+        eng.close()
+    with pytest.raises(EngineError, match="world > 1"):
+        HipEngine(Y=Y, L=L, psi0=np.zeros((N, 1)), loc0=None, K=1, rank=0, world=2, host_allreduce=lambda a: None)
+
+
+def test_inference_tflow_device_mu_init_equals_host_init():
+    """Above 4e6 elements inference_tflow leaves mu_guess to the engine; the fit equals the host-initialised one to the
+    tolerance of the parity suite."""
+    from clonealign_amd import hostprep
+    from clonealign_amd.inference import inference_tflow
+    rng = np.random.default_rng(21)
+    N, G, C = 2100, 2000, 3
+    L = rng.integers(1, 5, size=(G, C)).astype(np.float64)
+    L[L.min(1) == L.max(1), 0] += 1
+    z = rng.integers(0, C, N)
+    Y = rng.poisson(rng.lognormal(-1.0, 1.0, G)[None, :] * L[:, z].T * 0.5).astype(np.int32)
+    Y[:, Y.sum(0) == 0] = 1
+    kw = dict(max_iter=15, rel_tol=1e-9, verbose=False, seed=4, K=1)
+    a = inference_tflow(Y, L, **kw)                                               # device mu_guess (N * G > 4e6)
+    b = inference_tflow(Y, L, data_init_mu=hostprep.mu_guess(Y.astype(np.float64), True), **kw)   # host vector, v / mean(v)
+    ea, eb = a["convergence_info"]["elbo"], b["convergence_info"]["elbo"]
+    assert len(ea) == len(eb) == 16
+    assert np.abs(ea - eb).max() <= 1e-4 * np.abs(eb).max()
+    assert np.array_equal(a["ml_params"]["clone_probs"].argmax(1), b["ml_params"]["clone_probs"].argmax(1))
