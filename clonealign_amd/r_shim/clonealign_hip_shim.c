@@ -10,7 +10,7 @@
  *
  *   .Call("C_clonealign_fit", Y, L, psi0, loc0, X, extra, K, S, max_iter, rel_tol, learning_rate, eps)
  *     Y      numeric or integer matrix N x G (column-major, as R stores it)
- *     L      numeric matrix G x C;  psi0 N x K;  loc0 G;  X N x P or NULL;  extra N x C or NULL
+ *     L      numeric matrix G x C;  psi0 N x K;  loc0 G or NULL (device-side mu_guess);  X N x P or NULL;  extra N x C or NULL
  *     eps    numeric vector of (2 + 2*max_iter + 20) * S * G standard normals drawn with rnorm() by the
  *            caller (so set.seed() controls the fit exactly as it does through get_next_seed(), :49-51),
  *            or NULL for the engine's built-in Philox stream
@@ -48,7 +48,7 @@ SEXP C_clonealign_fit(SEXP Y, SEXP L, SEXP psi0, SEXP loc0, SEXP X, SEXP extra, 
   p.layout = CA_COL_MAJOR;                                   /* R matrices as they are: no transpose, no copy */
   p.y_dtype = Rf_isInteger(Y) ? CA_I32 : CA_F64;
   p.Y = Rf_isInteger(Y) ? (const void*)INTEGER(Y) : (const void*)REAL(Y);
-  p.L = REAL(L); p.psi0 = p.K > 0 ? REAL(psi0) : NULL; p.loc0 = REAL(loc0);
+  p.L = REAL(L); p.psi0 = p.K > 0 ? REAL(psi0) : NULL; p.loc0 = Rf_isNull(loc0) ? NULL : REAL(loc0);   /* NULL: data_init_mu = TRUE guess (:220-235) taken on the device */
   p.X = p.P > 0 ? REAL(X) : NULL;
   p.extra_loglik = Rf_isNull(extra) ? NULL : REAL(extra);
   ca_options o;
