@@ -74,8 +74,8 @@ def cpu_baseline(Yh, L, psi0, loc0, K, N_full, budget_s=20.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)   # the reference's default max_iter
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--cells", type=int, default=100_000)
     ap.add_argument("--genes", type=int, default=5_000)
     ap.add_argument("--clones", type=int, default=8)
