@@ -1894,18 +1894,14 @@ __global__ void __launch_bounds__(CA_TB) k_yw_dot(const float* __restrict__ YWpa
 // "block-split"), paid back by the 42 us cell epilogue launch it replaces.  Vs must be padded to a multiple of 32 genes
 // (last gene replicated, see k_final_gene / k_vprep); Mq is zero there.
 template <int D, int TL>
-__global__ void __launch_bounds__(CA_TB) k_fwd_cell(const float* __restrict__ F, const float* __restrict__ etamax2,
-                                                    const float* __restrict__ Vs /*[nk * 32][D]*/,
-                                                    const unsigned short* __restrict__ Mq /*[nk][2][64][8] bf16*/, ca_cell_ptrs p,
-                                                    const float* __restrict__ alpha_u, double* __restrict__ cell_part, int64_t N,
-                                                    int C, int K, int nk) {
+__device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, const float* __restrict__ etamax2,
+                                                 const float* __restrict__ Vs /*[nk * 32][D]*/,
+                                                 const unsigned short* __restrict__ Mq /*[nk][2][64][8] bf16*/, const ca_cell_ptrs& p,
+                                                 double* __restrict__ cell_part, int64_t N, int C, int K, int nk, int64_t cell0,
+                                                 int blk, ca_f32x4* comb /*[4][TL][64]: the four waves' partial accumulators*/,
+                                                 double* sm, const double* la) {
   constexpr int CP = 8;                    // lanes per cell in the epilogue (C <= 8)
-  __shared__ ca_f32x4 comb[4][TL][64];     // the four waves' partial accumulators; the block owns 16 * TL cells
-  __shared__ double sm[CA_TB];
-  __shared__ double la[64];
-  ca_log_softmax_alpha(alpha_u, C, la);    // wave 0; visible to all after the barrier below
   const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4, wv = threadIdx.x >> 6;
-  const int64_t cell0 = (int64_t)blockIdx.x * (TL * 16);
   float f[TL][D], em[TL];
   ca_f32x4 acc[TL];
 #pragma unroll
@@ -1967,7 +1963,7 @@ __global__ void __launch_bounds__(CA_TB) k_fwd_cell(const float* __restrict__ F,
     }
   }
 #pragma unroll
-  for (int t = 0; t < TL; ++t) comb[wv][t][lane] = acc[t];
+  for (int t = 0; t < TL; ++t) comb[(wv * TL + t) * 64 + lane] = acc[t];
   __syncthreads();
   // ---- cell epilogue for the block's cells; Z[cell][column] = sum over the four waves of comb[w][tile][16 q + column][r]
   //      with cell = 16 tile + 4 q + r (accumulator layout of the 16x16 MFMA)
@@ -1981,11 +1977,45 @@ __global__ void __launch_bounds__(CA_TB) k_fwd_cell(const float* __restrict__ F,
     const int lcc = inb ? lc : 0;
     const int t = lcc >> 4, row = lcc & 15, qq = row >> 2, r = row & 3;
     const int la_ = 16 * qq + cc, lb_ = 16 * qq + C + cc;
-    const double ZA = ((double)comb[0][t][la_][r] + (double)comb[1][t][la_][r]) + ((double)comb[2][t][la_][r] + (double)comb[3][t][la_][r]);
-    const double ZB = ((double)comb[0][t][lb_][r] + (double)comb[1][t][lb_][r]) + ((double)comb[2][t][lb_][r] + (double)comb[3][t][lb_][r]);
+    auto cz = [&](int w, int col) { return (double)comb[(w * TL + t) * 64 + col][r]; };
+    const double ZA = (cz(0, la_) + cz(1, la_)) + (cz(2, la_) + cz(3, la_));
+    const double ZB = (cz(0, lb_) + cz(1, lb_)) + (cz(2, lb_) + cz(3, lb_));
     ca_cell_fused_group<CP>(p, la, inb ? cell0 + lc : N, N, C, D, K, ZA, ZB, cacc);
   }
-  ca_cell_fused_finish<CP>(cacc, sm, cell_part, blockIdx.x, C);
+  ca_cell_fused_finish<CP>(cacc, sm, cell_part, blk, C);
+}
+
+template <int D, int TL>
+__global__ void __launch_bounds__(CA_TB) k_fwd_cell(const float* __restrict__ F, const float* __restrict__ etamax2,
+                                                    const float* __restrict__ Vs, const unsigned short* __restrict__ Mq, ca_cell_ptrs p,
+                                                    const float* __restrict__ alpha_u, double* __restrict__ cell_part, int64_t N,
+                                                    int C, int K, int nk) {
+  __shared__ ca_f32x4 comb[4 * TL * 64];
+  __shared__ double sm[CA_TB];
+  __shared__ double la[64];
+  ca_log_softmax_alpha(alpha_u, C, la);    // wave 0; visible to all after the body's barrier
+  ca_fwd_cell_body<D, TL>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)blockIdx.x * (TL * 16), blockIdx.x, comb, sm, la);
+}
+
+// Two block sizes in one launch: the first `nbig` blocks (one resident round: CUs x blocks per CU) own 16 * TLB cells each, the
+// rest of the cells go out in blocks of 16 * TLS.  Blocks are dispatched in index order, so the small ones fill the slots the
+// big ones free: the ragged end of the kernel -- CUs left with one wave per SIMD, or none, while the last big blocks finish --
+// shrinks from one big block's duration to one small block's.  (Small blocks everywhere would re-read the B operand from L2
+// three times as often: 64-cell blocks lose 5 % to 96-cell blocks at 100k cells.)
+template <int D, int TLB, int TLS>
+__global__ void __launch_bounds__(CA_TB) k_fwd_cell_mix(const float* __restrict__ F, const float* __restrict__ etamax2,
+                                                        const float* __restrict__ Vs, const unsigned short* __restrict__ Mq,
+                                                        ca_cell_ptrs p, const float* __restrict__ alpha_u,
+                                                        double* __restrict__ cell_part, int64_t N, int C, int K, int nk, int nbig) {
+  __shared__ ca_f32x4 comb[4 * TLB * 64];
+  __shared__ double sm[CA_TB];
+  __shared__ double la[64];
+  ca_log_softmax_alpha(alpha_u, C, la);
+  if ((int)blockIdx.x < nbig)
+    ca_fwd_cell_body<D, TLB>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)blockIdx.x * (TLB * 16), blockIdx.x, comb, sm, la);
+  else
+    ca_fwd_cell_body<D, TLS>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk,
+                             (int64_t)nbig * (TLB * 16) + (int64_t)((int)blockIdx.x - nbig) * (TLS * 16), blockIdx.x, comb, sm, la);
 }
 
 // fixed-order reduction of block partials: out[j] = sum_b part[b][j]; one block per column j

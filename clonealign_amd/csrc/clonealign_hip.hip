@@ -131,6 +131,7 @@ struct ca_engine {
   double* host_dev = nullptr;      // device view of host_pinned
   unsigned long long host_seq = 0, host_seq_next = 0;
   bool fwd_cell = false; int ncblk_f = 0, fc_tl = 4;   // forward sweep + cell epilogue in one kernel (k_fwd_cell)
+  int fc_nbig = 0;                                     // > 0: k_fwd_cell_mix, that many blocks of 16 * fc_tl cells, the rest 32-cell blocks
   bool fwd_mfma = false; int fsplit = 1, fkchunk = 1, nk32 = 1; unsigned short* Mq = nullptr;   // matrix-core forward sweep
   // matrix-core backward sweep (k_bwd_mfma): bf16 parts of coef, its own cell split
   bool bwd_mfma = false; unsigned short* coefq = nullptr; int64_t N16 = 0, cchunk_m = 0; int csplit_m = 1, nwt = 0;
@@ -841,6 +842,17 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst) {
   LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell<DV, TLV>), dim3(h->ncblk_f), dim3(CA_TB), 0, h->stream, h->F, h->etamax2, \
                                               h->Vs, h->Mq, cp, h->alpha_u, h->cell_part, h->N, h->C, h->K, h->nk32))
 #define CA_FCD(TLV) do { if (h->D == 1) CA_FC(1, TLV); else CA_FC(2, TLV); } while (0)
+#define CA_FCM(DV, TLV)                                                                                                      \
+  LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell_mix<DV, TLV, 2>), dim3(h->ncblk_f), dim3(CA_TB), 0, h->stream, h->F, \
+                                              h->etamax2, h->Vs, h->Mq, cp, h->alpha_u, h->cell_part, h->N, h->C, h->K, h->nk32, h->fc_nbig))
+#define CA_FCMD(TLV) do { if (h->D == 1) CA_FCM(1, TLV); else CA_FCM(2, TLV); } while (0)
+    if (h->fc_nbig > 0) {
+      switch (h->fc_tl) {
+        case 4: CA_FCMD(4); break;
+        case 5: CA_FCMD(5); break;
+        default: CA_FCMD(6); break;
+      }
+    } else
     switch (h->fc_tl) {
       case 2: CA_FCD(2); break;
       case 4: CA_FCD(4); break;
@@ -848,6 +860,8 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst) {
       case 6: CA_FCD(6); break;
       default: CA_FCD(8); break;
     }
+#undef CA_FCMD
+#undef CA_FCM
 #undef CA_FCD
 #undef CA_FC
   } else {
@@ -1349,6 +1363,24 @@ int create_impl(ca_engine* h, const ca_problem* p) {
       if (h->fwd_cell && cdiv(Nn, 64) < 2 * h->n_cu) h->fc_tl = 2;   // small shards: 64-cell blocks leave CUs with one block or none
       if (const char* e = getenv("CA_FC_TL")) { const int t = atoi(e); if (t == 2 || t == 4 || t == 5 || t == 6 || t == 8) h->fc_tl = t; }
       h->ncblk_f = cdiv(Nn, 16 * h->fc_tl);
+      // more blocks than one resident round: the first round in big blocks, the remainder in 32-cell blocks (k_fwd_cell_mix)
+      if (h->fwd_cell && (h->fc_tl == 4 || h->fc_tl == 5 || h->fc_tl == 6) && (D == 1 || D == 2)) {
+        int occ = 0;
+#define CA_OCC(DV, TLV) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_fwd_cell_mix<DV, TLV, 2>, CA_TB, 0)
+        if (D == 1) { if (h->fc_tl == 4) CA_OCC(1, 4); else if (h->fc_tl == 5) CA_OCC(1, 5); else CA_OCC(1, 6); }
+        else { if (h->fc_tl == 4) CA_OCC(2, 4); else if (h->fc_tl == 5) CA_OCC(2, 5); else CA_OCC(2, 6); }
+#undef CA_OCC
+        // measured at 100k cells (1042 blocks of 96): 1024 big + 53 small 2706 it/s, 768 + 821: 2682, 512 + 1589: 2669, all big
+        // 2642 -- what pays is every CU getting the same number of big blocks, so: whole multiples of the CU count in big
+        // blocks, the remainder (less than one big block per CU) in small ones
+        int nbig = (h->ncblk_f / h->n_cu) * h->n_cu;
+        (void)occ;
+        if (const char* e = getenv("CA_FC_NBIG")) nbig = atoi(e);
+        if (nbig > 0 && h->ncblk_f > nbig) {
+          h->fc_nbig = nbig;
+          h->ncblk_f = nbig + cdiv(Nn - (int64_t)nbig * 16 * h->fc_tl, 32);
+        }
+      }
     }
     int zsplit = h->gsplit;
     if (h->fwd_mfma) {
@@ -1379,8 +1411,9 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   }
   if (getenv("CA_VERBOSE"))
     fprintf(stderr, "[clonealign_hip] N=%lld G=%d C=%d D=%d n_cu=%d gsplit=%d gchunk=%d csplit=%d fused=%d fwd_mfma=%d fsplit=%d fkchunk=%d "
-            "bwd_mfma=%d csplit_m=%d cchunk_m=%lld nwt=%d fwd_cell=%d fc_tl=%d\n", (long long)Nn, G, C, D, h->n_cu, h->gsplit, h->gchunk, h->csplit,
-            (int)h->fused_ok, (int)h->fwd_mfma, h->fsplit, h->fkchunk, (int)h->bwd_mfma, h->csplit_m, (long long)h->cchunk_m, h->nwt, (int)h->fwd_cell, h->fc_tl);
+            "bwd_mfma=%d csplit_m=%d cchunk_m=%lld nwt=%d fwd_cell=%d fc_tl=%d fc_nbig=%d ncblk_f=%d\n", (long long)Nn, G, C, D, h->n_cu, h->gsplit,
+            h->gchunk, h->csplit, (int)h->fused_ok, (int)h->fwd_mfma, h->fsplit, h->fkchunk, (int)h->bwd_mfma, h->csplit_m,
+            (long long)h->cchunk_m, h->nwt, (int)h->fwd_cell, h->fc_tl, h->fc_nbig, h->ncblk_f);
   CACK(dalloc(h, &h->vmm, 2 * std::max(D, 1)));
   CACK(dalloc(h, &h->vmm_part, (int64_t)h->ngblk * 2 * std::max(D, 1)));
   CACK(dalloc(h, &h->etamax2, h->N16));

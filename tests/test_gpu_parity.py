@@ -273,15 +273,20 @@ FUSED_SHAPES = {
 }
 
 
-@pytest.mark.parametrize("fwd", ["cell", "mfma", "valu"])
+@pytest.mark.parametrize("fwd", ["cell", "cell_mix", "mfma", "valu"])
 @pytest.mark.parametrize("shape", list(FUSED_SHAPES))
 def test_fused_sweep_forward_variants_agree_with_oracle(shape, fwd, monkeypatch):
     """ca_iterate takes the fused two-eps sweep (monitor pass i + forward half of train pass i+1 from one exp per
     (cell, gene)); its forward contraction runs on the matrix cores (D in {1, 2}) -- in one kernel with the cell
     epilogue (k_fwd_cell, the default) or as k_fwd_mfma + k_cell_fused (CA_FWD_CELL=0) -- or on the VALU
-    (CA_FWD_MFMA=0, and always for D >= 3).  All against the oracle's call-by-call loop."""
+    (CA_FWD_MFMA=0, and always for D >= 3).  "cell_mix" forces the two-block-size launch of the large shapes
+    (k_fwd_cell_mix: 3 blocks of 64 cells, the rest in 32-cell blocks).  All against the oracle's call-by-call loop."""
     from clonealign_amd.engine import HipEngine
     from oracle.fused_numpy import FusedModel
+    if fwd == "cell_mix":
+        monkeypatch.setenv("CA_FC_TL", "4")
+        monkeypatch.setenv("CA_FC_NBIG", "3")
+        fwd = "cell"
     if fwd == "mfma":
         monkeypatch.setenv("CA_FWD_CELL", "0")
     if fwd == "valu":
