@@ -1353,28 +1353,22 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     h->fwd_mfma = (D == 1 || D == 2) && !(getenv("CA_FWD_MFMA") && atoi(getenv("CA_FWD_MFMA")) == 0);
     h->fwd_cell = h->fwd_mfma && h->tail_fuse && !(getenv("CA_FWD_CELL") && atoi(getenv("CA_FWD_CELL")) == 0);
     {
-      // cells per block of k_fwd_cell: 16 * TL, chosen for about four blocks per CU -- measured, not derived: at 100k cells
-      // 96 cells per block (1042 blocks) beats 80 (1250) by 1.2 % and 64 (1563) by 5 %, although the occupancy API
-      // reports only three resident blocks per CU for it.
-      {
-        const int want = (int)std::ceil((double)Nn / (16.0 * 4.2 * h->n_cu));
-        h->fc_tl = want <= 4 ? 4 : want <= 5 ? 5 : 6;   // 128 cells per block never won (200k: 1346 vs 1363, 400k: 609 vs 638 it/s)
-      }
-      if (h->fwd_cell && cdiv(Nn, 64) < 2 * h->n_cu) h->fc_tl = 2;   // small shards: 64-cell blocks leave CUs with one block or none
+      // cells per block of k_fwd_cell: 16 * TL -- measured, not derived.  96-cell blocks (fewest re-reads of the B operand
+      // from L2) as soon as there is one full round of them, the launch then carries a second, 32-cell block size for the
+      // cells that do not fill a whole round (k_fwd_cell_mix, below).  With that, TL = 6 is best or within 1 % of the best of
+      // {4, 5, 6} from 35k to 400k cells (35k: 6310 / 6207 / 6046 it/s for 6 / 5 / 4; 50k: 5012 / 4916 / 4951; 70k: 3499 /
+      // 3459 / 3523; 100k: 2691 / 2594 / 2625); 128-cell blocks never won (200k: 1346 vs 1363, 400k: 609 vs 638 it/s).
+      // Small shards: 32-cell blocks, or CUs are left with one block or none (25k: 7619 / 7443 / 6701 for TL = 2 / 4 / 6
+      // without the second block size, 7535 for 6 with it).
+      h->fc_tl = (h->fwd_cell && cdiv(Nn, 64) < 2 * h->n_cu) ? 2 : 6;
       if (const char* e = getenv("CA_FC_TL")) { const int t = atoi(e); if (t == 2 || t == 4 || t == 5 || t == 6 || t == 8) h->fc_tl = t; }
       h->ncblk_f = cdiv(Nn, 16 * h->fc_tl);
-      // more blocks than one resident round: the first round in big blocks, the remainder in 32-cell blocks (k_fwd_cell_mix)
+      // two block sizes in one launch (k_fwd_cell_mix)
       if (h->fwd_cell && (h->fc_tl == 4 || h->fc_tl == 5 || h->fc_tl == 6) && (D == 1 || D == 2)) {
-        int occ = 0;
-#define CA_OCC(DV, TLV) hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void*)k_fwd_cell_mix<DV, TLV, 2>, CA_TB, 0)
-        if (D == 1) { if (h->fc_tl == 4) CA_OCC(1, 4); else if (h->fc_tl == 5) CA_OCC(1, 5); else CA_OCC(1, 6); }
-        else { if (h->fc_tl == 4) CA_OCC(2, 4); else if (h->fc_tl == 5) CA_OCC(2, 5); else CA_OCC(2, 6); }
-#undef CA_OCC
         // measured at 100k cells (1042 blocks of 96): 1024 big + 53 small 2706 it/s, 768 + 821: 2682, 512 + 1589: 2669, all big
         // 2642 -- what pays is every CU getting the same number of big blocks, so: whole multiples of the CU count in big
         // blocks, the remainder (less than one big block per CU) in small ones
         int nbig = (h->ncblk_f / h->n_cu) * h->n_cu;
-        (void)occ;
         if (const char* e = getenv("CA_FC_NBIG")) nbig = atoi(e);
         if (nbig > 0 && h->ncblk_f > nbig) {
           h->fc_nbig = nbig;
