@@ -2167,6 +2167,32 @@ __global__ void __launch_bounds__(CA_TB) k_adam_cell(const float* __restrict__ F
     }
     return;
   }
+  // q(z) logits: an elementwise step over the flat [N * C] arrays, 16 bytes per lane (a lane per cell would fetch C
+  // strided floats per array: 2.4 TB/s at 100k x 8)
+  if (apply) {
+    const int64_t e0 = (int64_t)blockIdx.x * CA_TB * C, tot = N * (int64_t)C;
+    const int64_t e1 = e0 + (int64_t)CA_TB * C < tot ? e0 + (int64_t)CA_TB * C : tot;   // e0 is a multiple of 4 (CA_TB = 256)
+    for (int64_t i = e0 + 4 * (int64_t)threadIdx.x; i < e1; i += 4 * CA_TB) {
+      if (i + 4 <= e1) {
+        float4 th = *reinterpret_cast<const float4*>(glogit + i), m = *reinterpret_cast<const float4*>(m_gl + i);
+        float4 v = *reinterpret_cast<const float4*>(v_gl + i);
+        const float4 g = *reinterpret_cast<const float4*>(dgl + i);
+        ca_adam(th.x, m.x, v.x, -g.x, lr_t, b1, b2, aeps);
+        ca_adam(th.y, m.y, v.y, -g.y, lr_t, b1, b2, aeps);
+        ca_adam(th.z, m.z, v.z, -g.z, lr_t, b1, b2, aeps);
+        ca_adam(th.w, m.w, v.w, -g.w, lr_t, b1, b2, aeps);
+        *reinterpret_cast<float4*>(glogit + i) = th;
+        *reinterpret_cast<float4*>(m_gl + i) = m;
+        *reinterpret_cast<float4*>(v_gl + i) = v;
+      } else {
+        for (int64_t k = i; k < e1; ++k) {
+          float th = glogit[k], m = m_gl[k], v = v_gl[k];
+          ca_adam(th, m, v, -dgl[k], lr_t, b1, b2, aeps);
+          glogit[k] = th; m_gl[k] = m; v_gl[k] = v;
+        }
+      }
+    }
+  }
   // range of the updated V' over the gene blocks, per block (k_vmm_final folded in: same min / max as the extra block's)
   __shared__ float vmm[2 * 8];
   if (apply && D > 0 && D <= 8 && (int)threadIdx.x < D) {
@@ -2182,12 +2208,6 @@ __global__ void __launch_bounds__(CA_TB) k_adam_cell(const float* __restrict__ F
   __syncthreads();
   const int64_t n = (int64_t)blockIdx.x * CA_TB + threadIdx.x;
   if (n >= N) return;
-  if (apply)
-    for (int c = 0; c < C; ++c) {
-      float th = glogit[n * C + c], m = m_gl[n * C + c], v = v_gl[n * C + c];
-      ca_adam(th, m, v, -dgl[n * C + c], lr_t, b1, b2, aeps);
-      glogit[n * C + c] = th; m_gl[n * C + c] = m; v_gl[n * C + c] = v;
-    }
   if (apply && D > 0) {   // exponent bound for the updated psi and V' (k_etamax folded in)
     float e = 0.f;
     for (int d = 0; d < D; ++d) {
