@@ -1086,6 +1086,7 @@ struct ca_small_args {
   double* host_out; unsigned long long* host_flag; unsigned long long host_seq;   // ELBO mirrored into pinned host memory (ca_run)
   int reduce_only;          // stop after the cell-partial reduction (sharded: the sums are all-reduced before the ELBO assembly)
   const double* yw_part; int n_yw;      // with cell_part: block partials of sum_n psi_n.(YW)_n (k_yw_dot), added to red[0]
+  const double* ee_part; int n_ee;      // without cell_part: block partials of the OTHER draw's EE_p_y cell sum (pair sweep), replace red[0]
 };
 
 // wave 0 of the O(K + C) body: one lane per clone / latent dimension
@@ -1197,6 +1198,18 @@ __device__ __forceinline__ void ca_final_small_body(const ca_small_args& sa) {
       }
       if (threadIdx.x == 0) sa.red[j] = r;
     }
+    __threadfence_block();
+    __syncthreads();
+  } else if (sa.ee_part) {   // second ELBO of a pair sweep: red[1 .. 3 + C) stand (same parameters), only EE_p_y is the other draw's
+    double ea = 0.0;
+    for (int b = threadIdx.x; b < sa.n_ee; b += CA_TB) ea += sa.ee_part[b];
+    double r = ca_block_sum(ea, sm);
+    if (sa.yw_part) {
+      double ya = 0.0;
+      for (int b = threadIdx.x; b < sa.n_yw; b += CA_TB) ya += sa.yw_part[b];
+      r += ca_block_sum(ya, sm);
+    }
+    if (threadIdx.x == 0) sa.red[0] = r;
     __threadfence_block();
     __syncthreads();
   }
@@ -1756,10 +1769,11 @@ __global__ void __launch_bounds__(CA_TB) k_cell_par(const float* __restrict__ Zp
 // The Y stream's products are NOT touched here (psi.(YW) of the ELBO and the YW row sums come from k_yw_dot on the
 // side stream), so this epilogue depends on the forward sweep only -- and can run inside it (k_fwd_cell).
 // ca_cell_fused_group: the math for CA_TB / CP cells, one lane per (cell, clone); ZA / ZB are this lane's two Z values.
-struct ca_cell_acc { double ee, pr, q, gsumc; };
+struct ca_cell_acc { double ee, pr, q, gsumc, eeB; };
 struct ca_cell_ptrs {
   const double* A; const double* cn; const double* s64; const float* etamax2; const float* glogit; const float* F;
   float* coef; float* dgl; unsigned short* coefq;
+  double* ee_partB;   // non-null: also the second draw's expected log-likelihood per block (two ELBOs from one sweep: ca_final_elbo)
 };
 template <int CP>
 __device__ __forceinline__ void ca_cell_fused_group(const ca_cell_ptrs& p, const double* la, int64_t n, int64_t N, int C, int D, int K,
@@ -1805,11 +1819,12 @@ __device__ __forceinline__ void ca_cell_fused_group(const ca_cell_ptrs& p, const
   const double gfB = (live || (ok && !isfinite(llpB))) ? gam * fB : 0.0;
   const double fbarB = gsum(gfB);
   if (ok) p.dgl[nn * C + cc] = (float)(live || !isfinite(llpB) ? gam * (fB - fbarB) : 0.0);
-  if (ok) { acc.ee += gam * llpA; acc.pr += gam * la[cc]; }
+  if (ok) { acc.ee += gam * llpA; acc.pr += gam * la[cc]; acc.eeB += gam * llpB; }
   if (live) acc.q += gam * lg;
   acc.gsumc += gam;
   if (okn && c == 0) {
     acc.ee += p.cn[nn];
+    acc.eeB += p.cn[nn];
     for (int k = 0; k < K; ++k) {
       const double ps = (double)p.F[nn * D + k];
       acc.pr += -0.5 * ps * ps - 0.5 * CA_LOG2PI;
@@ -1818,9 +1833,14 @@ __device__ __forceinline__ void ca_cell_fused_group(const ca_cell_ptrs& p, const
 }
 // block partials of the epilogue: cell_part[blk][0..2] and the per-clone gamma sums
 template <int CP>
-__device__ __forceinline__ void ca_cell_fused_finish(const ca_cell_acc& acc, double* sm, double* __restrict__ cell_part, int blk, int C) {
+__device__ __forceinline__ void ca_cell_fused_finish(const ca_cell_acc& acc, double* sm, double* __restrict__ cell_part, int blk, int C,
+                                                     double* __restrict__ ee_partB = nullptr) {
   constexpr int CPB = CA_TB / CP;
   const int W_ = 3 + C;
+  if (ee_partB) {   // (uniform)
+    const double rb = ca_block_sum(acc.eeB, sm);
+    if (threadIdx.x == 0) ee_partB[blk] = rb;
+  }
   const double r0 = ca_block_sum(acc.ee, sm);
   const double r1 = ca_block_sum(acc.pr, sm);
   const double r2 = ca_block_sum(acc.q, sm);
@@ -1850,7 +1870,7 @@ __global__ void __launch_bounds__(CA_TB) k_cell_fused(const float* __restrict__ 
   __syncthreads();
   const int c = threadIdx.x % CP;
   const int cc = c < C ? c : C - 1;
-  ca_cell_acc acc = {0.0, 0.0, 0.0, 0.0};
+  ca_cell_acc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
   const int64_t ngroups = (N + CPB - 1) / CPB;
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int64_t n = grp * CPB + threadIdx.x / CP;
@@ -1970,7 +1990,7 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
   constexpr int CPB = CA_TB / CP;
   const int c = threadIdx.x % CP;
   const int cc = c < C ? c : C - 1;
-  ca_cell_acc cacc = {0.0, 0.0, 0.0, 0.0};
+  ca_cell_acc cacc = {0.0, 0.0, 0.0, 0.0, 0.0};
   for (int g0 = 0; g0 < TL * 16; g0 += CPB) {
     const int lc = g0 + (int)threadIdx.x / CP;       // local cell
     const bool inb = lc < TL * 16;
@@ -1982,7 +2002,7 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
     const double ZB = (cz(0, lb_) + cz(1, lb_)) + (cz(2, lb_) + cz(3, lb_));
     ca_cell_fused_group<CP>(p, la, inb ? cell0 + lc : N, N, C, D, K, ZA, ZB, cacc);
   }
-  ca_cell_fused_finish<CP>(cacc, sm, cell_part, blk, C);
+  ca_cell_fused_finish<CP>(cacc, sm, cell_part, blk, C, p.ee_partB);
 }
 
 template <int D, int TL>

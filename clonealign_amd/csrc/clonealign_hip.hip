@@ -122,7 +122,8 @@ struct ca_engine {
   // per-gene prologue of the next fused pass, computed ahead by the train pass before it (ca_pre_args): the loops announce
   // the next (monitor, train) eps slots in hint_*, train_update fills the alternate partial buffers, fused_pass swaps them in
   int64_t hint_A = -1, hint_B = -1, pre_A = -1, pre_B = -1;
-  bool pre_valid = false, pre_ok = true;
+  bool pre_valid = false, pre_ok = true, pair_elbo = true;
+  double* ee_partB = nullptr;   // pair sweeps: the second draw's per-block cell sums (ca_cell_ptrs::ee_partB)
   double *gene_part_alt = nullptr, *gene_partB_alt = nullptr;
   bool bwd_ready = false; int64_t bwd_slot = -1;
   double* yw_part = nullptr; int n_yw = 0;   // block partials of sum_n psi_n.(YW)_n (k_yw_dot)
@@ -582,6 +583,7 @@ ca_small_args small_args(ca_engine* h, const double* gene_part, int apply, float
   a.cell_part = reduce_cells ? h->cell_part : nullptr; a.ncblk = h->ncblk;
   a.host_out = nullptr; a.host_flag = nullptr; a.host_seq = 0; a.reduce_only = 0;
   a.yw_part = nullptr; a.n_yw = 0;
+  a.ee_part = nullptr; a.n_ee = 0;
   if (!apply && elbo_dst && h->host_seq_next && h->host_dev) {   // monitor pass inside ca_run: mirror the ELBO to the host
     a.host_out = h->host_dev + 32;
     a.host_flag = reinterpret_cast<unsigned long long*>(h->host_dev + 33);
@@ -816,9 +818,10 @@ int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_d
 
 // Monitor pass for eps slot A fused with the forward half of the NEXT train pass (eps slot B): one sweep,
 // one exp per (cell, gene) for both (same parameters, R/inference-tflow.R:401,403 of consecutive iterations).
-int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst) {
+int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, double* elbo_dstB = nullptr) {
   const float* epsA = h->eps_dev + slotA * (int64_t)h->G;
   const float* epsB = h->eps_dev + slotB * (int64_t)h->G;
+  if (elbo_dstB) CACK(flush_mon_tail(h));   // pair sweeps come from outside the loop: nothing may be left pending
   if (h->pre_valid && h->pre_A == slotA && h->pre_B == slotB) {   // the train pass before this one already ran the prologue
     std::swap(h->gene_part, h->gene_part_alt);
     std::swap(h->gene_partB, h->gene_partB_alt);
@@ -833,6 +836,7 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst) {
   ca_cell_ptrs cp;
   cp.A = h->A; cp.cn = h->cn; cp.s64 = h->s64; cp.etamax2 = h->etamax2; cp.glogit = h->glogit; cp.F = h->F;
   cp.coef = h->coef; cp.dgl = h->dgl; cp.coefq = h->bwd_mfma ? h->coefq : nullptr;
+  cp.ee_partB = (elbo_dstB && h->fwd_cell) ? h->ee_partB : nullptr;
   int CP = 1;
   while (CP < h->C) CP <<= 1;
   int cell_blocks = h->ncblk;
@@ -900,6 +904,18 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst) {
   h->mon_tail.ncblk = cell_blocks;
   if (h->K > 0) { h->mon_tail.yw_part = h->yw_part; h->mon_tail.n_yw = h->n_yw; }
   if (!h->tail_fuse) CACK(flush_mon_tail(h));
+  if (cp.ee_partB) {
+    // pair sweep (ca_final_elbo): both draws are monitor passes of the same parameters.  ELBO A as usual, then ELBO B from
+    // the same red[1 ..] (prior, entropy and sum-gamma terms do not depend on the draw), its own cell sum of the expected
+    // log-likelihood and its own per-gene partials.
+    CACK(flush_mon_tail(h));
+    ca_small_args b = small_args(h, h->gene_partB, 0, 0.f, elbo_dstB, false);
+    b.ee_part = h->ee_partB; b.n_ee = cell_blocks;
+    if (h->K > 0) { b.yw_part = h->yw_part; b.n_yw = h->n_yw; }
+    LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_final_small, dim3(1), dim3(CA_TB), 0, h->stream, b));
+    h->look_valid = false;   // no train pass follows: the second draw's coef / d logits are by-products
+    return CA_OK;
+  }
   h->look_valid = true;
   h->look_slot = slotB;
   h->bwd_ready = false;
@@ -1208,6 +1224,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   h->mon_tail = no_small_args();
   if (const char* e = getenv("CA_TAIL_FUSE")) h->tail_fuse = atoi(e) != 0;
   if (const char* e = getenv("CA_PRE")) h->pre_ok = atoi(e) != 0;
+  if (const char* e = getenv("CA_PAIR_ELBO")) h->pair_elbo = atoi(e) != 0;
   CACK(upload_y(h, p));
   const int G = h->G, C = h->C, K = h->K, P = h->P, S = h->S, D = h->D;
   const int64_t Nn = h->N;
@@ -1416,6 +1433,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   CACK(dalloc(h, &h->coef, (int64_t)S * h->nchunk * Nn * CA_CW));
   CACK(dalloc(h, &h->scratch, Nn * C));
   CACK(dalloc(h, &h->cell_part, (int64_t)std::max(h->ncblk, h->ncblk_f) * (3 + C)));
+  CACK(dalloc(h, &h->ee_partB, (int64_t)std::max(h->ncblk, h->ncblk_f)));
   CACK(dalloc(h, &h->gpart, (int64_t)std::max(h->csplit, h->csplit_m) * G * (S + D)));
   CACK(dalloc(h, &h->dFpart, (int64_t)std::max(h->ntile, h->nwt) * Nn * std::max(D, 1)));
   CACK(dalloc(h, &h->YWpart, (int64_t)(h->nseg + 1) * Nn * std::max(K, 1)));
@@ -1822,7 +1840,13 @@ int ca_final_elbo(ca_handle h, int32_t n_rep, const float* eps_stream, int64_t n
   HIPCK(h, hipSetDevice(h->device));
   CACK(stage_eps(h, eps_stream, n_draws, n_rep));
   CACK(ensure_elbo_cap(h, n_rep));
-  for (int i = 0; i < n_rep; ++i) CACK(run_pass(h, i, CA_MODE_ELBO, 0, h->elbo_dev + i));
+  // two draws per sweep where the fused matrix-core path exists (one exp per (cell, gene) serves both); single-shard only:
+  // a sharded monitor pass has its own (3 + C)-double all-reduce
+  const bool pairs = h->fused_ok && h->fwd_cell && !is_sharded(h) && h->pair_elbo;
+  for (int i = 0; i < n_rep; ++i) {
+    if (pairs && i + 1 < n_rep) { CACK(fused_pass(h, i, i + 1, h->elbo_dev + i, h->elbo_dev + i + 1)); ++i; }
+    else CACK(run_pass(h, i, CA_MODE_ELBO, 0, h->elbo_dev + i));
+  }
   std::vector<double> v((size_t)n_rep);
   HIPCK(h, hipMemcpyAsync(v.data(), h->elbo_dev, (size_t)n_rep * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   HIPCK(h, hipStreamSynchronize(h->stream));

@@ -408,3 +408,26 @@ def test_same_seed_is_bitwise_reproducible():
         assert np.array_equal(tr, outs[0][0]) and np.array_equal(fin, outs[0][2])
         for k, v in st.items():
             assert np.array_equal(v, outs[0][1][k]), k
+
+
+@pytest.mark.parametrize("shape", ["d1_c8_ragged", "d2_k1p1", "d1_c5"])
+def test_final_elbos_from_pair_sweeps_equal_single_passes(shape):
+    """ca_final_elbo takes two draws per sweep on the fused matrix-core path (the second draw's ELBO from the same pass as
+    the first's): every value must equal the single-draw monitor pass of that draw, and an odd count ends on a single pass."""
+    from clonealign_amd.engine import HipEngine
+    case = make_case(seed=8, **FUSED_SHAPES[shape])
+    eng = HipEngine(**case)
+    try:
+        G = case["Y"].shape[1]
+        eps = np.stack([eps_for(1, G, 300 + i) for i in range(9)])
+        eng.gamma_init(eps[0])
+        eng.iterate(2, eps[1:5])                                   # leave the loop's state behind (pending tails, look-ahead)
+        singles = np.array([eng.elbo(e) for e in eps[:5]])
+        pairs = eng.final_elbo(eps[:5], 5)                         # (0,1) (2,3) as pair sweeps, 4 as a single pass
+        assert np.abs(pairs - singles).max() <= 3e-6 * np.abs(singles).max(), (pairs, singles)
+        again = eng.final_elbo(eps[:5], 5)
+        assert np.array_equal(pairs, again)
+        e_next = eng.iterate(1, eps[5:7])                          # the loop carries on correctly after pair sweeps
+        assert np.isfinite(e_next)
+    finally:
+        eng.close()
