@@ -104,7 +104,11 @@ def correlations_from_sums(T, Syy, L, clone_counts):
 def _counts_array(a):
     """The count matrix in its own dtype when the engine can upload it as it is (no float64 copy of N x G), else float64."""
     a = np.asarray(a)
-    return a if a.dtype in (np.float64, np.float32, np.int32, np.uint16, np.uint8) else a.astype(np.float64)
+    if a.dtype in (np.float64, np.float32, np.int32, np.uint16, np.uint8):
+        return a
+    if a.dtype.kind in "iu" and a.size and 0 <= a.min() and a.max() <= np.iinfo(np.int32).max:
+        return a.astype(np.int32)            # e.g. numpy's default int64 counts: half the bytes of a float64 copy
+    return a.astype(np.float64)
 
 
 def _parse_expression(gene_expression_data):

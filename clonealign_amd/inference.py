@@ -102,7 +102,8 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
             "(R/inference-tflow.R:323 divides a float64 tensor by tf$to_float(S)); only float32 is supported")
     Y_dat = np.asarray(Y_dat)
     if Y_dat.dtype not in (np.float64, np.float32, np.int32, np.uint16, np.uint8):   # dtypes the engine uploads as they are
-        Y_dat = Y_dat.astype(np.float64)
+        fits = Y_dat.dtype.kind in "iu" and Y_dat.size and 0 <= Y_dat.min() and Y_dat.max() <= np.iinfo(np.int32).max
+        Y_dat = Y_dat.astype(np.int32 if fits else np.float64)
     L_dat = np.asarray(L_dat, dtype=np.float64)
     Y_dat, L_dat, keep = hostprep.gene_filter(Y_dat, L_dat, gene_filter_threshold)   # :117-124
     log(f"Removing {int((~keep).sum())} genes with low counts")
