@@ -155,7 +155,7 @@ def clonealign(gene_expression_data, copy_number_data, max_iter=200, rel_tol=1e-
                cov=None, ref=None, fix_alpha=False, dtype="float32", saturate=True,
                saturation_threshold=6, K=None, mc_samples=1, verbose=True, initial_shrink=5,
                clone_call_probability=0.95, data_init_mu=True, *, seed=None, engine=None,
-               engine_opts=None, clone_names=None):
+               engine_opts=None, clone_names=None, _reuse=None):
     """Assign scRNA-seq cells to clones.  Arguments as R/clonealign.R:184-203."""
     Y, gene_names = _parse_expression(gene_expression_data)
     N, G = Y.shape
@@ -188,7 +188,7 @@ def clonealign(gene_expression_data, copy_number_data, max_iter=200, rel_tol=1e-
                           dtype=dtype, saturate=saturate, saturation_threshold=saturation_threshold,
                           K=K, mc_samples=mc_samples, verbose=verbose, initial_shrink=initial_shrink,
                           data_init_mu=data_init_mu, gene_names=gene_names, seed=seed,
-                          engine=engine, engine_opts=engine_opts, post=_post)
+                          engine=engine, engine_opts=engine_opts, post=_post, _reuse=_reuse)
     res = ClonealignFit(res)
     res["clone"] = clone_assignment(res["ml_params"]["clone_probs"], clone_names,
                                     clone_call_probability)          # :283

@@ -97,6 +97,7 @@ struct ca_engine {
   float *glogit = nullptr, *m_gl = nullptr, *v_gl = nullptr;        // [N][C]
   float *V = nullptr, *m_V = nullptr, *v_V = nullptr;               // V [G][D] = (W | beta)
   float *loc = nullptr, *ls = nullptr, *m_loc = nullptr, *v_loc = nullptr, *m_ls = nullptr, *v_ls = nullptr;
+  float* loc_init = nullptr;   // loc as ca_create left it (loc0, or the device-side mu_guess): ca_reinit's default
   float *vchi = nullptr, *m_v = nullptr, *v_v = nullptr;            // [K]
   float *alpha_u = nullptr, *m_a = nullptr, *v_a = nullptr;         // [C]
   double dir_const = 0.0;
@@ -1508,6 +1509,8 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     CACK(dalloc(h, &h->YtX, (int64_t)G * std::max(P, 1)));
     CACK(upload_d(h, h->YtX, ytx));
   }
+  CACK(dalloc(h, &h->loc_init, G));
+  HIPCK(h, hipMemcpyAsync(h->loc_init, h->loc, (size_t)G * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
   h->dir_const = -((double)C * std::lgamma(1.0 / (double)C) - std::lgamma(1.0));
   h->b1p = (float)h->opt.beta1;
   h->b2p = (float)h->opt.beta2;
@@ -2119,6 +2122,49 @@ int ca_set_param(ca_handle h, const char* name, const double* in) {
     for (int64_t c = 0; c < r.cols; ++c)
       buf[i * r.stride + r.off + c] = (float)in[r.matrix ? hidx(h->layout, i, c, r.rows, r.cols) : i];
   CACK(upload_f(h, r.f, buf));
+  CACK(refresh_derived(h));
+  HIPCK(h, hipStreamSynchronize(h->stream));
+  return CA_OK;
+}
+
+// A new restart on the same data (R/clonealign.R:50-56 runs every restart through the whole of inference_tflow): all eight
+// variables back to their initial values (R/inference-tflow.R:240-273), Adam slots and beta powers cleared; the count matrix, its
+// fit constants and the column sums stay resident.
+int ca_reinit(ca_handle h, const double* psi0, const double* loc0) {
+  if (!h) return CA_ERR_INVALID;
+  if (h->K > 0 && !psi0) { h->err = "psi0 is required when K > 0"; return CA_ERR_INVALID; }
+  HIPCK(h, hipSetDevice(h->device));
+  if (h->y_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ydone, 0)); h->y_pending = false; }
+  HIPCK(h, hipStreamSynchronize(h->stream));
+  const int64_t N = h->N; const int G = h->G, C = h->C, K = h->K, D = h->D;
+  auto zero = [&](float* p, int64_t n) { return p && n > 0 ? hipMemsetAsync(p, 0, (size_t)n * sizeof(float), h->stream) : hipSuccess; };
+  const int64_t GD = (int64_t)G * std::max(D, 1), NK = N * std::max(K, 1);
+  HIPCK(h, zero(h->V, GD)); HIPCK(h, zero(h->m_V, GD)); HIPCK(h, zero(h->v_V, GD));
+  HIPCK(h, zero(h->ls, G)); HIPCK(h, zero(h->m_ls, G)); HIPCK(h, zero(h->v_ls, G));
+  HIPCK(h, zero(h->m_loc, G)); HIPCK(h, zero(h->v_loc, G));
+  HIPCK(h, zero(h->vchi, std::max(K, 1))); HIPCK(h, zero(h->m_v, std::max(K, 1))); HIPCK(h, zero(h->v_v, std::max(K, 1)));
+  HIPCK(h, zero(h->alpha_u, C)); HIPCK(h, zero(h->m_a, C)); HIPCK(h, zero(h->v_a, C));
+  HIPCK(h, zero(h->glogit, N * C)); HIPCK(h, zero(h->m_gl, N * C)); HIPCK(h, zero(h->v_gl, N * C));
+  HIPCK(h, zero(h->m_psi, NK)); HIPCK(h, zero(h->v_psi, NK));
+  if (loc0) {
+    std::vector<float> l0((size_t)G);
+    for (int g = 0; g < G; ++g) l0[g] = (float)loc0[g];
+    CACK(upload_f(h, h->loc, l0));
+  } else {
+    HIPCK(h, hipMemcpyAsync(h->loc, h->loc_init, (size_t)G * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+  }
+  if (K > 0) {   // psi columns of F; the covariate columns stay
+    std::vector<float> Fh;
+    CACK(download_f(h, Fh, h->F, N * D));
+    for (int64_t n = 0; n < N; ++n)
+      for (int k = 0; k < K; ++k) Fh[(size_t)n * D + k] = (float)psi0[hidx(h->layout, n, k, N, K)];
+    CACK(upload_f(h, h->F, Fh));
+  }
+  h->b1p = (float)h->opt.beta1;
+  h->b2p = (float)h->opt.beta2;
+  h->mon_tail.enabled = 0;
+  h->bwd_ready = false;
+  h->hint_A = h->hint_B = -1;
   CACK(refresh_derived(h));
   HIPCK(h, hipStreamSynchronize(h->stream));
   return CA_OK;

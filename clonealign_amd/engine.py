@@ -24,7 +24,7 @@ EXPORTS = (
     "ca_abi_version", "ca_default_options", "ca_create", "ca_destroy", "ca_last_error", "ca_get_info",
     "ca_synchronize", "ca_comm_unique_id", "ca_comm_init", "ca_set_host_allreduce", "ca_gamma_init", "ca_elbo", "ca_elbo_terms",
     "ca_step", "ca_gradients", "ca_run", "ca_iterate", "ca_final_elbo", "ca_init_psi_pca", "ca_clone_gene_sums", "ca_get_param", "ca_set_param",
-    "ca_get_gradient", "ca_get_kernel_times", "ca_reset_kernel_times", "ca_set_profile", "ca_eps_draw", "ca_allele_loglik", "ca_preprocess",
+    "ca_get_gradient", "ca_reinit", "ca_get_kernel_times", "ca_reset_kernel_times", "ca_set_profile", "ca_eps_draw", "ca_allele_loglik", "ca_preprocess",
 )
 
 
@@ -99,6 +99,7 @@ def load_library(path=None):
     lib.ca_get_param.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
     lib.ca_set_param.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
     lib.ca_get_gradient.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
+    lib.ca_reinit.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ca_get_kernel_times.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ca_reset_kernel_times.argtypes = [C.c_void_p]
     lib.ca_set_profile.argtypes = [C.c_void_p, C.c_int32]
@@ -330,6 +331,16 @@ class HipEngine:
         v = np.ascontiguousarray(np.asarray(value, dtype=np.float64).reshape(self._shape(name)))
         if v.size:
             self._ck(self.lib.ca_set_param(self.h, name.encode(), v.ctypes.data_as(C.c_void_p)))
+
+    def reinit(self, psi0, loc0=None):
+        """A new restart on the resident data: variables back to their initial values (psi = psi0, loc = loc0 or what the
+        constructor started from), fresh Adam state (ca_reinit)."""
+        p0 = None
+        if self.K > 0:
+            p0 = np.ascontiguousarray(np.asarray(psi0, dtype=np.float64).reshape(self.N, self.K))
+        l0 = None if loc0 is None else np.ascontiguousarray(np.asarray(loc0, dtype=np.float64).reshape(self.G))
+        self._ck(self.lib.ca_reinit(self.h, None if p0 is None else p0.ctypes.data_as(C.c_void_p),
+                                    None if l0 is None else l0.ctypes.data_as(C.c_void_p)))
 
     def get_params(self):
         """R/inference-tflow.R:424-434."""

@@ -78,7 +78,7 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
                     fix_alpha=False, dtype="float32", saturate=True, saturation_threshold=6,
                     K=1, mc_samples=1, verbose=True, initial_shrink=5, data_init_mu=True,
                     *, gene_names=None, seed=None, engine=None, engine_opts=None,
-                    psi_noise=None, eps_stream=None, psi_init="auto", post=None, allele_on="auto"):
+                    psi_noise=None, eps_stream=None, psi_init="auto", post=None, allele_on="auto", _reuse=None):
     """EM/VI inference on the MI355X engine.  Arguments as R/inference-tflow.R:71-89.
 
     Keyword-only extras (no reference counterpart): ``seed`` (replaces R's ``set.seed``
@@ -91,6 +91,9 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
     the device, ca_allele_loglik, once cells x variants exceeds 2e5);
     ``post(engine, ml_params)`` runs before the engine is closed (clonealign() uses it for the device-side
     correlation sums) and its result is returned under ``"post"``.
+    ``_reuse``: a dict owned by run_clonealign()'s restart loop (multirun.py).  The first fit leaves its prepared inputs and
+    its engine in it; later fits on the SAME data and settings skip the host passes and the upload and restart the resident
+    engine (``ca_reinit``).  The owner closes the engine.
     """
     log = (lambda m: print(m)) if verbose else (lambda m: None)
     log("Constructing HIP engine")                               # :102-104 ("Constructing tensorflow graph")
@@ -100,53 +103,62 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
         raise NotImplementedError(
             "dtype='float64': the reference graph cannot be built for float64 "
             "(R/inference-tflow.R:323 divides a float64 tensor by tf$to_float(S)); only float32 is supported")
-    Y_dat = np.asarray(Y_dat)
-    if Y_dat.dtype not in (np.float64, np.float32, np.int32, np.uint16, np.uint8):   # dtypes the engine uploads as they are
-        fits = Y_dat.dtype.kind in "iu" and Y_dat.size and 0 <= Y_dat.min() and Y_dat.max() <= np.iinfo(np.int32).max
-        Y_dat = Y_dat.astype(np.int32 if fits else np.float64)
-    L_dat = np.asarray(L_dat, dtype=np.float64)
-    Y_dat, L_dat, keep = hostprep.gene_filter(Y_dat, L_dat, gene_filter_threshold)   # :117-124
-    log(f"Removing {int((~keep).sum())} genes with low counts")
-    if gene_names is not None:
-        retained_genes = [g for g, k in zip(gene_names, keep) if k]     # :126-131
-    else:
-        retained_genes = np.flatnonzero(keep)                           # 0-based (R: which(), 1-based)
-    N, G = Y_dat.shape
-    C = L_dat.shape[1]
-    K = int(K)
-    if L_dat.shape[0] != G:
-        raise ValueError("nrow(L_dat) == G is not TRUE")               # :139
-    if saturate:
-        L_dat = hostprep.saturate(L_dat, saturation_threshold)          # :142-144
-    P = 0
-    if x is not None:                                                   # :147-153
-        x = np.asarray(x, dtype=np.float64)
-        if x.ndim == 1:
-            x = x.reshape(-1, 1)
-        if x.ndim != 2:
-            raise ValueError("is.matrix(x) is not TRUE")
-        P = x.shape[1]
-        if x.shape[0] != N:
-            raise ValueError("nrow(x) == N is not TRUE")
-    # allelic imbalance (:166-187): a parameter-free [N,C] additive term
-    use_allele = clone_allele is not None and ref is not None and cov is not None
-    extra = None
-    clone_probs_from_snv = None
-    if use_allele:
-        log("Using allelic imbalance info")
-        clone_allele = np.asarray(clone_allele, dtype=np.float64)
-        cov = np.asarray(cov, dtype=np.float64)
-        ref = np.asarray(ref, dtype=np.float64)
-        V = clone_allele.shape[0]
-        sanitize_allele_info(V, clone_allele, cov, ref, N, C)
-        if allele_on in ("device", "auto") and engine is None and (allele_on == "device" or N * V > 200_000):
-            from .engine import allele_loglik                          # 12 lgamma per (variant, cell)
-            dev = int((engine_opts or {}).get("device", 0))
-            extra = allele_loglik(clone_allele, cov, ref, device=dev)  # [N,C]
+    cached = None if _reuse is None else _reuse.get("prep")
+    if cached is None:
+        Y_dat = np.asarray(Y_dat)
+        if Y_dat.dtype not in (np.float64, np.float32, np.int32, np.uint16, np.uint8):   # dtypes the engine uploads as they are
+            fits = Y_dat.dtype.kind in "iu" and Y_dat.size and 0 <= Y_dat.min() and Y_dat.max() <= np.iinfo(np.int32).max
+            Y_dat = Y_dat.astype(np.int32 if fits else np.float64)
+        L_dat = np.asarray(L_dat, dtype=np.float64)
+        Y_dat, L_dat, keep = hostprep.gene_filter(Y_dat, L_dat, gene_filter_threshold)   # :117-124
+        log(f"Removing {int((~keep).sum())} genes with low counts")
+        if gene_names is not None:
+            retained_genes = [g for g, k in zip(gene_names, keep) if k]     # :126-131
         else:
-            alt = cov.T - ref.T
-            extra = construct_ai_likelihood(clone_allele, alt, cov.T)  # [N,C]
-        clone_probs_from_snv = np.exp(extra - logsumexp(extra, 1, keepdims=True))   # :436-440
+            retained_genes = np.flatnonzero(keep)                           # 0-based (R: which(), 1-based)
+        N, G = Y_dat.shape
+        C = L_dat.shape[1]
+        K = int(K)
+        if L_dat.shape[0] != G:
+            raise ValueError("nrow(L_dat) == G is not TRUE")               # :139
+        if saturate:
+            L_dat = hostprep.saturate(L_dat, saturation_threshold)          # :142-144
+        P = 0
+        if x is not None:                                                   # :147-153
+            x = np.asarray(x, dtype=np.float64)
+            if x.ndim == 1:
+                x = x.reshape(-1, 1)
+            if x.ndim != 2:
+                raise ValueError("is.matrix(x) is not TRUE")
+            P = x.shape[1]
+            if x.shape[0] != N:
+                raise ValueError("nrow(x) == N is not TRUE")
+        # allelic imbalance (:166-187): a parameter-free [N,C] additive term
+        use_allele = clone_allele is not None and ref is not None and cov is not None
+        extra = None
+        clone_probs_from_snv = None
+        if use_allele:
+            log("Using allelic imbalance info")
+            clone_allele = np.asarray(clone_allele, dtype=np.float64)
+            cov = np.asarray(cov, dtype=np.float64)
+            ref = np.asarray(ref, dtype=np.float64)
+            V = clone_allele.shape[0]
+            sanitize_allele_info(V, clone_allele, cov, ref, N, C)
+            if allele_on in ("device", "auto") and engine is None and (allele_on == "device" or N * V > 200_000):
+                from .engine import allele_loglik                          # 12 lgamma per (variant, cell)
+                dev = int((engine_opts or {}).get("device", 0))
+                extra = allele_loglik(clone_allele, cov, ref, device=dev)  # [N,C]
+            else:
+                alt = cov.T - ref.T
+                extra = construct_ai_likelihood(clone_allele, alt, cov.T)  # [N,C]
+            clone_probs_from_snv = np.exp(extra - logsumexp(extra, 1, keepdims=True))   # :436-440
+        if _reuse is not None:
+            _reuse["prep"] = dict(Y_dat=Y_dat, L_dat=L_dat, keep=keep, retained_genes=retained_genes, N=N, G=G, C=C, K=K, P=P,
+                                  x=x, extra=extra, clone_probs_from_snv=clone_probs_from_snv)
+    else:
+        Y_dat, L_dat, keep, retained_genes = cached["Y_dat"], cached["L_dat"], cached["keep"], cached["retained_genes"]
+        N, G, C, K, P, x = cached["N"], cached["G"], cached["C"], cached["K"], cached["P"], cached["x"]
+        extra, clone_probs_from_snv = cached["extra"], cached["clone_probs_from_snv"]
     rng = np.random.default_rng(seed)
     # initialisation (:204-235)
     if psi_noise is None:
@@ -156,25 +168,43 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
         raise ValueError("psi_init must be 'auto', 'host' or 'device'")
     device_pca = K > 0 and hasattr(Engine, "pca_init") and (psi_init == "device" or (psi_init == "auto" and N * G > 4_000_000))
     pcs = np.zeros((N, K)) if device_pca else hostprep.pca_init(Y_dat, K, psi_noise)
-    s_init = Y_dat.sum(1, dtype=np.float64)
-    if np.any(s_init == 0):
-        raise ValueError("Some cells have no counts mapping")          # :212-214
-    if (isinstance(data_init_mu, (bool, np.bool_)) and bool(data_init_mu) and N * G > 4_000_000 and getattr(Engine, "DEVICE_MU_INIT", False)
-            and int((engine_opts or {}).get("world", 1)) == 1):
-        loc0 = None      # the engine takes mu_guess (:220-235) and loc0 (:262) from the resident matrix: no host pass
+    if cached is not None and "loc0" in cached:
+        loc0 = cached["loc0"]                                           # same data: same s_init check, same mu_guess
     else:
-        mu_g = hostprep.mu_guess(Y_dat, data_init_mu, row_sums=s_init)
-        loc0 = hostprep.safe_inverse_softplus(mu_g)                     # :262
+        s_init = Y_dat.sum(1, dtype=np.float64)
+        if np.any(s_init == 0):
+            raise ValueError("Some cells have no counts mapping")      # :212-214
+        if (isinstance(data_init_mu, (bool, np.bool_)) and bool(data_init_mu) and N * G > 4_000_000
+                and getattr(Engine, "DEVICE_MU_INIT", False) and int((engine_opts or {}).get("world", 1)) == 1):
+            loc0 = None  # the engine takes mu_guess (:220-235) and loc0 (:262) from the resident matrix: no host pass
+        else:
+            mu_g = hostprep.mu_guess(Y_dat, data_init_mu, row_sums=s_init)
+            loc0 = hostprep.safe_inverse_softplus(mu_g)                 # :262
+        if _reuse is not None:
+            _reuse["prep"]["loc0"] = loc0
     S = int(mc_samples)
     if eps_stream is None:
         eps_seed = int(rng.integers(1, 2**31 - 1))                      # get_next_seed(), :49-51
         eps_stream = EpsStream(eps_seed, S, G)
 
-    eng = Engine(Y_dat, L_dat, pcs, loc0, K, S, X=x, extra_loglik=extra,
-                 learning_rate=learning_rate, **(engine_opts or {}))
+    eng = None if _reuse is None else _reuse.get("eng")
+    if eng is not None:
+        eng.reinit(pcs, loc0)                                           # restart on the resident data (ca_reinit)
+    else:
+        eng = Engine(Y_dat, L_dat, pcs, loc0, K, S, X=x, extra_loglik=extra,
+                     learning_rate=learning_rate, **(engine_opts or {}))
+        if _reuse is not None and hasattr(eng, "reinit"):
+            _reuse["eng"] = eng
+    keep_open = _reuse is not None and _reuse.get("eng") is eng
     try:
         if device_pca:
-            if np.any(Y_dat.min(0) == Y_dat.max(0)):     # prcomp(scale = TRUE) refuses constant genes (sd == 0)
+            if cached is not None and "const_gene" in cached:
+                const_gene = cached["const_gene"]
+            else:
+                const_gene = bool(np.any(Y_dat.min(0) == Y_dat.max(0)))
+                if _reuse is not None:
+                    _reuse["prep"]["const_gene"] = const_gene
+            if const_gene:                               # prcomp(scale = TRUE) refuses constant genes (sd == 0)
                 raise ValueError("cannot rescale a constant/zero column to unit variance")
             eng.pca_init(psi_noise, seed=int(rng.integers(0, 2**31 - 1)))
         log("Optimizing ELBO")
@@ -190,8 +220,14 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
             final = eng.final_elbo(eps_stream, N_FINAL_ELBO)
         else:
             final = [eng.elbo(eps_stream.next()) for _ in range(N_FINAL_ELBO)]   # :447-449
+    except BaseException:
+        if keep_open:                                                   # do not hand a failed engine to the next restart
+            _reuse.pop("eng", None)
+            keep_open = False
+        raise
     finally:
-        eng.close()                                                     # :457
+        if not keep_open:
+            eng.close()                                                 # :457
     final = np.asarray(final, dtype=np.float64)
     convergence_info = {
         "final_elbo": float(final.mean()),

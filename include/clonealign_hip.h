@@ -173,6 +173,12 @@ int ca_set_param(ca_handle h, const char* name, const double* in);
 /* after ca_gradients(): d ELBO / d variable, raw-variable names as in ca_set_param */
 int ca_get_gradient(ca_handle h, const char* name, double* out);
 
+/* A new restart on the same data: what run_clonealign()'s loop (R/clonealign.R:50-56) gets by calling inference_tflow() again --
+ * all eight variables at their initial values (R/inference-tflow.R:240-273: W, v, beta, alpha_unconstr, ls, gamma_logits = 0,
+ * psi = psi0, loc = loc0), fresh Adam state -- without uploading the count matrix or recomputing its fit constants.
+ * psi0: N x K in the problem's layout (NULL when K = 0); loc0: G values or NULL for the loc ca_create() started from. */
+int ca_reinit(ca_handle h, const double* psi0, const double* loc0);
+
 /* accumulated HIP-event time per profiled kernel class since the last reset; ca_set_profile changes the mask */
 int ca_get_kernel_times(ca_handle h, double ms[CA_KERNEL_COUNT], int64_t launches[CA_KERNEL_COUNT]);
 int ca_reset_kernel_times(ca_handle h);

@@ -382,3 +382,33 @@ def test_inference_tflow_device_mu_init_equals_host_init():
     assert len(ea) == len(eb) == 16
     assert np.abs(ea - eb).max() <= 1e-4 * np.abs(eb).max()
     assert np.array_equal(a["ml_params"]["clone_probs"].argmax(1), b["ml_params"]["clone_probs"].argmax(1))
+
+
+@pytest.mark.parametrize("big", [False, True])
+def test_run_clonealign_restarts_on_one_resident_engine_equal_separate_fits(big):
+    """run_clonealign()'s restarts share one engine per GPU (ca_reinit): every restart must equal the fit a fresh
+    clonealign() call with the same seed produces (R/clonealign.R:50-56 calls clonealign() again each time)."""
+    import warnings
+    import clonealign_amd as ca
+    rng = np.random.default_rng(33)
+    N, G, C = (2100, 2000, 3) if big else (260, 90, 3)       # big: device PCA / device mu_guess paths (N * G > 4e6)
+    L = rng.integers(1, 5, size=(G, C)).astype(np.float64)
+    L[L.min(1) == L.max(1), 0] += 1
+    z = rng.integers(0, C, N)
+    Y = rng.poisson(rng.lognormal(-0.8, 1.0, G)[None, :] * L[:, z].T * 0.6).astype(np.int32)
+    Y[:, Y.sum(0) == 0] = 1
+    Y[0, Y.min(0) == Y.max(0)] += 1
+    kw = dict(max_iter=12, rel_tol=1e-9, verbose=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        best = ca.run_clonealign(Y, L, initial_shrinks=(0, 5), n_repeats=2, print_elbos=False, seed=11, **kw)
+        ss = np.random.SeedSequence(11)
+        seeds = [int(s.generate_state(1)[0]) for s in ss.spawn(4)]
+        single = [ca.clonealign(Y, L, seed=s, **kw) for s in seeds]
+    elbos = np.array([f["convergence_info"]["final_elbo"] for f in single])
+    assert np.array_equal(best["multirun_info"]["elbos"], elbos)
+    ref = single[int(np.argmax(elbos))]
+    assert np.array_equal(best["convergence_info"]["elbo"], ref["convergence_info"]["elbo"])
+    assert np.array_equal(best["ml_params"]["clone_probs"], ref["ml_params"]["clone_probs"])
+    assert list(best["clone"]) == list(ref["clone"])
+    np.testing.assert_allclose(best["correlations"], ref["correlations"], rtol=0, atol=1e-12, equal_nan=True)

@@ -30,3 +30,17 @@ acc = float(np.mean(np.array([ord(c[-1]) - 97 if c != "unassigned" else -1 for c
 print(f"clonealign() {N} x {G} x {C}, {iters} iterations: {dt:.3f} s; {len(fit['convergence_info']['elbo']) - 1} iterations run; "
       f"labels equal to the simulated clone: {acc:.3f}")
 pstats.Stats(pr).sort_stats("cumulative").print_stats(14)
+
+if os.environ.get("E2E_RESTARTS", "1") != "0":
+    from clonealign_amd.api import run_clonealign  # noqa: E402
+    t0 = time.perf_counter()
+    best = run_clonealign(Y, L, initial_shrinks=(0, 5, 10), n_repeats=3, print_elbos=False, seed=2, max_iter=iters, verbose=False)
+    t_shared = time.perf_counter() - t0
+    ss = np.random.SeedSequence(2)
+    seeds = [int(s.generate_state(1)[0]) for s in ss.spawn(9)]
+    t0 = time.perf_counter()
+    fits = [clonealign(Y, L, seed=s, max_iter=iters, verbose=False) for s in seeds]
+    t_sep = time.perf_counter() - t0
+    same = np.array_equal(best["multirun_info"]["elbos"], np.array([f["convergence_info"]["final_elbo"] for f in fits]))
+    print(f"run_clonealign(), 9 restarts on one resident engine: {t_shared:.3f} s; nine separate clonealign() calls: {t_sep:.3f} s; "
+          f"identical ELBOs: {same}")
