@@ -51,6 +51,30 @@ __device__ __forceinline__ double ca_block_sum(double v, double* sm) {
   return r;
 }
 
+// NV block sums at once: the NV butterflies interleave (their shuffle latencies overlap) and share ONE pair of barriers.
+// Same additions in the same order as NV calls of ca_block_sum, so the results are bitwise the same.
+template <int NV>
+__device__ __forceinline__ void ca_block_sum_n(double (&v)[NV], double* sm /* >= (CA_TB / 64) * NV */) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] += __shfl_xor(v[i], o, 64);
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) sm[(threadIdx.x >> 6) * NV + i] = v[i];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    double r = sm[i];
+#pragma unroll
+    for (int w = 1; w < CA_TB / 64; ++w) r += sm[w * NV + i];
+    v[i] = r;
+  }
+}
+
 __device__ __forceinline__ unsigned short ca_bf16_rn(float f) {
   unsigned u = __float_as_uint(f);
   u += 0x7FFFu + ((u >> 16) & 1u);
@@ -642,11 +666,14 @@ __device__ __forceinline__ void ca_gene_pre_fused_body(const float* __restrict__
     }
   }
   const int W_ = 3 + K;
-  for (int w = 0; w < 2; ++w) {
-    double* gp = (w ? gene_partB : gene_partA) + (int64_t)blk * W_;
-    for (int i = 0; i < 3; ++i) {
-      const double r = ca_block_sum(t[w][i], sm);
-      if (threadIdx.x == 0) gp[i] = r;
+  {
+    double six[6] = {t[0][0], t[0][1], t[0][2], t[1][0], t[1][1], t[1][2]};
+    ca_block_sum_n<6>(six, sm);
+    if (threadIdx.x == 0) {
+      double* ga = gene_partA + (int64_t)blk * W_;
+      double* gb = gene_partB + (int64_t)blk * W_;
+      ga[0] = six[0]; ga[1] = six[1]; ga[2] = six[2];
+      gb[0] = six[3]; gb[1] = six[4]; gb[2] = six[5];
     }
   }
   for (int k = 0; k < K; ++k) {
@@ -1187,16 +1214,24 @@ __device__ __forceinline__ void ca_final_small_body(const ca_small_args& sa) {
   __shared__ double gs[3 + 16];
   if (sa.cell_part) {   // k_reduce_part folded in (same fixed order: strided partial sums, then the block tree)
     const int Wc = 3 + sa.C;
-    for (int j = 0; j < Wc; ++j) {
-      double acc = 0.0;
-      for (int b = threadIdx.x; b < sa.ncblk; b += CA_TB) acc += sa.cell_part[(int64_t)b * Wc + j];
-      double r = ca_block_sum(acc, sm);
-      if (j == 0 && sa.yw_part) {   // the psi.(YW) term of EE_p_y, from the side stream's k_yw_dot
+    for (int j0 = 0; j0 < Wc; j0 += 4) {   // four columns per pass (one pair of barriers, interleaved butterflies)
+      double a4[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int b = threadIdx.x; b < sa.ncblk; b += CA_TB) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (j0 + i < Wc) a4[i] += sa.cell_part[(int64_t)b * Wc + j0 + i];
+      }
+      ca_block_sum_n<4>(a4, sm);
+      if (j0 == 0 && sa.yw_part) {   // the psi.(YW) term of EE_p_y, from the side stream's k_yw_dot
         double ya = 0.0;
         for (int b = threadIdx.x; b < sa.n_yw; b += CA_TB) ya += sa.yw_part[b];
-        r += ca_block_sum(ya, sm);
+        a4[0] += ca_block_sum(ya, sm);
       }
-      if (threadIdx.x == 0) sa.red[j] = r;
+      if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (j0 + i < Wc) sa.red[j0 + i] = a4[i];
+      }
     }
     __threadfence_block();
     __syncthreads();
@@ -1215,7 +1250,17 @@ __device__ __forceinline__ void ca_final_small_body(const ca_small_args& sa) {
   }
   if (sa.reduce_only) return;   // (uniform) sharded runs: the ELBO is assembled after the all-reduce
   const int W_ = 3 + sa.K;
-  for (int j = 0; j < W_; ++j) {
+  {
+    double a3[3] = {0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < sa.ngblk; b += CA_TB) {
+      a3[0] += sa.gene_part[(int64_t)b * W_ + 0];
+      a3[1] += sa.gene_part[(int64_t)b * W_ + 1];
+      a3[2] += sa.gene_part[(int64_t)b * W_ + 2];
+    }
+    ca_block_sum_n<3>(a3, sm);
+    if (threadIdx.x == 0) { gs[0] = a3[0]; gs[1] = a3[1]; gs[2] = a3[2]; }
+  }
+  for (int j = 3; j < W_; ++j) {
     double acc = 0.0;
     for (int b = threadIdx.x; b < sa.ngblk; b += CA_TB) acc += sa.gene_part[(int64_t)b * W_ + j];
     const double r = ca_block_sum(acc, sm);
@@ -2124,20 +2169,18 @@ __device__ __forceinline__ void ca_final_gene_body(const double* __restrict__ re
       if (g == G - 1)   // pad to a multiple of 32 genes with the last gene's loading (k_fwd_cell reads whole k-steps)
         for (int gp = G; gp < ((G + 31) / 32) * 32; ++gp) Vs[(int64_t)gp * D + d] = v;
     }
-    __syncthreads();
-    smin[threadIdx.x] = ok ? v : INFINITY;
-    smax[threadIdx.x] = ok ? v : -INFINITY;
-    __syncthreads();
-    for (int s = CA_TB / 2; s > 0; s >>= 1) {
-      if (threadIdx.x < s) {
-        smin[threadIdx.x] = fminf(smin[threadIdx.x], smin[threadIdx.x + s]);
-        smax[threadIdx.x] = fmaxf(smax[threadIdx.x], smax[threadIdx.x + s]);
-      }
-      __syncthreads();
+    float mn = ok ? v : INFINITY, mx = ok ? v : -INFINITY;   // wave butterflies, then the four wave results through LDS
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      mn = fminf(mn, __shfl_xor(mn, o, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; }
+    __syncthreads();
     if (threadIdx.x == 0) {
-      vmm_part[((int64_t)blockIdx.x * 2 + 0) * D + d] = smin[0];
-      vmm_part[((int64_t)blockIdx.x * 2 + 1) * D + d] = smax[0];
+      vmm_part[((int64_t)blockIdx.x * 2 + 0) * D + d] = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
+      vmm_part[((int64_t)blockIdx.x * 2 + 1) * D + d] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
     }
   }
 }
