@@ -412,3 +412,37 @@ def test_run_clonealign_restarts_on_one_resident_engine_equal_separate_fits(big)
     assert np.array_equal(best["ml_params"]["clone_probs"], ref["ml_params"]["clone_probs"])
     assert list(best["clone"]) == list(ref["clone"])
     np.testing.assert_allclose(best["correlations"], ref["correlations"], rtol=0, atol=1e-12, equal_nan=True)
+
+
+def test_fused_loop_at_shard_size_matches_c_oracle():
+    """40k cells x 1.2k genes x 8 clones through ca_run: the decomposition of the large shapes (96-cell blocks plus the
+    second block size of k_fwd_cell_mix, several row groups of the Y stream, every CU busy in the backward sweep) against the
+    C/OpenMP float64 oracle driven call by call."""
+    from clonealign_amd.engine import HipEngine
+    from clonealign_amd.inference import run_vi_loop
+    from clonealign_amd.rng import EpsStream
+    from oracle.c_port import CPortModel
+    N, G, C = 40_000, 1_200, 8
+    Yd, L, psi0, loc0 = _synth(N, G, C, seed=5)
+    Y = Yd.cpu().numpy().astype(np.float64)
+    eng = HipEngine(Y, L, psi0, loc0, 1)
+    ora = CPortModel(Y, L, psi0, loc0, 1, dtype="float32")
+    try:
+        assert eng.info()["fwd_cell"] == 1
+        n_iter = 5
+        tr = np.asarray(eng.run(EpsStream(9, 1, G), n_iter, 1e-12))
+        to = np.asarray(run_vi_loop(ora, EpsStream(9, 1, G), n_iter, 1e-12))
+        assert tr.shape == to.shape == (n_iter + 1,)
+        assert np.abs(tr - to).max() <= 1e-5 * np.abs(to).max(), (tr, to)
+        fe = eng.final_elbo(np.stack([eps_for(1, G, 70 + i) for i in range(3)]), 3)
+        fo = np.array([ora.elbo(eps_for(1, G, 70 + i)) for i in range(3)])
+        assert np.abs(fe - fo).max() <= 1e-5 * np.abs(fo).max()
+        se, so = eng.get_state(), ora.get_state()
+        for n in ("W", "v", "psi", "alpha_unconstr", "loc", "ls", "gamma_logits"):
+            err = np.abs(se[n] - so[n]).max() / max(np.abs(so[n]).max(), 1e-30)
+            assert err < 2e-4, (n, err)
+        pe, po = eng.get("clone_probs"), ora.get_params()["clone_probs"]
+        robust = np.abs(po.max(1) - 0.95) > 1e-3
+        assert np.array_equal(pe.argmax(1)[robust], po.argmax(1)[robust])
+    finally:
+        eng.close(); ora.close()
