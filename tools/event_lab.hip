@@ -38,5 +38,46 @@ int main() {
   run(0, "no wait (same stream back to back)");
   run(1, "wait on an event completed 18 us earlier");
   run(2, "wait on an event completing with k0");
+  // The same dependency through stream memory operations (hipStreamWriteValue32 on the producer, hipStreamWaitValue32 on the
+  // consumer) instead of an event, and what the producer side pays: the kernel that follows the record / the write.
+  int can = 0;
+  CK(hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, 0));
+  printf("hipDeviceAttributeCanUseStreamWaitValue = %d\n", can);
+  unsigned* flag = nullptr;
+  CK(hipExtMallocWithFlags((void**)&flag, 8, hipMallocSignalMemory));
+  CK(hipMemset(flag, 0, 8));
+  unsigned seq = 0;
+  auto run2 = [&](int mode, const char* name) -> int {   // modes: 0/1 = value written early / late; 2/3 = producer side, event / value
+    std::vector<double> gaps;
+    for (int rep = 0; rep < 20; ++rep) {
+      ++seq;
+      CK(hipEventRecord(ev2, a)); CK(hipStreamWaitEvent(b, ev2, 0));
+      if (mode <= 1) {
+        hipLaunchKernelGGL(spin, dim3(1), dim3(64), 0, b, t, 2, mode == 0 ? 200 : 1950);
+        CK(hipStreamWriteValue32(b, flag, seq, 0));
+        hipLaunchKernelGGL(spin, dim3(1), dim3(64), 0, a, t, 0, 2000);
+        CK(hipStreamWaitValue32(a, flag, seq, hipStreamWaitValueGte, 0xFFFFFFFFu));
+        hipLaunchKernelGGL(spin, dim3(1), dim3(64), 0, a, t, 1, 500);
+      } else {
+        hipLaunchKernelGGL(spin, dim3(1), dim3(64), 0, b, t, 0, 1000);
+        if (mode == 2) { CK(hipEventRecord(ev, b)); CK(hipStreamWaitEvent(a, ev, 0)); }
+        else { CK(hipStreamWriteValue32(b, flag, seq, 0)); CK(hipStreamWaitValue32(a, flag, seq, hipStreamWaitValueGte, 0xFFFFFFFFu)); }
+        hipLaunchKernelGGL(spin, dim3(1), dim3(64), 0, b, t, 1, 500);     // the producer's next kernel
+        hipLaunchKernelGGL(spin, dim3(1), dim3(64), 0, a, t, 3, 500);     // the consumer
+      }
+      CK(hipStreamSynchronize(a)); CK(hipStreamSynchronize(b));
+      CK(hipMemcpy(h.data(), t, 64 * 8, hipMemcpyDeviceToHost));
+      if (rep >= 4) gaps.push_back((double)(h[2] - h[1]) / 100.0);
+    }
+    std::sort(gaps.begin(), gaps.end());
+    printf("%-60s median %.1f us (min %.1f, max %.1f)\n", name, gaps[gaps.size() / 2], gaps.front(), gaps.back());
+    return 0;
+  };
+  if (can) {
+    run2(0, "wait on a VALUE written 18 us earlier: k0 end -> k1 start");
+    run2(1, "wait on a VALUE written as k0 ends: k0 end -> k1 start");
+  }
+  run2(2, "producer side, event record + cross-stream wait: kb end -> next");
+  if (can) run2(3, "producer side, value write + cross-stream value wait: kb end -> next");
   return 0;
 }
