@@ -1,6 +1,6 @@
 """Summarise one tools/prof_round.sh output directory into the files kept under profiles/.
 
-  python tools/summarise_prof.py gpurun_out/prof_v10 r01_v10
+  python tools/summarise_prof.py gpurun_out/prof_v10 r01_v11
 
 writes profiles/<tag>_kernel_stats.csv (rocprofv3 --stats), <tag>_bench.json (the default bench line),
 <tag>_sq_counters.json (per-launch means of the SQ counters) and <tag>_pmc_hbm.json (HBM bytes per launch:
