@@ -149,6 +149,21 @@ __global__ void k_convert_y(const ST* __restrict__ src, YT* __restrict__ dst, in
   dst[i] = out;
 }
 
+// Row / column selection at upload (ca_problem.cell_index / gene_index): dst [N][G] row-major in the source's own type,
+// element (n, g) = src[cell_index[n] * sn + gene_index[g] * sg].  The raw matrix is uploaded once and cut here instead of
+// on the host (the reference copies Y[cells, genes] in R: R/preprocess.R:141-147, R/inference-tflow.R:117-124).
+template <typename ST>
+__global__ void k_gather_y(const ST* __restrict__ src, ST* __restrict__ dst, int64_t N, int G, int64_t sn, int64_t sg,
+                           const int64_t* __restrict__ cell_index, const int32_t* __restrict__ gene_index) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * (int64_t)G) return;
+  const int64_t n = i / G;
+  const int g = (int)(i - n * G);
+  const int64_t rn = cell_index ? cell_index[n] : n;
+  const int64_t rg = gene_index ? (int64_t)gene_index[g] : (int64_t)g;
+  dst[i] = src[rn * sn + rg * sg];
+}
+
 // u8 storage with an overflow list: the dense byte holds min(y, 255); the (rare) excess y - 255 goes to a
 // COO list (appended in arbitrary order here, sorted on the host afterwards so that every later sum over it
 // has a fixed order).

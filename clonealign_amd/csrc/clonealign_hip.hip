@@ -138,6 +138,10 @@ struct ca_engine {
   // matrix-core backward sweep (k_bwd_mfma): bf16 parts of coef, its own cell split
   bool bwd_mfma = false; unsigned short* coefq = nullptr; int64_t N16 = 0, cchunk_m = 0; int csplit_m = 1, nwt = 0;
   uint64_t draw = 0;  // built-in stream position
+  // count-matrix products on the int8 matrix cores (ca_ymfma.hip.h)
+  bool y_mfma = false;
+  // one-shot peer-to-peer all-reduce (set by ca_comm_init when every peer is reachable)
+  struct ca_p2p* p2p = nullptr;
   // ---- comm
   ca_nccl_comm comm = nullptr;
   ca_host_allreduce_fn host_ar = nullptr; void* host_ar_user = nullptr; double* host_ar_buf = nullptr; int64_t host_ar_cap = 0;
@@ -229,6 +233,21 @@ int prof_end(ca_engine* h) {
   } while (0)
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Configuration comes from ca_options (variant_off / tune).  The process environment is consulted ONLY when
+// CLONEALIGN_DEBUG_ENV is set (tools/tune.py, tools/fuzz_parity.py): NAME=0 switches a variant off, NAME=<n> sets a parameter.
+inline bool debug_env() { return getenv("CLONEALIGN_DEBUG_ENV") != nullptr; }
+inline bool variant_on(const ca_engine* h, unsigned bit, const char* env) {
+  if (h->opt.variant_off & bit) return false;
+  if (debug_env()) if (const char* e = getenv(env)) return atoi(e) != 0;
+  return true;
+}
+inline int tune_val(const ca_engine* h, int id, const char* env) {
+  int v = h->opt.tune[id];
+  if (v == 0 && debug_env()) if (const char* e = getenv(env)) { v = atoi(e); if (id == CA_TUNE_FC_NBIG && v == 0) v = -1; }
+  return v;
+}
+inline bool verbose(const ca_engine* h) { return (h->opt.variant_off & CA_OPT_VERBOSE) || (debug_env() && getenv("CA_VERBOSE")); }
 
 // Split count s in [1, smax] for a grid of xb * s equal blocks on `slots` resident block slots: fewest rounds per unit
 // of work (a grid just past a multiple of the slots runs a nearly empty last round), every extra split charged
@@ -1163,19 +1182,67 @@ int scan_and_convert(ca_engine* h, const ST* src_dev, int64_t sn, int64_t sg) {
   return CA_OK;
 }
 
-int upload_y(ca_engine* h, const ca_problem* p) {
+template <typename ST>
+int gather_y(ca_engine* h, const void* src, void** dst, int64_t sn, int64_t sg, const int64_t* ci_dev, const int32_t* gi_dev) {
   const int64_t total = h->N * (int64_t)h->G;
+  HIPCK(h, hipMalloc(dst, (size_t)total * sizeof(ST)));
+  hipLaunchKernelGGL((k_gather_y<ST>), dim3(cdiv(total, CA_TB)), dim3(CA_TB), 0, h->stream, (const ST*)src, (ST*)*dst, h->N, h->G, sn, sg,
+                     ci_dev, gi_dev);
+  HIPCK(h, hipGetLastError());
+  HIPCK(h, hipStreamSynchronize(h->stream));
+  return CA_OK;
+}
+
+int upload_y(ca_engine* h, const ca_problem* p) {
+  // the caller's matrix: N_src x G_src when a selection is given (ca_problem.cell_index / gene_index), else N x G
+  const bool sel = p->cell_index || p->gene_index;
+  const int64_t Ns = sel ? p->N_src : h->N;
+  const int64_t Gs = sel ? (int64_t)p->G_src : (int64_t)h->G;
+  const int64_t total = Ns * Gs;
   size_t esz = p->y_dtype == CA_F64 ? 8 : (p->y_dtype == CA_F32 || p->y_dtype == CA_I32) ? 4 : p->y_dtype == CA_U16 ? 2 : 1;
   const void* src = p->Y;
   void* staging = nullptr;
+  void* cut = nullptr;
+  int64_t* ci_dev = nullptr; int32_t* gi_dev = nullptr;
+  auto cleanup = [&]() { if (staging) hipFree(staging); if (cut) hipFree(cut); if (ci_dev) hipFree(ci_dev); if (gi_dev) hipFree(gi_dev); };
   if (!p->y_on_device) {
     HIPCK(h, hipMalloc(&staging, (size_t)total * esz));
-    HIPCK(h, hipMemcpy(staging, p->Y, (size_t)total * esz, hipMemcpyHostToDevice));
+    if (hipMemcpy(staging, p->Y, (size_t)total * esz, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); h->err = "upload of the count matrix failed"; return CA_ERR_HIP; }
     src = staging;
   }
-  const int64_t sn = p->layout == CA_COL_MAJOR ? 1 : h->G;
-  const int64_t sg = p->layout == CA_COL_MAJOR ? h->N : 1;
-  int rc;
+  int64_t sn = p->layout == CA_COL_MAJOR ? 1 : Gs;
+  int64_t sg = p->layout == CA_COL_MAJOR ? Ns : 1;
+  int rc = CA_OK;
+  if (sel) {
+    // selection lists: validated on the host (strictly increasing, in range), applied by a device gather into a compact
+    // row-major copy of the source type -- the storage scan / conversion below then sees only the selected counts
+    auto bad = [&](const char* m) { cleanup(); h->err = m; return CA_ERR_INVALID; };
+    if (p->cell_index) {
+      for (int64_t n = 0; n < h->N; ++n)
+        if (p->cell_index[n] < 0 || p->cell_index[n] >= Ns || (n > 0 && p->cell_index[n] <= p->cell_index[n - 1]))
+          return bad("cell_index must be strictly increasing and within [0, N_src)");
+      if (hipMalloc((void**)&ci_dev, (size_t)h->N * sizeof(int64_t)) != hipSuccess ||
+          hipMemcpy(ci_dev, p->cell_index, (size_t)h->N * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) return bad("cell_index upload failed");
+    } else if (h->N != Ns) return bad("N must equal N_src when cell_index is NULL");
+    if (p->gene_index) {
+      for (int g = 0; g < h->G; ++g)
+        if (p->gene_index[g] < 0 || p->gene_index[g] >= Gs || (g > 0 && p->gene_index[g] <= p->gene_index[g - 1]))
+          return bad("gene_index must be strictly increasing and within [0, G_src)");
+      if (hipMalloc((void**)&gi_dev, (size_t)h->G * sizeof(int32_t)) != hipSuccess ||
+          hipMemcpy(gi_dev, p->gene_index, (size_t)h->G * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) return bad("gene_index upload failed");
+    } else if (h->G != Gs) return bad("G must equal G_src when gene_index is NULL");
+    switch (p->y_dtype) {
+      case CA_F64: rc = gather_y<double>(h, src, &cut, sn, sg, ci_dev, gi_dev); break;
+      case CA_F32: rc = gather_y<float>(h, src, &cut, sn, sg, ci_dev, gi_dev); break;
+      case CA_I32: rc = gather_y<int32_t>(h, src, &cut, sn, sg, ci_dev, gi_dev); break;
+      case CA_U16: rc = gather_y<uint16_t>(h, src, &cut, sn, sg, ci_dev, gi_dev); break;
+      case CA_U8: rc = gather_y<uint8_t>(h, src, &cut, sn, sg, ci_dev, gi_dev); break;
+      default: h->err = "unknown y_dtype"; rc = CA_ERR_INVALID;
+    }
+    if (rc != CA_OK) { cleanup(); return rc; }
+    if (staging) { hipFree(staging); staging = nullptr; }
+    src = cut; sn = h->G; sg = 1;
+  }
   switch (p->y_dtype) {
     case CA_F64: rc = scan_and_convert<double>(h, (const double*)src, sn, sg); break;
     case CA_F32: rc = scan_and_convert<float>(h, (const float*)src, sn, sg); break;
@@ -1184,7 +1251,7 @@ int upload_y(ca_engine* h, const ca_problem* p) {
     case CA_U8: rc = scan_and_convert<uint8_t>(h, (const uint8_t*)src, sn, sg); break;
     default: h->err = "unknown y_dtype"; rc = CA_ERR_INVALID;
   }
-  if (staging) hipFree(staging);
+  cleanup();
   return rc;
 }
 
@@ -1196,7 +1263,7 @@ void launch_prep(ca_engine* h, const double* logL, const double* extra) {
 
 template <>
 void launch_prep<uint8_t>(ca_engine* h, const double* logL, const double* extra) {
-  if (getenv("CA_PREP_OLD")) {
+  if (!variant_on(h, CA_VAR_PREP_FAST, "CA_PREP_FAST")) {
     hipLaunchKernelGGL((k_prep_cells<uint8_t>), dim3((unsigned)h->N), dim3(CA_TB), 0, h->stream, (const uint8_t*)h->Y, logL, extra, h->A,
                        h->cn, h->s64, h->s32, h->N, h->G, h->Gp, h->C, h->ovf_rowptr, h->ovf_col, h->ovf_val);
     return;
@@ -1218,14 +1285,14 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   HIPCK(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
   HIPCK(h, hipEventCreateWithFlags(&h->ev_params, hipEventDisableTiming));
   HIPCK(h, hipEventCreateWithFlags(&h->ev_ydone, hipEventDisableTiming));
-  if (const char* e = getenv("CA_ASYNC_Y")) h->async_y = atoi(e) != 0;
+  h->async_y = variant_on(h, CA_VAR_ASYNC_Y, "CA_ASYNC_Y");
   HIPCK(h, hipHostMalloc((void**)&h->host_pinned, 64 * sizeof(double)));
   memset(h->host_pinned, 0, 64 * sizeof(double));
   if (hipHostGetDevicePointer((void**)&h->host_dev, h->host_pinned, 0) != hipSuccess) { h->host_dev = nullptr; (void)hipGetLastError(); }
   h->mon_tail = no_small_args();
-  if (const char* e = getenv("CA_TAIL_FUSE")) h->tail_fuse = atoi(e) != 0;
-  if (const char* e = getenv("CA_PRE")) h->pre_ok = atoi(e) != 0;
-  if (const char* e = getenv("CA_PAIR_ELBO")) h->pair_elbo = atoi(e) != 0;
+  h->tail_fuse = variant_on(h, CA_VAR_TAIL_FUSE, "CA_TAIL_FUSE");
+  h->pre_ok = variant_on(h, CA_VAR_PRE, "CA_PRE");
+  h->pair_elbo = variant_on(h, CA_VAR_PAIR_ELBO, "CA_PAIR_ELBO");
   CACK(upload_y(h, p));
   const int G = h->G, C = h->C, K = h->K, P = h->P, S = h->S, D = h->D;
   const int64_t Nn = h->N;
@@ -1244,22 +1311,23 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   // partial that the cell epilogue has to read back (at 12.5k cells 78 slices cost 2x the sweep itself)
   h->gsplit = std::max(1, std::min(std::min(target_blocks / std::max(nfb, 1), 16), std::max(1, G / 64)));
   h->gsplit = std::max(h->gsplit, cdiv(G, 1024));      // LDS slice: at most 1024 genes x (8 + D) floats = 64 KB
-  if (const char* e = getenv("CA_GSPLIT")) h->gsplit = std::max(std::max(1, atoi(e)), cdiv(G, 1024));   // tuning override
+  if (const int t = tune_val(h, CA_TUNE_GSPLIT, "CA_GSPLIT")) h->gsplit = std::max(std::max(1, t), cdiv(G, 1024));   // tuning override
   h->gchunk = cdiv(G, h->gsplit);
   h->gsplit = cdiv(G, h->gchunk);
   // genes per lane of the backward sweep: more genes amortise the per-cell wave reduction (tools/bwd_lab2.hip)
   h->RG = G >= 1024 ? 4 : 1;   // RG = 8 measured equal in the engine (272 vs 276 us): kept selectable, not default
-  if (const char* e = getenv("CA_RG")) { const int r = atoi(e); if (r == 1 || r == 4 || r == 8) h->RG = r; }
+  if (const int r = tune_val(h, CA_TUNE_RG, "CA_RG")) { if (r == 1 || r == 4 || r == 8) h->RG = r; }
   h->ntile = cdiv(G, 64 * h->RG);
   const int gblocks = cdiv(h->ntile, CA_TB / 64);
   h->csplit = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(target_blocks, gblocks), std::max<int64_t>(1, Nn / 64)));
-  if (const char* e = getenv("CA_CSPLIT")) h->csplit = std::max(1, atoi(e));   // tuning override
+  if (const int t = tune_val(h, CA_TUNE_CSPLIT, "CA_CSPLIT")) h->csplit = std::max(1, t);   // tuning override
   h->cchunk = (Nn + h->csplit - 1) / h->csplit;
   h->csplit = cdiv(Nn, h->cchunk);
   h->TR = 128;
-  if (const char* e = getenv("CA_TR")) h->TR = std::min(128, std::max(1, atoi(e)));   // tuning override (k_ypass keeps psi of <= 128 rows)
+  const int tr_set = tune_val(h, CA_TUNE_TR, "CA_TR");
+  if (tr_set) h->TR = std::min(128, std::max(1, tr_set));   // tuning override (k_ypass keeps psi of <= 128 rows)
   h->nrb = cdiv(Nn, h->TR);
-  while (!getenv("CA_TR") && (int64_t)h->nrb * h->nseg < 4 * h->n_cu && h->TR > 32) { h->TR /= 2; h->nrb = cdiv(Nn, h->TR); }
+  while (!tr_set && (int64_t)h->nrb * h->nseg < 4 * h->n_cu && h->TR > 32) { h->TR /= 2; h->nrb = cdiv(Nn, h->TR); }
   h->nrg = cdiv(h->nrb, CA_TB / 64);
   // ---- constants
   std::vector<double> Lrm((size_t)G * C), logL((size_t)G * C);
@@ -1304,7 +1372,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
       uint32_t u; memcpy(&u, &f, 4);
       if ((double)f != v || (u & 0xFFFFu) != 0) { exact = false; break; }
     }
-    h->bwd_mfma = exact && (D == 1 || D == 2) && h->nchunk == 1 && !(getenv("CA_BWD_MFMA") && atoi(getenv("CA_BWD_MFMA")) == 0);
+    h->bwd_mfma = exact && (D == 1 || D == 2) && h->nchunk == 1 && variant_on(h, CA_VAR_BWD_MFMA, "CA_BWD_MFMA");
     h->N16 = (Nn + 15) / 16 * 16;
     if (h->bwd_mfma) {
       h->nwt = cdiv(G, 4 * 16);
@@ -1320,7 +1388,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
         const int smax = (int)std::max<int64_t>(1, std::min<int64_t>(Nn / 256, cdiv(2 * (int64_t)per_cu * h->n_cu, xb)));
         h->csplit_m = pick_split(xb, (int64_t)per_cu * h->n_cu, smax, 1e-4);
       }
-      if (const char* e = getenv("CA_CSPLIT_M")) h->csplit_m = std::max(1, atoi(e));
+      if (const int t = tune_val(h, CA_TUNE_CSPLIT_M, "CA_CSPLIT_M")) h->csplit_m = std::max(1, t);
       h->csplit_m = (int)std::max<int64_t>(h->csplit_m, (Nn * D + 4079) / 4080);   // LDS: 4 waves x cchunk x D floats <= 64 KB
       h->cchunk_m = ((Nn + h->csplit_m - 1) / h->csplit_m + 15) / 16 * 16;
       h->csplit_m = cdiv(Nn, h->cchunk_m);
@@ -1364,12 +1432,12 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   // ---- pass buffers
   CACK(dalloc(h, &h->mu32, (int64_t)S * G));
   CACK(dalloc(h, &h->Mb, (int64_t)S * h->nchunk * G * CA_CW));
-  h->fused_ok = (S == 1 && C <= CA_CW) && !(getenv("CA_FUSED") && atoi(getenv("CA_FUSED")) == 0);
+  h->fused_ok = (S == 1 && C <= CA_CW) && variant_on(h, CA_VAR_FUSED, "CA_FUSED");
   if (h->fused_ok) {
     h->frow = (2 * C <= 8) ? 8 : 16;
     // matrix-core forward sweep (k_fwd_mfma): D in {1, 2}; few gene slices, streamed through LDS
-    h->fwd_mfma = (D == 1 || D == 2) && !(getenv("CA_FWD_MFMA") && atoi(getenv("CA_FWD_MFMA")) == 0);
-    h->fwd_cell = h->fwd_mfma && h->tail_fuse && !(getenv("CA_FWD_CELL") && atoi(getenv("CA_FWD_CELL")) == 0);
+    h->fwd_mfma = (D == 1 || D == 2) && variant_on(h, CA_VAR_FWD_MFMA, "CA_FWD_MFMA");
+    h->fwd_cell = h->fwd_mfma && h->tail_fuse && variant_on(h, CA_VAR_FWD_CELL, "CA_FWD_CELL");
     {
       // cells per block of k_fwd_cell: 16 * TL -- measured, not derived.  96-cell blocks (fewest re-reads of the B operand
       // from L2) as soon as there is one full round of them, the launch then carries a second, 32-cell block size for the
@@ -1379,7 +1447,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
       // Small shards: 32-cell blocks, or CUs are left with one block or none (25k: 7619 / 7443 / 6701 for TL = 2 / 4 / 6
       // without the second block size, 7535 for 6 with it).
       h->fc_tl = (h->fwd_cell && cdiv(Nn, 64) < 2 * h->n_cu) ? 2 : 6;
-      if (const char* e = getenv("CA_FC_TL")) { const int t = atoi(e); if (t == 2 || t == 4 || t == 5 || t == 6 || t == 8) h->fc_tl = t; }
+      if (const int t = tune_val(h, CA_TUNE_FC_TL, "CA_FC_TL")) { if (t == 2 || t == 4 || t == 5 || t == 6 || t == 8) h->fc_tl = t; }
       h->ncblk_f = cdiv(Nn, 16 * h->fc_tl);
       // two block sizes in one launch (k_fwd_cell_mix)
       if (h->fwd_cell && (h->fc_tl == 4 || h->fc_tl == 5 || h->fc_tl == 6) && (D == 1 || D == 2)) {
@@ -1387,7 +1455,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
         // 2642 -- what pays is every CU getting the same number of big blocks, so: whole multiples of the CU count in big
         // blocks, the remainder (less than one big block per CU) in small ones
         int nbig = (h->ncblk_f / h->n_cu) * h->n_cu;
-        if (const char* e = getenv("CA_FC_NBIG")) nbig = atoi(e);
+        if (const int t = tune_val(h, CA_TUNE_FC_NBIG, "CA_FC_NBIG")) nbig = t < 0 ? 0 : t;
         if (nbig > 0 && h->ncblk_f > nbig) {
           h->fc_nbig = nbig;
           h->ncblk_f = nbig + cdiv(Nn - (int64_t)nbig * 16 * h->fc_tl, 32);
@@ -1407,7 +1475,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
         // every gene slice adds an N x 16 float partial (written here, re-read by the cell epilogue): ~2 % of the sweep
         h->fsplit = pick_split(cblocks, (int64_t)per_cu * h->n_cu, std::max(1, std::min(16, h->nk32 / CA_FM_KC)), 0.02);
       }
-      if (const char* e = getenv("CA_FSPLIT")) h->fsplit = std::max(1, std::min(atoi(e), h->nk32));
+      if (const int t = tune_val(h, CA_TUNE_FSPLIT, "CA_FSPLIT")) h->fsplit = std::max(1, std::min(t, h->nk32));
       h->fkchunk = cdiv(h->nk32, h->fsplit);
       h->fsplit = cdiv(h->nk32, h->fkchunk);
       zsplit = h->fsplit;
@@ -1421,7 +1489,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     CACK(dalloc(h, &h->gene_partB_alt, (int64_t)h->ngblk * (3 + K)));
     if (!h->fwd_cell) CACK(dalloc(h, &h->Zpart2, (int64_t)zsplit * Nn * h->frow));   // k_fwd_cell keeps Z in the block
   }
-  if (getenv("CA_VERBOSE"))
+  if (verbose(h))
     fprintf(stderr, "[clonealign_hip] N=%lld G=%d C=%d D=%d n_cu=%d gsplit=%d gchunk=%d csplit=%d fused=%d fwd_mfma=%d fsplit=%d fkchunk=%d "
             "bwd_mfma=%d csplit_m=%d cchunk_m=%lld nwt=%d fwd_cell=%d fc_tl=%d fc_nbig=%d ncblk_f=%d\n", (long long)Nn, G, C, D, h->n_cu, h->gsplit,
             h->gchunk, h->csplit, (int)h->fused_ok, (int)h->fwd_mfma, h->fsplit, h->fkchunk, (int)h->bwd_mfma, h->csplit_m,
@@ -1649,6 +1717,7 @@ int ca_create(const ca_problem* p, const ca_options* o, ca_handle* out) {
   if (p->K > 0 && !p->psi0) return bad("psi0 is required when K > 0");
   if (p->P > 0 && !p->X) return bad("X is required when P > 0");
   if (opt.world < 1 || opt.rank < 0 || opt.rank >= opt.world) return bad("bad rank/world");
+  if ((p->cell_index || p->gene_index) && (p->N_src < p->N || p->G_src < p->G)) return bad("N_src / G_src must be at least N / G when a selection is given");
   ca_engine* h = new ca_engine();
   h->N = p->N; h->G = p->G; h->C = p->C; h->K = p->K; h->P = p->P; h->S = p->S; h->D = D;
   h->layout = p->layout; h->opt = opt; h->device = opt.device;
@@ -1688,6 +1757,9 @@ int ca_get_info(ca_handle h, ca_info* i) {
   i->y_storage = h->ystore; i->y_bytes_per_elem = h->ybytes; i->y_device_bytes = h->y_dev_bytes; i->device_bytes = h->dev_bytes;
   i->gsplit = h->gsplit; i->csplit = h->csplit; i->n_cu = h->n_cu; i->fused_sweep = h->fused_ok ? 1 : 0;
   i->fwd_mfma = (h->fused_ok && h->fwd_mfma) ? 1 : 0; i->bwd_mfma = h->bwd_mfma ? 1 : 0; i->fsplit = h->fsplit; i->fwd_cell = (h->fused_ok && h->fwd_cell) ? 1 : 0;
+  i->y_mfma = h->y_mfma ? 1 : 0;
+  i->transport = h->p2p ? CA_TRANSPORT_P2P : h->comm ? CA_TRANSPORT_RCCL : h->host_ar ? CA_TRANSPORT_HOST : CA_TRANSPORT_NONE;
+  i->red_n = h->red_n;
   return CA_OK;
 }
 
@@ -1778,6 +1850,11 @@ int ca_gradients(ca_handle h, const float* eps, double* elbo) {
 }
 
 int ca_run(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_stream, int64_t n_draws, double* trace, int32_t* n_elbo) {
+  return ca_run_ex(h, max_iter, rel_tol, eps_stream, n_draws, trace, n_elbo, nullptr, nullptr);
+}
+
+int ca_run_ex(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_stream, int64_t n_draws, double* trace, int32_t* n_elbo,
+              ca_poll_fn poll, void* user) {
   if (!h || !trace || !n_elbo || max_iter < 0) return CA_ERR_INVALID;
   HIPCK(h, hipSetDevice(h->device));
   const int64_t need = 2 + 2 * (int64_t)max_iter;
@@ -1793,6 +1870,8 @@ int ca_run(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_strea
   CACK(wait_host_elbo(h, h->host_seq, h->elbo_dev, &val));
   trace[0] = val; *n_elbo = 1;
   if (std::isnan(val)) { h->err = "Initial elbo is NA"; return CA_ERR_NAN; }   // :374-376
+  // (a stop request leaves the speculative backward sweep of the next train pass queued: it changes no variable)
+  if (poll && poll(user, 0, val) != 0) { h->err = "interrupted by the poll callback"; return CA_INTERRUPTED; }
   double diffs[10];
   for (double& d : diffs) d = 1e3;                                      // :379
   for (int i = 1; i <= max_iter; ++i) {
@@ -1813,6 +1892,7 @@ int ca_run(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_strea
     for (double d : diffs) mean += std::fabs(d);
     mean /= 10.0;
     if (std::isnan(mean)) { h->err = "missing value where TRUE/FALSE needed"; return CA_ERR_NAN; }  // R's if (NA) at :414
+    if (poll && poll(user, i, nv) != 0) { h->err = "interrupted by the poll callback"; return CA_INTERRUPTED; }
     if (mean < rel_tol) break;                                          // :414-415
   }
   return CA_OK;
@@ -1830,7 +1910,7 @@ int ca_iterate(ca_handle h, int32_t n_iter, const float* eps_stream, int64_t n_d
     CACK(monitor_pass(h, 2 * (int64_t)i + 1, i + 1 < n_iter ? 2 * (int64_t)i + 2 : -1, h->elbo_dev + i));
   }
   CACK(flush_mon_tail(h));
-  if (getenv("CA_VERBOSE") && n_iter > 0)
+  if (verbose(h) && n_iter > 0)
     fprintf(stderr, "[clonealign_hip] ca_iterate: host enqueue %.1f us per iteration\n",
             std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host0).count() / n_iter);
   if (last_elbo && n_iter > 0) return read_doubles(h, h->elbo_dev + (n_iter - 1), last_elbo, 1);

@@ -14,16 +14,24 @@ LIB_PATH = os.path.join(_HERE, "libclonealign_hip.so")
 
 CA_OK = 0
 CA_ERR_NAN = 4
+CA_INTERRUPTED = 7
+CA_ABI_VERSION = 2
 CA_F64, CA_F32, CA_I32, CA_U16, CA_U8 = 0, 1, 2, 3, 4
 CA_ROW_MAJOR, CA_COL_MAJOR = 0, 1
 YSTORE = {"auto": 0, "f32": 1, "u16": 2, "u8": 3}
 YSTORE_NAME = {v: k for k, v in YSTORE.items()}
 KERNEL_NAMES = ("fwd", "bwd", "ypass", "cell", "other")
+# ca_variant bits (ca_options.variant_off: a set bit switches the variant OFF) and ca_tune_id slots
+VARIANTS = {"fused": 1 << 0, "fwd_mfma": 1 << 1, "fwd_cell": 1 << 2, "bwd_mfma": 1 << 3, "tail_fuse": 1 << 4, "async_y": 1 << 5,
+            "pre": 1 << 6, "pair_elbo": 1 << 7, "prep_fast": 1 << 8, "y_mfma": 1 << 9, "p2p": 1 << 10}
+OPT_VERBOSE = 0x80000000
+TUNE = {"gsplit": 0, "fsplit": 1, "fc_tl": 2, "fc_nbig": 3, "csplit": 4, "csplit_m": 5, "tr": 6, "rg": 7}
+TRANSPORT_NAME = {0: "none", 1: "rccl", 2: "host", 3: "p2p"}
 
 EXPORTS = (
     "ca_abi_version", "ca_default_options", "ca_create", "ca_destroy", "ca_last_error", "ca_get_info",
     "ca_synchronize", "ca_comm_unique_id", "ca_comm_init", "ca_set_host_allreduce", "ca_gamma_init", "ca_elbo", "ca_elbo_terms",
-    "ca_step", "ca_gradients", "ca_run", "ca_iterate", "ca_final_elbo", "ca_init_psi_pca", "ca_clone_gene_sums", "ca_get_param", "ca_set_param",
+    "ca_step", "ca_gradients", "ca_run", "ca_run_ex", "ca_iterate", "ca_final_elbo", "ca_init_psi_pca", "ca_clone_gene_sums", "ca_get_param", "ca_set_param",
     "ca_get_gradient", "ca_reinit", "ca_get_kernel_times", "ca_reset_kernel_times", "ca_set_profile", "ca_eps_draw", "ca_allele_loglik", "ca_preprocess",
 )
 
@@ -32,14 +40,15 @@ class CaProblem(C.Structure):
     _fields_ = [("N", C.c_int64), ("G", C.c_int32), ("C", C.c_int32), ("K", C.c_int32), ("P", C.c_int32),
                 ("S", C.c_int32), ("layout", C.c_int32), ("y_dtype", C.c_int32), ("y_on_device", C.c_int32),
                 ("Y", C.c_void_p), ("L", C.c_void_p), ("psi0", C.c_void_p), ("loc0", C.c_void_p),
-                ("X", C.c_void_p), ("extra_loglik", C.c_void_p)]
+                ("X", C.c_void_p), ("extra_loglik", C.c_void_p),
+                ("N_src", C.c_int64), ("G_src", C.c_int32), ("cell_index", C.c_void_p), ("gene_index", C.c_void_p)]
 
 
 class CaOptions(C.Structure):
     _fields_ = [("learning_rate", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
                 ("adam_eps", C.c_double), ("seed", C.c_uint64), ("device", C.c_int32),
                 ("y_storage", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32), ("profile", C.c_int32),
-                ("reserved", C.c_int32 * 7)]
+                ("variant_off", C.c_uint32), ("tune", C.c_int32 * 8), ("reserved", C.c_int32 * 6)]
 
 
 class CaInfo(C.Structure):
@@ -47,7 +56,8 @@ class CaInfo(C.Structure):
                 ("S", C.c_int32), ("y_storage", C.c_int32), ("y_bytes_per_elem", C.c_int32),
                 ("y_device_bytes", C.c_int64), ("device_bytes", C.c_int64), ("gsplit", C.c_int32),
                 ("csplit", C.c_int32), ("n_cu", C.c_int32), ("fused_sweep", C.c_int32), ("fwd_mfma", C.c_int32),
-                ("bwd_mfma", C.c_int32), ("fsplit", C.c_int32), ("fwd_cell", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("bwd_mfma", C.c_int32), ("fsplit", C.c_int32), ("fwd_cell", C.c_int32), ("y_mfma", C.c_int32),
+                ("transport", C.c_int32), ("reserved", C.c_int32 * 1), ("red_n", C.c_int64)]
 
 
 class CaPreprocessParams(C.Structure):
@@ -57,6 +67,7 @@ class CaPreprocessParams(C.Structure):
 
 
 HOST_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int64)
+POLL_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_double)
 
 _lib = None
 
@@ -91,6 +102,8 @@ def load_library(path=None):
     lib.ca_gradients.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
     lib.ca_run.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_int64, C.c_void_p,
                            C.POINTER(C.c_int32)]
+    lib.ca_run_ex.argtypes = [C.c_void_p, C.c_int32, C.c_double, C.c_void_p, C.c_int64, C.c_void_p,
+                              C.POINTER(C.c_int32), POLL_FN, C.c_void_p]
     lib.ca_iterate.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_double)]
     lib.ca_final_elbo.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p,
                                   C.POINTER(C.c_double), C.POINTER(C.c_double)]
@@ -141,11 +154,24 @@ class HipEngine:
 
     def __init__(self, Y, L, psi0, loc0, K, S=1, X=None, extra_loglik=None, learning_rate=0.1,
                  device=0, y_storage="auto", seed=0x5EED5EED, rank=0, world=1, profile=False,
-                 y_device_ptr=None, y_device_dtype=None, shape=None, comm_id=None, host_allreduce=None):
+                 y_device_ptr=None, y_device_dtype=None, shape=None, comm_id=None, host_allreduce=None,
+                 layout="row", cell_index=None, gene_index=None, variant_off=(), tune=None, verbose=False):
+        """``layout``: "row" (C / numpy order) or "col" -- every matrix is then handed over column-major (Fortran order),
+        which is what the R caller has (R/inference-tflow.R:190-191,355) and what r_shim/clonealign_hip_shim.c passes; the
+        ``get``/``set`` matrices use the same layout.  ``cell_index`` / ``gene_index``: Y is the RAW matrix and the fit uses
+        these rows / columns of it (ca_problem.cell_index / gene_index); L, psi0, loc0, X, extra_loglik are for the selection.
+        ``variant_off``: names from VARIANTS (or a bitmask) to switch off; ``tune``: {name from TUNE: value}."""
         self.lib = load_library()
         self.h = C.c_void_p()
+        if layout not in ("row", "col"):
+            raise ValueError("layout must be 'row' or 'col'")
+        self.layout = CA_COL_MAJOR if layout == "col" else CA_ROW_MAJOR
+        self._order = "F" if layout == "col" else "C"
+        mat = lambda a, shape=None: np.require(  # noqa: E731  (a contiguous float64 matrix in the problem's layout)
+            np.asarray(a, dtype=np.float64) if shape is None else np.asarray(a, dtype=np.float64).reshape(shape),
+            requirements=[self._order, "A"])
         if y_device_ptr is not None:
-            N, G = shape
+            Ns, Gs = shape
             y_dt = _Y_DTYPES[np.dtype(y_device_dtype)]
             y_ptr = C.c_void_p(int(y_device_ptr))
             self._keep = []
@@ -153,26 +179,31 @@ class HipEngine:
             Y = np.asarray(Y)
             if Y.dtype not in _Y_DTYPES:
                 Y = Y.astype(np.float64)
-            Y = np.ascontiguousarray(Y)
-            N, G = Y.shape
+            Y = np.require(Y, requirements=[self._order, "A"])
+            Ns, Gs = Y.shape
             y_dt = _Y_DTYPES[Y.dtype]
             y_ptr = Y.ctypes.data_as(C.c_void_p)
             self._keep = [Y]
-        L = np.ascontiguousarray(np.asarray(L, dtype=np.float64))
+        ci = None if cell_index is None else np.ascontiguousarray(np.asarray(cell_index, dtype=np.int64))
+        gi = None if gene_index is None else np.ascontiguousarray(np.asarray(gene_index, dtype=np.int32))
+        N = Ns if ci is None else ci.shape[0]
+        G = Gs if gi is None else gi.shape[0]
+        L = mat(L)
         self.N, self.G, self.C = int(N), int(G), int(L.shape[1])
         self.K, self.S = int(K), int(S)
         loc0 = None if loc0 is None else np.ascontiguousarray(np.asarray(loc0, dtype=np.float64))
-        psi0 = np.ascontiguousarray(np.asarray(psi0, dtype=np.float64).reshape(self.N, self.K))
-        Xc = None if X is None else np.ascontiguousarray(np.asarray(X, dtype=np.float64).reshape(self.N, -1))
+        psi0 = mat(psi0, (self.N, self.K))
+        Xc = None if X is None else mat(X, (self.N, -1))
         self.P = 0 if Xc is None else Xc.shape[1]
-        ex = None if extra_loglik is None else np.ascontiguousarray(np.asarray(extra_loglik, dtype=np.float64))
+        ex = None if extra_loglik is None else mat(extra_loglik)
         if L.shape[0] != self.G or (loc0 is not None and loc0.shape[0] != self.G):
             raise ValueError("L / loc0 do not match the number of genes")
-        self._keep += [L, loc0, psi0, Xc, ex]
+        self._keep += [L, loc0, psi0, Xc, ex, ci, gi]
         ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
-        prob = CaProblem(N=self.N, G=self.G, C=self.C, K=self.K, P=self.P, S=self.S, layout=CA_ROW_MAJOR,
+        prob = CaProblem(N=self.N, G=self.G, C=self.C, K=self.K, P=self.P, S=self.S, layout=self.layout,
                          y_dtype=y_dt, y_on_device=int(y_device_ptr is not None), Y=y_ptr, L=ptr(L),
-                         psi0=ptr(psi0) if self.K > 0 else None, loc0=ptr(loc0), X=ptr(Xc), extra_loglik=ptr(ex))
+                         psi0=ptr(psi0) if self.K > 0 else None, loc0=ptr(loc0), X=ptr(Xc), extra_loglik=ptr(ex),
+                         N_src=int(Ns), G_src=int(Gs), cell_index=ptr(ci), gene_index=ptr(gi))
         opt = CaOptions()
         self.lib.ca_default_options(C.byref(opt))
         opt.learning_rate = float(learning_rate)
@@ -181,6 +212,10 @@ class HipEngine:
         opt.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         opt.rank, opt.world = int(rank), int(world)
         opt.profile = 0x1F if profile is True else int(profile)
+        voff = int(variant_off) if isinstance(variant_off, int) else sum(VARIANTS[v] for v in variant_off)
+        opt.variant_off = (voff | (OPT_VERBOSE if verbose else 0)) & 0xFFFFFFFF
+        for k, v in (tune or {}).items():
+            opt.tune[TUNE[k]] = int(v)
         rc = self.lib.ca_create(C.byref(prob), C.byref(opt), C.byref(self.h))
         if rc != CA_OK:
             msg = (self.lib.ca_last_error(None) or b"").decode()
@@ -233,7 +268,7 @@ class HipEngine:
         i = CaInfo()
         self._ck(self.lib.ca_get_info(self.h, C.byref(i)))
         return {f[0]: getattr(i, f[0]) for f in CaInfo._fields_ if f[0] != "reserved"} | {
-            "y_storage_name": YSTORE_NAME[i.y_storage]}
+            "y_storage_name": YSTORE_NAME[i.y_storage], "transport_name": TRANSPORT_NAME.get(i.transport, "?")}
 
     # -------------------------------------------------------------- sess$run equivalents
     def gamma_init(self, eps):
@@ -262,18 +297,41 @@ class HipEngine:
         self._ck(self.lib.ca_gradients(self.h, p, C.byref(out)))
         return {n: self._get(self.lib.ca_get_gradient, n) for n in self.VAR_NAMES}, out.value
 
-    def run(self, eps_stream, max_iter, rel_tol):
-        """Whole loop of R/inference-tflow.R:368-417 in one call; returns the ELBO trace."""
+    def run(self, eps_stream, max_iter, rel_tol, poll=None):
+        """Whole loop of R/inference-tflow.R:368-417 in one call; returns the ELBO trace.
+
+        ``poll(iteration, elbo)`` (optional) is called once per ELBO value as the host learns it (0 = the initial
+        ELBO); a truthy return stops the loop after that iteration (ca_run_ex, CA_INTERRUPTED): the trace so far is
+        returned and ``self.interrupted`` is set."""
         need = 2 + 2 * int(max_iter)
         start = getattr(eps_stream, "draw", None)
         _k, p, n = self._stream(eps_stream, need)
         trace = np.zeros(int(max_iter) + 1, dtype=np.float64)
         cnt = C.c_int32()
-        rc = self.lib.ca_run(self.h, int(max_iter), float(rel_tol), p, n, trace.ctypes.data_as(C.c_void_p),
-                             C.byref(cnt))
+        self.interrupted = False
+        if poll is None:
+            rc = self.lib.ca_run(self.h, int(max_iter), float(rel_tol), p, n, trace.ctypes.data_as(C.c_void_p),
+                                 C.byref(cnt))
+        else:
+            err = []
+
+            def _cb(_user, it, val, _f=poll):
+                try:
+                    return 1 if _f(int(it), float(val)) else 0
+                except BaseException as e:       # never unwind through C: stop the loop, re-raise afterwards
+                    err.append(e)
+                    return 1
+            cb = POLL_FN(_cb)
+            rc = self.lib.ca_run_ex(self.h, int(max_iter), float(rel_tol), p, n, trace.ctypes.data_as(C.c_void_p),
+                                    C.byref(cnt), cb, None)
+            if err:
+                raise err[0]
         if rc == CA_ERR_NAN:
             raise FloatingPointError((self.lib.ca_last_error(self.h) or b"").decode())
-        self._ck(rc)
+        if rc == CA_INTERRUPTED:
+            self.interrupted = True
+        else:
+            self._ck(rc)
         if start is not None:      # a stream object advances only by what the loop consumed
             eps_stream.draw = start + 2 * cnt.value
         return trace[:cnt.value].copy()
@@ -292,8 +350,9 @@ class HipEngine:
 
     def pca_init(self, noise=None, n_iter=40, seed=0):
         """psi <- scale(first K PCs of standardised log2(Y+1)) + noise, computed on the device (R/inference-tflow.R:204-208)."""
-        out = np.zeros((self.N, self.K), dtype=np.float64)
-        nz = None if noise is None else np.ascontiguousarray(np.asarray(noise, dtype=np.float64).reshape(self.N, self.K))
+        out = np.zeros((self.N, self.K), dtype=np.float64, order=self._order)
+        nz = None if noise is None else np.require(np.asarray(noise, dtype=np.float64).reshape(self.N, self.K),
+                                                   requirements=[self._order, "A"])
         if self.K > 0:
             self._ck(self.lib.ca_init_psi_pca(self.h, None if nz is None else nz.ctypes.data_as(C.c_void_p), int(n_iter),
                                               int(seed) & 0xFFFFFFFFFFFFFFFF, out.ctypes.data_as(C.c_void_p)))
@@ -302,7 +361,7 @@ class HipEngine:
     def clone_gene_sums(self, clone_idx):
         """(T[G,C], Syy[G]): per-gene count sums by assigned clone and sums of squares over assigned cells (-1 = unassigned)."""
         ci = np.ascontiguousarray(np.asarray(clone_idx, dtype=np.int32).reshape(self.N))
-        T = np.zeros((self.G, self.C), dtype=np.float64)
+        T = np.zeros((self.G, self.C), dtype=np.float64, order=self._order)
         Syy = np.zeros(self.G, dtype=np.float64)
         self._ck(self.lib.ca_clone_gene_sums(self.h, ci.ctypes.data_as(C.c_void_p), T.ctypes.data_as(C.c_void_p),
                                              Syy.ctypes.data_as(C.c_void_p)))
@@ -319,7 +378,7 @@ class HipEngine:
                 "chi": (K,), "v": (K,)}[name]
 
     def _get(self, fn, name):
-        out = np.zeros(self._shape(name), dtype=np.float64)
+        out = np.zeros(self._shape(name), dtype=np.float64, order=self._order)   # the library writes the problem's layout
         if out.size:
             self._ck(fn(self.h, name.encode(), out.ctypes.data_as(C.c_void_p)))
         return out
@@ -328,7 +387,7 @@ class HipEngine:
         return self._get(self.lib.ca_get_param, name)
 
     def set(self, name, value):
-        v = np.ascontiguousarray(np.asarray(value, dtype=np.float64).reshape(self._shape(name)))
+        v = np.require(np.asarray(value, dtype=np.float64).reshape(self._shape(name)), requirements=[self._order, "A"])
         if v.size:
             self._ck(self.lib.ca_set_param(self.h, name.encode(), v.ctypes.data_as(C.c_void_p)))
 
@@ -337,7 +396,7 @@ class HipEngine:
         constructor started from), fresh Adam state (ca_reinit)."""
         p0 = None
         if self.K > 0:
-            p0 = np.ascontiguousarray(np.asarray(psi0, dtype=np.float64).reshape(self.N, self.K))
+            p0 = np.require(np.asarray(psi0, dtype=np.float64).reshape(self.N, self.K), requirements=[self._order, "A"])
         l0 = None if loc0 is None else np.ascontiguousarray(np.asarray(loc0, dtype=np.float64).reshape(self.G))
         self._ck(self.lib.ca_reinit(self.h, None if p0 is None else p0.ctypes.data_as(C.c_void_p),
                                     None if l0 is None else l0.ctypes.data_as(C.c_void_p)))
@@ -388,20 +447,29 @@ def eps_draw(seed, draw, n):
     return out
 
 
-def allele_loglik(clone_allele, cov, ref, device=0):
+def _lay(layout):
+    if layout not in ("row", "col"):
+        raise ValueError("layout must be 'row' or 'col'")
+    return (CA_COL_MAJOR, "F") if layout == "col" else (CA_ROW_MAJOR, "C")
+
+
+def allele_loglik(clone_allele, cov, ref, device=0, layout="row"):
     """The allele-specific [N, C] addend of the log-likelihood on the device (ca_allele_loglik; R/allele-specific.R:17-58
-    with alt = cov - ref as at R/inference-tflow.R:173).  clone_allele [V, C]; cov, ref [N, V]."""
+    with alt = cov - ref as at R/inference-tflow.R:173).  clone_allele [V, C]; cov, ref [N, V].  ``layout="col"`` hands the
+    matrices over column-major, as the R caller would."""
     lib = load_library()
-    ca = np.ascontiguousarray(np.asarray(clone_allele, dtype=np.float64))
-    cv = np.ascontiguousarray(np.asarray(cov, dtype=np.float64))
-    rf = np.ascontiguousarray(np.asarray(ref, dtype=np.float64))
+    lay, order = _lay(layout)
+    req = [order, "A"]
+    ca = np.require(np.asarray(clone_allele, dtype=np.float64), requirements=req)
+    cv = np.require(np.asarray(cov, dtype=np.float64), requirements=req)
+    rf = np.require(np.asarray(ref, dtype=np.float64), requirements=req)
     V, Cn = ca.shape
     N = cv.shape[0]
     if cv.shape != (N, V) or rf.shape != (N, V):
         raise ValueError("cov and ref must be cells x variants, clone_allele variants x clones")
-    out = np.zeros((N, Cn), dtype=np.float64)
+    out = np.zeros((N, Cn), dtype=np.float64, order=order)
     err = C.create_string_buffer(256)
-    rc = lib.ca_allele_loglik(N, V, Cn, CA_ROW_MAJOR, ca.ctypes.data_as(C.c_void_p), cv.ctypes.data_as(C.c_void_p),
+    rc = lib.ca_allele_loglik(N, V, Cn, lay, ca.ctypes.data_as(C.c_void_p), cv.ctypes.data_as(C.c_void_p),
                               rf.ctypes.data_as(C.c_void_p), int(device), out.ctypes.data_as(C.c_void_p), err)
     if rc != CA_OK:
         raise EngineError(rc, err.value.decode() or "ca_allele_loglik")
@@ -412,7 +480,7 @@ _NP_DTYPE = {np.dtype(np.float64): 0, np.dtype(np.float32): 1, np.dtype(np.int32
 
 
 def preprocess_masks(Y, L, min_counts_per_gene=20, min_counts_per_cell=100, remove_outlying_genes=True, nmads=10,
-                     max_copy_number=6, remove_genes_same_copy_number=True, device=0):
+                     max_copy_number=6, remove_genes_same_copy_number=True, device=0, layout="row"):
     """Gene / cell retention masks of preprocess_for_clonealign() with the two O(N G) statistics taken on the device
     (ca_preprocess; R/preprocess.R:93-147).  Y [N, G] in float64/float32/int32/uint16/uint8 (other dtypes are converted
     to float64), L [G, C].  Returns (keep_gene bool[G], keep_cell bool[N], gene_sums[G], cell_sums[N])."""
@@ -420,8 +488,9 @@ def preprocess_masks(Y, L, min_counts_per_gene=20, min_counts_per_cell=100, remo
     Y = np.asarray(Y)
     if Y.dtype not in _NP_DTYPE:
         Y = Y.astype(np.float64)
-    Y = np.ascontiguousarray(Y)
-    L = np.ascontiguousarray(np.asarray(L, dtype=np.float64))
+    lay, order = _lay(layout)
+    Y = np.require(Y, requirements=[order, "A"])
+    L = np.require(np.asarray(L, dtype=np.float64), requirements=[order, "A"])
     N, G = Y.shape
     if L.shape[0] != G:
         raise ValueError("copy_number_data must have same number of genes (rows) as gene_expression_data")
@@ -432,7 +501,7 @@ def preprocess_masks(Y, L, min_counts_per_gene=20, min_counts_per_cell=100, remo
     gs = np.zeros(G, dtype=np.float64)
     cs = np.zeros(N, dtype=np.float64)
     err = C.create_string_buffer(256)
-    rc = lib.ca_preprocess(N, G, L.shape[1], CA_ROW_MAJOR, _NP_DTYPE[Y.dtype], 0, Y.ctypes.data_as(C.c_void_p),
+    rc = lib.ca_preprocess(N, G, L.shape[1], lay, _NP_DTYPE[Y.dtype], 0, Y.ctypes.data_as(C.c_void_p),
                            L.ctypes.data_as(C.c_void_p), C.byref(pp), int(device), kg.ctypes.data_as(C.c_void_p),
                            kc.ctypes.data_as(C.c_void_p), gs.ctypes.data_as(C.c_void_p), cs.ctypes.data_as(C.c_void_p), err)
     if rc != CA_OK:

@@ -1,8 +1,9 @@
 /*
  * R-side binding of libclonealign_hip.so: the `.Call` stub a clonealign maintainer adds under src/.
- * NOT compiled in this repository's CI (the build image has no R toolchain / Rinternals.h); it is the
- * reference-side half of the boundary documented in INTEGRATION.md and mirrors, call for call, what
- * clonealign_amd/engine.py does through ctypes.
+ * The build image has no R toolchain, so the suite compiles it against a minimal stand-in for the R API
+ * (tests/r_stub/, tests/test_shim_compiles.py) and drives C_clonealign_fit from a C harness on the GPU box
+ * (tests/test_gpu_shim.py); it is the reference-side half of the boundary documented in INTEGRATION.md and mirrors,
+ * call for call, what clonealign_amd/engine.py does through ctypes with layout="col".
  *
  * Replaces the body of inference_tflow() between R/inference-tflow.R:240 (graph build) and :457
  * (sess$close): everything before (gene filter, saturate, PCA / mu init) and after (naming, return list)
@@ -28,6 +29,15 @@ static void fail(ca_handle h, const char* what) {
   msg[sizeof(msg) - 1] = 0;
   ca_destroy(h);                       /* free device memory BEFORE the longjmp of Rf_error */
   Rf_error("%s: %s", what, msg);
+}
+
+/* The reference's loop is R-level and can be interrupted every iteration (R/inference-tflow.R:394-417).  ca_run_ex() calls
+ * this between iterations; R_CheckUserInterrupt() may longjmp, so it runs inside R_ToplevelExec() and never unwinds through
+ * the library: a pending interrupt makes the loop stop cleanly (CA_INTERRUPTED), the handle is freed, then R is told. */
+static void check_interrupt(void* unused) { (void)unused; R_CheckUserInterrupt(); }
+static int poll_interrupt(void* user, int32_t iter, double elbo) {
+  (void)user; (void)iter; (void)elbo;
+  return R_ToplevelExec(check_interrupt, NULL) == FALSE;
 }
 
 static SEXP fetch(ca_handle h, const char* name, R_xlen_t nrow, R_xlen_t ncol) {
@@ -67,9 +77,9 @@ SEXP C_clonealign_fit(SEXP Y, SEXP L, SEXP psi0, SEXP loc0, SEXP X, SEXP extra, 
   }
   SEXP elbo = PROTECT(Rf_allocVector(REALSXP, max_iter + 1));
   int n_elbo = 0;
-  /* whole loop of :368-417 in the library.  (To stay interruptible per iteration instead, call
-     ca_gamma_init / ca_elbo / ca_step from an R-level loop with R_CheckUserInterrupt() in between.) */
-  int rc = ca_run(h, max_iter, Rf_asReal(rel_tol_), eps, eps ? ndraw : 0, REAL(elbo), &n_elbo);
+  /* whole loop of :368-417 in the library, interruptible between iterations like the reference's R-level loop */
+  int rc = ca_run_ex(h, max_iter, Rf_asReal(rel_tol_), eps, eps ? ndraw : 0, REAL(elbo), &n_elbo, poll_interrupt, NULL);
+  if (rc == CA_INTERRUPTED) { UNPROTECT(1); ca_destroy(h); Rf_error("clonealign: interrupted"); }
   if (rc == CA_ERR_NAN) { UNPROTECT(1); fail(h, "clonealign");  /* "Initial elbo is NA", :374-376 */ }
   if (rc != CA_OK) { UNPROTECT(1); fail(h, "ca_run"); }
   SEXP finals = PROTECT(Rf_allocVector(REALSXP, 20));        /* :447-449 */

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CA_ABI_VERSION 1
+#define CA_ABI_VERSION 2
 
 typedef struct ca_engine* ca_handle;
 
@@ -39,8 +39,9 @@ enum ca_status {
   CA_ERR_HIP = 2,     /* HIP runtime failure */
   CA_ERR_NOMEM = 3,
   CA_ERR_NAN = 4,     /* "Initial elbo is NA" (R/inference-tflow.R:374-376) or NaN in the window test (:414) */
-  CA_ERR_COMM = 5,    /* RCCL failure */
-  CA_ERR_STATE = 6
+  CA_ERR_COMM = 5,    /* RCCL / peer-to-peer transport failure */
+  CA_ERR_STATE = 6,
+  CA_INTERRUPTED = 7  /* ca_run_ex(): the poll callback asked to stop; trace and variables are those of the last completed iteration */
 };
 
 enum ca_dtype { CA_F64 = 0, CA_F32 = 1, CA_I32 = 2, CA_U16 = 3, CA_U8 = 4 };
@@ -63,7 +64,38 @@ typedef struct ca_problem {
                           computed from the resident matrix (single-shard problems only) */
   const double* X;     /* N x P covariates or NULL (:147-153) */
   const double* extra_loglik; /* N x C additive log-lik (allele term, :302-304) or NULL */
+  /* Optional row / column selection of Y, so that the masks of ca_preprocess() (R/preprocess.R:141-147 returns filtered
+   * COPIES) or the gene filter of R/inference-tflow.R:117-124 never cut the matrix on the host: Y is then the RAW
+   * N_src x G_src matrix and cell n / gene g of the problem is its row cell_index[n] / column gene_index[g] (0-based,
+   * strictly increasing).  NULL = identity (then N_src / G_src are ignored).  L, psi0, loc0, X, extra_loglik are always
+   * given for the SELECTED cells and genes. */
+  int64_t N_src;
+  int32_t G_src;
+  const int64_t* cell_index;  /* N entries or NULL */
+  const int32_t* gene_index;  /* G entries or NULL */
 } ca_problem;
+
+/* Decomposition variants (bits of ca_options.variant_off: a set bit switches the variant OFF; 0 = the measured defaults).
+ * They exist so that every fallback stays under test and every choice can be re-measured. */
+enum ca_variant {
+  CA_VAR_FUSED = 1 << 0,      /* fused two-eps sweep (monitor pass i + forward half of train pass i+1) */
+  CA_VAR_FWD_MFMA = 1 << 1,   /* forward contraction on the matrix cores */
+  CA_VAR_FWD_CELL = 1 << 2,   /* forward sweep and cell epilogue in one kernel */
+  CA_VAR_BWD_MFMA = 1 << 3,   /* backward contraction on the matrix cores */
+  CA_VAR_TAIL_FUSE = 1 << 4,  /* O(K + C) bodies as extra blocks of other launches */
+  CA_VAR_ASYNC_Y = 1 << 5,    /* count-matrix products on the side stream */
+  CA_VAR_PRE = 1 << 6,        /* next pass's per-gene prologue on the per-cell Adam kernel */
+  CA_VAR_PAIR_ELBO = 1 << 7,  /* final ELBOs two draws per sweep */
+  CA_VAR_PREP_FAST = 1 << 8,  /* wave-per-cell fit-constant kernel for u8 storage */
+  CA_VAR_Y_MFMA = 1 << 9,     /* count-matrix products on the int8 matrix cores from tiled copies (else k_ypass) */
+  CA_VAR_P2P = 1 << 10        /* one-shot peer-to-peer all-reduce (else ncclAllReduce) after ca_comm_init() */
+};
+#define CA_OPT_VERBOSE 0x80000000u /* in variant_off: print the decomposition picks to stderr */
+/* decomposition parameters the heuristics pick; a non-zero ca_options.tune[id] overrides (CA_TUNE_FC_NBIG: -1 = one block size) */
+enum ca_tune_id {
+  CA_TUNE_GSPLIT = 0, CA_TUNE_FSPLIT = 1, CA_TUNE_FC_TL = 2, CA_TUNE_FC_NBIG = 3, CA_TUNE_CSPLIT = 4, CA_TUNE_CSPLIT_M = 5,
+  CA_TUNE_TR = 6, CA_TUNE_RG = 7, CA_TUNE_COUNT = 8
+};
 
 typedef struct ca_options {
   double learning_rate;             /* :75,345 */
@@ -73,8 +105,12 @@ typedef struct ca_options {
   int32_t y_storage;                /* ca_ystore: on-device width of the count matrix */
   int32_t rank, world;              /* cell-sharded data parallel: shard `rank` of `world` */
   int32_t profile;                  /* bitmask over ca_kernel_id: time those kernel classes with HIP events */
-  int32_t reserved[7];
+  uint32_t variant_off;             /* ca_variant bits to switch off (| CA_OPT_VERBOSE); 0 = defaults */
+  int32_t tune[8];                  /* ca_tune_id overrides, 0 = heuristic */
+  int32_t reserved[6];
 } ca_options;
+/* (The same switches can be set from the environment -- CA_FUSED=0, CA_CSPLIT=12, ... -- but ONLY when
+ *  CLONEALIGN_DEBUG_ENV is set: the library reads no configuration from the process environment otherwise.) */
 
 typedef struct ca_info {
   int64_t N;
@@ -90,8 +126,12 @@ typedef struct ca_info {
   int32_t bwd_mfma;          /* 1: the backward sweep's t = coef.L contraction runs on the matrix cores (k_bwd_mfma) */
   int32_t fsplit;            /* gene slices of the matrix-core forward sweep */
   int32_t fwd_cell;          /* 1: forward sweep and cell epilogue of the fused pass are ONE kernel (k_fwd_cell) */
-  int32_t reserved[3];
+  int32_t y_mfma;            /* 1: the loop's count-matrix products run on the int8 matrix cores (k_yw_mfma / k_yt_mfma) */
+  int32_t transport;         /* 0 none, 1 RCCL all-reduce, 2 host callback, 3 one-shot peer-to-peer (ca_transport) */
+  int32_t reserved[1];
+  int64_t red_n;             /* doubles all-reduced per train pass (= sharding.reduce_plan(...)["total"]) */
 } ca_info;
+enum ca_transport { CA_TRANSPORT_NONE = 0, CA_TRANSPORT_RCCL = 1, CA_TRANSPORT_HOST = 2, CA_TRANSPORT_P2P = 3 };
 
 /* kernel classes reported by ca_get_kernel_times() */
 enum ca_kernel_id {
@@ -142,6 +182,15 @@ int ca_gradients(ca_handle h, const float* eps, double* elbo);
  * draws) or NULL for the built-in stream.  elbo_trace receives 1 + iterations values. */
 int ca_run(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_stream, int64_t n_draws,
            double* elbo_trace, int32_t* n_elbo);
+/* The same loop with a host callback between iterations -- the reference's loop is R-level and can be interrupted or
+ * observed every iteration (R/inference-tflow.R:394-417, progress bar :395-399).  poll(user, i, elbo_i) is called once
+ * per ELBO value as the host learns it (i = 0 for the initial ELBO of :372, then 1, 2, ...), from the calling thread,
+ * while the GPU already works on the backward sweep of the next train pass.  A non-zero return stops the loop exactly
+ * like the convergence test does: the variables are those after iteration i, the trace has i + 1 values, and the call
+ * returns CA_INTERRUPTED.  An R shim calls R_CheckUserInterrupt() through R_ToplevelExec() here. */
+typedef int (*ca_poll_fn)(void* user, int32_t iter, double elbo);
+int ca_run_ex(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_stream, int64_t n_draws,
+              double* elbo_trace, int32_t* n_elbo, ca_poll_fn poll, void* user);
 /* n_iter iterations of {train, monitor} with no convergence test and no host sync inside
  * (the benchmark "step"); last_elbo may be NULL. */
 int ca_iterate(ca_handle h, int32_t n_iter, const float* eps_stream, int64_t n_draws, double* last_elbo);

@@ -1,0 +1,99 @@
+/* Fake R runtime behind tests/r_stub/Rinternals.h (test infrastructure only). */
+#include <setjmp.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "Rinternals.h"
+#include "R_ext/Utils.h"
+
+struct rstub_sexp {
+  int type; R_xlen_t n; int nrow, ncol;   /* nrow = -1: plain vector */
+  void* data; const char** names; struct rstub_sexp* next;
+};
+static struct rstub_sexp nil_obj = {NILSXP, 0, -1, -1, NULL, NULL, NULL};
+SEXP R_NilValue = &nil_obj;
+static struct rstub_sexp* all_objs = NULL;
+static void* all_ralloc[64]; static int n_ralloc = 0;
+int rstub_interrupt_after = 0;
+static int n_checks = 0;
+jmp_buf rstub_error_jmp; int rstub_error_armed = 0; char rstub_error_msg[1024];
+static jmp_buf* toplevel_jmp = NULL;
+
+static SEXP mk(int type, R_xlen_t n, int nrow, int ncol) {
+  struct rstub_sexp* s = (struct rstub_sexp*)calloc(1, sizeof(*s));
+  const size_t esz = type == REALSXP ? sizeof(double) : type == INTSXP ? sizeof(int) : sizeof(SEXP);
+  s->type = type; s->n = n; s->nrow = nrow; s->ncol = ncol;
+  s->data = calloc((size_t)(n > 0 ? n : 1), esz);
+  s->next = all_objs; all_objs = s;
+  return s;
+}
+int Rf_nrows(SEXP x) { return x->nrow >= 0 ? x->nrow : (int)x->n; }
+int Rf_ncols(SEXP x) { return x->nrow >= 0 ? x->ncol : 1; }
+int Rf_asInteger(SEXP x) { return x->type == INTSXP ? ((int*)x->data)[0] : (int)((double*)x->data)[0]; }
+double Rf_asReal(SEXP x) { return x->type == INTSXP ? (double)((int*)x->data)[0] : ((double*)x->data)[0]; }
+int Rf_isNull(SEXP x) { return x == R_NilValue || x->type == NILSXP; }
+int Rf_isInteger(SEXP x) { return x->type == INTSXP; }
+double* REAL(SEXP x) { return (double*)x->data; }
+int* INTEGER(SEXP x) { return (int*)x->data; }
+R_xlen_t XLENGTH(SEXP x) { return x->n; }
+SEXP Rf_allocVector(int type, R_xlen_t n) { return mk(type, n, -1, -1); }
+SEXP Rf_allocMatrix(int type, int nrow, int ncol) { return mk(type, (R_xlen_t)nrow * ncol, nrow, ncol); }
+SEXP Rf_mkNamed(int type, const char** names) {
+  R_xlen_t n = 0;
+  while (names[n][0]) ++n;
+  SEXP s = mk(type, n, -1, -1);
+  s->names = names;
+  for (R_xlen_t i = 0; i < n; ++i) ((SEXP*)s->data)[i] = R_NilValue;
+  return s;
+}
+SEXP SET_VECTOR_ELT(SEXP x, R_xlen_t i, SEXP v) { ((SEXP*)x->data)[i] = v; return v; }
+SEXP VECTOR_ELT(SEXP x, R_xlen_t i) { return ((SEXP*)x->data)[i]; }
+SEXP Rf_xlengthgets(SEXP x, R_xlen_t n) {
+  SEXP y = mk(x->type, n, -1, -1);
+  const size_t esz = x->type == REALSXP ? sizeof(double) : x->type == INTSXP ? sizeof(int) : sizeof(SEXP);
+  memcpy(y->data, x->data, (size_t)(n < x->n ? n : x->n) * esz);
+  return y;
+}
+SEXP Rf_protect(SEXP x) { return x; }
+void Rf_unprotect(int n) { (void)n; }
+void Rf_error(const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(rstub_error_msg, sizeof(rstub_error_msg), fmt, ap); va_end(ap);
+  if (rstub_error_armed) longjmp(rstub_error_jmp, 1);
+  fprintf(stderr, "Rf_error: %s\n", rstub_error_msg);
+  abort();
+}
+char* R_alloc(size_t n, int size) {
+  void* p = calloc(n ? n : 1, (size_t)size);
+  if (n_ralloc < 64) all_ralloc[n_ralloc++] = p;
+  return (char*)p;
+}
+int R_registerRoutines(DllInfo* d, const void* a, const R_CallMethodDef* b, const void* c, const void* e) { (void)d; (void)a; (void)b; (void)c; (void)e; return 1; }
+Rboolean R_useDynamicSymbols(DllInfo* d, Rboolean v) { (void)d; return v; }
+/* an interrupt inside R_ToplevelExec unwinds to it and makes it return FALSE */
+void R_CheckUserInterrupt(void) {
+  ++n_checks;
+  if (rstub_interrupt_after > 0 && n_checks >= rstub_interrupt_after) {
+    if (toplevel_jmp) longjmp(*toplevel_jmp, 1);
+    Rf_error("interrupt");
+  }
+}
+Rboolean R_ToplevelExec(void (*fun)(void*), void* data) {
+  jmp_buf jb; jmp_buf* prev = toplevel_jmp;
+  toplevel_jmp = &jb;
+  if (setjmp(jb)) { toplevel_jmp = prev; return FALSE; }
+  fun(data);
+  toplevel_jmp = prev;
+  return TRUE;
+}
+SEXP rstub_real_matrix(const double* d, int nrow, int ncol) { SEXP s = Rf_allocMatrix(REALSXP, nrow, ncol); memcpy(s->data, d, sizeof(double) * (size_t)nrow * ncol); return s; }
+SEXP rstub_int_matrix(const int* d, int nrow, int ncol) { SEXP s = Rf_allocMatrix(INTSXP, nrow, ncol); memcpy(s->data, d, sizeof(int) * (size_t)nrow * ncol); return s; }
+SEXP rstub_real_vector(const double* d, R_xlen_t n) { SEXP s = Rf_allocVector(REALSXP, n); memcpy(s->data, d, sizeof(double) * (size_t)n); return s; }
+SEXP rstub_scalar_int(int v) { SEXP s = Rf_allocVector(INTSXP, 1); ((int*)s->data)[0] = v; return s; }
+SEXP rstub_scalar_real(double v) { SEXP s = Rf_allocVector(REALSXP, 1); ((double*)s->data)[0] = v; return s; }
+const char* rstub_name(SEXP l, R_xlen_t i) { return l->names ? l->names[i] : ""; }
+void rstub_free_all(void) {
+  while (all_objs) { struct rstub_sexp* nx = all_objs->next; free(all_objs->data); free(all_objs); all_objs = nx; }
+  for (int i = 0; i < n_ralloc; ++i) free(all_ralloc[i]);
+  n_ralloc = 0; n_checks = 0;
+}

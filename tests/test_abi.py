@@ -23,16 +23,56 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), s
     assert set(syms) == set(engine.EXPORTS)
-    assert lib.ca_abi_version() == 1
+    assert lib.ca_abi_version() == engine.CA_ABI_VERSION == 2
 
 
-def test_structs_match_header_sizes():
+PROBE = r"""
+#include <stddef.h>
+#include <stdio.h>
+#include "clonealign_hip.h"
+#define F(T, f) printf(#T "." #f " %zu\n", offsetof(T, f))
+int main(void) {
+  printf("ca_problem %zu\nca_options %zu\nca_info %zu\nca_preprocess_params %zu\n", sizeof(ca_problem), sizeof(ca_options),
+         sizeof(ca_info), sizeof(ca_preprocess_params));
+  F(ca_problem, Y); F(ca_problem, extra_loglik); F(ca_problem, N_src); F(ca_problem, G_src); F(ca_problem, cell_index); F(ca_problem, gene_index);
+  F(ca_options, seed); F(ca_options, profile); F(ca_options, variant_off); F(ca_options, tune); F(ca_options, reserved);
+  F(ca_info, y_device_bytes); F(ca_info, fwd_cell); F(ca_info, y_mfma); F(ca_info, transport); F(ca_info, red_n);
+  printf("version %d\n", CA_ABI_VERSION);
+  return 0;
+}
+"""
+
+
+def test_structs_match_the_header_as_the_c_compiler_lays_them_out(tmp_path):
+    """sizeof / offsetof from gcc against the ctypes mirrors in engine.py: the header is the contract."""
+    import subprocess
     from clonealign_amd import engine
-    assert ctypes.sizeof(engine.CaProblem) == 8 + 4 * 8 + 6 * 8
-    assert ctypes.sizeof(engine.CaOptions) == 4 * 8 + 8 + 4 * 5 + 4 * 7
+    src = tmp_path / "probe.c"
+    src.write_text(PROBE)
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
+    got = dict(line.rsplit(" ", 1) for line in subprocess.check_output([str(exe)], text=True).strip().splitlines())
+    mirror = {"ca_problem": engine.CaProblem, "ca_options": engine.CaOptions, "ca_info": engine.CaInfo,
+              "ca_preprocess_params": engine.CaPreprocessParams}
+    for name, cls in mirror.items():
+        assert int(got[name]) == ctypes.sizeof(cls), name
+    for key, val in got.items():
+        if "." in key:
+            st, f = key.split(".")
+            assert int(val) == getattr(mirror[st], f).offset, key
+    assert int(got["version"]) == engine.CA_ABI_VERSION
     opt = engine.CaOptions()
     engine.load_library().ca_default_options(ctypes.byref(opt))
     assert (opt.learning_rate, opt.beta1, opt.beta2, opt.adam_eps, opt.world) == (0.1, 0.9, 0.999, 1e-8, 1)
+    assert opt.variant_off == 0 and list(opt.tune) == [0] * 8
+
+
+def test_library_reads_no_configuration_from_the_environment():
+    """ADVICE/VERDICT r1: the CA_* switches live in ca_options; getenv is reached only behind CLONEALIGN_DEBUG_ENV."""
+    src = open(os.path.join(ROOT, "clonealign_amd", "csrc", "clonealign_hip.hip")).read()
+    uses = re.findall(r'getenv\("([A-Z_]+)"\)', src)
+    assert set(uses) <= {"CLONEALIGN_DEBUG_ENV", "CLONEALIGN_RCCL_LIB", "CA_VERBOSE"}, uses
+    assert src.count("getenv(env)") == 2 and "debug_env()" in src
 
 
 def test_create_fails_loudly_without_gpu_or_with_bad_args():

@@ -37,6 +37,7 @@ for it in range(n_cases):
     if rng.random() < 0.4:          # counts above 255: overflow list next to 1-byte storage
         idx = rng.integers(0, case["Y"].size, size=max(1, case["Y"].size // 3000))
         case["Y"].reshape(-1)[idx] += rng.integers(200, 2000, size=idx.size)
+    env = dict(env, CLONEALIGN_DEBUG_ENV="1")      # the library reads CA_* from the environment only in this debug mode
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     eng = None
