@@ -145,137 +145,134 @@ __device__ __forceinline__ double ca_digits_to_double(int o) {
   return v;
 }
 
-// Row products.  A wave owns TL cell tiles (16 cells each) for ALL gene steps; accumulators D[cell][4 k + digit].
-// Output: raw digit sums out[n][16] (int32, bias undone) -- the caller's epilogue kernel or the lab reads them; the
-// engine's form (k_yw_mfma) finishes in the kernel: YW[n][k] float and the block's share of sum_n psi_n . (YW)_n.
-template <int TL>
-__device__ __forceinline__ void ca_yw_sweep(const uint4* __restrict__ Yf, const uint4* __restrict__ Wq, int64_t T0, int64_t NT, int GS,
+// One wave's stream: TL tiles of the matrix image (tile t at mat[t], consecutive steps 64 uint4 apart) against the
+// parameter image par, steps [s0, s1), DEPTH steps in flight (DEPTH * TL KiB per wave; the ring is fully unrolled so
+// every buffer is a fixed register).  acc[t] = D of tile t, acc1 = the all-ones tile's D (digit sums of the parameter).
+template <int TL, int DEPTH>
+__device__ __forceinline__ void ca_ym_sweep(const uint4* const (&mat)[TL], const uint4* __restrict__ par, int64_t s0, int64_t s1,
                                             ca_i32x4 (&acc)[TL], ca_i32x4& acc1) {
-  const int lane = threadIdx.x & 63;
   const uint4 ones = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};
-  const uint4* yp[TL];
 #pragma unroll
-  for (int t = 0; t < TL; ++t) {
-    const int64_t T = (T0 + t < NT) ? T0 + t : NT - 1;   // tiles past the end re-read the last one (never stored)
-    yp[t] = Yf + T * GS * 64 + lane;
-    acc[t] = (ca_i32x4){0, 0, 0, 0};
-  }
+  for (int t = 0; t < TL; ++t) acc[t] = (ca_i32x4){0, 0, 0, 0};
   acc1 = (ca_i32x4){0, 0, 0, 0};
-  uint4 a0[TL], a1[TL], b0, b1;
-  // two steps in flight: 2 TL KiB per wave
+  uint4 a[DEPTH][TL], b[DEPTH];
 #pragma unroll
-  for (int t = 0; t < TL; ++t) a0[t] = yp[t][0];
-  b0 = Wq[lane];
-  if (GS > 1) {
+  for (int d = 0; d < DEPTH; ++d) {
+    const int64_t s = (s0 + d < s1) ? s0 + d : (s1 > s0 ? s1 - 1 : s0);   // past the end: re-read the last step (never used)
 #pragma unroll
-    for (int t = 0; t < TL; ++t) a1[t] = yp[t][64];
-    b1 = Wq[64 + lane];
+    for (int t = 0; t < TL; ++t) a[d][t] = mat[t][s * 64];
+    b[d] = par[s * 64];
   }
-  int s = 0;
-  for (; s + 1 < GS; s += 2) {
-    acc1 = ca_mfma_i8(ones, b0, acc1);
+  for (int64_t s = s0; s < s1; s += DEPTH) {
 #pragma unroll
-    for (int t = 0; t < TL; ++t) acc[t] = ca_mfma_i8(a0[t], b0, acc[t]);
-    if (s + 2 < GS) {
+    for (int d = 0; d < DEPTH; ++d) {
+      if (s + d < s1) {   // wave-uniform
+        acc1 = ca_mfma_i8(ones, b[d], acc1);
 #pragma unroll
-      for (int t = 0; t < TL; ++t) a0[t] = yp[t][(int64_t)(s + 2) * 64];
-      b0 = Wq[(int64_t)(s + 2) * 64 + lane];
+        for (int t = 0; t < TL; ++t) acc[t] = ca_mfma_i8(a[d][t], b[d], acc[t]);
+        if (s + d + DEPTH < s1) {
+#pragma unroll
+          for (int t = 0; t < TL; ++t) a[d][t] = mat[t][(s + d + DEPTH) * 64];
+          b[d] = par[(s + d + DEPTH) * 64];
+        }
+      }
     }
-    acc1 = ca_mfma_i8(ones, b1, acc1);
-#pragma unroll
-    for (int t = 0; t < TL; ++t) acc[t] = ca_mfma_i8(a1[t], b1, acc[t]);
-    if (s + 3 < GS) {
-#pragma unroll
-      for (int t = 0; t < TL; ++t) a1[t] = yp[t][(int64_t)(s + 3) * 64];
-      b1 = Wq[(int64_t)(s + 3) * 64 + lane];
-    }
-  }
-  if (s < GS) {
-    acc1 = ca_mfma_i8(ones, b0, acc1);
-#pragma unroll
-    for (int t = 0; t < TL; ++t) acc[t] = ca_mfma_i8(a0[t], b0, acc[t]);
   }
 }
 
-template <int TL>
+// Row products.  A wave owns TL cell tiles (16 cells each) for ALL gene steps; accumulators D[cell][4 k + digit].
+template <int TL, int DEPTH>
+__device__ __forceinline__ void ca_yw_wave(const uint4* __restrict__ Yf, const uint4* __restrict__ Wq, int64_t T0, int64_t NT, int GS,
+                                           ca_i32x4 (&acc)[TL], ca_i32x4& acc1) {
+  const int lane = threadIdx.x & 63;
+  const uint4* mat[TL];
+#pragma unroll
+  for (int t = 0; t < TL; ++t) mat[t] = Yf + ((T0 + t < NT) ? T0 + t : NT - 1) * GS * 64 + lane;   // tiles past the end re-read the last one
+  ca_ym_sweep<TL, DEPTH>(mat, Wq + lane, 0, GS, acc, acc1);
+}
+// lab / test form: raw digit sums out[n][16] (int32, bias undone)
+template <int TL, int DEPTH>
 __global__ void __launch_bounds__(CA_YM_TB) k_yw_mfma_raw(const uint4* __restrict__ Yf, const uint4* __restrict__ Wq, int64_t NT, int GS,
                                                           int* __restrict__ out /*[NT * 16][16]*/) {
   const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
   const int64_t T0 = ((int64_t)blockIdx.x * (CA_YM_TB / 64) + (threadIdx.x >> 6)) * TL;
   if (T0 >= NT) return;
   ca_i32x4 acc[TL], acc1;
-  ca_yw_sweep<TL>(Yf, Wq, T0, NT, GS, acc, acc1);
+  ca_yw_wave<TL, DEPTH>(Yf, Wq, T0, NT, GS, acc, acc1);
 #pragma unroll
   for (int t = 0; t < TL; ++t)
     if (T0 + t < NT)
 #pragma unroll
       for (int r = 0; r < 4; ++r) out[((T0 + t) * 16 + 4 * q + r) * 16 + j] = acc[t][r] + 128 * acc1[r];
 }
-
-// Column products.  A wave owns TL gene tiles for the cell steps [s0, s1) of its slice; accumulators D[gene][4 k + digit].
-template <int TL>
-__device__ __forceinline__ void ca_yt_sweep(const uint4* __restrict__ Yb, const uint4* __restrict__ Pq, int T0, int GT, int64_t NS,
-                                            int64_t s0, int64_t s1, ca_i32x4 (&acc)[TL], ca_i32x4& acc1) {
-  const int lane = threadIdx.x & 63;
-  const uint4 ones = {0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u};
-  const uint4* yp[TL];
+// engine form: finishes in the kernel.  YW[n][k] (float, what psi's gradient reads) and the block's share of
+// sum_n psi_n . (YW)_n in fp64 (the one ELBO term that needs the row products); the overflow list's entries of each cell
+// (counts above 255, CSR) are added by the four lanes of the cell's quad.  Block = 4 waves = 64 TL cells.
+template <int TL, int DEPTH>
+__global__ void __launch_bounds__(CA_YM_TB) k_yw_mfma(const uint4* __restrict__ Yf, const uint4* __restrict__ Wq, int64_t NT, int GS,
+                                                      int64_t N, int K, const float* __restrict__ F, int Df, const float* __restrict__ V,
+                                                      int Dv, const unsigned* __restrict__ amax, const int64_t* __restrict__ ovf_rowptr,
+                                                      const int* __restrict__ ovf_col, const float* __restrict__ ovf_val,
+                                                      float* __restrict__ YW, double* __restrict__ yw_part) {
+  __shared__ double sm[CA_YM_TB / 64];
+  const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4, k = j >> 2, p = j & 3;
+  const int64_t T0 = ((int64_t)blockIdx.x * (CA_YM_TB / 64) + (threadIdx.x >> 6)) * TL;
+  double part = 0.0;
+  if (T0 < NT) {   // wave-uniform
+    ca_i32x4 acc[TL], acc1;
+    ca_yw_wave<TL, DEPTH>(Yf, Wq, T0, NT, GS, acc, acc1);
+    const double inv = ldexp(1.0, -ca_fix_exp(__uint_as_float(amax[0])));
 #pragma unroll
-  for (int t = 0; t < TL; ++t) {
-    const int T = (T0 + t < GT) ? T0 + t : GT - 1;
-    yp[t] = Yb + (int64_t)T * NS * 64 + lane;
-    acc[t] = (ca_i32x4){0, 0, 0, 0};
+    for (int t = 0; t < TL; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t n = (T0 + t) * 16 + 4 * q + r;
+        const bool live = n < N && k < K;
+        double v = ca_digits_to_double(live ? acc[t][r] + 128 * acc1[r] : 0) * inv;
+        if (ovf_rowptr) {   // (uniform)
+          double a = 0.0;
+          if (live)
+            for (int64_t e = ovf_rowptr[n] + p; e < ovf_rowptr[n + 1]; e += 4) a += (double)ovf_val[e] * (double)V[(int64_t)ovf_col[e] * Dv + k];
+          a += __shfl_xor(a, 1, 64);
+          a += __shfl_xor(a, 2, 64);
+          v += a;
+        }
+        if (live && p == 0) {
+          YW[n * K + k] = (float)v;
+          part += (double)F[n * Df + k] * v;
+        }
+      }
   }
-  acc1 = (ca_i32x4){0, 0, 0, 0};
-  if (s0 >= s1) return;
-  uint4 a0[TL], a1[TL], b0, b1;
 #pragma unroll
-  for (int t = 0; t < TL; ++t) a0[t] = yp[t][s0 * 64];
-  b0 = Pq[s0 * 64 + lane];
-  if (s0 + 1 < s1) {
-#pragma unroll
-    for (int t = 0; t < TL; ++t) a1[t] = yp[t][(s0 + 1) * 64];
-    b1 = Pq[(s0 + 1) * 64 + lane];
-  }
-  int64_t s = s0;
-  for (; s + 1 < s1; s += 2) {
-    acc1 = ca_mfma_i8(ones, b0, acc1);
-#pragma unroll
-    for (int t = 0; t < TL; ++t) acc[t] = ca_mfma_i8(a0[t], b0, acc[t]);
-    if (s + 2 < s1) {
-#pragma unroll
-      for (int t = 0; t < TL; ++t) a0[t] = yp[t][(s + 2) * 64];
-      b0 = Pq[(s + 2) * 64 + lane];
-    }
-    acc1 = ca_mfma_i8(ones, b1, acc1);
-#pragma unroll
-    for (int t = 0; t < TL; ++t) acc[t] = ca_mfma_i8(a1[t], b1, acc[t]);
-    if (s + 3 < s1) {
-#pragma unroll
-      for (int t = 0; t < TL; ++t) a1[t] = yp[t][(s + 3) * 64];
-      b1 = Pq[(s + 3) * 64 + lane];
-    }
-  }
-  if (s < s1) {
-    acc1 = ca_mfma_i8(ones, b0, acc1);
-#pragma unroll
-    for (int t = 0; t < TL; ++t) acc[t] = ca_mfma_i8(a0[t], b0, acc[t]);
-  }
+  for (int o = 1; o < 64; o <<= 1) part += __shfl_xor(part, o, 64);
+  if (lane == 0) sm[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) yw_part[blockIdx.x] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
-// grid (ceil(GT / (4 TL)), csplit): digit sums of the slice, out[slice][GT * 16][16] int32 (bias undone)
-template <int TL>
-__global__ void __launch_bounds__(CA_YM_TB) k_yt_mfma(const uint4* __restrict__ Yb, const uint4* __restrict__ Pq, int GT, int64_t NS,
-                                                      int64_t schunk, int* __restrict__ out) {
+// Column products.  A wave owns TL gene tiles for the cell steps [s0, s1) of its slice; accumulators D[gene][4 k + digit].
+// grid (ceil(GT / (4 TL)) [+ extra blocks], csplit): digit sums of the slice, out[slice][GT * 16][16] int32 (bias undone).
+template <int TL, int DEPTH>
+__device__ __forceinline__ void ca_yt_block(const uint4* __restrict__ Yb, const uint4* __restrict__ Pq, int GT, int64_t NS, int64_t schunk,
+                                            int* __restrict__ out) {
   const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
   const int T0 = (blockIdx.x * (CA_YM_TB / 64) + (int)(threadIdx.x >> 6)) * TL;
   if (T0 >= GT) return;
   const int64_t s0 = (int64_t)blockIdx.y * schunk, s1 = (s0 + schunk < NS) ? s0 + schunk : NS;
+  const uint4* mat[TL];
+#pragma unroll
+  for (int t = 0; t < TL; ++t) mat[t] = Yb + (int64_t)((T0 + t < GT) ? T0 + t : GT - 1) * NS * 64 + lane;
   ca_i32x4 acc[TL], acc1;
-  ca_yt_sweep<TL>(Yb, Pq, T0, GT, NS, s0, s1, acc, acc1);
+  ca_ym_sweep<TL, DEPTH>(mat, Pq + lane, s0, s1, acc, acc1);
   int* o = out + (int64_t)blockIdx.y * GT * 256;
 #pragma unroll
   for (int t = 0; t < TL; ++t)
     if (T0 + t < GT)
 #pragma unroll
       for (int r = 0; r < 4; ++r) o[((int64_t)(T0 + t) * 16 + 4 * q + r) * 16 + j] = acc[t][r] + 128 * acc1[r];
+}
+template <int TL, int DEPTH>
+__global__ void __launch_bounds__(CA_YM_TB) k_yt_mfma_raw(const uint4* __restrict__ Yb, const uint4* __restrict__ Pq, int GT, int64_t NS,
+                                                          int64_t schunk, int* __restrict__ out) {
+  ca_yt_block<TL, DEPTH>(Yb, Pq, GT, NS, schunk, out);
 }

@@ -102,8 +102,8 @@ def test_col_major_device_helpers_match_row_major():
     L[::7] = 2.0                                       # same copy number everywhere
     L[3, 1] = 9.0                                      # above max_copy_number
     for ydt in (np.int32, np.float64):
-        r = preprocess_masks(Y.astype(ydt), L, min_counts_per_gene=150, min_counts_per_cell=120, layout="row")
-        c = preprocess_masks(Y.astype(ydt), L, min_counts_per_gene=150, min_counts_per_cell=120, layout="col")
+        r = preprocess_masks(Y.astype(ydt), L, min_counts_per_gene=600, min_counts_per_cell=560, layout="row")
+        c = preprocess_masks(Y.astype(ydt), L, min_counts_per_gene=600, min_counts_per_cell=560, layout="col")
         for x, y in zip(r, c):
             assert np.array_equal(x, y)
         assert 0 < r[0].sum() < r[0].size and 0 < r[1].sum() < r[1].size
@@ -161,7 +161,9 @@ def test_poll_hook_cancels_between_iterations():
         t_cut = cut.run(eps, 12, 1e-12, poll=lambda i, v: i >= k)
         assert cut.interrupted and len(t_cut) == k + 1 and np.array_equal(t_cut, t_full[:k + 1])
         t_ref = ref.run(eps, k, 1e-12)                      # a plain run of exactly k iterations
-        assert np.array_equal(t_ref, t_cut)
+        # (its LAST monitor pass has no train pass to share a sweep with and takes the plain fp32 kernel instead of the
+        #  fused matrix-core one: same variables, ELBO equal to fp32 rounding)
+        assert np.array_equal(t_ref[:-1], t_cut[:-1]) and abs(t_ref[-1] - t_cut[-1]) <= 2e-6 * abs(t_ref[-1])
         for n in ref.VAR_NAMES:
             assert np.array_equal(ref.get(n), cut.get(n)), n
         # cancelling at the initial ELBO; an exception in the callback stops the loop and is re-raised

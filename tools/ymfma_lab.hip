@@ -45,25 +45,25 @@ __global__ void ref_yt(const uint8_t* Y, const float* F, int Df, int K, const un
   }
 }
 
-template <int TL> float time_yw(const uint4* Yf, const uint4* Wq, int64_t NT, int GS, int* out, int reps) {
+template <int TL, int DEPTH> float time_yw(const uint4* Yf, const uint4* Wq, int64_t NT, int GS, int* out, int reps) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   const int grid = (int)((NT + 4 * TL - 1) / (4 * TL));
-  hipLaunchKernelGGL(k_yw_mfma_raw<TL>, dim3(grid), dim3(256), 0, 0, Yf, Wq, NT, GS, out);
+  hipLaunchKernelGGL((k_yw_mfma_raw<TL, DEPTH>), dim3(grid), dim3(256), 0, 0, Yf, Wq, NT, GS, out);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(a));
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_yw_mfma_raw<TL>, dim3(grid), dim3(256), 0, 0, Yf, Wq, NT, GS, out);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_yw_mfma_raw<TL, DEPTH>), dim3(grid), dim3(256), 0, 0, Yf, Wq, NT, GS, out);
   CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
   float ms; CK(hipEventElapsedTime(&ms, a, b));
   return ms / reps * 1e3f;
 }
-template <int TL> float time_yt(const uint4* Yb, const uint4* Pq, int GT, int64_t NS, int csplit, int* out, int reps) {
+template <int TL, int DEPTH> float time_yt(const uint4* Yb, const uint4* Pq, int GT, int64_t NS, int csplit, int* out, int reps) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   const int64_t schunk = (NS + csplit - 1) / csplit;
   const dim3 grid((GT + 4 * TL - 1) / (4 * TL), csplit);
-  hipLaunchKernelGGL(k_yt_mfma<TL>, grid, dim3(256), 0, 0, Yb, Pq, GT, NS, schunk, out);
+  hipLaunchKernelGGL((k_yt_mfma_raw<TL, DEPTH>), grid, dim3(256), 0, 0, Yb, Pq, GT, NS, schunk, out);
   CK(hipDeviceSynchronize());
   CK(hipEventRecord(a));
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_yt_mfma<TL>, grid, dim3(256), 0, 0, Yb, Pq, GT, NS, schunk, out);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_yt_mfma_raw<TL, DEPTH>), grid, dim3(256), 0, 0, Yb, Pq, GT, NS, schunk, out);
   CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
   float ms; CK(hipEventElapsedTime(&ms, a, b));
   return ms / reps * 1e3f;
@@ -104,10 +104,10 @@ int main(int argc, char** argv) {
   // ---- exactness
   hipLaunchKernelGGL(ref_yw, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, 0, Y, V, K, K, amax, N, G, Gp, ryw);
   hipLaunchKernelGGL(ref_yt, dim3((G + 255) / 256), dim3(256), 0, 0, Y, F, K, K, amax, N, G, Gp, ryt);
-  hipLaunchKernelGGL(k_yw_mfma_raw<4>, dim3((unsigned)((NT + 15) / 16)), dim3(256), 0, 0, Yf, Wq, NT, GS, oyw);
+  hipLaunchKernelGGL((k_yw_mfma_raw<4, 2>), dim3((unsigned)((NT + 15) / 16)), dim3(256), 0, 0, Yf, Wq, NT, GS, oyw);
   const int csplit = 6;
   const int64_t schunk = (NS + csplit - 1) / csplit;
-  hipLaunchKernelGGL(k_yt_mfma<1>, dim3((GT + 3) / 4, csplit), dim3(256), 0, 0, Yb, Pq, GT, NS, schunk, oyt);
+  hipLaunchKernelGGL((k_yt_mfma_raw<1, 4>), dim3((GT + 3) / 4, csplit), dim3(256), 0, 0, Yb, Pq, GT, NS, schunk, oyt);
   CK(hipDeviceSynchronize());
   {
     std::vector<int> o((size_t)NT * 256); std::vector<long long> r((size_t)N * 16);
@@ -130,9 +130,9 @@ int main(int argc, char** argv) {
   // ---- timing
   const double bytes = (double)N * G;
   const int reps = 30;
-#define TYW(TL) { const float us = time_yw<TL>(Yf, Wq, NT, GS, oyw, reps); printf("yw  TL=%d           %8.1f us  %.2f TB/s (stored %.0f MB)\n", TL, us, bytes / us * 1e-6, (double)NT * GS * 1024 / 1e6); }
-  TYW(1) TYW(2) TYW(4) TYW(6)
-#define TYT(TL, CS) { const float us = time_yt<TL>(Yb, Pq, GT, NS, CS, oyt, reps); printf("yt  TL=%d csplit=%2d %8.1f us  %.2f TB/s\n", TL, CS, us, bytes / us * 1e-6); }
-  TYT(1, 4) TYT(1, 6) TYT(1, 8) TYT(1, 12) TYT(1, 16) TYT(2, 8) TYT(2, 12) TYT(2, 16) TYT(4, 16)
+#define TYW(TL, DP) { const float us = time_yw<TL, DP>(Yf, Wq, NT, GS, oyw, reps); printf("yw  TL=%d depth=%d           %8.1f us  %.2f TB/s (stored %.0f MB)\n", TL, DP, us, bytes / us * 1e-6, (double)NT * GS * 1024 / 1e6); }
+  TYW(1, 2) TYW(1, 4) TYW(1, 8) TYW(2, 2) TYW(2, 4) TYW(4, 1) TYW(4, 2) TYW(4, 3)
+#define TYT(TL, DP, CS) { const float us = time_yt<TL, DP>(Yb, Pq, GT, NS, CS, oyt, reps); printf("yt  TL=%d depth=%d csplit=%2d %8.1f us  %.2f TB/s\n", TL, DP, CS, us, bytes / us * 1e-6); }
+  TYT(1, 2, 8) TYT(1, 4, 8) TYT(1, 8, 8) TYT(1, 4, 12) TYT(1, 4, 16) TYT(2, 2, 12) TYT(2, 4, 12) TYT(2, 4, 8) TYT(2, 4, 6) TYT(4, 2, 12) TYT(4, 2, 16)
   return 0;
 }
