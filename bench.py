@@ -84,6 +84,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cells", type=int, default=4096)
     ap.add_argument("--seed", type=int, default=20243)
+    ap.add_argument("--variant-off", default="", help="comma-separated engine variants to switch off (engine.VARIANTS), for A/B runs")
+    ap.add_argument("--variant-on", default="", help="comma-separated opt-in engine variants (engine.VARIANTS_ON), for A/B runs")
+    ap.add_argument("--tune", default="", help="comma-separated name=value decomposition overrides (engine.TUNE), for A/B runs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -127,7 +130,10 @@ def main():
 
     def make_engine(**kw):
         return HipEngine(None, aux["L"], psi0, loc0, K, 1, y_device_ptr=Yd.data_ptr(), y_device_dtype=np.int32,
-                         shape=(n_loc, G), device=local_rank, y_storage=args.y_storage, rank=rank, world=world, profile=0, **kw)
+                         shape=(n_loc, G), device=local_rank, y_storage=args.y_storage, rank=rank, world=world, profile=0,
+                         variant_off=tuple(v for v in args.variant_off.split(",") if v),
+                         variant_on=tuple(v for v in args.variant_on.split(",") if v),
+                         tune={k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(",") if kv)}, **kw)
 
     collective = "none"
     if world == 1:

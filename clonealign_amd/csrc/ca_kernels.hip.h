@@ -36,6 +36,20 @@ __device__ __forceinline__ float ca_wave_sum_lane63(float v) {
   return v;
 }
 
+// v + v[lane ^ 16] + v[lane ^ 32] + v[lane ^ 48] in every lane, on the VALU: gfx950's v_permlane16_swap / v_permlane32_swap exchange
+// odd and even rows of 16 lanes / the two halves of 32 between two registers; with the same value in both, the pair that
+// comes back is (own-or-even copy, partner-or-odd copy), so their sum is x + x[lane ^ 16] (then ^ 32).  __shfl_xor would go
+// through ds_bpermute_b32 and an s_waitcnt lgkmcnt(0) each.
+__device__ __forceinline__ float ca_sum_xor16_32(float v) {
+  typedef unsigned v2u __attribute__((ext_vector_type(2)));
+  unsigned u = __float_as_uint(v);
+  v2u r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+  v = __uint_as_float(r.x) + __uint_as_float(r.y);
+  u = __float_as_uint(v);
+  r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r.x) + __uint_as_float(r.y);
+}
+
 // deterministic block sum of doubles (blockDim.x == CA_TB); result valid in every thread.  Xor-butterfly inside each
 // wave (no LDS, no barrier), then the CA_TB / 64 wave totals through LDS in wave order: 2 barriers instead of the
 // 10 of an LDS tree -- the per-gene / per-cell / O(K + C) kernels are chains of these.
@@ -1312,6 +1326,9 @@ __device__ __forceinline__ void ca_split3(float x, unsigned short& p1, unsigned 
   p3 = ca_bf16_rn(x);
 }
 
+#ifndef CA_BWD_PD
+#define CA_BWD_PD 2   // batches of operands in flight per wave (3 and more cost the third wave per SIMD: 140 -> 200 us)
+#endif
 template <int TL, int DD>
 __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __restrict__ cq /*[N16][4][8] bf16 parts of coef*/,
                                                     const float* __restrict__ F /*[N16][DD]*/, const float* __restrict__ etamax2 /*[N16]*/,
@@ -1382,28 +1399,36 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
   if (!active)
     for (int64_t i = lane; i < (n1 - n0) * DD; i += 64) myd[i] = 0.f;
   // MFMA B operand: lane (column j, k-group q) holds part q of coef[cell b0+j][0..8): 16 bytes, 1 KiB per wave.
-  // The next batch's operands are fetched while the current one is in the pipes (cell arrays padded to 16).
-  uint4 craw_n = {0u, 0u, 0u, 0u};
-  float fc_n[DD], ec_n = 0.f;
+  // The operands of the next PD batches are in flight while the current one is in the pipes (cell arrays padded to 16): a
+  // batch is 380 issue cycles = 0.6 us of wall time at three waves per SIMD, one batch of look-ahead left the wave parked on
+  // s_waitcnt for 31 % of its cycles (SQ_WAIT_ANY, profiles/r01_v11_sq_counters.json) and far more beside an HBM stream.
+  constexpr int PD = CA_BWD_PD;
+  uint4 craw_r[PD];
+  float fc_r[PD][DD], ec_r[PD];
 #pragma unroll
-  for (int d = 0; d < DD; ++d) fc_n[d] = 0.f;
-  if (active && n0 < n1) {
-    craw_n = *reinterpret_cast<const uint4*>(cq + ((n0 + j) * 4 + q) * 8);
+  for (int d_ = 0; d_ < PD; ++d_) {
+    const int64_t bb = n0 + 16 * d_;
+    const int64_t bl = (active && bb < n1) ? bb : (N > 0 ? ((n0 < N) ? n0 : 0) : 0);   // past the slice: re-read its first batch (never used)
+    craw_r[d_] = *reinterpret_cast<const uint4*>(cq + ((bl + j) * 4 + q) * 8);
 #pragma unroll
-    for (int d = 0; d < DD; ++d) fc_n[d] = F[(n0 + j) * DD + d];
-    ec_n = etamax2[n0 + j];
+    for (int d = 0; d < DD; ++d) fc_r[d_][d] = F[(bl + j) * DD + d];
+    ec_r[d_] = etamax2[bl + j];
   }
-  for (int64_t b0 = n0; active && b0 < n1; b0 += 16) {
-    const uint4 craw = craw_n;
+  for (int64_t b00 = n0; active && b00 < n1; b00 += 16 * PD) {
+#pragma unroll
+  for (int d_ = 0; d_ < PD; ++d_) {
+    const int64_t b0 = b00 + 16 * d_;
+    if (b0 < n1) {   // wave-uniform
+    const uint4 craw = craw_r[d_];
     float fc[DD];
 #pragma unroll
-    for (int d = 0; d < DD; ++d) fc[d] = fc_n[d];
-    const float ec = ec_n;
-    if (b0 + 16 < n1) {
-      craw_n = *reinterpret_cast<const uint4*>(cq + ((b0 + 16 + j) * 4 + q) * 8);
+    for (int d = 0; d < DD; ++d) fc[d] = fc_r[d_][d];
+    const float ec = ec_r[d_];
+    if (b0 + 16 * PD < n1) {
+      craw_r[d_] = *reinterpret_cast<const uint4*>(cq + ((b0 + 16 * PD + j) * 4 + q) * 8);
 #pragma unroll
-      for (int d = 0; d < DD; ++d) fc_n[d] = F[(b0 + 16 + j) * DD + d];
-      ec_n = etamax2[b0 + 16 + j];
+      for (int d = 0; d < DD; ++d) fc_r[d_][d] = F[(b0 + 16 * PD + j) * DD + d];
+      ec_r[d_] = etamax2[b0 + 16 * PD + j];
     }
     const ca_bf16x8 Cf = __builtin_bit_cast(ca_bf16x8, craw);
     ca_f32x2 dF[DD];
@@ -1433,10 +1458,11 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
 #pragma unroll
     for (int d = 0; d < DD; ++d) {
       float dd = dF[d].x + dF[d].y;
-      dd += __shfl_xor(dd, 16);
-      dd += __shfl_xor(dd, 32);
+      dd = ca_sum_xor16_32(dd);   // over the four lane groups q (v_permlane16/32_swap: no LDS round trip, no lgkmcnt wait per batch)
       if (q == 0 && n < n1) myd[(n - n0) * DD + d] = dd;
     }
+    }   // b0 < n1
+  }     // ring slot
   }
   __syncthreads();
   const int64_t wstride = cchunk * DD;
@@ -2299,4 +2325,40 @@ __global__ void __launch_bounds__(CA_TB) k_adam_cell(const float* __restrict__ F
     }
     etamax2[n] = e;
   }
+}
+
+// ------------------------------------------------------------------ count-matrix products on the int8 matrix cores
+#include "ca_ymfma.hip.h"
+
+// Column products, engine form: the sweep of ca_yt_block plus, as extra blocks of the launch, the gene side of the overflow
+// list (per-chunk sums of the counts above 255; they depend on psi only).
+template <int TL, int DEPTH>
+__global__ void __launch_bounds__(CA_YM_TB) k_yt_mfma(const uint4* __restrict__ Yb, const uint4* __restrict__ Pq, int GT, int64_t NS,
+                                                      int64_t schunk, int* __restrict__ out, int nb_main, ca_ovf_args ovf,
+                                                      const float* __restrict__ F, int Df, int K) {
+  if ((int)blockIdx.x >= nb_main) {
+    if (blockIdx.y == 0) ca_ovf_chunks_body(blockIdx.x - nb_main, ovf.chunk_start, ovf.row2, ovf.val2, F, Df, ovf.csum, ovf.nchunk, K, 0);
+    return;
+  }
+  ca_yt_block<TL, DEPTH>(Yb, Pq, GT, NS, schunk, out);
+}
+// Y^T psi from the slices' digit sums: integer sum over the slices (exact), digits combined in fp64, the fixed-point scale
+// taken out, the overflow list's chunk sums of the gene added.  One thread per (gene, k); red_y is [G][K].
+__global__ void __launch_bounds__(CA_TB) k_yt_finish(const int* __restrict__ out /*[csplit][GT * 16][16]*/, int csplit, int GT, int G, int K,
+                                                     const unsigned* __restrict__ amax, const int* __restrict__ col_chunk_ptr,
+                                                     const float* __restrict__ csum, double* __restrict__ red_y) {
+  const int i = blockIdx.x * CA_TB + threadIdx.x;
+  if (i >= G * K) return;
+  const int g = i / K, k = i - g * K;
+  double v = 0.0;
+#pragma unroll
+  for (int p = 3; p >= 0; --p) {
+    long long a = 0;
+    for (int sp = 0; sp < csplit; ++sp) a += out[(((int64_t)sp * GT * 16) + g) * 16 + 4 * k + p];
+    v = v * 256.0 + (double)a;
+  }
+  v *= ldexp(1.0, -ca_fix_exp(__uint_as_float(amax[1])));
+  if (csum)
+    for (int ch = col_chunk_ptr[g]; ch < col_chunk_ptr[g + 1]; ++ch) v += (double)csum[(int64_t)ch * K + k];
+  red_y[i] = v;
 }

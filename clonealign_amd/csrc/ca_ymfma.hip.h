@@ -134,6 +134,12 @@ __global__ void __launch_bounds__(CA_YM_TB) k_ym_quant(const float* __restrict__
 }
 
 // ---------------------------------------------------------------- the two streams
+// streamed once: non-temporal, so the tiles do not push the sweeps' shared operands out of the XCD's L2
+__device__ __forceinline__ uint4 ca_ld_stream(const uint4* p) {
+  typedef unsigned v4u __attribute__((ext_vector_type(4)));
+  const v4u v = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(p));
+  return (uint4){v.x, v.y, v.z, v.w};
+}
 __device__ __forceinline__ ca_i32x4 ca_mfma_i8(uint4 a, uint4 b, ca_i32x4 c) {
   return __builtin_amdgcn_mfma_i32_16x16x64_i8(__builtin_bit_cast(ca_i32x4, a), __builtin_bit_cast(ca_i32x4, b), c, 0, 0, 0);
 }
@@ -160,7 +166,7 @@ __device__ __forceinline__ void ca_ym_sweep(const uint4* const (&mat)[TL], const
   for (int d = 0; d < DEPTH; ++d) {
     const int64_t s = (s0 + d < s1) ? s0 + d : (s1 > s0 ? s1 - 1 : s0);   // past the end: re-read the last step (never used)
 #pragma unroll
-    for (int t = 0; t < TL; ++t) a[d][t] = mat[t][s * 64];
+    for (int t = 0; t < TL; ++t) a[d][t] = ca_ld_stream(mat[t] + s * 64);
     b[d] = par[s * 64];
   }
   for (int64_t s = s0; s < s1; s += DEPTH) {
@@ -172,7 +178,7 @@ __device__ __forceinline__ void ca_ym_sweep(const uint4* const (&mat)[TL], const
         for (int t = 0; t < TL; ++t) acc[t] = ca_mfma_i8(a[d][t], b[d], acc[t]);
         if (s + d + DEPTH < s1) {
 #pragma unroll
-          for (int t = 0; t < TL; ++t) a[d][t] = mat[t][(s + d + DEPTH) * 64];
+          for (int t = 0; t < TL; ++t) a[d][t] = ca_ld_stream(mat[t] + (s + d + DEPTH) * 64);
           b[d] = par[(s + d + DEPTH) * 64];
         }
       }
@@ -238,8 +244,9 @@ __global__ void __launch_bounds__(CA_YM_TB) k_yw_mfma(const uint4* __restrict__ 
           v += a;
         }
         if (live && p == 0) {
-          YW[n * K + k] = (float)v;
-          part += (double)F[n * Df + k] * v;
+          const float vf = (float)v;         // YW is a float32 array; the ELBO term is taken from the same values
+          YW[n * K + k] = vf;
+          part += (double)F[n * Df + k] * (double)vf;
         }
       }
   }

@@ -138,8 +138,11 @@ struct ca_engine {
   // matrix-core backward sweep (k_bwd_mfma): bf16 parts of coef, its own cell split
   bool bwd_mfma = false; unsigned short* coefq = nullptr; int64_t N16 = 0, cchunk_m = 0; int csplit_m = 1, nwt = 0;
   uint64_t draw = 0;  // built-in stream position
-  // count-matrix products on the int8 matrix cores (ca_ymfma.hip.h)
+  // count-matrix products on the int8 matrix cores (ca_ymfma.hip.h): tiled copies, fixed-point parameter images
   bool y_mfma = false;
+  int64_t ym_NT = 0, ym_NS = 0, ym_schunk = 0; int ym_GS = 0, ym_GT = 0, ym_csplit = 1, ym_tl = 4;
+  uint4 *Yf = nullptr, *Yb = nullptr, *Wq = nullptr, *Pq = nullptr; unsigned* ym_amax = nullptr; int* ym_out = nullptr;
+  hipEvent_t ev_ywdone = nullptr; bool yw_pending = false, on_side = false;
   // one-shot peer-to-peer all-reduce (set by ca_comm_init when every peer is reachable)
   struct ca_p2p* p2p = nullptr;
   // ---- comm
@@ -394,9 +397,22 @@ int download_f(ca_engine* h, std::vector<float>& v, const float* src, int64_t n)
   return CA_OK;
 }
 
+// The side stream's products: the row products (YW, psi.(YW) partials) are done at ev_ywdone, everything (also Y^T psi)
+// at ev_ydone.  all = false waits for the row products only (the backward sweep's ELBO tail needs nothing else).
+int wait_y(ca_engine* h, bool all) {
+  if (all) {
+    if (h->y_pending) HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ydone, 0));
+    h->y_pending = false; h->yw_pending = false;
+  } else if (h->yw_pending) {
+    HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ywdone, 0));
+    h->yw_pending = false;
+  }
+  return CA_OK;
+}
+
 // ---- derived state that depends on the parameters only (not on eps) -------------------------
 int refresh_derived(ca_engine* h) {
-  if (h->y_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ydone, 0)); h->y_pending = false; }
+  CACK(wait_y(h, true));
   h->y_defer = false;   // a deferred side-stream Y pass would not be ordered after this parameter change: redo it in line
   h->pre_valid = false;
   if (h->D > 0) {
@@ -409,20 +425,66 @@ int refresh_derived(ca_engine* h) {
   return CA_OK;
 }
 
+// The same two products on the int8 matrix cores (ca_ymfma.hip.h): fixed-point images of W and psi, then one stream
+// over each tiled copy of the count matrix.  Runs on h->stream (the side stream when deferred).
+template <int TL, int DEPTH>
+void launch_yw(ca_engine* h) {
+  hipLaunchKernelGGL((k_yw_mfma<TL, DEPTH>), dim3(cdiv(h->ym_NT, 4 * TL)), dim3(CA_YM_TB), 0, h->stream, h->Yf, h->Wq, h->ym_NT, h->ym_GS, h->N,
+                     h->K, h->F, h->D, h->V, h->D, h->ym_amax, h->n_ovf > 0 ? h->ovf_rowptr : nullptr, h->ovf_col, h->ovf_val, h->YW, h->yw_part);
+}
+int ycache_mfma(ca_engine* h) {
+  HIPCK(h, hipMemsetAsync(h->ym_amax, 0, 2 * sizeof(unsigned), h->stream));
+  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_ym_absmax, dim3(cdiv(std::max<int64_t>(h->N, h->G), CA_YM_TB)), dim3(CA_YM_TB), 0, h->stream,
+                                                h->V, h->D, (int64_t)h->G, h->F, h->D, h->N, h->K, h->ym_amax));
+  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_ym_quant, dim3(cdiv((h->ym_GS + h->ym_NS) * 64, CA_YM_TB)), dim3(CA_YM_TB), 0, h->stream,
+                                                h->V, h->D, (int64_t)h->G, h->ym_GS, h->F, h->D, h->N, h->ym_NS, h->K, h->ym_amax, h->Wq, h->Pq));
+  // row products: YW and the psi.(YW) partials, one block per 64 * TL cells (n_yw blocks when TL = 4)
+  CACK(prof_begin(h, CA_KERNEL_YPASS));
+  if (h->ym_tl == 4) launch_yw<4, 2>(h);
+  else if (h->ym_tl == 2) launch_yw<2, 4>(h);
+  else launch_yw<1, 8>(h);
+  HIPCK(h, hipGetLastError());
+  CACK(prof_end(h));
+  if (h->on_side) { HIPCK(h, hipEventRecord(h->ev_ywdone, h->stream)); h->yw_pending = true; }
+  // column products: digit sums per cell slice, then Y^T psi into red_y
+  ca_ovf_args ovf;
+  memset(&ovf, 0, sizeof(ovf));
+  int nb_ovf = 0;
+  if (h->n_ovf > 0) {
+    nb_ovf = cdiv(h->n_ovf_chunk, CA_TB / 64);
+    ovf.chunk_start = h->ovf_chunk_start; ovf.row2 = h->ovf_row2; ovf.val2 = h->ovf_val2; ovf.csum = h->ovf_csum; ovf.nchunk = h->n_ovf_chunk;
+  }
+  const int nb_main = cdiv(h->ym_GT, 4 * 2);
+  LAUNCH(h, CA_KERNEL_YPASS, hipLaunchKernelGGL((k_yt_mfma<2, 2>), dim3(nb_main + nb_ovf, h->ym_csplit), dim3(CA_YM_TB), 0, h->stream, h->Yb, h->Pq,
+                                                h->ym_GT, h->ym_NS, h->ym_schunk, h->ym_out, nb_main, ovf, h->F, h->D, h->K));
+  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_yt_finish, dim3(cdiv((int64_t)h->G * h->K, CA_TB)), dim3(CA_TB), 0, h->stream, h->ym_out,
+                                                h->ym_csplit, h->ym_GT, h->G, h->K, h->ym_amax, h->n_ovf > 0 ? h->ovf_col_chunk_ptr : nullptr,
+                                                h->n_ovf > 0 ? h->ovf_csum : nullptr, h->red + h->off_y));
+  h->ycache_valid = true;
+  return CA_OK;
+}
+
 // Y.W and Y^T.psi for the current parameters (once per parameter state)
 int ensure_ycache(ca_engine* h) {
   if (h->y_defer) {   // deferred side-stream start (train_tail): ordered after the parameter update by ev_params
     h->y_defer = false;
     HIPCK(h, hipStreamWaitEvent(h->stream2, h->ev_params, 0));
     std::swap(h->stream, h->stream2);
+    h->on_side = true;
     const int rc = ensure_ycache(h);
+    h->on_side = false;
     std::swap(h->stream, h->stream2);
     CACK(rc);
     HIPCK(h, hipEventRecord(h->ev_ydone, h->stream2));
     h->y_pending = true;
+    if (!h->yw_pending) {   // (the VALU stream has no earlier point: its row products are finished by its last launch)
+      HIPCK(h, hipEventRecord(h->ev_ywdone, h->stream2));
+      h->yw_pending = true;
+    }
     return CA_OK;
   }
   if (h->ycache_valid || h->K == 0) { h->ycache_valid = true; return CA_OK; }
+  if (h->y_mfma) return ycache_mfma(h);
   dim3 grid((unsigned)((int64_t)h->nrg * h->nseg));
   // entries above 255: one extra "segment" of YW and one extra term of Y^T psi; their per-entry work rides on the
   // first stream launch, the per-gene sums on the column-sum launch
@@ -619,7 +681,7 @@ inline bool is_sharded(const ca_engine* h) { return h->opt.world > 1 || h->comm 
 // ready for the all-reduce.  The Y stream (side stream) must have delivered the psi.(YW) partials first.
 int mon_tail_local_sums(ca_engine* h) {
   if (!h->mon_tail.enabled || !h->mon_tail.cell_part) return CA_OK;
-  if (h->y_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ydone, 0)); h->y_pending = false; }
+  CACK(wait_y(h, false));
   ca_small_args r = h->mon_tail;
   r.reduce_only = 1; r.host_out = nullptr;
   LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_final_small, dim3(1), dim3(CA_TB), 0, h->stream, r));
@@ -629,7 +691,7 @@ int mon_tail_local_sums(ca_engine* h) {
 // a fused monitor pass leaves its ELBO assembly for the next train pass's per-gene kernel; if none is coming, run it now
 int flush_mon_tail(ca_engine* h) {
   if (!h->mon_tail.enabled) return CA_OK;
-  if (h->y_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ydone, 0)); h->y_pending = false; }
+  CACK(wait_y(h, false));
   if (is_sharded(h) && h->mon_tail.cell_part) {   // local sums, then the (3 + C)-double all-reduce of a monitor pass
     CACK(mon_tail_local_sums(h));
     CACK(allreduce(h, h->red, 3 + h->C));
@@ -655,7 +717,7 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
     // kernel later than the cell epilogue that used to need it.
     ca_small_args bwd_tail = no_small_args();
     if (h->mon_tail.enabled && h->mon_tail.cell_part) {
-      if (h->y_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ydone, 0)); h->y_pending = false; }
+      CACK(wait_y(h, false));   // the psi.(YW) partials; the column products may still be streaming beside this sweep
       bwd_tail = h->mon_tail;
       merged = is_sharded(h);
       if (merged) { bwd_tail.reduce_only = 1; bwd_tail.host_out = nullptr; }
@@ -701,7 +763,7 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
                               h->red + h->off_g, h->csplit, (int64_t)h->G * W_, h->G * W_));
   }
   // the Y stream's results (Y^T psi in red_y, the psi.(YW) partials) are first needed from here on
-  if (h->y_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ydone, 0)); h->y_pending = false; }
+  CACK(wait_y(h, true));
   // sharded loop: a pending monitor pass's cell sums travel with this pass's gene sums -- ONE all-reduce per iteration;
   // the ELBO is assembled after it (k_final_gene's extra block, or ca_run's flush)
   if (cell_sums_global && !merged) CACK(allreduce(h, h->red + h->off_g, h->red_n - h->off_g));
@@ -798,10 +860,10 @@ int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_d
       float* Zp = h->Zpart + (((int64_t)s * h->nchunk + ch) * h->gsplit) * h->N * CA_CW;
       LAUNCH(h, CA_KERNEL_FWD, launch_fwd(nc, h->D, dim3(cdiv(h->N, CA_TB * kFwdR), h->gsplit), h->stream, h->F, h->etamax2, h->Vs, M, Zp, h->N, h->G, h->gchunk));
     }
-  if (h->y_pending) {   // the cell epilogue is the first consumer of YW / Y^T psi
-    HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ydone, 0));
-    h->y_pending = false;
-  }
+  CACK(wait_y(h, true));   // the cell epilogue is the first consumer of YW / Y^T psi
+  // (matrix-core products arrive as finished row sums: one "strip", already in YW)
+  const float* ywp = h->y_mfma ? h->YW : h->YWpart;
+  const int ywseg = h->y_mfma ? 1 : h->nseg + (h->n_ovf > 0 ? 1 : 0);
   if (h->C <= 64) {
     int CP = 1;
     while (CP < h->C) CP <<= 1;
@@ -809,8 +871,8 @@ int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_d
 #define CA_CELL(CPV)                                                                                                          \
   LAUNCH(h, CA_KERNEL_CELL,                                                                                                   \
          hipLaunchKernelGGL((k_cell_par<CPV>), grid, dim3(CA_TB), 0, h->stream, h->Zpart, h->A, h->cn, h->s64, h->etamax2,    \
-                            h->glogit, h->alpha_u, h->F, h->YWpart, h->YW, h->coef, h->dgl, h->cell_part, h->N, h->C, h->S,  \
-                            h->D, h->K, h->gsplit, h->nchunk, h->nseg + (h->n_ovf > 0 ? 1 : 0), mode, h->bwd_mfma ? h->coefq : nullptr, h->N16))
+                            h->glogit, h->alpha_u, h->F, ywp, h->YW, h->coef, h->dgl, h->cell_part, h->N, h->C, h->S,       \
+                            h->D, h->K, h->gsplit, h->nchunk, ywseg, mode, h->bwd_mfma ? h->coefq : nullptr, h->N16))
     switch (CP) {
       case 1: CA_CELL(1); break;
       case 2: CA_CELL(2); break;
@@ -824,8 +886,8 @@ int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_d
   } else {
     LAUNCH(h, CA_KERNEL_CELL,
            hipLaunchKernelGGL(k_cell, dim3(h->ncblk), dim3(CA_TB), 0, h->stream, h->Zpart, h->A, h->cn, h->s64, h->etamax2, h->glogit,
-                              h->alpha_u, h->F, h->YWpart, h->YW, h->coef, h->dgl, h->scratch, h->cell_part, h->N, h->C, h->S, h->D,
-                              h->K, h->gsplit, h->nchunk, h->nseg + (h->n_ovf > 0 ? 1 : 0), mode));
+                              h->alpha_u, h->F, ywp, h->YW, h->coef, h->dgl, h->scratch, h->cell_part, h->N, h->C, h->S, h->D,
+                              h->K, h->gsplit, h->nchunk, ywseg, mode));
   }
   if (mode == CA_MODE_GINIT) return CA_OK;
   LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_reduce_part, dim3(3 + h->C), dim3(CA_TB), 0, h->stream, h->cell_part, h->red, h->ncblk, 3 + h->C));
@@ -1285,7 +1347,11 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   HIPCK(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
   HIPCK(h, hipEventCreateWithFlags(&h->ev_params, hipEventDisableTiming));
   HIPCK(h, hipEventCreateWithFlags(&h->ev_ydone, hipEventDisableTiming));
-  h->async_y = variant_on(h, CA_VAR_ASYNC_Y, "CA_ASYNC_Y");
+  HIPCK(h, hipEventCreateWithFlags(&h->ev_ywdone, hipEventDisableTiming));
+  // side stream for the count-matrix products: pays from ~4e7 counts up (12.5k x 5k: 9543 it/s against 9207 in line;
+  // 10k x 2k: 10917 against 13017 -- two cross-stream events per iteration cost more than the overlap returns)
+  h->async_y = variant_on(h, CA_VAR_ASYNC_Y, "CA_ASYNC_Y") &&
+               ((double)h->N * (double)h->G >= 4e7 || (h->opt.variant_on & CA_VARX_ASYNC_SMALL) || (debug_env() && getenv("CA_ASYNC_SMALL")));
   HIPCK(h, hipHostMalloc((void**)&h->host_pinned, 64 * sizeof(double)));
   memset(h->host_pinned, 0, 64 * sizeof(double));
   if (hipHostGetDevicePointer((void**)&h->host_dev, h->host_pinned, 0) != hipSuccess) { h->host_dev = nullptr; (void)hipGetLastError(); }
@@ -1491,9 +1557,9 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   }
   if (verbose(h))
     fprintf(stderr, "[clonealign_hip] N=%lld G=%d C=%d D=%d n_cu=%d gsplit=%d gchunk=%d csplit=%d fused=%d fwd_mfma=%d fsplit=%d fkchunk=%d "
-            "bwd_mfma=%d csplit_m=%d cchunk_m=%lld nwt=%d fwd_cell=%d fc_tl=%d fc_nbig=%d ncblk_f=%d\n", (long long)Nn, G, C, D, h->n_cu, h->gsplit,
+            "bwd_mfma=%d csplit_m=%d cchunk_m=%lld nwt=%d fwd_cell=%d fc_tl=%d fc_nbig=%d ncblk_f=%d ystore=%d\n", (long long)Nn, G, C, D, h->n_cu, h->gsplit,
             h->gchunk, h->csplit, (int)h->fused_ok, (int)h->fwd_mfma, h->fsplit, h->fkchunk, (int)h->bwd_mfma, h->csplit_m,
-            (long long)h->cchunk_m, h->nwt, (int)h->fwd_cell, h->fc_tl, h->fc_nbig, h->ncblk_f);
+            (long long)h->cchunk_m, h->nwt, (int)h->fwd_cell, h->fc_tl, h->fc_nbig, h->ncblk_f, h->ystore);
   CACK(dalloc(h, &h->vmm, 2 * std::max(D, 1)));
   CACK(dalloc(h, &h->vmm_part, (int64_t)h->ngblk * 2 * std::max(D, 1)));
   CACK(dalloc(h, &h->etamax2, h->N16));
@@ -1511,6 +1577,36 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   h->n_yw = cdiv(Nn, CA_TB);
   CACK(dalloc(h, &h->yw_part, h->n_yw));
   CACK(dalloc(h, &h->ytpsi, (int64_t)h->Gp * std::max(K, 1)));
+  // ---- count-matrix products on the int8 matrix cores: two tiled copies of the 1-byte matrix (cell-tiled for Y.W,
+  //      gene-tiled for Y^T.psi), each in the operand layout of v_mfma_i32_16x16x64_i8 (ca_ymfma.hip.h)
+  if (h->ystore == CA_YSTORE_U8 && K >= 1 && K <= 4 && ((h->opt.variant_on & CA_VARX_Y_MFMA2) || (debug_env() && getenv("CA_Y_MFMA2")))) {
+    h->ym_NT = cdiv(Nn, 16); h->ym_NS = cdiv(Nn, 64); h->ym_GS = cdiv(G, 64); h->ym_GT = cdiv(G, 16);
+    uint8_t *yf = nullptr, *yb = nullptr;
+    CACK(dalloc(h, &yf, h->ym_NT * h->ym_GS * 1024));
+    CACK(dalloc(h, &yb, (int64_t)h->ym_GT * h->ym_NS * 1024));
+    h->Yf = (uint4*)yf; h->Yb = (uint4*)yb;
+    uint8_t *wq = nullptr, *pq = nullptr;
+    CACK(dalloc(h, &wq, (int64_t)h->ym_GS * 1024));
+    CACK(dalloc(h, &pq, h->ym_NS * 1024));
+    h->Wq = (uint4*)wq; h->Pq = (uint4*)pq;
+    CACK(dalloc(h, &h->ym_amax, 2));
+    // waves: rows 64 TL cells per block, at least ~4 waves per CU; columns 8 gene tiles per block x cell slices
+    h->ym_tl = (h->ym_NT / 4 >= 4 * h->n_cu) ? 4 : (h->ym_NT / 2 >= 4 * h->n_cu) ? 2 : 1;
+    h->n_yw = cdiv(h->ym_NT, 4 * h->ym_tl);   // blocks of k_yw_mfma = partials of sum_n psi_n.(YW)_n
+    CACK(dalloc(h, &h->yw_part, h->n_yw));
+    const int gblocks = cdiv(h->ym_GT, 8);
+    h->ym_csplit = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, cdiv(8 * (int64_t)h->n_cu, 4 * gblocks)), h->ym_NS / 4));
+    h->ym_schunk = cdiv(h->ym_NS, h->ym_csplit);
+    h->ym_csplit = cdiv(h->ym_NS, h->ym_schunk);
+    CACK(dalloc(h, &h->ym_out, (int64_t)h->ym_csplit * h->ym_GT * 256));
+    hipLaunchKernelGGL(k_tile_yf, dim3(cdiv(h->ym_NT * h->ym_GS * 64, CA_YM_TB)), dim3(CA_YM_TB), 0, h->stream, (const uint8_t*)h->Y, h->Yf, Nn, h->Gp,
+                       h->ym_NT, h->ym_GS);
+    hipLaunchKernelGGL(k_tile_yb, dim3((unsigned)h->ym_NS, cdiv(h->ym_GT, 4)), dim3(CA_YM_TB), 0, h->stream, (const uint8_t*)h->Y, h->Yb, Nn, h->Gp,
+                       h->ym_GT, h->ym_NS);
+    HIPCK(h, hipGetLastError());
+    h->y_mfma = true;
+    h->y_dev_bytes += (h->ym_NT * h->ym_GS + (int64_t)h->ym_GT * h->ym_NS) * 1024;
+  }
   h->off_g = 3 + C;
   h->off_y = h->off_g + (int64_t)G * (S + D);
   h->red_n = h->off_y + (int64_t)G * K;
@@ -1738,6 +1834,7 @@ int ca_destroy(ca_handle h) {
   if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
   if (h->ev_params) hipEventDestroy(h->ev_params);
   if (h->ev_ydone) hipEventDestroy(h->ev_ydone);
+  if (h->ev_ywdone) hipEventDestroy(h->ev_ywdone);
   if (h->comm) g_rccl.CommDestroy(h->comm);
   for (auto& e : h->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   for (void* q : h->allocs) hipFree(q);
@@ -1958,7 +2055,7 @@ int ca_init_psi_pca(ca_handle h, const double* noise, int32_t n_iter, uint64_t s
   if (!h) return CA_ERR_INVALID;
   if (h->K == 0) return CA_OK;
   HIPCK(h, hipSetDevice(h->device));
-  if (h->y_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ydone, 0)); h->y_pending = false; }
+  CACK(wait_y(h, true));
   const int64_t N = h->N; const int G = h->G, Gp = h->Gp, K = h->K;
   const int q = std::min(std::min(K + 4, 12), G);
   if (n_iter <= 0) n_iter = 40;
@@ -2099,7 +2196,7 @@ int ca_init_psi_pca(ca_handle h, const double* noise, int32_t n_iter, uint64_t s
 int ca_clone_gene_sums(ca_handle h, const int32_t* clone_of_cell, double* Tout, double* Syy) {
   if (!h || !clone_of_cell || !Tout || !Syy) return CA_ERR_INVALID;
   HIPCK(h, hipSetDevice(h->device));
-  if (h->y_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ydone, 0)); h->y_pending = false; }
+  CACK(wait_y(h, true));
   const int64_t N = h->N; const int G = h->G, Gp = h->Gp, C = h->C;
   float *Fp = nullptr, *Vp = nullptr, *YWp = nullptr, *YTp = nullptr, *csum = nullptr; double* ytd = nullptr;
   auto cleanup = [&]() { hipFree(Fp); hipFree(Vp); hipFree(YWp); hipFree(YTp); hipFree(csum); hipFree(ytd); };
@@ -2214,7 +2311,7 @@ int ca_reinit(ca_handle h, const double* psi0, const double* loc0) {
   if (!h) return CA_ERR_INVALID;
   if (h->K > 0 && !psi0) { h->err = "psi0 is required when K > 0"; return CA_ERR_INVALID; }
   HIPCK(h, hipSetDevice(h->device));
-  if (h->y_pending) { HIPCK(h, hipStreamWaitEvent(h->stream, h->ev_ydone, 0)); h->y_pending = false; }
+  CACK(wait_y(h, true));
   HIPCK(h, hipStreamSynchronize(h->stream));
   const int64_t N = h->N; const int G = h->G, C = h->C, K = h->K, D = h->D;
   auto zero = [&](float* p, int64_t n) { return p && n > 0 ? hipMemsetAsync(p, 0, (size_t)n * sizeof(float), h->stream) : hipSuccess; };

@@ -23,7 +23,8 @@ YSTORE_NAME = {v: k for k, v in YSTORE.items()}
 KERNEL_NAMES = ("fwd", "bwd", "ypass", "cell", "other")
 # ca_variant bits (ca_options.variant_off: a set bit switches the variant OFF) and ca_tune_id slots
 VARIANTS = {"fused": 1 << 0, "fwd_mfma": 1 << 1, "fwd_cell": 1 << 2, "bwd_mfma": 1 << 3, "tail_fuse": 1 << 4, "async_y": 1 << 5,
-            "pre": 1 << 6, "pair_elbo": 1 << 7, "prep_fast": 1 << 8, "y_mfma": 1 << 9, "p2p": 1 << 10}
+            "pre": 1 << 6, "pair_elbo": 1 << 7, "prep_fast": 1 << 8, "p2p": 1 << 10}
+VARIANTS_ON = {"y_mfma2": 1 << 0, "async_small": 1 << 1}      # ca_variant_on: opt-in variants
 OPT_VERBOSE = 0x80000000
 TUNE = {"gsplit": 0, "fsplit": 1, "fc_tl": 2, "fc_nbig": 3, "csplit": 4, "csplit_m": 5, "tr": 6, "rg": 7}
 TRANSPORT_NAME = {0: "none", 1: "rccl", 2: "host", 3: "p2p"}
@@ -48,7 +49,8 @@ class CaOptions(C.Structure):
     _fields_ = [("learning_rate", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
                 ("adam_eps", C.c_double), ("seed", C.c_uint64), ("device", C.c_int32),
                 ("y_storage", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32), ("profile", C.c_int32),
-                ("variant_off", C.c_uint32), ("tune", C.c_int32 * 8), ("reserved", C.c_int32 * 6)]
+                ("variant_off", C.c_uint32), ("tune", C.c_int32 * 8), ("variant_on", C.c_uint32),
+                ("reserved", C.c_int32 * 5)]
 
 
 class CaInfo(C.Structure):
@@ -77,7 +79,7 @@ def load_library(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    p = path or os.environ.get("CLONEALIGN_HIP_LIB") or LIB_PATH     # (the override is for A/B builds of the same ABI)
     if not os.path.exists(p):
         raise RuntimeError(
             f"{p} not found: build the HIP engine first (python -c 'import __graft_entry__ as g; g.build()' "
@@ -155,12 +157,13 @@ class HipEngine:
     def __init__(self, Y, L, psi0, loc0, K, S=1, X=None, extra_loglik=None, learning_rate=0.1,
                  device=0, y_storage="auto", seed=0x5EED5EED, rank=0, world=1, profile=False,
                  y_device_ptr=None, y_device_dtype=None, shape=None, comm_id=None, host_allreduce=None,
-                 layout="row", cell_index=None, gene_index=None, variant_off=(), tune=None, verbose=False):
+                 layout="row", cell_index=None, gene_index=None, variant_off=(), variant_on=(), tune=None, verbose=False):
         """``layout``: "row" (C / numpy order) or "col" -- every matrix is then handed over column-major (Fortran order),
         which is what the R caller has (R/inference-tflow.R:190-191,355) and what r_shim/clonealign_hip_shim.c passes; the
         ``get``/``set`` matrices use the same layout.  ``cell_index`` / ``gene_index``: Y is the RAW matrix and the fit uses
         these rows / columns of it (ca_problem.cell_index / gene_index); L, psi0, loc0, X, extra_loglik are for the selection.
-        ``variant_off``: names from VARIANTS (or a bitmask) to switch off; ``tune``: {name from TUNE: value}."""
+        ``variant_off``: names from VARIANTS (or a bitmask) to switch off; ``variant_on``: names from VARIANTS_ON to switch on;
+        ``tune``: {name from TUNE: value}."""
         self.lib = load_library()
         self.h = C.c_void_p()
         if layout not in ("row", "col"):
@@ -214,6 +217,7 @@ class HipEngine:
         opt.profile = 0x1F if profile is True else int(profile)
         voff = int(variant_off) if isinstance(variant_off, int) else sum(VARIANTS[v] for v in variant_off)
         opt.variant_off = (voff | (OPT_VERBOSE if verbose else 0)) & 0xFFFFFFFF
+        opt.variant_on = int(variant_on) if isinstance(variant_on, int) else sum(VARIANTS_ON[v] for v in variant_on)
         for k, v in (tune or {}).items():
             opt.tune[TUNE[k]] = int(v)
         rc = self.lib.ca_create(C.byref(prob), C.byref(opt), C.byref(self.h))

@@ -87,8 +87,16 @@ enum ca_variant {
   CA_VAR_PRE = 1 << 6,        /* next pass's per-gene prologue on the per-cell Adam kernel */
   CA_VAR_PAIR_ELBO = 1 << 7,  /* final ELBOs two draws per sweep */
   CA_VAR_PREP_FAST = 1 << 8,  /* wave-per-cell fit-constant kernel for u8 storage */
-  CA_VAR_Y_MFMA = 1 << 9,     /* count-matrix products on the int8 matrix cores from tiled copies (else k_ypass) */
   CA_VAR_P2P = 1 << 10        /* one-shot peer-to-peer all-reduce (else ncclAllReduce) after ca_comm_init() */
+};
+/* Opt-in variants (bits of ca_options.variant_on): measured slower than the default on the headline workload, kept built and
+ * under test because they are the evidence for the choice. */
+enum ca_variant_on {
+  CA_VARX_Y_MFMA2 = 1 << 0,   /* count-matrix products on the int8 matrix cores from TWO tiled copies (cell-tiled for Y.W,
+                                 gene-tiled for Y^T.psi; ca_ymfma.hip.h): 6.0 TB/s per stream against 4.7 for k_ypass, but twice
+                                 the bytes per iteration */
+  CA_VARX_ASYNC_SMALL = 1 << 1 /* side stream also below 4e7 counts (small shards run the Y stream in line: the two cross-stream
+                                 events cost more than the overlap returns there) */
 };
 #define CA_OPT_VERBOSE 0x80000000u /* in variant_off: print the decomposition picks to stderr */
 /* decomposition parameters the heuristics pick; a non-zero ca_options.tune[id] overrides (CA_TUNE_FC_NBIG: -1 = one block size) */
@@ -107,7 +115,8 @@ typedef struct ca_options {
   int32_t profile;                  /* bitmask over ca_kernel_id: time those kernel classes with HIP events */
   uint32_t variant_off;             /* ca_variant bits to switch off (| CA_OPT_VERBOSE); 0 = defaults */
   int32_t tune[8];                  /* ca_tune_id overrides, 0 = heuristic */
-  int32_t reserved[6];
+  uint32_t variant_on;              /* ca_variant_on bits to switch on; 0 = defaults */
+  int32_t reserved[5];
 } ca_options;
 /* (The same switches can be set from the environment -- CA_FUSED=0, CA_CSPLIT=12, ... -- but ONLY when
  *  CLONEALIGN_DEBUG_ENV is set: the library reads no configuration from the process environment otherwise.) */
@@ -126,7 +135,7 @@ typedef struct ca_info {
   int32_t bwd_mfma;          /* 1: the backward sweep's t = coef.L contraction runs on the matrix cores (k_bwd_mfma) */
   int32_t fsplit;            /* gene slices of the matrix-core forward sweep */
   int32_t fwd_cell;          /* 1: forward sweep and cell epilogue of the fused pass are ONE kernel (k_fwd_cell) */
-  int32_t y_mfma;            /* 1: the loop's count-matrix products run on the int8 matrix cores (k_yw_mfma / k_yt_mfma) */
+  int32_t y_mfma;            /* 1: the loop's count-matrix products run on the int8 matrix cores (k_yw_mfma / k_yt_mfma, opt-in) */
   int32_t transport;         /* 0 none, 1 RCCL all-reduce, 2 host callback, 3 one-shot peer-to-peer (ca_transport) */
   int32_t reserved[1];
   int64_t red_n;             /* doubles all-reduced per train pass (= sharding.reduce_plan(...)["total"]) */

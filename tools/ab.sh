@@ -1,13 +1,8 @@
 #!/bin/bash
-# A/B of one engine switch on the bench shapes: tools/ab.sh VAR=VALUE [cells ...]   (against the default, interleaved twice)
-KV=$1; shift
-for c in "$@"; do
-  for rep in 1 2; do
-    for mode in base alt; do
-      if [ $mode = alt ]; then export "$KV"; else unset "${KV%%=*}"; fi
-      python3 bench.py --cells $c --steps 300 --warmup 30 --no-cpu-baseline 2>/dev/null | grep "^{" | python3 -c "
+# A/B of engine variants on the default workload: tools/ab.sh "<bench args>" "<bench args>" ...   (prints it/s and the profiled per-class ms)
+for a in "$@"; do
+  python3 bench.py --steps 100 --warmup 10 --no-cpu-baseline $a 2>/dev/null | python3 -c "
 import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$mode', '$KV', d['config']['cells'], round(d['value'],1), 'it/s', round(d['ms_per_step']*1000,1), 'us')"
-    done
-  done
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernel_ms_per_iter_warmup']
+print('%-40s %7.1f it/s %.4f ms  ' % ('$a', d['value'], d['ms_per_step']), {n: round(v*1e3) for n,v in k.items()})"
 done

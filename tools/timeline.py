@@ -1,0 +1,19 @@
+"""One steady-state iteration of a rocprofv3 kernel trace as a timeline: start / end of every kernel relative to the
+iteration's forward sweep, per queue.  python tools/timeline.py <kernel_trace.csv> [iteration-from-the-end]"""
+import csv
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+back = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+fw = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("void k_fwd_cell") or r["Kernel_Name"].startswith("k_fwd_cell")]
+i0, i1 = fw[-back - 1], fw[-back]
+t0 = int(rows[i0]["Start_Timestamp"])
+print(f"iteration length {(int(rows[i1]['Start_Timestamp']) - t0) / 1000:.1f} us")
+lo = i0
+while lo > 0 and int(rows[lo - 1]["End_Timestamp"]) > t0 - 40000:
+    lo -= 1
+for r in rows[lo:i1 + 1]:
+    s, e = (int(r["Start_Timestamp"]) - t0) / 1000, (int(r["End_Timestamp"]) - t0) / 1000
+    name = r["Kernel_Name"].replace("void ", "").split("(")[0][:34]
+    print(f"  q{r['Queue_Id']:>2} {s:9.1f} -> {e:9.1f}  ({e - s:7.1f})  {name}  grid {r.get('Grid_Size', '?')} wg {r.get('Workgroup_Size', '?')} vgpr {r.get('VGPR_Count', '?')}")
