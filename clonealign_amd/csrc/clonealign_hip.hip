@@ -245,6 +245,11 @@ inline bool variant_on(const ca_engine* h, unsigned bit, const char* env) {
   if (debug_env()) if (const char* e = getenv(env)) return atoi(e) != 0;
   return true;
 }
+inline bool variantx_on(const ca_engine* h, unsigned bit, const char* env) {   // opt-in variants (ca_options.variant_on)
+  if (h->opt.variant_on & bit) return true;
+  if (debug_env()) if (const char* e = getenv(env)) return atoi(e) != 0;
+  return false;
+}
 inline int tune_val(const ca_engine* h, int id, const char* env) {
   int v = h->opt.tune[id];
   if (v == 0 && debug_env()) if (const char* e = getenv(env)) { v = atoi(e); if (id == CA_TUNE_FC_NBIG && v == 0) v = -1; }
@@ -1351,7 +1356,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   // side stream for the count-matrix products: pays from ~4e7 counts up (12.5k x 5k: 9543 it/s against 9207 in line;
   // 10k x 2k: 10917 against 13017 -- two cross-stream events per iteration cost more than the overlap returns)
   h->async_y = variant_on(h, CA_VAR_ASYNC_Y, "CA_ASYNC_Y") &&
-               ((double)h->N * (double)h->G >= 4e7 || (h->opt.variant_on & CA_VARX_ASYNC_SMALL) || (debug_env() && getenv("CA_ASYNC_SMALL")));
+               ((double)h->N * (double)h->G >= 4e7 || variantx_on(h, CA_VARX_ASYNC_SMALL, "CA_ASYNC_SMALL"));
   HIPCK(h, hipHostMalloc((void**)&h->host_pinned, 64 * sizeof(double)));
   memset(h->host_pinned, 0, 64 * sizeof(double));
   if (hipHostGetDevicePointer((void**)&h->host_dev, h->host_pinned, 0) != hipSuccess) { h->host_dev = nullptr; (void)hipGetLastError(); }
@@ -1579,7 +1584,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   CACK(dalloc(h, &h->ytpsi, (int64_t)h->Gp * std::max(K, 1)));
   // ---- count-matrix products on the int8 matrix cores: two tiled copies of the 1-byte matrix (cell-tiled for Y.W,
   //      gene-tiled for Y^T.psi), each in the operand layout of v_mfma_i32_16x16x64_i8 (ca_ymfma.hip.h)
-  if (h->ystore == CA_YSTORE_U8 && K >= 1 && K <= 4 && ((h->opt.variant_on & CA_VARX_Y_MFMA2) || (debug_env() && getenv("CA_Y_MFMA2")))) {
+  if (h->ystore == CA_YSTORE_U8 && K >= 1 && K <= 4 && variantx_on(h, CA_VARX_Y_MFMA2, "CA_Y_MFMA2")) {
     h->ym_NT = cdiv(Nn, 16); h->ym_NS = cdiv(Nn, 64); h->ym_GS = cdiv(G, 64); h->ym_GT = cdiv(G, 16);
     uint8_t *yf = nullptr, *yb = nullptr;
     CACK(dalloc(h, &yf, h->ym_NT * h->ym_GS * 1024));

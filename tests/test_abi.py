@@ -72,7 +72,7 @@ def test_library_reads_no_configuration_from_the_environment():
     src = open(os.path.join(ROOT, "clonealign_amd", "csrc", "clonealign_hip.hip")).read()
     uses = re.findall(r'getenv\("([A-Z_]+)"\)', src)
     assert set(uses) <= {"CLONEALIGN_DEBUG_ENV", "CLONEALIGN_RCCL_LIB", "CA_VERBOSE"}, uses
-    assert src.count("getenv(env)") == 2 and "debug_env()" in src
+    assert src.count("getenv(env)") == 3 and "debug_env()" in src
 
 
 def test_create_fails_loudly_without_gpu_or_with_bad_args():
