@@ -2362,3 +2362,57 @@ __global__ void __launch_bounds__(CA_TB) k_yt_finish(const int* __restrict__ out
     for (int ch = col_chunk_ptr[g]; ch < col_chunk_ptr[g + 1]; ++ch) v += (double)csum[(int64_t)ch * K + k];
   red_y[i] = v;
 }
+
+// ------------------------------------------------------------------ one-shot peer-to-peer all-reduce
+// Slab of a rank (fine-grained device memory, IPC-mapped by every peer):
+//   inbox[parity 2][source rank W][cap doubles]   then   flag[parity 2][source rank W] (uint64, holds the sequence number)
+// Call `seq` (1, 2, ...) uses parity seq & 1.  A rank is at most one call ahead of any peer: it raises its flag for seq + 1
+// only after it has summed seq, and a peer can only overwrite the parity of seq with seq + 2 after seeing that flag.
+struct ca_p2p_args {
+  double* const* peers;          // [W] slab base of every rank as mapped in THIS process (own included)
+  int rank, world;
+  int64_t cap;
+  unsigned long long seq;
+  unsigned int* arrive;          // device counter, monotonic: block arrivals of all calls so far
+  unsigned int arrive_target;    // value of *arrive when every block of this call has published
+};
+__device__ __forceinline__ double* ca_p2p_inbox(double* slab, int64_t cap, int world, int par, int src) {
+  return slab + ((int64_t)par * world + src) * cap;
+}
+__device__ __forceinline__ unsigned long long* ca_p2p_flag(double* slab, int64_t cap, int world, int par, int src) {
+  return reinterpret_cast<unsigned long long*>(slab + 2 * (int64_t)world * cap) + (int64_t)par * world + src;
+}
+__global__ void __launch_bounds__(CA_TB) k_p2p_allreduce(double* __restrict__ buf, int64_t n, ca_p2p_args a) {
+  const int par = (int)(a.seq & 1ull);
+  const int64_t i0 = (int64_t)blockIdx.x * CA_TB + threadIdx.x, stride = (int64_t)gridDim.x * CA_TB;
+  // 1. publish: my summands into my inbox on every rank (plain stores into fine-grained memory; xGMI writes for remote peers)
+  for (int p = 0; p < a.world; ++p) {
+    double* dst = ca_p2p_inbox(a.peers[p], a.cap, a.world, par, a.rank);
+    for (int64_t i = i0; i < n; i += stride) dst[i] = buf[i];
+  }
+  __threadfence_system();
+  __syncthreads();
+  __shared__ unsigned int last;
+  if (threadIdx.x == 0) last = atomicAdd(a.arrive, 1u) + 1u == a.arrive_target;
+  __syncthreads();
+  if (last) {   // every block's stores are out (each fenced before its arrival): raise my flag on every rank
+    __threadfence_system();
+    if ((int)threadIdx.x < a.world)
+      __hip_atomic_store(ca_p2p_flag(a.peers[threadIdx.x], a.cap, a.world, par, a.rank), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // 2. wait for the W flags of MY slab, one lane per source rank
+  double* mine = a.peers[a.rank];
+  if ((int)threadIdx.x < a.world) {
+    unsigned long long* f = ca_p2p_flag(mine, a.cap, a.world, par, threadIdx.x);
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) __builtin_amdgcn_s_sleep(2);
+  }
+  __syncthreads();
+  __threadfence_system();
+  // 3. the same W additions in the same order on every rank
+  for (int64_t i = i0; i < n; i += stride) {
+    double s = 0.0;
+    for (int r = 0; r < a.world; ++r)
+      s += __hip_atomic_load(ca_p2p_inbox(mine, a.cap, a.world, par, r) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    buf[i] = s;
+  }
+}

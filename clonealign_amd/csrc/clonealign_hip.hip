@@ -7,6 +7,7 @@
 #include "clonealign_hip.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -63,6 +64,19 @@ constexpr int kNcclSum = 0;      // ncclSum
 struct EvPair { hipEvent_t a, b; int kid; };
 
 }  // namespace
+
+struct ca_p2p {
+  double* slab = nullptr; size_t slab_bytes = 0; int64_t cap = 0;
+  std::vector<void*> opened;             // peers' slabs as mapped here (nullptr for ranks of this process' own slab)
+  double** peers_dev = nullptr;          // device array [world]
+  unsigned int* arrive = nullptr; unsigned int arrived = 0;
+  unsigned long long seq = 0;
+  bool connected = false;
+};
+struct ca_p2p_wire {   // what travels in a CA_P2P_HANDLE_BYTES handle
+  hipIpcMemHandle_t mem; int64_t cap; int32_t rank, world, device, pid;
+};
+static_assert(sizeof(ca_p2p_wire) <= CA_P2P_HANDLE_BYTES, "handle too small");
 
 struct ca_engine {
   // ---- problem
@@ -143,8 +157,8 @@ struct ca_engine {
   int64_t ym_NT = 0, ym_NS = 0, ym_schunk = 0; int ym_GS = 0, ym_GT = 0, ym_csplit = 1, ym_tl = 4;
   uint4 *Yf = nullptr, *Yb = nullptr, *Wq = nullptr, *Pq = nullptr; unsigned* ym_amax = nullptr; int* ym_out = nullptr;
   hipEvent_t ev_ywdone = nullptr; bool yw_pending = false, on_side = false;
-  // one-shot peer-to-peer all-reduce (set by ca_comm_init when every peer is reachable)
-  struct ca_p2p* p2p = nullptr;
+  // one-shot peer-to-peer all-reduce (ca_p2p_export / ca_p2p_connect)
+  ca_p2p* p2p = nullptr;
   // ---- comm
   ca_nccl_comm comm = nullptr;
   ca_host_allreduce_fn host_ar = nullptr; void* host_ar_user = nullptr; double* host_ar_buf = nullptr; int64_t host_ar_cap = 0;
@@ -621,7 +635,20 @@ void sym_eig(std::vector<double> T, int q, std::vector<double>& lam, std::vector
 }
 
 int allreduce(ca_engine* h, double* buf, int64_t n) {
-  if (h->opt.world <= 1 && !h->comm && !h->host_ar) return CA_OK;   // a 1-rank communicator still reduces (tests)
+  if (h->opt.world <= 1 && !h->comm && !h->host_ar && !(h->p2p && h->p2p->connected)) return CA_OK;   // a 1-rank communicator still reduces (tests)
+  if (h->p2p && h->p2p->connected) {
+    ca_p2p* pp = h->p2p;
+    for (int64_t o = 0; o < n; o += pp->cap) {   // (one launch for everything the loop reduces; longer vectors go in pieces)
+      const int64_t m = std::min<int64_t>(pp->cap, n - o);
+      const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(m, CA_TB), 64));
+      ca_p2p_args a;
+      a.peers = pp->peers_dev; a.rank = h->opt.rank; a.world = h->opt.world; a.cap = pp->cap;
+      a.seq = ++pp->seq; a.arrive = pp->arrive;
+      pp->arrived += (unsigned)nblk; a.arrive_target = pp->arrived;
+      LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_p2p_allreduce, dim3(nblk), dim3(CA_TB), 0, h->stream, buf + o, m, a));
+    }
+    return CA_OK;
+  }
   if (h->host_ar) {
     if (n > h->host_ar_cap) {
       if (h->host_ar_buf) HIPCK(h, hipHostFree(h->host_ar_buf));
@@ -681,7 +708,7 @@ ca_small_args small_args(ca_engine* h, const double* gene_part, int apply, float
 }
 // a fused monitor pass leaves its ELBO assembly for the next backward sweep; if none is coming, run it now
 int allreduce(ca_engine* h, double* buf, int64_t n);
-inline bool is_sharded(const ca_engine* h) { return h->opt.world > 1 || h->comm || h->host_ar; }
+inline bool is_sharded(const ca_engine* h) { return h->opt.world > 1 || h->comm || h->host_ar || (h->p2p && h->p2p->connected); }
 // Reduce a pending monitor tail's cell partials (and psi.(YW) partials) for a sharded run: red[0 .. 3 + C) local sums,
 // ready for the all-reduce.  The Y stream (side stream) must have delivered the psi.(YW) partials first.
 int mon_tail_local_sums(ca_engine* h) {
@@ -773,7 +800,7 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
   // the ELBO is assembled after it (k_final_gene's extra block, or ca_run's flush)
   if (cell_sums_global && !merged) CACK(allreduce(h, h->red + h->off_g, h->red_n - h->off_g));
   else CACK(allreduce(h, h->red, h->red_n));
-  if (h->opt.world > 1 || h->comm || h->host_ar) h->ycache_valid = false;   // red_y now holds the GLOBAL sum
+  if (is_sharded(h)) h->ycache_valid = false;   // red_y now holds the GLOBAL sum
   return CA_OK;
 }
 
@@ -1841,6 +1868,13 @@ int ca_destroy(ca_handle h) {
   if (h->ev_ydone) hipEventDestroy(h->ev_ydone);
   if (h->ev_ywdone) hipEventDestroy(h->ev_ywdone);
   if (h->comm) g_rccl.CommDestroy(h->comm);
+  if (h->p2p) {
+    for (void* q : h->p2p->opened) if (q) hipIpcCloseMemHandle(q);
+    if (h->p2p->slab) hipFree(h->p2p->slab);
+    if (h->p2p->peers_dev) hipFree(h->p2p->peers_dev);
+    if (h->p2p->arrive) hipFree(h->p2p->arrive);
+    delete h->p2p;
+  }
   for (auto& e : h->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
   for (void* q : h->allocs) hipFree(q);
   if (h->eps_dev) hipFree(h->eps_dev);
@@ -1860,7 +1894,7 @@ int ca_get_info(ca_handle h, ca_info* i) {
   i->gsplit = h->gsplit; i->csplit = h->csplit; i->n_cu = h->n_cu; i->fused_sweep = h->fused_ok ? 1 : 0;
   i->fwd_mfma = (h->fused_ok && h->fwd_mfma) ? 1 : 0; i->bwd_mfma = h->bwd_mfma ? 1 : 0; i->fsplit = h->fsplit; i->fwd_cell = (h->fused_ok && h->fwd_cell) ? 1 : 0;
   i->y_mfma = h->y_mfma ? 1 : 0;
-  i->transport = h->p2p ? CA_TRANSPORT_P2P : h->comm ? CA_TRANSPORT_RCCL : h->host_ar ? CA_TRANSPORT_HOST : CA_TRANSPORT_NONE;
+  i->transport = (h->p2p && h->p2p->connected) ? CA_TRANSPORT_P2P : h->comm ? CA_TRANSPORT_RCCL : h->host_ar ? CA_TRANSPORT_HOST : CA_TRANSPORT_NONE;
   i->red_n = h->red_n;
   return CA_OK;
 }
@@ -1893,6 +1927,78 @@ int ca_comm_init(ca_handle h, const char id[128]) {
     h->comm = nullptr;
     return CA_ERR_COMM;
   }
+  return setup_global_sums(h);
+}
+
+int ca_p2p_export(ca_handle h, char handle[CA_P2P_HANDLE_BYTES]) {
+  if (!h || !handle) return CA_ERR_INVALID;
+  HIPCK(h, hipSetDevice(h->device));
+  if (!h->p2p) {
+    ca_p2p* pp = new ca_p2p();
+    const int W = h->opt.world;
+    // room for everything one call reduces: the train pass's summands, the setup sums, the PCA / correlation packs
+    pp->cap = std::max<int64_t>(std::max<int64_t>(h->red_n, (int64_t)h->G * (h->C + 2) + 64), 4096);
+    pp->slab_bytes = ((size_t)2 * W * pp->cap + (size_t)2 * W) * sizeof(double);
+    // fine-grained (coherent for remote writers and for the polling loads), like the buffers of RCCL's low-latency protocol
+    if (hipExtMallocWithFlags((void**)&pp->slab, pp->slab_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      if (hipMalloc((void**)&pp->slab, pp->slab_bytes) != hipSuccess) { delete pp; h->err = "p2p slab allocation failed"; return CA_ERR_NOMEM; }
+    }
+    HIPCK(h, hipMemset(pp->slab, 0, pp->slab_bytes));
+    HIPCK(h, hipMalloc((void**)&pp->peers_dev, (size_t)W * sizeof(double*)));
+    HIPCK(h, hipMalloc((void**)&pp->arrive, sizeof(unsigned int)));
+    HIPCK(h, hipMemset(pp->arrive, 0, sizeof(unsigned int)));
+    h->p2p = pp;
+  }
+  ca_p2p_wire w;
+  memset(&w, 0, sizeof(w));
+  HIPCK(h, hipIpcGetMemHandle(&w.mem, h->p2p->slab));
+  w.cap = h->p2p->cap; w.rank = h->opt.rank; w.world = h->opt.world; w.device = h->device; w.pid = (int32_t)getpid();
+  memset(handle, 0, CA_P2P_HANDLE_BYTES);
+  memcpy(handle, &w, sizeof(w));
+  return CA_OK;
+}
+
+int ca_p2p_connect(ca_handle h, const char* handles) {
+  if (!h || !handles) return CA_ERR_INVALID;
+  if (!h->p2p) { h->err = "ca_p2p_connect before ca_p2p_export"; return CA_ERR_STATE; }
+  if (!variant_on(h, CA_VAR_P2P, "CA_P2P")) { h->err = "peer-to-peer transport switched off (CA_VAR_P2P)"; return CA_ERR_COMM; }
+  HIPCK(h, hipSetDevice(h->device));
+  ca_p2p* pp = h->p2p;
+  const int W = h->opt.world;
+  std::vector<double*> peers((size_t)W, nullptr);
+  pp->opened.assign((size_t)W, nullptr);
+  for (int r = 0; r < W; ++r) {
+    ca_p2p_wire w;
+    memcpy(&w, handles + (size_t)r * CA_P2P_HANDLE_BYTES, sizeof(w));
+    if (w.rank != r || w.world != W || w.cap != pp->cap) {
+      h->err = "p2p handle " + std::to_string(r) + " does not match this problem (rank / world / payload size)";
+      return CA_ERR_COMM;
+    }
+    if (r == h->opt.rank) { peers[r] = pp->slab; continue; }
+    if (w.device != h->device) {
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, h->device, w.device) != hipSuccess || !can) {
+        (void)hipGetLastError();
+        h->err = "no peer access from device " + std::to_string(h->device) + " to device " + std::to_string(w.device);
+        return CA_ERR_COMM;
+      }
+      const hipError_t e = hipDeviceEnablePeerAccess(w.device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { h->err = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e); return CA_ERR_COMM; }
+      (void)hipGetLastError();
+    }
+    void* q = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&q, w.mem, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      h->err = std::string("hipIpcOpenMemHandle (rank ") + std::to_string(r) + "): " + hipGetErrorString(e);
+      return CA_ERR_COMM;
+    }
+    pp->opened[r] = q;
+    peers[r] = (double*)q;
+  }
+  HIPCK(h, hipMemcpy(pp->peers_dev, peers.data(), (size_t)W * sizeof(double*), hipMemcpyHostToDevice));
+  pp->connected = true;
   return setup_global_sums(h);
 }
 
@@ -2048,7 +2154,7 @@ int ca_final_elbo(ca_handle h, int32_t n_rep, const float* eps_stream, int64_t n
 
 // host-side all-reduce of a small double vector through the engine's transport (device scratch round trip)
 static int allreduce_host_vec(ca_engine* h, std::vector<double>& v, double* dev_scratch) {
-  if (h->opt.world <= 1 && !h->comm && !h->host_ar) return CA_OK;
+  if (!is_sharded(h)) return CA_OK;
   HIPCK(h, hipMemcpyAsync(dev_scratch, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   CACK(allreduce(h, dev_scratch, (int64_t)v.size()));
   HIPCK(h, hipMemcpyAsync(v.data(), dev_scratch, v.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -2238,7 +2344,7 @@ int ca_clone_gene_sums(ca_handle h, const int32_t* clone_of_cell, double* Tout, 
   PCK(hipMemcpyAsync(Syy, ytd, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, h->stream));
   PCK(hipStreamSynchronize(h->stream));
   cleanup();
-  if (h->opt.world > 1 || h->comm || h->host_ar) {   // sharded: totals over all cells
+  if (is_sharded(h)) {   // sharded: totals over all cells
     std::vector<double> pack((size_t)G * C + G);
     for (int g = 0; g < G; ++g) { for (int c = 0; c < C; ++c) pack[(size_t)g * C + c] = out[(size_t)g * C + c]; pack[(size_t)G * C + g] = Syy[g]; }
     double* scratch = nullptr;

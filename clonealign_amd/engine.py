@@ -16,6 +16,7 @@ CA_OK = 0
 CA_ERR_NAN = 4
 CA_INTERRUPTED = 7
 CA_ABI_VERSION = 2
+P2P_HANDLE_BYTES = 128
 CA_F64, CA_F32, CA_I32, CA_U16, CA_U8 = 0, 1, 2, 3, 4
 CA_ROW_MAJOR, CA_COL_MAJOR = 0, 1
 YSTORE = {"auto": 0, "f32": 1, "u16": 2, "u8": 3}
@@ -31,7 +32,7 @@ TRANSPORT_NAME = {0: "none", 1: "rccl", 2: "host", 3: "p2p"}
 
 EXPORTS = (
     "ca_abi_version", "ca_default_options", "ca_create", "ca_destroy", "ca_last_error", "ca_get_info",
-    "ca_synchronize", "ca_comm_unique_id", "ca_comm_init", "ca_set_host_allreduce", "ca_gamma_init", "ca_elbo", "ca_elbo_terms",
+    "ca_synchronize", "ca_comm_unique_id", "ca_comm_init", "ca_p2p_export", "ca_p2p_connect", "ca_set_host_allreduce", "ca_gamma_init", "ca_elbo", "ca_elbo_terms",
     "ca_step", "ca_gradients", "ca_run", "ca_run_ex", "ca_iterate", "ca_final_elbo", "ca_init_psi_pca", "ca_clone_gene_sums", "ca_get_param", "ca_set_param",
     "ca_get_gradient", "ca_reinit", "ca_get_kernel_times", "ca_reset_kernel_times", "ca_set_profile", "ca_eps_draw", "ca_allele_loglik", "ca_preprocess",
 )
@@ -96,6 +97,8 @@ def load_library(path=None):
     lib.ca_synchronize.argtypes = [C.c_void_p]
     lib.ca_comm_unique_id.argtypes = [C.c_char_p]
     lib.ca_comm_init.argtypes = [C.c_void_p, C.c_char_p]
+    lib.ca_p2p_export.argtypes = [C.c_void_p, C.c_char_p]
+    lib.ca_p2p_connect.argtypes = [C.c_void_p, C.c_char_p]
     lib.ca_set_host_allreduce.argtypes = [C.c_void_p, HOST_ALLREDUCE_FN, C.c_void_p]
     lib.ca_gamma_init.argtypes = [C.c_void_p, C.c_void_p]
     lib.ca_elbo.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
@@ -156,12 +159,14 @@ class HipEngine:
 
     def __init__(self, Y, L, psi0, loc0, K, S=1, X=None, extra_loglik=None, learning_rate=0.1,
                  device=0, y_storage="auto", seed=0x5EED5EED, rank=0, world=1, profile=False,
-                 y_device_ptr=None, y_device_dtype=None, shape=None, comm_id=None, host_allreduce=None,
+                 y_device_ptr=None, y_device_dtype=None, shape=None, comm_id=None, host_allreduce=None, p2p_exchange=None,
                  layout="row", cell_index=None, gene_index=None, variant_off=(), variant_on=(), tune=None, verbose=False):
         """``layout``: "row" (C / numpy order) or "col" -- every matrix is then handed over column-major (Fortran order),
         which is what the R caller has (R/inference-tflow.R:190-191,355) and what r_shim/clonealign_hip_shim.c passes; the
         ``get``/``set`` matrices use the same layout.  ``cell_index`` / ``gene_index``: Y is the RAW matrix and the fit uses
         these rows / columns of it (ca_problem.cell_index / gene_index); L, psi0, loc0, X, extra_loglik are for the selection.
+        ``p2p_exchange(handle: bytes) -> list[bytes]`` (world > 1): an all-gather of the ranks' P2P_HANDLE_BYTES-byte handles in
+        rank order (torch.distributed / MPI); selects the one-shot peer-to-peer all-reduce (ca_p2p_export / ca_p2p_connect).
         ``variant_off``: names from VARIANTS (or a bitmask) to switch off; ``variant_on``: names from VARIANTS_ON to switch on;
         ``tune``: {name from TUNE: value}."""
         self.lib = load_library()
@@ -238,10 +243,17 @@ class HipEngine:
                         return 1
                 self._cb = HOST_ALLREDUCE_FN(_cb)
                 self._ck(self.lib.ca_set_host_allreduce(self.h, self._cb, None))
+            elif p2p_exchange is not None:
+                buf = C.create_string_buffer(P2P_HANDLE_BYTES)
+                self._ck(self.lib.ca_p2p_export(self.h, buf))
+                allh = p2p_exchange(bytes(buf.raw))
+                if len(allh) != world or any(len(x) != P2P_HANDLE_BYTES for x in allh):
+                    raise ValueError("p2p_exchange must return one handle per rank, in rank order")
+                self._ck(self.lib.ca_p2p_connect(self.h, b"".join(allh)))
             elif comm_id is not None:
                 self._ck(self.lib.ca_comm_init(self.h, comm_id))
             else:
-                raise ValueError("world > 1 needs comm_id (bytes from comm_unique_id(), broadcast from rank 0) "
+                raise ValueError("world > 1 needs p2p_exchange, comm_id (bytes from comm_unique_id(), broadcast from rank 0) "
                                  "or host_allreduce")
 
     # -------------------------------------------------------------- plumbing

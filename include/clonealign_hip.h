@@ -168,6 +168,15 @@ int ca_synchronize(ca_handle h);
  * Rank 0 calls ca_comm_unique_id() and distributes the 128 bytes out of band. */
 int ca_comm_unique_id(char id[128]);
 int ca_comm_init(ca_handle h, const char id[128]);
+/* One-shot peer-to-peer all-reduce over xGMI: the per-iteration payload is ~120 KB, i.e. latency-bound, so
+ * instead of a ring every rank WRITES its summands into an inbox slab of every peer (IPC-mapped device memory), raises a
+ * sequence flag there, waits for the W flags of its own slab and adds the W inboxes in rank order 0..W-1 -- the same additions
+ * in the same order on every rank, so the replicas stay bit-identical, in one kernel on the engine's stream, no host round
+ * trip.  Setup: every rank exports a handle, the caller exchanges them out of band (like the RCCL id: torch.distributed /
+ * MPI all-gather), every rank connects.  Needs peer access between the devices (same node); ranks may share a device. */
+#define CA_P2P_HANDLE_BYTES 128
+int ca_p2p_export(ca_handle h, char handle[CA_P2P_HANDLE_BYTES]);
+int ca_p2p_connect(ca_handle h, const char* handles /* world x CA_P2P_HANDLE_BYTES, in rank order */);
 /* Alternative transport for world > 1 (MPI, gloo, tests): the engine hands the summand buffer to the
  * host callback, which must replace buf[0..n) by its sum over all ranks (same order on every rank)
  * and return 0.  Slower than RCCL (one device<->host round trip per reduction); same results. */

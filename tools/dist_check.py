@@ -1,0 +1,84 @@
+"""Cell-sharded fit under torch.distributed.run: every rank builds its shard's engine, the ranks run the whole loop (ca_run)
+on a shared eps stream, rank 0 writes the ELBO trace, the transport the engine reports, the replicated parameters of every
+rank and the engine's all-reduce payload size to --out (JSON).  Used by tests/test_gpu_multi.py (2 ranks on 2 GPUs, or 2 ranks
+on ONE GPU with --same-device for the peer-to-peer transport) -- started as a fresh process before anything touches the GPU.
+
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P tools/dist_check.py \
+         --transport p2p|rccl|host --cells 6000 --genes 700 --clones 5 --iters 6 --out /tmp/x.json [--same-device]
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--transport", default="p2p")
+    ap.add_argument("--cells", type=int, default=6000)
+    ap.add_argument("--genes", type=int, default=700)
+    ap.add_argument("--clones", type=int, default=5)
+    ap.add_argument("--iters", type=int, default=6)
+    ap.add_argument("--seed", type=int, default=5)
+    ap.add_argument("--same-device", action="store_true")
+    ap.add_argument("--out", required=True)
+    args = ap.parse_args()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    import torch.distributed as dist
+    from clonealign_amd import sharding
+    from clonealign_amd.engine import HipEngine, comm_unique_id
+    from tests._cases import eps_for, make_case
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    case = make_case(seed=args.seed, N=args.cells, G=args.genes, C=args.clones, K=1)
+    lo, hi = sharding.cell_range(args.cells, rank, world)
+    kw = {}
+    if world > 1:
+        if args.transport == "p2p":
+            def exchange(hd):
+                box = [None] * world
+                dist.all_gather_object(box, hd)
+                return box
+            kw["p2p_exchange"] = exchange
+        elif args.transport == "rccl":
+            box = [comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            kw["comm_id"] = box[0]
+        else:
+            import torch
+
+            def gloo_sum(buf):
+                t = torch.from_numpy(buf.copy())
+                dist.all_reduce(t)
+                buf[:] = t.numpy()
+            kw["host_allreduce"] = gloo_sum
+    eng = HipEngine(case["Y"][lo:hi], case["L"], case["psi0"][lo:hi], case["loc0"], 1, 1, device=local, rank=rank, world=world, **kw)
+    eps = np.stack([eps_for(1, args.genes, 300 + i) for i in range(2 + 2 * args.iters + 4)])
+    trace = eng.run(eps, args.iters, 1e-12)
+    finals = eng.final_elbo(eps[2 + 2 * args.iters:], 4)
+    info = eng.info()
+    rep = {n: eng.get(n).tolist() for n in ("W", "loc", "ls", "alpha_unconstr", "v")}
+    mine = dict(rank=rank, trace=trace.tolist(), finals=finals.tolist(), transport=info["transport_name"], red_n=int(info["red_n"]),
+                rep=rep, psi_head=eng.get("psi")[:5, 0].tolist(), lo=lo, hi=hi)
+    eng.close()
+    if world > 1:
+        box = [None] * world
+        dist.all_gather_object(box, mine)
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        box = [mine]
+    if rank == 0:
+        json.dump(dict(world=world, ranks=box, plan=sharding.reduce_plan(args.genes, args.clones, 1, 0, 1)), open(args.out, "w"))
+
+
+if __name__ == "__main__":
+    main()
