@@ -5,14 +5,16 @@ One "step" = one iteration of the reference's loop (R/inference-tflow.R:401,403)
 pass (forward + backward + Adam, fresh eps) followed by a monitor pass (forward, fresh eps).
 Workload at N=1: BASELINE.json configs[2] -- synthetic 100k cells x 5k genes x 8 clones
 (the configuration the metric is quoted on).  With N>1 GPUs the SAME 100k cells are sharded
-across the ranks (configs[3]: strong scaling) with one RCCL all-reduce of the per-gene
-gradient sums per train pass.
+across the ranks (configs[3]: strong scaling) with ONE all-reduce of the per-gene gradient sums
+per train pass on the device (one-shot peer-to-peer over xGMI, else RCCL).  A run whose data path
+would fall back to the host exits non-zero unless --allow-host-fallback is given.
 
   python bench.py --gpus 1 --steps 50 --warmup 5
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -43,32 +45,64 @@ def algorithmic_work(kernel, N, G, C, K, fused=False, steps=1):
     return "hbm", 0.0
 
 
-def cpu_baseline(Yh, L, psi0, loc0, K, N_full, budget_s=20.0):
-    """Oracle (kind 'port') timed on the host cores on a bounded cell sample of the same workload."""
-    try:
-        from oracle import c_port
-        return c_port.time_baseline(Yh, L, psi0, loc0, K, N_full, budget_s)
-    except Exception:  # C port unavailable: numpy restatement
-        pass
-    from oracle.fused_numpy import FusedModel
-    n = Yh.shape[0]
-    m = FusedModel(Yh, L, psi0[:n], loc0, K, 1, dtype="float32")
-    rng = np.random.default_rng(0)
-    G = Yh.shape[1]
-    e = lambda: rng.normal(size=(1, G)).astype(np.float32)  # noqa: E731
-    m.gamma_init(e())
-    m.step(e()); m.elbo(e())
-    t0 = time.perf_counter()
-    it = 0
-    while True:
-        m.step(e()); m.elbo(e())
-        it += 1
-        if time.perf_counter() - t0 > budget_s or it >= 50:
+def pmc_traffic(build_id, kernel_class):
+    """HBM bytes per launch of a kernel class from the PMC passes committed under profiles/ -- only from a file that was
+    collected on THIS build of the library (matching ca_build_id) and only under the class's own key; else None."""
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("build_id") == build_id and kernel_class in d.get("classes", {}):
+            c = d["classes"][kernel_class]
+            return c.get("hbm_bytes"), {"file": os.path.basename(f), "kernel": c.get("kernel")}
+    return None, None
+
+
+def cpu_baseline(Ycells, L, psi0, loc0, K, N_full, budget_s=24.0):
+    """Oracle (kind 'port': the fused C + OpenMP float64 restatement, oracle/c) timed on the host cores at THREE sample sizes
+    of the same workload; the rate is quoted from the largest sample and the smaller ones show that time per iteration is
+    linear in the cell count (so that scaling the sample to the full matrix is sound)."""
+    from oracle import c_port
+    sizes = [n for n in (4096, 16384, 65536) if n <= Ycells.shape[0]] or [Ycells.shape[0]]
+    rows, cores = [], 1
+    for n in sizes:
+        r = c_port.time_baseline(Ycells[:n], L, psi0, loc0, K, N_full, budget_s * n / sum(sizes))
+        rows.append({"cells": n, "scaled_it_per_s": r["value"], "s_per_iter_sample": n / N_full / r["value"]})
+        cores = r["cores"]
+    big = rows[-1]
+    return {"value": big["scaled_it_per_s"], "unit": "iterations/s", "cores": cores, "kind": "port",
+            "sample": f"C + OpenMP float64 fused oracle (oracle/c) on the first {big['cells']} of {N_full} cells x {L.shape[0]} genes, "
+                      f"rate scaled by {big['cells']}/{N_full}; linearity: "
+                      + ", ".join(f"{r['cells']} cells {r['s_per_iter_sample'] * 1e3:.1f} ms/iter" for r in rows),
+            "samples": rows}
+
+
+def cpu_ref_dataflow(budget_s=10.0):
+    """BASELINE.md section 3 'CPU-ref-dataflow': the literal restatement that follows the reference's dataflow op for op
+    (materialises [S,G,C,N], recomputes the lgamma terms every pass, autodiff) in float32 on the host cores, at cfg-2."""
+    import torch
+    from clonealign_amd.hostprep import mu_guess, safe_inverse_softplus
+    from oracle.literal_torch import LiteralModel
+    N, G, C = 10_000, 2_000, 4
+    rng = np.random.default_rng(20242)
+    L = rng.integers(1, 5, size=(G, C)).astype(np.float64)
+    Y = rng.poisson(rng.lognormal(-1.0, 1.0, G)[None, :] * L[:, rng.integers(0, C, N)].T * 0.5).astype(np.float64)
+    Y[:, 0] += 1
+    loc0 = safe_inverse_softplus(np.maximum(mu_guess(Y, True), 1e-6))
+    m = LiteralModel(Y, L, np.random.default_rng(1).normal(size=(N, 1)), loc0, 1, 1, dtype="float32")
+    e = lambda i: np.random.default_rng(i).normal(size=(1, G)).astype(np.float32)  # noqa: E731
+    m.gamma_init(e(0)); m.step(e(1)); m.elbo(e(2))
+    t0, it = time.perf_counter(), 0
+    while it < 20:
+        m.step(e(3 + 2 * it)); m.elbo(e(4 + 2 * it)); it += 1
+        if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return {"value": it / dt * n / N_full, "unit": "iterations/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"numpy float64 fused oracle, first {n} of {N_full} cells x {G} genes, {it} iterations, "
-                      f"rate scaled by {n}/{N_full}"}
+    return {"value": it / dt, "unit": "iterations/s", "cores": torch.get_num_threads(), "kind": "port",
+            "workload": f"synthetic {N} cells x {G} genes x {C} clones (BASELINE.json configs[1])",
+            "what": "oracle/literal_torch.py in float32: materialising dataflow of R/inference-tflow.R:288-296, two full passes "
+                    f"per iteration, {it} iterations in {dt:.1f} s"}
 
 
 def main():
@@ -76,14 +110,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)   # the reference's default max_iter
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--repeats", type=int, default=5, help="the --steps long timed region is run this many times; value = median region")
     ap.add_argument("--cells", type=int, default=100_000)
     ap.add_argument("--genes", type=int, default=5_000)
     ap.add_argument("--clones", type=int, default=8)
     ap.add_argument("--latent", type=int, default=1)
     ap.add_argument("--y-storage", default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-cells", type=int, default=4096)
+    ap.add_argument("--cpu-sample-cells", type=int, default=65536)
     ap.add_argument("--seed", type=int, default=20243)
+    ap.add_argument("--collective", default="auto", choices=["auto", "p2p", "rccl", "host"],
+                    help="data-path all-reduce at --gpus > 1: auto = one-shot peer-to-peer, else RCCL")
+    ap.add_argument("--allow-host-fallback", action="store_true",
+                    help="at --gpus > 1, let the run continue on the gloo host all-reduce when no device transport comes up "
+                         "(the result is then NOT a measurement of the device data path)")
     ap.add_argument("--variant-off", default="", help="comma-separated engine variants to switch off (engine.VARIANTS), for A/B runs")
     ap.add_argument("--variant-on", default="", help="comma-separated opt-in engine variants (engine.VARIANTS_ON), for A/B runs")
     ap.add_argument("--tune", default="", help="comma-separated name=value decomposition overrides (engine.TUNE), for A/B runs")
@@ -100,7 +140,8 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from clonealign_amd import synth
+    from clonealign_amd import engine as eng_mod
+    from clonealign_amd import sharding, synth
     from clonealign_amd.engine import HipEngine, comm_unique_id
 
     if not torch.cuda.is_available():
@@ -108,11 +149,10 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only; data path = RCCL in the engine
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only; the data path is in the engine
 
     N, G, C, K = args.cells, args.genes, args.clones, args.latent
-    lo = (N * rank) // world
-    hi = (N * (rank + 1)) // world
+    lo, hi = sharding.cell_range(N, rank, world)
     Yd, aux = synth.make_problem_torch(N, G, C, seed=args.seed, rows=(lo, hi), device=f"cuda:{local_rank}")
     n_loc = hi - lo
     # data-driven loc0 (R/inference-tflow.R:220-235,262) from GLOBAL column means; psi0 ~ N(0,1)
@@ -135,46 +175,71 @@ def main():
                          variant_on=tuple(v for v in args.variant_on.split(",") if v),
                          tune={k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(",") if kv)}, **kw)
 
-    collective = "none"
+    collective, tried = "none", []
     if world == 1:
         eng = make_engine()
     else:
-        # data path: RCCL all-reduce inside the engine (xGMI).  If the communicator cannot be brought up on EVERY rank,
-        # all ranks fall back together to the host hook over gloo (slower, same results) rather than dying.
-        ok = 1
-        eng = None
-        try:
-            box = [comm_unique_id() if rank == 0 else None]
-        except Exception as e:  # noqa: BLE001
-            box, ok = [None], 0
-            print(f"[rank {rank}] RCCL unavailable: {e}", file=sys.stderr, flush=True)
-        dist.broadcast_object_list(box, src=0)
-        if box[0] is None:
-            ok = 0
-        if ok:
-            try:
-                eng = make_engine(comm_id=box[0])
-            except Exception as e:  # noqa: BLE001
-                ok = 0
-                print(f"[rank {rank}] RCCL communicator init failed: {e}", file=sys.stderr, flush=True)
-        flag = torch.tensor([ok], dtype=torch.int32)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag[0]) == 1:
-            collective = "rccl"
-        else:
-            if eng is not None:
-                eng.close()
+        # Device data path: one-shot peer-to-peer all-reduce (IPC inbox slabs over xGMI), else RCCL.  Every transport is
+        # brought up collectively -- all ranks succeed or all move on to the next one -- and the run FAILS when none of the
+        # device transports comes up, unless the host fallback was asked for explicitly.
+        def gloo_sum(buf):
+            t = torch.from_numpy(buf.copy())
+            dist.all_reduce(t)
+            buf[:] = t.numpy()
 
-            def gloo_sum(buf):
-                t = torch.from_numpy(buf.copy())
-                dist.all_reduce(t)
-                buf[:] = t.numpy()
-            eng = make_engine(host_allreduce=gloo_sum)
+        def exchange(hd):
+            box = [None] * world
+            dist.all_gather_object(box, hd)
+            return box
+
+        order = {"auto": ["p2p", "rccl"], "p2p": ["p2p"], "rccl": ["rccl"], "host": []}[args.collective]
+        if args.allow_host_fallback or args.collective == "host":
+            order.append("host")
+        eng = None
+        for tr in order:
+            ok, e_new, why = 1, None, ""
+            try:
+                if tr == "p2p":
+                    e_new = make_engine(p2p_exchange=exchange)
+                elif tr == "rccl":
+                    box = [None]
+                    try:
+                        if rank == 0:
+                            box = [comm_unique_id()]
+                    except Exception as ex:  # noqa: BLE001
+                        why = str(ex)
+                    dist.broadcast_object_list(box, src=0)
+                    if box[0] is None:
+                        raise RuntimeError("RCCL unavailable on rank 0: " + why)
+                    e_new = make_engine(comm_id=box[0])
+                else:
+                    e_new = make_engine(host_allreduce=gloo_sum)
+            except Exception as ex:  # noqa: BLE001
+                ok, why = 0, str(ex)
+                print(f"[rank {rank}] transport {tr} failed: {ex}", file=sys.stderr, flush=True)
+            flag = torch.tensor([ok], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            tried.append(tr)
+            if int(flag[0]) == 1:
+                eng, collective = e_new, tr
+                break
+            if e_new is not None:
+                e_new.close()
+        if eng is None:
+            if rank == 0:
+                print(f"bench.py: no device all-reduce transport came up on all {world} ranks (tried {tried}); refusing to report a "
+                      "scaling number from a host fallback (pass --allow-host-fallback to run it anyway)", file=sys.stderr, flush=True)
+            dist.barrier()
+            raise SystemExit(3)
+        if collective == "host":
             collective = "gloo-host-fallback"
     info = eng.info()
+    if world > 1:
+        assert info["transport_name"] == {"p2p": "p2p", "rccl": "rccl"}.get(collective, "host"), info["transport_name"]
+        assert info["red_n"] == sharding.reduce_plan(G, C, K, 0, 1)["total"], (info["red_n"], sharding.reduce_plan(G, C, K, 0, 1))
     Ysample = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        Ysample = Yd[:args.cpu_sample_cells].cpu().numpy()
+        Ysample = Yd[:min(args.cpu_sample_cells, n_loc)].cpu().numpy().astype(np.float64)
     del Yd
     torch.cuda.empty_cache()
 
@@ -197,22 +262,40 @@ def main():
         torch.cuda.synchronize()
         eng.synchronize()
 
-    barrier()
-    t0 = time.perf_counter()
-    last = eng.iterate(args.steps, eps_t)
-    eng.synchronize()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t[0])
+    # --- timed: `repeats` regions of exactly `steps` iterations, each bracketed by barrier + synchronize on both sides and
+    #     maxed over the ranks; the quoted value is the MEDIAN region (a 20-step region at cfg-3 is only 7 ms long)
+    regions, last = [], float("nan")
+    for _ in range(max(args.repeats, 1)):
+        barrier()
+        t0 = time.perf_counter()
+        last = eng.iterate(args.steps, eps_t)
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0])
+        regions.append(dt)
+    dt = float(np.median(regions))
     kt_timed = eng.kernel_times(reset=True)
-    # second half of the metric ("wall-clock to convergence"): the reference's default fit, max_iter = 200, rel_tol = 1e-6,
-    # through ca_run (host reads the ELBO every iteration for the window-10 stop rule), then the 20 final ELBOs
+    # a monitor pass on its own (plain forward + its (3 + C)-double all-reduce + read-back): the latency floor of one collective
+    mon_us = None
+    if world > 1:
+        eng.set_profile(0)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            eng.elbo(eps0)
+        eng.synchronize()
+        mon_us = (time.perf_counter() - t1) / 20 * 1e6
+    # second half of the metric ("wall-clock to convergence"): the reference's default fit FROM ITS INITIAL VALUES (ca_reinit:
+    # variables, Adam slots and beta powers reset), max_iter = 200, rel_tol = 1e-6, through ca_run (host reads the ELBO every
+    # iteration for the window-10 stop rule), then the 20 final ELBOs
     eng.set_profile(0)
+    eng.reinit(psi0, loc0)
     barrier()
     t1 = time.perf_counter()
     trace = eng.run(None, 200, 1e-6)
@@ -223,6 +306,7 @@ def main():
         raise SystemExit(f"non-finite ELBO after the timed steps: {last}")
 
     if rank == 0:
+        build = eng_mod.build_id()
         ms, launches = kt_timed[dominant]
         per_launch_s = ms / max(launches, 1) * 1e-3
         bound, work = algorithmic_work(dominant, n_loc, G, C, K, bool(info.get("fused_sweep")), args.steps)
@@ -230,39 +314,27 @@ def main():
             achieved, peak, unit = work / per_launch_s / 1e9, PEAK_HBM_GBS, "GB/s"
         else:
             achieved, peak, unit = work / per_launch_s / 1e12, PEAK_F32_TFLOPS, "TFLOP/s"
-        traffic = None
-        try:   # HBM bytes per launch from the committed PMC passes (same workload only)
-            if (N, G, C, K, world) == (100_000, 5_000, 8, 1, 1):
-                pm = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
-                key = dominant
-                if dominant == "fwd" and not info.get("fwd_mfma"):
-                    key = "fwd_valu"
-                if dominant == "bwd" and not info.get("bwd_mfma"):
-                    key = "bwd_valu"
-                traffic = pm.get(key, {}).get("hbm_bytes")
-        except Exception:
-            traffic = None
+        same_workload = (N, G, C, K, world) == (100_000, 5_000, 8, 1, 1)
+        traffic, traffic_src = pmc_traffic(build, dominant) if same_workload else (None, None)
         # the HBM-bound kernel of the iteration (SURVEY.md section 8d asks for both roofs): the Y stream, timed by HIP events on
-        # its own (side) stream during the warmup iterations, where every kernel class is timed
+        # its own stream during the warmup iterations, where every kernel class is timed
         ystream = None
         if K > 0 and kt["ypass"][1] > 0:
             y_s = kt["ypass"][0] / kt["ypass"][1] * 1e-3
             canon = n_loc * G * 4.0 + (n_loc + G) * K * 4.0 * 2
-            ytraffic = None
-            try:
-                if (N, G, C, K, world) == (100_000, 5_000, 8, 1, 1):
-                    ytraffic = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]["ypass"]["hbm_bytes"]
-            except Exception:
-                ytraffic = None
+            ytraffic, ysrc = pmc_traffic(build, "ypass") if same_workload else (None, None)
             ystream = {"bound": "hbm", "kernel": "ypass", "achieved": canon / y_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                       "frac": canon / y_s / 1e9 / PEAK_HBM_GBS, "traffic": ytraffic, "launch_ms": y_s * 1e3,
+                       "frac": canon / y_s / 1e9 / PEAK_HBM_GBS, "traffic": ytraffic, "traffic_source": ysrc, "launch_ms": y_s * 1e3,
                        "stored_GBps": n_loc * G * float(info["y_bytes_per_elem"]) / y_s / 1e9,
                        "note": "canonical 4 B per count (the reference feeds float32); the matrix is stored at "
                                f"{info['y_bytes_per_elem']} B per count, so frac > 1 means fewer bytes moved than the canonical "
                                "stream, not more than the memory system delivers (stored_GBps is the physical rate)"}
+        step_s = dt / args.steps
+        it_flops = N * G * (8.0 * C + 12.0 * K + 3.0)                       # SURVEY.md section 8d, whole iteration, all ranks
+        it_bytes = N * G * 4.0 + N * (8.0 * C + 6.0 * K + 2.0) * 4.0
         out = {
             "metric": "ELBO iterations/sec", "value": args.steps / dt, "unit": "iterations/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"synthetic {N} cells x {G} genes x {C} clones, K={K}, S=1, cell-sharded over "
@@ -270,28 +342,49 @@ def main():
                        "cells": N, "genes": G, "clones": C, "K": K, "mc_samples": 1, "learning_rate": 0.1,
                        "y_storage": info["y_storage_name"], "y_bytes_per_elem": info["y_bytes_per_elem"],
                        "fused_sweep": bool(info.get("fused_sweep")), "fwd_mfma": bool(info.get("fwd_mfma")),
-                       "bwd_mfma": bool(info.get("bwd_mfma")),
-                       "parallelism": f"cells/{world}" if world > 1 else "single", "collective": collective},
+                       "bwd_mfma": bool(info.get("bwd_mfma")), "y_mfma": bool(info.get("y_mfma")),
+                       "parallelism": f"cells/{world}" if world > 1 else "single", "collective": collective,
+                       "collectives_tried": tried, "allreduce_doubles_per_train_pass": int(info["red_n"]),
+                       "build_id": build},
+            "repeats": {"n": len(regions), "ms_per_step_median": step_s * 1e3, "ms_per_step_min": min(regions) / args.steps * 1e3,
+                        "ms_per_step_max": max(regions) / args.steps * 1e3,
+                        "what": "the --steps long region timed this many times (barrier + synchronize on both sides each time); "
+                                "value / ms_per_step are the median region"},
             "roofline": {"bound": bound, "kernel": dominant, "achieved": achieved, "peak": peak, "unit": unit,
-                         "frac": achieved / peak, "traffic": traffic,
+                         "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": per_launch_s * 1e3, "launches": int(launches),
                          "note": ("algorithmic fp32 flops of the fused two-eps sweep against the fp32 peak; the contraction "
                                   "itself runs as bf16 hi/lo MFMAs (fp32-accurate), the kernel is bound by VALU issue "
-                                  "(v_exp_f32 + bf16 split: 88 us at 2.4 GHz, tools/inst_lab.hip) and shares the GPU with the "
-                                  "Y-stream kernel on a side stream (standalone 110 us; DESIGN.md sections 5 and 8)")
-                         if dominant == "fwd" else ""},
+                                  "(v_exp_f32 + bf16 split) and shares the GPU with the Y-stream kernel on a side stream "
+                                  "(DESIGN.md sections 5 and 8); traffic is filled only from a PMC file of THIS build")
+                         if dominant == "fwd" else "traffic is filled only from a PMC file of THIS build"},
+            "roofline_iteration": {"flops": it_flops, "bytes_canonical": it_bytes,
+                                   "achieved_TFLOPs": it_flops / step_s / 1e12,
+                                   "frac_of_fp32_peak": it_flops / step_s / 1e12 / (PEAK_F32_TFLOPS * world),
+                                   "achieved_GBps_canonical": it_bytes / step_s / 1e9,
+                                   "frac_of_hbm_peak_canonical": it_bytes / step_s / 1e9 / (PEAK_HBM_GBS * world),
+                                   "what": "whole iteration (train + monitor pass) against both roofs: N G (8C + 12K + 3) flop and "
+                                           "N G 4 + N (8C + 6K + 2) 4 canonical bytes (SURVEY.md section 8d) over ms_per_step"},
             "kernel_ms_per_iter_warmup": {k: v[0] / max(args.warmup, 1) for k, v in kt.items()},
             "roofline_ystream": ystream,
             "final_elbo": last,
             "fit_wallclock": {"seconds": fit_s, "iterations": int(len(trace) - 1), "max_iter": 200, "rel_tol": 1e-6,
-                              "final_elbo_mean": float(np.mean(finals)),
-                              "what": "ca_run + 20 final ELBOs, eps generated by the built-in Philox stream (inside the time)"},
+                              "final_elbo_mean": float(np.mean(finals)), "from_initial_values": True,
+                              "what": "ca_reinit (initial values, fresh Adam state), ca_run + 20 final ELBOs, eps generated by the "
+                                      "built-in Philox stream (inside the time)"},
         }
+        if mon_us is not None:
+            out["monitor_pass_us_with_collective"] = mon_us
         if Ysample is not None:
             out["cpu_baseline"] = cpu_baseline(Ysample, aux["L"], psi0, loc0, K, N)
+            try:
+                out["cpu_ref_dataflow"] = cpu_ref_dataflow()
+            except Exception as ex:  # noqa: BLE001
+                out["cpu_ref_dataflow"] = {"error": str(ex)}
         print(json.dumps(out), flush=True)
     eng.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

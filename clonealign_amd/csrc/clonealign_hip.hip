@@ -1815,6 +1815,10 @@ static int preprocess_t(const ST* src, int64_t N, int G, int C, int layout, cons
 extern "C" {
 
 int ca_abi_version(void) { return CA_ABI_VERSION; }
+#ifndef CA_BUILD_ID
+#define CA_BUILD_ID "unknown"
+#endif
+const char* ca_build_id(void) { return CA_BUILD_ID; }
 
 int ca_default_options(ca_options* o) {
   if (!o) return CA_ERR_INVALID;

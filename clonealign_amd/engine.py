@@ -31,7 +31,7 @@ TUNE = {"gsplit": 0, "fsplit": 1, "fc_tl": 2, "fc_nbig": 3, "csplit": 4, "csplit
 TRANSPORT_NAME = {0: "none", 1: "rccl", 2: "host", 3: "p2p"}
 
 EXPORTS = (
-    "ca_abi_version", "ca_default_options", "ca_create", "ca_destroy", "ca_last_error", "ca_get_info",
+    "ca_abi_version", "ca_build_id", "ca_default_options", "ca_create", "ca_destroy", "ca_last_error", "ca_get_info",
     "ca_synchronize", "ca_comm_unique_id", "ca_comm_init", "ca_p2p_export", "ca_p2p_connect", "ca_set_host_allreduce", "ca_gamma_init", "ca_elbo", "ca_elbo_terms",
     "ca_step", "ca_gradients", "ca_run", "ca_run_ex", "ca_iterate", "ca_final_elbo", "ca_init_psi_pca", "ca_clone_gene_sums", "ca_get_param", "ca_set_param",
     "ca_get_gradient", "ca_reinit", "ca_get_kernel_times", "ca_reset_kernel_times", "ca_set_profile", "ca_eps_draw", "ca_allele_loglik", "ca_preprocess",
@@ -88,8 +88,10 @@ def load_library(path=None):
     lib = C.CDLL(p)
     lib.ca_last_error.restype = C.c_char_p
     lib.ca_last_error.argtypes = [C.c_void_p]
+    lib.ca_build_id.restype = C.c_char_p
+    lib.ca_build_id.argtypes = []
     for name in EXPORTS:
-        if name != "ca_last_error":
+        if name not in ("ca_last_error", "ca_build_id"):
             getattr(lib, name).restype = C.c_int
     lib.ca_create.argtypes = [C.POINTER(CaProblem), C.POINTER(CaOptions), C.POINTER(C.c_void_p)]
     lib.ca_destroy.argtypes = [C.c_void_p]
@@ -129,6 +131,24 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+_SOURCES = ("clonealign_amd/csrc/clonealign_hip.hip", "clonealign_amd/csrc/ca_kernels.hip.h", "clonealign_amd/csrc/ca_ymfma.hip.h",
+            "clonealign_amd/csrc/philox_host.h", "include/clonealign_hip.h")
+
+
+def source_build_id():
+    """What ca_build_id() of a library built from the sources in this tree returns (same recipe as csrc/Makefile)."""
+    import hashlib
+    root = os.path.dirname(_HERE)
+    h = hashlib.sha1()
+    for f in _SOURCES:
+        h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def build_id():
+    return load_library().ca_build_id().decode()
 
 
 class EngineError(RuntimeError):

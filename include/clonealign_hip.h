@@ -153,6 +153,7 @@ enum ca_kernel_id {
 };
 
 int ca_abi_version(void);
+const char* ca_build_id(void); /* first 16 hex digits of the SHA-1 over the library's sources, as built */
 int ca_default_options(ca_options* opts);
 
 /* Build the engine: upload Y/L/init, precompute the fit constants (lgamma terms,

@@ -67,6 +67,13 @@ def test_structs_match_the_header_as_the_c_compiler_lays_them_out(tmp_path):
     assert opt.variant_off == 0 and opt.variant_on == 0 and list(opt.tune) == [0] * 8
 
 
+def test_library_is_built_from_the_sources_in_the_tree():
+    """the .so files are git-ignored but travel to the GPU box; the build id (hash of the sources, compiled in) must be
+    the one the tree gives, or the tests would validate older kernels."""
+    from clonealign_amd import engine
+    assert engine.build_id() == engine.source_build_id()
+
+
 def test_library_reads_no_configuration_from_the_environment():
     """ADVICE/VERDICT r1: the CA_* switches live in ca_options; getenv is reached only behind CLONEALIGN_DEBUG_ENV."""
     src = open(os.path.join(ROOT, "clonealign_amd", "csrc", "clonealign_hip.hip")).read()

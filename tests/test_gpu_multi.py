@@ -88,3 +88,32 @@ def test_two_gpus_rccl_allreduce(tmp_path, single):
 @pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs")
 def test_two_gpus_peer_to_peer_allreduce(tmp_path, single):
     _check(_run(2, "p2p", tmp_path / "p2p2.json", False), single, "p2p")
+
+
+def _bench(world, extra, same_device=True):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    if same_device:
+        env["CLONEALIGN_BENCH_DEVICE"] = "0"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2",
+           "--repeats", "2", "--cells", "20000", "--genes", "1000", "--clones", "4", "--no-cpu-baseline", *extra]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+
+
+def test_bench_two_ranks_use_a_device_transport_and_fail_loudly_without_one():
+    """bench.py --gpus 2 (both ranks on device 0 here): the all-reduce runs on the device (peer-to-peer), the JSON line says so;
+    asking for RCCL -- which refuses two ranks on one device -- must exit non-zero instead of quietly measuring a host path,
+    and only --allow-host-fallback lets such a run through (marked as what it is)."""
+    r = _bench(2, [])
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["collective"] == "p2p" and line["config"]["collectives_tried"] == ["p2p"]
+    assert line["scaling"] == "strong" and line["value"] > 0 and line["repeats"]["n"] == 2
+    assert line["config"]["allreduce_doubles_per_train_pass"] == 3 + 4 + 1000 * 2 + 1000
+    if _gpus() < 2:
+        r = _bench(2, ["--collective", "rccl"])
+        assert r.returncode != 0 and "refusing to report" in r.stderr
+        r = _bench(2, ["--collective", "rccl", "--allow-host-fallback"])
+        assert r.returncode == 0, r.stderr[-2000:]
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["config"]["collective"] == "gloo-host-fallback" and line["config"]["collectives_tried"] == ["rccl", "host"]

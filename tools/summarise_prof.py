@@ -19,7 +19,9 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 shutil.copy(glob.glob(os.path.join(src, "stats", "*kernel_stats.csv"))[0], os.path.join(out, f"{tag}_kernel_stats.csv"))
 line = [l for l in open(os.path.join(src, "bench_default.json")) if l.startswith("{")][-1]
-json.dump(json.loads(line), open(os.path.join(out, f"{tag}_bench.json"), "w"), indent=1)
+bench = json.loads(line)
+json.dump(bench, open(os.path.join(out, f"{tag}_bench.json"), "w"), indent=1)
+build_id = bench.get("config", {}).get("build_id")
 
 
 def per_kernel(path):
@@ -46,7 +48,15 @@ for which, sub, scale in (("fetch", "pmc_fetch", 2.0), ("write", "pmc_write", 1.
             hbm.setdefault(k, {})[which + "_bytes"] = scale * 1024.0 * sum(v) / len(v)   # KiB units; FETCH_SIZE doubled on gfx950
 for k, d in hbm.items():
     d["hbm_bytes"] = d.get("fetch_bytes", 0.0) + d.get("write_bytes", 0.0)
-json.dump({"_doc": f"HBM bytes per launch from separate FETCH_SIZE / WRITE_SIZE passes (KiB counters; FETCH_SIZE x2 on gfx950 as "
+# per kernel class of bench.py's roofline objects: the kernel of that class with the most launches in the profiled run
+PREFIX = {"fwd": ("k_fwd_cell", "k_fwd_mfma", "k_fwd_lds"), "bwd": ("k_bwd_mfma", "k_bwd"), "ypass": ("k_ypass", "k_yw_mfma", "k_yt_mfma")}
+classes = {}
+for cls, pre in PREFIX.items():
+    cand = [(keep.get(k, {}).get("launches", 0), k) for k in hbm if k.startswith(pre)]
+    if cand:
+        k = max(cand)[1]
+        classes[cls] = {"kernel": k, "hbm_bytes": hbm[k]["hbm_bytes"]}
+json.dump({"build_id": build_id, "classes": classes, "_doc": f"HBM bytes per launch from separate FETCH_SIZE / WRITE_SIZE passes (KiB counters; FETCH_SIZE x2 on gfx950 as "
                    f"MI355X_MICROARCH.md prescribes), build {tag}, same command as the SQ pass.", "kernels": hbm},
           open(os.path.join(out, f"{tag}_pmc_hbm.json"), "w"), indent=1)
 print("wrote", sorted(f for f in os.listdir(out) if f.startswith(tag)))
