@@ -155,10 +155,28 @@ def clonealign(gene_expression_data, copy_number_data, max_iter=200, rel_tol=1e-
                cov=None, ref=None, fix_alpha=False, dtype="float32", saturate=True,
                saturation_threshold=6, K=None, mc_samples=1, verbose=True, initial_shrink=5,
                clone_call_probability=0.95, data_init_mu=True, *, seed=None, engine=None,
-               engine_opts=None, clone_names=None, _reuse=None):
-    """Assign scRNA-seq cells to clones.  Arguments as R/clonealign.R:184-203."""
+               engine_opts=None, clone_names=None, allele_ref="cov", cell_index=None, gene_index=None, _reuse=None):
+    """Assign scRNA-seq cells to clones.  Arguments as R/clonealign.R:184-203.
+
+    Keyword-only extras: ``allele_ref`` -- "cov" (default) reproduces the reference, which forwards ``ref = cov`` to
+    inference_tflow (R/clonealign.R:271) so that the allele-specific term sees alt = 0; "ref" forwards the caller's ``ref``
+    (the evident intent: an explicit opt-in, the default stays reference-identical).  ``cell_index`` / ``gene_index``: masks or
+    index arrays from ``preprocess_for_clonealign(..., return_masks=True)``; the raw matrix is then fitted on that selection
+    without a filtered copy (``copy_number_data`` etc. are given for the selected genes / cells)."""
+    if allele_ref not in ("cov", "ref"):
+        raise ValueError("allele_ref must be 'cov' (reference behaviour) or 'ref'")
     Y, gene_names = _parse_expression(gene_expression_data)
     N, G = Y.shape
+    sel_g = None if gene_index is None else (np.flatnonzero(np.asarray(gene_index)) if np.asarray(gene_index).dtype == bool
+                                             else np.asarray(gene_index, dtype=np.int64))
+    sel_c = None if cell_index is None else (np.flatnonzero(np.asarray(cell_index)) if np.asarray(cell_index).dtype == bool
+                                             else np.asarray(cell_index, dtype=np.int64))
+    if sel_g is not None:
+        G = len(sel_g)
+        if gene_names is not None:
+            gene_names = [gene_names[i] for i in sel_g]
+    if sel_c is not None:
+        N = len(sel_c)
     if K is None:
         K = 1                                                        # :226-232 (both branches give 1)
     L, cn = _parse_cnv(copy_number_data)
@@ -184,22 +202,25 @@ def clonealign(gene_expression_data, copy_number_data, max_iter=200, rel_tol=1e-
 
     res = inference_tflow(Y, L, max_iter=max_iter, rel_tol=rel_tol, learning_rate=learning_rate,
                           gene_filter_threshold=gene_filter_threshold, x=x,
-                          clone_allele=clone_allele, cov=cov, ref=cov, fix_alpha=fix_alpha,
+                          clone_allele=clone_allele, cov=cov, ref=(cov if allele_ref == "cov" else ref), fix_alpha=fix_alpha,
                           dtype=dtype, saturate=saturate, saturation_threshold=saturation_threshold,
                           K=K, mc_samples=mc_samples, verbose=verbose, initial_shrink=initial_shrink,
                           data_init_mu=data_init_mu, gene_names=gene_names, seed=seed,
-                          engine=engine, engine_opts=engine_opts, post=_post, _reuse=_reuse)
+                          engine=engine, engine_opts=engine_opts, post=_post, cell_index=sel_c, gene_index=sel_g, _reuse=_reuse)
     res = ClonealignFit(res)
     res["clone"] = clone_assignment(res["ml_params"]["clone_probs"], clone_names,
                                     clone_call_probability)          # :283
     res["clone_names"] = list(clone_names)                           # colnames(clone_probs), :286
-    keepset = set(res["retained_genes"])
-    keep = np.array([g in keepset for g in gene_names])
+    # the retained genes as the boolean mask inference_tflow applied (matching by NAME would mark a filtered gene that shares
+    # its symbol with a retained one as kept, and L[keep] would then have more rows than the fitted matrix)
+    keep = np.asarray(res.pop("retained_mask"), dtype=bool)
     post = res.pop("post", None)
     if post is not None:
         res["correlations"] = correlations_from_sums(post["T"], post["Syy"], L[keep, :], post["counts"])   # :292-294
     else:
-        res["correlations"] = compute_correlations(Y[:, keep], L[keep, :], res["clone"], clone_names)      # :292-294
+        Ysel = Y if (sel_c is None and sel_g is None) else Y[np.ix_(np.arange(Y.shape[0]) if sel_c is None else sel_c,
+                                                                    np.arange(Y.shape[1]) if sel_g is None else sel_g)]
+        res["correlations"] = compute_correlations(Ysel[:, keep], L[keep, :], res["clone"], clone_names)   # :292-294
     cor = res["correlations"]
     if np.any(~np.isnan(cor)):
         if np.nanquantile(cor, 0.25) < 0:                            # :296-300

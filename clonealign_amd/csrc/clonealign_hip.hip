@@ -1820,6 +1820,14 @@ int ca_abi_version(void) { return CA_ABI_VERSION; }
 #endif
 const char* ca_build_id(void) { return CA_BUILD_ID; }
 
+int ca_device_count(int32_t* n) {
+  int c = 0;
+  const hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) { (void)hipGetLastError(); c = 0; }
+  if (n) *n = c;
+  return e == hipSuccess ? CA_OK : CA_ERR_HIP;
+}
+
 int ca_default_options(ca_options* o) {
   if (!o) return CA_ERR_INVALID;
   memset(o, 0, sizeof(*o));

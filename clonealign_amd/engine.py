@@ -31,7 +31,7 @@ TUNE = {"gsplit": 0, "fsplit": 1, "fc_tl": 2, "fc_nbig": 3, "csplit": 4, "csplit
 TRANSPORT_NAME = {0: "none", 1: "rccl", 2: "host", 3: "p2p"}
 
 EXPORTS = (
-    "ca_abi_version", "ca_build_id", "ca_default_options", "ca_create", "ca_destroy", "ca_last_error", "ca_get_info",
+    "ca_abi_version", "ca_build_id", "ca_device_count", "ca_default_options", "ca_create", "ca_destroy", "ca_last_error", "ca_get_info",
     "ca_synchronize", "ca_comm_unique_id", "ca_comm_init", "ca_p2p_export", "ca_p2p_connect", "ca_set_host_allreduce", "ca_gamma_init", "ca_elbo", "ca_elbo_terms",
     "ca_step", "ca_gradients", "ca_run", "ca_run_ex", "ca_iterate", "ca_final_elbo", "ca_init_psi_pca", "ca_clone_gene_sums", "ca_get_param", "ca_set_param",
     "ca_get_gradient", "ca_reinit", "ca_get_kernel_times", "ca_reset_kernel_times", "ca_set_profile", "ca_eps_draw", "ca_allele_loglik", "ca_preprocess",
@@ -93,6 +93,7 @@ def load_library(path=None):
     for name in EXPORTS:
         if name not in ("ca_last_error", "ca_build_id"):
             getattr(lib, name).restype = C.c_int
+    lib.ca_device_count.argtypes = [C.POINTER(C.c_int32)]
     lib.ca_create.argtypes = [C.POINTER(CaProblem), C.POINTER(CaOptions), C.POINTER(C.c_void_p)]
     lib.ca_destroy.argtypes = [C.c_void_p]
     lib.ca_get_info.argtypes = [C.c_void_p, C.POINTER(CaInfo)]
@@ -128,9 +129,18 @@ def load_library(path=None):
                                   C.POINTER(CaPreprocessParams), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p]
     lib.ca_allele_loglik.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                      C.c_void_p, C.c_char_p]
+    # initialise this library's HIP runtime NOW: torch bundles its own, and whichever runtime is loaded first must also be
+    # initialised first (loaded first but initialised second it reports "no ROCm-capable device is detected")
+    lib.ca_device_count(None)
     if path is None:
         _lib = lib
     return lib
+
+
+def device_count():
+    n = C.c_int32()
+    load_library().ca_device_count(C.byref(n))
+    return n.value
 
 
 _SOURCES = ("clonealign_amd/csrc/clonealign_hip.hip", "clonealign_amd/csrc/ca_kernels.hip.h", "clonealign_amd/csrc/ca_ymfma.hip.h",

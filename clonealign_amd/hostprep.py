@@ -43,6 +43,38 @@ def gene_filter(Y, L, gene_filter_threshold=0):
     return np.ascontiguousarray(Y[:, keep]), L[keep, :], keep
 
 
+def selected_sums(Y, rows, cols, axis):
+    """colSums (axis=0) / rowSums (axis=1) of Y[rows][:, cols] in float64 WITHOUT materialising the sub-matrix: the full
+    sums minus the sums over the dropped rows / columns (masks from preprocessing keep almost everything), or the direct
+    sums when more is dropped than kept.  rows / cols: sorted index arrays or None (= all)."""
+    N, G = Y.shape
+    rows = None if rows is None or len(rows) == N else np.asarray(rows)
+    cols = None if cols is None or len(cols) == G else np.asarray(cols)
+
+    def sums(sub_rows, sub_cols):
+        A = Y if sub_rows is None else Y[sub_rows]
+        out = A.sum(axis, dtype=np.float64)
+        return out if sub_cols is None else out[sub_cols]
+
+    if axis == 0:        # per column, over the selected rows
+        if rows is None:
+            out = Y.sum(0, dtype=np.float64)
+        elif len(rows) * 2 < N:
+            out = Y[rows].sum(0, dtype=np.float64)
+        else:
+            drop = np.setdiff1d(np.arange(N), rows, assume_unique=True)
+            out = Y.sum(0, dtype=np.float64) - Y[drop].sum(0, dtype=np.float64)
+        return out if cols is None else out[cols]
+    if cols is None:     # per row, over the selected columns
+        out = Y.sum(1, dtype=np.float64)
+    elif len(cols) * 2 < G:
+        out = Y[:, cols].sum(1, dtype=np.float64)
+    else:
+        drop = np.setdiff1d(np.arange(G), cols, assume_unique=True)
+        out = Y.sum(1, dtype=np.float64) - Y[:, drop].sum(1, dtype=np.float64)
+    return out if rows is None else out[rows]
+
+
 def r_scale(x):
     """R's ``scale(x)``: centre columns, divide by the (n-1) standard deviation."""
     x = np.asarray(x, dtype=np.float64)

@@ -78,7 +78,8 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
                     fix_alpha=False, dtype="float32", saturate=True, saturation_threshold=6,
                     K=1, mc_samples=1, verbose=True, initial_shrink=5, data_init_mu=True,
                     *, gene_names=None, seed=None, engine=None, engine_opts=None,
-                    psi_noise=None, eps_stream=None, psi_init="auto", post=None, allele_on="auto", _reuse=None):
+                    psi_noise=None, eps_stream=None, psi_init="auto", post=None, allele_on="auto", cell_index=None,
+                    gene_index=None, _reuse=None):
     """EM/VI inference on the MI355X engine.  Arguments as R/inference-tflow.R:71-89.
 
     Keyword-only extras (no reference counterpart): ``seed`` (replaces R's ``set.seed``
@@ -91,6 +92,11 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
     the device, ca_allele_loglik, once cells x variants exceeds 2e5);
     ``post(engine, ml_params)`` runs before the engine is closed (clonealign() uses it for the device-side
     correlation sums) and its result is returned under ``"post"``.
+    ``cell_index`` / ``gene_index`` (sorted integer arrays or boolean masks): fit only these rows / columns of ``Y_dat`` --
+    the masks of ``preprocess_for_clonealign(..., return_masks=True)``.  ``L_dat`` (and ``x``, ``cov``, ``ref``) are then given
+    for the SELECTED genes / cells.  Above 4e6 selected counts the HIP engine takes the raw matrix and the index lists
+    (``ca_problem.cell_index / gene_index``): no filtered copy of the matrix is made on the host, neither here nor for the gene
+    filter of :117-124 (the reference copies in R: R/preprocess.R:141-147, R/inference-tflow.R:117-124).
     ``_reuse``: a dict owned by run_clonealign()'s restart loop (multirun.py).  The first fit leaves its prepared inputs and
     its engine in it; later fits on the SAME data and settings skip the host passes and the upload and restart the resident
     engine (``ca_reinit``).  The owner closes the engine.
@@ -110,13 +116,38 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
             fits = Y_dat.dtype.kind in "iu" and Y_dat.size and 0 <= Y_dat.min() and Y_dat.max() <= np.iinfo(np.int32).max
             Y_dat = Y_dat.astype(np.int32 if fits else np.float64)
         L_dat = np.asarray(L_dat, dtype=np.float64)
-        Y_dat, L_dat, keep = hostprep.gene_filter(Y_dat, L_dat, gene_filter_threshold)   # :117-124
+        # optional selection of rows / columns of the raw matrix (masks of preprocess_for_clonealign)
+        as_index = lambda m, n: None if m is None else (np.flatnonzero(np.asarray(m)) if np.asarray(m).dtype == bool  # noqa: E731
+                                                        else np.asarray(m, dtype=np.int64))
+        ci, gi = as_index(cell_index, Y_dat.shape[0]), as_index(gene_index, Y_dat.shape[1])
+        n_sel = Y_dat.shape[0] if ci is None else len(ci)
+        g_sel = Y_dat.shape[1] if gi is None else len(gi)
+        if L_dat.shape[0] != g_sel:
+            raise ValueError("nrow(L_dat) == G is not TRUE")               # :139
+        device_cut = (engine is None and n_sel * g_sel > 4_000_000 and
+                      int((engine_opts or {}).get("world", 1)) == 1)      # the engine cuts the raw matrix at upload
+        sel = None
+        if device_cut:
+            col = hostprep.selected_sums(Y_dat, ci, gi, axis=0)            # colSums over the selected cells, selected genes
+            keep = ~(col <= gene_filter_threshold)                         # :117-124 on the selection
+            gi_full = np.arange(Y_dat.shape[1]) if gi is None else gi
+            if not keep.all() or ci is not None or gi is not None:
+                sel = dict(cell_index=ci, gene_index=gi_full[keep].astype(np.int32) if (gi is not None or not keep.all()) else None)
+                if sel["cell_index"] is None and sel["gene_index"] is None:
+                    sel = None
+            L_dat = L_dat[keep, :]
+            row_sums = hostprep.selected_sums(Y_dat, ci, None if sel is None else sel["gene_index"], axis=1)
+        else:
+            if ci is not None or gi is not None:
+                Y_dat = Y_dat[np.ix_(np.arange(Y_dat.shape[0]) if ci is None else ci, np.arange(Y_dat.shape[1]) if gi is None else gi)]
+            Y_dat, L_dat, keep = hostprep.gene_filter(Y_dat, L_dat, gene_filter_threshold)   # :117-124
+            row_sums = None
         log(f"Removing {int((~keep).sum())} genes with low counts")
         if gene_names is not None:
             retained_genes = [g for g, k in zip(gene_names, keep) if k]     # :126-131
         else:
             retained_genes = np.flatnonzero(keep)                           # 0-based (R: which(), 1-based)
-        N, G = Y_dat.shape
+        N, G = (n_sel, int(keep.sum())) if device_cut else Y_dat.shape
         C = L_dat.shape[1]
         K = int(K)
         if L_dat.shape[0] != G:
@@ -154,11 +185,13 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
             clone_probs_from_snv = np.exp(extra - logsumexp(extra, 1, keepdims=True))   # :436-440
         if _reuse is not None:
             _reuse["prep"] = dict(Y_dat=Y_dat, L_dat=L_dat, keep=keep, retained_genes=retained_genes, N=N, G=G, C=C, K=K, P=P,
-                                  x=x, extra=extra, clone_probs_from_snv=clone_probs_from_snv)
+                                  x=x, extra=extra, clone_probs_from_snv=clone_probs_from_snv, sel=sel, row_sums=row_sums,
+                                  device_cut=device_cut)
     else:
         Y_dat, L_dat, keep, retained_genes = cached["Y_dat"], cached["L_dat"], cached["keep"], cached["retained_genes"]
         N, G, C, K, P, x = cached["N"], cached["G"], cached["C"], cached["K"], cached["P"], cached["x"]
         extra, clone_probs_from_snv = cached["extra"], cached["clone_probs_from_snv"]
+        sel, row_sums, device_cut = cached["sel"], cached["row_sums"], cached["device_cut"]
     rng = np.random.default_rng(seed)
     # initialisation (:204-235)
     if psi_noise is None:
@@ -167,18 +200,22 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
     if psi_init not in ("auto", "host", "device"):
         raise ValueError("psi_init must be 'auto', 'host' or 'device'")
     device_pca = K > 0 and hasattr(Engine, "pca_init") and (psi_init == "device" or (psi_init == "auto" and N * G > 4_000_000))
+    if device_cut and not device_pca and K > 0:
+        raise ValueError("psi_init='host' needs the filtered matrix on the host; it is cut on the device at this size")
     pcs = np.zeros((N, K)) if device_pca else hostprep.pca_init(Y_dat, K, psi_noise)
     if cached is not None and "loc0" in cached:
         loc0 = cached["loc0"]                                           # same data: same s_init check, same mu_guess
     else:
-        s_init = Y_dat.sum(1, dtype=np.float64)
+        s_init = row_sums if row_sums is not None else Y_dat.sum(1, dtype=np.float64)
         if np.any(s_init == 0):
             raise ValueError("Some cells have no counts mapping")      # :212-214
         if (isinstance(data_init_mu, (bool, np.bool_)) and bool(data_init_mu) and N * G > 4_000_000
                 and getattr(Engine, "DEVICE_MU_INIT", False) and int((engine_opts or {}).get("world", 1)) == 1):
             loc0 = None  # the engine takes mu_guess (:220-235) and loc0 (:262) from the resident matrix: no host pass
         else:
-            mu_g = hostprep.mu_guess(Y_dat, data_init_mu, row_sums=s_init)
+            if device_cut and isinstance(data_init_mu, (bool, np.bool_)) and bool(data_init_mu):
+                raise ValueError("data_init_mu=True on a device-cut matrix needs the engine's device-side initialisation")
+            mu_g = hostprep.mu_guess(np.empty((0, G)) if device_cut else Y_dat, data_init_mu, row_sums=s_init)
             loc0 = hostprep.safe_inverse_softplus(mu_g)                 # :262
         if _reuse is not None:
             _reuse["prep"]["loc0"] = loc0
@@ -192,7 +229,7 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
         eng.reinit(pcs, loc0)                                           # restart on the resident data (ca_reinit)
     else:
         eng = Engine(Y_dat, L_dat, pcs, loc0, K, S, X=x, extra_loglik=extra,
-                     learning_rate=learning_rate, **(engine_opts or {}))
+                     learning_rate=learning_rate, **(engine_opts or {}), **(sel or {}))
         if _reuse is not None and hasattr(eng, "reinit"):
             _reuse["eng"] = eng
     keep_open = _reuse is not None and _reuse.get("eng") is eng
@@ -200,13 +237,18 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
         if device_pca:
             if cached is not None and "const_gene" in cached:
                 const_gene = cached["const_gene"]
-            else:
-                const_gene = bool(np.any(Y_dat.min(0) == Y_dat.max(0)))
+            else:   # (a device-cut matrix is checked by the device routine itself: same message from ca_init_psi_pca)
+                const_gene = False if device_cut else bool(np.any(Y_dat.min(0) == Y_dat.max(0)))
                 if _reuse is not None:
                     _reuse["prep"]["const_gene"] = const_gene
             if const_gene:                               # prcomp(scale = TRUE) refuses constant genes (sd == 0)
                 raise ValueError("cannot rescale a constant/zero column to unit variance")
-            eng.pca_init(psi_noise, seed=int(rng.integers(0, 2**31 - 1)))
+            try:
+                eng.pca_init(psi_noise, seed=int(rng.integers(0, 2**31 - 1)))
+            except RuntimeError as e:
+                if "constant/zero column" in str(e):
+                    raise ValueError("cannot rescale a constant/zero column to unit variance") from e
+                raise
         log("Optimizing ELBO")
         if hasattr(eng, "run"):
             elbos = eng.run(eps_stream, max_iter, rel_tol)
@@ -247,6 +289,7 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
         "ml_params": ml_params,
         "convergence_info": convergence_info,
         "retained_genes": retained_genes,
+        "retained_mask": np.asarray(keep, dtype=bool),      # the same genes as a mask over the (selected) input genes
         "clone_probs_from_snv": clone_probs_from_snv,
         **({"post": post_out} if post is not None else {}),
     }

@@ -27,10 +27,14 @@ def get_outlying_genes(Y, nmads):
 def preprocess_for_clonealign(gene_expression_data, copy_number_data, min_counts_per_gene=20,
                               min_counts_per_cell=100, remove_outlying_genes=True, nmads=10,
                               max_copy_number=6, remove_genes_same_copy_number=True,
-                              gene_names=None, cell_names=None, on="auto", device=0):
+                              gene_names=None, cell_names=None, on="auto", device=0, return_masks=False):
     """Filter genes/cells exactly in the order of R/preprocess.R:114-139.
 
-    ``on`` in {"auto", "host", "device"}: where colSums / rowSums are taken ("auto": on the device above 2e7 elements)."""
+    ``on`` in {"auto", "host", "device"}: where colSums / rowSums are taken ("auto": on the device above 2e7 elements).
+    ``return_masks=True`` (device statistics): no filtered copy of the count matrix is made -- the result carries
+    ``keep_cells`` / ``keep_genes`` (boolean masks over the input) next to the filtered copy-number matrix and names, for
+    ``clonealign(raw, result["copy_number_data"], cell_index=result["keep_cells"], gene_index=result["keep_genes"])``: the
+    engine cuts the raw matrix at upload (ca_problem.cell_index / gene_index; the reference returns copies, :141-147)."""
     Y, gn = _parse_expression(gene_expression_data)
     L, _ = _parse_cnv(copy_number_data)
     G = Y.shape[1]
@@ -44,12 +48,18 @@ def preprocess_for_clonealign(gene_expression_data, copy_number_data, min_counts
         from .engine import preprocess_masks
         kg, kc, _gs, _cs = preprocess_masks(Y, L, min_counts_per_gene, min_counts_per_cell, remove_outlying_genes, nmads,
                                             max_copy_number, remove_genes_same_copy_number, device=device)
+        if return_masks:
+            return {"keep_cells": kc, "keep_genes": kg, "copy_number_data": L[kg, :], "retained_cells": cells[kc],
+                    "retained_genes": genes[kg]}
         return {
             "gene_expression_data": Y[np.ix_(kc, kg)],
             "copy_number_data": L[kg, :],
             "retained_cells": cells[kc],
             "retained_genes": genes[kg],
         }
+
+    if return_masks:
+        raise ValueError("return_masks=True needs the device statistics (on='device')")
 
     def keep_genes(mask):
         nonlocal Y, L, genes

@@ -154,6 +154,11 @@ enum ca_kernel_id {
 
 int ca_abi_version(void);
 const char* ca_build_id(void); /* first 16 hex digits of the SHA-1 over the library's sources, as built */
+/* Number of HIP devices this library's runtime sees (0 and CA_ERR_HIP when there is none).  Also initialises the runtime: a host
+ * that loads a second HIP runtime into the process (PyTorch bundles its own) should call this right after loading the library,
+ * so that the load order and the initialisation order agree (the runtime initialised second after being loaded first sees
+ * "no ROCm-capable device"). */
+int ca_device_count(int32_t* n);
 int ca_default_options(ca_options* opts);
 
 /* Build the engine: upload Y/L/init, precompute the fit constants (lgamma terms,

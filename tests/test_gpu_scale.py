@@ -446,3 +446,83 @@ def test_fused_loop_at_shard_size_matches_c_oracle():
         assert np.array_equal(pe.argmax(1)[robust], po.argmax(1)[robust])
     finally:
         eng.close(); ora.close()
+
+
+def test_config5_run_clonealign_eight_restarts_at_size():
+    """BASELINE.json configs[4]: run_clonealign with 8 restarts on 50k cells x 3k genes x 6 clones, dealt over the visible GPUs
+    (one resident engine per GPU, restarts = ca_reinit), best-ELBO selection (R/clonealign.R:50-65).  One restart's fused loop
+    is checked against the C oracle through ca_run, and the winner against a fresh clonealign() of the same seed."""
+    import warnings
+    import torch
+    import clonealign_amd as ca
+    from clonealign_amd.engine import HipEngine
+    from clonealign_amd.inference import run_vi_loop
+    from clonealign_amd.rng import EpsStream
+    from oracle.c_port import CPortModel
+    N, G, C = 50_000, 3_000, 6
+    Yd, L, psi0, loc0 = _synth(N, G, C, seed=20245)
+    Y = Yd.cpu().numpy()                                       # int32 counts
+    del Yd
+    devices = list(range(torch.cuda.device_count()))
+    kw = dict(max_iter=25, rel_tol=1e-9, verbose=False)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        best = ca.run_clonealign(Y, L, initial_shrinks=(0, 5), n_repeats=4, print_elbos=False, seed=77, devices=devices, **kw)
+    elbos = best["multirun_info"]["elbos"]
+    assert elbos.shape == (8,) and np.all(np.isfinite(elbos)) and len(set(elbos.tolist())) == 8      # eight different restarts
+    assert best["convergence_info"]["final_elbo"] == elbos.max()                                      # which.max, :65
+    assert len(best["multirun_info"]["clone_prevalences_at_different_shrinks"]) == 8
+    assert best["ml_params"]["clone_probs"].shape == (N, C) and len(best["clone"]) == N
+    seeds = [int(s.generate_state(1)[0]) for s in np.random.SeedSequence(77).spawn(8)]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        again = ca.clonealign(Y, L, seed=seeds[int(np.argmax(elbos))], **kw)
+    assert np.array_equal(again["convergence_info"]["elbo"], best["convergence_info"]["elbo"])         # restart == separate fit
+    assert np.array_equal(again["ml_params"]["clone_probs"], best["ml_params"]["clone_probs"])
+    # the same shape through ca_run against the C oracle (4 iterations of the fused loop)
+    eng = HipEngine(Y, L, psi0, loc0, 1)
+    ora = CPortModel(Y.astype(np.float64), L, psi0, loc0, 1, dtype="float32")
+    try:
+        tr = np.asarray(eng.run(EpsStream(5, 1, G), 4, 1e-12))
+        to = np.asarray(run_vi_loop(ora, EpsStream(5, 1, G), 4, 1e-12))
+        assert tr.shape == to.shape == (5,) and np.abs(tr - to).max() <= 1e-5 * np.abs(to).max(), (tr, to)
+        se, so = eng.get_state(), ora.get_state()
+        for n in ("W", "v", "psi", "alpha_unconstr", "loc", "ls", "gamma_logits"):
+            err = np.abs(se[n] - so[n]).max() / max(np.abs(so[n]).max(), 1e-30)
+            assert err < 2e-4, (n, err)
+    finally:
+        eng.close(); ora.close()
+
+
+def test_preprocessing_masks_feed_the_upload_without_a_host_copy():
+    """SURVEY section 8f row 3 tail: preprocess_for_clonealign(return_masks=True) -> clonealign(raw, cell_index=, gene_index=): the
+    engine cuts the raw matrix at upload (ca_problem.cell_index / gene_index), and the gene filter of R/inference-tflow.R:117-124
+    rides on the same lists.  Same fit as preprocessing to filtered copies (what R/preprocess.R:141-147 returns) first."""
+    import warnings
+    import clonealign_amd as ca
+    from clonealign_amd.preprocess import preprocess_for_clonealign
+    rng = np.random.default_rng(61)
+    N, G, C = 4200, 1500, 4
+    L = rng.integers(1, 5, size=(G, C)).astype(np.float64)
+    L[::11] = 2.0                                                    # same copy number in all clones: removed
+    L[5, 0] = 8.0                                                    # above max_copy_number: removed
+    z = rng.integers(0, C, N)
+    Y = rng.poisson(rng.lognormal(-1.2, 1.1, G)[None, :] * L[:, z].T * 0.5).astype(np.int32)
+    Y[::97] = 0                                                      # empty cells: removed by min_counts_per_cell
+    Y[0, Y.min(0) == Y.max(0)] += 1
+    pp = dict(min_counts_per_gene=60, min_counts_per_cell=40)
+    m = preprocess_for_clonealign(Y, L, on="device", return_masks=True, **pp)
+    f = preprocess_for_clonealign(Y, L, on="device", **pp)
+    assert 0 < m["keep_cells"].sum() < N and 0 < m["keep_genes"].sum() < G
+    assert f["gene_expression_data"].shape == (m["keep_cells"].sum(), m["keep_genes"].sum())
+    assert m["keep_cells"].sum() * m["keep_genes"].sum() > 4_000_000          # the device-cut path of inference_tflow
+    kw = dict(max_iter=10, rel_tol=1e-9, verbose=False, seed=9, gene_filter_threshold=70)   # the gene filter bites on top
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = ca.clonealign(Y, m["copy_number_data"], cell_index=m["keep_cells"], gene_index=m["keep_genes"], **kw)
+        b = ca.clonealign(f["gene_expression_data"], f["copy_number_data"], **kw)
+    assert 0 < len(a["retained_genes"]) < m["keep_genes"].sum()
+    assert len(a["retained_genes"]) == len(b["retained_genes"])
+    assert np.array_equal(a["convergence_info"]["elbo"], b["convergence_info"]["elbo"])
+    assert np.array_equal(a["ml_params"]["clone_probs"], b["ml_params"]["clone_probs"])
+    np.testing.assert_allclose(a["correlations"], b["correlations"], rtol=0, atol=1e-12, equal_nan=True)

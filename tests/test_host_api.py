@@ -189,3 +189,68 @@ def test_correlations_from_sums_equals_direct_computation():
     viasums = correlations_from_sums(T, Syy, L, np.bincount(idx[idx >= 0], minlength=3))
     np.testing.assert_allclose(viasums[:7], direct[:7], rtol=1e-10)
     assert np.isnan(viasums[7]) and np.isnan(viasums[8]) and np.isnan(direct[8])
+
+
+def test_duplicated_gene_names_do_not_confuse_the_retained_mask(example):
+    """the retained genes are tracked as the boolean mask inference_tflow applied, not by name -- a filtered gene that
+    shares its symbol with a retained one must not pull a copy-number row into the correlations."""
+    Y, L, clones, genes, cells = example
+    Y = Y.copy()
+    Y[:, 7] = 0                                   # gene 7 is filtered (colSums == 0) ...
+    genes = list(genes)
+    genes[7] = genes[3]                           # ... and shares its name with retained gene 3
+    sce = {"assays": {"counts": Y.T}, "rownames": genes}
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cal = ca.clonealign(sce, L, clone_names=clones, verbose=False, max_iter=3, seed=1, **ORACLE)
+    assert len(cal["retained_genes"]) == 99 == len(cal["ml_params"]["mu"]) == len(cal["correlations"])
+    ref = ca.api.compute_correlations(np.delete(Y, 7, 1), np.delete(L, 7, 0), cal["clone"], clones)
+    np.testing.assert_allclose(cal["correlations"], ref, equal_nan=True)
+
+
+def test_allele_ref_opt_in_forwards_the_real_reference_counts(example):
+    """R/clonealign.R:271 forwards ref = cov, so the allele term sees alt = 0; allele_ref="ref" is the explicit opt-in for the
+    evident intent, the default stays reference-identical."""
+    Y, L, clones, genes, cells = example
+    rng = np.random.default_rng(3)
+    V = 12
+    cov = rng.poisson(8, size=(Y.shape[0], V)).astype(np.float64)
+    ref = rng.binomial(cov.astype(int), 0.5).astype(np.float64)
+    clone_allele = rng.integers(1, 4, size=(V, 3)).astype(np.float64)
+    kw = dict(clone_allele=clone_allele, cov=cov, ref=ref, max_iter=3, seed=4)
+    a = _cal(example, **kw)                                     # default: ref = cov
+    b = _cal(example, **kw, allele_ref="cov")
+    c = _cal(example, **kw, allele_ref="ref")
+    from clonealign_amd.inference import construct_ai_likelihood
+    for fit, r in ((a, cov), (b, cov), (c, ref)):
+        ex = construct_ai_likelihood(clone_allele, cov.T - r.T, cov.T)
+        want = np.exp(ex - np.logaddexp.reduce(ex, 1, keepdims=True))
+        np.testing.assert_allclose(fit["clone_probs_from_snv"], want, rtol=1e-12)
+    assert np.array_equal(a["convergence_info"]["elbo"], b["convergence_info"]["elbo"])
+    assert not np.array_equal(a["convergence_info"]["elbo"], c["convergence_info"]["elbo"])
+    with pytest.raises(ValueError):
+        _cal(example, **kw, allele_ref="alt")
+
+
+def test_cell_and_gene_selection_equals_fitting_the_filtered_copy(example):
+    """clonealign(raw, L[sel], cell_index=, gene_index=) == clonealign(raw[cells][:, genes], L[sel]) (host-cut path of the mirror;
+    the device-cut path is tests/test_gpu_scale.py)."""
+    Y, L, clones, genes, cells = example
+    rng = np.random.default_rng(8)
+    kc = rng.random(Y.shape[0]) < 0.8
+    kg = rng.random(Y.shape[1]) < 0.7
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = ca.clonealign(Y, L[kg], clone_names=clones, verbose=False, max_iter=4, seed=2, cell_index=kc, gene_index=kg, **ORACLE)
+        b = ca.clonealign(Y[np.ix_(kc, kg)], L[kg], clone_names=clones, verbose=False, max_iter=4, seed=2, **ORACLE)
+        c = ca.clonealign(Y, L[kg], clone_names=clones, verbose=False, max_iter=4, seed=2, cell_index=np.flatnonzero(kc),
+                          gene_index=np.flatnonzero(kg), **ORACLE)
+    for x in (a, c):
+        assert np.array_equal(x["convergence_info"]["elbo"], b["convergence_info"]["elbo"])
+        assert list(x["clone"]) == list(b["clone"]) and len(x["clone"]) == kc.sum()
+        np.testing.assert_allclose(x["correlations"], b["correlations"], equal_nan=True)
+    for rows, cols in ((None, None), (np.flatnonzero(kc), None), (None, np.flatnonzero(kg)), (np.flatnonzero(kc), np.flatnonzero(kg)),
+                       (np.arange(5), np.arange(7))):
+        sub = Y[np.ix_(np.arange(Y.shape[0]) if rows is None else rows, np.arange(Y.shape[1]) if cols is None else cols)]
+        np.testing.assert_array_equal(hostprep.selected_sums(Y, rows, cols, 0), sub.sum(0))
+        np.testing.assert_array_equal(hostprep.selected_sums(Y, rows, cols, 1), sub.sum(1))
