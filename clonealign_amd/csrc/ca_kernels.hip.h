@@ -1991,6 +1991,70 @@ __global__ void __launch_bounds__(CA_TB) k_yw_dot(const float* __restrict__ YWpa
   if (threadIdx.x == 0) yw_part[blockIdx.x] = r;
 }
 
+// Both finishing steps of the Y stream in ONE launch: the column sums of its Y^T psi slab (k_colsum's arithmetic, blocks
+// [0, nb_col)) and the row sums + psi.(YW) partials (k_yw_dot's, the blocks after).  Small problems pay a launch and its gap for
+// each of them otherwise.  1024 threads per block like k_colsum; the row side uses the first 256 of them.
+__global__ void __launch_bounds__(1024) k_yfinish(const float* __restrict__ part, double* __restrict__ out, int rows, int64_t ld, int cols,
+                                                  const int* __restrict__ col_chunk_ptr, const float* __restrict__ csum, int K, int G,
+                                                  int nb_col, const float* __restrict__ YWpart, int nseg, const float* __restrict__ F, int D,
+                                                  int64_t N, float* __restrict__ YW, double* __restrict__ yw_part) {
+  if ((int)blockIdx.x < nb_col) {
+    constexpr int RL = 16;
+    __shared__ double smc[RL][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (c < cols) {
+      int r = ty;
+      for (; r + 3 * RL < rows; r += 4 * RL) {
+        const float v0 = part[(int64_t)r * ld + c], v1 = part[(int64_t)(r + RL) * ld + c];
+        const float v2 = part[(int64_t)(r + 2 * RL) * ld + c], v3 = part[(int64_t)(r + 3 * RL) * ld + c];
+        a0 += (double)v0; a1 += (double)v1; a2 += (double)v2; a3 += (double)v3;
+      }
+      for (; r < rows; r += RL) a0 += (double)part[(int64_t)r * ld + c];
+      a0 += a2; a1 += a3;
+      if (csum && ty == 0) {
+        const int g = c / K, k = c - g * K;
+        if (g < G)
+          for (int ch = col_chunk_ptr[g]; ch < col_chunk_ptr[g + 1]; ++ch) a1 += (double)csum[(int64_t)ch * K + k];
+      }
+    }
+    smc[ty][tx] = a0 + a1;
+    __syncthreads();
+#pragma unroll
+    for (int s_ = RL / 2; s_ > 0; s_ >>= 1) {
+      if (ty < s_) smc[ty][tx] += smc[ty + s_][tx];
+      __syncthreads();
+    }
+    if (ty == 0 && c < cols) out[c] = smc[0][tx];
+    return;
+  }
+  // row side: one block of CA_TB cells (the same partition and order as k_yw_dot)
+  __shared__ double smr[CA_TB / 64];
+  const int blk = (int)blockIdx.x - nb_col;
+  double a = 0.0;
+  if (threadIdx.x < CA_TB) {
+    const int64_t n = (int64_t)blk * CA_TB + threadIdx.x;
+    if (n < N)
+      for (int k = 0; k < K; ++k) {
+        double yw = 0.0;
+        for (int sg = 0; sg < nseg; ++sg) yw += (double)YWpart[((int64_t)sg * N + n) * K + k];
+        YW[n * K + k] = (float)yw;
+        a += (double)F[n * D + k] * yw;
+      }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
+    if ((threadIdx.x & 63) == 0) smr[threadIdx.x >> 6] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double r = smr[0];
+#pragma unroll
+    for (int w = 1; w < CA_TB / 64; ++w) r += smr[w];
+    yw_part[blk] = r;
+  }
+}
+
 // ------------------------------------------------------------------ forward sweep + cell epilogue in one kernel
 // The fused two-eps sweep with NO partial slabs: a block owns 16 * TL cells for ALL genes, its four waves take every fourth
 // k-step (B operand and V' straight from L2 with one k-step of prefetch -- no LDS staging to share, each wave has its own
@@ -2160,13 +2224,30 @@ __device__ __forceinline__ void ca_final_gene_body(const double* __restrict__ re
                                                       float* __restrict__ v_ls, float* __restrict__ m_V, float* __restrict__ v_V,
                                                       float* __restrict__ g_loc, float* __restrict__ g_ls, float* __restrict__ g_V,
                                                       float* __restrict__ Vs, float* __restrict__ vmm_part,
-                                                      int G, int S, int D, int K, int apply, float lr_t, float b1, float b2, float aeps, float* smin, float* smax) {
+                                                      int G, int S, int D, int K, int apply, float lr_t, float b1, float b2, float aeps, float* smin, float* smax,
+                                                      const float* __restrict__ gfold /*[nfold][G][S+D] or null*/, int nfold) {
   const int g = blockIdx.x * CA_TB + threadIdx.x;
   const bool ok = g < G;
   if (ok) {
   const double l = (double)loc[g], lsd = (double)ls[g], sd = exp(lsd), cs = colsum[g];
   const int W_ = S + D;
-  const double* rg = red_g + (int64_t)g * W_;
+  // small problems: the backward sweep's cell-split partials are summed here (fixed order, fp64) instead of by a k_colsum
+  // launch of their own -- one launch and its gap less per iteration where launches are what an iteration costs
+  double rfold[12];
+  if (gfold) {
+    for (int w = 0; w < W_; ++w) {
+      double a = 0.0;
+      for (int sp0 = 0; sp0 < nfold; sp0 += 8) {   // eight loads in flight, added in slice order
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = gfold[((int64_t)(sp0 + i < nfold ? sp0 + i : nfold - 1) * G + g) * W_ + w];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) a += (sp0 + i < nfold) ? (double)v[i] : 0.0;
+      }
+      rfold[w] = a;
+    }
+  }
+  const double* rg = gfold ? rfold : red_g + (int64_t)g * W_;
   double gl = 0.0, gs = 0.0;
   for (int s = 0; s < S; ++s) {
     const double e = (double)eps[(int64_t)s * G + g];
@@ -2235,7 +2316,7 @@ __global__ void __launch_bounds__(CA_TB) k_final_gene(const double* __restrict__
                                                       float* __restrict__ g_loc, float* __restrict__ g_ls, float* __restrict__ g_V,
                                                       float* __restrict__ Vs, float* __restrict__ vmm_part,
                                                       int G, int S, int D, int K, int apply, float lr_t, float b1, float b2, float aeps, ca_small_args mon, int gblocks,
-                                                      ca_psi_args psi) {
+                                                      ca_psi_args psi, const float* __restrict__ gfold, int nfold) {
   if ((int)blockIdx.x >= gblocks) {
     int b = (int)blockIdx.x - gblocks;
     if (mon.enabled) {   // one extra block: the pending monitor pass's ELBO (ca_final_small_body), beside the gene blocks
@@ -2247,7 +2328,7 @@ __global__ void __launch_bounds__(CA_TB) k_final_gene(const double* __restrict__
   }
   __shared__ float smin[CA_TB], smax[CA_TB];
   ca_final_gene_body(red_g, red_y, eps, colsum, YtX, vchi, loc, ls, V, m_loc, v_loc, m_ls, v_ls, m_V, v_V, g_loc, g_ls, g_V, Vs, vmm_part, G, S, D, K,
-                     apply, lr_t, b1, b2, aeps, smin, smax);
+                     apply, lr_t, b1, b2, aeps, smin, smax, gfold, nfold);
 }
 
 // ------------------------------------------------------------------ ELBO assembly + the O(K + C) variables (body: ca_final_small_body above)

@@ -134,6 +134,7 @@ struct ca_engine {
   bool fused_ok = false, look_valid = false; int64_t look_slot = 0; int frow = 8;
   float *Mb2 = nullptr, *mu32B = nullptr, *Zpart2 = nullptr; double* gene_partB = nullptr;
   bool y_defer = false;
+  bool fold_gsum = false, fold_now = false;   // small problems: the backward sweep's partials are summed inside k_final_gene
   // per-gene prologue of the next fused pass, computed ahead by the train pass before it (ca_pre_args): the loops announce
   // the next (monitor, train) eps slots in hint_*, train_update fills the alternate partial buffers, fused_pass swaps them in
   int64_t hint_A = -1, hint_B = -1, pre_A = -1, pre_B = -1;
@@ -527,13 +528,15 @@ int ensure_ycache(ca_engine* h) {
     CACK(prof_end(h));
   }
   // YTpart is [nrb][Gp*K]: column sums over the row blocks (+ the overflow list's chunk sums per gene); ytpsi is laid
-  // out [Gp][K] (first G rows used)
-  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->Gp * h->K, 64)), dim3(1024), 0, h->stream,
-                                                h->YTpart, h->red + h->off_y, h->nrg, (int64_t)h->Gp * h->K, h->Gp * h->K,
-                                                h->n_ovf > 0 ? h->ovf_col_chunk_ptr : nullptr, h->n_ovf > 0 ? h->ovf_csum : nullptr, h->K, h->G));
-  // row side: YW = sum of the strips, and the psi.(YW) partials of the ELBO (the fused loop's cell epilogue leaves both to this)
-  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_yw_dot, dim3(h->n_yw), dim3(CA_TB), 0, h->stream, h->YWpart,
-                                                h->nseg + (h->n_ovf > 0 ? 1 : 0), h->F, h->D, h->K, h->N, h->YW, h->yw_part));
+  // out [Gp][K] (first G rows used).  Row side: YW = sum of the strips, and the psi.(YW) partials of the ELBO (the fused
+  // loop's cell epilogue leaves both to this).  One launch for both (k_yfinish = k_colsum's blocks + k_yw_dot's).
+  {
+    const int nb_col = cdiv((int64_t)h->Gp * h->K, 64);
+    LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_yfinish, dim3(nb_col + h->n_yw), dim3(1024), 0, h->stream, h->YTpart, h->red + h->off_y, h->nrg,
+                                                  (int64_t)h->Gp * h->K, h->Gp * h->K, h->n_ovf > 0 ? h->ovf_col_chunk_ptr : nullptr,
+                                                  h->n_ovf > 0 ? h->ovf_csum : nullptr, h->K, h->G, nb_col, h->YWpart,
+                                                  h->nseg + (h->n_ovf > 0 ? 1 : 0), h->F, h->D, h->N, h->YW, h->yw_part));
+  }
   h->ycache_valid = true;
   return CA_OK;
 }
@@ -771,11 +774,14 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
       else h->mon_tail.enabled = 0;
     }
     // (summing the sweep's partials inside k_final_gene instead -- one thread per gene, csplit_m loads in a row -- was
-    //  slower than this parallel launch: 2219 -> 2190 it/s)
-    LAUNCH(h, CA_KERNEL_OTHER,
-           hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->G * W_, 64)), dim3(1024), 0, h->stream, h->gpart,
-                              h->red + h->off_g, h->csplit_m, (int64_t)h->G * W_, h->G * W_));
+    //  slower than this parallel launch at 100k cells: 2219 -> 2190 it/s; small unsharded problems fold it: fold_gsum)
+    h->fold_now = h->fold_gsum && !is_sharded(h);
+    if (!h->fold_now)
+      LAUNCH(h, CA_KERNEL_OTHER,
+             hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->G * W_, 64)), dim3(1024), 0, h->stream, h->gpart,
+                                h->red + h->off_g, h->csplit_m, (int64_t)h->G * W_, h->G * W_));
   } else {
+    h->fold_now = false;
     CACK(flush_mon_tail(h));
     for (int s = 0; s < h->S; ++s)
       for (int ch = 0; ch < h->nchunk; ++ch) {
@@ -829,7 +835,9 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
          hipLaunchKernelGGL(k_final_gene, dim3(h->ngblk + (mon.enabled ? 1 : 0) + psi.nblk), dim3(CA_TB), 0, h->stream, h->red + h->off_g,
                             h->red + h->off_y, eps, h->colsum, h->YtX, h->vchi, h->loc, h->ls, h->V, h->m_loc, h->v_loc, h->m_ls,
                             h->v_ls, h->m_V, h->v_V, h->g_loc, h->g_ls, h->g_V, h->Vs, h->vmm_part, h->G, h->S, h->D, h->K, apply,
-                            lr_t, (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, mon, h->ngblk, psi));
+                            lr_t, (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, mon, h->ngblk, psi,
+                            h->fold_now ? h->gpart : nullptr, h->csplit_m));
+  h->fold_now = false;
   if (apply && h->async_y && h->K > 0) {
     // psi is final: the Y pass for the new parameters goes to the side stream from HERE (its launches are issued by the
     // next pass, so the main stream is not left waiting for the host to get through them), and the per-cell kernel below
@@ -972,6 +980,7 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
       }
     } else
     switch (h->fc_tl) {
+      case 1: CA_FCD(1); break;
       case 2: CA_FCD(2); break;
       case 4: CA_FCD(4); break;
       case 5: CA_FCD(5); break;
@@ -1490,6 +1499,8 @@ int create_impl(ca_engine* h, const ca_problem* p) {
       h->csplit_m = (int)std::max<int64_t>(h->csplit_m, (Nn * D + 4079) / 4080);   // LDS: 4 waves x cchunk x D floats <= 64 KB
       h->cchunk_m = ((Nn + h->csplit_m - 1) / h->csplit_m + 15) / 16 * 16;
       h->csplit_m = cdiv(Nn, h->cchunk_m);
+      // launches, not bandwidth, are what an iteration costs below ~32k cells: fold the column sums of the sweep's partials
+      h->fold_gsum = Nn <= 32768 && S + D <= 12 && h->tail_fuse && variant_on(h, CA_VAR_FOLD_GSUM, "CA_FOLD_GSUM");
       CACK(dalloc(h, &h->coefq, (int64_t)S * h->N16 * 32));
     }
   }
@@ -1544,8 +1555,10 @@ int create_impl(ca_engine* h, const ca_problem* p) {
       // 3459 / 3523; 100k: 2691 / 2594 / 2625); 128-cell blocks never won (200k: 1346 vs 1363, 400k: 609 vs 638 it/s).
       // Small shards: 32-cell blocks, or CUs are left with one block or none (25k: 7619 / 7443 / 6701 for TL = 2 / 4 / 6
       // without the second block size, 7535 for 6 with it).
+      // (16-cell blocks, fc_tl = 1, were tried for shards below 16k cells -- twice the waves per SIMD -- and lost: 12.5k cells
+      //  39 us against 35, every block re-reads the B operand)
       h->fc_tl = (h->fwd_cell && cdiv(Nn, 64) < 2 * h->n_cu) ? 2 : 6;
-      if (const int t = tune_val(h, CA_TUNE_FC_TL, "CA_FC_TL")) { if (t == 2 || t == 4 || t == 5 || t == 6 || t == 8) h->fc_tl = t; }
+      if (const int t = tune_val(h, CA_TUNE_FC_TL, "CA_FC_TL")) { if (t == 1 || t == 2 || t == 4 || t == 5 || t == 6 || t == 8) h->fc_tl = t; }
       h->ncblk_f = cdiv(Nn, 16 * h->fc_tl);
       // two block sizes in one launch (k_fwd_cell_mix)
       if (h->fwd_cell && (h->fc_tl == 4 || h->fc_tl == 5 || h->fc_tl == 6) && (D == 1 || D == 2)) {
