@@ -2497,3 +2497,15 @@ __global__ void __launch_bounds__(CA_TB) k_p2p_allreduce(double* __restrict__ bu
     buf[i] = s;
   }
 }
+
+// the one-copy stream with the gene side of the overflow list (per-chunk sums of the counts above 255, psi only) as extra blocks
+__global__ void __launch_bounds__(CA_YM_TB, CA_YS_WAVES) k_ys_mfma_ovf(const uint8_t* __restrict__ Ys, const uint4* __restrict__ Wr,
+                                                                       const uint4* __restrict__ Pr, int64_t N, int Gp, int RS,
+                                                                       int* __restrict__ YWi, int* __restrict__ YTi, int nb_main, ca_ovf_args ovf,
+                                                                       const float* __restrict__ F, int Df) {
+  if ((int)blockIdx.x >= nb_main) {
+    ca_ovf_chunks_body(blockIdx.x - nb_main, ovf.chunk_start, ovf.row2, ovf.val2, F, Df, ovf.csum, ovf.nchunk, 1, 0);
+    return;
+  }
+  ca_ys_mfma_body((int)blockIdx.x, Ys, Wr, Pr, N, Gp, RS, YWi, YTi);
+}

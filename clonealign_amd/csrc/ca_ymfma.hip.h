@@ -103,8 +103,8 @@ __device__ __forceinline__ int ca_digit(int x, int p) {
   return d;
 }
 // one thread per (step, lane) of an image; src [rows][ld], columns 0..K-1
-__device__ __forceinline__ uint4 ca_quant16(const float* __restrict__ src, int ld, int64_t rows, int K, int64_t step, int l, float sc) {
-  const int col = l & 15, k = col >> 2, p = col & 3;
+__device__ __forceinline__ uint4 ca_quant16(const float* __restrict__ src, int ld, int64_t rows, int K, int64_t step, int l, float sc, int rep = 0) {
+  const int col = l & 15, k = rep ? 0 : col >> 2, p = col & 3;   // rep: K = 1, the digits repeated in all four column groups
   unsigned w[4] = {0u, 0u, 0u, 0u};
   if (k < K) {
     const int64_t r0 = step * 64 + 16 * (l >> 4);
@@ -112,7 +112,7 @@ __device__ __forceinline__ uint4 ca_quant16(const float* __restrict__ src, int l
     for (int b = 0; b < 16; ++b) {
       const int64_t r = r0 + b;
       const float v = r < rows ? src[r * ld + k] : 0.f;
-      const int x = (int)rintf(v * sc);
+      const int x = (int)rintf(fminf(fmaxf(v * sc, -2147483000.f), 2147483000.f));
       w[b >> 2] |= ((unsigned)ca_digit(x, p) & 0xFFu) << (8 * (b & 3));
     }
   }
@@ -120,17 +120,33 @@ __device__ __forceinline__ uint4 ca_quant16(const float* __restrict__ src, int l
 }
 __global__ void __launch_bounds__(CA_YM_TB) k_ym_quant(const float* __restrict__ V, int Dv, int64_t G, int GS, const float* __restrict__ F,
                                                        int Df, int64_t N, int64_t NS, int K, const unsigned* __restrict__ amax,
-                                                       uint4* __restrict__ Wq, uint4* __restrict__ Pq) {
+                                                       uint4* __restrict__ Wq, uint4* __restrict__ Pq, int rep = 0) {
   const int64_t i = (int64_t)blockIdx.x * CA_YM_TB + threadIdx.x;
   const int l = (int)(i & 63);
   const int64_t st = i >> 6;
   if (st < GS) {
     const float sc = ldexpf(1.f, ca_fix_exp(__uint_as_float(amax[0])));
-    Wq[st * 64 + l] = ca_quant16(V, Dv, G, K, st, l, sc);
+    Wq[st * 64 + l] = ca_quant16(V, Dv, G, K, st, l, sc, rep);
   } else if (st < GS + NS) {
     const float sc = ldexpf(1.f, ca_fix_exp(__uint_as_float(amax[1])));
-    Pq[(st - GS) * 64 + l] = ca_quant16(F, Df, N, K, st - GS, l, sc);
+    Pq[(st - GS) * 64 + l] = ca_quant16(F, Df, N, K, st - GS, l, sc, rep);
   }
+}
+// row-major u8 [N][Gp] -> biased copy in 4-KiB pieces of 64 cells x 64 genes, [N64/64][Gp/64][64 rows][64 B] (rows past N:
+// count 0): a wave's load instruction then covers 1 KiB of consecutive addresses, like the row-major stream's, instead of
+// sixteen 64-byte pieces in sixteen DRAM pages (3.4 TB/s measured with the row-major copy).  One thread per 16 bytes.
+__global__ void __launch_bounds__(CA_YM_TB) k_bias_y(const uint8_t* __restrict__ Y, uint4* __restrict__ Ys, int64_t N, int64_t N64, int Gp) {
+  const int64_t i = (int64_t)blockIdx.x * CA_YM_TB + threadIdx.x;     // index of the 16-byte chunk in the DESTINATION
+  const int64_t per_piece = 256, nb = Gp / 64;
+  if (i >= (N64 / 64) * nb * per_piece) return;
+  const int c = (int)(i & 3), r = (int)((i >> 2) & 63);
+  const int64_t piece = i >> 8;
+  const int64_t cs = piece / nb, gb = piece - cs * nb;
+  const int64_t n = cs * 64 + r;
+  uint4 v = {0u, 0u, 0u, 0u};
+  if (n < N) v = *reinterpret_cast<const uint4*>(Y + n * (int64_t)Gp + gb * 64 + 16 * c);
+  v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
+  Ys[i] = v;
 }
 
 // ---------------------------------------------------------------- the two streams
@@ -282,4 +298,339 @@ template <int TL, int DEPTH>
 __global__ void __launch_bounds__(CA_YM_TB) k_yt_mfma_raw(const uint4* __restrict__ Yb, const uint4* __restrict__ Pq, int GT, int64_t NS,
                                                           int64_t schunk, int* __restrict__ out) {
   ca_yt_block<TL, DEPTH>(Yb, Pq, GT, NS, schunk, out);
+}
+
+// =====================================================================================================================
+// ONE copy, both products: the count matrix stays row-major (biased bytes, y ^ 0x80) and every 64-cell x 128-gene piece
+// goes through the wave's own LDS region once.  Read back row-wise (ds_read_b128) it is the A operand of the row
+// products; read back through gfx950's transposing LDS read (ds_read_b64_tr_b8: per 16-lane group a block of 8 rows x 16
+// bytes comes back column-major, lane 2q+p supplies the address of row q / bytes 8p..8p+7 and lane i receives column i --
+// measured, tools/trb8_lab.hip) it is the B operand of the column products.  Half the bytes of the two-copy form.  K = 1.
+//
+//   Ys   [N64/64][Gp/64][64][64 B]  biased bytes in 4-KiB pieces (64 cells x 64 genes, row-major inside), Gp a multiple of 512,
+//        rows past N and genes past G hold 0x80 (count 0)
+//   Wr   [Gp/64][64 lanes][16 B]  byte (l, b) = digit (l & 3) of fix(W[64 s + 16 (l >> 4) + b])   (every column group the same)
+//   Pr   [N64/64][64 lanes][16 B] byte (l, b) = digit (l & 3) of fix(psi[64 s + 16 (l >> 4) + b])
+// The digits are replicated over the four groups of four operand columns (rows) so that FOUR tiles share one accumulator:
+// tile t multiplies against the image masked down to group t, and its sums land in columns (rows) 4t .. 4t+3.
+//   YWi  [nseg][N][4]   int32 digit sums of a gene segment (512 genes), bias undone
+//   YTi  [nrg][Gp][4]   int32 digit sums of a row group (4 strips of RS cells), bias undone
+constexpr int CA_YS_GW = 512;      // genes per segment (block = one segment x four strips); the switch in k_ys_mfma assumes 8 x 64
+static_assert(CA_YS_GW == 512, "k_ys_mfma's accumulator switch has eight cases");
+constexpr int CA_YS_PITCH = 80;    // LDS row pitch of the 64-byte rows: 16 lanes of a ds_read_b128 group fall on 16 different bank quads
+
+// The eight transposed reads of a 64-gene block (four gene tiles x two halves of the 16 cells) and their wait in ONE asm
+// statement: the compiler treats an asm output as valid as soon as the statement ends, and would otherwise be free to copy a
+// result register (to line up the four VGPRs of an MFMA operand) before the data has arrived.
+__device__ __forceinline__ void ca_ds_read_tr_b8_x8(unsigned addr, uint2 (&lo)[4], uint2 (&hi)[4]) {
+  asm volatile(
+      "ds_read_b64_tr_b8 %0, %8\n\tds_read_b64_tr_b8 %4, %8 offset:640\n\t"
+      "ds_read_b64_tr_b8 %1, %8 offset:16\n\tds_read_b64_tr_b8 %5, %8 offset:656\n\t"
+      "ds_read_b64_tr_b8 %2, %8 offset:32\n\tds_read_b64_tr_b8 %6, %8 offset:672\n\t"
+      "ds_read_b64_tr_b8 %3, %8 offset:48\n\tds_read_b64_tr_b8 %7, %8 offset:688\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(lo[2]), "=&v"(lo[3]), "=&v"(hi[0]), "=&v"(hi[1]), "=&v"(hi[2]), "=&v"(hi[3])
+      : "v"(addr)
+      : "memory");
+}
+static_assert(8 * CA_YS_PITCH == 640, "offsets in ca_ds_read_tr_b8_x8 assume the 80-byte pitch");
+__device__ __forceinline__ uint4 ca_and4(uint4 a, unsigned m) { return (uint4){a.x & m, a.y & m, a.z & m, a.w & m}; }
+
+// The bias (stored byte = y - 128) is undone by the finisher: 128 x the digit sums of the parameter images, which the
+// quantiser leaves per 64-step (Wsum[Gp/64][4], Psum[N64/64][4]) -- no all-ones MFMA and no accumulator for it here.
+// DEPTH pieces (4 KiB each: 64 cells x 64 genes) and their W digits are in flight per wave; the piece loop is unrolled by
+// DEPTH only (fully unrolled, the scheduler hoists every piece's loads and spills).
+#ifndef CA_YS_DEPTH
+#define CA_YS_DEPTH 2   // measured at 100k x 5k: depth 2 / 3 waves 92 us, depth 4 / 2 waves 95, depth 1 / 4 waves 104 (5.5 TB/s stored)
+#endif
+#ifndef CA_YS_WAVES
+#define CA_YS_WAVES 3   // waves per SIMD the register budget is set for
+#endif
+__device__ __forceinline__ void ca_ys_mfma_body(int blk, const uint8_t* __restrict__ Ys, const uint4* __restrict__ Wr,
+                                                const uint4* __restrict__ Pr, int64_t N, int Gp,
+                                                int RS /* cells per strip, multiple of 64 */, int* __restrict__ YWi,
+                                                int* __restrict__ YTi) {
+  constexpr int DEPTH = CA_YS_DEPTH, NP = CA_YS_GW / 64;
+  static_assert(NP % DEPTH == 0, "pieces per cell step must be a multiple of the pipeline depth");
+  extern __shared__ __attribute__((aligned(16))) unsigned char ca_ys_lds[];   // [4 waves][64][CA_YS_PITCH], reused for the combine
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+  const int nseg = Gp / CA_YS_GW;
+  const int rg = blk / nseg, seg = blk - rg * nseg;
+  unsigned char* my = ca_ys_lds + (size_t)wv * 64 * CA_YS_PITCH;
+  const int64_t c0 = ((int64_t)rg * 4 + wv) * RS;             // first cell of this wave's strip
+  const int64_t c1 = (c0 + RS < N) ? c0 + RS : N;             // (rows up to the next multiple of 64 exist and hold zeros)
+  const int g0 = seg * CA_YS_GW;
+  const unsigned grp = (unsigned)(j >> 2);
+  unsigned msk[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) msk[t] = grp == (unsigned)t ? 0xFFFFFFFFu : 0u;
+  ca_i32x4 acc_yt[NP];
+#pragma unroll
+  for (int a = 0; a < NP; ++a) acc_yt[a] = (ca_i32x4){0, 0, 0, 0};
+  // staging: load instruction i of a piece covers rows 16 i .. 16 i + 15, 64 bytes each
+  const int lrow = lane >> 2, lch = lane & 3;
+  unsigned char* wr_dst = my + lrow * CA_YS_PITCH + 16 * lch;
+  const unsigned char* rd_row = my + j * CA_YS_PITCH + 16 * q;
+  const unsigned rd_tr = (unsigned)(size_t)my + (unsigned)((16 * q + (j >> 1)) * CA_YS_PITCH + 8 * (j & 1));
+  const uint8_t* src = Ys + ((c0 >> 6) * (int64_t)(Gp / 64) + (g0 >> 6)) * 4096 + 16 * lane;   // piece (cell step, gene block), 1 KiB per load
+  const uint4* wsrc = Wr + (int64_t)(g0 >> 6) * 64 + lane;
+  uint4 R[DEPTH][4], W[DEPTH];
+  // piece number k of the strip: cell step k / NP, gene block k % NP
+  const int64_t npieces = c0 < c1 ? ((c1 - c0 + 63) / 64) * NP : 0;
+  auto issue = [&](int slot, int64_t k) {
+    const uint8_t* p = src + ((k / NP) * (int64_t)(Gp / 64) + (k % NP)) * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) R[slot][i] = ca_ld_stream(reinterpret_cast<const uint4*>(p + 1024 * i));
+    W[slot] = wsrc[(k % NP) * 64];
+  };
+#pragma unroll
+  for (int d_ = 0; d_ < DEPTH; ++d_)
+    if (d_ < npieces) issue(d_, d_);
+  ca_i32x4 acc_yw = {0, 0, 0, 0};
+  uint4 pr = {0u, 0u, 0u, 0u};
+  for (int64_t k0 = 0; k0 < npieces; k0 += DEPTH) {
+    const int gb0 = (int)(k0 % NP);
+    const int64_t cs = c0 + (k0 / NP) * 64;
+    if (gb0 == 0) {   // (wave-uniform) a new cell step
+      acc_yw = (ca_i32x4){0, 0, 0, 0};
+      pr = Pr[(cs >> 6) * 64 + lane];
+    }
+    ca_i32x4 dd[DEPTH];
+#pragma unroll
+    for (int d_ = 0; d_ < DEPTH; ++d_) {
+      // the piece is in R[d_]: park it in LDS, start the loads of the piece DEPTH further on, then feed the matrix core
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(wr_dst + 16 * i * CA_YS_PITCH) = R[d_][i];
+      const uint4 wr = W[d_];
+      if (k0 + d_ + DEPTH < npieces) issue(d_, k0 + d_ + DEPTH);
+      // row products: the four cell tiles against this 64-gene block, one accumulator (tile t -> columns 4t .. 4t+3)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const uint4 a = *reinterpret_cast<const uint4*>(rd_row + 16 * t * CA_YS_PITCH);
+        acc_yw = ca_mfma_i8(a, ca_and4(wr, msk[t]), acc_yw);
+      }
+      // column products: the four gene tiles of the block against the 64 cells, one accumulator (tile t -> rows 4t .. 4t+3)
+      ca_i32x4 d = {0, 0, 0, 0};
+      {
+        uint2 lo[4], hi[4];
+        ca_ds_read_tr_b8_x8(rd_tr, lo, hi);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) d = ca_mfma_i8(ca_and4(pr, msk[t]), (uint4){lo[t].x, lo[t].y, hi[t].x, hi[t].y}, d);
+      }
+      dd[d_] = d;
+    }
+    // which accumulators the DEPTH pieces belong to depends on the (dynamic) block index only through this switch
+#define CA_YS_ADD(B)                                                       \
+  case B:                                                                  \
+    _Pragma("unroll") for (int d_ = 0; d_ < DEPTH; ++d_) acc_yt[B + d_] += dd[d_]; \
+    break;
+    switch (gb0) {
+      CA_YS_ADD(0)
+#if CA_YS_DEPTH <= 4
+      CA_YS_ADD(4)
+#endif
+#if CA_YS_DEPTH <= 2
+      CA_YS_ADD(2) CA_YS_ADD(6)
+#endif
+#if CA_YS_DEPTH == 1
+      CA_YS_ADD(1) CA_YS_ADD(3) CA_YS_ADD(5) CA_YS_ADD(7)
+#endif
+      default: break;
+    }
+#undef CA_YS_ADD
+    if (gb0 + DEPTH == NP) {   // (uniform) the cell step is complete: lane (column 4t + p, q) holds cells 16 t + 4 q + r, digit p
+      const int t = j >> 2, p = j & 3;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t n = cs + 16 * t + 4 * q + r;
+        if (n < N) YWi[((int64_t)seg * N + n) * 4 + p] = acc_yw[r];
+      }
+    }
+  }
+  // column products of the strip: lane (gene n = j, q), accumulator a: gene tile 4 a + q, digits r = 0..3; combine the four
+  // strips of the block in LDS (integer sums: any order), one row of YTi per block
+  __syncthreads();
+  int* comb = reinterpret_cast<int*>(ca_ys_lds);   // [4 waves][8 acc][64 lanes][4]: 32 KB > the 20 KB of tiles: the launch asks for 32 KB
+#pragma unroll
+  for (int a = 0; a < NP; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) comb[((wv * NP + a) * 64 + lane) * 4 + r] = acc_yt[a][r];
+  __syncthreads();
+  for (int i = threadIdx.x; i < NP * 64 * 4; i += CA_YM_TB) {
+    const int r = i & 3, l = (i >> 2) & 63, a = i >> 8;
+    const int v = (comb[i] + comb[i + NP * 256]) + (comb[i + 2 * NP * 256] + comb[i + 3 * NP * 256]);
+    const int gene = g0 + 16 * (4 * a + (l >> 4)) + (l & 15);
+    YTi[((int64_t)rg * Gp + gene) * 4 + r] = v;
+  }
+}
+__global__ void __launch_bounds__(CA_YM_TB, CA_YS_WAVES) k_ys_mfma(const uint8_t* __restrict__ Ys, const uint4* __restrict__ Wr,
+                                                                   const uint4* __restrict__ Pr, int64_t N, int Gp, int RS,
+                                                                   int* __restrict__ YWi, int* __restrict__ YTi) {
+  ca_ys_mfma_body((int)blockIdx.x, Ys, Wr, Pr, N, Gp, RS, YWi, YTi);
+}
+constexpr int CA_YS_LDS_BYTES = 4 * (CA_YS_GW / 64) * 64 * 4 * 4;   // the combine buffer (32 KB) >= 4 x 64 x CA_YS_PITCH
+
+// per-step digit sums of a replicated image (for the bias): sums[step][p] = sum over the step's 64 entries of digit p
+__global__ void __launch_bounds__(CA_YM_TB) k_ym_digit_sums(const uint4* __restrict__ img, int64_t steps, int* __restrict__ sums) {
+  const int64_t i = (int64_t)blockIdx.x * CA_YM_TB + threadIdx.x;
+  const int l = (int)(i & 63);
+  const int64_t st = i >> 6;
+  int s = 0;
+  if (st < steps) {
+    const uint4 v = img[st * 64 + l];
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) s += (int)(signed char)((w[d] >> (8 * b)) & 0xFFu);
+  }
+  // lanes (col j = p, q = 0..3) hold digit p: sum over q
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  if (st < steps && l < 4) sums[st * 4 + l] = s;
+}
+
+// Parameter images of the one-copy stream, one launch per parameter state.  lag = 0: the fixed-point exponents come from the
+// exact maxima in amax_in (k_ym_absmax ran before).  lag = 1: amax_in holds the exact maxima of the PREVIOUS state and
+// `slack` bounds what one Adam step can add to any magnitude (TF1 Adam: |step| <= lr_t (1 - b1) / sqrt((1 - b2)(1 - b1^2 / b2)),
+// Cauchy-Schwarz on the two moving averages), so 2^e (max + slack) < 2^30 holds without a second pass.  Either way the
+// kernel leaves the exact maxima of THIS state in amax_out (atomicMax of float bit patterns: order-independent), clears
+// amax_clear for the state after, and writes the exponents it used to exps[2] for the finisher.  Digit sums per 64-step go
+// to Wsum / Psum (the bias of the stored bytes).  K = 1.
+__global__ void __launch_bounds__(CA_YM_TB) k_ys_quant(const float* __restrict__ V, int Dv, int64_t G, int GS, const float* __restrict__ F,
+                                                       int Df, int64_t N, int64_t NS, const unsigned* __restrict__ amax_in, float slack_w,
+                                                       float slack_p, unsigned* __restrict__ amax_out, unsigned* __restrict__ amax_clear,
+                                                       int* __restrict__ exps, uint4* __restrict__ Wr, uint4* __restrict__ Pr,
+                                                       int* __restrict__ Wsum, int* __restrict__ Psum) {
+  const int64_t i = (int64_t)blockIdx.x * CA_YM_TB + threadIdx.x;
+  const int l = (int)(i & 63);
+  const int64_t st = i >> 6;
+  const int ew = ca_fix_exp(__uint_as_float(amax_in[0]) + slack_w), ep = ca_fix_exp(__uint_as_float(amax_in[1]) + slack_p);
+  if (i == 0) { exps[0] = ew; exps[1] = ep; amax_clear[0] = 0u; amax_clear[1] = 0u; }
+  if (st >= GS + NS) return;   // (whole waves: 64 lanes per step)
+  const bool isw = st < GS;
+  const float* src = isw ? V : F;
+  const int ld = isw ? Dv : Df;
+  const int64_t rows = isw ? G : N, step = isw ? st : st - GS;
+  const float sc = ldexpf(1.f, isw ? ew : ep);
+  const uint4 v = ca_quant16(src, ld, rows, 1, step, l, sc, 1);
+  (isw ? Wr : Pr)[step * 64 + l] = v;
+  // digit sums of the step (lanes with column p = l & 3 < 4 in the first group hold digit p for the 16 entries of group q)
+  int sd = 0;
+  {
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) sd += (int)(signed char)((w[d] >> (8 * b)) & 0xFFu);
+  }
+  sd += __shfl_xor(sd, 16, 64);
+  sd += __shfl_xor(sd, 32, 64);
+  if (l < 4) (isw ? Wsum : Psum)[step * 4 + l] = sd;
+  // exact maxima of this state for the next one's bound: lane (0, q) covers the step's entries 16 q .. 16 q + 15
+  float m = 0.f;
+  if ((l & 15) == 0) {
+    const int64_t r0 = step * 64 + 16 * (l >> 4);
+    for (int b = 0; b < 16; ++b) if (r0 + b < rows) m = fmaxf(m, fabsf(src[(r0 + b) * ld]));
+  }
+  m = fmaxf(m, __shfl_xor(m, 16, 64));
+  m = fmaxf(m, __shfl_xor(m, 32, 64));
+  if (l == 0) atomicMax(amax_out + (isw ? 0 : 1), __float_as_uint(m));
+}
+
+// Finisher of the one-copy stream, one launch: blocks [0, nb_col) turn the row groups' digit sums into Y^T psi (red_y), the
+// blocks after turn the gene segments' digit sums into YW (float) and the block's share of sum_n psi_n . (YW)_n.  Integer sums
+// over slices (exact, any order), the bias 128 x (digit sums of the parameter image) added, digits combined in fp64, the
+// fixed-point scale taken out, the overflow list's entries (counts above 255) added in fp64.
+__global__ void __launch_bounds__(CA_YM_TB) k_ys_finish(const int* __restrict__ YTi, int nrg, int Gp, int G, const int* __restrict__ Psum,
+                                                        int64_t NS, const int* __restrict__ exps, const int* __restrict__ col_chunk_ptr,
+                                                        const float* __restrict__ csum, double* __restrict__ red_y, int nb_col,
+                                                        const int* __restrict__ YWi, int nseg, int64_t N, const int* __restrict__ Wsum, int GS,
+                                                        const float* __restrict__ F, int Df, const float* __restrict__ V, int Dv,
+                                                        const int64_t* __restrict__ ovf_rowptr, const int* __restrict__ ovf_col,
+                                                        const float* __restrict__ ovf_val, float* __restrict__ YW, double* __restrict__ yw_part) {
+  __shared__ long long tot[4];
+  __shared__ double smr[CA_YM_TB / 64];
+  const bool colside = (int)blockIdx.x < nb_col;
+  {   // digit totals of the OTHER operand's image: every block needs them (a few thousand ints, L2-resident)
+    const int* sums = colside ? Psum : Wsum;
+    const int64_t steps = colside ? NS : (int64_t)GS;
+    const int p = threadIdx.x & 3;
+    long long a = 0;
+    for (int64_t st = threadIdx.x >> 2; st < steps; st += CA_YM_TB / 4) a += sums[st * 4 + p];
+#pragma unroll
+    for (int o = 4; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
+    __shared__ long long part[CA_YM_TB / 64][4];
+    if ((threadIdx.x & 63) < 4) part[threadIdx.x >> 6][p] = a;
+    __syncthreads();
+    if (threadIdx.x < 4) tot[threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
+    __syncthreads();
+  }
+  if (colside) {   // block = 16 genes x 16 row lanes: the nrg slices of a gene are read by 16 lanes, four loads in flight each
+    __shared__ long long cs_[16][16][4];
+    const int gx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int g = blockIdx.x * 16 + gx;
+    long long s[4] = {0, 0, 0, 0};
+    if (g < G) {
+      int r = ty;
+      for (; r + 48 < nrg; r += 64) {
+        int4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const int4*>(YTi + ((int64_t)(r + 16 * u) * Gp + g) * 4);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w; }
+      }
+      for (; r < nrg; r += 16) {
+        const int4 v = *reinterpret_cast<const int4*>(YTi + ((int64_t)r * Gp + g) * 4);
+        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < 4; ++p) cs_[ty][gx][p] = s[p];
+    __syncthreads();
+    if (ty != 0 || g >= G) return;
+    for (int t = 1; t < 16; ++t)
+#pragma unroll
+      for (int p = 0; p < 4; ++p) s[p] += cs_[t][gx][p];
+    double v = 0.0;
+#pragma unroll
+    for (int p = 3; p >= 0; --p) v = v * 256.0 + (double)(s[p] + 128 * tot[p]);
+    v *= ldexp(1.0, -exps[1]);
+    if (csum)
+      for (int ch = col_chunk_ptr[g]; ch < col_chunk_ptr[g + 1]; ++ch) v += (double)csum[ch];
+    red_y[g] = v;
+    return;
+  }
+  const int blk = (int)blockIdx.x - nb_col;
+  const int64_t n = (int64_t)blk * CA_YM_TB + threadIdx.x;
+  double a = 0.0;
+  if (n < N) {
+    long long s[4] = {0, 0, 0, 0};
+    int sg = 0;
+    for (; sg + 3 < nseg; sg += 4) {   // four loads in flight
+      int4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const int4*>(YWi + ((int64_t)(sg + u) * N + n) * 4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w; }
+    }
+    for (; sg < nseg; ++sg) {
+      const int4 v = *reinterpret_cast<const int4*>(YWi + ((int64_t)sg * N + n) * 4);
+      s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
+    }
+    double v = 0.0;
+#pragma unroll
+    for (int p = 3; p >= 0; --p) v = v * 256.0 + (double)(s[p] + 128 * tot[p]);
+    v *= ldexp(1.0, -exps[0]);
+    if (ovf_rowptr)
+      for (int64_t e = ovf_rowptr[n]; e < ovf_rowptr[n + 1]; ++e) v += (double)ovf_val[e] * (double)V[(int64_t)ovf_col[e] * Dv];
+    const float vf = (float)v;
+    YW[n] = vf;
+    a = (double)F[n * Df] * (double)vf;
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
+  if ((threadIdx.x & 63) == 0) smr[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) yw_part[blk] = (smr[0] + smr[1]) + (smr[2] + smr[3]);
 }

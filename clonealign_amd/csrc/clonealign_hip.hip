@@ -158,6 +158,10 @@ struct ca_engine {
   int64_t ym_NT = 0, ym_NS = 0, ym_schunk = 0; int ym_GS = 0, ym_GT = 0, ym_csplit = 1, ym_tl = 4;
   uint4 *Yf = nullptr, *Yb = nullptr, *Wq = nullptr, *Pq = nullptr; unsigned* ym_amax = nullptr; int* ym_out = nullptr;
   hipEvent_t ev_ywdone = nullptr; bool yw_pending = false, on_side = false;
+  // ... and from ONE tiled copy through the transposing LDS read (k_ys_mfma; K = 1)
+  bool y_ys = false; uint8_t* Ys = nullptr; uint4 *Wr = nullptr, *Pr = nullptr; int *Wsum = nullptr, *Psum = nullptr, *YWi = nullptr, *YTi = nullptr;
+  int* ys_exps = nullptr; unsigned* ys_amax = nullptr;   // [3][2] each: rotating slots, see k_ys_quant
+  int ys_slot = 0, ys_steps = -1, ys_RS = 256, ys_nrg = 0, ys_nseg = 0; int64_t ys_N64 = 0; float ys_step_bound = -1.f;
   // one-shot peer-to-peer all-reduce (ca_p2p_export / ca_p2p_connect)
   ca_p2p* p2p = nullptr;
   // ---- comm
@@ -435,6 +439,7 @@ int refresh_derived(ca_engine* h) {
   CACK(wait_y(h, true));
   h->y_defer = false;   // a deferred side-stream Y pass would not be ordered after this parameter change: redo it in line
   h->pre_valid = false;
+  h->ys_steps = -1;     // arbitrary parameter change: the fixed-point exponents are taken from exact maxima again
   if (h->D > 0) {
     LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_vprep, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->V, h->Vs, h->vmm_part, h->G, h->D));
     LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_vmm_final, dim3(1), dim3(64), 0, h->stream, h->vmm_part, h->vmm, h->ngblk, h->D));
@@ -484,6 +489,47 @@ int ycache_mfma(ca_engine* h) {
   return CA_OK;
 }
 
+// Both products from ONE tiled copy through the transposing LDS read (k_ys_mfma): a quantiser launch (fixed-point images of W and
+// psi; exact maxima by a separate pass only for the first state after a reset, afterwards bounded from the previous state's),
+// the stream, the finisher.  Three launches, like the VALU stream's.
+int ycache_ys(ca_engine* h) {
+  const int GS = h->Gp / 64;
+  const int64_t NS = h->ys_N64 / 64;
+  const int s0 = h->ys_slot, s1 = (s0 + 1) % 3, s2 = (s0 + 2) % 3;
+  float slack = 0.f;
+  if (h->ys_steps < 0 || h->ys_steps > 4 || h->ys_step_bound <= 0.f) {
+    HIPCK(h, hipMemsetAsync(h->ys_amax, 0, 6 * sizeof(unsigned), h->stream));
+    LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_ym_absmax, dim3(cdiv(std::max<int64_t>(h->N, h->G), CA_YM_TB)), dim3(CA_YM_TB), 0, h->stream,
+                                                  h->V, h->D, (int64_t)h->G, h->F, h->D, h->N, 1, h->ys_amax + 2 * s0));
+  } else {
+    slack = (float)h->ys_steps * h->ys_step_bound;
+  }
+  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_ys_quant, dim3(cdiv((GS + NS) * 64, CA_YM_TB)), dim3(CA_YM_TB), 0, h->stream, h->V, h->D,
+                                                (int64_t)h->G, GS, h->F, h->D, h->N, NS, h->ys_amax + 2 * s0, slack, slack, h->ys_amax + 2 * s1,
+                                                h->ys_amax + 2 * s2, h->ys_exps + 2 * s0, h->Wr, h->Pr, h->Wsum, h->Psum));
+  const int nb_main = h->ys_nrg * h->ys_nseg;
+  if (h->n_ovf > 0) {
+    ca_ovf_args ovf;
+    memset(&ovf, 0, sizeof(ovf));
+    ovf.chunk_start = h->ovf_chunk_start; ovf.row2 = h->ovf_row2; ovf.val2 = h->ovf_val2; ovf.csum = h->ovf_csum; ovf.nchunk = h->n_ovf_chunk;
+    LAUNCH(h, CA_KERNEL_YPASS, hipLaunchKernelGGL(k_ys_mfma_ovf, dim3(nb_main + cdiv(h->n_ovf_chunk, CA_TB / 64)), dim3(CA_YM_TB), CA_YS_LDS_BYTES,
+                                                  h->stream, h->Ys, h->Wr, h->Pr, h->N, h->Gp, h->ys_RS, h->YWi, h->YTi, nb_main, ovf, h->F, h->D));
+  } else {
+    LAUNCH(h, CA_KERNEL_YPASS, hipLaunchKernelGGL(k_ys_mfma, dim3(nb_main), dim3(CA_YM_TB), CA_YS_LDS_BYTES, h->stream, h->Ys, h->Wr, h->Pr, h->N,
+                                                  h->Gp, h->ys_RS, h->YWi, h->YTi));
+  }
+  const int nb_col = cdiv(h->G, 16);
+  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_ys_finish, dim3(nb_col + h->n_yw), dim3(CA_YM_TB), 0, h->stream, h->YTi, h->ys_nrg, h->Gp, h->G,
+                                                h->Psum, NS, h->ys_exps + 2 * s0, h->n_ovf > 0 ? h->ovf_col_chunk_ptr : nullptr,
+                                                h->n_ovf > 0 ? h->ovf_csum : nullptr, h->red + h->off_y, nb_col, h->YWi, h->ys_nseg, h->N, h->Wsum, GS,
+                                                h->F, h->D, h->V, h->D, h->n_ovf > 0 ? h->ovf_rowptr : nullptr, h->ovf_col, h->ovf_val, h->YW,
+                                                h->yw_part));
+  h->ys_slot = s1;
+  h->ys_steps = 0;
+  h->ycache_valid = true;
+  return CA_OK;
+}
+
 // Y.W and Y^T.psi for the current parameters (once per parameter state)
 int ensure_ycache(ca_engine* h) {
   if (h->y_defer) {   // deferred side-stream start (train_tail): ordered after the parameter update by ev_params
@@ -504,6 +550,7 @@ int ensure_ycache(ca_engine* h) {
     return CA_OK;
   }
   if (h->ycache_valid || h->K == 0) { h->ycache_valid = true; return CA_OK; }
+  if (h->y_ys) return ycache_ys(h);
   if (h->y_mfma) return ycache_mfma(h);
   dim3 grid((unsigned)((int64_t)h->nrg * h->nseg));
   // entries above 255: one extra "segment" of YW and one extra term of Y^T psi; their per-entry work rides on the
@@ -865,6 +912,7 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
   if (pre.nblk) { h->pre_valid = true; h->pre_A = h->hint_A; h->pre_B = h->hint_B; }
   h->hint_A = h->hint_B = -1;
   if (apply) {
+    if (h->ys_steps >= 0) h->ys_steps += 1;
     h->b1p *= (float)h->opt.beta1;
     h->b2p *= (float)h->opt.beta2;
     h->ycache_valid = false;   // V', its range and etamax2 were refreshed inside the step's own kernels
@@ -902,8 +950,9 @@ int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_d
     }
   CACK(wait_y(h, true));   // the cell epilogue is the first consumer of YW / Y^T psi
   // (matrix-core products arrive as finished row sums: one "strip", already in YW)
-  const float* ywp = h->y_mfma ? h->YW : h->YWpart;
-  const int ywseg = h->y_mfma ? 1 : h->nseg + (h->n_ovf > 0 ? 1 : 0);
+  const bool yw_done = h->y_mfma || h->y_ys;
+  const float* ywp = yw_done ? h->YW : h->YWpart;
+  const int ywseg = yw_done ? 1 : h->nseg + (h->n_ovf > 0 ? 1 : 0);
   if (h->C <= 64) {
     int CP = 1;
     while (CP < h->C) CP <<= 1;
@@ -1652,6 +1701,41 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     h->y_mfma = true;
     h->y_dev_bytes += (h->ym_NT * h->ym_GS + (int64_t)h->ym_GT * h->ym_NS) * 1024;
   }
+  // ---- both products from ONE tiled copy (k_ys_mfma): K = 1, 1-byte storage
+  if (h->ystore == CA_YSTORE_U8 && K == 1 && variantx_on(h, CA_VARX_Y_MFMA1, "CA_Y_MFMA1")) {
+    h->ys_N64 = (Nn + 63) / 64 * 64;
+    h->ys_nseg = h->Gp / CA_YS_GW;                  // Gp is a multiple of 1024
+    // strips of RS cells per wave: about one resident round of blocks (3 per CU), at least 64 cells
+    h->ys_RS = 64;
+    while (h->ys_RS < 512 && cdiv(Nn, 4 * h->ys_RS) * h->ys_nseg > 4 * h->n_cu) h->ys_RS *= 2;
+    h->ys_nrg = cdiv(Nn, 4 * h->ys_RS);
+    CACK(dalloc(h, &h->Ys, h->ys_N64 * h->Gp));
+    uint8_t *wr = nullptr, *pr = nullptr;
+    CACK(dalloc(h, &wr, (int64_t)(h->Gp / 64) * 1024));
+    CACK(dalloc(h, &pr, (h->ys_N64 / 64) * 1024));
+    h->Wr = (uint4*)wr; h->Pr = (uint4*)pr;
+    CACK(dalloc(h, &h->Wsum, (int64_t)(h->Gp / 64) * 4));
+    CACK(dalloc(h, &h->Psum, (h->ys_N64 / 64) * 4));
+    CACK(dalloc(h, &h->YWi, (int64_t)h->ys_nseg * Nn * 4));
+    CACK(dalloc(h, &h->YTi, (int64_t)h->ys_nrg * h->Gp * 4));
+    CACK(dalloc(h, &h->ys_exps, 6));
+    CACK(dalloc(h, &h->ys_amax, 6));
+    hipLaunchKernelGGL(k_bias_y, dim3(cdiv(h->ys_N64 * (h->Gp / 16), CA_YM_TB)), dim3(CA_YM_TB), 0, h->stream, (const uint8_t*)h->Y, (uint4*)h->Ys, Nn,
+                       h->ys_N64, h->Gp);
+    HIPCK(h, hipGetLastError());
+    {
+      // what ONE TF1-Adam step can add to a magnitude: lr_t |m| / sqrt(v) <= lr_t (1 - b1) / sqrt((1 - b2)(1 - b1^2 / b2)) (Cauchy-
+      // Schwarz on the two moving averages), lr_t = lr sqrt(1 - b2^t) / (1 - b1^t) maximised over t
+      const double b1 = h->opt.beta1, b2 = h->opt.beta2, lr = h->opt.learning_rate;
+      if (b1 >= 0 && b2 > 0 && b1 * b1 < b2 && b2 < 1 && lr > 0) {
+        double sup = 0.0, p1 = 1.0, p2 = 1.0;
+        for (int t = 1; t <= 200000; ++t) { p1 *= b1; p2 *= b2; sup = std::max(sup, std::sqrt(1.0 - p2) / (1.0 - p1)); }
+        h->ys_step_bound = (float)(1.02 * lr * sup * (1.0 - b1) / std::sqrt((1.0 - b2) * (1.0 - b1 * b1 / b2)));
+      }
+    }
+    h->y_ys = true;
+    h->y_dev_bytes += h->ys_N64 * h->Gp;
+  }
   h->off_g = 3 + C;
   h->off_y = h->off_g + (int64_t)G * (S + D);
   h->red_n = h->off_y + (int64_t)G * K;
@@ -1918,7 +2002,7 @@ int ca_get_info(ca_handle h, ca_info* i) {
   i->y_storage = h->ystore; i->y_bytes_per_elem = h->ybytes; i->y_device_bytes = h->y_dev_bytes; i->device_bytes = h->dev_bytes;
   i->gsplit = h->gsplit; i->csplit = h->csplit; i->n_cu = h->n_cu; i->fused_sweep = h->fused_ok ? 1 : 0;
   i->fwd_mfma = (h->fused_ok && h->fwd_mfma) ? 1 : 0; i->bwd_mfma = h->bwd_mfma ? 1 : 0; i->fsplit = h->fsplit; i->fwd_cell = (h->fused_ok && h->fwd_cell) ? 1 : 0;
-  i->y_mfma = h->y_mfma ? 1 : 0;
+  i->y_mfma = h->y_ys ? 2 : h->y_mfma ? 1 : 0;
   i->transport = (h->p2p && h->p2p->connected) ? CA_TRANSPORT_P2P : h->comm ? CA_TRANSPORT_RCCL : h->host_ar ? CA_TRANSPORT_HOST : CA_TRANSPORT_NONE;
   i->red_n = h->red_n;
   return CA_OK;

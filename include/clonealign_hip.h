@@ -96,6 +96,8 @@ enum ca_variant_on {
   CA_VARX_Y_MFMA2 = 1 << 0,   /* count-matrix products on the int8 matrix cores from TWO tiled copies (cell-tiled for Y.W,
                                  gene-tiled for Y^T.psi; ca_ymfma.hip.h): 6.0 TB/s per stream against 4.7 for k_ypass, but twice
                                  the bytes per iteration */
+  CA_VARX_Y_MFMA1 = 1 << 2,   /* both count-matrix products on the int8 matrix cores from ONE tiled copy, the column products through
+                                 the transposing LDS read ds_read_b64_tr_b8 (k_ys_mfma; K = 1) */
   CA_VARX_ASYNC_SMALL = 1 << 1 /* side stream also below 4e7 counts (small shards run the Y stream in line: the two cross-stream
                                  events cost more than the overlap returns there) */
 };
@@ -136,7 +138,7 @@ typedef struct ca_info {
   int32_t bwd_mfma;          /* 1: the backward sweep's t = coef.L contraction runs on the matrix cores (k_bwd_mfma) */
   int32_t fsplit;            /* gene slices of the matrix-core forward sweep */
   int32_t fwd_cell;          /* 1: forward sweep and cell epilogue of the fused pass are ONE kernel (k_fwd_cell) */
-  int32_t y_mfma;            /* 1: the loop's count-matrix products run on the int8 matrix cores (k_yw_mfma / k_yt_mfma, opt-in) */
+  int32_t y_mfma;            /* the loop's count-matrix products on the int8 matrix cores: 0 no (k_ypass), 1 two tiled copies, 2 one */
   int32_t transport;         /* 0 none, 1 RCCL all-reduce, 2 host callback, 3 one-shot peer-to-peer (ca_transport) */
   int32_t reserved[1];
   int64_t red_n;             /* doubles all-reduced per train pass (= sharding.reduce_plan(...)["total"]) */

@@ -433,22 +433,26 @@ def test_final_elbos_from_pair_sweeps_equal_single_passes(shape):
         eng.close()
 
 
+@pytest.mark.parametrize("variant", ["y_mfma2", "y_mfma1"])
 @pytest.mark.parametrize("shape", [dict(N=1000, G=333, C=4, K=1), dict(N=777, G=130, C=3, K=2), dict(N=2100, G=1500, C=6, K=1, P=1),
-                                   dict(N=70, G=40, C=2, K=4)])
-def test_count_matrix_products_on_the_int8_matrix_cores(shape):
+                                   dict(N=70, G=40, C=2, K=4), dict(N=4133, G=1030, C=8, K=1)])
+def test_count_matrix_products_on_the_int8_matrix_cores(shape, variant):
     """Y.W and Y^T.psi of the loop from the tiled int8 copies (k_yw_mfma / k_yt_mfma: fixed-point parameters in four
-    base-256 digits, exact integer accumulation; the opt-in variant "y_mfma2") against the VALU stream (k_ypass) and the oracle:
-    ragged N and G (padding tiles), K up to 4, counts above 255 (overflow list next to the 1-byte copies), call by call and
-    through the fused loop."""
+    base-256 digits, exact integer accumulation; the opt-in variant "y_mfma2"), or both from ONE tiled copy whose column form
+    comes out of the transposing LDS read (k_ys_mfma, "y_mfma1", K = 1; its fixed-point exponents are bounded from the previous
+    state's maxima inside the loop), against the VALU stream (k_ypass) and the oracle: ragged N and G (padding tiles), K up to
+    4, counts above 255 (overflow list next to the 1-byte copies), call by call and through the fused loop."""
     from clonealign_amd.engine import HipEngine
     from oracle.fused_numpy import FusedModel
     case = make_case(seed=41, **shape)
     rng = np.random.default_rng(9)
     idx = rng.integers(0, case["Y"].size, size=max(3, case["Y"].size // 2000))
     case["Y"].reshape(-1)[idx] += rng.integers(200, 3000, size=idx.size)          # overflow-list entries
-    mf, va, ora = HipEngine(**case, variant_on=("y_mfma2",)), HipEngine(**case), FusedModel(**case, dtype="float32")
+    if variant == "y_mfma1" and shape["K"] != 1:
+        pytest.skip("the one-copy stream is built for K = 1")
+    mf, va, ora = HipEngine(**case, variant_on=(variant,)), HipEngine(**case), FusedModel(**case, dtype="float32")
     try:
-        assert (mf.info()["y_mfma"], va.info()["y_mfma"]) == (1, 0) and mf.info()["y_storage_name"] == "u8"
+        assert (mf.info()["y_mfma"], va.info()["y_mfma"]) == ({"y_mfma2": 1, "y_mfma1": 2}[variant], 0) and mf.info()["y_storage_name"] == "u8"
         st = perturbed_state({n: getattr(ora, n).shape for n in ora.VAR_NAMES}, amp=0.25)
         for n, v in st.items():
             setattr(ora, n, v.astype(ora.pdt))
@@ -461,7 +465,7 @@ def test_count_matrix_products_on_the_int8_matrix_cores(shape):
         for n in ora.VAR_NAMES:
             assert _rel(gm[n], go[n]) < 2e-5, (n, _rel(gm[n], go[n]))
             assert _rel(gm[n], gv[n]) < 3e-6, (n, _rel(gm[n], gv[n]))     # the two streams agree far inside the oracle bound
-        n_iter = 4
+        n_iter = 7                       # (more Adam steps than the lagged exponent bound covers without an exact pass: 4)
         epss = np.stack([eps_for(1, ora.G, 100 + i) for i in range(2 * n_iter)])
         lm, lv = mf.iterate(n_iter, epss), va.iterate(n_iter, epss)
         for i in range(n_iter):
@@ -480,18 +484,22 @@ def test_fixed_point_images_follow_the_parameter_scale():
     keep ~30 significant bits: products from W = 1e-6-scale and psi = 50-scale states still match the VALU stream."""
     from clonealign_amd.engine import HipEngine
     case = make_case(seed=43, N=900, G=260, C=3, K=1)
+    m1 = HipEngine(**case, variant_on=("y_mfma1",))
     mf, va = HipEngine(**case, variant_on=("y_mfma2",)), HipEngine(**case)
     try:
         rng = np.random.default_rng(1)
         for wamp, pamp in ((1e-6, 50.0), (3.0, 1e-4), (0.0, 1.0)):
             W = rng.normal(size=(260, 1)) * wamp
             psi = rng.normal(size=(900, 1)) * pamp
-            for eng in (mf, va):
+            for eng in (mf, va, m1):
                 eng.set("W", W); eng.set("psi", psi)
             eps = eps_for(1, 260, 5)
             gm, _ = mf.gradients(eps)
+            g1, _ = m1.gradients(eps)
             gv, _ = va.gradients(eps)
             for n in ("psi", "W"):
                 assert _rel(gm[n], gv[n]) < 3e-6, (wamp, pamp, n, _rel(gm[n], gv[n]))
+                assert _rel(g1[n], gv[n]) < 3e-6, (wamp, pamp, n, _rel(g1[n], gv[n]))
+                assert np.array_equal(g1[n], gm[n]), n      # same fixed-point images, exact integer sums: the two MFMA forms agree bit for bit
     finally:
-        mf.close(); va.close()
+        mf.close(); va.close(); m1.close()

@@ -127,6 +127,56 @@ int main(int argc, char** argv) {
     }
     printf("YtPsi digits: %lld mismatches of %lld\n", bad, (long long)G * 4 * K);
   }
+  // ---- one copy, both products (k_ys_mfma), K = 1
+  if (K == 1) {
+    const int64_t N64 = (N + 63) / 64 * 64;
+    const int Gp5 = (G + CA_YS_GW - 1) / CA_YS_GW * CA_YS_GW;      // here Gp (multiple of 1024) serves
+    (void)Gp5;
+    uint4 *Ys, *Wr, *Pr; int *YWi, *YTi;
+    const int nseg = Gp / CA_YS_GW;
+    CK(hipMalloc(&Ys, N64 * Gp)); CK(hipMalloc(&Wr, (int64_t)(Gp / 64) * 1024)); CK(hipMalloc(&Pr, (N64 / 64) * 1024));
+    CK(hipMalloc(&YWi, (int64_t)nseg * N * 16));
+    hipLaunchKernelGGL(k_bias_y, dim3((unsigned)((N64 * (Gp / 16) + 255) / 256)), dim3(256), 0, 0, Y, Ys, N, N64, Gp);
+    hipLaunchKernelGGL(k_ym_quant, dim3((unsigned)(((Gp / 64 + N64 / 64) * 64 + 255) / 256)), dim3(256), 0, 0, V, K, (int64_t)G, Gp / 64, F, K, N, N64 / 64, K, amax, Wr, Pr, 1);
+    int *Wsum, *Psum;
+    CK(hipMalloc(&Wsum, (Gp / 64) * 16)); CK(hipMalloc(&Psum, (N64 / 64) * 16));
+    hipLaunchKernelGGL(k_ym_digit_sums, dim3((unsigned)((Gp / 64 * 64 + 255) / 256)), dim3(256), 0, 0, Wr, (int64_t)(Gp / 64), Wsum);
+    hipLaunchKernelGGL(k_ym_digit_sums, dim3((unsigned)((N64 / 64 * 64 + 255) / 256)), dim3(256), 0, 0, Pr, N64 / 64, Psum);
+    CK(hipDeviceSynchronize());
+    std::vector<int> hW((size_t)(Gp / 64) * 4), hP((size_t)(N64 / 64) * 4);
+    CK(hipMemcpy(hW.data(), Wsum, hW.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hP.data(), Psum, hP.size() * 4, hipMemcpyDeviceToHost));
+    long long Wtot[4] = {0, 0, 0, 0}, Ptot[4] = {0, 0, 0, 0};
+    for (size_t i = 0; i < hW.size(); ++i) Wtot[i & 3] += hW[i];
+    for (size_t i = 0; i < hP.size(); ++i) Ptot[i & 3] += hP[i];
+    for (int RS : {128, 256, 512}) {
+      const int nrg = (int)((N + 4 * RS - 1) / (4 * RS));
+      CK(hipMalloc(&YTi, (int64_t)nrg * Gp * 16));
+      CK(hipMemset(YWi, 0xFF, (int64_t)nseg * N * 16));
+      const size_t lds = CA_YS_LDS_BYTES;
+      hipLaunchKernelGGL(k_ys_mfma, dim3(nrg * nseg), dim3(256), lds, 0, reinterpret_cast<const uint8_t*>(Ys), Wr, Pr, N, Gp, RS, YWi, YTi);
+      CK(hipDeviceSynchronize());
+      std::vector<int> o((size_t)nseg * N * 4), ot((size_t)nrg * Gp * 4); std::vector<long long> r((size_t)N * 16), rt((size_t)G * 16);
+      CK(hipMemcpy(o.data(), YWi, o.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(ot.data(), YTi, ot.size() * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(r.data(), ryw, r.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(rt.data(), ryt, rt.size() * 8, hipMemcpyDeviceToHost));
+      long long bad = 0, badt = 0;
+      for (int64_t n = 0; n < N; ++n) for (int pd = 0; pd < 4; ++pd) {
+        long long a = 128 * Wtot[pd]; for (int sg = 0; sg < nseg; ++sg) a += o[((size_t)sg * N + n) * 4 + pd];
+        if (a != r[n * 16 + pd]) { if (bad < 4) printf("  ys/yw mismatch n=%lld p=%d got %lld want %lld\n", (long long)n, pd, a, r[n * 16 + pd]); ++bad; }
+      }
+      for (int g = 0; g < G; ++g) for (int pd = 0; pd < 4; ++pd) {
+        long long a = 128 * Ptot[pd]; for (int q = 0; q < nrg; ++q) a += ot[((size_t)q * Gp + g) * 4 + pd];
+        if (a != rt[(size_t)g * 16 + pd]) { if (badt < 4 || (pd == 0 && badt < 200 && RS == 128)) printf("  ys/yt mismatch g=%d (mod512 %d) p=%d got %lld want %lld\n", g, g % 512, pd, a, rt[(size_t)g * 16 + pd]); ++badt; }
+      }
+      hipEvent_t ea, eb; CK(hipEventCreate(&ea)); CK(hipEventCreate(&eb));
+      CK(hipEventRecord(ea));
+      for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k_ys_mfma, dim3(nrg * nseg), dim3(256), lds, 0, reinterpret_cast<const uint8_t*>(Ys), Wr, Pr, N, Gp, RS, YWi, YTi);
+      CK(hipEventRecord(eb)); CK(hipEventSynchronize(eb));
+      float ms; CK(hipEventElapsedTime(&ms, ea, eb));
+      printf("ONE COPY k_ys_mfma RS=%d: YW %lld / YtPsi %lld mismatches;  %.1f us  %.2f TB/s stored (%d blocks)\n", RS, bad, badt, ms / 20 * 1e3,
+             (double)N64 * Gp / (ms / 20 * 1e-3) * 1e-12, nrg * nseg);
+      CK(hipFree(YTi));
+    }
+  }
   // ---- timing
   const double bytes = (double)N * G;
   const int reps = 30;
