@@ -577,12 +577,20 @@ int ensure_ycache(ca_engine* h) {
   // YTpart is [nrb][Gp*K]: column sums over the row blocks (+ the overflow list's chunk sums per gene); ytpsi is laid
   // out [Gp][K] (first G rows used).  Row side: YW = sum of the strips, and the psi.(YW) partials of the ELBO (the fused
   // loop's cell epilogue leaves both to this).  One launch for both (k_yfinish = k_colsum's blocks + k_yw_dot's).
-  {
+  if (!h->on_side) {
     const int nb_col = cdiv((int64_t)h->Gp * h->K, 64);
     LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_yfinish, dim3(nb_col + h->n_yw), dim3(1024), 0, h->stream, h->YTpart, h->red + h->off_y, h->nrg,
                                                   (int64_t)h->Gp * h->K, h->Gp * h->K, h->n_ovf > 0 ? h->ovf_col_chunk_ptr : nullptr,
                                                   h->n_ovf > 0 ? h->ovf_csum : nullptr, h->K, h->G, nb_col, h->YWpart,
                                                   h->nseg + (h->n_ovf > 0 ? 1 : 0), h->F, h->D, h->N, h->YW, h->yw_part));
+  } else {
+    // on the side stream, beside the forward sweep, the two finishers stay two small launches: the merged one's 1024-thread
+    // blocks need sixteen free wave slots at once and took 64 us to get through a GPU the sweep has filled (profiles/r02_v1_timeline.txt)
+    LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->Gp * h->K, 64)), dim3(1024), 0, h->stream,
+                                                  h->YTpart, h->red + h->off_y, h->nrg, (int64_t)h->Gp * h->K, h->Gp * h->K,
+                                                  h->n_ovf > 0 ? h->ovf_col_chunk_ptr : nullptr, h->n_ovf > 0 ? h->ovf_csum : nullptr, h->K, h->G));
+    LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_yw_dot, dim3(h->n_yw), dim3(CA_TB), 0, h->stream, h->YWpart,
+                                                  h->nseg + (h->n_ovf > 0 ? 1 : 0), h->F, h->D, h->K, h->N, h->YW, h->yw_part));
   }
   h->ycache_valid = true;
   return CA_OK;
