@@ -427,13 +427,14 @@ __global__ void __launch_bounds__(CA_TB) k_prep_cells_u8(const uint8_t* __restri
 // alternating groups of U so the prefetch needs no register copies; row totals are parked one per lane with
 // v_writelane and stored 64 at a time (a per-row store would sit in the same in-order vmcnt queue as the loads).
 template <typename YT, int KK, int TF = 0>
-__global__ void __launch_bounds__(CA_TB) k_ypass(const YT* __restrict__ Y, const float* __restrict__ F, int Dstride,
-                                                 const float* __restrict__ V, int koff, float* __restrict__ YWpart,
-                                                 float* __restrict__ YTpart, int64_t N, int G, int Gp, int nseg,
-                                                 int nrb, int TR, int K, ca_ovf_args ovf, int nb_main) {
+__device__ __forceinline__ void ca_ypass_body(int blk, const YT* __restrict__ Y, const float* __restrict__ F, int Dstride,
+                                              const float* __restrict__ V, int koff, float* __restrict__ YWpart,
+                                              float* __restrict__ YTpart, int64_t N, int G, int Gp, int nseg,
+                                              int nrb, int TR, int K, const ca_ovf_args& ovf, int nb_main,
+                                              float (*ycomb)[64][YVec<YT>::VEC + 1] /* [CA_TB / 64] rows of shared memory */) {
   constexpr int VEC = YVec<YT>::VEC;
-  if ((int)blockIdx.x >= nb_main) {   // overflow-list blocks (identity transform only: the VI loop)
-    const int b = blockIdx.x - nb_main;
+  if (blk >= nb_main) {   // overflow-list blocks (identity transform only: the VI loop)
+    const int b = blk - nb_main;
     if (b < ovf.nb_rows) ca_ovf_rows_body(b, ovf.rowptr, ovf.col, ovf.val, V, Dstride, ovf.YWextra, N, K, 0);
     else ca_ovf_chunks_body(b - ovf.nb_rows, ovf.chunk_start, ovf.row2, ovf.val2, F, Dstride, ovf.csum, ovf.nchunk, K, 0);
     return;
@@ -442,8 +443,8 @@ __global__ void __launch_bounds__(CA_TB) k_ypass(const YT* __restrict__ Y, const
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   // block = one gene segment x 4 consecutive row blocks (one per wave): the four column partials are combined in LDS at
   // the end, so YTpart has one row per BLOCK (a quarter of the slab the column-sum kernel has to read back)
-  const int rg = (int)blockIdx.x / nseg;                    // wave-uniform from here on
-  const int sg = (int)blockIdx.x - rg * nseg;
+  const int rg = blk / nseg;                    // wave-uniform from here on
+  const int sg = blk - rg * nseg;
   const int rb = rg * (CA_TB / 64) + wave;
   const bool live = rb < nrb;
   const int col0 = sg * 64 * VEC + lane * VEC;
@@ -533,7 +534,6 @@ __global__ void __launch_bounds__(CA_TB) k_ypass(const YT* __restrict__ Y, const
     if (i0 + U < nrows) consume(bufB, i0 + U);
   }
   // combine the four waves' column partials (fixed order) and write the block's row of YTpart
-  __shared__ float ycomb[CA_TB / 64][64][VEC + 1];
 #pragma unroll
   for (int k = 0; k < KK; ++k) {
     __syncthreads();
@@ -546,6 +546,14 @@ __global__ void __launch_bounds__(CA_TB) k_ypass(const YT* __restrict__ Y, const
       YTpart[((int64_t)rg * Gp + sg * 64 * VEC + i) * K + koff + k] = v;
     }
   }
+}
+template <typename YT, int KK, int TF = 0>
+__global__ void __launch_bounds__(CA_TB) k_ypass(const YT* __restrict__ Y, const float* __restrict__ F, int Dstride,
+                                                 const float* __restrict__ V, int koff, float* __restrict__ YWpart,
+                                                 float* __restrict__ YTpart, int64_t N, int G, int Gp, int nseg,
+                                                 int nrb, int TR, int K, ca_ovf_args ovf, int nb_main) {
+  __shared__ float ycomb[CA_TB / 64][64][YVec<YT>::VEC + 1];
+  ca_ypass_body<YT, KK, TF>((int)blockIdx.x, Y, F, Dstride, V, koff, YWpart, YTpart, N, G, Gp, nseg, nrb, TR, K, ovf, nb_main, ycomb);
 }
 
 // Column sums of a [rows][ld] float slab in fp64 and in a fixed order: out[c] = sum_r part[r*ld + c].
@@ -2186,6 +2194,47 @@ __global__ void __launch_bounds__(CA_TB) k_fwd_cell_mix(const float* __restrict_
   else
     ca_fwd_cell_body<D, TLS>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk,
                              (int64_t)nbig * (TLB * 16) + (int64_t)((int)blockIdx.x - nbig) * (TLS * 16), blockIdx.x, comb, sm, la);
+}
+
+
+// The Y stream RIDING on the forward sweep's launch (u8 storage, K = 1): the blocks of k_ypass and the blocks of the sweep are
+// interleaved in one grid, so both are resident side by side from the first microsecond and no second queue, no cross-stream
+// event and none of the ~6 us dispatch gaps that each of those costs is involved (profiles/r02_v1_gaps.txt: 33 us of gaps per
+// iteration with the side stream).  Block b: even -> sweep block b / 2, odd -> stream block b / 2, until one kind runs out.
+struct ca_yride_args {
+  const uint8_t* Y; const float* F; int Dstride; const float* V; float* YWpart; float* YTpart;
+  int G, Gp, nseg, nrb, TR, nb_main, nb_y;   // nb_y = nb_main + overflow-list blocks
+  ca_ovf_args ovf;
+};
+__device__ __forceinline__ bool ca_ride_split(int b, int nf, int ny, int& idx) {   // true: sweep block idx, false: stream block idx
+  const int m = nf < ny ? nf : ny;
+  if (b < 2 * m) { idx = b >> 1; return (b & 1) == 0; }
+  idx = b - m;                       // the tail belongs to whichever kind is left
+  return nf > ny;
+}
+template <int D, int TLB, int TLS>
+__global__ void __launch_bounds__(CA_TB) k_fwd_cell_mix_y(const float* __restrict__ F, const float* __restrict__ etamax2,
+                                                          const float* __restrict__ Vs, const unsigned short* __restrict__ Mq,
+                                                          ca_cell_ptrs p, const float* __restrict__ alpha_u,
+                                                          double* __restrict__ cell_part, int64_t N, int C, int K, int nk, int nbig,
+                                                          int nf, ca_yride_args y) {
+  constexpr size_t FW = sizeof(ca_f32x4) * 4 * TLB * 64 + sizeof(double) * (CA_TB + 64);
+  constexpr size_t YW_ = sizeof(float) * (CA_TB / 64) * 64 * 17;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[FW > YW_ ? FW : YW_];
+  int idx;
+  if (!ca_ride_split((int)blockIdx.x, nf, y.nb_y, idx)) {
+    ca_ypass_body<uint8_t, 1, 0>(idx, y.Y, y.F, y.Dstride, y.V, 0, y.YWpart, y.YTpart, N, y.G, y.Gp, y.nseg, y.nrb, y.TR, 1, y.ovf, y.nb_main,
+                                 reinterpret_cast<float (*)[64][17]>(smem));
+    return;
+  }
+  ca_f32x4* comb = reinterpret_cast<ca_f32x4*>(smem);
+  double* sm = reinterpret_cast<double*>(smem + sizeof(ca_f32x4) * 4 * TLB * 64);
+  double* la = sm + CA_TB;
+  ca_log_softmax_alpha(alpha_u, C, la);
+  if (nbig > 0 && idx >= nbig)
+    ca_fwd_cell_body<D, TLS>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)nbig * (TLB * 16) + (int64_t)(idx - nbig) * (TLS * 16), idx, comb, sm, la);
+  else
+    ca_fwd_cell_body<D, TLB>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)idx * (TLB * 16), idx, comb, sm, la);
 }
 
 // fixed-order reduction of block partials: out[j] = sum_b part[b][j]; one block per column j

@@ -134,6 +134,7 @@ struct ca_engine {
   bool fused_ok = false, look_valid = false; int64_t look_slot = 0; int frow = 8;
   float *Mb2 = nullptr, *mu32B = nullptr, *Zpart2 = nullptr; double* gene_partB = nullptr;
   bool y_defer = false;
+  bool ride_ok = false;   // the Y stream's blocks ride on the forward sweep's launch (k_fwd_cell_mix_y) instead of a side stream
   bool fold_gsum = false, fold_now = false;   // small problems: the backward sweep's partials are summed inside k_final_gene
   // per-gene prologue of the next fused pass, computed ahead by the train pass before it (ca_pre_args): the loops announce
   // the next (monitor, train) eps slots in hint_*, train_update fills the alternate partial buffers, fused_pass swaps them in
@@ -893,7 +894,7 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
                             lr_t, (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, mon, h->ngblk, psi,
                             h->fold_now ? h->gpart : nullptr, h->csplit_m));
   h->fold_now = false;
-  if (apply && h->async_y && h->K > 0) {
+  if (apply && h->async_y && h->K > 0 && !h->ride_ok) {
     // psi is final: the Y pass for the new parameters goes to the side stream from HERE (its launches are issued by the
     // next pass, so the main stream is not left waiting for the host to get through them), and the per-cell kernel below
     // (q(z) logits, exponent bound, the O(K + C) update and the next pass's per-gene prologue: 12-16 us) is its head
@@ -1011,7 +1012,9 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
                               h->fwd_mfma ? h->Mq : nullptr));
   }
   h->pre_valid = false;
-  CACK(ensure_ycache(h));
+  // the Y products of this parameter state: riding on the sweep's own launch (below), or from the side stream / in line
+  const bool ride = h->ride_ok && !h->ycache_valid && h->fwd_cell && !h->y_defer && !h->y_pending;
+  if (!ride) CACK(ensure_ycache(h));
   ca_cell_ptrs cp;
   cp.A = h->A; cp.cn = h->cn; cp.s64 = h->s64; cp.etamax2 = h->etamax2; cp.glogit = h->glogit; cp.F = h->F;
   cp.coef = h->coef; cp.dgl = h->dgl; cp.coefq = h->bwd_mfma ? h->coefq : nullptr;
@@ -1019,7 +1022,35 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
   int CP = 1;
   while (CP < h->C) CP <<= 1;
   int cell_blocks = h->ncblk;
-  if (h->fwd_cell) {   // sweep + cell epilogue in one kernel: no Z partials, one launch
+  if (h->fwd_cell && ride) {   // ... and the Y stream's blocks interleaved with the sweep's in the same grid
+    cell_blocks = h->ncblk_f;
+    ca_yride_args ya;
+    memset(&ya, 0, sizeof(ya));
+    ya.Y = (const uint8_t*)h->Y; ya.F = h->F; ya.Dstride = h->D; ya.V = h->V; ya.YWpart = h->YWpart; ya.YTpart = h->YTpart;
+    ya.G = h->G; ya.Gp = h->Gp; ya.nseg = h->nseg; ya.nrb = h->nrb; ya.TR = h->TR;
+    ya.nb_main = h->nrg * h->nseg; ya.nb_y = ya.nb_main;
+    if (h->n_ovf > 0) {
+      ya.ovf.nb_rows = cdiv(h->N, CA_TB); ya.ovf.nb_chunks = cdiv(h->n_ovf_chunk, CA_TB / 64);
+      ya.ovf.rowptr = h->ovf_rowptr; ya.ovf.col = h->ovf_col; ya.ovf.val = h->ovf_val; ya.ovf.YWextra = h->YWpart + (int64_t)h->nseg * h->N * h->K;
+      ya.ovf.chunk_start = h->ovf_chunk_start; ya.ovf.row2 = h->ovf_row2; ya.ovf.val2 = h->ovf_val2; ya.ovf.csum = h->ovf_csum; ya.ovf.nchunk = h->n_ovf_chunk;
+      ya.nb_y += ya.ovf.nb_rows + ya.ovf.nb_chunks;
+    }
+    const dim3 grid((unsigned)(h->ncblk_f + ya.nb_y));
+#define CA_FCY(DV, TLBV)                                                                                                              \
+  LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell_mix_y<DV, TLBV, 2>), grid, dim3(CA_TB), 0, h->stream, h->F, h->etamax2, h->Vs, h->Mq, \
+                                              cp, h->alpha_u, h->cell_part, h->N, h->C, h->K, h->nk32, h->fc_nbig, h->ncblk_f, ya))
+    if (h->fc_tl == 6) { if (h->D == 1) CA_FCY(1, 6); else CA_FCY(2, 6); }
+    else { if (h->D == 1) CA_FCY(1, 2); else CA_FCY(2, 2); }
+#undef CA_FCY
+    {   // the stream's finishers, in line behind the launch they rode on (one launch: column sums + row sums / psi.(YW) partials)
+      const int nb_col = cdiv((int64_t)h->Gp * h->K, 64);
+      LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_yfinish, dim3(nb_col + h->n_yw), dim3(1024), 0, h->stream, h->YTpart, h->red + h->off_y, h->nrg,
+                                                    (int64_t)h->Gp * h->K, h->Gp * h->K, h->n_ovf > 0 ? h->ovf_col_chunk_ptr : nullptr,
+                                                    h->n_ovf > 0 ? h->ovf_csum : nullptr, h->K, h->G, nb_col, h->YWpart,
+                                                    h->nseg + (h->n_ovf > 0 ? 1 : 0), h->F, h->D, h->N, h->YW, h->yw_part));
+    }
+    h->ycache_valid = true;
+  } else if (h->fwd_cell) {   // sweep + cell epilogue in one kernel: no Z partials, one launch
     cell_blocks = h->ncblk_f;
 #define CA_FC(DV, TLV)                                                                                                       \
   LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell<DV, TLV>), dim3(h->ncblk_f), dim3(CA_TB), 0, h->stream, h->F, h->etamax2, \
@@ -1659,9 +1690,9 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   }
   if (verbose(h))
     fprintf(stderr, "[clonealign_hip] N=%lld G=%d C=%d D=%d n_cu=%d gsplit=%d gchunk=%d csplit=%d fused=%d fwd_mfma=%d fsplit=%d fkchunk=%d "
-            "bwd_mfma=%d csplit_m=%d cchunk_m=%lld nwt=%d fwd_cell=%d fc_tl=%d fc_nbig=%d ncblk_f=%d ystore=%d\n", (long long)Nn, G, C, D, h->n_cu, h->gsplit,
+            "bwd_mfma=%d csplit_m=%d cchunk_m=%lld nwt=%d fwd_cell=%d fc_tl=%d fc_nbig=%d ncblk_f=%d ystore=%d async_y=%d\n", (long long)Nn, G, C, D, h->n_cu, h->gsplit,
             h->gchunk, h->csplit, (int)h->fused_ok, (int)h->fwd_mfma, h->fsplit, h->fkchunk, (int)h->bwd_mfma, h->csplit_m,
-            (long long)h->cchunk_m, h->nwt, (int)h->fwd_cell, h->fc_tl, h->fc_nbig, h->ncblk_f, h->ystore);
+            (long long)h->cchunk_m, h->nwt, (int)h->fwd_cell, h->fc_tl, h->fc_nbig, h->ncblk_f, h->ystore, (int)h->async_y);
   CACK(dalloc(h, &h->vmm, 2 * std::max(D, 1)));
   CACK(dalloc(h, &h->vmm_part, (int64_t)h->ngblk * 2 * std::max(D, 1)));
   CACK(dalloc(h, &h->etamax2, h->N16));
@@ -1744,6 +1775,9 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     h->y_ys = true;
     h->y_dev_bytes += h->ys_N64 * h->Gp;
   }
+  // the Y stream rides on the forward sweep's launch: 1-byte storage, K = 1, the fused sweep with its default block shapes
+  h->ride_ok = h->ystore == CA_YSTORE_U8 && K == 1 && h->fused_ok && h->fwd_cell && (h->fc_tl == 6 || (h->fc_tl == 2 && h->fc_nbig == 0)) &&
+               !h->y_mfma && !h->y_ys && variant_on(h, CA_VAR_Y_RIDE, "CA_Y_RIDE");
   h->off_g = 3 + C;
   h->off_y = h->off_g + (int64_t)G * (S + D);
   h->red_n = h->off_y + (int64_t)G * K;

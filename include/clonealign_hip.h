@@ -88,7 +88,8 @@ enum ca_variant {
   CA_VAR_PAIR_ELBO = 1 << 7,  /* final ELBOs two draws per sweep */
   CA_VAR_PREP_FAST = 1 << 8,  /* wave-per-cell fit-constant kernel for u8 storage */
   CA_VAR_P2P = 1 << 10,       /* one-shot peer-to-peer all-reduce (else ncclAllReduce) after ca_comm_init() */
-  CA_VAR_FOLD_GSUM = 1 << 11  /* small problems: backward-sweep partials summed inside the per-gene kernel (else a k_colsum launch) */
+  CA_VAR_FOLD_GSUM = 1 << 11, /* small problems: backward-sweep partials summed inside the per-gene kernel (else a k_colsum launch) */
+  CA_VAR_Y_RIDE = 1 << 12     /* the Y stream's blocks ride on the forward sweep's launch (else side stream / in line) */
 };
 /* Opt-in variants (bits of ca_options.variant_on): measured slower than the default on the headline workload, kept built and
  * under test because they are the evidence for the choice. */

@@ -136,7 +136,10 @@ def test_full_size_two_shards_equal_one_engine(full):
     [t.start() for t in ts]
     [t.join() for t in ts]
     for r in range(2):
-        assert np.abs(out[r][0] - tr_ref).max() <= 1e-7 * np.abs(tr_ref).max()
+        # (one 100k-cell handle and two 50k-cell shards add the same fp32 partial sums in a different order: 4.3e-8 measured,
+        #  tools/stress_shards.py; the replicas themselves must agree bit for bit)
+        assert np.abs(out[r][0] - tr_ref).max() <= 3e-7 * np.abs(tr_ref).max()
+        assert np.array_equal(out[r][0], out[0][0])
         for n, v in st_ref.items():
             assert np.abs(out[r][1][n] - v).max() <= 1e-4 * max(np.abs(v).max(), 1e-30), n
             assert np.array_equal(out[r][1][n], out[0][1][n])
