@@ -1588,7 +1588,8 @@ int create_impl(ca_engine* h, const ca_problem* p) {
       h->cchunk_m = ((Nn + h->csplit_m - 1) / h->csplit_m + 15) / 16 * 16;
       h->csplit_m = cdiv(Nn, h->cchunk_m);
       // launches, not bandwidth, are what an iteration costs below ~32k cells: fold the column sums of the sweep's partials
-      h->fold_gsum = Nn <= 32768 && S + D <= 12 && h->tail_fuse && variant_on(h, CA_VAR_FOLD_GSUM, "CA_FOLD_GSUM");
+      h->fold_gsum = (Nn <= 32768 || variantx_on(h, CA_VARX_FOLD_ALWAYS, "CA_FOLD_ALWAYS")) && S + D <= 12 && h->tail_fuse &&
+                     variant_on(h, CA_VAR_FOLD_GSUM, "CA_FOLD_GSUM");
       CACK(dalloc(h, &h->coefq, (int64_t)S * h->N16 * 32));
     }
   }

@@ -99,6 +99,7 @@ enum ca_variant_on {
                                  the bytes per iteration */
   CA_VARX_Y_MFMA1 = 1 << 2,   /* both count-matrix products on the int8 matrix cores from ONE tiled copy, the column products through
                                  the transposing LDS read ds_read_b64_tr_b8 (k_ys_mfma; K = 1) */
+  CA_VARX_FOLD_ALWAYS = 1 << 3, /* backward-sweep partials summed inside the per-gene kernel at every size (default: up to 32k cells) */
   CA_VARX_ASYNC_SMALL = 1 << 1 /* side stream also below 4e7 counts (small shards run the Y stream in line: the two cross-stream
                                  events cost more than the overlap returns there) */
 };
