@@ -2262,8 +2262,14 @@ int ca_iterate(ca_handle h, int32_t n_iter, const float* eps_stream, int64_t n_d
   if (!h || n_iter < 0) return CA_ERR_INVALID;
   HIPCK(h, hipSetDevice(h->device));
   CACK(stage_eps(h, eps_stream, n_draws, 2 * (int64_t)n_iter));
-  CACK(ensure_elbo_cap(h, std::max(1, n_iter)));
+  CACK(ensure_elbo_cap(h, std::max(1, n_iter) + 1));
   const auto t_host0 = std::chrono::steady_clock::now();
+  // The first train pass has no monitor pass before it to share a sweep with.  Instead of the plain kernels (fp32 VALU sweep,
+  // separate cell epilogue, the Y stream in line: 0.65 ms at cfg-3, 4 % of a 20-iteration call) its forward half takes the fused
+  // matrix-core sweep with its own draw in both column halves; the monitor half's ELBO goes to a scratch slot.
+  // (sharded with the general backward sweep the extra monitor tail would cost a collective of its own: plain kernels there)
+  if (n_iter > 0 && h->fused_ok && !h->look_valid && (h->bwd_mfma || !is_sharded(h)))
+    CACK(fused_pass(h, 0, 0, h->elbo_dev + n_iter));
   for (int i = 0; i < n_iter; ++i) {
     h->hint_A = 2 * (int64_t)i + 1; h->hint_B = i + 1 < n_iter ? 2 * (int64_t)i + 2 : -1;
     CACK(train_pass(h, 2 * (int64_t)i));
