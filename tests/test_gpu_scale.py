@@ -417,15 +417,17 @@ def test_run_clonealign_restarts_on_one_resident_engine_equal_separate_fits(big)
     np.testing.assert_allclose(best["correlations"], ref["correlations"], rtol=0, atol=1e-12, equal_nan=True)
 
 
-def test_fused_loop_at_shard_size_matches_c_oracle():
+@pytest.mark.parametrize("shape", [(40_000, 1_200, 8), (10_000, 2_000, 4)], ids=["shard40k", "cfg2"])
+def test_fused_loop_at_shard_size_matches_c_oracle(shape):
     """40k cells x 1.2k genes x 8 clones through ca_run: the decomposition of the large shapes (96-cell blocks plus the
     second block size of k_fwd_cell_mix, several row groups of the Y stream, every CU busy in the backward sweep) against the
-    C/OpenMP float64 oracle driven call by call."""
+    C/OpenMP float64 oracle driven call by call.  cfg2 = BASELINE.json configs[1] through the same whole-loop call the bench
+    drives (32-cell blocks, the Y stream riding on the sweep's launch, the sweep's partials summed inside k_final_gene)."""
     from clonealign_amd.engine import HipEngine
     from clonealign_amd.inference import run_vi_loop
     from clonealign_amd.rng import EpsStream
     from oracle.c_port import CPortModel
-    N, G, C = 40_000, 1_200, 8
+    N, G, C = shape
     Yd, L, psi0, loc0 = _synth(N, G, C, seed=5)
     Y = Yd.cpu().numpy().astype(np.float64)
     eng = HipEngine(Y, L, psi0, loc0, 1)
@@ -440,6 +442,12 @@ def test_fused_loop_at_shard_size_matches_c_oracle():
         fe = eng.final_elbo(np.stack([eps_for(1, G, 70 + i) for i in range(3)]), 3)
         fo = np.array([ora.elbo(eps_for(1, G, 70 + i)) for i in range(3)])
         assert np.abs(fe - fo).max() <= 1e-5 * np.abs(fo).max()
+        # ... and three more iterations through ca_iterate (what bench.py times): first and last sweep carry one draw twice
+        eps_it = np.stack([eps_for(1, G, 200 + i) for i in range(6)])
+        last = eng.iterate(3, eps_it)
+        for i in range(3):
+            ora.step(eps_it[2 * i]); lo = ora.elbo(eps_it[2 * i + 1])
+        assert abs(last - lo) <= 1e-5 * abs(lo), (last, lo)
         se, so = eng.get_state(), ora.get_state()
         for n in ("W", "v", "psi", "alpha_unconstr", "loc", "ls", "gamma_logits"):
             err = np.abs(se[n] - so[n]).max() / max(np.abs(so[n]).max(), 1e-30)
