@@ -59,23 +59,29 @@ def pmc_traffic(build_id, kernel_class):
     return None, None
 
 
-def cpu_baseline(Ycells, L, psi0, loc0, K, N_full, budget_s=24.0):
-    """Oracle (kind 'port': the fused C + OpenMP float64 restatement, oracle/c) timed on the host cores at THREE sample sizes
-    of the same workload; the rate is quoted from the largest sample and the smaller ones show that time per iteration is
-    linear in the cell count (so that scaling the sample to the full matrix is sound)."""
+def cpu_baseline(Ycells, L, psi0, loc0, K, N_full, budget_s=22.0):
+    """The CPU ports of the oracle (kind 'port') timed on the host cores.  Headline: the float32 SIMD port
+    (oracle/c/clonealign_simd.c: unit-stride gene loops, libmvec exp/log, AVX-512 where the host has it) at up to FOUR sample
+    sizes of the same workload, the largest being the FULL matrix when the host has the memory for it -- then the quoted rate is
+    not extrapolated; the smaller samples show how time per iteration grows with the cell count.  Beside it the scalar
+    float64 port (oracle/c/clonealign_oracle.c, the tests' checker) on the smallest sample."""
     from oracle import c_port
-    sizes = [n for n in (4096, 16384, 65536) if n <= Ycells.shape[0]] or [Ycells.shape[0]]
+    sizes = [n for n in (4096, 16384, 65536) if n < Ycells.shape[0]] + [Ycells.shape[0]]
     rows, cores = [], 1
     for n in sizes:
-        r = c_port.time_baseline(Ycells[:n], L, psi0, loc0, K, N_full, budget_s * n / sum(sizes))
+        r = c_port.time_baseline(Ycells[:n], L, psi0, loc0, K, N_full, budget_s * n / sum(sizes), simd=True)
         rows.append({"cells": n, "scaled_it_per_s": r["value"], "s_per_iter_sample": n / N_full / r["value"]})
         cores = r["cores"]
+    scalar = c_port.time_baseline(Ycells[:sizes[0]], L, psi0, loc0, K, N_full, 4.0)
     big = rows[-1]
+    full = big["cells"] == N_full
     return {"value": big["scaled_it_per_s"], "unit": "iterations/s", "cores": cores, "kind": "port",
-            "sample": f"C + OpenMP float64 fused oracle (oracle/c) on the first {big['cells']} of {N_full} cells x {L.shape[0]} genes, "
-                      f"rate scaled by {big['cells']}/{N_full}; linearity: "
+            "sample": f"C + OpenMP float32 SIMD port (oracle/c/clonealign_simd.c) on "
+                      + (f"ALL {N_full} cells (not extrapolated)" if full else f"the first {big['cells']} of {N_full} cells, rate scaled by {big['cells']}/{N_full}")
+                      + f" x {L.shape[0]} genes; time per iteration by sample (fixed cost of the thread team shows at the small ones): "
                       + ", ".join(f"{r['cells']} cells {r['s_per_iter_sample'] * 1e3:.1f} ms/iter" for r in rows),
-            "samples": rows}
+            "samples": rows, "extrapolated": not full,
+            "scalar_f64": {"value": scalar["value"], "unit": "iterations/s", "cores": scalar["cores"], "sample": scalar["sample"]}}
 
 
 def cpu_ref_dataflow(budget_s=10.0):
@@ -117,7 +123,8 @@ def main():
     ap.add_argument("--latent", type=int, default=1)
     ap.add_argument("--y-storage", default="auto")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-cells", type=int, default=65536)
+    ap.add_argument("--cpu-sample-cells", type=int, default=0,
+                    help="cells handed to the CPU baseline; 0 = all of them when the host has 10x the matrix free, else 65536")
     ap.add_argument("--seed", type=int, default=20243)
     ap.add_argument("--collective", default="auto", choices=["auto", "p2p", "rccl", "host"],
                     help="data-path all-reduce at --gpus > 1: auto = one-shot peer-to-peer, else RCCL")
@@ -239,7 +246,11 @@ def main():
         assert info["red_n"] == sharding.reduce_plan(G, C, K, 0, 1)["total"], (info["red_n"], sharding.reduce_plan(G, C, K, 0, 1))
     Ysample = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        Ysample = Yd[:min(args.cpu_sample_cells, n_loc)].cpu().numpy().astype(np.float64)
+        n_cpu = args.cpu_sample_cells
+        if n_cpu <= 0:
+            import psutil
+            n_cpu = n_loc if psutil.virtual_memory().available > 10 * 8 * n_loc * G else 65536
+        Ysample = Yd[:min(n_cpu, n_loc)].cpu().numpy().astype(np.float64)
     del Yd
     torch.cuda.empty_cache()
 

@@ -43,6 +43,31 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
+_LIB_SIMD = os.path.join(_DIR, "libclonealign_simd.so")
+_lib_simd = None
+
+
+def load_simd():
+    """The float32 SIMD sibling (oracle/c/clonealign_simd.c): a CPU baseline, checked against the float64 port."""
+    global _lib_simd
+    if _lib_simd is None:
+        if not os.path.exists(_LIB_SIMD):
+            subprocess.check_call(["make", "-C", _DIR])
+        lib = C.CDLL(_LIB_SIMD)
+        lib.cs_create.restype = C.c_void_p
+        lib.cs_create.argtypes = [C.c_long, C.c_int, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_double]
+        lib.cs_destroy.argtypes = [C.c_void_p]
+        lib.cs_elbo.restype = C.c_double
+        lib.cs_elbo.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.cs_gamma_init.argtypes = [C.c_void_p, C.c_void_p]
+        lib.cs_step.argtypes = [C.c_void_p, C.c_void_p]
+        lib.cs_get.restype = C.c_long
+        lib.cs_get.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int]
+        lib.cs_num_threads.restype = C.c_int
+        _lib_simd = lib
+    return _lib_simd
+
+
 class CPortModel:
     VAR_NAMES = ("W", "v", "psi", "beta", "alpha_unconstr", "loc", "ls", "gamma_logits")
 
@@ -126,10 +151,40 @@ class CPortModel:
         self.close()
 
 
-def time_baseline(Yh, L, psi0, loc0, K, N_full, budget_s=20.0):
-    """Iterations/s of the C port on all host cores, on a cell sample, scaled to N_full cells."""
+class CSimdModel(CPortModel):
+    """Same interface over the float32 SIMD port (S = 1; no ``set`` / ``gradients`` -- a baseline, not a checker)."""
+
+    def __init__(self, Y, L, psi0, loc0, K, S=1, X=None, extra_loglik=None, learning_rate=0.1, dtype="float32"):
+        assert S == 1 and dtype == "float32"
+        lib = load_simd()
+        Y = np.ascontiguousarray(Y, dtype=np.float64)
+        L = np.ascontiguousarray(L, dtype=np.float64)
+        self.N, self.G = Y.shape
+        self.C, self.K, self.S = L.shape[1], int(K), 1
+        X = None if X is None else np.ascontiguousarray(np.asarray(X, dtype=np.float64).reshape(self.N, -1))
+        self.P = 0 if X is None else X.shape[1]
+        assert self.C <= 64 and self.K + self.P <= 8
+        psi0 = np.ascontiguousarray(np.asarray(psi0, dtype=np.float64).reshape(self.N, self.K))
+        loc0 = np.ascontiguousarray(loc0, dtype=np.float64)
+        ex = None if extra_loglik is None else np.ascontiguousarray(extra_loglik, dtype=np.float64)
+        self.h = lib.cs_create(self.N, self.G, self.C, self.K, self.P, _p(Y), _p(L), _p(psi0), _p(loc0), _p(X), _p(ex),
+                               float(learning_rate))
+
+        class _Names:   # the parent's methods call self.lib.co_*: route them to the cs_* entry points
+            co_elbo, co_gamma_init, co_step, co_get, co_destroy = lib.cs_elbo, lib.cs_gamma_init, lib.cs_step, lib.cs_get, lib.cs_destroy
+        self.lib = _Names
+
+    def set(self, name, value):
+        raise NotImplementedError
+
+    def gradients(self, eps):
+        raise NotImplementedError
+
+
+def time_baseline(Yh, L, psi0, loc0, K, N_full, budget_s=20.0, simd=False):
+    """Iterations/s of the C port on all host cores, on a cell sample, scaled to N_full cells.  ``simd``: the float32 SIMD port."""
     n, G = Yh.shape
-    m = CPortModel(Yh, L, psi0[:n], loc0, K, 1, dtype="float32")
+    m = (CSimdModel if simd else CPortModel)(Yh, L, psi0[:n], loc0, K, 1, dtype="float32")
     rng = np.random.default_rng(0)
     e = lambda: rng.normal(size=G).astype(np.float32)  # noqa: E731
     m.gamma_init(e())
@@ -144,6 +199,8 @@ def time_baseline(Yh, L, psi0, loc0, K, N_full, budget_s=20.0):
     dt = time.perf_counter() - t0
     threads = load().co_num_threads()
     m.close()
+    what = ("C+OpenMP float32 SIMD port (oracle/c/clonealign_simd.c: libmvec exp/log, AVX-512 where the host has it)" if simd
+            else "C+OpenMP float64 fused oracle (oracle/c)")
     return {"value": it / dt * n / N_full, "unit": "iterations/s", "cores": int(threads), "kind": "port",
-            "sample": f"C+OpenMP float64 fused oracle (oracle/c), first {n} of {N_full} cells x {G} genes, {it} iterations "
+            "sample": f"{what}, first {n} of {N_full} cells x {G} genes, {it} iterations "
                       f"in {dt:.1f} s on {threads} threads, rate scaled by {n}/{N_full}"}
