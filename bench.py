@@ -29,8 +29,10 @@ PEAK_HBM_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 PEAK_F32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 vector == fp32 MFMA peak
 
 
-def algorithmic_work(kernel, N, G, C, K, fused=False, steps=1):
-    """Per-launch algorithmic work of each kernel class."""
+def algorithmic_work(kernel, N, G, C, K, fused=False, steps=1, ride=False):
+    """Per-launch algorithmic work of each kernel class.  ``ride``: the Y stream's blocks run inside
+    the forward sweep's launch (k_fwd_cell_mix_y), so that launch also does the two count-matrix products, 2 flop each per
+    (count, latent dimension); its HBM side is reported by roofline_ystream."""
     if kernel == "ypass":     # one pass over Y: Y.W and Y^T.psi; canonical 4 B/elem + outputs
         return "hbm", N * G * 4.0 + (N + G) * K * 4.0 * 2
     if kernel == "fwd":       # eta 2K, Z 2C, +1 (exp not counted)
@@ -38,8 +40,9 @@ def algorithmic_work(kernel, N, G, C, K, fused=False, steps=1):
         if not fused:
             return "mfma", plain
         # fused two-eps sweep: 2C columns share one eta/exp; per timed call: steps-1 fused launches + 2 plain ones
+        # (since r02 the first and the last sweep of a ca_iterate call are fused launches carrying ONE draw twice: still `plain` useful work)
         two = N * G * (4.0 * C + 2.0 * K + 1.0)
-        return "mfma", ((steps - 1) * two + 2 * plain) / (steps + 1)
+        return "mfma", ((steps - 1) * two + 2 * plain) / (steps + 1) + (N * G * 4.0 * K if ride else 0.0)
     if kernel == "bwd":       # eta 2K, t 2C, dM/dmu 2C-equivalent, deta 1, dpsi 2K, dW 2K
         return "mfma", N * G * (4.0 * C + 6.0 * K + 1.0)
     return "hbm", 0.0
@@ -320,7 +323,8 @@ def main():
         build = eng_mod.build_id()
         ms, launches = kt_timed[dominant]
         per_launch_s = ms / max(launches, 1) * 1e-3
-        bound, work = algorithmic_work(dominant, n_loc, G, C, K, bool(info.get("fused_sweep")), args.steps)
+        ride = bool(info.get("y_ride")) and dominant == "fwd"
+        bound, work = algorithmic_work(dominant, n_loc, G, C, K, bool(info.get("fused_sweep")), args.steps, ride)
         if bound == "hbm":
             achieved, peak, unit = work / per_launch_s / 1e9, PEAK_HBM_GBS, "GB/s"
         else:
@@ -330,11 +334,12 @@ def main():
         # the HBM-bound kernel of the iteration (SURVEY.md section 8d asks for both roofs): the Y stream, timed by HIP events on
         # its own stream during the warmup iterations, where every kernel class is timed
         ystream = None
-        if K > 0 and kt["ypass"][1] > 0:
-            y_s = kt["ypass"][0] / kt["ypass"][1] * 1e-3
+        if K > 0 and (kt["ypass"][1] > 0 or ride):
+            # riding: the stream has no launch of its own -- its bytes are spread over the merged launch's whole duration
+            y_s = per_launch_s if ride else kt["ypass"][0] / kt["ypass"][1] * 1e-3
             canon = n_loc * G * 4.0 + (n_loc + G) * K * 4.0 * 2
-            ytraffic, ysrc = pmc_traffic(build, "ypass") if same_workload else (None, None)
-            ystream = {"bound": "hbm", "kernel": "ypass", "achieved": canon / y_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            ytraffic, ysrc = pmc_traffic(build, "fwd" if ride else "ypass") if same_workload else (None, None)
+            ystream = {"bound": "hbm", "kernel": "ypass (blocks inside the forward sweep's launch)" if ride else "ypass", "achieved": canon / y_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                        "frac": canon / y_s / 1e9 / PEAK_HBM_GBS, "traffic": ytraffic, "traffic_source": ysrc, "launch_ms": y_s * 1e3,
                        "stored_GBps": n_loc * G * float(info["y_bytes_per_elem"]) / y_s / 1e9,
                        "note": "canonical 4 B per count (the reference feeds float32); the matrix is stored at "
@@ -366,8 +371,11 @@ def main():
                          "launch_ms": per_launch_s * 1e3, "launches": int(launches),
                          "note": ("algorithmic fp32 flops of the fused two-eps sweep against the fp32 peak; the contraction "
                                   "itself runs as bf16 hi/lo MFMAs (fp32-accurate), the kernel is bound by VALU issue "
-                                  "(v_exp_f32 + bf16 split) and shares the GPU with the Y-stream kernel on a side stream "
-                                  "(DESIGN.md sections 5 and 8); traffic is filled only from a PMC file of THIS build")
+                                  "(v_exp_f32 + bf16 split)"
+                                  + ("; the Y stream's blocks ride inside this launch (its 4K flop per count are counted, its "
+                                     "512 MB of HBM reads are roofline_ystream's), so launch_ms is sweep + stream"
+                                     if ride else " and shares the GPU with the Y-stream kernel on a side stream")
+                                  + " (DESIGN.md sections 5 and 8); traffic is filled only from a PMC file of THIS build")
                          if dominant == "fwd" else "traffic is filled only from a PMC file of THIS build"},
             "roofline_iteration": {"flops": it_flops, "bytes_canonical": it_bytes,
                                    "achieved_TFLOPs": it_flops / step_s / 1e12,

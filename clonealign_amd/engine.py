@@ -60,7 +60,7 @@ class CaInfo(C.Structure):
                 ("y_device_bytes", C.c_int64), ("device_bytes", C.c_int64), ("gsplit", C.c_int32),
                 ("csplit", C.c_int32), ("n_cu", C.c_int32), ("fused_sweep", C.c_int32), ("fwd_mfma", C.c_int32),
                 ("bwd_mfma", C.c_int32), ("fsplit", C.c_int32), ("fwd_cell", C.c_int32), ("y_mfma", C.c_int32),
-                ("transport", C.c_int32), ("reserved", C.c_int32 * 1), ("red_n", C.c_int64)]
+                ("transport", C.c_int32), ("y_ride", C.c_int32), ("red_n", C.c_int64)]
 
 
 class CaPreprocessParams(C.Structure):

@@ -142,7 +142,7 @@ typedef struct ca_info {
   int32_t fwd_cell;          /* 1: forward sweep and cell epilogue of the fused pass are ONE kernel (k_fwd_cell) */
   int32_t y_mfma;            /* the loop's count-matrix products on the int8 matrix cores: 0 no (k_ypass), 1 two tiled copies, 2 one */
   int32_t transport;         /* 0 none, 1 RCCL all-reduce, 2 host callback, 3 one-shot peer-to-peer (ca_transport) */
-  int32_t reserved[1];
+  int32_t y_ride;            /* 1: the Y stream's blocks ride on the fused forward sweep's launch (k_fwd_cell_mix_y): no launch of its own */
   int64_t red_n;             /* doubles all-reduced per train pass (= sharding.reduce_plan(...)["total"]) */
 } ca_info;
 enum ca_transport { CA_TRANSPORT_NONE = 0, CA_TRANSPORT_RCCL = 1, CA_TRANSPORT_HOST = 2, CA_TRANSPORT_P2P = 3 };
