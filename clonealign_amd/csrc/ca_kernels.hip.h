@@ -2282,27 +2282,25 @@ __device__ __forceinline__ void ca_final_gene_body(const double* __restrict__ re
   const int W_ = S + D;
   // small problems: the backward sweep's cell-split partials are summed here (fixed order, fp64) instead of by a k_colsum
   // launch of their own -- one launch and its gap less per iteration where launches are what an iteration costs
-  double rfold[12];
-  if (gfold) {
-    for (int w = 0; w < W_; ++w) {
-      double a = 0.0;
-      for (int sp0 = 0; sp0 < nfold; sp0 += 8) {   // eight loads in flight, added in slice order
-        float v[8];
+  // (computed where it is used, once per column: an indexed local array would live in scratch memory)
+  auto rgv = [&](int w) -> double {
+    if (!gfold) return red_g[(int64_t)g * W_ + w];
+    double a = 0.0;
+    for (int sp0 = 0; sp0 < nfold; sp0 += 8) {   // eight loads in flight, added in slice order
+      float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = gfold[((int64_t)(sp0 + i < nfold ? sp0 + i : nfold - 1) * G + g) * W_ + w];
+      for (int i = 0; i < 8; ++i) v[i] = gfold[((int64_t)(sp0 + i < nfold ? sp0 + i : nfold - 1) * G + g) * W_ + w];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a += (sp0 + i < nfold) ? (double)v[i] : 0.0;
-      }
-      rfold[w] = a;
+      for (int i = 0; i < 8; ++i) a += (sp0 + i < nfold) ? (double)v[i] : 0.0;
     }
-  }
-  const double* rg = gfold ? rfold : red_g + (int64_t)g * W_;
+    return a;
+  };
   double gl = 0.0, gs = 0.0;
   for (int s = 0; s < S; ++s) {
     const double e = (double)eps[(int64_t)s * G + g];
     const double x = l + sd * e;
     const double mu = ca_softplus_d(x), lm = log(mu), sig = ca_sigmoid_d(x);
-    const double dmu = cs / ((double)S * mu) + rg[s] - lm / ((double)S * mu);
+    const double dmu = cs / ((double)S * mu) + rgv(s) - lm / ((double)S * mu);
     const double dx = dmu * sig + (1.0 - sig) / (double)S;
     gl += dx;
     gs += dx * e * sd;
@@ -2319,7 +2317,7 @@ __device__ __forceinline__ void ca_final_gene_body(const double* __restrict__ re
     ls[g] = th; m_ls[g] = m; v_ls[g] = v;
   }
   for (int d = 0; d < D; ++d) {
-    double gv = rg[S + d];
+    double gv = rgv(S + d);
     if (d < K) gv += red_y[(int64_t)g * K + d] - exp((double)vchi[d]) * (double)V[(int64_t)g * D + d];
     else gv += YtX[(int64_t)g * (D - K) + (d - K)];
     g_V[(int64_t)g * D + d] = (float)gv;

@@ -117,7 +117,8 @@ typedef struct ca_options {
   int32_t device;                   /* HIP device ordinal */
   int32_t y_storage;                /* ca_ystore: on-device width of the count matrix */
   int32_t rank, world;              /* cell-sharded data parallel: shard `rank` of `world` */
-  int32_t profile;                  /* bitmask over ca_kernel_id: time those kernel classes with HIP events */
+  int32_t profile;                  /* bits 0..4: bitmask over ca_kernel_id, time those kernel classes with HIP events; bits 8..15: sampling
+                                     * stride - 1 (0 = every launch; an event pair costs the stream 5-6 us, so live measurements sample) */
   uint32_t variant_off;             /* ca_variant bits to switch off (| CA_OPT_VERBOSE); 0 = defaults */
   int32_t tune[8];                  /* ca_tune_id overrides, 0 = heuristic */
   uint32_t variant_on;              /* ca_variant_on bits to switch on; 0 = defaults */
