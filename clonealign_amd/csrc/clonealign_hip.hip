@@ -1166,9 +1166,14 @@ int read_doubles(ca_engine* h, const double* dev, double* out, int n);
 int wait_host_elbo(ca_engine* h, unsigned long long seq, const double* dev, double* out) {
   if (!h->host_dev) return read_doubles(h, dev, out, 1);
   volatile unsigned long long* flag = reinterpret_cast<volatile unsigned long long*>(h->host_pinned + 33);
+  // (the stream is asked only when the flag is overdue: a hipStreamQuery behind freshly queued work makes the runtime put a
+  //  marker packet into the queue, and the update half's first launch then started 5.8 us late in EVERY iteration of ca_run --
+  //  the "unexplained gap" of round 1; host API trace in profiles/r02_ab_ystream.txt section 7)
   unsigned spins = 0;
+  auto t_next = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
   while (*flag != seq) {
-    if ((++spins & 0x3FFu) == 0) {
+    if ((++spins & 0x3FFu) == 0 && std::chrono::steady_clock::now() >= t_next) {
+      t_next = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
       const hipError_t q = hipStreamQuery(h->stream);
       if (q == hipSuccess) {
         if (*flag == seq) break;
