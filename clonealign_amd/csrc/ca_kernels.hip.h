@@ -501,12 +501,22 @@ __device__ __forceinline__ void ca_ypass_body(int blk, const YT* __restrict__ Y,
           float p0 = 0.f, p1 = 0.f;
 #pragma unroll
           for (int j = 0; j < VEC; j += 2) {
+#if !defined(CA_LAB_YSKIP) || (CA_LAB_YSKIP & 1) == 0
             p0 = fmaf(y[j], w[j][k], p0);
             p1 = fmaf(y[j + 1], w[j + 1][k], p1);
+#endif
+#if !defined(CA_LAB_YSKIP) || (CA_LAB_YSKIP & 2) == 0
             acc[j][k] = fmaf(y[j], ps, acc[j][k]);
             acc[j + 1][k] = fmaf(y[j + 1], ps, acc[j + 1][k]);
+#else
+            if (j == 0) acc[0][k] += y[0] + y[5] + y[10] + y[15 % VEC];
+#endif
           }
+#if defined(CA_LAB_YSKIP) && (CA_LAB_YSKIP & 1)
+          const int tot = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, y[3]));   // (timing lab: no row product, no wave sum)
+#else
           const int tot = __builtin_amdgcn_readlane(__builtin_bit_cast(int, ca_wave_sum_lane63(p0 + p1)), 63);
+#endif
           {   // keep[k] lane (i & 63) <- tot  (v_writelane_b32: value and lane select are both scalars, the select goes through m0)
             const int slot = i & 63;
 #pragma clang diagnostic push
@@ -2204,13 +2214,24 @@ __global__ void __launch_bounds__(CA_TB) k_fwd_cell_mix(const float* __restrict_
 struct ca_yride_args {
   const uint8_t* Y; const float* F; int Dstride; const float* V; float* YWpart; float* YTpart;
   int G, Gp, nseg, nrb, TR, nb_main, nb_y;   // nb_y = nb_main + overflow-list blocks
+  int pat_a, pat_b;                          // interleave: pat_a sweep blocks, then pat_b stream blocks, ...
   ca_ovf_args ovf;
 };
-__device__ __forceinline__ bool ca_ride_split(int b, int nf, int ny, int& idx) {   // true: sweep block idx, false: stream block idx
-  const int m = nf < ny ? nf : ny;
-  if (b < 2 * m) { idx = b >> 1; return (b & 1) == 0; }
-  idx = b - m;                       // the tail belongs to whichever kind is left
-  return nf > ny;
+// true: sweep block idx, false: stream block idx.  Periods of pa sweep blocks followed by pb stream blocks while both kinds last,
+// then the sweep's remainder, then the stream's.
+__device__ __forceinline__ bool ca_ride_split(int b, int nf, int ny, int pa, int pb, int& idx) {
+  const int per = pa + pb;
+  const int m = (nf / pa) < (ny / pb) ? (nf / pa) : (ny / pb);
+  if (b < m * per) {
+    const int p = b / per, r = b - p * per;
+    if (r < pa) { idx = p * pa + r; return true; }
+    idx = p * pb + (r - pa);
+    return false;
+  }
+  const int t = b - m * per, restf = nf - m * pa;
+  if (t < restf) { idx = m * pa + t; return true; }
+  idx = m * pb + (t - restf);
+  return false;
 }
 template <int D, int TLB, int TLS>
 __global__ void __launch_bounds__(CA_TB) k_fwd_cell_mix_y(const float* __restrict__ F, const float* __restrict__ etamax2,
@@ -2222,7 +2243,7 @@ __global__ void __launch_bounds__(CA_TB) k_fwd_cell_mix_y(const float* __restric
   constexpr size_t YW_ = sizeof(float) * (CA_TB / 64) * 64 * 17;
   __shared__ __attribute__((aligned(16))) unsigned char smem[FW > YW_ ? FW : YW_];
   int idx;
-  if (!ca_ride_split((int)blockIdx.x, nf, y.nb_y, idx)) {
+  if (!ca_ride_split((int)blockIdx.x, nf, y.nb_y, y.pat_a, y.pat_b, idx)) {
     ca_ypass_body<uint8_t, 1, 0>(idx, y.Y, y.F, y.Dstride, y.V, 0, y.YWpart, y.YTpart, N, y.G, y.Gp, y.nseg, y.nrb, y.TR, 1, y.ovf, y.nb_main,
                                  reinterpret_cast<float (*)[64][17]>(smem));
     return;

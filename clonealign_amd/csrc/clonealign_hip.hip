@@ -1040,6 +1040,12 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
       ya.ovf.chunk_start = h->ovf_chunk_start; ya.ovf.row2 = h->ovf_row2; ya.ovf.val2 = h->ovf_val2; ya.ovf.csum = h->ovf_csum; ya.ovf.nchunk = h->n_ovf_chunk;
       ya.nb_y += ya.ovf.nb_rows + ya.ovf.nb_chunks;
     }
+    // Interleave of the two kinds in dispatch order.  Blocks go round-robin over the 8 XCDs, so a period that divides 8 (the
+    // obvious even / odd split) puts ALL sweep blocks on four XCDs and all stream blocks on the other four; two sweep blocks per
+    // stream block mixes them on every CU: cfg-3 2795 -> 3008 it/s, 12.5k cells 10.9k -> 12.1k, cfg-2 16.3k -> 17.9k
+    // (profiles/r02_ab_ystream.txt section 8).
+    ya.pat_a = 2; ya.pat_b = 1;
+    if (debug_env()) { if (const char* e = getenv("CA_RIDE_PAT")) { int a_ = 1, b_ = 1; if (sscanf(e, "%d,%d", &a_, &b_) == 2 && a_ > 0 && b_ > 0) { ya.pat_a = a_; ya.pat_b = b_; } } }
     const dim3 grid((unsigned)(h->ncblk_f + ya.nb_y));
 #define CA_FCY(DV, TLBV)                                                                                                              \
   LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell_mix_y<DV, TLBV, 2>), grid, dim3(CA_TB), 0, h->stream, h->F, h->etamax2, h->Vs, h->Mq, \
