@@ -188,7 +188,7 @@ def main():
                          shape=(n_loc, G), device=local_rank, y_storage=args.y_storage, rank=rank, world=world, profile=0,
                          variant_off=tuple(v for v in args.variant_off.split(",") if v),
                          variant_on=tuple(v for v in args.variant_on.split(",") if v),
-                         tune={k: int(v) for k, v in (kv.split("=") for kv in args.tune.split(",") if kv)}, **kw)
+                         tune={k: (v if ":" in v else int(v)) for k, v in (kv.split("=") for kv in args.tune.split(",") if kv)}, **kw)
 
     collective, tried = "none", []
     if world == 1:

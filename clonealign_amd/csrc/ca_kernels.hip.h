@@ -501,22 +501,12 @@ __device__ __forceinline__ void ca_ypass_body(int blk, const YT* __restrict__ Y,
           float p0 = 0.f, p1 = 0.f;
 #pragma unroll
           for (int j = 0; j < VEC; j += 2) {
-#if !defined(CA_LAB_YSKIP) || (CA_LAB_YSKIP & 1) == 0
             p0 = fmaf(y[j], w[j][k], p0);
             p1 = fmaf(y[j + 1], w[j + 1][k], p1);
-#endif
-#if !defined(CA_LAB_YSKIP) || (CA_LAB_YSKIP & 2) == 0
             acc[j][k] = fmaf(y[j], ps, acc[j][k]);
             acc[j + 1][k] = fmaf(y[j + 1], ps, acc[j + 1][k]);
-#else
-            if (j == 0) acc[0][k] += y[0] + y[5] + y[10] + y[15 % VEC];
-#endif
           }
-#if defined(CA_LAB_YSKIP) && (CA_LAB_YSKIP & 1)
-          const int tot = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, y[3]));   // (timing lab: no row product, no wave sum)
-#else
           const int tot = __builtin_amdgcn_readlane(__builtin_bit_cast(int, ca_wave_sum_lane63(p0 + p1)), 63);
-#endif
           {   // keep[k] lane (i & 63) <- tot  (v_writelane_b32: value and lane select are both scalars, the select goes through m0)
             const int slot = i & 63;
 #pragma clang diagnostic push

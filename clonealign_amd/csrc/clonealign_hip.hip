@@ -1045,7 +1045,9 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
     // stream block mixes them on every CU: cfg-3 2795 -> 3008 it/s, 12.5k cells 10.9k -> 12.1k, cfg-2 16.3k -> 17.9k
     // (profiles/r02_ab_ystream.txt section 8).
     ya.pat_a = 2; ya.pat_b = 1;
-    if (debug_env()) { if (const char* e = getenv("CA_RIDE_PAT")) { int a_ = 1, b_ = 1; if (sscanf(e, "%d,%d", &a_, &b_) == 2 && a_ > 0 && b_ > 0) { ya.pat_a = a_; ya.pat_b = b_; } } }
+    if (h->opt.ride_pattern > 0 && (h->opt.ride_pattern >> 8) > 0 && (h->opt.ride_pattern & 255) > 0) {
+      ya.pat_a = h->opt.ride_pattern >> 8; ya.pat_b = h->opt.ride_pattern & 255;
+    }
     const dim3 grid((unsigned)(h->ncblk_f + ya.nb_y));
 #define CA_FCY(DV, TLBV)                                                                                                              \
   LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell_mix_y<DV, TLBV, 2>), grid, dim3(CA_TB), 0, h->stream, h->F, h->etamax2, h->Vs, h->Mq, \
@@ -1717,8 +1719,9 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   CACK(dalloc(h, &h->Zpart, (int64_t)S * h->gsplit * h->nchunk * Nn * CA_CW));
   CACK(dalloc(h, &h->coef, (int64_t)S * h->nchunk * Nn * CA_CW));
   CACK(dalloc(h, &h->scratch, Nn * C));
-  CACK(dalloc(h, &h->cell_part, (int64_t)std::max(h->ncblk, h->ncblk_f) * (3 + C)));
-  CACK(dalloc(h, &h->ee_partB, (int64_t)std::max(h->ncblk, h->ncblk_f)));
+  const int64_t n_cpart = std::max(h->ncblk, h->ncblk_f);
+  CACK(dalloc(h, &h->cell_part, n_cpart * (3 + C)));
+  CACK(dalloc(h, &h->ee_partB, n_cpart));
   CACK(dalloc(h, &h->gpart, (int64_t)std::max(h->csplit, h->csplit_m) * G * (S + D)));
   CACK(dalloc(h, &h->dFpart, (int64_t)std::max(h->ntile, h->nwt) * Nn * std::max(D, 1)));
   CACK(dalloc(h, &h->YWpart, (int64_t)(h->nseg + 1) * Nn * std::max(K, 1)));

@@ -51,7 +51,7 @@ class CaOptions(C.Structure):
                 ("adam_eps", C.c_double), ("seed", C.c_uint64), ("device", C.c_int32),
                 ("y_storage", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32), ("profile", C.c_int32),
                 ("variant_off", C.c_uint32), ("tune", C.c_int32 * 8), ("variant_on", C.c_uint32),
-                ("reserved", C.c_int32 * 5)]
+                ("ride_pattern", C.c_int32), ("reserved", C.c_int32 * 4)]
 
 
 class CaInfo(C.Structure):
@@ -254,7 +254,10 @@ class HipEngine:
         opt.variant_off = (voff | (OPT_VERBOSE if verbose else 0)) & 0xFFFFFFFF
         opt.variant_on = int(variant_on) if isinstance(variant_on, int) else sum(VARIANTS_ON[v] for v in variant_on)
         for k, v in (tune or {}).items():
-            opt.tune[TUNE[k]] = int(v)
+            if k == "ride_pattern":       # (a << 8) | b, or "a:b"
+                opt.ride_pattern = (lambda a, b: (int(a) << 8) | int(b))(*str(v).split(":")) if ":" in str(v) else int(v)
+            else:
+                opt.tune[TUNE[k]] = int(v)
         rc = self.lib.ca_create(C.byref(prob), C.byref(opt), C.byref(self.h))
         if rc != CA_OK:
             msg = (self.lib.ca_last_error(None) or b"").decode()

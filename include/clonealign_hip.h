@@ -122,7 +122,9 @@ typedef struct ca_options {
   uint32_t variant_off;             /* ca_variant bits to switch off (| CA_OPT_VERBOSE); 0 = defaults */
   int32_t tune[8];                  /* ca_tune_id overrides, 0 = heuristic */
   uint32_t variant_on;              /* ca_variant_on bits to switch on; 0 = defaults */
-  int32_t reserved[5];
+  int32_t ride_pattern;             /* 0 = default; else (a << 8) | b: a forward-sweep blocks, then b Y-stream blocks, ... in the dispatch
+                                     * order of the merged launch (k_fwd_cell_mix_y); periods that divide 8 put the two kinds on disjoint XCDs */
+  int32_t reserved[4];
 } ca_options;
 /* (The same switches can be set from the environment -- CA_FUSED=0, CA_CSPLIT=12, ... -- but ONLY when
  *  CLONEALIGN_DEBUG_ENV is set: the library reads no configuration from the process environment otherwise.) */
