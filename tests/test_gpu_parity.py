@@ -503,3 +503,35 @@ def test_fixed_point_images_follow_the_parameter_scale():
                 assert np.array_equal(g1[n], gm[n]), n      # same fixed-point images, exact integer sums: the two MFMA forms agree bit for bit
     finally:
         mf.close(); va.close(); m1.close()
+
+
+@pytest.mark.parametrize("shape", [dict(N=3000, G=700, C=5, K=1), dict(N=40_100, G=1100, C=8, K=1), dict(N=33, G=1030, C=3, K=1)])
+def test_riding_dispatch_order_does_not_change_a_single_bit(shape):
+    """The Y stream's blocks ride inside the forward sweep's launch in a dispatch order (ca_options.ride_pattern; default two sweep
+    blocks per stream block) that decides only WHERE and WHEN a block runs: every pattern -- also ones longer than either list of
+    blocks, and the even / odd split the default replaced -- must give the loop's results bit for bit, on small grids (32-cell
+    blocks only), on grids with two sweep block sizes, and on a grid with more stream blocks than sweep blocks."""
+    from clonealign_amd.engine import HipEngine
+    case = make_case(seed=77, **shape)
+    rng = np.random.default_rng(3)
+    idx = rng.integers(0, case["Y"].size, size=max(3, case["Y"].size // 5000))
+    case["Y"].reshape(-1)[idx] += rng.integers(200, 900, size=idx.size)            # overflow-list blocks ride too
+    G = case["Y"].shape[1]
+    epss = np.stack([eps_for(1, G, 300 + i) for i in range(10)])
+    ref = None
+    for pat in (None, "1:1", "3:2", "16:8", "1:200", "255:1"):
+        eng = HipEngine(**case, tune=({} if pat is None else {"ride_pattern": pat}))
+        try:
+            assert eng.info()["y_ride"] == 1
+            eng.gamma_init(eps_for(1, G, 0))
+            last = eng.iterate(5, epss)
+            out = (last, eng.get_state(), eng.get("clone_probs"))
+        finally:
+            eng.close()
+        if ref is None:
+            ref = out
+            continue
+        assert out[0] == ref[0], pat
+        for n in ref[1]:
+            assert np.array_equal(out[1][n], ref[1][n]), (pat, n)
+        assert np.array_equal(out[2], ref[2]), pat
