@@ -805,7 +805,7 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
   const int W_ = h->S + h->D;
   bool merged = false;
   if (h->bwd_mfma) {
-    constexpr int TL = 4;
+    constexpr int TL = CA_BWD_TL;
     const int xb = cdiv(h->nwt, CA_TB / 64);
     // A pending monitor pass's tail rides on the sweep as one extra block (its fp64 chains hide under 130 us of sweep):
     // whole when unsharded; sharded, only the local sums of the cell / psi.(YW) partials -- ONE all-reduce per iteration
@@ -1596,13 +1596,13 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     h->bwd_mfma = exact && (D == 1 || D == 2) && h->nchunk == 1 && variant_on(h, CA_VAR_BWD_MFMA, "CA_BWD_MFMA");
     h->N16 = (Nn + 15) / 16 * 16;
     if (h->bwd_mfma) {
-      h->nwt = cdiv(G, 4 * 16);
+      h->nwt = cdiv(G, CA_BWD_TL * 16);
       const int xb = cdiv(h->nwt, CA_TB / 64);
       {
         // resident blocks per CU from the compiler's register count (LDS, 16 B per cell of the slice, is not the limit
         // at the slice lengths this produces); one or two full rounds instead of "about 8 blocks per CU"
         int per_cu = 4;
-        const void* bfn = D == 1 ? (const void*)k_bwd_mfma<4, 1> : (const void*)k_bwd_mfma<4, 2>;
+        const void* bfn = D == 1 ? (const void*)k_bwd_mfma<CA_BWD_TL, 1> : (const void*)k_bwd_mfma<CA_BWD_TL, 2>;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bfn, CA_TB, 16 * 1024) != hipSuccess || per_cu < 1)
           per_cu = 4;
         (void)hipGetLastError();
