@@ -252,15 +252,13 @@ def main():
     if world > 1:
         assert info["transport_name"] == {"p2p": "p2p", "rccl": "rccl"}.get(collective, "host"), info["transport_name"]
         assert info["red_n"] == sharding.reduce_plan(G, C, K, 0, 1)["total"], (info["red_n"], sharding.reduce_plan(G, C, K, 0, 1))
-    Ysample = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        n_cpu = args.cpu_sample_cells
-        if n_cpu <= 0:
-            import psutil
-            n_cpu = n_loc if psutil.virtual_memory().available > 10 * 8 * n_loc * G else 65536
-        Ysample = Yd[:min(n_cpu, n_loc)].cpu().numpy().astype(np.float64)
-    del Yd
-    torch.cuda.empty_cache()
+    # The CPU baseline's copy of the counts is taken AFTER the GPU measurements (the generated matrix stays on the device until
+    # then): fetching and converting 2 GB here left the GPU idle for seconds in front of the timed region, and W = 5 warm-up
+    # iterations (1.7 ms) do not bring its clocks back -- the driver-style run read 3 % low whenever the baseline was on.
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    if not want_cpu:
+        del Yd
+        torch.cuda.empty_cache()
 
     rng = np.random.default_rng(args.seed + 2 + 0)   # same eps on every rank
     eps0 = rng.normal(size=(1, G)).astype(np.float32)
@@ -402,7 +400,13 @@ def main():
         }
         if mon_us is not None:
             out["monitor_pass_us_with_collective"] = mon_us
-        if Ysample is not None:
+        if want_cpu:
+            n_cpu = args.cpu_sample_cells
+            if n_cpu <= 0:
+                import psutil
+                n_cpu = n_loc if psutil.virtual_memory().available > 10 * 8 * n_loc * G else 65536
+            Ysample = Yd[:min(n_cpu, n_loc)].cpu().numpy().astype(np.float64)
+            del Yd
             out["cpu_baseline"] = cpu_baseline(Ysample, aux["L"], psi0, loc0, K, N)
             try:
                 out["cpu_ref_dataflow"] = cpu_ref_dataflow()
