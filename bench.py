@@ -137,6 +137,8 @@ def main():
     ap.add_argument("--allow-host-fallback", action="store_true",
                     help="at --gpus > 1, let the run continue on the gloo host all-reduce when no device transport comes up "
                          "(the result is then NOT a measurement of the device data path)")
+    ap.add_argument("--allow-foreign-lib", action="store_true",
+                    help="run a library whose ca_build_id() is not the tree's (CLONEALIGN_HIP_LIB timing builds; labelled in the output)")
     ap.add_argument("--no-live-events", action="store_true",
                     help="A/B only: no HIP events around the dominant kernel in the timed region (roofline then comes from the warm-up)")
     ap.add_argument("--variant-off", default="", help="comma-separated engine variants to switch off (engine.VARIANTS), for A/B runs")
@@ -156,11 +158,18 @@ def main():
     import torch
     import torch.distributed as dist
     from clonealign_amd import engine as eng_mod
-    from clonealign_amd import sharding, synth
+    from clonealign_amd import sharding
+    import synth_data as synth
     from clonealign_amd.engine import HipEngine, comm_unique_id
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+    # the number of record must come from the sources in this tree: a stale .so, or a timing build reached through
+    # CLONEALIGN_HIP_LIB (tools/lab_ab.sh builds some that give wrong results on purpose), is refused
+    foreign = eng_mod.build_id() != eng_mod.source_build_id()
+    if foreign and not args.allow_foreign_lib:
+        raise SystemExit(f"bench.py: the engine library's build id {eng_mod.build_id()} is not the tree's {eng_mod.source_build_id()} "
+                         "(stale build or CLONEALIGN_HIP_LIB override); rebuild, or pass --allow-foreign-lib for a labelled A/B run")
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -310,6 +319,37 @@ def main():
             eng.elbo(eps0)
         eng.synchronize()
         mon_us = (time.perf_counter() - t1) / 20 * 1e6
+    # the collective on its own: 200 back-to-back all-reduces of the train pass's payload (15 011 doubles at cfg-4) on the
+    # transport in use and -- when it also comes up on every rank -- on RCCL, between two HIP events on the engine's stream
+    ar_us = None
+    if world > 1 and collective in ("p2p", "rccl"):
+        ar_us = {"payload_doubles": int(info["red_n"]), "calls": 200}
+        try:
+            ar_us[collective] = eng.comm_benchmark(collective, 200)
+            if collective == "p2p":
+                box, why = [None], ""
+                try:
+                    if rank == 0:
+                        box = [comm_unique_id()]
+                except Exception as ex:  # noqa: BLE001
+                    why = str(ex)
+                dist.broadcast_object_list(box, src=0)
+                ok = 0
+                if box[0] is not None:
+                    try:
+                        eng.comm_init(box[0])
+                        ok = 1
+                    except Exception as ex:  # noqa: BLE001
+                        why = str(ex)
+                flag = torch.tensor([ok], dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag[0]) == 1:
+                    ar_us["rccl"] = eng.comm_benchmark("rccl", 200)
+                else:
+                    ar_us["rccl"] = None
+                    ar_us["rccl_unavailable"] = why[:200]
+        except Exception as ex:  # noqa: BLE001
+            ar_us["error"] = str(ex)[:200]
     # second half of the metric ("wall-clock to convergence"): the reference's default fit FROM ITS INITIAL VALUES (ca_reinit:
     # variables, Adam slots and beta powers reset), max_iter = 200, rel_tol = 1e-6, through ca_run (host reads the ELBO every
     # iteration for the window-10 stop rule), then the 20 final ELBOs
@@ -366,7 +406,7 @@ def main():
                        "bwd_mfma": bool(info.get("bwd_mfma")), "y_mfma": bool(info.get("y_mfma")),
                        "parallelism": f"cells/{world}" if world > 1 else "single", "collective": collective,
                        "collectives_tried": tried, "allreduce_doubles_per_train_pass": int(info["red_n"]),
-                       "build_id": build},
+                       "build_id": build, **({"foreign_library": True} if foreign else {})},
             "repeats": {"n": len(regions), "ms_per_step_median": step_s * 1e3, "ms_per_step_min": min(regions) / args.steps * 1e3,
                         "ms_per_step_max": max(regions) / args.steps * 1e3,
                         "what": "the --steps long region timed this many times (barrier + synchronize on both sides each time); "
@@ -400,6 +440,8 @@ def main():
         }
         if mon_us is not None:
             out["monitor_pass_us_with_collective"] = mon_us
+        if ar_us is not None:
+            out["allreduce_us"] = ar_us
         if want_cpu:
             n_cpu = args.cpu_sample_cells
             if n_cpu <= 0:

@@ -470,10 +470,17 @@ __device__ __forceinline__ void ca_ypass_body(int blk, const YT* __restrict__ Y,
       const int64_t r = r0 + (i < nrows ? i : (nrows > 0 ? nrows - 1 : 0));
       psv[k][hh] = F[r * Dstride + koff + k];
     }
+#if defined(CA_LAB_YL2)   // timing lab only (wrong results): every strip reads the first 512 rows -- the stream's loads hit L2 / MALL
+  const char* base = reinterpret_cast<const char*>(Y) + (r0 & 511) * (int64_t)Gp * (int64_t)sizeof(YT);
+#else
   const char* base = reinterpret_cast<const char*>(Y) + r0 * (int64_t)Gp * (int64_t)sizeof(YT);   // scalar
+#endif
   const int voff = col0 * (int)sizeof(YT);                                                          // per lane
   const int64_t pitch = (int64_t)Gp * (int64_t)sizeof(YT);
-  constexpr int U = 4;   // rows per group; two groups alternate (2 x U 16-byte loads in flight per lane)
+#ifndef CA_YP_U
+#define CA_YP_U 4
+#endif
+  constexpr int U = CA_YP_U;   // rows per group; two groups alternate (2 x U 16-byte loads in flight per lane)
   auto fetch = [&](uint4 (&buf)[U], int i0) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -500,12 +507,19 @@ __device__ __forceinline__ void ca_ypass_body(int blk, const YT* __restrict__ Y,
           const float ps = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, i < 64 ? psv[k][0] : psv[k][1]), i & 63));
           float p0 = 0.f, p1 = 0.f;
 #pragma unroll
+#if defined(CA_LAB_YSKIP) && CA_LAB_YSKIP >= 2   // timing lab only (wrong results): no product at all, the loaded dwords are kept alive
+          for (int j = 0; j < VEC; j += 4) p0 += y[j];
+          acc[0][k] += ps;
+#else
           for (int j = 0; j < VEC; j += 2) {
             p0 = fmaf(y[j], w[j][k], p0);
             p1 = fmaf(y[j + 1], w[j + 1][k], p1);
+#if !defined(CA_LAB_YSKIP)                       // (CA_LAB_YSKIP = 1: no column product)
             acc[j][k] = fmaf(y[j], ps, acc[j][k]);
             acc[j + 1][k] = fmaf(y[j + 1], ps, acc[j + 1][k]);
+#endif
           }
+#endif
           const int tot = __builtin_amdgcn_readlane(__builtin_bit_cast(int, ca_wave_sum_lane63(p0 + p1)), 63);
           {   // keep[k] lane (i & 63) <- tot  (v_writelane_b32: value and lane select are both scalars, the select goes through m0)
             const int slot = i & 63;
@@ -2226,8 +2240,11 @@ __device__ __forceinline__ bool ca_ride_split(int b, int nf, int ny, int pa, int
   idx = m * pb + (t - restf);
   return false;
 }
+#ifndef CA_RIDE_WAVES
+#define CA_RIDE_WAVES 1   // (lab: minimum waves per SIMD the merged launch's register budget is set for)
+#endif
 template <int D, int TLB, int TLS>
-__global__ void __launch_bounds__(CA_TB) k_fwd_cell_mix_y(const float* __restrict__ F, const float* __restrict__ etamax2,
+__global__ void __launch_bounds__(CA_TB, CA_RIDE_WAVES) k_fwd_cell_mix_y(const float* __restrict__ F, const float* __restrict__ etamax2,
                                                           const float* __restrict__ Vs, const unsigned short* __restrict__ Mq,
                                                           ca_cell_ptrs p, const float* __restrict__ alpha_u,
                                                           double* __restrict__ cell_part, int64_t N, int C, int K, int nk, int nbig,
@@ -2517,6 +2534,8 @@ struct ca_p2p_args {
   unsigned long long seq;
   unsigned int* arrive;          // device counter, monotonic: block arrivals of all calls so far
   unsigned int arrive_target;    // value of *arrive when every block of this call has published
+  unsigned long long* err;       // pinned host word of this rank: 0, or the sequence number of the first call that gave up
+  unsigned long long timeout_ticks;   // s_memrealtime ticks (100 MHz) a block waits for the peers' flags before it gives up
 };
 __device__ __forceinline__ double* ca_p2p_inbox(double* slab, int64_t cap, int world, int par, int src) {
   return slab + ((int64_t)par * world + src) * cap;
@@ -2524,7 +2543,18 @@ __device__ __forceinline__ double* ca_p2p_inbox(double* slab, int64_t cap, int w
 __device__ __forceinline__ unsigned long long* ca_p2p_flag(double* slab, int64_t cap, int world, int par, int src) {
   return reinterpret_cast<unsigned long long*>(slab + 2 * (int64_t)world * cap) + (int64_t)par * world + src;
 }
+// The wait for the peers is BOUNDED: a dead or desynchronised peer must end in CA_ERR_COMM on the host, not in a GPU spin that
+// nothing can interrupt.  A block that has waited timeout_ticks writes the call's sequence number to the rank's error word
+// (pinned host memory, checked by the host at every synchronisation point) and returns without touching buf; every later
+// call on a failed transport returns at once, so work already queued behind it drains quickly.  Recovery = a fresh engine.
 __global__ void __launch_bounds__(CA_TB) k_p2p_allreduce(double* __restrict__ buf, int64_t n, ca_p2p_args a) {
+  __shared__ unsigned int last, bad;
+  if (threadIdx.x == 0) {
+    bad = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull;
+    last = 0u;
+  }
+  __syncthreads();
+  if (bad) return;
   const int par = (int)(a.seq & 1ull);
   const int64_t i0 = (int64_t)blockIdx.x * CA_TB + threadIdx.x, stride = (int64_t)gridDim.x * CA_TB;
   // 1. publish: my summands into my inbox on every rank (plain stores into fine-grained memory; xGMI writes for remote peers)
@@ -2534,7 +2564,6 @@ __global__ void __launch_bounds__(CA_TB) k_p2p_allreduce(double* __restrict__ bu
   }
   __threadfence_system();
   __syncthreads();
-  __shared__ unsigned int last;
   if (threadIdx.x == 0) last = atomicAdd(a.arrive, 1u) + 1u == a.arrive_target;
   __syncthreads();
   if (last) {   // every block's stores are out (each fenced before its arrival): raise my flag on every rank
@@ -2542,13 +2571,24 @@ __global__ void __launch_bounds__(CA_TB) k_p2p_allreduce(double* __restrict__ bu
     if ((int)threadIdx.x < a.world)
       __hip_atomic_store(ca_p2p_flag(a.peers[threadIdx.x], a.cap, a.world, par, a.rank), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  // 2. wait for the W flags of MY slab, one lane per source rank
+  // 2. wait for the W flags of MY slab, one lane per source rank (world <= CA_TB, checked by ca_p2p_export)
   double* mine = a.peers[a.rank];
   if ((int)threadIdx.x < a.world) {
     unsigned long long* f = ca_p2p_flag(mine, a.cap, a.world, par, threadIdx.x);
-    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) __builtin_amdgcn_s_sleep(2);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
+      __builtin_amdgcn_s_sleep(2);
+      if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) { atomicOr(&bad, 1u); break; }
+    }
   }
   __syncthreads();
+  if (bad) {
+    if (threadIdx.x == 0) {
+      unsigned long long expect = 0ull;
+      __hip_atomic_compare_exchange_strong(a.err, &expect, a.seq, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
   __threadfence_system();
   // 3. the same W additions in the same order on every rank
   for (int64_t i = i0; i < n; i += stride) {
@@ -2568,5 +2608,45 @@ __global__ void __launch_bounds__(CA_YM_TB, CA_YS_WAVES) k_ys_mfma_ovf(const uin
     ca_ovf_chunks_body(blockIdx.x - nb_main, ovf.chunk_start, ovf.row2, ovf.val2, F, Df, ovf.csum, ovf.nchunk, 1, 0);
     return;
   }
-  ca_ys_mfma_body((int)blockIdx.x, Ys, Wr, Pr, N, Gp, RS, YWi, YTi);
+  extern __shared__ __attribute__((aligned(16))) unsigned char ca_ys_dyn[];
+  ca_ys_mfma_body<CA_YS_DEPTH>((int)blockIdx.x, Ys, Wr, Pr, N, Gp, RS, YWi, YTi, ca_ys_dyn);
+}
+
+// The one-copy int8 matrix-core stream RIDING on the forward sweep's launch (round 3).  The vector stream of k_fwd_cell_mix_y
+// spends 3.5 vector instructions per count in a launch whose vector pipes are full (profiles/r02_v2_sq_counters.json: 44 % of
+// the merged launch's VALU instructions are the stream's), and a matrix-core instruction occupies the same issue pipe as the
+// vector ALU on this part (tools/overlap_lab.hip: MFMA + 8 v_fmac = 16 + 8 x 2.3 cycles, also across waves) -- so what counts
+// is issue cycles per count: 123 per KiB for the vector stream, 8 MFMAs per 4 KiB = 32 per KiB plus the LDS transit here.
+// Same block mix and dispatch order as k_fwd_cell_mix_y; stream blocks are ca_ys_mfma_body's (DEPTH pieces in flight per wave),
+// the overflow list's gene-side chunk blocks follow them.
+struct ca_ysride_args {
+  const uint8_t* Ys; const uint4* Wr; const uint4* Pr; int* YWi; int* YTi;
+  const float* F; int Df;
+  int Gp, RS, nb_main, nb_y;   // nb_y = nb_main + overflow-chunk blocks
+  int pat_a, pat_b;
+  ca_ovf_args ovf;
+};
+template <int D, int TLB, int TLS, int DEPTH>
+__global__ void __launch_bounds__(CA_TB, DEPTH == 1 ? 4 : 3) k_fwd_cell_mix_ys(const float* __restrict__ F, const float* __restrict__ etamax2,
+                                                           const float* __restrict__ Vs, const unsigned short* __restrict__ Mq,
+                                                           ca_cell_ptrs p, const float* __restrict__ alpha_u,
+                                                           double* __restrict__ cell_part, int64_t N, int C, int K, int nk, int nbig,
+                                                           int nf, ca_ysride_args y) {
+  constexpr size_t FW = sizeof(ca_f32x4) * 4 * TLB * 64 + sizeof(double) * (CA_TB + 64);
+  constexpr size_t SM = FW > (size_t)CA_YS_LDS_BYTES ? FW : (size_t)CA_YS_LDS_BYTES;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SM];
+  int idx;
+  if (!ca_ride_split((int)blockIdx.x, nf, y.nb_y, y.pat_a, y.pat_b, idx)) {
+    if (idx >= y.nb_main) ca_ovf_chunks_body(idx - y.nb_main, y.ovf.chunk_start, y.ovf.row2, y.ovf.val2, y.F, y.Df, y.ovf.csum, y.ovf.nchunk, 1, 0);
+    else ca_ys_mfma_body<DEPTH>(idx, y.Ys, y.Wr, y.Pr, N, y.Gp, y.RS, y.YWi, y.YTi, smem);
+    return;
+  }
+  ca_f32x4* comb = reinterpret_cast<ca_f32x4*>(smem);
+  double* sm = reinterpret_cast<double*>(smem + sizeof(ca_f32x4) * 4 * TLB * 64);
+  double* la = sm + CA_TB;
+  ca_log_softmax_alpha(alpha_u, C, la);
+  if (nbig > 0 && idx >= nbig)
+    ca_fwd_cell_body<D, TLS>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)nbig * (TLB * 16) + (int64_t)(idx - nbig) * (TLS * 16), idx, comb, sm, la);
+  else
+    ca_fwd_cell_body<D, TLB>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)idx * (TLB * 16), idx, comb, sm, la);
 }

@@ -346,13 +346,14 @@ __device__ __forceinline__ uint4 ca_and4(uint4 a, unsigned m) { return (uint4){a
 #ifndef CA_YS_WAVES
 #define CA_YS_WAVES 3   // waves per SIMD the register budget is set for
 #endif
+template <int DEPTH = CA_YS_DEPTH>
 __device__ __forceinline__ void ca_ys_mfma_body(int blk, const uint8_t* __restrict__ Ys, const uint4* __restrict__ Wr,
                                                 const uint4* __restrict__ Pr, int64_t N, int Gp,
                                                 int RS /* cells per strip, multiple of 64 */, int* __restrict__ YWi,
-                                                int* __restrict__ YTi) {
-  constexpr int DEPTH = CA_YS_DEPTH, NP = CA_YS_GW / 64;
+                                                int* __restrict__ YTi,
+                                                unsigned char* ca_ys_lds /* 16-byte aligned, CA_YS_LDS_BYTES: [4 waves][64][CA_YS_PITCH], reused for the combine */) {
+  constexpr int NP = CA_YS_GW / 64;
   static_assert(NP % DEPTH == 0, "pieces per cell step must be a multiple of the pipeline depth");
-  extern __shared__ __attribute__((aligned(16))) unsigned char ca_ys_lds[];   // [4 waves][64][CA_YS_PITCH], reused for the combine
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
   const int nseg = Gp / CA_YS_GW;
   const int rg = blk / nseg, seg = blk - rg * nseg;
@@ -424,18 +425,14 @@ __device__ __forceinline__ void ca_ys_mfma_body(int blk, const uint8_t* __restri
   case B:                                                                  \
     _Pragma("unroll") for (int d_ = 0; d_ < DEPTH; ++d_) acc_yt[B + d_] += dd[d_]; \
     break;
-    switch (gb0) {
-      CA_YS_ADD(0)
-#if CA_YS_DEPTH <= 4
-      CA_YS_ADD(4)
-#endif
-#if CA_YS_DEPTH <= 2
-      CA_YS_ADD(2) CA_YS_ADD(6)
-#endif
-#if CA_YS_DEPTH == 1
-      CA_YS_ADD(1) CA_YS_ADD(3) CA_YS_ADD(5) CA_YS_ADD(7)
-#endif
-      default: break;
+    if constexpr (DEPTH == 1) {
+      switch (gb0) { CA_YS_ADD(0) CA_YS_ADD(1) CA_YS_ADD(2) CA_YS_ADD(3) CA_YS_ADD(4) CA_YS_ADD(5) CA_YS_ADD(6) CA_YS_ADD(7) default: break; }
+    } else if constexpr (DEPTH == 2) {
+      switch (gb0) { CA_YS_ADD(0) CA_YS_ADD(2) CA_YS_ADD(4) CA_YS_ADD(6) default: break; }
+    } else if constexpr (DEPTH == 4) {
+      switch (gb0) { CA_YS_ADD(0) CA_YS_ADD(4) default: break; }
+    } else {
+      switch (gb0) { CA_YS_ADD(0) default: break; }
     }
 #undef CA_YS_ADD
     if (gb0 + DEPTH == NP) {   // (uniform) the cell step is complete: lane (column 4t + p, q) holds cells 16 t + 4 q + r, digit p
@@ -466,7 +463,8 @@ __device__ __forceinline__ void ca_ys_mfma_body(int blk, const uint8_t* __restri
 __global__ void __launch_bounds__(CA_YM_TB, CA_YS_WAVES) k_ys_mfma(const uint8_t* __restrict__ Ys, const uint4* __restrict__ Wr,
                                                                    const uint4* __restrict__ Pr, int64_t N, int Gp, int RS,
                                                                    int* __restrict__ YWi, int* __restrict__ YTi) {
-  ca_ys_mfma_body((int)blockIdx.x, Ys, Wr, Pr, N, Gp, RS, YWi, YTi);
+  extern __shared__ __attribute__((aligned(16))) unsigned char ca_ys_dyn[];
+  ca_ys_mfma_body<CA_YS_DEPTH>((int)blockIdx.x, Ys, Wr, Pr, N, Gp, RS, YWi, YTi, ca_ys_dyn);
 }
 constexpr int CA_YS_LDS_BYTES = 4 * (CA_YS_GW / 64) * 64 * 4 * 4;   // the combine buffer (32 KB) >= 4 x 64 x CA_YS_PITCH
 

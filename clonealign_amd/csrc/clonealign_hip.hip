@@ -71,10 +71,15 @@ struct ca_p2p {
   double** peers_dev = nullptr;          // device array [world]
   unsigned int* arrive = nullptr; unsigned int arrived = 0;
   unsigned long long seq = 0;
-  bool connected = false;
+  bool mapped = false;                   // ca_p2p_connect has mapped every peer's slab
+  bool connected = false;                // ca_p2p_commit(1): the transport is the engine's all-reduce
+  unsigned long long* err_host = nullptr;   // pinned: 0, or the sequence number of the first call whose wait for a peer ran out
+  unsigned long long* err_dev = nullptr;    // the same word as the device sees it
+  unsigned long long timeout_ticks = 0;     // bound of the device-side wait, s_memrealtime ticks (100 MHz)
 };
 struct ca_p2p_wire {   // what travels in a CA_P2P_HANDLE_BYTES handle
   hipIpcMemHandle_t mem; int64_t cap; int32_t rank, world, device, pid;
+  uint64_t local_ptr;   // the slab's address in the exporting process: peers of the SAME process take it as it is (an IPC handle cannot be opened by the process that made it)
 };
 static_assert(sizeof(ca_p2p_wire) <= CA_P2P_HANDLE_BYTES, "handle too small");
 
@@ -135,6 +140,7 @@ struct ca_engine {
   float *Mb2 = nullptr, *mu32B = nullptr, *Zpart2 = nullptr; double* gene_partB = nullptr;
   bool y_defer = false;
   bool ride_ok = false;   // the Y stream's blocks ride on the forward sweep's launch (k_fwd_cell_mix_y) instead of a side stream
+  bool ride_ys = false;   // ... as the one-copy int8 matrix-core stream (k_fwd_cell_mix_ys)
   bool fold_gsum = false, fold_now = false;   // small problems: the backward sweep's partials are summed inside k_final_gene
   // per-gene prologue of the next fused pass, computed ahead by the train pass before it (ca_pre_args): the loops announce
   // the next (monitor, train) eps slots in hint_*, train_update fills the alternate partial buffers, fused_pass swaps them in
@@ -193,6 +199,23 @@ namespace {
     if (rc_ != CA_OK) return rc_; \
   } while (0)
 
+// The peer-to-peer all-reduce gives up inside the kernel when a peer does not show (k_p2p_allreduce); the host learns it here,
+// at every point where it has waited for the stream anyway.
+int comm_check(ca_engine* h) {
+  if (h->p2p && h->p2p->err_host && *reinterpret_cast<volatile unsigned long long*>(h->p2p->err_host) != 0ull) {
+    h->err = "peer-to-peer all-reduce #" + std::to_string(*reinterpret_cast<volatile unsigned long long*>(h->p2p->err_host)) +
+             ": a peer's flag did not arrive within the time limit (peer lost or out of step); this engine's transport is dead -- "
+             "destroy the engine and start over in a fresh process";
+    return CA_ERR_COMM;
+  }
+  return CA_OK;
+}
+#define SYNC(h)                                          \
+  do {                                                   \
+    HIPCK(h, hipStreamSynchronize((h)->stream));         \
+    CACK(comm_check(h));                                 \
+  } while (0)
+
 template <typename T>
 int dalloc(ca_engine* h, T** p, int64_t n) {
   if (n <= 0) n = 1;
@@ -213,7 +236,7 @@ int dalloc(ca_engine* h, T** p, int64_t n) {
 // ---- profiling wrappers ------------------------------------------------------------------
 int prof_flush(ca_engine* h) {
   if (h->ev_used == 0) return CA_OK;
-  HIPCK(h, hipStreamSynchronize(h->stream));
+  SYNC(h);
   if (h->stream2) HIPCK(h, hipStreamSynchronize(h->stream2));
   for (size_t i = 0; i < h->ev_used; ++i) {
     float ms = 0.f;
@@ -411,20 +434,20 @@ inline int64_t hidx(int layout, int64_t r, int64_t c, int64_t R, int64_t Cn) {
 int upload_f(ca_engine* h, float* dst, const std::vector<float>& v) {
   if (v.empty()) return CA_OK;
   HIPCK(h, hipMemcpyAsync(dst, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice, h->stream));
-  HIPCK(h, hipStreamSynchronize(h->stream));
+  SYNC(h);
   return CA_OK;
 }
 int upload_d(ca_engine* h, double* dst, const std::vector<double>& v) {
   if (v.empty()) return CA_OK;
   HIPCK(h, hipMemcpyAsync(dst, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
-  HIPCK(h, hipStreamSynchronize(h->stream));
+  SYNC(h);
   return CA_OK;
 }
 int download_f(ca_engine* h, std::vector<float>& v, const float* src, int64_t n) {
   v.resize((size_t)n);
   if (n == 0) return CA_OK;
   HIPCK(h, hipMemcpyAsync(v.data(), src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-  HIPCK(h, hipStreamSynchronize(h->stream));
+  SYNC(h);
   return CA_OK;
 }
 
@@ -499,7 +522,8 @@ int ycache_mfma(ca_engine* h) {
 // Both products from ONE tiled copy through the transposing LDS read (k_ys_mfma): a quantiser launch (fixed-point images of W and
 // psi; exact maxima by a separate pass only for the first state after a reset, afterwards bounded from the previous state's),
 // the stream, the finisher.  Three launches, like the VALU stream's.
-int ycache_ys(ca_engine* h) {
+// quantiser of the one-copy stream: fixed-point images of W and psi for the current parameters (slot ys_slot)
+int ys_quant(ca_engine* h) {
   const int GS = h->Gp / 64;
   const int64_t NS = h->ys_N64 / 64;
   const int s0 = h->ys_slot, s1 = (s0 + 1) % 3, s2 = (s0 + 2) % 3;
@@ -514,6 +538,26 @@ int ycache_ys(ca_engine* h) {
   LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_ys_quant, dim3(cdiv((GS + NS) * 64, CA_YM_TB)), dim3(CA_YM_TB), 0, h->stream, h->V, h->D,
                                                 (int64_t)h->G, GS, h->F, h->D, h->N, NS, h->ys_amax + 2 * s0, slack, slack, h->ys_amax + 2 * s1,
                                                 h->ys_amax + 2 * s2, h->ys_exps + 2 * s0, h->Wr, h->Pr, h->Wsum, h->Psum));
+  return CA_OK;
+}
+// finisher of the one-copy stream (digit sums -> Y^T psi in red_y, YW, psi.(YW) partials); advances the quantiser's slot ring
+int ys_finish(ca_engine* h) {
+  const int GS = h->Gp / 64;
+  const int64_t NS = h->ys_N64 / 64;
+  const int s0 = h->ys_slot, s1 = (s0 + 1) % 3;
+  const int nb_col = cdiv(h->G, 16);
+  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_ys_finish, dim3(nb_col + h->n_yw), dim3(CA_YM_TB), 0, h->stream, h->YTi, h->ys_nrg, h->Gp, h->G,
+                                                h->Psum, NS, h->ys_exps + 2 * s0, h->n_ovf > 0 ? h->ovf_col_chunk_ptr : nullptr,
+                                                h->n_ovf > 0 ? h->ovf_csum : nullptr, h->red + h->off_y, nb_col, h->YWi, h->ys_nseg, h->N, h->Wsum, GS,
+                                                h->F, h->D, h->V, h->D, h->n_ovf > 0 ? h->ovf_rowptr : nullptr, h->ovf_col, h->ovf_val, h->YW,
+                                                h->yw_part));
+  h->ys_slot = s1;
+  h->ys_steps = 0;
+  h->ycache_valid = true;
+  return CA_OK;
+}
+int ycache_ys(ca_engine* h) {
+  CACK(ys_quant(h));
   const int nb_main = h->ys_nrg * h->ys_nseg;
   if (h->n_ovf > 0) {
     ca_ovf_args ovf;
@@ -525,16 +569,7 @@ int ycache_ys(ca_engine* h) {
     LAUNCH(h, CA_KERNEL_YPASS, hipLaunchKernelGGL(k_ys_mfma, dim3(nb_main), dim3(CA_YM_TB), CA_YS_LDS_BYTES, h->stream, h->Ys, h->Wr, h->Pr, h->N,
                                                   h->Gp, h->ys_RS, h->YWi, h->YTi));
   }
-  const int nb_col = cdiv(h->G, 16);
-  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_ys_finish, dim3(nb_col + h->n_yw), dim3(CA_YM_TB), 0, h->stream, h->YTi, h->ys_nrg, h->Gp, h->G,
-                                                h->Psum, NS, h->ys_exps + 2 * s0, h->n_ovf > 0 ? h->ovf_col_chunk_ptr : nullptr,
-                                                h->n_ovf > 0 ? h->ovf_csum : nullptr, h->red + h->off_y, nb_col, h->YWi, h->ys_nseg, h->N, h->Wsum, GS,
-                                                h->F, h->D, h->V, h->D, h->n_ovf > 0 ? h->ovf_rowptr : nullptr, h->ovf_col, h->ovf_val, h->YW,
-                                                h->yw_part));
-  h->ys_slot = s1;
-  h->ys_steps = 0;
-  h->ycache_valid = true;
-  return CA_OK;
+  return ys_finish(h);
 }
 
 // Y.W and Y^T.psi for the current parameters (once per parameter state)
@@ -708,7 +743,7 @@ int allreduce(ca_engine* h, double* buf, int64_t n) {
       const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(m, CA_TB), 64));
       ca_p2p_args a;
       a.peers = pp->peers_dev; a.rank = h->opt.rank; a.world = h->opt.world; a.cap = pp->cap;
-      a.seq = ++pp->seq; a.arrive = pp->arrive;
+      a.seq = ++pp->seq; a.arrive = pp->arrive; a.err = pp->err_dev; a.timeout_ticks = pp->timeout_ticks;
       pp->arrived += (unsigned)nblk; a.arrive_target = pp->arrived;
       LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_p2p_allreduce, dim3(nblk), dim3(CA_TB), 0, h->stream, buf + o, m, a));
     }
@@ -721,7 +756,7 @@ int allreduce(ca_engine* h, double* buf, int64_t n) {
       h->host_ar_cap = n;
     }
     HIPCK(h, hipMemcpyAsync(h->host_ar_buf, buf, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCK(h, hipStreamSynchronize(h->stream));
+    SYNC(h);
     if (h->host_ar(h->host_ar_user, h->host_ar_buf, n) != 0) { h->err = "host all-reduce callback failed"; return CA_ERR_COMM; }
     HIPCK(h, hipMemcpyAsync(buf, h->host_ar_buf, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream));
     return CA_OK;
@@ -740,7 +775,7 @@ int setup_global_sums(ca_engine* h) {
   if (h->sums_global) return CA_OK;
   CACK(allreduce(h, h->colsum, h->G));
   if (h->P > 0 && h->K > 0) CACK(allreduce(h, h->YtX, (int64_t)h->G * h->P));
-  HIPCK(h, hipStreamSynchronize(h->stream));
+  SYNC(h);
   h->sums_global = true;
   return CA_OK;
 }
@@ -900,7 +935,7 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
                             lr_t, (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, mon, h->ngblk, psi,
                             h->fold_now ? h->gpart : nullptr, h->csplit_m));
   h->fold_now = false;
-  if (apply && h->async_y && h->K > 0 && !h->ride_ok) {
+  if (apply && h->async_y && h->K > 0 && !h->ride_ok && !h->ride_ys) {
     // psi is final: the Y pass for the new parameters goes to the side stream from HERE (its launches are issued by the
     // next pass, so the main stream is not left waiting for the host to get through them), and the per-cell kernel below
     // (q(z) logits, exponent bound, the O(K + C) update and the next pass's per-gene prologue: 12-16 us) is its head
@@ -1019,7 +1054,7 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
   }
   h->pre_valid = false;
   // the Y products of this parameter state: riding on the sweep's own launch (below), or from the side stream / in line
-  const bool ride = h->ride_ok && !h->ycache_valid && h->fwd_cell && !h->y_defer && !h->y_pending;
+  const bool ride = (h->ride_ok || h->ride_ys) && !h->ycache_valid && h->fwd_cell && !h->y_defer && !h->y_pending;
   if (!ride) CACK(ensure_ycache(h));
   ca_cell_ptrs cp;
   cp.A = h->A; cp.cn = h->cn; cp.s64 = h->s64; cp.etamax2 = h->etamax2; cp.glogit = h->glogit; cp.F = h->F;
@@ -1028,7 +1063,34 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
   int CP = 1;
   while (CP < h->C) CP <<= 1;
   int cell_blocks = h->ncblk;
-  if (h->fwd_cell && ride) {   // ... and the Y stream's blocks interleaved with the sweep's in the same grid
+  if (h->fwd_cell && ride && h->ride_ys) {   // the one-copy int8 matrix-core stream's blocks interleaved with the sweep's
+    cell_blocks = h->ncblk_f;
+    CACK(ys_quant(h));
+    ca_ysride_args ya;
+    memset(&ya, 0, sizeof(ya));
+    ya.Ys = h->Ys; ya.Wr = h->Wr; ya.Pr = h->Pr; ya.YWi = h->YWi; ya.YTi = h->YTi; ya.F = h->F; ya.Df = h->D;
+    ya.Gp = h->Gp; ya.RS = h->ys_RS; ya.nb_main = h->ys_nrg * h->ys_nseg; ya.nb_y = ya.nb_main;
+    if (h->n_ovf > 0) {
+      ya.ovf.chunk_start = h->ovf_chunk_start; ya.ovf.row2 = h->ovf_row2; ya.ovf.val2 = h->ovf_val2; ya.ovf.csum = h->ovf_csum; ya.ovf.nchunk = h->n_ovf_chunk;
+      ya.nb_y += cdiv(h->n_ovf_chunk, CA_TB / 64);
+    }
+    ya.pat_a = 2; ya.pat_b = 1;
+    if (h->opt.ride_pattern > 0 && (h->opt.ride_pattern >> 8) > 0 && (h->opt.ride_pattern & 255) > 0) {
+      ya.pat_a = h->opt.ride_pattern >> 8; ya.pat_b = h->opt.ride_pattern & 255;
+    }
+    const dim3 grid((unsigned)(h->ncblk_f + ya.nb_y));
+#define CA_FCYS(DV, TLBV, DPV)                                                                                                        \
+  LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell_mix_ys<DV, TLBV, 2, DPV>), grid, dim3(CA_TB), 0, h->stream, h->F, h->etamax2, h->Vs, \
+                                              h->Mq, cp, h->alpha_u, h->cell_part, h->N, h->C, h->K, h->nk32, h->fc_nbig, h->ncblk_f, ya))
+#define CA_FCYS_D(TLBV, DPV) do { if (h->D == 1) CA_FCYS(1, TLBV, DPV); else CA_FCYS(2, TLBV, DPV); } while (0)
+    // (one piece in flight per wave: 128 VGPRs = four waves per SIMD like the vector stream's launch; two pieces, 162 VGPRs and
+    //  three waves, measured 2824 against 2869 it/s at cfg-3 -- profiles/r03_ab_ystream.txt)
+    if (h->fc_tl == 6) CA_FCYS_D(6, 1);
+    else CA_FCYS_D(2, 1);
+#undef CA_FCYS_D
+#undef CA_FCYS
+    CACK(ys_finish(h));
+  } else if (h->fwd_cell && ride) {   // ... and the Y stream's blocks interleaved with the sweep's in the same grid
     cell_blocks = h->ncblk_f;
     ca_yride_args ya;
     memset(&ya, 0, sizeof(ya));
@@ -1053,7 +1115,8 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
 #define CA_FCY(DV, TLBV)                                                                                                              \
   LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell_mix_y<DV, TLBV, 2>), grid, dim3(CA_TB), 0, h->stream, h->F, h->etamax2, h->Vs, h->Mq, \
                                               cp, h->alpha_u, h->cell_part, h->N, h->C, h->K, h->nk32, h->fc_nbig, h->ncblk_f, ya))
-    if (h->fc_tl == 6) { if (h->D == 1) CA_FCY(1, 6); else CA_FCY(2, 6); }
+    if (h->fc_tl == 8) { if (h->D == 1) CA_FCY(1, 8); else CA_FCY(2, 8); }
+    else if (h->fc_tl == 6) { if (h->D == 1) CA_FCY(1, 6); else CA_FCY(2, 6); }
     else { if (h->D == 1) CA_FCY(1, 2); else CA_FCY(2, 2); }
 #undef CA_FCY
     {   // the stream's finishers, in line behind the launch they rode on (one launch: column sums + row sums / psi.(YW) partials)
@@ -1078,6 +1141,7 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
       switch (h->fc_tl) {
         case 4: CA_FCMD(4); break;
         case 5: CA_FCMD(5); break;
+        case 8: CA_FCMD(8); break;
         default: CA_FCMD(6); break;
       }
     } else
@@ -1193,7 +1257,7 @@ int wait_host_elbo(ca_engine* h, unsigned long long seq, const double* dev, doub
   }
   std::atomic_thread_fence(std::memory_order_acquire);
   *out = *reinterpret_cast<volatile double*>(h->host_pinned + 32);
-  return CA_OK;
+  return comm_check(h);
 }
 
 // monitor pass on eps slot m; with next >= 0 (and the fused path available) also the forward half of the train
@@ -1212,7 +1276,7 @@ int ensure_eps_cap(ca_engine* h, int64_t draws) {
   float* p = nullptr;
   HIPCK(h, hipMalloc((void**)&p, (size_t)draws * h->S * h->G * sizeof(float)));
   if (h->eps_dev) {
-    HIPCK(h, hipStreamSynchronize(h->stream));
+    SYNC(h);
     HIPCK(h, hipFree(h->eps_dev));
     h->dev_bytes -= h->eps_cap * (int64_t)h->S * h->G * 4;
   }
@@ -1226,7 +1290,7 @@ int ensure_elbo_cap(ca_engine* h, int64_t n) {
   double* p = nullptr;
   HIPCK(h, hipMalloc((void**)&p, (size_t)n * sizeof(double)));
   if (h->elbo_dev) {
-    HIPCK(h, hipStreamSynchronize(h->stream));
+    SYNC(h);
     HIPCK(h, hipFree(h->elbo_dev));
   }
   h->elbo_dev = p;
@@ -1245,7 +1309,7 @@ int stage_eps(ca_engine* h, const float* eps_stream, int64_t have, int64_t need)
       return CA_ERR_INVALID;
     }
     HIPCK(h, hipMemcpyAsync(h->eps_dev, eps_stream, (size_t)need * per * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    HIPCK(h, hipStreamSynchronize(h->stream));
+    SYNC(h);
   } else {
     // counter-based stream: draws are independent, so a long run's worth (2 + 2 max_iter draws) is generated by several
     // host threads -- same values whatever the thread count -- straight into a pinned staging buffer the engine keeps
@@ -1270,14 +1334,14 @@ int stage_eps(ca_engine* h, const float* eps_stream, int64_t have, int64_t need)
     }
     h->draw += need;
     HIPCK(h, hipMemcpyAsync(h->eps_dev, out, bytes, hipMemcpyHostToDevice, h->stream));
-    HIPCK(h, hipStreamSynchronize(h->stream));
+    SYNC(h);
   }
   return CA_OK;
 }
 
 int read_doubles(ca_engine* h, const double* dev, double* out, int n) {
   HIPCK(h, hipMemcpyAsync(h->host_pinned, dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCK(h, hipStreamSynchronize(h->stream));
+  SYNC(h);
   for (int i = 0; i < n; ++i) out[i] = h->host_pinned[i];
   return CA_OK;
 }
@@ -1295,7 +1359,7 @@ int scan_and_convert(ca_engine* h, const ST* src_dev, int64_t sn, int64_t sg) {
   HIPCK(h, hipGetLastError());
   double hm[4];
   HIPCK(h, hipMemcpyAsync(hm, maxv, 32, hipMemcpyDeviceToHost, h->stream));
-  HIPCK(h, hipStreamSynchronize(h->stream));
+  SYNC(h);
   const double mx = hm[0];
   int fl;
   memcpy(&fl, &hm[1], sizeof(int));
@@ -1343,7 +1407,7 @@ int scan_and_convert(ca_engine* h, const ST* src_dev, int64_t sn, int64_t sg) {
     HIPCK(h, hipMemcpyAsync(h->h_orow.data(), orow, n255 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipMemcpyAsync(h->h_ocol.data(), ocol, n255 * sizeof(int), hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipMemcpyAsync(h->h_oval.data(), oval, n255 * sizeof(float), hipMemcpyDeviceToHost, h->stream));
-    HIPCK(h, hipStreamSynchronize(h->stream));
+    SYNC(h);
     hipFree(orow); hipFree(ocol); hipFree(oval); hipFree(maxv);
     // fixed order: sort by (cell, gene) for the CSR copy and by (gene, cell) for the CSC copy
     const int64_t nz = (int64_t)n255;
@@ -1392,7 +1456,7 @@ int scan_and_convert(ca_engine* h, const ST* src_dev, int64_t sn, int64_t sg) {
   else hipLaunchKernelGGL((k_convert_y<ST, float>), grid, dim3(CA_TB), 0, h->stream, src_dev, (float*)h->Y, h->N, h->G, h->Gp, sn, sg, flags);
   HIPCK(h, hipGetLastError());
   HIPCK(h, hipMemcpyAsync(hm, maxv, 16, hipMemcpyDeviceToHost, h->stream));
-  HIPCK(h, hipStreamSynchronize(h->stream));
+  SYNC(h);
   memcpy(&fl, &hm[1], sizeof(int));
   hipFree(maxv);
   if (fl & 1) { h->err = "counts are not exactly representable in the on-device storage type"; return CA_ERR_INVALID; }
@@ -1406,7 +1470,7 @@ int gather_y(ca_engine* h, const void* src, void** dst, int64_t sn, int64_t sg, 
   hipLaunchKernelGGL((k_gather_y<ST>), dim3(cdiv(total, CA_TB)), dim3(CA_TB), 0, h->stream, (const ST*)src, (ST*)*dst, h->N, h->G, sn, sg,
                      ci_dev, gi_dev);
   HIPCK(h, hipGetLastError());
-  HIPCK(h, hipStreamSynchronize(h->stream));
+  SYNC(h);
   return CA_OK;
 }
 
@@ -1581,7 +1645,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   else if (h->ystore == CA_YSTORE_U16) launch_prep<uint16_t>(h, logL_dev, extra_dev);
   else launch_prep<float>(h, logL_dev, extra_dev);
   HIPCK(h, hipGetLastError());
-  HIPCK(h, hipStreamSynchronize(h->stream));
+  SYNC(h);
   hipFree(logL_dev);
   if (extra_dev) hipFree(extra_dev);
   // ---- variables (:240-272)
@@ -1676,7 +1740,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
       if (const int t = tune_val(h, CA_TUNE_FC_TL, "CA_FC_TL")) { if (t == 1 || t == 2 || t == 4 || t == 5 || t == 6 || t == 8) h->fc_tl = t; }
       h->ncblk_f = cdiv(Nn, 16 * h->fc_tl);
       // two block sizes in one launch (k_fwd_cell_mix)
-      if (h->fwd_cell && (h->fc_tl == 4 || h->fc_tl == 5 || h->fc_tl == 6) && (D == 1 || D == 2)) {
+      if (h->fwd_cell && (h->fc_tl == 4 || h->fc_tl == 5 || h->fc_tl == 6 || h->fc_tl == 8) && (D == 1 || D == 2)) {
         // measured at 100k cells (1042 blocks of 96): 1024 big + 53 small 2706 it/s, 768 + 821: 2682, 512 + 1589: 2669, all big
         // 2642 -- what pays is every CU getting the same number of big blocks, so: whole multiples of the CU count in big
         // blocks, the remainder (less than one big block per CU) in small ones
@@ -1804,8 +1868,10 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     h->y_dev_bytes += h->ys_N64 * h->Gp;
   }
   // the Y stream rides on the forward sweep's launch: 1-byte storage, K = 1, the fused sweep with its default block shapes
-  h->ride_ok = h->ystore == CA_YSTORE_U8 && K == 1 && h->fused_ok && h->fwd_cell && (h->fc_tl == 6 || (h->fc_tl == 2 && h->fc_nbig == 0)) &&
+  h->ride_ok = h->ystore == CA_YSTORE_U8 && K == 1 && h->fused_ok && h->fwd_cell && (h->fc_tl == 6 || h->fc_tl == 8 || (h->fc_tl == 2 && h->fc_nbig == 0)) &&
                !h->y_mfma && !h->y_ys && variant_on(h, CA_VAR_Y_RIDE, "CA_Y_RIDE");
+  h->ride_ys = h->y_ys && h->fused_ok && h->fwd_cell && (h->fc_tl == 6 || (h->fc_tl == 2 && h->fc_nbig == 0)) &&
+               variant_on(h, CA_VAR_Y_RIDE, "CA_Y_RIDE");
   h->off_g = 3 + C;
   h->off_y = h->off_g + (int64_t)G * (S + D);
   h->red_n = h->off_y + (int64_t)G * K;
@@ -1826,7 +1892,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     if (!p->loc0) {
       srow.resize((size_t)Nn);
       HIPCK(h, hipMemcpyAsync(srow.data(), h->s64, (size_t)Nn * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      HIPCK(h, hipStreamSynchronize(h->stream));
+      SYNC(h);
     }
     std::vector<double> cs((size_t)G, 0.0), ytx((size_t)G * std::max(P, 1), 0.0);
     float *Ft = nullptr, *Vt = nullptr, *YWp = nullptr, *YTp = nullptr; double* yt = nullptr;
@@ -1854,7 +1920,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
       hipLaunchKernelGGL(k_colsum, dim3(cdiv(h->Gp, 64)), dim3(1024), 0, h->stream, YTp, yt, h->nrg, (int64_t)h->Gp, h->Gp);
       std::vector<double> tmp((size_t)G);
       HIPCK(h, hipMemcpyAsync(tmp.data(), yt, (size_t)G * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      HIPCK(h, hipStreamSynchronize(h->stream));
+      SYNC(h);
       for (int64_t e = 0; e < h->n_ovf; ++e)   // overflow list, fixed (cell, gene) order
         tmp[h->h_ocol[e]] += (double)h->h_oval[e] * (double)col[h->h_orow[e]];
       if (j >= cols) {
@@ -1878,7 +1944,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   h->b1p = (float)h->opt.beta1;
   h->b2p = (float)h->opt.beta2;
   CACK(refresh_derived(h));
-  HIPCK(h, hipStreamSynchronize(h->stream));
+  SYNC(h);
   return CA_OK;
 }
 
@@ -2049,6 +2115,7 @@ int ca_destroy(ca_handle h) {
   if (h->comm) g_rccl.CommDestroy(h->comm);
   if (h->p2p) {
     for (void* q : h->p2p->opened) if (q) hipIpcCloseMemHandle(q);
+    if (h->p2p->err_host) hipHostFree(h->p2p->err_host);
     if (h->p2p->slab) hipFree(h->p2p->slab);
     if (h->p2p->peers_dev) hipFree(h->p2p->peers_dev);
     if (h->p2p->arrive) hipFree(h->p2p->arrive);
@@ -2074,7 +2141,7 @@ int ca_get_info(ca_handle h, ca_info* i) {
   i->gsplit = h->gsplit; i->csplit = h->csplit; i->n_cu = h->n_cu; i->fused_sweep = h->fused_ok ? 1 : 0;
   i->fwd_mfma = (h->fused_ok && h->fwd_mfma) ? 1 : 0; i->bwd_mfma = h->bwd_mfma ? 1 : 0; i->fsplit = h->fsplit; i->fwd_cell = (h->fused_ok && h->fwd_cell) ? 1 : 0;
   i->y_mfma = h->y_ys ? 2 : h->y_mfma ? 1 : 0;
-  i->y_ride = h->ride_ok ? 1 : 0;
+  i->y_ride = (h->ride_ok || h->ride_ys) ? 1 : 0;
   i->transport = (h->p2p && h->p2p->connected) ? CA_TRANSPORT_P2P : h->comm ? CA_TRANSPORT_RCCL : h->host_ar ? CA_TRANSPORT_HOST : CA_TRANSPORT_NONE;
   i->red_n = h->red_n;
   return CA_OK;
@@ -2083,7 +2150,7 @@ int ca_get_info(ca_handle h, ca_info* i) {
 int ca_synchronize(ca_handle h) {
   if (!h) return CA_ERR_INVALID;
   HIPCK(h, hipSetDevice(h->device));
-  HIPCK(h, hipStreamSynchronize(h->stream));
+  SYNC(h);
   return CA_OK;
 }
 
@@ -2114,73 +2181,148 @@ int ca_comm_init(ca_handle h, const char id[128]) {
 int ca_p2p_export(ca_handle h, char handle[CA_P2P_HANDLE_BYTES]) {
   if (!h || !handle) return CA_ERR_INVALID;
   HIPCK(h, hipSetDevice(h->device));
+  if (h->opt.world > CA_TB) { h->err = "peer-to-peer transport: at most " + std::to_string(CA_TB) + " ranks (one flag lane per rank)"; return CA_ERR_COMM; }
   if (!h->p2p) {
     ca_p2p* pp = new ca_p2p();
     const int W = h->opt.world;
     // room for everything one call reduces: the train pass's summands, the setup sums, the PCA / correlation packs
     pp->cap = std::max<int64_t>(std::max<int64_t>(h->red_n, (int64_t)h->G * (h->C + 2) + 64), 4096);
     pp->slab_bytes = ((size_t)2 * W * pp->cap + (size_t)2 * W) * sizeof(double);
-    // fine-grained (coherent for remote writers and for the polling loads), like the buffers of RCCL's low-latency protocol
+    // Fine-grained memory or nothing: the slab is written by remote peers over xGMI and polled here, which ordinary
+    // (coarse-grained) device memory does not keep coherent -- a stale flag would be a hang or a wrong sum.  The caller moves
+    // on to RCCL when this fails.
     if (hipExtMallocWithFlags((void**)&pp->slab, pp->slab_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
       (void)hipGetLastError();
-      if (hipMalloc((void**)&pp->slab, pp->slab_bytes) != hipSuccess) { delete pp; h->err = "p2p slab allocation failed"; return CA_ERR_NOMEM; }
+      delete pp;
+      h->err = "peer-to-peer transport: fine-grained device memory unavailable (hipExtMallocWithFlags(hipDeviceMallocFinegrained) failed)";
+      return CA_ERR_COMM;
     }
-    HIPCK(h, hipMemset(pp->slab, 0, pp->slab_bytes));
-    HIPCK(h, hipMalloc((void**)&pp->peers_dev, (size_t)W * sizeof(double*)));
-    HIPCK(h, hipMalloc((void**)&pp->arrive, sizeof(unsigned int)));
-    HIPCK(h, hipMemset(pp->arrive, 0, sizeof(unsigned int)));
+    auto fail = [&](const std::string& m) { if (pp->err_host) hipHostFree(pp->err_host); if (pp->peers_dev) hipFree(pp->peers_dev);
+                                            if (pp->arrive) hipFree(pp->arrive); hipFree(pp->slab); delete pp; h->err = m; return CA_ERR_HIP; };
+    if (hipMemset(pp->slab, 0, pp->slab_bytes) != hipSuccess) return fail("hipMemset of the p2p slab failed");
+    if (hipMalloc((void**)&pp->peers_dev, (size_t)W * sizeof(double*)) != hipSuccess) return fail("hipMalloc (p2p peer table) failed");
+    if (hipMalloc((void**)&pp->arrive, sizeof(unsigned int)) != hipSuccess) return fail("hipMalloc (p2p arrival counter) failed");
+    if (hipMemset(pp->arrive, 0, sizeof(unsigned int)) != hipSuccess) return fail("hipMemset (p2p arrival counter) failed");
+    if (hipHostMalloc((void**)&pp->err_host, sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) return fail("hipHostMalloc (p2p error word) failed");
+    *pp->err_host = 0ull;
+    if (hipHostGetDevicePointer((void**)&pp->err_dev, pp->err_host, 0) != hipSuccess) return fail("hipHostGetDevicePointer (p2p error word) failed");
+    const int ms = h->opt.comm_timeout_ms > 0 ? h->opt.comm_timeout_ms : 10000;
+    pp->timeout_ticks = (unsigned long long)ms * 100000ull;   // s_memrealtime counts at 100 MHz
     h->p2p = pp;
   }
   ca_p2p_wire w;
   memset(&w, 0, sizeof(w));
   HIPCK(h, hipIpcGetMemHandle(&w.mem, h->p2p->slab));
   w.cap = h->p2p->cap; w.rank = h->opt.rank; w.world = h->opt.world; w.device = h->device; w.pid = (int32_t)getpid();
+  w.local_ptr = (uint64_t)(uintptr_t)h->p2p->slab;
   memset(handle, 0, CA_P2P_HANDLE_BYTES);
   memcpy(handle, &w, sizeof(w));
   return CA_OK;
 }
 
+static void p2p_unmap(ca_p2p* pp) {
+  for (void*& q : pp->opened) if (q) { hipIpcCloseMemHandle(q); q = nullptr; }
+  (void)hipGetLastError();
+  pp->mapped = false;
+}
+
+// Phase 1: map every peer's slab.  Touches no peer and launches nothing, so a rank whose peer failed does not end up waiting for
+// it: the caller agrees on every rank's result over its control plane and then calls ca_p2p_commit on all ranks.
 int ca_p2p_connect(ca_handle h, const char* handles) {
   if (!h || !handles) return CA_ERR_INVALID;
   if (!h->p2p) { h->err = "ca_p2p_connect before ca_p2p_export"; return CA_ERR_STATE; }
   if (!variant_on(h, CA_VAR_P2P, "CA_P2P")) { h->err = "peer-to-peer transport switched off (CA_VAR_P2P)"; return CA_ERR_COMM; }
   HIPCK(h, hipSetDevice(h->device));
   ca_p2p* pp = h->p2p;
+  if (pp->connected) { h->err = "ca_p2p_connect: the transport is already committed"; return CA_ERR_STATE; }
   const int W = h->opt.world;
   std::vector<double*> peers((size_t)W, nullptr);
+  p2p_unmap(pp);
   pp->opened.assign((size_t)W, nullptr);
+  auto fail = [&](const std::string& m) { p2p_unmap(pp); h->err = m; return CA_ERR_COMM; };
   for (int r = 0; r < W; ++r) {
     ca_p2p_wire w;
     memcpy(&w, handles + (size_t)r * CA_P2P_HANDLE_BYTES, sizeof(w));
-    if (w.rank != r || w.world != W || w.cap != pp->cap) {
-      h->err = "p2p handle " + std::to_string(r) + " does not match this problem (rank / world / payload size)";
-      return CA_ERR_COMM;
-    }
+    if (w.rank != r || w.world != W || w.cap != pp->cap)
+      return fail("p2p handle " + std::to_string(r) + " does not match this problem (rank / world / payload size)");
     if (r == h->opt.rank) { peers[r] = pp->slab; continue; }
     if (w.device != h->device) {
       int can = 0;
       if (hipDeviceCanAccessPeer(&can, h->device, w.device) != hipSuccess || !can) {
         (void)hipGetLastError();
-        h->err = "no peer access from device " + std::to_string(h->device) + " to device " + std::to_string(w.device);
-        return CA_ERR_COMM;
+        return fail("no peer access from device " + std::to_string(h->device) + " to device " + std::to_string(w.device));
       }
       const hipError_t e = hipDeviceEnablePeerAccess(w.device, 0);
-      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { h->err = std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e); return CA_ERR_COMM; }
       (void)hipGetLastError();
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+    }
+    if (w.pid == (int32_t)getpid()) {   // a handle of THIS process (one R session driving several devices): the slab's own address
+      peers[r] = (double*)(uintptr_t)w.local_ptr;
+      continue;
     }
     void* q = nullptr;
     const hipError_t e = hipIpcOpenMemHandle(&q, w.mem, hipIpcMemLazyEnablePeerAccess);
     if (e != hipSuccess) {
       (void)hipGetLastError();
-      h->err = std::string("hipIpcOpenMemHandle (rank ") + std::to_string(r) + "): " + hipGetErrorString(e);
-      return CA_ERR_COMM;
+      return fail(std::string("hipIpcOpenMemHandle (rank ") + std::to_string(r) + "): " + hipGetErrorString(e));
     }
     pp->opened[r] = q;
     peers[r] = (double*)q;
   }
-  HIPCK(h, hipMemcpy(pp->peers_dev, peers.data(), (size_t)W * sizeof(double*), hipMemcpyHostToDevice));
+  if (hipMemcpy(pp->peers_dev, peers.data(), (size_t)W * sizeof(double*), hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy (p2p peer table) failed");
+  pp->mapped = true;
+  return CA_OK;
+}
+
+// Phase 2, collective: all_ranks_ok = 1 only if ca_p2p_connect returned CA_OK on EVERY rank (the caller's control plane says
+// so).  Then the transport becomes the engine's all-reduce and the setup sums are reduced -- the first call that waits for
+// peers.  all_ranks_ok = 0: the mappings are dropped and the engine is left without a transport (next: ca_comm_init).
+int ca_p2p_commit(ca_handle h, int32_t all_ranks_ok) {
+  if (!h) return CA_ERR_INVALID;
+  if (!h->p2p) { h->err = "ca_p2p_commit before ca_p2p_export"; return CA_ERR_STATE; }
+  HIPCK(h, hipSetDevice(h->device));
+  ca_p2p* pp = h->p2p;
+  if (!all_ranks_ok) { p2p_unmap(pp); pp->connected = false; return CA_OK; }
+  if (!pp->mapped) { h->err = "ca_p2p_commit(1) without a successful ca_p2p_connect on this rank"; return CA_ERR_STATE; }
   pp->connected = true;
   return setup_global_sums(h);
+}
+
+// Times n_calls all-reduces of n_doubles doubles on one of the engine's device transports, back to back on the engine's stream
+// (HIP events around the batch).  Collective: every rank calls it with the same arguments.  The buffer is scratch.
+int ca_comm_benchmark(ca_handle h, int32_t transport, int32_t n_calls, int64_t n_doubles, double* us_per_call) {
+  if (!h || !us_per_call || n_calls < 1 || n_doubles < 1) return CA_ERR_INVALID;
+  HIPCK(h, hipSetDevice(h->device));
+  const bool want_p2p = transport == CA_TRANSPORT_P2P;
+  if (want_p2p && !(h->p2p && h->p2p->connected)) { h->err = "ca_comm_benchmark: no committed peer-to-peer transport"; return CA_ERR_STATE; }
+  if (transport == CA_TRANSPORT_RCCL && !h->comm) { h->err = "ca_comm_benchmark: no RCCL communicator (ca_comm_init)"; return CA_ERR_STATE; }
+  if (!want_p2p && transport != CA_TRANSPORT_RCCL) { h->err = "ca_comm_benchmark: transport must be CA_TRANSPORT_P2P or CA_TRANSPORT_RCCL"; return CA_ERR_INVALID; }
+  double* buf = nullptr;
+  HIPCK(h, hipMalloc((void**)&buf, (size_t)n_doubles * sizeof(double)));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  auto cleanup = [&]() { if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); hipFree(buf); };
+  int rc = CA_OK;
+  // the RCCL leg runs with the peer-to-peer transport hidden from allreduce()
+  const bool was = h->p2p && h->p2p->connected;
+  if (!want_p2p && was) h->p2p->connected = false;
+  auto run = [&]() -> int {
+    HIPCK(h, hipMemsetAsync(buf, 0, (size_t)n_doubles * sizeof(double), h->stream));
+    HIPCK(h, hipEventCreate(&e0)); HIPCK(h, hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) CACK(allreduce(h, buf, n_doubles));   // warm-up (RCCL builds its channels on first use)
+    HIPCK(h, hipEventRecord(e0, h->stream));
+    for (int i = 0; i < n_calls; ++i) CACK(allreduce(h, buf, n_doubles));
+    HIPCK(h, hipEventRecord(e1, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    CACK(comm_check(h));
+    float ms = 0.f;
+    HIPCK(h, hipEventElapsedTime(&ms, e0, e1));
+    *us_per_call = (double)ms * 1e3 / n_calls;
+    return CA_OK;
+  };
+  rc = run();
+  if (!want_p2p && was) h->p2p->connected = true;
+  cleanup();
+  return rc;
 }
 
 int ca_set_host_allreduce(ca_handle h, ca_host_allreduce_fn fn, void* user) {
@@ -2198,7 +2340,7 @@ int ca_gamma_init(ca_handle h, const float* eps) {
   HIPCK(h, hipSetDevice(h->device));
   CACK(stage_one(h, eps));
   CACK(run_pass(h, 0, CA_MODE_GINIT, 0, nullptr));
-  HIPCK(h, hipStreamSynchronize(h->stream));
+  SYNC(h);
   return CA_OK;
 }
 
@@ -2223,7 +2365,7 @@ int ca_step(ca_handle h, const float* eps) {
   HIPCK(h, hipSetDevice(h->device));
   CACK(stage_one(h, eps));
   CACK(run_pass(h, 0, CA_MODE_TRAIN, 1, h->elbo_dev));
-  HIPCK(h, hipStreamSynchronize(h->stream));
+  SYNC(h);
   return CA_OK;
 }
 
@@ -2313,7 +2455,7 @@ int ca_iterate(ca_handle h, int32_t n_iter, const float* eps_stream, int64_t n_d
     fprintf(stderr, "[clonealign_hip] ca_iterate: host enqueue %.1f us per iteration\n",
             std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host0).count() / n_iter);
   if (last_elbo && n_iter > 0) return read_doubles(h, h->elbo_dev + (n_iter - 1), last_elbo, 1);
-  HIPCK(h, hipStreamSynchronize(h->stream));
+  SYNC(h);
   return CA_OK;
 }
 
@@ -2331,7 +2473,7 @@ int ca_final_elbo(ca_handle h, int32_t n_rep, const float* eps_stream, int64_t n
   }
   std::vector<double> v((size_t)n_rep);
   HIPCK(h, hipMemcpyAsync(v.data(), h->elbo_dev, (size_t)n_rep * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCK(h, hipStreamSynchronize(h->stream));
+  SYNC(h);
   double m = 0.0;
   for (double x : v) m += x;
   m /= n_rep;
@@ -2349,7 +2491,7 @@ static int allreduce_host_vec(ca_engine* h, std::vector<double>& v, double* dev_
   HIPCK(h, hipMemcpyAsync(dev_scratch, v.data(), v.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
   CACK(allreduce(h, dev_scratch, (int64_t)v.size()));
   HIPCK(h, hipMemcpyAsync(v.data(), dev_scratch, v.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-  HIPCK(h, hipStreamSynchronize(h->stream));
+  SYNC(h);
   return CA_OK;
 }
 
@@ -2376,7 +2518,7 @@ int ca_init_psi_pca(ca_handle h, const double* noise, int32_t n_iter, uint64_t s
     hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)Gp * qq, 64)), dim3(1024), 0, h->stream, YTp, ytd, nrb_tot, (int64_t)Gp * qq, Gp * qq);
     out.resize((size_t)G * qq);
     HIPCK(h, hipMemcpyAsync(out.data(), ytd, (size_t)G * qq * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCK(h, hipStreamSynchronize(h->stream));
+    SYNC(h);
     return CA_OK;
   };
   int rc = CA_OK;
@@ -2490,7 +2632,7 @@ int ca_init_psi_pca(ca_handle h, const double* noise, int32_t n_iter, uint64_t s
   cleanup();
   if (rc != CA_OK) return rc;
   CACK(refresh_derived(h));
-  HIPCK(h, hipStreamSynchronize(h->stream));
+  SYNC(h);
   return CA_OK;
 #undef PCK
 }
@@ -2557,7 +2699,7 @@ static int get_generic(ca_handle h, const char* name, double* out, bool grad) {
   if (r.rows * r.cols == 0) return CA_OK;
   if (r.d) {
     HIPCK(h, hipMemcpyAsync(out, r.d, (size_t)r.rows * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HIPCK(h, hipStreamSynchronize(h->stream));
+    SYNC(h);
     return CA_OK;
   }
   std::vector<float> buf;
@@ -2602,7 +2744,7 @@ int ca_set_param(ca_handle h, const char* name, const double* in) {
       buf[i * r.stride + r.off + c] = (float)in[r.matrix ? hidx(h->layout, i, c, r.rows, r.cols) : i];
   CACK(upload_f(h, r.f, buf));
   CACK(refresh_derived(h));
-  HIPCK(h, hipStreamSynchronize(h->stream));
+  SYNC(h);
   return CA_OK;
 }
 
@@ -2614,7 +2756,7 @@ int ca_reinit(ca_handle h, const double* psi0, const double* loc0) {
   if (h->K > 0 && !psi0) { h->err = "psi0 is required when K > 0"; return CA_ERR_INVALID; }
   HIPCK(h, hipSetDevice(h->device));
   CACK(wait_y(h, true));
-  HIPCK(h, hipStreamSynchronize(h->stream));
+  SYNC(h);
   const int64_t N = h->N; const int G = h->G, C = h->C, K = h->K, D = h->D;
   auto zero = [&](float* p, int64_t n) { return p && n > 0 ? hipMemsetAsync(p, 0, (size_t)n * sizeof(float), h->stream) : hipSuccess; };
   const int64_t GD = (int64_t)G * std::max(D, 1), NK = N * std::max(K, 1);
@@ -2645,7 +2787,7 @@ int ca_reinit(ca_handle h, const double* psi0, const double* loc0) {
   h->bwd_ready = false;
   h->hint_A = h->hint_B = -1;
   CACK(refresh_derived(h));
-  HIPCK(h, hipStreamSynchronize(h->stream));
+  SYNC(h);
   return CA_OK;
 }
 

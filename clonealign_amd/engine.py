@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libclonealign_hip.so")
 CA_OK = 0
 CA_ERR_NAN = 4
 CA_INTERRUPTED = 7
-CA_ABI_VERSION = 2
+CA_ABI_VERSION = 3
 P2P_HANDLE_BYTES = 128
 CA_F64, CA_F32, CA_I32, CA_U16, CA_U8 = 0, 1, 2, 3, 4
 CA_ROW_MAJOR, CA_COL_MAJOR = 0, 1
@@ -32,7 +32,7 @@ TRANSPORT_NAME = {0: "none", 1: "rccl", 2: "host", 3: "p2p"}
 
 EXPORTS = (
     "ca_abi_version", "ca_build_id", "ca_device_count", "ca_default_options", "ca_create", "ca_destroy", "ca_last_error", "ca_get_info",
-    "ca_synchronize", "ca_comm_unique_id", "ca_comm_init", "ca_p2p_export", "ca_p2p_connect", "ca_set_host_allreduce", "ca_gamma_init", "ca_elbo", "ca_elbo_terms",
+    "ca_synchronize", "ca_comm_unique_id", "ca_comm_init", "ca_p2p_export", "ca_p2p_connect", "ca_p2p_commit", "ca_comm_benchmark", "ca_set_host_allreduce", "ca_gamma_init", "ca_elbo", "ca_elbo_terms",
     "ca_step", "ca_gradients", "ca_run", "ca_run_ex", "ca_iterate", "ca_final_elbo", "ca_init_psi_pca", "ca_clone_gene_sums", "ca_get_param", "ca_set_param",
     "ca_get_gradient", "ca_reinit", "ca_get_kernel_times", "ca_reset_kernel_times", "ca_set_profile", "ca_eps_draw", "ca_allele_loglik", "ca_preprocess",
 )
@@ -51,7 +51,7 @@ class CaOptions(C.Structure):
                 ("adam_eps", C.c_double), ("seed", C.c_uint64), ("device", C.c_int32),
                 ("y_storage", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32), ("profile", C.c_int32),
                 ("variant_off", C.c_uint32), ("tune", C.c_int32 * 8), ("variant_on", C.c_uint32),
-                ("ride_pattern", C.c_int32), ("reserved", C.c_int32 * 4)]
+                ("ride_pattern", C.c_int32), ("comm_timeout_ms", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 class CaInfo(C.Structure):
@@ -102,6 +102,8 @@ def load_library(path=None):
     lib.ca_comm_init.argtypes = [C.c_void_p, C.c_char_p]
     lib.ca_p2p_export.argtypes = [C.c_void_p, C.c_char_p]
     lib.ca_p2p_connect.argtypes = [C.c_void_p, C.c_char_p]
+    lib.ca_p2p_commit.argtypes = [C.c_void_p, C.c_int32]
+    lib.ca_comm_benchmark.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_double)]
     lib.ca_set_host_allreduce.argtypes = [C.c_void_p, HOST_ALLREDUCE_FN, C.c_void_p]
     lib.ca_gamma_init.argtypes = [C.c_void_p, C.c_void_p]
     lib.ca_elbo.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
@@ -190,13 +192,15 @@ class HipEngine:
     def __init__(self, Y, L, psi0, loc0, K, S=1, X=None, extra_loglik=None, learning_rate=0.1,
                  device=0, y_storage="auto", seed=0x5EED5EED, rank=0, world=1, profile=False,
                  y_device_ptr=None, y_device_dtype=None, shape=None, comm_id=None, host_allreduce=None, p2p_exchange=None,
-                 layout="row", cell_index=None, gene_index=None, variant_off=(), variant_on=(), tune=None, verbose=False):
+                 layout="row", cell_index=None, gene_index=None, variant_off=(), variant_on=(), tune=None, verbose=False,
+                 comm_timeout_ms=0, defer_transport=False):
         """``layout``: "row" (C / numpy order) or "col" -- every matrix is then handed over column-major (Fortran order),
         which is what the R caller has (R/inference-tflow.R:190-191,355) and what r_shim/clonealign_hip_shim.c passes; the
         ``get``/``set`` matrices use the same layout.  ``cell_index`` / ``gene_index``: Y is the RAW matrix and the fit uses
         these rows / columns of it (ca_problem.cell_index / gene_index); L, psi0, loc0, X, extra_loglik are for the selection.
         ``p2p_exchange(handle: bytes) -> list[bytes]`` (world > 1): an all-gather of the ranks' P2P_HANDLE_BYTES-byte handles in
         rank order (torch.distributed / MPI); selects the one-shot peer-to-peer all-reduce (ca_p2p_export / ca_p2p_connect).
+        ``comm_timeout_ms``: bound of the peer-to-peer all-reduce's device-side wait for its peers (0 = 10 s; ca_options).
         ``variant_off``: names from VARIANTS (or a bitmask) to switch off; ``variant_on``: names from VARIANTS_ON to switch on;
         ``tune``: {name from TUNE: value}."""
         self.lib = load_library()
@@ -250,6 +254,7 @@ class HipEngine:
         opt.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         opt.rank, opt.world = int(rank), int(world)
         opt.profile = 0x1F if profile is True else int(profile)
+        opt.comm_timeout_ms = int(comm_timeout_ms)
         voff = int(variant_off) if isinstance(variant_off, int) else sum(VARIANTS[v] for v in variant_off)
         opt.variant_off = (voff | (OPT_VERBOSE if verbose else 0)) & 0xFFFFFFFF
         opt.variant_on = int(variant_on) if isinstance(variant_on, int) else sum(VARIANTS_ON[v] for v in variant_on)
@@ -277,17 +282,50 @@ class HipEngine:
                 self._cb = HOST_ALLREDUCE_FN(_cb)
                 self._ck(self.lib.ca_set_host_allreduce(self.h, self._cb, None))
             elif p2p_exchange is not None:
-                buf = C.create_string_buffer(P2P_HANDLE_BYTES)
-                self._ck(self.lib.ca_p2p_export(self.h, buf))
-                allh = p2p_exchange(bytes(buf.raw))
-                if len(allh) != world or any(len(x) != P2P_HANDLE_BYTES for x in allh):
-                    raise ValueError("p2p_exchange must return one handle per rank, in rank order")
-                self._ck(self.lib.ca_p2p_connect(self.h, b"".join(allh)))
+                try:
+                    self._p2p_setup(p2p_exchange, world)
+                except BaseException:
+                    self.close()          # (frees the device resources now, not whenever the half-built object is collected)
+                    raise
             elif comm_id is not None:
                 self._ck(self.lib.ca_comm_init(self.h, comm_id))
-            else:
+            elif not defer_transport:   # (defer_transport: the caller brings the transport up itself -- _p2p_setup / comm_init)
                 raise ValueError("world > 1 needs p2p_exchange, comm_id (bytes from comm_unique_id(), broadcast from rank 0) "
                                  "or host_allreduce")
+
+    def _p2p_setup(self, p2p_exchange, world):
+        """Two-phase bring-up of the one-shot peer-to-peer all-reduce (include/clonealign_hip.h): export, all-gather the handles,
+        map the peers, AGREE over the control plane that every rank got that far, and only then commit -- the first call that
+        waits for peers on the device.  A failure on any rank fails every rank the same way, with nobody left waiting."""
+        err = None
+        buf = C.create_string_buffer(P2P_HANDLE_BYTES)
+        exported = self.lib.ca_p2p_export(self.h, buf) == CA_OK
+        if not exported:
+            err = (self.lib.ca_last_error(self.h) or b"").decode()
+        allh = p2p_exchange(bytes(buf.raw) if exported else bytes(P2P_HANDLE_BYTES))
+        if len(allh) != world or any(len(x) != P2P_HANDLE_BYTES for x in allh):
+            raise ValueError("p2p_exchange must return one handle per rank, in rank order")
+        ok = exported
+        if ok and self.lib.ca_p2p_connect(self.h, b"".join(allh)) != CA_OK:
+            ok, err = False, (self.lib.ca_last_error(self.h) or b"").decode()
+        flags = p2p_exchange(bytes([1 if ok else 0]) + bytes(P2P_HANDLE_BYTES - 1))
+        all_ok = len(flags) == world and all(len(f) > 0 and f[0] == 1 for f in flags)
+        if exported:
+            self._ck(self.lib.ca_p2p_commit(self.h, 1 if all_ok else 0))
+        if not all_ok:
+            raise EngineError(5, err or "peer-to-peer transport: another rank failed to export or map its peers")
+
+    def comm_init(self, comm_id):
+        """Join the RCCL communicator whose id rank 0 made (comm_unique_id()); collective.  Beside a committed peer-to-peer
+        transport it only serves comm_benchmark("rccl"): the engine keeps reducing over peer-to-peer."""
+        self._ck(self.lib.ca_comm_init(self.h, comm_id))
+
+    def comm_benchmark(self, transport, n_calls=200, n_doubles=None):
+        """us per all-reduce of ``n_doubles`` (default: the train pass's payload) on ``transport`` ("p2p" | "rccl"); collective."""
+        us = C.c_double()
+        n = int(self.info()["red_n"] if n_doubles is None else n_doubles)
+        self._ck(self.lib.ca_comm_benchmark(self.h, {"rccl": 1, "p2p": 3}[transport], int(n_calls), n, C.byref(us)))
+        return us.value
 
     # -------------------------------------------------------------- plumbing
     def _ck(self, rc):

@@ -44,22 +44,20 @@ def gene_filter(Y, L, gene_filter_threshold=0):
 
 
 def selected_sums(Y, rows, cols, axis):
-    """colSums (axis=0) / rowSums (axis=1) of Y[rows][:, cols] in float64 WITHOUT materialising the sub-matrix: the full
-    sums minus the sums over the dropped rows / columns (masks from preprocessing keep almost everything), or the direct
-    sums when more is dropped than kept.  rows / cols: sorted index arrays or None (= all)."""
+    """colSums (axis=0) / rowSums (axis=1) of Y[rows][:, cols] in float64 WITHOUT materialising the sub-matrix.
+    Integer counts: the full sums minus the sums over the dropped rows / columns when less is dropped than kept (masks
+    from preprocessing keep almost everything) -- exact, every partial sum is an integer below 2^53.  Floating-point
+    counts are always summed directly over the selection: the subtraction would leave rounding residue (a true 0 coming
+    out as 1e-12) exactly where the gene filter compares against its threshold (R/inference-tflow.R:117-124).
+    rows / cols: sorted index arrays or None (= all)."""
     N, G = Y.shape
     rows = None if rows is None or len(rows) == N else np.asarray(rows)
     cols = None if cols is None or len(cols) == G else np.asarray(cols)
-
-    def sums(sub_rows, sub_cols):
-        A = Y if sub_rows is None else Y[sub_rows]
-        out = A.sum(axis, dtype=np.float64)
-        return out if sub_cols is None else out[sub_cols]
-
+    exact = Y.dtype.kind in "iu"
     if axis == 0:        # per column, over the selected rows
         if rows is None:
             out = Y.sum(0, dtype=np.float64)
-        elif len(rows) * 2 < N:
+        elif not exact or len(rows) * 2 < N:
             out = Y[rows].sum(0, dtype=np.float64)
         else:
             drop = np.setdiff1d(np.arange(N), rows, assume_unique=True)
@@ -67,7 +65,7 @@ def selected_sums(Y, rows, cols, axis):
         return out if cols is None else out[cols]
     if cols is None:     # per row, over the selected columns
         out = Y.sum(1, dtype=np.float64)
-    elif len(cols) * 2 < G:
+    elif not exact or len(cols) * 2 < G:
         out = Y[:, cols].sum(1, dtype=np.float64)
     else:
         drop = np.setdiff1d(np.arange(G), cols, assume_unique=True)

@@ -105,6 +105,8 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
     log("Constructing HIP engine")                               # :102-104 ("Constructing tensorflow graph")
     if dtype not in ("float32", "float64"):
         raise ValueError("'arg' should be one of 'float32', 'float64'")   # match.arg, :112
+    if psi_init not in ("auto", "host", "device"):
+        raise ValueError("psi_init must be 'auto', 'host' or 'device'")
     if dtype == "float64":
         raise NotImplementedError(
             "dtype='float64': the reference graph cannot be built for float64 "
@@ -136,7 +138,13 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
                 if sel["cell_index"] is None and sel["gene_index"] is None:
                     sel = None
             L_dat = L_dat[keep, :]
-            row_sums = hostprep.selected_sums(Y_dat, ci, None if sel is None else sel["gene_index"], axis=1)
+            if psi_init == "host" and K > 0:
+                # the caller insists on the exact host SVD (:204-208): it needs the filtered matrix on the host after all
+                rows = np.arange(Y_dat.shape[0]) if ci is None else ci
+                Y_dat = Y_dat[np.ix_(rows, gi_full[keep])]
+                device_cut, sel, row_sums = False, None, None
+            else:
+                row_sums = hostprep.selected_sums(Y_dat, ci, None if sel is None else sel["gene_index"], axis=1)
         else:
             if ci is not None or gi is not None:
                 Y_dat = Y_dat[np.ix_(np.arange(Y_dat.shape[0]) if ci is None else ci, np.arange(Y_dat.shape[1]) if gi is None else gi)]
@@ -197,11 +205,10 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
     if psi_noise is None:
         psi_noise = rng.normal(0.0, 0.05, size=(K, N)).T if K > 0 else np.zeros((N, 0))  # column-major fill
     Engine = engine if engine is not None else _default_engine_factory()
-    if psi_init not in ("auto", "host", "device"):
-        raise ValueError("psi_init must be 'auto', 'host' or 'device'")
-    device_pca = K > 0 and hasattr(Engine, "pca_init") and (psi_init == "device" or (psi_init == "auto" and N * G > 4_000_000))
-    if device_cut and not device_pca and K > 0:
-        raise ValueError("psi_init='host' needs the filtered matrix on the host; it is cut on the device at this size")
+    # a matrix that is cut on the device (decided on the size BEFORE the gene filter) takes both device-side initialisations,
+    # whatever is left after the filter: the filtered copy does not exist on the host
+    big = N * G > 4_000_000 or device_cut
+    device_pca = K > 0 and hasattr(Engine, "pca_init") and (psi_init == "device" or (psi_init == "auto" and big))
     pcs = np.zeros((N, K)) if device_pca else hostprep.pca_init(Y_dat, K, psi_noise)
     if cached is not None and "loc0" in cached:
         loc0 = cached["loc0"]                                           # same data: same s_init check, same mu_guess
@@ -209,7 +216,7 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
         s_init = row_sums if row_sums is not None else Y_dat.sum(1, dtype=np.float64)
         if np.any(s_init == 0):
             raise ValueError("Some cells have no counts mapping")      # :212-214
-        if (isinstance(data_init_mu, (bool, np.bool_)) and bool(data_init_mu) and N * G > 4_000_000
+        if (isinstance(data_init_mu, (bool, np.bool_)) and bool(data_init_mu) and big
                 and getattr(Engine, "DEVICE_MU_INIT", False) and int((engine_opts or {}).get("world", 1)) == 1):
             loc0 = None  # the engine takes mu_guess (:220-235) and loc0 (:262) from the resident matrix: no host pass
         else:

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CA_ABI_VERSION 2
+#define CA_ABI_VERSION 3
 
 typedef struct ca_engine* ca_handle;
 
@@ -124,7 +124,9 @@ typedef struct ca_options {
   uint32_t variant_on;              /* ca_variant_on bits to switch on; 0 = defaults */
   int32_t ride_pattern;             /* 0 = default; else (a << 8) | b: a forward-sweep blocks, then b Y-stream blocks, ... in the dispatch
                                      * order of the merged launch (k_fwd_cell_mix_y); periods that divide 8 put the two kinds on disjoint XCDs */
-  int32_t reserved[4];
+  int32_t comm_timeout_ms;          /* peer-to-peer all-reduce: how long a rank waits on the device for its peers' flags before the call
+                                     * gives up and the engine reports CA_ERR_COMM (0 = 10 000 ms) */
+  int32_t reserved[3];
 } ca_options;
 /* (The same switches can be set from the environment -- CA_FUSED=0, CA_CSPLIT=12, ... -- but ONLY when
  *  CLONEALIGN_DEBUG_ENV is set: the library reads no configuration from the process environment otherwise.) */
@@ -189,8 +191,25 @@ int ca_comm_init(ca_handle h, const char id[128]);
  * trip.  Setup: every rank exports a handle, the caller exchanges them out of band (like the RCCL id: torch.distributed /
  * MPI all-gather), every rank connects.  Needs peer access between the devices (same node); ranks may share a device. */
 #define CA_P2P_HANDLE_BYTES 128
+/* Setup is two-phase so that a one-sided failure cannot leave the other ranks waiting on the device:
+ *   1. every rank: ca_p2p_export (allocates the slab in FINE-GRAINED device memory -- CA_ERR_COMM when that is unavailable, never
+ *      a coarse-grained fallback -- and returns the handle); the caller all-gathers the handles out of band;
+ *   2. every rank: ca_p2p_connect (maps the peers' slabs: IPC handles of other processes, the slab's own address for handles of
+ *      the SAME process -- one host process may drive several devices, one handle per device on one host thread each; peer access
+ *      is enabled between different devices).  Launches nothing and waits for nobody;
+ *   3. the caller agrees over its control plane whether step 2 succeeded on EVERY rank, then every rank calls
+ *      ca_p2p_commit(h, all_ok): 1 makes the transport the engine's all-reduce and reduces the setup sums (the first call that
+ *      waits for peers); 0 drops the mappings (next: ca_comm_init, or a host callback).
+ * The device-side wait for the peers' flags is bounded (ca_options.comm_timeout_ms): when it runs out the call leaves its buffer
+ * alone, every later all-reduce on this engine returns at once, and the next API call that synchronises returns CA_ERR_COMM.
+ * The engine is then dead: destroy it (a fresh process is the recovery).  Calls that reduce are collective: every rank must make
+ * the same sequence of ca_* calls, and a ca_run_ex poll hook must take the same decision on every rank. */
 int ca_p2p_export(ca_handle h, char handle[CA_P2P_HANDLE_BYTES]);
 int ca_p2p_connect(ca_handle h, const char* handles /* world x CA_P2P_HANDLE_BYTES, in rank order */);
+int ca_p2p_commit(ca_handle h, int32_t all_ranks_ok);
+/* us per all-reduce of n_doubles doubles on one device transport (CA_TRANSPORT_P2P or CA_TRANSPORT_RCCL) of this engine, n_calls
+ * back to back on the engine's stream between two HIP events; collective.  bench.py reports it beside the iteration time. */
+int ca_comm_benchmark(ca_handle h, int32_t transport, int32_t n_calls, int64_t n_doubles, double* us_per_call);
 /* Alternative transport for world > 1 (MPI, gloo, tests): the engine hands the summand buffer to the
  * host callback, which must replace buf[0..n) by its sum over all ranks (same order on every rank)
  * and return 0.  Slower than RCCL (one device<->host round trip per reduction); same results. */

@@ -68,7 +68,7 @@ def cheap_init(Y, K=1, seed=0):
     """Initialisation for benchmarks: psi0 ~ N(0,1) (the iteration rate does not depend on
     it; prcomp at 100k x 5k would dwarf the loop) and the reference's
     data-driven loc0 (R/inference-tflow.R:220-235,262)."""
-    from .hostprep import mu_guess, safe_inverse_softplus
+    from clonealign_amd.hostprep import mu_guess, safe_inverse_softplus
     rng = np.random.default_rng(seed)
     psi0 = rng.normal(size=(Y.shape[0], K))
     loc0 = safe_inverse_softplus(np.maximum(mu_guess(Y, True), 1e-6))

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), s
     assert set(syms) == set(engine.EXPORTS)
-    assert lib.ca_abi_version() == engine.CA_ABI_VERSION == 2
+    assert lib.ca_abi_version() == engine.CA_ABI_VERSION == 3
 
 
 PROBE = r"""
@@ -35,7 +35,7 @@ int main(void) {
   printf("ca_problem %zu\nca_options %zu\nca_info %zu\nca_preprocess_params %zu\n", sizeof(ca_problem), sizeof(ca_options),
          sizeof(ca_info), sizeof(ca_preprocess_params));
   F(ca_problem, Y); F(ca_problem, extra_loglik); F(ca_problem, N_src); F(ca_problem, G_src); F(ca_problem, cell_index); F(ca_problem, gene_index);
-  F(ca_options, seed); F(ca_options, profile); F(ca_options, variant_off); F(ca_options, tune); F(ca_options, variant_on); F(ca_options, ride_pattern); F(ca_options, reserved);
+  F(ca_options, seed); F(ca_options, profile); F(ca_options, variant_off); F(ca_options, tune); F(ca_options, variant_on); F(ca_options, ride_pattern); F(ca_options, comm_timeout_ms); F(ca_options, reserved);
   F(ca_info, y_device_bytes); F(ca_info, fwd_cell); F(ca_info, y_mfma); F(ca_info, transport); F(ca_info, y_ride); F(ca_info, red_n);
   printf("version %d\n", CA_ABI_VERSION);
   return 0;

@@ -117,3 +117,22 @@ def test_bench_two_ranks_use_a_device_transport_and_fail_loudly_without_one():
         assert r.returncode == 0, r.stderr[-2000:]
         line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         assert line["config"]["collective"] == "gloo-host-fallback" and line["config"]["collectives_tried"] == ["rccl", "host"]
+
+
+@pytest.mark.skipif(_gpus() < 8, reason="needs an 8-GPU node (BASELINE.json configs[3]: 100k x 5k x 8 cell-sharded over 8 MI355X)")
+def test_bench_on_eight_gpus_uses_a_device_collective_and_replicas_agree(tmp_path):
+    """The driver's scaling run, as a test for the day a node is available: bench.py --gpus 8 --steps 20 at the full BASELINE
+    size must come up on a DEVICE transport (peer-to-peer over xGMI, else RCCL), report the collective's own cost, and the
+    8-rank fit of tools/dist_check.py must leave bit-identical replicas that match the one-handle fit."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1800, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["config"]["collective"] in {"p2p", "rccl"}, line["config"]
+    assert line["config"]["allreduce_doubles_per_train_pass"] == 3 + 8 + 5000 * 2 + 5000
+    assert line["allreduce_us"].get(line["config"]["collective"], 0) > 0, line["allreduce_us"]
+    single = _run(1, "none", tmp_path / "one.json", True)["ranks"][0]
+    for tr in ("p2p", "rccl"):
+        _check(_run(8, tr, tmp_path / f"{tr}8.json", False), single, tr)

@@ -10,7 +10,7 @@ pytestmark = pytest.mark.gpu
 
 def _synth(N, G, C, seed=20243, device_counts=False):
     import torch
-    from clonealign_amd import synth
+    import synth_data as synth
     from clonealign_amd.hostprep import safe_inverse_softplus
     Yd, aux = synth.make_problem_torch(N, G, C, seed=seed, device="cuda:0")
     rm = Yd.sum(1, keepdim=True).to(torch.float64) / G
@@ -384,6 +384,32 @@ def test_inference_tflow_device_mu_init_equals_host_init():
     ea, eb = a["convergence_info"]["elbo"], b["convergence_info"]["elbo"]
     assert len(ea) == len(eb) == 16
     assert np.abs(ea - eb).max() <= 1e-4 * np.abs(eb).max()
+    assert np.array_equal(a["ml_params"]["clone_probs"].argmax(1), b["ml_params"]["clone_probs"].argmax(1))
+
+
+@pytest.mark.parametrize("psi_init", ["auto", "host"])
+def test_inference_tflow_just_above_the_device_cut_threshold_with_filtered_genes(psi_init):
+    """2100 x 2000 counts (4.2e6 > 4e6: the engine cuts the raw matrix at upload) with 200 all-zero genes: after the gene
+    filter of R/inference-tflow.R:117-124 only 3.78e6 counts are left -- below the threshold of the device-side
+    initialisations.  The fit must run (round-2 regression: ValueError) and equal the fit on the host-filtered copy."""
+    from clonealign_amd.inference import inference_tflow
+    rng = np.random.default_rng(33)
+    N, G, C = 2100, 2000, 3
+    L = rng.integers(1, 5, size=(G, C)).astype(np.float64)
+    L[L.min(1) == L.max(1), 0] += 1
+    z = rng.integers(0, C, N)
+    Y = rng.poisson(rng.lognormal(-1.0, 1.0, G)[None, :] * L[:, z].T * 0.5).astype(np.int32)
+    Y[:, Y.sum(0) == 0] = 1
+    dead = rng.choice(G, 200, replace=False)
+    Y[:, dead] = 0
+    kw = dict(max_iter=12, rel_tol=1e-9, verbose=False, seed=4, K=1, psi_init=psi_init)
+    a = inference_tflow(Y, L, **kw)
+    assert a["retained_mask"].sum() == G - 200 and not a["retained_mask"][dead].any()
+    keep = a["retained_mask"]
+    b = inference_tflow(Y[:, keep], L[keep], **{**kw, "psi_init": "device" if psi_init == "auto" else "host"})
+    ea, eb = a["convergence_info"]["elbo"], b["convergence_info"]["elbo"]
+    assert len(ea) == len(eb) == 13
+    assert np.abs(ea - eb).max() <= 1e-4 * np.abs(eb).max()   # (device mu_guess vs host mu_guess: 2e-6 on loc0)
     assert np.array_equal(a["ml_params"]["clone_probs"].argmax(1), b["ml_params"]["clone_probs"].argmax(1))
 
 

@@ -254,3 +254,10 @@ def test_cell_and_gene_selection_equals_fitting_the_filtered_copy(example):
         sub = Y[np.ix_(np.arange(Y.shape[0]) if rows is None else rows, np.arange(Y.shape[1]) if cols is None else cols)]
         np.testing.assert_array_equal(hostprep.selected_sums(Y, rows, cols, 0), sub.sum(0))
         np.testing.assert_array_equal(hostprep.selected_sums(Y, rows, cols, 1), sub.sum(1))
+    # floating-point counts: summed directly over the selection (no full-sum-minus-dropped shortcut), so a gene whose selected
+    # counts are all zero compares as an exact 0 against the gene filter's threshold whatever the dropped cells hold
+    Yf = Y.astype(np.float64) + 0.1
+    Yf[np.flatnonzero(kc), 5] = 0.0
+    col = hostprep.selected_sums(Yf, np.flatnonzero(kc), None, 0)
+    assert col[5] == 0.0
+    np.testing.assert_array_equal(col, Yf[kc].sum(0))

@@ -46,7 +46,7 @@ def test_simd_baseline_port_follows_the_float64_port(shape):
     ELBO terms before and after gamma init, then seven Adam iterations (float32 accumulation over the genes: 1e-5 on the ELBO;
     the q(z) logits are O(1e3) numbers updated from differences of such numbers: 5e-3 of their range).  Loaded AFTER the float64
     port on purpose: the SIMD library must not depend on flush-to-zero being set by whoever was loaded first."""
-    from clonealign_amd import synth
+    import synth_data as synth
     from oracle.c_port import CSimdModel
     N, G, C, K, P = shape
     d = synth.make_problem(N, G, C, seed=3, median_s=500)

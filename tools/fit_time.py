@@ -8,7 +8,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-from clonealign_amd import synth  # noqa: E402
+import synth_data as synth  # noqa: E402
 from clonealign_amd.engine import HipEngine  # noqa: E402
 from clonealign_amd.hostprep import safe_inverse_softplus  # noqa: E402
 
