@@ -76,7 +76,8 @@ def cpu_baseline(Ycells, L, psi0, loc0, K, N_full, budget_s=22.0):
     rows, cores = [], 1
     for n in sizes:
         r = c_port.time_baseline(Ycells[:n], L, psi0, loc0, K, N_full, budget_s * n / sum(sizes), simd=True)
-        rows.append({"cells": n, "scaled_it_per_s": r["value"], "s_per_iter_sample": n / N_full / r["value"]})
+        rows.append({"cells": n, "scaled_it_per_s": r["value"], "s_per_iter_sample": n / N_full / r["value"],
+                     "us_per_cell": 1e6 / (N_full * r["value"])})   # flat over the samples = time linear in the cell count
         cores = r["cores"]
     scalar = c_port.time_baseline(Ycells[:sizes[0]], L, psi0, loc0, K, N_full, 4.0)
     big = rows[-1]
@@ -88,6 +89,30 @@ def cpu_baseline(Ycells, L, psi0, loc0, K, N_full, budget_s=22.0):
                       + ", ".join(f"{r['cells']} cells {r['s_per_iter_sample'] * 1e3:.1f} ms/iter" for r in rows),
             "samples": rows, "extrapolated": not full,
             "scalar_f64": {"value": scalar["value"], "unit": "iterations/s", "cores": scalar["cores"], "sample": scalar["sample"]}}
+
+
+def parity_check(eng, Ycells, L, psi0, loc0, K, iters=2):
+    """Outside the timed region: the engine, restarted from its initial values, against the float64 C oracle on the SAME matrix
+    through the whole-loop call (gamma init, initial ELBO, `iters` iterations of ca_run vs the oracle driven call by call,
+    R/inference-tflow.R:368-417).  Reports the largest relative ELBO difference and the largest relative parameter difference."""
+    from clonealign_amd.inference import run_vi_loop
+    from clonealign_amd.rng import EpsStream
+    from oracle.c_port import CPortModel
+    G = Ycells.shape[1]
+    t0 = time.perf_counter()
+    ora = CPortModel(Ycells, L, psi0, loc0, K, dtype="float32")
+    try:
+        eng.reinit(psi0, loc0)
+        tr = np.asarray(eng.run(EpsStream(77, 1, G), iters, 1e-12))
+        to = np.asarray(run_vi_loop(ora, EpsStream(77, 1, G), iters, 1e-12))
+        se, so = eng.get_state(), ora.get_state()
+        perr = max(float(np.abs(se[n] - so[n]).max(initial=0) / max(np.abs(so[n]).max(initial=0), 1e-30)) for n in so)
+    finally:
+        ora.close()
+    return {"iters": iters, "cells": int(Ycells.shape[0]), "max_rel_elbo": float(np.abs(tr - to).max() / np.abs(to).max()),
+            "max_rel_param": perr, "elbo_engine": tr.tolist(), "elbo_oracle": to.tolist(), "seconds": time.perf_counter() - t0,
+            "what": "ca_run on the bench engine (restarted from its initial values) vs oracle/c/clonealign_oracle.c (float64 arithmetic, "
+                    "float32 variables) on the same cells, same eps stream; not part of any timed region"}
 
 
 def cpu_ref_dataflow(budget_s=10.0):
@@ -137,6 +162,8 @@ def main():
     ap.add_argument("--allow-host-fallback", action="store_true",
                     help="at --gpus > 1, let the run continue on the gloo host all-reduce when no device transport comes up "
                          "(the result is then NOT a measurement of the device data path)")
+    ap.add_argument("--busy-seconds", type=float, default=4.0,
+                    help="untimed iterations run for this long after the measurements (single GPU), so that a coarse GPU-utilisation sampler sees the device at work")
     ap.add_argument("--allow-foreign-lib", action="store_true",
                     help="run a library whose ca_build_id() is not the tree's (CLONEALIGN_HIP_LIB timing builds; labelled in the output)")
     ap.add_argument("--no-live-events", action="store_true",
@@ -154,6 +181,10 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # CPU baseline: the OpenMP team is pinned before any OpenMP runtime starts, so the pages of the baseline's float32 matrix
+    # (first touched inside its own parallel loop, oracle/c/clonealign_simd.c) stay local to the threads that stream them
+    os.environ.setdefault("OMP_PROC_BIND", "spread")
+    os.environ.setdefault("OMP_PLACES", "threads")
 
     import torch
     import torch.distributed as dist
@@ -361,6 +392,16 @@ def main():
     finals = eng.final_elbo(None, 20)
     eng.synchronize()
     fit_s = time.perf_counter() - t1
+    # keep the device demonstrably busy for a few seconds after the measurements (untimed): the timed regions of a 20-step run are
+    # 35 ms inside a minute of CPU baseline, which a once-per-few-seconds utilisation sampler around the run never lands on
+    busy_s, busy_it = 0.0, 0
+    if world == 1 and args.busy_seconds > 0:
+        tb = time.perf_counter()
+        while time.perf_counter() - tb < args.busy_seconds:
+            eng.iterate(args.steps, eps_t)
+            eng.synchronize()
+            busy_it += args.steps
+        busy_s = time.perf_counter() - tb
     if not np.isfinite(last):
         raise SystemExit(f"non-finite ELBO after the timed steps: {last}")
 
@@ -438,6 +479,9 @@ def main():
                               "what": "ca_reinit (initial values, fresh Adam state), ca_run + 20 final ELBOs, eps generated by the "
                                       "built-in Philox stream (inside the time)"},
         }
+        if busy_it:
+            out["untimed_busy_tail"] = {"seconds": busy_s, "iterations": busy_it, "it_per_s": busy_it / busy_s,
+                                        "what": "untimed ca_iterate calls after the measurements (see --busy-seconds); not part of value"}
         if mon_us is not None:
             out["monitor_pass_us_with_collective"] = mon_us
         if ar_us is not None:
@@ -449,6 +493,11 @@ def main():
                 n_cpu = n_loc if psutil.virtual_memory().available > 10 * 8 * n_loc * G else 65536
             Ysample = Yd[:min(n_cpu, n_loc)].cpu().numpy().astype(np.float64)
             del Yd
+            try:
+                out["parity_check"] = parity_check(eng, Ysample, aux["L"], psi0[:Ysample.shape[0]], loc0, K) if Ysample.shape[0] == n_loc else {
+                    "skipped": "the host has no room for the full matrix in float64; tests/test_gpu_scale.py holds the at-size check"}
+            except Exception as ex:  # noqa: BLE001
+                out["parity_check"] = {"error": str(ex)[:300]}
             out["cpu_baseline"] = cpu_baseline(Ysample, aux["L"], psi0, loc0, K, N)
             try:
                 out["cpu_ref_dataflow"] = cpu_ref_dataflow()

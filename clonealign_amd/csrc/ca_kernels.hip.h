@@ -2222,6 +2222,7 @@ struct ca_yride_args {
   const uint8_t* Y; const float* F; int Dstride; const float* V; float* YWpart; float* YTpart;
   int G, Gp, nseg, nrb, TR, nb_main, nb_y;   // nb_y = nb_main + overflow-list blocks
   int pat_a, pat_b;                          // interleave: pat_a sweep blocks, then pat_b stream blocks, ...
+  int pers;                                  // > 0: that many LONG-LIVED stream blocks lead the grid, block s takes units s, s + pers, ...
   ca_ovf_args ovf;
 };
 // true: sweep block idx, false: stream block idx.  Periods of pa sweep blocks followed by pb stream blocks while both kinds last,
@@ -2243,6 +2244,9 @@ __device__ __forceinline__ bool ca_ride_split(int b, int nf, int ny, int pa, int
 #ifndef CA_RIDE_WAVES
 #define CA_RIDE_WAVES 1   // (lab: minimum waves per SIMD the merged launch's register budget is set for)
 #endif
+#ifdef CA_LAB_STAMPS   // timing lab only: every block of the merged launch leaves {start, end, kind << 32 | index, HW_ID | XCC_ID << 32}
+__device__ unsigned long long ca_lab_stamps[8192 * 4];
+#endif
 template <int D, int TLB, int TLS>
 __global__ void __launch_bounds__(CA_TB, CA_RIDE_WAVES) k_fwd_cell_mix_y(const float* __restrict__ F, const float* __restrict__ etamax2,
                                                           const float* __restrict__ Vs, const unsigned short* __restrict__ Mq,
@@ -2253,19 +2257,130 @@ __global__ void __launch_bounds__(CA_TB, CA_RIDE_WAVES) k_fwd_cell_mix_y(const f
   constexpr size_t YW_ = sizeof(float) * (CA_TB / 64) * 64 * 17;
   __shared__ __attribute__((aligned(16))) unsigned char smem[FW > YW_ ? FW : YW_];
   int idx;
-  if (!ca_ride_split((int)blockIdx.x, nf, y.nb_y, y.pat_a, y.pat_b, idx)) {
+#ifdef CA_LAB_STAMPS
+  const unsigned long long st0_ = __builtin_amdgcn_s_memrealtime();
+#endif
+  bool sweep;
+  if (y.pers > 0) {
+    // Long-lived stream blocks first: y.pers of them (two per CU) take the leading slots and walk through ALL units of the count
+    // matrix, so the stream holds the same share of every CU's slots for as long as it lasts -- with stream blocks of one unit
+    // the slots they free go to whatever comes next in the grid, mostly sweep blocks, and the CUs end up with unequal numbers of
+    // those (tools/stamps.py).  The sweep's blocks follow, then the overflow list's.
+    const int b = (int)blockIdx.x;
+    sweep = b >= y.pers && b < y.pers + nf;
+    idx = sweep ? b - y.pers : (b < y.pers ? b : y.nb_main + (b - y.pers - nf));
+  } else {
+    sweep = ca_ride_split((int)blockIdx.x, nf, y.nb_y, y.pat_a, y.pat_b, idx);
+  }
+  if (!sweep) {
+#ifdef CA_LAB_YPRIO
+    __builtin_amdgcn_s_setprio(CA_LAB_YPRIO);
+#endif
+    if (y.pers > 0 && idx < y.pers) {
+      for (int u = idx; u < y.nb_main; u += y.pers)
+        ca_ypass_body<uint8_t, 1, 0>(u, y.Y, y.F, y.Dstride, y.V, 0, y.YWpart, y.YTpart, N, y.G, y.Gp, y.nseg, y.nrb, y.TR, 1, y.ovf, y.nb_main,
+                                     reinterpret_cast<float (*)[64][17]>(smem));
+    } else
     ca_ypass_body<uint8_t, 1, 0>(idx, y.Y, y.F, y.Dstride, y.V, 0, y.YWpart, y.YTpart, N, y.G, y.Gp, y.nseg, y.nrb, y.TR, 1, y.ovf, y.nb_main,
                                  reinterpret_cast<float (*)[64][17]>(smem));
-    return;
+  } else {
+    ca_f32x4* comb = reinterpret_cast<ca_f32x4*>(smem);
+    double* sm = reinterpret_cast<double*>(smem + sizeof(ca_f32x4) * 4 * TLB * 64);
+    double* la = sm + CA_TB;
+    ca_log_softmax_alpha(alpha_u, C, la);
+    if (nbig > 0 && idx >= nbig)
+      ca_fwd_cell_body<D, TLS>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)nbig * (TLB * 16) + (int64_t)(idx - nbig) * (TLS * 16), idx, comb, sm, la);
+    else
+      ca_fwd_cell_body<D, TLB>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)idx * (TLB * 16), idx, comb, sm, la);
   }
-  ca_f32x4* comb = reinterpret_cast<ca_f32x4*>(smem);
-  double* sm = reinterpret_cast<double*>(smem + sizeof(ca_f32x4) * 4 * TLB * 64);
-  double* la = sm + CA_TB;
-  ca_log_softmax_alpha(alpha_u, C, la);
-  if (nbig > 0 && idx >= nbig)
-    ca_fwd_cell_body<D, TLS>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)nbig * (TLB * 16) + (int64_t)(idx - nbig) * (TLS * 16), idx, comb, sm, la);
-  else
-    ca_fwd_cell_body<D, TLB>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)idx * (TLB * 16), idx, comb, sm, la);
+#ifdef CA_LAB_STAMPS
+  __syncthreads();
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {
+    unsigned long long* st = ca_lab_stamps + 4 * (size_t)blockIdx.x;
+    st[0] = st0_; st[1] = __builtin_amdgcn_s_memrealtime();
+    st[2] = ((unsigned long long)(sweep ? (nbig > 0 && idx >= nbig ? 2 : 1) : 0) << 32) | (unsigned)idx;
+    st[3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+  }
+#endif
+}
+
+// The Y stream FUSED IN SEQUENCE with the sweep (round 3): every sweep block also streams one unit of the count matrix (one gene
+// segment x four row blocks, what a k_ypass block does), either before or after its sweep.  Block timelines of the interleaved
+// form (tools/stamps.py, profiles/r03_ab_ystream.txt) show why: everything resident on a CU -- sweep and stream blocks alike --
+// ends when that CU's vector work is done, CUs that drew two, three or four sweep blocks at the start end at 42, 62 and 83 us,
+// a stream block needs 83 us instead of the 40 it takes alone, and the launch ends when the last stragglers have gone through.
+// Here every block carries the same work, so every CU carries the same work, and at any time about half the blocks of a CU are
+// in their (latency-bound) stream phase while the other half has the vector pipes: which half goes first alternates along the
+// XCD's own block sequence, whichever way the dispatcher deals that sequence over the CUs (i = b / 8: i ^ (i >> 5)).
+// Blocks past the sweep's own: leftover stream units (small shards have more units than sweep blocks), then the overflow list's.
+template <int D, int TLB, int TLS>
+__global__ void __launch_bounds__(CA_TB, CA_RIDE_WAVES) k_fwd_cell_seq_y(const float* __restrict__ F, const float* __restrict__ etamax2,
+                                                                         const float* __restrict__ Vs, const unsigned short* __restrict__ Mq,
+                                                                         ca_cell_ptrs p, const float* __restrict__ alpha_u,
+                                                                         double* __restrict__ cell_part, int64_t N, int C, int K, int nk, int nbig,
+                                                                         int nf, ca_yride_args y) {
+  constexpr size_t FW = sizeof(ca_f32x4) * 4 * TLB * 64 + sizeof(double) * (CA_TB + 64);
+  constexpr size_t YW_ = sizeof(float) * (CA_TB / 64) * 64 * 17;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[FW > YW_ ? FW : YW_];
+  const int b = (int)blockIdx.x;
+#ifdef CA_LAB_STAMPS
+  const unsigned long long st0_ = __builtin_amdgcn_s_memrealtime();
+#endif
+  const bool sweep_blk = b < nf;
+  int unit;
+  bool first = false;
+  if (!sweep_blk) {                                // stream-only blocks
+    const int e = b - nf, rest = y.nb_main > nf ? y.nb_main - nf : 0;
+    unit = e < rest ? nf + e : y.nb_main + (e - rest);
+  } else {
+    const int i = b >> 3;
+    unit = b < y.nb_main ? b : -1;
+    first = ((i ^ (i >> 5)) & 1) != 0;
+#if defined(CA_LAB_YSKIP) && CA_LAB_YSKIP == 3   // timing lab only (wrong results): no stream phase at all
+    unit = -1;
+#endif
+#if defined(CA_LAB_SEQ_ORDER)                   // timing lab only: 0 = every block sweeps first, 1 = every block streams first
+    first = CA_LAB_SEQ_ORDER != 0;
+#endif
+  }
+  if (unit >= 0 && (!sweep_blk || first)) {
+#ifdef CA_LAB_YPRIO
+    __builtin_amdgcn_s_setprio(CA_LAB_YPRIO);
+#endif
+    ca_ypass_body<uint8_t, 1, 0>(unit, y.Y, y.F, y.Dstride, y.V, 0, y.YWpart, y.YTpart, N, y.G, y.Gp, y.nseg, y.nrb, y.TR, 1, y.ovf, y.nb_main,
+                                 reinterpret_cast<float (*)[64][17]>(smem));
+    if (sweep_blk) __syncthreads();
+#ifdef CA_LAB_YPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+  }
+  if (sweep_blk) {
+    ca_f32x4* comb = reinterpret_cast<ca_f32x4*>(smem);
+    double* sm = reinterpret_cast<double*>(smem + sizeof(ca_f32x4) * 4 * TLB * 64);
+    double* la = sm + CA_TB;
+    ca_log_softmax_alpha(alpha_u, C, la);
+    if (nbig > 0 && b >= nbig)
+      ca_fwd_cell_body<D, TLS>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)nbig * (TLB * 16) + (int64_t)(b - nbig) * (TLS * 16), b, comb, sm, la);
+    else
+      ca_fwd_cell_body<D, TLB>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)b * (TLB * 16), b, comb, sm, la);
+    if (unit >= 0 && !first) {
+      __syncthreads();
+#ifdef CA_LAB_YPRIO
+      __builtin_amdgcn_s_setprio(CA_LAB_YPRIO);
+#endif
+      ca_ypass_body<uint8_t, 1, 0>(unit, y.Y, y.F, y.Dstride, y.V, 0, y.YWpart, y.YTpart, N, y.G, y.Gp, y.nseg, y.nrb, y.TR, 1, y.ovf, y.nb_main,
+                                   reinterpret_cast<float (*)[64][17]>(smem));
+    }
+  }
+#ifdef CA_LAB_STAMPS
+  __syncthreads();
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {
+    unsigned long long* st = ca_lab_stamps + 4 * (size_t)blockIdx.x;
+    st[0] = st0_; st[1] = __builtin_amdgcn_s_memrealtime();
+    st[2] = ((unsigned long long)(b >= nf ? 0 : (nbig > 0 && b >= nbig ? 2 : 1)) << 32) | (unsigned)b;
+    st[3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+  }
+#endif
 }
 
 // fixed-order reduction of block partials: out[j] = sum_b part[b][j]; one block per column j

@@ -141,6 +141,7 @@ struct ca_engine {
   bool y_defer = false;
   bool ride_ok = false;   // the Y stream's blocks ride on the forward sweep's launch (k_fwd_cell_mix_y) instead of a side stream
   bool ride_ys = false;   // ... as the one-copy int8 matrix-core stream (k_fwd_cell_mix_ys)
+  bool ride_seq = false;  // ... fused in sequence into the sweep's own blocks (k_fwd_cell_seq_y)
   bool fold_gsum = false, fold_now = false;   // small problems: the backward sweep's partials are summed inside k_final_gene
   // per-gene prologue of the next fused pass, computed ahead by the train pass before it (ca_pre_args): the loops announce
   // the next (monitor, train) eps slots in hint_*, train_update fills the alternate partial buffers, fused_pass swaps them in
@@ -1111,10 +1112,21 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
     if (h->opt.ride_pattern > 0 && (h->opt.ride_pattern >> 8) > 0 && (h->opt.ride_pattern & 255) > 0) {
       ya.pat_a = h->opt.ride_pattern >> 8; ya.pat_b = h->opt.ride_pattern & 255;
     }
-    const dim3 grid((unsigned)(h->ncblk_f + ya.nb_y));
+    // ride_seq: no separate stream blocks -- sweep block b also streams unit b (k_fwd_cell_seq_y); units past the sweep's block
+    // count and the overflow list's blocks follow as stream-only blocks
+    const bool seq = h->ride_seq;
+    if (!seq && h->opt.ride_pattern < 0) ya.pers = std::min(-h->opt.ride_pattern, ya.nb_main);   // long-lived stream blocks lead the grid
+    const dim3 grid(seq ? (unsigned)(h->ncblk_f + std::max(0, ya.nb_main - h->ncblk_f) + (ya.nb_y - ya.nb_main))
+                        : ya.pers > 0 ? (unsigned)(ya.pers + h->ncblk_f + (ya.nb_y - ya.nb_main)) : (unsigned)(h->ncblk_f + ya.nb_y));
 #define CA_FCY(DV, TLBV)                                                                                                              \
-  LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell_mix_y<DV, TLBV, 2>), grid, dim3(CA_TB), 0, h->stream, h->F, h->etamax2, h->Vs, h->Mq, \
-                                              cp, h->alpha_u, h->cell_part, h->N, h->C, h->K, h->nk32, h->fc_nbig, h->ncblk_f, ya))
+  do {                                                                                                                                \
+    if (seq)                                                                                                                          \
+      LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell_seq_y<DV, TLBV, 2>), grid, dim3(CA_TB), 0, h->stream, h->F, h->etamax2, h->Vs, h->Mq, \
+                                                  cp, h->alpha_u, h->cell_part, h->N, h->C, h->K, h->nk32, h->fc_nbig, h->ncblk_f, ya)); \
+    else                                                                                                                              \
+      LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell_mix_y<DV, TLBV, 2>), grid, dim3(CA_TB), 0, h->stream, h->F, h->etamax2, h->Vs, h->Mq, \
+                                                  cp, h->alpha_u, h->cell_part, h->N, h->C, h->K, h->nk32, h->fc_nbig, h->ncblk_f, ya)); \
+  } while (0)
     if (h->fc_tl == 8) { if (h->D == 1) CA_FCY(1, 8); else CA_FCY(2, 8); }
     else if (h->fc_tl == 6) { if (h->D == 1) CA_FCY(1, 6); else CA_FCY(2, 6); }
     else { if (h->D == 1) CA_FCY(1, 2); else CA_FCY(2, 2); }
@@ -1870,6 +1882,8 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   // the Y stream rides on the forward sweep's launch: 1-byte storage, K = 1, the fused sweep with its default block shapes
   h->ride_ok = h->ystore == CA_YSTORE_U8 && K == 1 && h->fused_ok && h->fwd_cell && (h->fc_tl == 6 || h->fc_tl == 8 || (h->fc_tl == 2 && h->fc_nbig == 0)) &&
                !h->y_mfma && !h->y_ys && variant_on(h, CA_VAR_Y_RIDE, "CA_Y_RIDE");
+  constexpr bool kRideSeqDefault = false;
+  h->ride_seq = h->ride_ok && variant_on(h, CA_VAR_RIDE_SEQ, "CA_RIDE_SEQ") && (kRideSeqDefault || variantx_on(h, CA_VARX_RIDE_SEQ, "CA_RIDE_SEQ_ON"));
   h->ride_ys = h->y_ys && h->fused_ok && h->fwd_cell && (h->fc_tl == 6 || (h->fc_tl == 2 && h->fc_nbig == 0)) &&
                variant_on(h, CA_VAR_Y_RIDE, "CA_Y_RIDE");
   h->off_g = 3 + C;
@@ -2048,6 +2062,11 @@ static int preprocess_t(const ST* src, int64_t N, int G, int C, int layout, cons
 extern "C" {
 
 int ca_abi_version(void) { return CA_ABI_VERSION; }
+#ifdef CA_LAB_STAMPS   // timing lab only (tools/stamps.py): per-block stamps of the last merged forward launch
+int ca_lab_read_stamps(unsigned long long* out, int n_blocks) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(ca_lab_stamps), (size_t)n_blocks * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
+}
+#endif
 #ifndef CA_BUILD_ID
 #define CA_BUILD_ID "unknown"
 #endif

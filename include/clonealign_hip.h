@@ -89,7 +89,9 @@ enum ca_variant {
   CA_VAR_PREP_FAST = 1 << 8,  /* wave-per-cell fit-constant kernel for u8 storage */
   CA_VAR_P2P = 1 << 10,       /* one-shot peer-to-peer all-reduce (else ncclAllReduce) after ca_comm_init() */
   CA_VAR_FOLD_GSUM = 1 << 11, /* small problems: backward-sweep partials summed inside the per-gene kernel (else a k_colsum launch) */
-  CA_VAR_Y_RIDE = 1 << 12     /* the Y stream's blocks ride on the forward sweep's launch (else side stream / in line) */
+  CA_VAR_Y_RIDE = 1 << 12,    /* the Y stream's blocks ride on the forward sweep's launch (else side stream / in line) */
+  CA_VAR_RIDE_SEQ = 1 << 13   /* off: the riding stream as blocks of its own interleaved in the sweep's grid (k_fwd_cell_mix_y), never fused in
+                                 sequence into the sweep's blocks (k_fwd_cell_seq_y; see CA_VARX_RIDE_SEQ) */
 };
 /* Opt-in variants (bits of ca_options.variant_on): measured slower than the default on the headline workload, kept built and
  * under test because they are the evidence for the choice. */
@@ -100,6 +102,8 @@ enum ca_variant_on {
   CA_VARX_Y_MFMA1 = 1 << 2,   /* both count-matrix products on the int8 matrix cores from ONE tiled copy, the column products through
                                  the transposing LDS read ds_read_b64_tr_b8 (k_ys_mfma; K = 1) */
   CA_VARX_FOLD_ALWAYS = 1 << 3, /* backward-sweep partials summed inside the per-gene kernel at every size (default: up to 32k cells) */
+  CA_VARX_RIDE_SEQ = 1 << 4,  /* riding Y stream fused in sequence: every forward-sweep block also streams one unit of the count matrix,
+                                 before or after its sweep (k_fwd_cell_seq_y), instead of separate stream blocks in the same grid */
   CA_VARX_ASYNC_SMALL = 1 << 1 /* side stream also below 4e7 counts (small shards run the Y stream in line: the two cross-stream
                                  events cost more than the overlap returns there) */
 };

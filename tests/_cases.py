@@ -31,3 +31,15 @@ def perturbed_state(model_shapes, seed=1, amp=0.3):
 
 def eps_for(S, G, seed):
     return np.random.default_rng(seed).normal(size=(S, G)).astype(np.float32)
+
+
+def label_flips(p_test, p_ref, threshold=0.95, margin=1e-3):
+    """clone_assignment of R/inference-tflow.R:22-29 on two [N,C] posterior matrices: label = argmax if max >= 0.95 else
+    "unassigned" (-1 here).  Returns (cells whose label differs, those of them whose reference maximum is NOT within
+    ``margin`` of the threshold).  A label can only flip where the maximum crosses 0.95 (above it the runner-up is <= 0.05),
+    so the second number must be 0 and the first is the count the tests print and bound."""
+    lt = np.where(p_test.max(1) >= threshold, p_test.argmax(1), -1)
+    lr = np.where(p_ref.max(1) >= threshold, p_ref.argmax(1), -1)
+    diff = lt != lr
+    near = np.abs(p_ref.max(1) - threshold) <= margin
+    return int(diff.sum()), int((diff & ~near).sum())

@@ -12,6 +12,7 @@ typedef struct rstub_sexp* SEXP;
 typedef ptrdiff_t R_xlen_t;
 typedef enum { FALSE = 0, TRUE = 1 } Rboolean;
 #define NILSXP 0
+#define LGLSXP 10
 #define INTSXP 13
 #define REALSXP 14
 #define STRSXP 16
@@ -25,6 +26,7 @@ int Rf_isNull(SEXP);
 int Rf_isInteger(SEXP);
 double* REAL(SEXP);
 int* INTEGER(SEXP);
+int* LOGICAL(SEXP);
 R_xlen_t XLENGTH(SEXP);
 SEXP Rf_allocVector(int type, R_xlen_t n);
 SEXP Rf_allocMatrix(int type, int nrow, int ncol);
@@ -48,6 +50,8 @@ Rboolean R_ToplevelExec(void (*fun)(void*), void* data);
 SEXP rstub_real_matrix(const double* data, int nrow, int ncol);   /* copies */
 SEXP rstub_int_matrix(const int* data, int nrow, int ncol);
 SEXP rstub_real_vector(const double* data, R_xlen_t n);
+SEXP rstub_list(R_xlen_t n);   /* VECSXP of R_NilValue */
+SEXP rstub_int_vector(const int* data, R_xlen_t n);
 SEXP rstub_scalar_int(int v);
 SEXP rstub_scalar_real(double v);
 const char* rstub_name(SEXP list, R_xlen_t i);

@@ -51,3 +51,89 @@ int harness_fit(const double* Yd, const int* Yi, int N, int G, const double* L, 
   rstub_free_all();
   return 0;
 }
+
+
+/* ---- the other .Call entry points, driven the same way ---- */
+SEXP C_clonealign_multifit(SEXP Y, SEXP L, SEXP psi0, SEXP psi_noise, SEXP loc0, SEXP X, SEXP extra, SEXP K_, SEXP S_, SEXP max_iter_,
+                           SEXP rel_tol_, SEXP lr_, SEXP eps_, SEXP devices_, SEXP want_sums_, SEXP call_prob_);
+SEXP C_clonealign_preprocess(SEXP Y, SEXP L, SEXP min_gene_, SEXP min_cell_, SEXP outl_, SEXP nmads_, SEXP max_cn_, SEXP same_cn_, SEXP device_);
+SEXP C_clonealign_allele_loglik(SEXP clone_allele, SEXP cov, SEXP ref, SEXP device_);
+
+/* R restarts; psi is [R][N*K] (psi0 when by_noise = 0, the PCA noise otherwise), eps [R][n_eps] or NULL.  Outputs are [R][...]. */
+int harness_multifit(const double* Yd, const int* Yi, int N, int G, const double* L, int C, const double* psi, int by_noise,
+                     const double* loc0, int K, int S, int max_iter, double rel_tol, double lr, const double* eps, long n_eps, int R,
+                     const int* devices, int n_dev, int want_sums, int interrupt_after, double* elbo, long* n_elbo, double* finals,
+                     double* mu, double* clone_probs, double* alpha, double* psi_out, double* W, double* T, double* Syy, char* err) {
+  rstub_interrupt_after = interrupt_after;
+  rstub_error_armed = 1;
+  if (setjmp(rstub_error_jmp)) {
+    rstub_error_armed = 0;
+    strncpy(err, rstub_error_msg, 1023); err[1023] = 0;
+    rstub_free_all();
+    return 1;
+  }
+  SEXP plist = rstub_list(R), elist = eps ? rstub_list(R) : R_NilValue;
+  for (int r = 0; r < R; ++r) {
+    SET_VECTOR_ELT(plist, r, rstub_real_matrix(psi + (size_t)r * N * K, N, K));
+    if (eps) SET_VECTOR_ELT(elist, r, rstub_real_vector(eps + (size_t)r * n_eps, n_eps));
+  }
+  SEXP out = C_clonealign_multifit(Yi ? rstub_int_matrix(Yi, N, G) : rstub_real_matrix(Yd, N, G), rstub_real_matrix(L, G, C),
+                                   by_noise ? R_NilValue : plist, by_noise ? plist : R_NilValue, loc0 ? rstub_real_vector(loc0, G) : R_NilValue,
+                                   R_NilValue, R_NilValue, rstub_scalar_int(K), rstub_scalar_int(S), rstub_scalar_int(max_iter),
+                                   rstub_scalar_real(rel_tol), rstub_scalar_real(lr), elist, rstub_int_vector(devices, n_dev),
+                                   rstub_scalar_int(want_sums), rstub_scalar_real(0.95));
+  rstub_error_armed = 0;
+  for (int r = 0; r < R; ++r) {
+    SEXP f = VECTOR_ELT(out, r);
+    copy_out(f, "elbo", elbo + (size_t)r * (max_iter + 1), max_iter + 1, n_elbo + r);
+    copy_out(f, "final_elbos", finals + (size_t)r * 20, 20, NULL);
+    copy_out(f, "mu", mu + (size_t)r * G, G, NULL);
+    copy_out(f, "clone_probs", clone_probs + (size_t)r * N * C, (long)N * C, NULL);
+    copy_out(f, "alpha", alpha + (size_t)r * C, C, NULL);
+    copy_out(f, "psi", psi_out + (size_t)r * N * K, (long)N * K, NULL);
+    copy_out(f, "W", W + (size_t)r * G * K, (long)G * K, NULL);
+    if (want_sums) {
+      copy_out(f, "T", T + (size_t)r * G * C, (long)G * C, NULL);
+      copy_out(f, "Syy", Syy + (size_t)r * G, G, NULL);
+    }
+  }
+  rstub_free_all();
+  return 0;
+}
+
+int harness_preprocess(const double* Yd, const int* Yi, int N, int G, const double* L, int C, double min_gene, double min_cell, int outl,
+                       double nmads, double max_cn, int same_cn, int* keep_gene, int* keep_cell, double* gene_sums, double* cell_sums, char* err) {
+  rstub_error_armed = 1;
+  if (setjmp(rstub_error_jmp)) {
+    rstub_error_armed = 0;
+    strncpy(err, rstub_error_msg, 1023); err[1023] = 0;
+    rstub_free_all();
+    return 1;
+  }
+  SEXP out = C_clonealign_preprocess(Yi ? rstub_int_matrix(Yi, N, G) : rstub_real_matrix(Yd, N, G), rstub_real_matrix(L, G, C),
+                                     rstub_scalar_real(min_gene), rstub_scalar_real(min_cell), rstub_scalar_int(outl), rstub_scalar_real(nmads),
+                                     rstub_scalar_real(max_cn), rstub_scalar_int(same_cn), rstub_scalar_int(0));
+  rstub_error_armed = 0;
+  memcpy(keep_gene, LOGICAL(VECTOR_ELT(out, 0)), sizeof(int) * (size_t)G);
+  memcpy(keep_cell, LOGICAL(VECTOR_ELT(out, 1)), sizeof(int) * (size_t)N);
+  memcpy(gene_sums, REAL(VECTOR_ELT(out, 2)), sizeof(double) * (size_t)G);
+  memcpy(cell_sums, REAL(VECTOR_ELT(out, 3)), sizeof(double) * (size_t)N);
+  rstub_free_all();
+  return 0;
+}
+
+int harness_allele(const double* clone_allele, int V, int C, const double* cov, const double* ref, int N, double* out, char* err) {
+  rstub_error_armed = 1;
+  if (setjmp(rstub_error_jmp)) {
+    rstub_error_armed = 0;
+    strncpy(err, rstub_error_msg, 1023); err[1023] = 0;
+    rstub_free_all();
+    return 1;
+  }
+  SEXP o = C_clonealign_allele_loglik(rstub_real_matrix(clone_allele, V, C), rstub_real_matrix(cov, N, V), rstub_real_matrix(ref, N, V),
+                                      rstub_scalar_int(0));
+  rstub_error_armed = 0;
+  memcpy(out, REAL(o), sizeof(double) * (size_t)N * C);
+  rstub_free_all();
+  return 0;
+}

@@ -22,7 +22,7 @@ static jmp_buf* toplevel_jmp = NULL;
 
 static SEXP mk(int type, R_xlen_t n, int nrow, int ncol) {
   struct rstub_sexp* s = (struct rstub_sexp*)calloc(1, sizeof(*s));
-  const size_t esz = type == REALSXP ? sizeof(double) : type == INTSXP ? sizeof(int) : sizeof(SEXP);
+  const size_t esz = type == REALSXP ? sizeof(double) : (type == INTSXP || type == LGLSXP) ? sizeof(int) : sizeof(SEXP);
   s->type = type; s->n = n; s->nrow = nrow; s->ncol = ncol;
   s->data = calloc((size_t)(n > 0 ? n : 1), esz);
   s->next = all_objs; all_objs = s;
@@ -36,8 +36,13 @@ int Rf_isNull(SEXP x) { return x == R_NilValue || x->type == NILSXP; }
 int Rf_isInteger(SEXP x) { return x->type == INTSXP; }
 double* REAL(SEXP x) { return (double*)x->data; }
 int* INTEGER(SEXP x) { return (int*)x->data; }
+int* LOGICAL(SEXP x) { return (int*)x->data; }
 R_xlen_t XLENGTH(SEXP x) { return x->n; }
-SEXP Rf_allocVector(int type, R_xlen_t n) { return mk(type, n, -1, -1); }
+SEXP Rf_allocVector(int type, R_xlen_t n) {
+  SEXP s = mk(type, n, -1, -1);
+  if (type == VECSXP) for (R_xlen_t i = 0; i < n; ++i) ((SEXP*)s->data)[i] = R_NilValue;
+  return s;
+}
 SEXP Rf_allocMatrix(int type, int nrow, int ncol) { return mk(type, (R_xlen_t)nrow * ncol, nrow, ncol); }
 SEXP Rf_mkNamed(int type, const char** names) {
   R_xlen_t n = 0;
@@ -51,7 +56,7 @@ SEXP SET_VECTOR_ELT(SEXP x, R_xlen_t i, SEXP v) { ((SEXP*)x->data)[i] = v; retur
 SEXP VECTOR_ELT(SEXP x, R_xlen_t i) { return ((SEXP*)x->data)[i]; }
 SEXP Rf_xlengthgets(SEXP x, R_xlen_t n) {
   SEXP y = mk(x->type, n, -1, -1);
-  const size_t esz = x->type == REALSXP ? sizeof(double) : x->type == INTSXP ? sizeof(int) : sizeof(SEXP);
+  const size_t esz = x->type == REALSXP ? sizeof(double) : (x->type == INTSXP || x->type == LGLSXP) ? sizeof(int) : sizeof(SEXP);
   memcpy(y->data, x->data, (size_t)(n < x->n ? n : x->n) * esz);
   return y;
 }
@@ -89,6 +94,8 @@ Rboolean R_ToplevelExec(void (*fun)(void*), void* data) {
 SEXP rstub_real_matrix(const double* d, int nrow, int ncol) { SEXP s = Rf_allocMatrix(REALSXP, nrow, ncol); memcpy(s->data, d, sizeof(double) * (size_t)nrow * ncol); return s; }
 SEXP rstub_int_matrix(const int* d, int nrow, int ncol) { SEXP s = Rf_allocMatrix(INTSXP, nrow, ncol); memcpy(s->data, d, sizeof(int) * (size_t)nrow * ncol); return s; }
 SEXP rstub_real_vector(const double* d, R_xlen_t n) { SEXP s = Rf_allocVector(REALSXP, n); memcpy(s->data, d, sizeof(double) * (size_t)n); return s; }
+SEXP rstub_list(R_xlen_t n) { return Rf_allocVector(VECSXP, n); }
+SEXP rstub_int_vector(const int* d, R_xlen_t n) { SEXP s = Rf_allocVector(INTSXP, n); memcpy(s->data, d, sizeof(int) * (size_t)n); return s; }
 SEXP rstub_scalar_int(int v) { SEXP s = Rf_allocVector(INTSXP, 1); ((int*)s->data)[0] = v; return s; }
 SEXP rstub_scalar_real(double v) { SEXP s = Rf_allocVector(REALSXP, 1); ((double*)s->data)[0] = v; return s; }
 const char* rstub_name(SEXP l, R_xlen_t i) { return l->names ? l->names[i] : ""; }

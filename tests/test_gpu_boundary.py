@@ -251,3 +251,118 @@ def test_r_shim_interrupt_and_error_paths_free_the_engine_first():
     # built-in eps stream (eps = NULL) works through the shim as well
     rc, msg, out = _call_shim(lib, case["Y"], case["L"], case["psi0"], None, 1, 1, 5, 1e-12, 0.1, None)
     assert rc == 0 and len(out["elbo"]) == 6 and np.all(np.isfinite(out["elbo"]))
+
+
+def _call_multifit(lib, Y, L, psi, by_noise, loc0, K, max_iter, eps, devices, want_sums, interrupt_after=0):
+    """psi: [R, N, K] (psi0 per restart, or the PCA noise per restart); eps: [R, draws, S*G] or None."""
+    N, G = Y.shape
+    Cn, R = L.shape[1], psi.shape[0]
+    ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)                       # noqa: E731
+    Yd = None if Y.dtype == np.int32 else np.asfortranarray(Y, dtype=np.float64)
+    Yi = np.asfortranarray(Y) if Y.dtype == np.int32 else None
+    Lf = np.asfortranarray(L, dtype=np.float64)
+    pf = np.ascontiguousarray(np.stack([np.asfortranarray(psi[r]).reshape(-1, order="F") for r in range(R)]))   # R column-major matrices
+    l0 = None if loc0 is None else np.ascontiguousarray(loc0, dtype=np.float64)
+    ev = None if eps is None else np.ascontiguousarray(eps, dtype=np.float64).reshape(R, -1)
+    dv = np.ascontiguousarray(devices, dtype=np.int32)
+    o = dict(elbo=np.zeros((R, max_iter + 1)), finals=np.zeros((R, 20)), mu=np.zeros((R, G)), clone_probs=np.zeros((R, N * Cn)),
+             alpha=np.zeros((R, Cn)), psi=np.zeros((R, N * K)), W=np.zeros((R, G * K)), T=np.zeros((R, G * Cn)), Syy=np.zeros((R, G)))
+    n_elbo = (C.c_long * R)()
+    err = C.create_string_buffer(1024)
+    lib.harness_multifit.restype = C.c_int
+    rc = lib.harness_multifit(ptr(Yd), ptr(Yi), C.c_int(N), C.c_int(G), ptr(Lf), C.c_int(Cn), ptr(pf), C.c_int(int(by_noise)), ptr(l0),
+                              C.c_int(K), C.c_int(1), C.c_int(max_iter), C.c_double(1e-12), C.c_double(0.1), ptr(ev),
+                              C.c_long(0 if ev is None else ev.shape[1]), C.c_int(R), ptr(dv), C.c_int(len(dv)), C.c_int(int(want_sums)),
+                              C.c_int(interrupt_after), ptr(o["elbo"]), n_elbo, ptr(o["finals"]), ptr(o["mu"]), ptr(o["clone_probs"]),
+                              ptr(o["alpha"]), ptr(o["psi"]), ptr(o["W"]), ptr(o["T"]), ptr(o["Syy"]), err)
+    o["n_elbo"] = [int(v) for v in n_elbo]
+    o["clone_probs"] = o["clone_probs"].reshape(R, Cn, N).transpose(0, 2, 1)     # column-major N x C per restart
+    o["psi"] = o["psi"].reshape(R, K, N).transpose(0, 2, 1)
+    o["W"] = o["W"].reshape(R, K, G).transpose(0, 2, 1)
+    o["T"] = o["T"].reshape(R, Cn, G).transpose(0, 2, 1)
+    return rc, err.value.decode(), o
+
+
+@pytest.mark.parametrize("ydt", [np.float64, np.int32])
+def test_r_shim_multifit_runs_the_restart_loop_on_resident_engines(ydt):
+    """C_clonealign_multifit (run_clonealign's restart loop, R/clonealign.R:50-56, as ONE .Call): five restarts dealt over two
+    worker threads (both on device 0 here; one per device on a node), the first restart of a worker uploads, the others are
+    ca_reinit()s.  Every restart must equal the Python mirror's separate fit with the same psi0 and eps bit for bit, and the
+    correlation sums (compute_correlations, :318-334) the mirror's device pass."""
+    from clonealign_amd.engine import HipEngine
+    lib = _harness()
+    case = make_case(seed=5, N=900, G=260, C=4, K=1)
+    N, G, R, max_iter = 900, 260, 5, 8
+    rng = np.random.default_rng(1)
+    psi = np.stack([case["psi0"] + rng.normal(0, 0.05, size=(N, 1)) for _ in range(R)])
+    eps = np.stack([np.stack([eps_for(1, G, 1000 * r + i) for i in range(2 + 2 * max_iter + 20)]) for r in range(R)])
+    Y = case["Y"].astype(ydt)
+    rc, msg, out = _call_multifit(lib, Y, case["L"], psi, False, case["loc0"], 1, max_iter, eps, [0, 0], True)
+    assert rc == 0, msg
+    for r in range(R):
+        eng = HipEngine(Y, case["L"], psi[r], case["loc0"], 1, 1, layout="col")
+        try:
+            t = eng.run(eps[r].astype(np.float32), max_iter, 1e-12)
+            fin = eng.final_elbo(eps[r, 2 + 2 * max_iter:].astype(np.float32), 20)
+            assert out["n_elbo"][r] == max_iter + 1 and np.array_equal(out["elbo"][r], t), r
+            assert np.array_equal(out["finals"][r], fin), r
+            p = eng.get_params()
+            for n in ("mu", "clone_probs", "alpha", "psi", "W"):
+                assert np.array_equal(out[n][r], np.asarray(p[n]).reshape(out[n][r].shape)), (r, n)
+            cp = np.asarray(p["clone_probs"])
+            call = np.where(cp.max(1) >= 0.95, cp.argmax(1), -1)
+            T, Syy = eng.clone_gene_sums(call)
+            assert np.array_equal(out["T"][r], T) and np.array_equal(out["Syy"][r], Syy), r
+        finally:
+            eng.close()
+    assert len({tuple(out["elbo"][r]) for r in range(R)}) == R          # five different restarts
+    # psi initialised on the device per restart (prcomp + scale of :204-208 by subspace iteration, plus the restart's noise)
+    noise = rng.normal(0, 0.05, size=(2, N, 1))
+    rc, msg, o2 = _call_multifit(lib, Y, case["L"], noise, True, None, 1, 4, None, [0], False)
+    assert rc == 0, msg
+    assert np.all(np.isfinite(o2["elbo"][:, :5])) and not np.array_equal(o2["psi"][0], o2["psi"][1])
+    # Ctrl-C while the workers run: they stop between iterations, the engines are freed, then R gets its error
+    rc, msg, _ = _call_multifit(lib, Y, case["L"], psi, False, case["loc0"], 1, 4000, None, [0, 0], False, interrupt_after=2)
+    assert rc == 1 and "interrupted" in msg
+
+
+def test_r_shim_preprocess_and_allele_entry_points_match_the_python_mirror():
+    """C_clonealign_preprocess (R/preprocess.R:93-147) and C_clonealign_allele_loglik (R/allele-specific.R:17-58) through the
+    stand-in R API, column-major, integer and double count matrices: identical to the ctypes mirror of the same C ABI."""
+    from clonealign_amd import engine as E
+    from clonealign_amd import preprocess as pre
+    lib = _harness()
+    rng = np.random.default_rng(9)
+    N, G, Cn = 700, 300, 4
+    L = rng.integers(1, 8, size=(G, Cn)).astype(np.float64)
+    Y = rng.poisson(rng.lognormal(0.0, 1.5, G)[None, :] * 0.6, size=(N, G)).astype(np.int32)
+    Y[:, :5] = 0
+    Y[:7] = 0
+    ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)                       # noqa: E731
+    for ydt in (np.int32, np.float64):
+        Yc = Y.astype(ydt)
+        kg, kc = np.zeros(G, dtype=np.int32), np.zeros(N, dtype=np.int32)
+        gs, cs = np.zeros(G), np.zeros(N)
+        err = C.create_string_buffer(1024)
+        Yf = np.asfortranarray(Yc)
+        lib.harness_preprocess.restype = C.c_int
+        rc = lib.harness_preprocess(ptr(Yf) if ydt == np.float64 else None, ptr(Yf) if ydt == np.int32 else None, C.c_int(N), C.c_int(G),
+                                    ptr(np.asfortranarray(L)), C.c_int(Cn), C.c_double(20.0), C.c_double(100.0), C.c_int(1), C.c_double(10.0),
+                                    C.c_double(6.0), C.c_int(1), ptr(kg), ptr(kc), ptr(gs), ptr(cs), err)
+        assert rc == 0, err.value
+        mg, mc, mgs, mcs = E.preprocess_masks(Yc, L, min_counts_per_gene=20, min_counts_per_cell=100, remove_outlying_genes=True,
+                                              nmads=10, max_copy_number=6, remove_genes_same_copy_number=True, layout="col")
+        assert np.array_equal(kg.astype(bool), mg) and np.array_equal(kc.astype(bool), mc)
+        assert np.array_equal(gs, mgs) and np.array_equal(cs, mcs)
+        assert 0 < kg.sum() < G and 0 < kc.sum() < N
+    V = 40
+    ca_ = rng.integers(1, 4, size=(V, Cn)).astype(np.float64)
+    cov = rng.integers(0, 30, size=(N, V)).astype(np.float64)
+    ref = np.floor(cov * rng.random((N, V)))
+    out = np.zeros((N, Cn), order="F")
+    err = C.create_string_buffer(1024)
+    lib.harness_allele.restype = C.c_int
+    rc = lib.harness_allele(ptr(np.asfortranarray(ca_)), C.c_int(V), C.c_int(Cn), ptr(np.asfortranarray(cov)), ptr(np.asfortranarray(ref)),
+                            C.c_int(N), ptr(out), err)
+    assert rc == 0, err.value
+    assert np.array_equal(out, E.allele_loglik(ca_, cov, ref, layout="col"))

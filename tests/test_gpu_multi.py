@@ -96,7 +96,7 @@ def _bench(world, extra, same_device=True):
         env["CLONEALIGN_BENCH_DEVICE"] = "0"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2",
-           "--repeats", "2", "--cells", "20000", "--genes", "1000", "--clones", "4", "--no-cpu-baseline", *extra]
+           "--repeats", "2", "--cells", "20000", "--genes", "1000", "--clones", "4", "--no-cpu-baseline", "--busy-seconds", "0", *extra]
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
 
 

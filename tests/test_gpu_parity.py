@@ -134,11 +134,12 @@ def test_example_sce_full_fit_matches_oracle():
     pg, po = fit_g["ml_params"], fit_o["ml_params"]
     for k in ("mu", "alpha", "psi", "W", "chi", "clone_probs"):
         assert _rel(pg[k], po[k]) < 1e-4, k
-    # labels identical except where the oracle itself sits within 1e-3 of the 0.95 threshold
-    mx = po["clone_probs"].max(1)
-    robust = np.abs(mx - 0.95) > 1e-3
-    assert np.array_equal(fit_g["clone"][robust], fit_o["clone"][robust])
-    assert robust.sum() >= 190
+    # labels: a flip is possible only where the oracle itself sits within 1e-3 of the 0.95 threshold; counted and bounded
+    from tests._cases import label_flips
+    flips, far = label_flips(pg["clone_probs"], po["clone_probs"])
+    n_lab = int((fit_g["clone"] != fit_o["clone"]).sum())
+    print(f"example_sce, 200 iterations: {flips} of 200 labels differ from the oracle's ({far} outside the 1e-3 margin)")
+    assert far == 0 and flips == n_lab and flips <= 2
 
 
 @pytest.mark.parametrize("name,n_iter", [("cfg1", 200), ("tiny_k0", 12), ("tiny_full", 12)])
@@ -157,10 +158,11 @@ def test_engine_replays_golden_vectors(name, n_iter):
         for k, v in p.items():
             assert _rel(v, g["param_" + k]) < 1e-4, k
         if name == "cfg1":
+            from tests._cases import label_flips
             lab = clone_assignment(p["clone_probs"], ["A", "B", "C"])
-            mx = g["param_clone_probs"].max(1)
-            robust = np.abs(mx - 0.95) > 1e-3
-            assert np.array_equal(lab[robust], g["clone"][robust]) and robust.sum() >= 190
+            flips, far = label_flips(p["clone_probs"], g["param_clone_probs"])
+            print(f"golden cfg1: {flips} of 200 labels differ from the golden's ({far} outside the 1e-3 margin)")
+            assert far == 0 and flips == int((lab != g["clone"]).sum()) and flips <= 2
     finally:
         eng.close()
 
@@ -384,8 +386,8 @@ def test_random_shapes_whole_loop_matches_oracle(shape):
             e = ora.elbo(eps[2 * i + 1])
         assert abs(last - e) <= 1e-4 * abs(e)
         p = eng.get_state()
-        for n in ora.VAR_NAMES:
-            assert _rel(p[n], getattr(ora, n)) < 1e-3, (n, _rel(p[n], getattr(ora, n)))
+        for n in ora.VAR_NAMES:    # north_star: ML parameters within 1e-4 relative
+            assert _rel(p[n], getattr(ora, n)) < 1e-4, (n, _rel(p[n], getattr(ora, n)))
     finally:
         eng.close()
 
@@ -519,8 +521,12 @@ def test_riding_dispatch_order_does_not_change_a_single_bit(shape):
     G = case["Y"].shape[1]
     epss = np.stack([eps_for(1, G, 300 + i) for i in range(10)])
     ref = None
-    for pat in (None, "1:1", "3:2", "16:8", "1:200", "255:1"):
-        eng = HipEngine(**case, tune=({} if pat is None else {"ride_pattern": pat}))
+    for pat in (None, "1:1", "3:2", "16:8", "1:200", "255:1", "seq", "mixed"):
+        # ("seq" / "mixed": the two ways the stream can ride -- fused in sequence into the sweep's own blocks, k_fwd_cell_seq_y, or as
+        #  blocks of their own interleaved in the same grid, k_fwd_cell_mix_y -- whichever of them is the default)
+        kw = (dict(variant_on=("ride_seq",)) if pat == "seq" else dict(variant_off=("ride_seq",)) if pat == "mixed" else
+              dict(tune=({} if pat is None else {"ride_pattern": pat})))
+        eng = HipEngine(**case, **kw)
         try:
             assert eng.info()["y_ride"] == 1
             eng.gamma_init(eps_for(1, G, 0))

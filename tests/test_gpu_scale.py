@@ -41,11 +41,11 @@ def test_cfg2_iterations_match_c_oracle():
         for n in ("W", "v", "psi", "alpha_unconstr", "loc", "ls", "gamma_logits"):
             err = np.abs(se[n] - so[n]).max() / max(np.abs(so[n]).max(), 1e-30)
             assert err < 1e-4, (n, err)
-        # clone calls: identical wherever the oracle is not within 1e-3 of the 0.95 threshold
-        pe, po = eng.get("clone_probs"), ora.get_params()["clone_probs"]
-        robust = np.abs(po.max(1) - 0.95) > 1e-3
-        assert np.array_equal(pe.argmax(1)[robust], po.argmax(1)[robust])
-        assert np.array_equal((pe.max(1) >= 0.95)[robust], (po.max(1) >= 0.95)[robust])
+        # clone calls (R/inference-tflow.R:22-29): counted; a flip needs the oracle within 1e-3 of the 0.95 threshold
+        from tests._cases import label_flips
+        flips, far = label_flips(eng.get("clone_probs"), ora.get_params()["clone_probs"])
+        print(f"cfg-2, 4 iterations: {flips} of {N} labels differ from the oracle's ({far} outside the margin)")
+        assert far == 0 and flips <= 2
     finally:
         eng.close(); ora.close()
 
@@ -64,7 +64,7 @@ def full():
                       shape=(hi - lo, G), **kw)
         del sub
         return e
-    return dict(N=N, G=G, C=C, make=make, Yd=Yd)
+    return dict(N=N, G=G, C=C, make=make, Yd=Yd, L=L, psi0=psi0, loc0=loc0)
 
 
 def _drive(eng, G, n_iter):
@@ -143,6 +143,77 @@ def test_full_size_two_shards_equal_one_engine(full):
         for n, v in st_ref.items():
             assert np.abs(out[r][1][n] - v).max() <= 1e-4 * max(np.abs(v).max(), 1e-30), n
             assert np.array_equal(out[r][1][n], out[0][1][n])
+
+
+def test_full_size_cfg3_matches_c_oracle(full):
+    """BASELINE.json configs[2] against the oracle AT SIZE: gamma init, initial ELBO and two iterations of the
+    whole-loop call the benchmark drives (ca_run: fused two-eps sweeps, the Y stream riding on the forward sweep, both
+    matrix-core sweeps) on all 100k cells x 5k genes x 8 clones, against the C/OpenMP float64 port run call by call
+    (R/inference-tflow.R:368-417; about 3 s per pass on the box's host cores).  Trace within 1e-5, parameters within 1e-4
+    (north_star), clone labels counted."""
+    from clonealign_amd.inference import run_vi_loop
+    from clonealign_amd.rng import EpsStream
+    from oracle.c_port import CPortModel
+    from tests._cases import label_flips
+    N, G, Yd, L, psi0, loc0 = (full[k] for k in ("N", "G", "Yd", "L", "psi0", "loc0"))
+    Y = np.empty((N, G), dtype=np.float64)
+    for b0 in range(0, N, 16384):
+        Y[b0:b0 + 16384] = Yd[b0:b0 + 16384].cpu().numpy()
+    eng = full["make"]()
+    ora = CPortModel(Y, L, psi0, loc0, 1, dtype="float32")
+    try:
+        info = eng.info()
+        assert (info["fwd_mfma"], info["bwd_mfma"], info["y_ride"], info["y_storage_name"]) == (1, 1, 1, "u8")
+        n_iter = 2
+        tr = np.asarray(eng.run(EpsStream(31, 1, G), n_iter, 1e-12))
+        to = np.asarray(run_vi_loop(ora, EpsStream(31, 1, G), n_iter, 1e-12))
+        rel = np.abs(tr - to).max() / np.abs(to).max()
+        print(f"cfg-3 at size: ELBO trace engine {tr.tolist()} oracle {to.tolist()} max rel {rel:.2e}")
+        assert tr.shape == to.shape == (n_iter + 1,) and rel <= 1e-5
+        se, so = eng.get_state(), ora.get_state()
+        for n in ("W", "v", "psi", "alpha_unconstr", "loc", "ls", "gamma_logits"):
+            err = np.abs(se[n] - so[n]).max() / max(np.abs(so[n]).max(), 1e-30)
+            assert err < 1e-4, (n, err)
+        flips, far = label_flips(eng.get("clone_probs"), ora.get_params()["clone_probs"])
+        print(f"cfg-3 at size: {flips} of {N} labels differ from the oracle's ({far} outside the 1e-3 margin)")
+        assert far == 0 and flips <= 5
+    finally:
+        eng.close(); ora.close()
+
+
+@pytest.mark.parametrize("seed", [2, 3, 4])
+def test_ragged_shapes_between_shard_and_bench_size_match_c_oracle(seed):
+    """tools/fuzz_large.py's sweep as fixed cases: ragged cell counts from 20k to 90k (both block sizes of the forward sweep,
+    several row groups of the Y stream, the resident-round split of the backward sweep), K in {1, 2}, optional covariate and
+    counts above 255 (overflow list), whole loop + final ELBOs against the C oracle."""
+    from clonealign_amd.engine import HipEngine
+    from clonealign_amd.inference import run_vi_loop
+    from clonealign_amd.rng import EpsStream
+    from oracle.c_port import CPortModel
+    from tests._cases import make_case
+    rng = np.random.default_rng(seed)
+    N, G, C = int(rng.integers(20_000, 90_000)), int(rng.integers(200, 1500)), int(rng.integers(2, 9))
+    K, P = int(rng.choice([1, 1, 2])), int(rng.choice([0, 0, 1]))
+    case = make_case(seed=int(rng.integers(0, 10**6)), N=N, G=G, C=C, K=K, **({"P": P} if P else {}))
+    if seed % 2 == 0:
+        idx = rng.integers(0, case["Y"].size, size=case["Y"].size // 20000)
+        case["Y"].reshape(-1)[idx] += rng.integers(200, 2000, size=idx.size)
+    eng = HipEngine(**case)
+    ora = CPortModel(case["Y"], case["L"], case["psi0"], case["loc0"], K, X=case["X"], dtype="float32")
+    try:
+        n_iter = 3
+        tr = np.asarray(eng.run(EpsStream(4, 1, G), n_iter, 1e-12))
+        to = np.asarray(run_vi_loop(ora, EpsStream(4, 1, G), n_iter, 1e-12))
+        eps = np.stack([eps_for(1, G, 60 + i) for i in range(3)])
+        fe, fo = eng.final_elbo(eps, 3), np.array([ora.elbo(e) for e in eps])
+        assert tr.shape == to.shape and np.abs(tr - to).max() <= 1e-5 * np.abs(to).max(), (N, G, C, K, P, tr, to)
+        assert np.abs(fe - fo).max() <= 1e-5 * np.abs(fo).max()
+        se, so = eng.get_state(), ora.get_state()
+        for n in ("W", "v", "psi", "beta", "alpha_unconstr", "loc", "ls", "gamma_logits"):
+            err = np.abs(se[n] - so[n]).max(initial=0) / max(np.abs(so[n]).max(initial=0), 1e-30)
+            assert err < 1e-4, (n, err, N, G, C, K, P)
+    finally:
+        eng.close(); ora.close()
 
 
 def test_edge_shapes_and_invalid_inputs():
@@ -475,12 +546,13 @@ def test_fused_loop_at_shard_size_matches_c_oracle(shape):
             ora.step(eps_it[2 * i]); lo = ora.elbo(eps_it[2 * i + 1])
         assert abs(last - lo) <= 1e-5 * abs(lo), (last, lo)
         se, so = eng.get_state(), ora.get_state()
-        for n in ("W", "v", "psi", "alpha_unconstr", "loc", "ls", "gamma_logits"):
+        for n in ("W", "v", "psi", "alpha_unconstr", "loc", "ls", "gamma_logits"):   # north_star: parameters within 1e-4
             err = np.abs(se[n] - so[n]).max() / max(np.abs(so[n]).max(), 1e-30)
-            assert err < 2e-4, (n, err)
-        pe, po = eng.get("clone_probs"), ora.get_params()["clone_probs"]
-        robust = np.abs(po.max(1) - 0.95) > 1e-3
-        assert np.array_equal(pe.argmax(1)[robust], po.argmax(1)[robust])
+            assert err < 1e-4, (n, err)
+        from tests._cases import label_flips
+        flips, far = label_flips(eng.get("clone_probs"), ora.get_params()["clone_probs"])
+        print(f"{shape}: {flips} of {N} labels differ from the oracle's ({far} outside the margin)")
+        assert far == 0 and flips <= 3
     finally:
         eng.close(); ora.close()
 
@@ -526,7 +598,7 @@ def test_config5_run_clonealign_eight_restarts_at_size():
         se, so = eng.get_state(), ora.get_state()
         for n in ("W", "v", "psi", "alpha_unconstr", "loc", "ls", "gamma_logits"):
             err = np.abs(se[n] - so[n]).max() / max(np.abs(so[n]).max(), 1e-30)
-            assert err < 2e-4, (n, err)
+            assert err < 1e-4, (n, err)
     finally:
         eng.close(); ora.close()
 

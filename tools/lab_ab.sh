@@ -5,7 +5,7 @@
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 ARGS="$1"; shift
 run() {
-  python3 $ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --allow-foreign-lib $ARGS 2>/dev/null | python3 -c "
+  python3 $ROOT/bench.py --steps 100 --warmup 10 --no-cpu-baseline --busy-seconds 0 --allow-foreign-lib $ARGS 2>/dev/null | python3 -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['kernel_ms_per_iter_warmup']
 print('%-28s %7.1f it/s %.4f ms  ' % ('$1', d['value'], d['ms_per_step']), {n: round(v*1e3) for n,v in k.items()})"

@@ -3,7 +3,7 @@ import json, os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def run(env, extra=()):
     e = dict(os.environ); e.update({k: str(v) for k, v in env.items()}); e["CLONEALIGN_DEBUG_ENV"] = "1"
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "5", "--no-cpu-baseline", *extra],
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "60", "--warmup", "5", "--no-cpu-baseline", "--busy-seconds", "0", *extra],
                          env=e, capture_output=True, text=True).stdout.strip().splitlines()[-1]
     d = json.loads(out)
     k = d["kernel_ms_per_iter_warmup"]
