@@ -485,7 +485,14 @@ __device__ __forceinline__ void ca_ypass_body(int blk, const YT* __restrict__ Y,
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int i = (i0 + u < nrows) ? i0 + u : nrows - 1;   // tail rows re-read the last row (never consumed)
-      buf[u] = *reinterpret_cast<const uint4*>(base + (int64_t)i * pitch + voff);
+      {   // Streamed once per pass: NON-TEMPORAL, so the matrix does not push what the sweeps share -- the B operand every sweep
+          // block re-reads, coef, the partial slabs -- out of the XCDs' L2.  With default-policy loads the 512 MB of a pass went
+          // through 8 x 4 MB of L2: the merged forward launch AND the kernels after it were slower (backward sweep 146 -> 140 us,
+          // the small kernels 44 -> 40 us; 3035 -> 3090 it/s at cfg-3, profiles/r03_ab_ystream.txt).
+        typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+        const v4u_ t_ = __builtin_nontemporal_load(reinterpret_cast<const v4u_*>(base + (int64_t)i * pitch + voff));
+        buf[u] = (uint4){t_.x, t_.y, t_.z, t_.w};
+      }
     }
   };
   float keep[KK];
@@ -1354,7 +1361,11 @@ __device__ __forceinline__ void ca_split3(float x, unsigned short& p1, unsigned 
 #ifndef CA_BWD_PD
 #define CA_BWD_PD 2   // batches of operands in flight per wave (3 and more cost the third wave per SIMD: 140 -> 200 us)
 #endif
-template <int TL, int DD>
+// FRAC (round 3): copy numbers that are not bf16-exact (clonealign() accepts any non-negative matrix; saturate() only caps it at 6,
+// R/clonealign.R:394-397).  L is then split in two bf16 parts like M in the forward sweep, coef in two, and the 24 operand slots
+// carry [c1 L_hi | c2 L_hi | c1 L_lo]: what is dropped (c2 L_lo, and the third part of coef) is below 2^-17 of the product -- the
+// forward sweep's own accuracy.  Integer copy numbers keep the exact three-part form.
+template <int TL, int DD, bool FRAC = false>
 __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __restrict__ cq /*[N16][4][8] bf16 parts of coef*/,
                                                     const float* __restrict__ F /*[N16][DD]*/, const float* __restrict__ etamax2 /*[N16]*/,
                                                     const float* __restrict__ Lb /*[G][8]*/, const float* __restrict__ mu,
@@ -1387,7 +1398,10 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
       const float lr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
       unsigned short b[8];
 #pragma unroll
-      for (int c = 0; c < 8; ++c) b[c] = ca_bf16_rn(lr[c]);
+      for (int c = 0; c < 8; ++c) {
+        b[c] = ca_bf16_rn(lr[c]);
+        if (FRAC && q == 2) b[c] = ca_bf16_rn(lr[c] - __uint_as_float((unsigned)b[c] << 16));   // the third slot group multiplies L_lo
+      }
       const unsigned msk = ok ? 0xFFFFFFFFu : 0u;
       const uint4 raw = {((unsigned)b[0] | ((unsigned)b[1] << 16)) & msk, ((unsigned)b[2] | ((unsigned)b[3] << 16)) & msk,
                          ((unsigned)b[4] | ((unsigned)b[5] << 16)) & msk, ((unsigned)b[6] | ((unsigned)b[7] << 16)) & msk};
@@ -1428,13 +1442,14 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
   // batch is 380 issue cycles = 0.6 us of wall time at three waves per SIMD, one batch of look-ahead left the wave parked on
   // s_waitcnt for 31 % of its cycles (SQ_WAIT_ANY, profiles/r01_v11_sq_counters.json) and far more beside an HBM stream.
   constexpr int PD = CA_BWD_PD;
+  const int qc = (FRAC && q == 2) ? 0 : q;   // which part of coef this lane group carries (FRAC: c1, c2, c1 again)
   uint4 craw_r[PD];
   float fc_r[PD][DD], ec_r[PD];
 #pragma unroll
   for (int d_ = 0; d_ < PD; ++d_) {
     const int64_t bb = n0 + 16 * d_;
     const int64_t bl = (active && bb < n1) ? bb : (N > 0 ? ((n0 < N) ? n0 : 0) : 0);   // past the slice: re-read its first batch (never used)
-    craw_r[d_] = *reinterpret_cast<const uint4*>(cq + ((bl + j) * 4 + q) * 8);
+    craw_r[d_] = *reinterpret_cast<const uint4*>(cq + ((bl + j) * 4 + qc) * 8);
 #pragma unroll
     for (int d = 0; d < DD; ++d) fc_r[d_][d] = F[(bl + j) * DD + d];
     ec_r[d_] = etamax2[bl + j];
@@ -1450,7 +1465,7 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
     for (int d = 0; d < DD; ++d) fc[d] = fc_r[d_][d];
     const float ec = ec_r[d_];
     if (b0 + 16 * PD < n1) {
-      craw_r[d_] = *reinterpret_cast<const uint4*>(cq + ((b0 + 16 * PD + j) * 4 + q) * 8);
+      craw_r[d_] = *reinterpret_cast<const uint4*>(cq + ((b0 + 16 * PD + j) * 4 + qc) * 8);
 #pragma unroll
       for (int d = 0; d < DD; ++d) fc_r[d_][d] = F[(b0 + 16 * PD + j) * DD + d];
       ec_r[d_] = etamax2[b0 + 16 * PD + j];
@@ -2114,25 +2129,34 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
   const ca_bf16x2 neg_lo = __builtin_bit_cast(ca_bf16x2, m0), neg_hi = __builtin_bit_cast(ca_bf16x2, m1);
   const uint4* Bq = reinterpret_cast<const uint4*>(Mq);
   constexpr int NV4 = 2 * D;   // float4 per lane and k-step: V'[8 genes][D]
-  uint4 b1n = {0u, 0u, 0u, 0u}, b2n = {0u, 0u, 0u, 0u};
-  float4 vn[NV4];
-#pragma unroll
-  for (int i = 0; i < NV4; ++i) vn[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto fetch = [&](int ks) {
-    b1n = Bq[(int64_t)ks * 128 + lane];
-    b2n = Bq[(int64_t)ks * 128 + 64 + lane];
+#ifndef CA_FWD_PF
+#define CA_FWD_PF 1   // k-steps of operands in flight per wave
+#endif
+  constexpr int PF = CA_FWD_PF;
+  uint4 b1r[PF], b2r[PF];
+  float4 vr[PF][NV4];
+  auto fetch = [&](int slot, int ks) {
+    b1r[slot] = Bq[(int64_t)ks * 128 + lane];
+    b2r[slot] = Bq[(int64_t)ks * 128 + 64 + lane];
     const float4* vp = reinterpret_cast<const float4*>(Vs + ((int64_t)ks * 32 + 8 * q) * D);
 #pragma unroll
-    for (int i = 0; i < NV4; ++i) vn[i] = vp[i];
+    for (int i = 0; i < NV4; ++i) vr[slot][i] = vp[i];
   };
-  int ks = wv;
-  if (ks < nk) fetch(ks);
-  for (; ks < nk; ks += 4) {
-    const ca_bf16x8 B1 = __builtin_bit_cast(ca_bf16x8, b1n), B2 = __builtin_bit_cast(ca_bf16x8, b2n);
+#pragma unroll
+  for (int s_ = 0; s_ < PF; ++s_) {
+    const int k0 = wv + 4 * s_;
+    fetch(s_, k0 < nk ? k0 : (nk - 1));
+  }
+  for (int ks0 = wv; ks0 < nk; ks0 += 4 * PF) {
+#pragma unroll
+  for (int s_ = 0; s_ < PF; ++s_) {
+    const int ks = ks0 + 4 * s_;
+    if (ks < nk) {   // wave-uniform
+    const ca_bf16x8 B1 = __builtin_bit_cast(ca_bf16x8, b1r[s_]), B2 = __builtin_bit_cast(ca_bf16x8, b2r[s_]);
     float vf[8 * D];
 #pragma unroll
-    for (int i = 0; i < NV4; ++i) { vf[4 * i] = vn[i].x; vf[4 * i + 1] = vn[i].y; vf[4 * i + 2] = vn[i].z; vf[4 * i + 3] = vn[i].w; }
-    if (ks + 4 < nk) fetch(ks + 4);
+    for (int i = 0; i < NV4; ++i) { vf[4 * i] = vr[s_][i].x; vf[4 * i + 1] = vr[s_][i].y; vf[4 * i + 2] = vr[s_][i].z; vf[4 * i + 3] = vr[s_][i].w; }
+    if (ks + 4 * PF < nk) fetch(s_, ks + 4 * PF);
 #pragma unroll
     for (int t = 0; t < TL; ++t) {
       unsigned hi[4], lo[4];
@@ -2156,6 +2180,8 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
       a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B1, a, 0, 0, 0);
       acc[t] = a;
     }
+    }   // ks < nk
+  }     // ring slot
   }
 #pragma unroll
   for (int t = 0; t < TL; ++t) comb[(wv * TL + t) * 64 + lane] = acc[t];

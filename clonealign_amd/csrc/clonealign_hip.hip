@@ -160,7 +160,7 @@ struct ca_engine {
   int fc_nbig = 0;                                     // > 0: k_fwd_cell_mix, that many blocks of 16 * fc_tl cells, the rest 32-cell blocks
   bool fwd_mfma = false; int fsplit = 1, fkchunk = 1, nk32 = 1; unsigned short* Mq = nullptr;   // matrix-core forward sweep
   // matrix-core backward sweep (k_bwd_mfma): bf16 parts of coef, its own cell split
-  bool bwd_mfma = false; unsigned short* coefq = nullptr; int64_t N16 = 0, cchunk_m = 0; int csplit_m = 1, nwt = 0;
+  bool bwd_mfma = false, bwd_frac = false; unsigned short* coefq = nullptr; int64_t N16 = 0, cchunk_m = 0; int csplit_m = 1, nwt = 0;
   uint64_t draw = 0;  // built-in stream position
   // count-matrix products on the int8 matrix cores (ca_ymfma.hip.h): tiled copies, fixed-point parameter images
   bool y_mfma = false;
@@ -855,9 +855,10 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
       merged = is_sharded(h);
       if (merged) { bwd_tail.reduce_only = 1; bwd_tail.host_out = nullptr; }
     }
-#define CA_BWDM(DDV)                                                                                                        \
+#define CA_BWDM(DDV) do { if (h->bwd_frac) CA_BWDM_(DDV, true); else CA_BWDM_(DDV, false); } while (0)
+#define CA_BWDM_(DDV, FRV)                                                                                                  \
   LAUNCH(h, CA_KERNEL_BWD,                                                                                                 \
-         hipLaunchKernelGGL((k_bwd_mfma<TL, DDV>), dim3(xb + ((s == 0 && bwd_tail.enabled) ? 1 : 0), h->csplit_m), dim3(CA_TB), \
+         hipLaunchKernelGGL((k_bwd_mfma<TL, DDV, FRV>), dim3(xb + ((s == 0 && bwd_tail.enabled) ? 1 : 0), h->csplit_m), dim3(CA_TB), \
                             (size_t)h->cchunk_m * 4 * DDV * sizeof(float), h->stream,                                       \
                             h->coefq + (int64_t)s * h->N16 * 32, h->F, h->etamax2, h->Lb, mu32 + (int64_t)s * h->G, h->Vs,  \
                             h->V, h->gpart, h->dFpart, h->N, h->G, h->cchunk_m, h->S, s, 1, s == 0 ? 1 : 0,                 \
@@ -867,6 +868,7 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
       else CA_BWDM(2);
     }
 #undef CA_BWDM
+#undef CA_BWDM_
     if (bwd_tail.enabled) {
       if (merged) { h->mon_tail.cell_part = nullptr; h->mon_tail.yw_part = nullptr; }   // local sums done; assembly still pending
       else h->mon_tail.enabled = 0;
@@ -1115,7 +1117,11 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
     // ride_seq: no separate stream blocks -- sweep block b also streams unit b (k_fwd_cell_seq_y); units past the sweep's block
     // count and the overflow list's blocks follow as stream-only blocks
     const bool seq = h->ride_seq;
-    if (!seq && h->opt.ride_pattern < 0) ya.pers = std::min(-h->opt.ride_pattern, ya.nb_main);   // long-lived stream blocks lead the grid
+    // Long-lived stream blocks lead the grid (ca_yride_args::pers) when there are at least two units of the matrix per CU: one
+    // such block per CU measured best (cfg-3, with the non-temporal stream: 2:1 interleave 3090, 256 blocks 3147, 341 / 512
+    // blocks 3008 / 2979, 192 / 128 blocks 2790 / 2320 it/s).  ride_pattern < 0 sets the number, > 0 asks for the interleave.
+    if (!seq && h->opt.ride_pattern < 0) ya.pers = std::min(-h->opt.ride_pattern, ya.nb_main);
+    else if (!seq && h->opt.ride_pattern == 0 && ya.nb_main >= 2 * h->n_cu) ya.pers = h->n_cu;
     const dim3 grid(seq ? (unsigned)(h->ncblk_f + std::max(0, ya.nb_main - h->ncblk_f) + (ya.nb_y - ya.nb_main))
                         : ya.pers > 0 ? (unsigned)(ya.pers + h->ncblk_f + (ya.nb_y - ya.nb_main)) : (unsigned)(h->ncblk_f + ya.nb_y));
 #define CA_FCY(DV, TLBV)                                                                                                              \
@@ -1669,7 +1675,8 @@ int create_impl(ca_engine* h, const ca_problem* p) {
       uint32_t u; memcpy(&u, &f, 4);
       if ((double)f != v || (u & 0xFFFFu) != 0) { exact = false; break; }
     }
-    h->bwd_mfma = exact && (D == 1 || D == 2) && h->nchunk == 1 && variant_on(h, CA_VAR_BWD_MFMA, "CA_BWD_MFMA");
+    h->bwd_frac = !exact;   // copy numbers that are not bf16-exact: the sweep's two-part form (k_bwd_mfma<.., FRAC>)
+    h->bwd_mfma = (D == 1 || D == 2) && h->nchunk == 1 && variant_on(h, CA_VAR_BWD_MFMA, "CA_BWD_MFMA");
     h->N16 = (Nn + 15) / 16 * 16;
     if (h->bwd_mfma) {
       h->nwt = cdiv(G, CA_BWD_TL * 16);
@@ -1678,7 +1685,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
         // resident blocks per CU from the compiler's register count (LDS, 16 B per cell of the slice, is not the limit
         // at the slice lengths this produces); one or two full rounds instead of "about 8 blocks per CU"
         int per_cu = 4;
-        const void* bfn = D == 1 ? (const void*)k_bwd_mfma<CA_BWD_TL, 1> : (const void*)k_bwd_mfma<CA_BWD_TL, 2>;
+        const void* bfn = D == 1 ? (const void*)k_bwd_mfma<CA_BWD_TL, 1, false> : (const void*)k_bwd_mfma<CA_BWD_TL, 2, false>;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bfn, CA_TB, 16 * 1024) != hipSuccess || per_cu < 1)
           per_cu = 4;
         (void)hipGetLastError();
