@@ -2555,14 +2555,23 @@ __global__ void __launch_bounds__(CA_TB) k_final_small(ca_small_args a) { ca_fin
 
 // ------------------------------------------------------------------ per-cell variables: the q(z) logits and the exponent bound
 // (psi's own step runs as extra blocks of k_final_gene, see ca_psi_args)
+// ------------------------------------------------------------------ count-matrix products on the int8 matrix cores
+#include "ca_ymfma.hip.h"
+
 __global__ void __launch_bounds__(CA_TB) k_adam_cell(const float* __restrict__ F, float* __restrict__ glogit, const float* __restrict__ dgl,
                                                      float* __restrict__ m_gl, float* __restrict__ v_gl, int64_t N, int C, int D,
                                                      int apply, float lr_t, float b1, float b2, float aeps,
                                                      const float* __restrict__ vmm_part, int ngblk, float* __restrict__ etamax2,
-                                                     ca_small_args tail, int cblocks, ca_pre_args pre) {
+                                                     ca_small_args tail, int cblocks, ca_pre_args pre, ca_ysq_args ysq) {
   // Block order = dispatch order: the two latency chains first (the next pass's per-gene prologue, then the O(K + C) update),
-  // the bandwidth-bound cell blocks after them -- the chains are what the kernel's duration hangs on.
+  // the bandwidth-bound cell blocks after them -- the chains are what the kernel's duration hangs on.  Last: the quantiser of
+  // the int8 count-matrix stream (ca_ys_quant_body), when that stream is in use: W and psi are final once k_final_gene has run.
   const int nx = pre.nblk + 1;
+  if ((int)blockIdx.x >= nx + cblocks) {
+    __shared__ float smq[2 * (CA_YM_TB / 64)];
+    ca_ys_quant_body((int)blockIdx.x - nx - cblocks, ysq, smq);
+    return;
+  }
   if ((int)blockIdx.x < nx) {
     const int b = (int)blockIdx.x;
     if (b < pre.nblk) {   // the next eps pair's per-gene prologue (ca_pre_args)
@@ -2627,8 +2636,6 @@ __global__ void __launch_bounds__(CA_TB) k_adam_cell(const float* __restrict__ F
   }
 }
 
-// ------------------------------------------------------------------ count-matrix products on the int8 matrix cores
-#include "ca_ymfma.hip.h"
 
 // Column products, engine form: the sweep of ca_yt_block plus, as extra blocks of the launch, the gene side of the overflow
 // list (per-chunk sums of the counts above 255; they depend on psi only).
@@ -2740,17 +2747,18 @@ __global__ void __launch_bounds__(CA_TB) k_p2p_allreduce(double* __restrict__ bu
   }
 }
 
-// the one-copy stream with the gene side of the overflow list (per-chunk sums of the counts above 255, psi only) as extra blocks
-__global__ void __launch_bounds__(CA_YM_TB, CA_YS_WAVES) k_ys_mfma_ovf(const uint8_t* __restrict__ Ys, const uint4* __restrict__ Wr,
-                                                                       const uint4* __restrict__ Pr, int64_t N, int Gp, int RS,
-                                                                       int* __restrict__ YWi, int* __restrict__ YTi, int nb_main, ca_ovf_args ovf,
-                                                                       const float* __restrict__ F, int Df) {
+// the one-copy stream with the overflow list's per-entry work (cell side, then gene side) as extra blocks, like k_ypass
+__global__ void __launch_bounds__(CA_YM_TB, CA_YS_WAVES) k_ys_mfma_ovf(const uint8_t* __restrict__ Ys, ca_ys_io io, int64_t N, int Gp, int RS,
+                                                                       int nb_main, ca_ovf_args ovf, const float* __restrict__ F,
+                                                                       const float* __restrict__ V, int Dstride) {
   if ((int)blockIdx.x >= nb_main) {
-    ca_ovf_chunks_body(blockIdx.x - nb_main, ovf.chunk_start, ovf.row2, ovf.val2, F, Df, ovf.csum, ovf.nchunk, 1, 0);
+    const int b = (int)blockIdx.x - nb_main;
+    if (b < ovf.nb_rows) ca_ovf_rows_body(b, ovf.rowptr, ovf.col, ovf.val, V, Dstride, ovf.YWextra, N, 1, 0);
+    else ca_ovf_chunks_body(b - ovf.nb_rows, ovf.chunk_start, ovf.row2, ovf.val2, F, Dstride, ovf.csum, ovf.nchunk, 1, 0);
     return;
   }
   extern __shared__ __attribute__((aligned(16))) unsigned char ca_ys_dyn[];
-  ca_ys_mfma_body<CA_YS_DEPTH>((int)blockIdx.x, Ys, Wr, Pr, N, Gp, RS, YWi, YTi, ca_ys_dyn);
+  ca_ys_mfma_body<CA_YS_DEPTH>((int)blockIdx.x, Ys, io, N, Gp, RS, ca_ys_dyn);
 }
 
 // The one-copy int8 matrix-core stream RIDING on the forward sweep's launch (round 3).  The vector stream of k_fwd_cell_mix_y
@@ -2761,10 +2769,11 @@ __global__ void __launch_bounds__(CA_YM_TB, CA_YS_WAVES) k_ys_mfma_ovf(const uin
 // Same block mix and dispatch order as k_fwd_cell_mix_y; stream blocks are ca_ys_mfma_body's (DEPTH pieces in flight per wave),
 // the overflow list's gene-side chunk blocks follow them.
 struct ca_ysride_args {
-  const uint8_t* Ys; const uint4* Wr; const uint4* Pr; int* YWi; int* YTi;
-  const float* F; int Df;
+  const uint8_t* Ys; ca_ys_io io;
+  const float* F; const float* V; int Df;
   int Gp, RS, nb_main, nb_y;   // nb_y = nb_main + overflow-chunk blocks
   int pat_a, pat_b;
+  int pers;                    // > 0: that many long-lived stream blocks lead the grid (see ca_yride_args::pers)
   ca_ovf_args ovf;
 };
 template <int D, int TLB, int TLS, int DEPTH>
@@ -2777,9 +2786,32 @@ __global__ void __launch_bounds__(CA_TB, DEPTH == 1 ? 4 : 3) k_fwd_cell_mix_ys(c
   constexpr size_t SM = FW > (size_t)CA_YS_LDS_BYTES ? FW : (size_t)CA_YS_LDS_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SM];
   int idx;
-  if (!ca_ride_split((int)blockIdx.x, nf, y.nb_y, y.pat_a, y.pat_b, idx)) {
-    if (idx >= y.nb_main) ca_ovf_chunks_body(idx - y.nb_main, y.ovf.chunk_start, y.ovf.row2, y.ovf.val2, y.F, y.Df, y.ovf.csum, y.ovf.nchunk, 1, 0);
-    else ca_ys_mfma_body<DEPTH>(idx, y.Ys, y.Wr, y.Pr, N, y.Gp, y.RS, y.YWi, y.YTi, smem);
+  bool sweep;
+  if (y.pers > 0) {
+    const int b = (int)blockIdx.x;
+    sweep = b >= y.pers && b < y.pers + nf;
+    idx = sweep ? b - y.pers : (b < y.pers ? b : y.nb_main + (b - y.pers - nf));
+  } else {
+    sweep = ca_ride_split((int)blockIdx.x, nf, y.nb_y, y.pat_a, y.pat_b, idx);
+  }
+  if (!sweep) {
+    if (idx >= y.nb_main) {   // the overflow list's blocks: cell side (an extra segment of YWpart), then gene side (chunk sums)
+      const int b = idx - y.nb_main;
+      if (b < y.ovf.nb_rows) ca_ovf_rows_body(b, y.ovf.rowptr, y.ovf.col, y.ovf.val, y.V, y.Df, y.ovf.YWextra, N, 1, 0);
+      else ca_ovf_chunks_body(b - y.ovf.nb_rows, y.ovf.chunk_start, y.ovf.row2, y.ovf.val2, y.F, y.Df, y.ovf.csum, y.ovf.nchunk, 1, 0);
+      return;
+    }
+#ifdef CA_LAB_YPRIO
+    __builtin_amdgcn_s_setprio(CA_LAB_YPRIO);
+#endif
+    if (y.pers > 0) {
+      for (int u = idx; u < y.nb_main; u += y.pers) {
+        if (u != idx) __syncthreads();   // the previous unit's combine has been read by every wave before the LDS regions are reused
+        ca_ys_mfma_body<DEPTH>(u, y.Ys, y.io, N, y.Gp, y.RS, smem);
+      }
+    } else {
+      ca_ys_mfma_body<DEPTH>(idx, y.Ys, y.io, N, y.Gp, y.RS, smem);
+    }
     return;
   }
   ca_f32x4* comb = reinterpret_cast<ca_f32x4*>(smem);

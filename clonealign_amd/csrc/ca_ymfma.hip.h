@@ -346,15 +346,27 @@ __device__ __forceinline__ uint4 ca_and4(uint4 a, unsigned m) { return (uint4){a
 #ifndef CA_YS_WAVES
 #define CA_YS_WAVES 3   // waves per SIMD the register budget is set for
 #endif
+// What the stream needs besides the matrix: the parameter images, their per-step digit sums (the bias of the stored bytes), the two
+// fixed-point exponents the quantiser used, and the float partial slabs it leaves for the finisher -- the SAME slabs, with the same
+// meaning, as the vector stream's (k_ypass): YWpart [nseg][N] = the segment's share of (Y.W)_n, YTpart [nrg][Gp] = the row group's
+// share of (Y^T psi)_g, so one finisher (k_yfinish) serves both.  Digits are combined in fp64 from exact integer sums.
+struct ca_ys_io {
+  const uint4* Wr; const uint4* Pr; const int* Wsum; const int* Psum; const int* exps;   // exps[0] for W, exps[1] for psi
+  float* YWpart; float* YTpart;
+};
 template <int DEPTH = CA_YS_DEPTH>
-__device__ __forceinline__ void ca_ys_mfma_body(int blk, const uint8_t* __restrict__ Ys, const uint4* __restrict__ Wr,
-                                                const uint4* __restrict__ Pr, int64_t N, int Gp,
-                                                int RS /* cells per strip, multiple of 64 */, int* __restrict__ YWi,
-                                                int* __restrict__ YTi,
+__device__ __forceinline__ void ca_ys_mfma_body(int blk, const uint8_t* __restrict__ Ys, const ca_ys_io& io, int64_t N, int Gp,
+                                                int RS /* cells per strip, multiple of 64 */,
                                                 unsigned char* ca_ys_lds /* 16-byte aligned, CA_YS_LDS_BYTES: [4 waves][64][CA_YS_PITCH], reused for the combine */) {
+  const uint4* __restrict__ Wr = io.Wr;
+  const uint4* __restrict__ Pr = io.Pr;
   constexpr int NP = CA_YS_GW / 64;
   static_assert(NP % DEPTH == 0, "pieces per cell step must be a multiple of the pipeline depth");
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, q = lane >> 4;
+  const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+  // the wave index as a SCALAR: strip bounds, piece addresses and the piece loop are then wave-uniform (scalar registers, scalar
+  // branches, loads of the form global_load v, v_off, s[base]) instead of 64-bit vector arithmetic per lane -- the kernel that rides
+  // on the forward sweep has 128 vector registers for everything
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int nseg = Gp / CA_YS_GW;
   const int rg = blk / nseg, seg = blk - rg * nseg;
   unsigned char* my = ca_ys_lds + (size_t)wv * 64 * CA_YS_PITCH;
@@ -373,25 +385,37 @@ __device__ __forceinline__ void ca_ys_mfma_body(int blk, const uint8_t* __restri
   unsigned char* wr_dst = my + lrow * CA_YS_PITCH + 16 * lch;
   const unsigned char* rd_row = my + j * CA_YS_PITCH + 16 * q;
   const unsigned rd_tr = (unsigned)(size_t)my + (unsigned)((16 * q + (j >> 1)) * CA_YS_PITCH + 8 * (j & 1));
-  const uint8_t* src = Ys + ((c0 >> 6) * (int64_t)(Gp / 64) + (g0 >> 6)) * 4096 + 16 * lane;   // piece (cell step, gene block), 1 KiB per load
-  const uint4* wsrc = Wr + (int64_t)(g0 >> 6) * 64 + lane;
+  const uint8_t* src = Ys + ((c0 >> 6) * (int64_t)(Gp / 64) + (g0 >> 6)) * 4096;   // (scalar) piece (cell step, gene block), 1 KiB per load
+  const uint4* wsrc = Wr + (int64_t)(g0 >> 6) * 64;                                 // (scalar)
+  const unsigned voff = 16u * (unsigned)lane;                                       // the lane's 16 bytes of a 1-KiB load
   uint4 R[DEPTH][4], W[DEPTH];
   // piece number k of the strip: cell step k / NP, gene block k % NP
-  const int64_t npieces = c0 < c1 ? ((c1 - c0 + 63) / 64) * NP : 0;
-  auto issue = [&](int slot, int64_t k) {
-    const uint8_t* p = src + ((k / NP) * (int64_t)(Gp / 64) + (k % NP)) * 4096;
+  const int npieces = c0 < c1 ? (int)((c1 - c0 + 63) / 64) * NP : 0;
+  auto issue = [&](int slot, int k) {
+    const uint8_t* p = src + ((int64_t)(k / NP) * (int64_t)(Gp / 64) + (k % NP)) * 4096;   // (scalar)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) R[slot][i] = ca_ld_stream(reinterpret_cast<const uint4*>(p + 1024 * i));
-    W[slot] = wsrc[(k % NP) * 64];
+    for (int i = 0; i < 4; ++i) R[slot][i] = ca_ld_stream(reinterpret_cast<const uint4*>(p + 1024 * i + voff));
+    W[slot] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(wsrc + (k % NP) * 64) + voff);
   };
 #pragma unroll
   for (int d_ = 0; d_ < DEPTH; ++d_)
     if (d_ < npieces) issue(d_, d_);
   ca_i32x4 acc_yw = {0, 0, 0, 0};
   uint4 pr = {0u, 0u, 0u, 0u};
-  for (int64_t k0 = 0; k0 < npieces; k0 += DEPTH) {
-    const int gb0 = (int)(k0 % NP);
-    const int64_t cs = c0 + (k0 / NP) * 64;
+  // bias of the row products: 128 x (digit sums of the segment's W image) per digit -- wave-uniform addresses, so the sums live
+  // in scalar registers for the whole strip and cost the piece loop no vector register; a lane picks digit p = j & 3 at the flush
+  int wtot[4] = {0, 0, 0, 0};
+  {
+    const int* ws = io.Wsum + (g0 >> 6) * 4;
+#pragma unroll
+    for (int a = 0; a < NP; ++a)
+#pragma unroll
+      for (int p_ = 0; p_ < 4; ++p_) wtot[p_] += ws[a * 4 + p_];
+  }
+  const int e_w = io.exps[0];
+  for (int k0 = 0; k0 < npieces; k0 += DEPTH) {
+    const int gb0 = k0 % NP;
+    const int64_t cs = c0 + (int64_t)(k0 / NP) * 64;
     if (gb0 == 0) {   // (wave-uniform) a new cell step
       acc_yw = (ca_i32x4){0, 0, 0, 0};
       pr = Pr[(cs >> 6) * 64 + lane];
@@ -440,7 +464,11 @@ __device__ __forceinline__ void ca_ys_mfma_body(int blk, const uint8_t* __restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int64_t n = cs + 16 * t + 4 * q + r;
-        if (n < N) YWi[((int64_t)seg * N + n) * 4 + p] = acc_yw[r];
+        const int wb = p == 0 ? wtot[0] : p == 1 ? wtot[1] : p == 2 ? wtot[2] : wtot[3];
+        long long v = ((long long)acc_yw[r] + 128ll * (long long)wb) << (8 * p);   // digit p of the quad's four (lanes j & 3): exact in 64 bits
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        if (p == 0 && n < N) io.YWpart[(int64_t)seg * N + n] = (float)ldexp((double)v, -e_w);
       }
     }
   }
@@ -453,18 +481,33 @@ __device__ __forceinline__ void ca_ys_mfma_body(int blk, const uint8_t* __restri
 #pragma unroll
     for (int r = 0; r < 4; ++r) comb[((wv * NP + a) * 64 + lane) * 4 + r] = acc_yt[a][r];
   __syncthreads();
-  for (int i = threadIdx.x; i < NP * 64 * 4; i += CA_YM_TB) {
-    const int r = i & 3, l = (i >> 2) & 63, a = i >> 8;
-    const int v = (comb[i] + comb[i + NP * 256]) + (comb[i + 2 * NP * 256] + comb[i + 3 * NP * 256]);
+  // bias of the column products: 128 x (digit sums of psi's image over the block's cell steps); scale 2^-e_psi
+  long long pb[4] = {0, 0, 0, 0};
+  {
+    const int64_t s0_ = ((int64_t)rg * 4 * RS) >> 6;
+    const int64_t s1_ = (((int64_t)rg * 4 + 4) * RS < ((N + 63) / 64) * 64 ? ((int64_t)rg * 4 + 4) * RS : ((N + 63) / 64) * 64) >> 6;
+    for (int64_t st = s0_; st < s1_; ++st) {
+      const int4 d4 = *reinterpret_cast<const int4*>(io.Psum + st * 4);
+      pb[0] += d4.x; pb[1] += d4.y; pb[2] += d4.z; pb[3] += d4.w;
+    }
+  }
+  const double inv_p = ldexp(1.0, -io.exps[1]);
+  for (int i = threadIdx.x; i < NP * 64; i += CA_YM_TB) {
+    const int l = i & 63, a = i >> 6;
+    double v = 0.0;
+#pragma unroll
+    for (int r = 3; r >= 0; --r) {
+      const int o = i * 4 + r;
+      const int sr = (comb[o] + comb[o + NP * 256]) + (comb[o + 2 * NP * 256] + comb[o + 3 * NP * 256]);
+      v = v * 256.0 + (double)((long long)sr + 128 * pb[r]);
+    }
     const int gene = g0 + 16 * (4 * a + (l >> 4)) + (l & 15);
-    YTi[((int64_t)rg * Gp + gene) * 4 + r] = v;
+    io.YTpart[(int64_t)rg * Gp + gene] = (float)(v * inv_p);
   }
 }
-__global__ void __launch_bounds__(CA_YM_TB, CA_YS_WAVES) k_ys_mfma(const uint8_t* __restrict__ Ys, const uint4* __restrict__ Wr,
-                                                                   const uint4* __restrict__ Pr, int64_t N, int Gp, int RS,
-                                                                   int* __restrict__ YWi, int* __restrict__ YTi) {
+__global__ void __launch_bounds__(CA_YM_TB, CA_YS_WAVES) k_ys_mfma(const uint8_t* __restrict__ Ys, ca_ys_io io, int64_t N, int Gp, int RS) {
   extern __shared__ __attribute__((aligned(16))) unsigned char ca_ys_dyn[];
-  ca_ys_mfma_body<CA_YS_DEPTH>((int)blockIdx.x, Ys, Wr, Pr, N, Gp, RS, YWi, YTi, ca_ys_dyn);
+  ca_ys_mfma_body<CA_YS_DEPTH>((int)blockIdx.x, Ys, io, N, Gp, RS, ca_ys_dyn);
 }
 constexpr int CA_YS_LDS_BYTES = 4 * (CA_YS_GW / 64) * 64 * 4 * 4;   // the combine buffer (32 KB) >= 4 x 64 x CA_YS_PITCH
 
@@ -488,147 +531,72 @@ __global__ void __launch_bounds__(CA_YM_TB) k_ym_digit_sums(const uint4* __restr
   if (st < steps && l < 4) sums[st * 4 + l] = s;
 }
 
-// Parameter images of the one-copy stream, one launch per parameter state.  lag = 0: the fixed-point exponents come from the
-// exact maxima in amax_in (k_ym_absmax ran before).  lag = 1: amax_in holds the exact maxima of the PREVIOUS state and
-// `slack` bounds what one Adam step can add to any magnitude (TF1 Adam: |step| <= lr_t (1 - b1) / sqrt((1 - b2)(1 - b1^2 / b2)),
-// Cauchy-Schwarz on the two moving averages), so 2^e (max + slack) < 2^30 holds without a second pass.  Either way the
-// kernel leaves the exact maxima of THIS state in amax_out (atomicMax of float bit patterns: order-independent), clears
-// amax_clear for the state after, and writes the exponents it used to exps[2] for the finisher.  Digit sums per 64-step go
-// to Wsum / Psum (the bias of the stored bytes).  K = 1.
-__global__ void __launch_bounds__(CA_YM_TB) k_ys_quant(const float* __restrict__ V, int Dv, int64_t G, int GS, const float* __restrict__ F,
-                                                       int Df, int64_t N, int64_t NS, const unsigned* __restrict__ amax_in, float slack_w,
-                                                       float slack_p, unsigned* __restrict__ amax_out, unsigned* __restrict__ amax_clear,
-                                                       int* __restrict__ exps, uint4* __restrict__ Wr, uint4* __restrict__ Pr,
-                                                       int* __restrict__ Wsum, int* __restrict__ Psum) {
-  const int64_t i = (int64_t)blockIdx.x * CA_YM_TB + threadIdx.x;
-  const int l = (int)(i & 63);
-  const int64_t st = i >> 6;
-  const int ew = ca_fix_exp(__uint_as_float(amax_in[0]) + slack_w), ep = ca_fix_exp(__uint_as_float(amax_in[1]) + slack_p);
-  if (i == 0) { exps[0] = ew; exps[1] = ep; amax_clear[0] = 0u; amax_clear[1] = 0u; }
-  if (st >= GS + NS) return;   // (whole waves: 64 lanes per step)
-  const bool isw = st < GS;
-  const float* src = isw ? V : F;
-  const int ld = isw ? Dv : Df;
-  const int64_t rows = isw ? G : N, step = isw ? st : st - GS;
-  const float sc = ldexpf(1.f, isw ? ew : ep);
-  const uint4 v = ca_quant16(src, ld, rows, 1, step, l, sc, 1);
-  (isw ? Wr : Pr)[step * 64 + l] = v;
-  // digit sums of the step (lanes with column p = l & 3 < 4 in the first group hold digit p for the 16 entries of group q)
-  int sd = 0;
-  {
-    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+// Parameter images of the one-copy stream for one parameter state.  The fixed-point exponents need the largest magnitudes of W
+// and psi: lag = 0 takes them from amax_in as exact maxima (k_ym_absmax ran before: ONE pair); in the loop amax_in holds the PREVIOUS
+// state's maxima as per-block pairs (what this body left last time) and `slack` bounds what the Adam steps since can add to any
+// magnitude (TF1 Adam: |step| <= lr_t (1 - b1) / sqrt((1 - b2)(1 - b1^2 / b2)), Cauchy-Schwarz on the two moving averages), so
+// 2^e (max + slack) < 2^30 holds without a second pass.  Every block reduces the n_in pairs itself (a few KB from L2) and leaves
+// its own pair in amax_out -- no atomics: the first form of this kernel raised one atomicMax per wave on two addresses and spent
+// 20 of its 25 us queueing there (rocprofv3, profiles/r03_ab_ystream.txt).  Block 0 writes the exponents used to exps[2] for
+// the stream.  Digit sums per 64-step go to Wsum / Psum (the bias of the stored bytes).  K = 1.
+// In the loop the body runs as EXTRA BLOCKS of the per-cell Adam kernel (k_adam_cell), which is where W and psi become final.
+struct ca_ysq_args {
+  int nblk;                       // blocks of the quantiser (0 = none riding)
+  const float* V; int Dv; int64_t G; int GS; const float* F; int Df; int64_t N; int64_t NS;
+  const float* amax_in; int n_in; float slack_w, slack_p;
+  float* amax_out;                // [nblk][2]
+  int* exps; uint4* Wr; uint4* Pr; int* Wsum; int* Psum;
+};
+__device__ __forceinline__ void ca_ys_quant_body(int blk, const ca_ysq_args& a, float* sm /* >= 2 * (CA_YM_TB / 64) floats */) {
+  const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
+  // largest magnitudes of the state amax_in describes
+  float mw = 0.f, mp = 0.f;
+  for (int i = tid; i < a.n_in; i += CA_YM_TB) { mw = fmaxf(mw, a.amax_in[2 * i]); mp = fmaxf(mp, a.amax_in[2 * i + 1]); }
 #pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) sd += (int)(signed char)((w[d] >> (8 * b)) & 0xFFu);
-  }
-  sd += __shfl_xor(sd, 16, 64);
-  sd += __shfl_xor(sd, 32, 64);
-  if (l < 4) (isw ? Wsum : Psum)[step * 4 + l] = sd;
-  // exact maxima of this state for the next one's bound: lane (0, q) covers the step's entries 16 q .. 16 q + 15
-  float m = 0.f;
-  if ((l & 15) == 0) {
-    const int64_t r0 = step * 64 + 16 * (l >> 4);
-    for (int b = 0; b < 16; ++b) if (r0 + b < rows) m = fmaxf(m, fabsf(src[(r0 + b) * ld]));
-  }
-  m = fmaxf(m, __shfl_xor(m, 16, 64));
-  m = fmaxf(m, __shfl_xor(m, 32, 64));
-  if (l == 0) atomicMax(amax_out + (isw ? 0 : 1), __float_as_uint(m));
-}
-
-// Finisher of the one-copy stream, one launch: blocks [0, nb_col) turn the row groups' digit sums into Y^T psi (red_y), the
-// blocks after turn the gene segments' digit sums into YW (float) and the block's share of sum_n psi_n . (YW)_n.  Integer sums
-// over slices (exact, any order), the bias 128 x (digit sums of the parameter image) added, digits combined in fp64, the
-// fixed-point scale taken out, the overflow list's entries (counts above 255) added in fp64.
-__global__ void __launch_bounds__(CA_YM_TB) k_ys_finish(const int* __restrict__ YTi, int nrg, int Gp, int G, const int* __restrict__ Psum,
-                                                        int64_t NS, const int* __restrict__ exps, const int* __restrict__ col_chunk_ptr,
-                                                        const float* __restrict__ csum, double* __restrict__ red_y, int nb_col,
-                                                        const int* __restrict__ YWi, int nseg, int64_t N, const int* __restrict__ Wsum, int GS,
-                                                        const float* __restrict__ F, int Df, const float* __restrict__ V, int Dv,
-                                                        const int64_t* __restrict__ ovf_rowptr, const int* __restrict__ ovf_col,
-                                                        const float* __restrict__ ovf_val, float* __restrict__ YW, double* __restrict__ yw_part) {
-  __shared__ long long tot[4];
-  __shared__ double smr[CA_YM_TB / 64];
-  const bool colside = (int)blockIdx.x < nb_col;
-  {   // digit totals of the OTHER operand's image: every block needs them (a few thousand ints, L2-resident)
-    const int* sums = colside ? Psum : Wsum;
-    const int64_t steps = colside ? NS : (int64_t)GS;
-    const int p = threadIdx.x & 3;
-    long long a = 0;
-    for (int64_t st = threadIdx.x >> 2; st < steps; st += CA_YM_TB / 4) a += sums[st * 4 + p];
-#pragma unroll
-    for (int o = 4; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
-    __shared__ long long part[CA_YM_TB / 64][4];
-    if ((threadIdx.x & 63) < 4) part[threadIdx.x >> 6][p] = a;
-    __syncthreads();
-    if (threadIdx.x < 4) tot[threadIdx.x] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
-    __syncthreads();
-  }
-  if (colside) {   // block = 16 genes x 16 row lanes: the nrg slices of a gene are read by 16 lanes, four loads in flight each
-    __shared__ long long cs_[16][16][4];
-    const int gx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int g = blockIdx.x * 16 + gx;
-    long long s[4] = {0, 0, 0, 0};
-    if (g < G) {
-      int r = ty;
-      for (; r + 48 < nrg; r += 64) {
-        int4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const int4*>(YTi + ((int64_t)(r + 16 * u) * Gp + g) * 4);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w; }
-      }
-      for (; r < nrg; r += 16) {
-        const int4 v = *reinterpret_cast<const int4*>(YTi + ((int64_t)r * Gp + g) * 4);
-        s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-      }
-    }
-#pragma unroll
-    for (int p = 0; p < 4; ++p) cs_[ty][gx][p] = s[p];
-    __syncthreads();
-    if (ty != 0 || g >= G) return;
-    for (int t = 1; t < 16; ++t)
-#pragma unroll
-      for (int p = 0; p < 4; ++p) s[p] += cs_[t][gx][p];
-    double v = 0.0;
-#pragma unroll
-    for (int p = 3; p >= 0; --p) v = v * 256.0 + (double)(s[p] + 128 * tot[p]);
-    v *= ldexp(1.0, -exps[1]);
-    if (csum)
-      for (int ch = col_chunk_ptr[g]; ch < col_chunk_ptr[g + 1]; ++ch) v += (double)csum[ch];
-    red_y[g] = v;
-    return;
-  }
-  const int blk = (int)blockIdx.x - nb_col;
-  const int64_t n = (int64_t)blk * CA_YM_TB + threadIdx.x;
-  double a = 0.0;
-  if (n < N) {
-    long long s[4] = {0, 0, 0, 0};
-    int sg = 0;
-    for (; sg + 3 < nseg; sg += 4) {   // four loads in flight
-      int4 v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const int4*>(YWi + ((int64_t)(sg + u) * N + n) * 4);
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { s[0] += v[u].x; s[1] += v[u].y; s[2] += v[u].z; s[3] += v[u].w; }
-    }
-    for (; sg < nseg; ++sg) {
-      const int4 v = *reinterpret_cast<const int4*>(YWi + ((int64_t)sg * N + n) * 4);
-      s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w;
-    }
-    double v = 0.0;
-#pragma unroll
-    for (int p = 3; p >= 0; --p) v = v * 256.0 + (double)(s[p] + 128 * tot[p]);
-    v *= ldexp(1.0, -exps[0]);
-    if (ovf_rowptr)
-      for (int64_t e = ovf_rowptr[n]; e < ovf_rowptr[n + 1]; ++e) v += (double)ovf_val[e] * (double)V[(int64_t)ovf_col[e] * Dv];
-    const float vf = (float)v;
-    YW[n] = vf;
-    a = (double)F[n * Df] * (double)vf;
-  }
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) a += __shfl_xor(a, o, 64);
-  if ((threadIdx.x & 63) == 0) smr[threadIdx.x >> 6] = a;
+  for (int o = 32; o > 0; o >>= 1) { mw = fmaxf(mw, __shfl_xor(mw, o, 64)); mp = fmaxf(mp, __shfl_xor(mp, o, 64)); }
+  if (l == 0) { sm[2 * wv] = mw; sm[2 * wv + 1] = mp; }
   __syncthreads();
-  if (threadIdx.x == 0) yw_part[blk] = (smr[0] + smr[1]) + (smr[2] + smr[3]);
+  mw = fmaxf(fmaxf(sm[0], sm[2]), fmaxf(sm[4], sm[6]));
+  mp = fmaxf(fmaxf(sm[1], sm[3]), fmaxf(sm[5], sm[7]));
+  __syncthreads();
+  const int ew = ca_fix_exp(mw + a.slack_w), ep = ca_fix_exp(mp + a.slack_p);
+  if (blk == 0 && tid == 0) { a.exps[0] = ew; a.exps[1] = ep; }
+  const int64_t st = (int64_t)blk * (CA_YM_TB / 64) + wv;      // one wave per 64-step of an image
+  float m = 0.f;
+  bool isw = true;
+  if (st < a.GS + a.NS) {
+    isw = st < a.GS;
+    const float* src = isw ? a.V : a.F;
+    const int ld = isw ? a.Dv : a.Df;
+    const int64_t rows = isw ? a.G : a.N, step = isw ? st : st - a.GS;
+    const float sc = ldexpf(1.f, isw ? ew : ep);
+    const uint4 v = ca_quant16(src, ld, rows, 1, step, l, sc, 1);
+    (isw ? a.Wr : a.Pr)[step * 64 + l] = v;
+    int sd = 0;   // digit sums of the step (lanes with column p = l & 3 in the first group hold digit p for the 16 entries of group q)
+    {
+      const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) sd += (int)(signed char)((w[d] >> (8 * b)) & 0xFFu);
+    }
+    sd += __shfl_xor(sd, 16, 64);
+    sd += __shfl_xor(sd, 32, 64);
+    if (l < 4) (isw ? a.Wsum : a.Psum)[step * 4 + l] = sd;
+    // exact maximum of this step's 64 entries, one per lane
+    const int64_t r = step * 64 + l;
+    if (r < rows) m = fabsf(src[r * ld]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  }
+  if (l == 0) { sm[2 * wv] = isw ? m : 0.f; sm[2 * wv + 1] = isw ? 0.f : m; }
+  __syncthreads();
+  if (tid == 0) {
+    a.amax_out[2 * blk] = fmaxf(fmaxf(sm[0], sm[2]), fmaxf(sm[4], sm[6]));
+    a.amax_out[2 * blk + 1] = fmaxf(fmaxf(sm[1], sm[3]), fmaxf(sm[5], sm[7]));
+  }
+}
+__global__ void __launch_bounds__(CA_YM_TB) k_ys_quant(ca_ysq_args a) {
+  __shared__ float sm[2 * (CA_YM_TB / 64)];
+  ca_ys_quant_body((int)blockIdx.x, a, sm);
 }

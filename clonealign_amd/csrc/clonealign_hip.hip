@@ -168,8 +168,11 @@ struct ca_engine {
   uint4 *Yf = nullptr, *Yb = nullptr, *Wq = nullptr, *Pq = nullptr; unsigned* ym_amax = nullptr; int* ym_out = nullptr;
   hipEvent_t ev_ywdone = nullptr; bool yw_pending = false, on_side = false;
   // ... and from ONE tiled copy through the transposing LDS read (k_ys_mfma; K = 1)
-  bool y_ys = false; uint8_t* Ys = nullptr; uint4 *Wr = nullptr, *Pr = nullptr; int *Wsum = nullptr, *Psum = nullptr, *YWi = nullptr, *YTi = nullptr;
-  int* ys_exps = nullptr; unsigned* ys_amax = nullptr;   // [3][2] each: rotating slots, see k_ys_quant
+  bool y_ys = false; uint8_t* Ys = nullptr; uint4 *Wr = nullptr, *Pr = nullptr; int *Wsum = nullptr, *Psum = nullptr;
+  int* ys_exps = nullptr;        // [3][2]: rotating slots, see ca_ys_quant_body
+  unsigned* ys_amax = nullptr;   // [2]: exact maxima of a fresh state (k_ym_absmax), float bit patterns
+  float* ys_amaxp = nullptr; int ys_nq = 0;   // [3][ys_nq][2]: per-block maxima each quantiser run leaves for the next one
+  bool ys_quant_ready = false;   // the images of the CURRENT parameter state were made by the quantiser riding on k_adam_cell
   int ys_slot = 0, ys_steps = -1, ys_RS = 256, ys_nrg = 0, ys_nseg = 0; int64_t ys_N64 = 0; float ys_step_bound = -1.f;
   // one-shot peer-to-peer all-reduce (ca_p2p_export / ca_p2p_connect)
   ca_p2p* p2p = nullptr;
@@ -471,6 +474,7 @@ int refresh_derived(ca_engine* h) {
   h->y_defer = false;   // a deferred side-stream Y pass would not be ordered after this parameter change: redo it in line
   h->pre_valid = false;
   h->ys_steps = -1;     // arbitrary parameter change: the fixed-point exponents are taken from exact maxima again
+  h->ys_quant_ready = false;
   if (h->D > 0) {
     LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_vprep, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->V, h->Vs, h->vmm_part, h->G, h->D));
     LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_vmm_final, dim3(1), dim3(64), 0, h->stream, h->vmm_part, h->vmm, h->ngblk, h->D));
@@ -523,37 +527,66 @@ int ycache_mfma(ca_engine* h) {
 // Both products from ONE tiled copy through the transposing LDS read (k_ys_mfma): a quantiser launch (fixed-point images of W and
 // psi; exact maxima by a separate pass only for the first state after a reset, afterwards bounded from the previous state's),
 // the stream, the finisher.  Three launches, like the VALU stream's.
-// quantiser of the one-copy stream: fixed-point images of W and psi for the current parameters (slot ys_slot)
-int ys_quant(ca_engine* h) {
-  const int GS = h->Gp / 64;
-  const int64_t NS = h->ys_N64 / 64;
-  const int s0 = h->ys_slot, s1 = (s0 + 1) % 3, s2 = (s0 + 2) % 3;
-  float slack = 0.f;
-  if (h->ys_steps < 0 || h->ys_steps > 4 || h->ys_step_bound <= 0.f) {
-    HIPCK(h, hipMemsetAsync(h->ys_amax, 0, 6 * sizeof(unsigned), h->stream));
-    LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_ym_absmax, dim3(cdiv(std::max<int64_t>(h->N, h->G), CA_YM_TB)), dim3(CA_YM_TB), 0, h->stream,
-                                                  h->V, h->D, (int64_t)h->G, h->F, h->D, h->N, 1, h->ys_amax + 2 * s0));
+// Arguments of the quantiser for the current parameters (slot ys_slot).  lagged = true: the exponents are bounded from the previous
+// state's maxima (`steps` Adam steps ago) -- possible up to 4 steps back; else the caller runs k_ym_absmax first (exact maxima).
+ca_ysq_args ys_quant_args(ca_engine* h, int steps, bool* lagged) {
+  ca_ysq_args a;
+  memset(&a, 0, sizeof(a));
+  const int s0 = h->ys_slot, s1 = (s0 + 1) % 3;
+  a.nblk = h->ys_nq;
+  a.V = h->V; a.Dv = h->D; a.G = h->G; a.GS = h->Gp / 64; a.F = h->F; a.Df = h->D; a.N = h->N; a.NS = h->ys_N64 / 64;
+  *lagged = steps >= 0 && steps <= 4 && h->ys_step_bound > 0.f;
+  if (*lagged) {
+    a.amax_in = h->ys_amaxp + (int64_t)s0 * h->ys_nq * 2; a.n_in = h->ys_nq;
+    a.slack_w = a.slack_p = (float)steps * h->ys_step_bound;
   } else {
-    slack = (float)h->ys_steps * h->ys_step_bound;
+    a.amax_in = reinterpret_cast<const float*>(h->ys_amax); a.n_in = 1;
   }
-  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_ys_quant, dim3(cdiv((GS + NS) * 64, CA_YM_TB)), dim3(CA_YM_TB), 0, h->stream, h->V, h->D,
-                                                (int64_t)h->G, GS, h->F, h->D, h->N, NS, h->ys_amax + 2 * s0, slack, slack, h->ys_amax + 2 * s1,
-                                                h->ys_amax + 2 * s2, h->ys_exps + 2 * s0, h->Wr, h->Pr, h->Wsum, h->Psum));
+  a.amax_out = h->ys_amaxp + (int64_t)s1 * h->ys_nq * 2;
+  a.exps = h->ys_exps + 2 * s0; a.Wr = h->Wr; a.Pr = h->Pr; a.Wsum = h->Wsum; a.Psum = h->Psum;
+  return a;
+}
+// quantiser of the one-copy stream as launches of its own (first pass after a reset, call-by-call API); inside the loop it rides
+// on k_adam_cell (train_update) and this is a no-op
+int ys_quant(ca_engine* h) {
+  if (h->ys_quant_ready) return CA_OK;
+  bool lagged = false;
+  ca_ysq_args a = ys_quant_args(h, h->ys_steps, &lagged);
+  if (!lagged) {
+    HIPCK(h, hipMemsetAsync(h->ys_amax, 0, 2 * sizeof(unsigned), h->stream));
+    LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_ym_absmax, dim3(cdiv(std::max<int64_t>(h->N, h->G), CA_YM_TB)), dim3(CA_YM_TB), 0, h->stream,
+                                                  h->V, h->D, (int64_t)h->G, h->F, h->D, h->N, 1, h->ys_amax));
+  }
+  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_ys_quant, dim3(a.nblk), dim3(CA_YM_TB), 0, h->stream, a));
   return CA_OK;
 }
-// finisher of the one-copy stream (digit sums -> Y^T psi in red_y, YW, psi.(YW) partials); advances the quantiser's slot ring
+ca_ys_io ys_io(ca_engine* h) {
+  ca_ys_io io;
+  io.Wr = h->Wr; io.Pr = h->Pr; io.Wsum = h->Wsum; io.Psum = h->Psum; io.exps = h->ys_exps + 2 * h->ys_slot;
+  io.YWpart = h->YWpart; io.YTpart = h->YTpart;
+  return io;
+}
+ca_ovf_args ys_ovf(ca_engine* h) {
+  ca_ovf_args ovf;
+  memset(&ovf, 0, sizeof(ovf));
+  if (h->n_ovf > 0) {
+    ovf.nb_rows = cdiv(h->N, CA_TB); ovf.nb_chunks = cdiv(h->n_ovf_chunk, CA_TB / 64);
+    ovf.rowptr = h->ovf_rowptr; ovf.col = h->ovf_col; ovf.val = h->ovf_val; ovf.YWextra = h->YWpart + (int64_t)h->ys_nseg * h->N;
+    ovf.chunk_start = h->ovf_chunk_start; ovf.row2 = h->ovf_row2; ovf.val2 = h->ovf_val2; ovf.csum = h->ovf_csum; ovf.nchunk = h->n_ovf_chunk;
+  }
+  return ovf;
+}
+// finisher of the one-copy stream: the vector stream's own (k_yfinish) over the float partial slabs the stream left; advances
+// the quantiser's slot ring
 int ys_finish(ca_engine* h) {
-  const int GS = h->Gp / 64;
-  const int64_t NS = h->ys_N64 / 64;
-  const int s0 = h->ys_slot, s1 = (s0 + 1) % 3;
-  const int nb_col = cdiv(h->G, 16);
-  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_ys_finish, dim3(nb_col + h->n_yw), dim3(CA_YM_TB), 0, h->stream, h->YTi, h->ys_nrg, h->Gp, h->G,
-                                                h->Psum, NS, h->ys_exps + 2 * s0, h->n_ovf > 0 ? h->ovf_col_chunk_ptr : nullptr,
-                                                h->n_ovf > 0 ? h->ovf_csum : nullptr, h->red + h->off_y, nb_col, h->YWi, h->ys_nseg, h->N, h->Wsum, GS,
-                                                h->F, h->D, h->V, h->D, h->n_ovf > 0 ? h->ovf_rowptr : nullptr, h->ovf_col, h->ovf_val, h->YW,
-                                                h->yw_part));
-  h->ys_slot = s1;
+  const int nb_col = cdiv((int64_t)h->Gp, 64);
+  LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_yfinish, dim3(nb_col + h->n_yw), dim3(1024), 0, h->stream, h->YTpart, h->red + h->off_y, h->ys_nrg,
+                                                (int64_t)h->Gp, h->Gp, h->n_ovf > 0 ? h->ovf_col_chunk_ptr : nullptr,
+                                                h->n_ovf > 0 ? h->ovf_csum : nullptr, 1, h->G, nb_col, h->YWpart,
+                                                h->ys_nseg + (h->n_ovf > 0 ? 1 : 0), h->F, h->D, h->N, h->YW, h->yw_part));
+  h->ys_slot = (h->ys_slot + 1) % 3;
   h->ys_steps = 0;
+  h->ys_quant_ready = false;
   h->ycache_valid = true;
   return CA_OK;
 }
@@ -561,14 +594,12 @@ int ycache_ys(ca_engine* h) {
   CACK(ys_quant(h));
   const int nb_main = h->ys_nrg * h->ys_nseg;
   if (h->n_ovf > 0) {
-    ca_ovf_args ovf;
-    memset(&ovf, 0, sizeof(ovf));
-    ovf.chunk_start = h->ovf_chunk_start; ovf.row2 = h->ovf_row2; ovf.val2 = h->ovf_val2; ovf.csum = h->ovf_csum; ovf.nchunk = h->n_ovf_chunk;
-    LAUNCH(h, CA_KERNEL_YPASS, hipLaunchKernelGGL(k_ys_mfma_ovf, dim3(nb_main + cdiv(h->n_ovf_chunk, CA_TB / 64)), dim3(CA_YM_TB), CA_YS_LDS_BYTES,
-                                                  h->stream, h->Ys, h->Wr, h->Pr, h->N, h->Gp, h->ys_RS, h->YWi, h->YTi, nb_main, ovf, h->F, h->D));
+    const ca_ovf_args ovf = ys_ovf(h);
+    LAUNCH(h, CA_KERNEL_YPASS, hipLaunchKernelGGL(k_ys_mfma_ovf, dim3(nb_main + ovf.nb_rows + ovf.nb_chunks), dim3(CA_YM_TB), CA_YS_LDS_BYTES,
+                                                  h->stream, h->Ys, ys_io(h), h->N, h->Gp, h->ys_RS, nb_main, ovf, h->F, h->V, h->D));
   } else {
-    LAUNCH(h, CA_KERNEL_YPASS, hipLaunchKernelGGL(k_ys_mfma, dim3(nb_main), dim3(CA_YM_TB), CA_YS_LDS_BYTES, h->stream, h->Ys, h->Wr, h->Pr, h->N,
-                                                  h->Gp, h->ys_RS, h->YWi, h->YTi));
+    LAUNCH(h, CA_KERNEL_YPASS, hipLaunchKernelGGL(k_ys_mfma, dim3(nb_main), dim3(CA_YM_TB), CA_YS_LDS_BYTES, h->stream, h->Ys, ys_io(h), h->N,
+                                                  h->Gp, h->ys_RS));
   }
   return ys_finish(h);
 }
@@ -957,11 +988,20 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
     pre.gene_partA = h->gene_part_alt; pre.gene_partB = h->gene_partB_alt; pre.Mq = h->fwd_mfma ? h->Mq : nullptr;
     pre.G = h->G; pre.D = h->D; pre.K = h->K; pre.mrow = h->frow; pre.C = h->C;
   }
+  // the int8 count-matrix stream's quantiser for the state this step produces: extra blocks of the same launch (W and psi are
+  // final since k_final_gene), exponents bounded from the maxima of the state before (`ys_steps` steps ago, + this one)
+  ca_ysq_args ysq;
+  memset(&ysq, 0, sizeof(ysq));
+  if (apply && h->y_ys && h->K > 0 && !h->ys_quant_ready) {
+    bool lagged = false;
+    const ca_ysq_args a = ys_quant_args(h, h->ys_steps >= 0 ? h->ys_steps + 1 : -1, &lagged);
+    if (lagged) { ysq = a; h->ys_quant_ready = true; }
+  }
   LAUNCH(h, CA_KERNEL_OTHER,
-         hipLaunchKernelGGL(k_adam_cell, dim3(N256 + 1 + pre.nblk), dim3(CA_TB), 0, h->stream, h->F, h->glogit, h->dgl, h->m_gl, h->v_gl,
+         hipLaunchKernelGGL(k_adam_cell, dim3(N256 + 1 + pre.nblk + ysq.nblk), dim3(CA_TB), 0, h->stream, h->F, h->glogit, h->dgl, h->m_gl, h->v_gl,
                             h->N, h->C, h->D, apply, lr_t, (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps,
                             h->vmm_part, h->ngblk, h->etamax2, small_args(h, h->gene_part, apply ? 1 : 0, lr_t, elbo_dst, false),
-                            N256, pre));
+                            N256, pre, ysq));
   if (pre.nblk) { h->pre_valid = true; h->pre_A = h->hint_A; h->pre_B = h->hint_B; }
   h->hint_A = h->hint_B = -1;
   if (apply) {
@@ -1071,17 +1111,17 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
     CACK(ys_quant(h));
     ca_ysride_args ya;
     memset(&ya, 0, sizeof(ya));
-    ya.Ys = h->Ys; ya.Wr = h->Wr; ya.Pr = h->Pr; ya.YWi = h->YWi; ya.YTi = h->YTi; ya.F = h->F; ya.Df = h->D;
+    ya.Ys = h->Ys; ya.io = ys_io(h); ya.F = h->F; ya.V = h->V; ya.Df = h->D;
     ya.Gp = h->Gp; ya.RS = h->ys_RS; ya.nb_main = h->ys_nrg * h->ys_nseg; ya.nb_y = ya.nb_main;
-    if (h->n_ovf > 0) {
-      ya.ovf.chunk_start = h->ovf_chunk_start; ya.ovf.row2 = h->ovf_row2; ya.ovf.val2 = h->ovf_val2; ya.ovf.csum = h->ovf_csum; ya.ovf.nchunk = h->n_ovf_chunk;
-      ya.nb_y += cdiv(h->n_ovf_chunk, CA_TB / 64);
-    }
+    ya.ovf = ys_ovf(h);
+    ya.nb_y += ya.ovf.nb_rows + ya.ovf.nb_chunks;
     ya.pat_a = 2; ya.pat_b = 1;
     if (h->opt.ride_pattern > 0 && (h->opt.ride_pattern >> 8) > 0 && (h->opt.ride_pattern & 255) > 0) {
       ya.pat_a = h->opt.ride_pattern >> 8; ya.pat_b = h->opt.ride_pattern & 255;
     }
-    const dim3 grid((unsigned)(h->ncblk_f + ya.nb_y));
+    if (h->opt.ride_pattern < 0) ya.pers = std::min(-h->opt.ride_pattern, ya.nb_main);
+    else if (h->opt.ride_pattern == 0 && ya.nb_main >= 2 * h->n_cu) ya.pers = h->n_cu;
+    const dim3 grid(ya.pers > 0 ? (unsigned)(ya.pers + h->ncblk_f + (ya.nb_y - ya.nb_main)) : (unsigned)(h->ncblk_f + ya.nb_y));
 #define CA_FCYS(DV, TLBV, DPV)                                                                                                        \
   LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell_mix_ys<DV, TLBV, 2, DPV>), grid, dim3(CA_TB), 0, h->stream, h->F, h->etamax2, h->Vs, \
                                               h->Mq, cp, h->alpha_u, h->cell_part, h->N, h->C, h->K, h->nk32, h->fc_nbig, h->ncblk_f, ya))
@@ -1852,7 +1892,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     h->y_dev_bytes += (h->ym_NT * h->ym_GS + (int64_t)h->ym_GT * h->ym_NS) * 1024;
   }
   // ---- both products from ONE tiled copy (k_ys_mfma): K = 1, 1-byte storage
-  if (h->ystore == CA_YSTORE_U8 && K == 1 && variantx_on(h, CA_VARX_Y_MFMA1, "CA_Y_MFMA1")) {
+  if (h->ystore == CA_YSTORE_U8 && K == 1 && !h->y_mfma && variant_on(h, CA_VAR_Y_MFMA1, "CA_Y_MFMA1")) {
     h->ys_N64 = (Nn + 63) / 64 * 64;
     h->ys_nseg = h->Gp / CA_YS_GW;                  // Gp is a multiple of 1024
     // strips of RS cells per wave: about one resident round of blocks (3 per CU), at least 64 cells
@@ -1866,10 +1906,12 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     h->Wr = (uint4*)wr; h->Pr = (uint4*)pr;
     CACK(dalloc(h, &h->Wsum, (int64_t)(h->Gp / 64) * 4));
     CACK(dalloc(h, &h->Psum, (h->ys_N64 / 64) * 4));
-    CACK(dalloc(h, &h->YWi, (int64_t)h->ys_nseg * Nn * 4));
-    CACK(dalloc(h, &h->YTi, (int64_t)h->ys_nrg * h->Gp * 4));
+    CACK(dalloc(h, &h->YWpart, (int64_t)(std::max(h->nseg, h->ys_nseg) + 1) * Nn));      // (replaces the vector stream's smaller slabs)
+    CACK(dalloc(h, &h->YTpart, (int64_t)(std::max(h->nrb, h->ys_nrg) + 1) * h->Gp));
     CACK(dalloc(h, &h->ys_exps, 6));
-    CACK(dalloc(h, &h->ys_amax, 6));
+    CACK(dalloc(h, &h->ys_amax, 2));
+    h->ys_nq = cdiv((int64_t)(h->Gp / 64) + h->ys_N64 / 64, CA_YM_TB / 64);
+    CACK(dalloc(h, &h->ys_amaxp, (int64_t)3 * h->ys_nq * 2));
     hipLaunchKernelGGL(k_bias_y, dim3(cdiv(h->ys_N64 * (h->Gp / 16), CA_YM_TB)), dim3(CA_YM_TB), 0, h->stream, (const uint8_t*)h->Y, (uint4*)h->Ys, Nn,
                        h->ys_N64, h->Gp);
     HIPCK(h, hipGetLastError());
@@ -2283,6 +2325,13 @@ int ca_p2p_connect(ca_handle h, const char* handles) {
       if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
     }
     if (w.pid == (int32_t)getpid()) {   // a handle of THIS process (one R session driving several devices): the slab's own address
+      // ... but not two ranks of one process on ONE device: the runtime's device-wide synchronising calls (hipFree, hipMalloc of
+      // a grown eps buffer, ...) made for one handle wait for every kernel on the device, also the other handle's all-reduce
+      // kernel -- which waits for this rank.  Measured: the second all-reduce of such a pair ran into the device-side time
+      // limit (tests/test_gpu_sharding.py).  Separate processes sharing a device are fine (their runtimes do not see each other).
+      if (w.device == h->device && !(h->opt.variant_on & CA_VARX_P2P_SAME_DEVICE))
+        return fail("peer-to-peer transport: ranks " + std::to_string(h->opt.rank) + " and " + std::to_string(r) + " are handles of one process on one "
+                    "device; use one rank per device (or one process per rank)");
       peers[r] = (double*)(uintptr_t)w.local_ptr;
       continue;
     }

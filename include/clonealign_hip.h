@@ -90,6 +90,10 @@ enum ca_variant {
   CA_VAR_P2P = 1 << 10,       /* one-shot peer-to-peer all-reduce (else ncclAllReduce) after ca_comm_init() */
   CA_VAR_FOLD_GSUM = 1 << 11, /* small problems: backward-sweep partials summed inside the per-gene kernel (else a k_colsum launch) */
   CA_VAR_Y_RIDE = 1 << 12,    /* the Y stream's blocks ride on the forward sweep's launch (else side stream / in line) */
+  CA_VAR_Y_MFMA1 = 1 << 14,   /* both count-matrix products on the int8 matrix cores from ONE tiled copy of the 1-byte matrix, the column products
+                                 through the transposing LDS read ds_read_b64_tr_b8 (ca_ymfma.hip.h; K = 1): the default since round 3, when its
+                                 blocks ride on the forward sweep as long-lived stream blocks and its quantiser on the per-cell Adam kernel.
+                                 Off: the vector stream (k_ypass / k_fwd_cell_mix_y) */
   CA_VAR_RIDE_SEQ = 1 << 13   /* off: the riding stream as blocks of its own interleaved in the sweep's grid (k_fwd_cell_mix_y), never fused in
                                  sequence into the sweep's blocks (k_fwd_cell_seq_y; see CA_VARX_RIDE_SEQ) */
 };
@@ -99,11 +103,12 @@ enum ca_variant_on {
   CA_VARX_Y_MFMA2 = 1 << 0,   /* count-matrix products on the int8 matrix cores from TWO tiled copies (cell-tiled for Y.W,
                                  gene-tiled for Y^T.psi; ca_ymfma.hip.h): 6.0 TB/s per stream against 4.7 for k_ypass, but twice
                                  the bytes per iteration */
-  CA_VARX_Y_MFMA1 = 1 << 2,   /* both count-matrix products on the int8 matrix cores from ONE tiled copy, the column products through
-                                 the transposing LDS read ds_read_b64_tr_b8 (k_ys_mfma; K = 1) */
+  CA_VARX_Y_MFMA1 = 1 << 2,   /* (round 2's opt-in for what is now the default, CA_VAR_Y_MFMA1; accepted and ignored) */
   CA_VARX_FOLD_ALWAYS = 1 << 3, /* backward-sweep partials summed inside the per-gene kernel at every size (default: up to 32k cells) */
   CA_VARX_RIDE_SEQ = 1 << 4,  /* riding Y stream fused in sequence: every forward-sweep block also streams one unit of the count matrix,
                                  before or after its sweep (k_fwd_cell_seq_y), instead of separate stream blocks in the same grid */
+  CA_VARX_P2P_SAME_DEVICE = 1 << 5, /* test rigs only: let ca_p2p_connect map a peer handle of the SAME process on the SAME device (refused
+                                 otherwise: device-wide synchronising runtime calls of one handle would wait on the other's all-reduce) */
   CA_VARX_ASYNC_SMALL = 1 << 1 /* side stream also below 4e7 counts (small shards run the Y stream in line: the two cross-stream
                                  events cost more than the overlap returns there) */
 };
@@ -126,8 +131,11 @@ typedef struct ca_options {
   uint32_t variant_off;             /* ca_variant bits to switch off (| CA_OPT_VERBOSE); 0 = defaults */
   int32_t tune[8];                  /* ca_tune_id overrides, 0 = heuristic */
   uint32_t variant_on;              /* ca_variant_on bits to switch on; 0 = defaults */
-  int32_t ride_pattern;             /* 0 = default; else (a << 8) | b: a forward-sweep blocks, then b Y-stream blocks, ... in the dispatch
-                                     * order of the merged launch (k_fwd_cell_mix_y); periods that divide 8 put the two kinds on disjoint XCDs */
+  int32_t ride_pattern;             /* dispatch order of the merged forward launch (sweep blocks + Y-stream blocks in one grid).  0 = default:
+                                     * one LONG-LIVED stream block per CU leads the grid, each walks through every n-th unit of the count matrix
+                                     * (from two units per CU up; below that the 2:1 interleave).  < 0: that many long-lived stream blocks.
+                                     * > 0: (a << 8) | b = a sweep blocks, then b single-unit stream blocks, ...; periods that divide 8 put the
+                                     * two kinds on disjoint XCDs.  Results do not depend on it (tests/test_gpu_parity.py) */
   int32_t comm_timeout_ms;          /* peer-to-peer all-reduce: how long a rank waits on the device for its peers' flags before the call
                                      * gives up and the engine reports CA_ERR_COMM (0 = 10 000 ms) */
   int32_t reserved[3];
@@ -199,8 +207,9 @@ int ca_comm_init(ca_handle h, const char id[128]);
  *   1. every rank: ca_p2p_export (allocates the slab in FINE-GRAINED device memory -- CA_ERR_COMM when that is unavailable, never
  *      a coarse-grained fallback -- and returns the handle); the caller all-gathers the handles out of band;
  *   2. every rank: ca_p2p_connect (maps the peers' slabs: IPC handles of other processes, the slab's own address for handles of
- *      the SAME process -- one host process may drive several devices, one handle per device on one host thread each; peer access
- *      is enabled between different devices).  Launches nothing and waits for nobody;
+ *      the SAME process -- one host process may drive several devices, one handle per DEVICE on one host thread each; peer access
+ *      is enabled between different devices; two handles of one process on one device are refused).  Launches nothing and waits
+ *      for nobody;
  *   3. the caller agrees over its control plane whether step 2 succeeded on EVERY rank, then every rank calls
  *      ca_p2p_commit(h, all_ok): 1 makes the transport the engine's all-reduce and reduces the setup sums (the first call that
  *      waits for peers); 0 drops the mappings (next: ca_comm_init, or a host callback).

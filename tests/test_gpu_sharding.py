@@ -180,14 +180,23 @@ class _ThreadExchange:
         return fn
 
 
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs: one process may hold ONE rank per device (two ranks of one process on one "
+                                           "device are refused, see test_two_ranks_of_one_process_on_one_device_are_refused)")
 @pytest.mark.parametrize("world", [2, 3])
 def test_handles_of_one_process_join_through_the_device_transport(world):
     """SURVEY section 8b "one process / 8 devices": the R session that calls clonealign() is ONE process.  W handles on W host
-    threads of this process (all on device 0 here) are joined by the one-shot peer-to-peer all-reduce itself -- the handles of
+    threads of this process, one per device, are joined by the one-shot peer-to-peer all-reduce itself -- the handles of
     the own process are mapped by address, not through IPC (which cannot open a handle in the process that made it) -- and
     the fit equals the single-handle fit; replicas bit-identical."""
     from clonealign_amd.engine import HipEngine
     from clonealign_amd.rng import EpsStream
+    if _n_gpus() < world:
+        pytest.skip(f"needs {world} GPUs")
     case = make_case(seed=21, N=1500, G=400, C=5, K=1)
     N, G = case["Y"].shape[0], case["Y"].shape[1]
     ref = HipEngine(**case)
@@ -203,7 +212,7 @@ def test_handles_of_one_process_join_through_the_device_transport(world):
             shard = dict(case)
             for k in ("Y", "psi0"):
                 shard[k] = shard[k][lo:hi]
-            eng = HipEngine(**shard, rank=rank, world=world, p2p_exchange=ex.make(rank), comm_timeout_ms=20000)
+            eng = HipEngine(**shard, rank=rank, world=world, device=rank, p2p_exchange=ex.make(rank), comm_timeout_ms=20000)
             assert eng.info()["transport_name"] == "p2p"
             tr = np.asarray(eng.run(EpsStream(5, 1, G), 6, 1e-12))
             us = eng.comm_benchmark("p2p", 50)
@@ -223,6 +232,29 @@ def test_handles_of_one_process_join_through_the_device_transport(world):
         for n in ("W", "v", "alpha_unconstr", "loc", "ls"):
             assert np.array_equal(st[n], out[0][1][n]), n
             assert np.abs(st[n] - st_ref[n]).max(initial=0) <= 2e-5 * max(np.abs(st_ref[n]).max(initial=0), 1e-30), n
+
+
+def test_two_ranks_of_one_process_on_one_device_are_refused():
+    """Two handles of ONE process on ONE device cannot be joined by the device transport: a device-wide synchronising runtime call made
+    for one of them (hipFree of a grown buffer, hipMalloc) waits for every kernel on the device, including the other's all-reduce
+    kernel, which waits for this rank -- measured as a time-out of the pair's second all-reduce.  ca_p2p_connect says so at once, on
+    both ranks (two-phase setup: nobody is left waiting), and both engines close cleanly."""
+    from clonealign_amd.engine import EngineError, HipEngine
+    case = make_case(seed=23, N=300, G=90, C=3, K=1)
+    ex = _ThreadExchange(2)
+    err = [None, None]
+
+    def worker(rank):
+        lo, hi = cell_range(300, rank, 2)
+        shard = {k: (v[lo:hi] if k in ("Y", "psi0") else v) for k, v in case.items()}
+        try:
+            HipEngine(**shard, rank=rank, world=2, p2p_exchange=ex.make(rank)).close()
+        except EngineError as e:
+            err[rank] = e
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert all(e is not None and e.code == 5 and "one process on one device" in str(e) for e in err), err
 
 
 def test_peer_to_peer_gives_up_on_a_missing_peer_instead_of_hanging():
@@ -249,7 +281,7 @@ def test_peer_to_peer_gives_up_on_a_missing_peer_instead_of_hanging():
         return [payload, bytes([1]) + bytes(E.P2P_HANDLE_BYTES - 1)]
     t0 = time.perf_counter()
     with pytest.raises(EngineError) as ei:
-        HipEngine(**half, rank=0, world=2, p2p_exchange=exchange, comm_timeout_ms=300)
+        HipEngine(**half, rank=0, world=2, p2p_exchange=exchange, comm_timeout_ms=300, variant_on=("p2p_same_device",))
     dt = time.perf_counter() - t0
     assert ei.value.code == 5 and "did not arrive" in str(ei.value), str(ei.value)
     assert dt < 20.0, dt

@@ -6,17 +6,17 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$1
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o st --output-format csv -- python3 $R/bench.py --no-cpu-baseline > $OUT/bench_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pf --output-format csv -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_pf.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pw --output-format csv -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_pw.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES -d $OUT/pmc_sq -o ps --output-format csv -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline > $OUT/bench_ps.log 2>&1
+rocprofv3 --kernel-trace --stats -d $OUT/stats -o st --output-format csv -- python3 $R/bench.py --no-cpu-baseline --busy-seconds 0 > $OUT/bench_stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o pf --output-format csv -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --busy-seconds 0 > $OUT/bench_pf.log 2>&1
+rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o pw --output-format csv -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --busy-seconds 0 > $OUT/bench_pw.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_VALU_MFMA_BUSY_CYCLES -d $OUT/pmc_sq -o ps --output-format csv -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --busy-seconds 0 > $OUT/bench_ps.log 2>&1
 ls -R $OUT | head -40
 cd $R
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 tail -c 600 $OUT/bench_default.json
 for cfg in "10000 2000 4" "50000 3000 6" "12500 5000 8" "25000 5000 8" "50000 5000 8"; do  # (BASELINE configs[1], [4]; one eighth, quarter, half of configs[2])
   set -- $cfg
-  python3 bench.py --steps 100 --warmup 10 --repeats 3 --no-cpu-baseline --cells $1 --genes $2 --clones $3 2>/dev/null | python3 -c "
+  python3 bench.py --steps 100 --warmup 10 --repeats 3 --no-cpu-baseline --busy-seconds 0 --cells $1 --genes $2 --clones $3 2>/dev/null | python3 -c "
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$cfg', round(d['value'],1), round(d['ms_per_step'],4))"
 done

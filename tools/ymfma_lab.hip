@@ -128,6 +128,11 @@ int main(int argc, char** argv) {
     printf("YtPsi digits: %lld mismatches of %lld\n", bad, (long long)G * 4 * K);
   }
   // ---- one copy, both products (k_ys_mfma), K = 1
+  // (Round 2's form of the kernel, which left raw int32 digit sums: that is what this section checks digit for digit -- result in
+  //  profiles/r02_lab_trb8_corun.txt.  Since round 3 the engine's body combines the digits itself and leaves float partial slabs for
+  //  the vector stream's finisher (ca_ys_io); tests/test_gpu_parity.py holds that form to the oracle.  Build with
+  //  -DYMFMA_LAB_ROUND2_ONE_COPY against the round-2 header to re-run this section.)
+#ifdef YMFMA_LAB_ROUND2_ONE_COPY
   if (K == 1) {
     const int64_t N64 = (N + 63) / 64 * 64;
     const int Gp5 = (G + CA_YS_GW - 1) / CA_YS_GW * CA_YS_GW;      // here Gp (multiple of 1024) serves
@@ -177,6 +182,7 @@ int main(int argc, char** argv) {
       CK(hipFree(YTi));
     }
   }
+#endif
   // ---- timing
   const double bytes = (double)N * G;
   const int reps = 30;
