@@ -181,10 +181,10 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    # CPU baseline: the OpenMP team is pinned before any OpenMP runtime starts, so the pages of the baseline's float32 matrix
-    # (first touched inside its own parallel loop, oracle/c/clonealign_simd.c) stay local to the threads that stream them
-    os.environ.setdefault("OMP_PROC_BIND", "spread")
-    os.environ.setdefault("OMP_PLACES", "threads")
+    # (CPU baseline placement: its float32 matrix is first touched inside the baseline's own OpenMP loop, static schedule, the same
+    #  partition every pass uses -- oracle/c/clonealign_simd.c.  Pinning the team through OMP_PROC_BIND here was tried and removed:
+    #  libgomp then pins THIS thread to one core, the engine's Philox generator threads inherit that mask, and the 200-iteration fit
+    #  below took 0.091 s instead of 0.063.)
 
     import torch
     import torch.distributed as dist
