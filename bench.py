@@ -162,6 +162,9 @@ def main():
     ap.add_argument("--allow-host-fallback", action="store_true",
                     help="at --gpus > 1, let the run continue on the gloo host all-reduce when no device transport comes up "
                          "(the result is then NOT a measurement of the device data path)")
+    ap.add_argument("--preheat-ms", type=float, default=60.0,
+                    help="untimed iterations run for this long right before the timed regions (after the --warmup steps): the GPU's clocks need "
+                         "~30 ms of load to ramp; 0 = none")
     ap.add_argument("--busy-seconds", type=float, default=4.0,
                     help="untimed iterations run for this long after the measurements (single GPU), so that a coarse GPU-utilisation sampler sees the device at work")
     ap.add_argument("--allow-foreign-lib", action="store_true",
@@ -321,8 +324,21 @@ def main():
         torch.cuda.synchronize()
         eng.synchronize()
 
+    # --- clock pre-heat (untimed, after the W warm-up steps): the device needs ~30 ms of continuous load to reach its operating
+    #     clocks -- kernel trace of a default run (profiles/r03_v1_timeline.txt): the iteration period falls from
+    #     322 us right after an idle gap to 289 us 30 ms later, the merged forward launch from 151 to 135 us.  W = 5 warm-up steps are
+    #     1.6 ms of work, and a 20-step timed region is 6 ms: without this the whole region sits on the ramp and measures the power
+    #     management, not the kernels.  The same iterations, the same arguments as the timed call; `preheat_ms` is in the output.
+    pre_it, t_pre = 0, time.perf_counter()
+    if args.preheat_ms > 0:
+        barrier()
+        t_pre = time.perf_counter()
+        while (time.perf_counter() - t_pre) * 1e3 < args.preheat_ms:
+            eng.iterate(args.steps, eps_t)
+            pre_it += args.steps
+    pre_ms = (time.perf_counter() - t_pre) * 1e3
     # --- timed: `repeats` regions of exactly `steps` iterations, each bracketed by barrier + synchronize on both sides and
-    #     maxed over the ranks; the quoted value is the MEDIAN region (a 20-step region at cfg-3 is only 7 ms long)
+    #     maxed over the ranks; the quoted value is the MEDIAN region (a 20-step region at cfg-3 is only 6 ms long)
     regions, last = [], float("nan")
     for _ in range(max(args.repeats, 1)):
         barrier()
@@ -479,6 +495,8 @@ def main():
                               "what": "ca_reinit (initial values, fresh Adam state), ca_run + 20 final ELBOs, eps generated by the "
                                       "built-in Philox stream (inside the time)"},
         }
+        out["preheat"] = {"ms": pre_ms, "iterations": pre_it,
+                          "what": "untimed iterations between the --warmup steps and the timed regions (clock ramp; see --preheat-ms)"}
         if busy_it:
             out["untimed_busy_tail"] = {"seconds": busy_s, "iterations": busy_it, "it_per_s": busy_it / busy_s,
                                         "what": "untimed ca_iterate calls after the measurements (see --busy-seconds); not part of value"}

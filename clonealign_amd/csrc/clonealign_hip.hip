@@ -155,7 +155,8 @@ struct ca_engine {
   bool tail_fuse = true;
   double* host_dev = nullptr;      // device view of host_pinned
   unsigned long long host_seq = 0, host_seq_next = 0;
-  float* eps_stage = nullptr; size_t eps_stage_bytes = 0;   // pinned staging buffer of the built-in eps stream
+  float* eps_stage = nullptr; size_t eps_stage_bytes = 0;   // pinned staging buffer of the eps stream (built-in or the caller's)
+  hipEvent_t ev_stage = nullptr;                             // completes when the last copy out of eps_stage has been made
   bool fwd_cell = false; int ncblk_f = 0, fc_tl = 4;   // forward sweep + cell epilogue in one kernel (k_fwd_cell)
   int fc_nbig = 0;                                     // > 0: k_fwd_cell_mix, that many blocks of 16 * fc_tl cells, the rest 32-cell blocks
   bool fwd_mfma = false; int fsplit = 1, fkchunk = 1, nk32 = 1; unsigned short* Mq = nullptr;   // matrix-core forward sweep
@@ -1366,8 +1367,22 @@ int stage_eps(ca_engine* h, const float* eps_stream, int64_t have, int64_t need)
       h->err = "eps stream too short: need " + std::to_string(need) + " draws, got " + std::to_string(have);
       return CA_ERR_INVALID;
     }
-    HIPCK(h, hipMemcpyAsync(h->eps_dev, eps_stream, (size_t)need * per * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    SYNC(h);
+    // Through the engine's pinned staging buffer, stream-ordered, WITHOUT draining the stream: a copy from the caller's pageable
+    // memory followed by a synchronisation left the GPU idle for ~250 us at the start of every call (kernel trace of the
+    // driver's 20-step command: 4 % of its time).  The buffer is reused only after the copy that last read it has completed.
+    const size_t bytes = (size_t)need * per * sizeof(float);
+    if (bytes > h->eps_stage_bytes) {
+      if (h->ev_stage) HIPCK(h, hipEventSynchronize(h->ev_stage));
+      if (h->eps_stage) HIPCK(h, hipHostFree(h->eps_stage));
+      h->eps_stage = nullptr; h->eps_stage_bytes = 0;
+      HIPCK(h, hipHostMalloc((void**)&h->eps_stage, bytes));
+      h->eps_stage_bytes = bytes;
+    }
+    if (!h->ev_stage) HIPCK(h, hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming));
+    else HIPCK(h, hipEventSynchronize(h->ev_stage));
+    memcpy(h->eps_stage, eps_stream, bytes);
+    HIPCK(h, hipMemcpyAsync(h->eps_dev, h->eps_stage, bytes, hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipEventRecord(h->ev_stage, h->stream));
   } else {
     // counter-based stream: draws are independent, so a long run's worth (2 + 2 max_iter draws) is generated by several
     // host threads -- same values whatever the thread count -- straight into a pinned staging buffer the engine keeps
@@ -1379,6 +1394,7 @@ int stage_eps(ca_engine* h, const float* eps_stream, int64_t have, int64_t need)
       HIPCK(h, hipHostMalloc((void**)&h->eps_stage, bytes));
       h->eps_stage_bytes = bytes;
     }
+    if (h->ev_stage) HIPCK(h, hipEventSynchronize(h->ev_stage));
     float* out = h->eps_stage;
     const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(need / 4, 48), (int64_t)std::thread::hardware_concurrency() / 2));
     if (nt > 1 && need * per >= (1 << 16)) {
@@ -1392,7 +1408,8 @@ int stage_eps(ca_engine* h, const float* eps_stream, int64_t have, int64_t need)
     }
     h->draw += need;
     HIPCK(h, hipMemcpyAsync(h->eps_dev, out, bytes, hipMemcpyHostToDevice, h->stream));
-    SYNC(h);
+    if (!h->ev_stage) HIPCK(h, hipEventCreateWithFlags(&h->ev_stage, hipEventDisableTiming));
+    HIPCK(h, hipEventRecord(h->ev_stage, h->stream));
   }
   return CA_OK;
 }
@@ -2180,6 +2197,7 @@ int ca_destroy(ca_handle h) {
   if (h->ev_params) hipEventDestroy(h->ev_params);
   if (h->ev_ydone) hipEventDestroy(h->ev_ydone);
   if (h->ev_ywdone) hipEventDestroy(h->ev_ywdone);
+  if (h->ev_stage) hipEventDestroy(h->ev_stage);
   if (h->comm) g_rccl.CommDestroy(h->comm);
   if (h->p2p) {
     for (void* q : h->p2p->opened) if (q) hipIpcCloseMemHandle(q);
