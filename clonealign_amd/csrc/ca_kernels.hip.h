@@ -700,13 +700,24 @@ __device__ __forceinline__ void ca_gene_pre_fused_body(const float* __restrict__
     double bx = 0.0;
     for (int p = K; p < D; ++p) bx += (double)V[(int64_t)g * D + p] * YtX[(int64_t)g * (D - K) + (p - K)];
     const float* lp = Lb + (int64_t)g * CA_CW;
+    const bool c16 = C > CA_CW;   // 9..16 clones: ONE draw per sweep, its clones 8.. in the second column half (copy numbers: second chunk of Lb)
     for (int w = 0; w < 2; ++w) {
       const double e = (double)(w ? epsB : epsA)[g];
       const double x = l + sd * e;
       const double mu = ca_softplus_d(x), lm = log(mu);
       const float muf = (float)mu;
       (w ? muB : muA)[g] = muf;
-      if (Mq) {   // two bf16 parts in the B-operand layout of k_fwd_mfma: [g / 32][part][16 (g % 32) / 8 + column][g % 8]
+      if (Mq && c16) {
+        if (w == 0) {
+          unsigned short* mq = Mq + ((int64_t)(g >> 5) * 128 + 16 * ((g & 31) >> 3)) * 8 + (g & 7);
+          for (int c = 0; c < C; ++c) {
+            const float x = (c < CA_CW ? lp[c] : Lb[((int64_t)G + g) * CA_CW + (c - CA_CW)]) * muf;
+            const unsigned short p1 = ca_bf16_rn(x);
+            mq[c * 8] = p1;
+            mq[(64 + c) * 8] = ca_bf16_rn(x - __uint_as_float((unsigned)p1 << 16));
+          }
+        }
+      } else if (Mq) {   // two bf16 parts in the B-operand layout of k_fwd_mfma: [g / 32][part][16 (g % 32) / 8 + column][g % 8]
         unsigned short* mq = Mq + ((int64_t)(g >> 5) * 128 + 16 * ((g & 31) >> 3) + w * C) * 8 + (g & 7);
         for (int c = 0; c < C; ++c) {
           const float x = lp[c] * muf;
@@ -1365,7 +1376,9 @@ __device__ __forceinline__ void ca_split3(float x, unsigned short& p1, unsigned 
 // R/clonealign.R:394-397).  L is then split in two bf16 parts like M in the forward sweep, coef in two, and the 24 operand slots
 // carry [c1 L_hi | c2 L_hi | c1 L_lo]: what is dropped (c2 L_lo, and the third part of coef) is below 2^-17 of the product -- the
 // forward sweep's own accuracy.  Integer copy numbers keep the exact three-part form.
-template <int TL, int DD, bool FRAC = false>
+// C16 (round 3): 9..16 clones with integer copy numbers.  The 32 operand slots carry two bf16 parts of coef for sixteen clones,
+// slot group q = 2 * part + chunk (what the sixteen-lane cell epilogue writes), against L of clone chunk q & 1 in both parts.
+template <int TL, int DD, bool FRAC = false, bool C16 = false>
 __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __restrict__ cq /*[N16][4][8] bf16 parts of coef*/,
                                                     const float* __restrict__ F /*[N16][DD]*/, const float* __restrict__ etamax2 /*[N16]*/,
                                                     const float* __restrict__ Lb /*[G][8]*/, const float* __restrict__ mu,
@@ -1391,10 +1404,11 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
        // All prologue loads are unconditional on a clamped index and masked afterwards: guarded loads compile to one
        // branch + wait each and ran back to back (13 us per block, tools/bwd_lab3.hip)
       const int g = gbase + 16 * m + j;
-      const bool ok = g < G && q < 3;
+      const bool ok = g < G && (C16 || q < 3);
       const int gg = g < G ? g : G - 1;
-      const float4 r0 = *reinterpret_cast<const float4*>(Lb + (int64_t)gg * CA_CW);
-      const float4 r1 = *reinterpret_cast<const float4*>(Lb + (int64_t)gg * CA_CW + 4);
+      const int64_t lrow = C16 ? (int64_t)(q & 1) * G + gg : (int64_t)gg;      // (C16: the clone chunk of this slot group)
+      const float4 r0 = *reinterpret_cast<const float4*>(Lb + lrow * CA_CW);
+      const float4 r1 = *reinterpret_cast<const float4*>(Lb + lrow * CA_CW + 4);
       const float lr[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
       unsigned short b[8];
 #pragma unroll
@@ -1827,11 +1841,16 @@ __global__ void __launch_bounds__(CA_TB) k_cell_par(const float* __restrict__ Zp
       if (mode == CA_MODE_TRAIN && ok) {
         const float cfv = (float)(-gam * sn / ((double)S * Z));
         coef[(((int64_t)s * nchunk + ch) * N + nn) * CA_CW + cc] = cfv;
-        if (coefq) {   // three bf16 parts for the matrix-core backward sweep (nchunk == 1)
+        if (coefq) {   // bf16 parts for the matrix-core backward sweep: three for up to eight clones, two per clone chunk for 9..16
           unsigned short p1, p2, p3;
           ca_split3(cfv, p1, p2, p3);
-          unsigned short* qp = coefq + (((int64_t)s * N16 + nn) * 4) * 8 + cc;
-          qp[0] = p1; qp[8] = p2; qp[16] = p3;
+          if (nchunk == 2) {   // (slot = 2 * part + chunk, as the sixteen-lane fused epilogue writes it)
+            unsigned short* qp = coefq + (((int64_t)s * N16 + nn) * 4 + ch) * 8 + cc;
+            qp[0] = p1; qp[16] = p2;
+          } else {
+            unsigned short* qp = coefq + (((int64_t)s * N16 + nn) * 4) * 8 + cc;
+            qp[0] = p1; qp[8] = p2; qp[16] = p3;
+          }
         }
       }
     }
@@ -1932,12 +1951,22 @@ __device__ __forceinline__ void ca_cell_fused_group(const ca_cell_ptrs& p, const
   const double llpB = Anc - sn * (log(ZB) + em);
   if (ok) {
     const float cfv = (float)(-gam * sn / ZB);
+    if constexpr (CP == 16) {   // 9..16 clones: coef in clone chunks of 8 like Lb; two bf16 parts, slot = 2 * part + chunk (k_bwd_mfma<.., C16>)
+      p.coef[((int64_t)(cc >> 3) * N + nn) * CA_CW + (cc & 7)] = cfv;
+      if (p.coefq) {
+        unsigned short p1, p2, p3;
+        ca_split3(cfv, p1, p2, p3);
+        unsigned short* qp = p.coefq + (nn * 4 + (cc >> 3)) * 8 + (cc & 7);
+        qp[0] = p1; qp[16] = p2;
+      }
+    } else {
     p.coef[nn * CA_CW + cc] = cfv;
     if (p.coefq) {
       unsigned short p1, p2, p3;
       ca_split3(cfv, p1, p2, p3);
       unsigned short* qp = p.coefq + (nn * 4) * 8 + cc;
       qp[0] = p1; qp[8] = p2; qp[16] = p3;
+    }
     }
   }
   const double fB = llpB + la[cc] - lg;
@@ -2103,14 +2132,16 @@ __global__ void __launch_bounds__(1024) k_yfinish(const float* __restrict__ part
 // launch and one inter-kernel gap less.  Sweep alone 119 us against 108 us for k_fwd_mfma (tools/fwd_mfma_lab.hip,
 // "block-split"), paid back by the 42 us cell epilogue launch it replaces.  Vs must be padded to a multiple of 32 genes
 // (last gene replicated, see k_final_gene / k_vprep); Mq is zero there.
-template <int D, int TL>
+template <int D, int TL, bool C16 = false>
 __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, const float* __restrict__ etamax2,
                                                  const float* __restrict__ Vs /*[nk * 32][D]*/,
                                                  const unsigned short* __restrict__ Mq /*[nk][2][64][8] bf16*/, const ca_cell_ptrs& p,
                                                  double* __restrict__ cell_part, int64_t N, int C, int K, int nk, int64_t cell0,
                                                  int blk, ca_f32x4* comb /*[4][TL][64]: the four waves' partial accumulators*/,
                                                  double* sm, const double* la) {
-  constexpr int CP = 8;                    // lanes per cell in the epilogue (C <= 8)
+  // C16 (round 3): 9..16 clones.  The sixteen operand columns then belong to ONE draw (clones 0..15) instead of two draws of up to
+  // eight clones, the epilogue works with sixteen lanes per cell, and monitor and train passes each take a sweep of their own.
+  constexpr int CP = C16 ? 16 : 8;         // lanes per cell in the epilogue
   const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4, wv = threadIdx.x >> 6;
   float f[TL][D], em[TL];
   ca_f32x4 acc[TL];
@@ -2197,7 +2228,7 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
     const bool inb = lc < TL * 16;
     const int lcc = inb ? lc : 0;
     const int t = lcc >> 4, row = lcc & 15, qq = row >> 2, r = row & 3;
-    const int la_ = 16 * qq + cc, lb_ = 16 * qq + C + cc;
+    const int la_ = 16 * qq + cc, lb_ = C16 ? la_ : 16 * qq + C + cc;
     auto cz = [&](int w, int col) { return (double)comb[(w * TL + t) * 64 + col][r]; };
     const double ZA = (cz(0, la_) + cz(1, la_)) + (cz(2, la_) + cz(3, la_));
     const double ZB = (cz(0, lb_) + cz(1, lb_)) + (cz(2, lb_) + cz(3, lb_));
@@ -2206,7 +2237,7 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
   ca_cell_fused_finish<CP>(cacc, sm, cell_part, blk, C, p.ee_partB);
 }
 
-template <int D, int TL>
+template <int D, int TL, bool C16 = false>
 __global__ void __launch_bounds__(CA_TB) k_fwd_cell(const float* __restrict__ F, const float* __restrict__ etamax2,
                                                     const float* __restrict__ Vs, const unsigned short* __restrict__ Mq, ca_cell_ptrs p,
                                                     const float* __restrict__ alpha_u, double* __restrict__ cell_part, int64_t N,
@@ -2215,7 +2246,7 @@ __global__ void __launch_bounds__(CA_TB) k_fwd_cell(const float* __restrict__ F,
   __shared__ double sm[CA_TB];
   __shared__ double la[64];
   ca_log_softmax_alpha(alpha_u, C, la);    // wave 0; visible to all after the body's barrier
-  ca_fwd_cell_body<D, TL>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)blockIdx.x * (TL * 16), blockIdx.x, comb, sm, la);
+  ca_fwd_cell_body<D, TL, C16>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)blockIdx.x * (TL * 16), blockIdx.x, comb, sm, la);
 }
 
 // Two block sizes in one launch: the first `nbig` blocks (one resident round: CUs x blocks per CU) own 16 * TLB cells each, the
@@ -2223,7 +2254,7 @@ __global__ void __launch_bounds__(CA_TB) k_fwd_cell(const float* __restrict__ F,
 // big ones free: the ragged end of the kernel -- CUs left with one wave per SIMD, or none, while the last big blocks finish --
 // shrinks from one big block's duration to one small block's.  (Small blocks everywhere would re-read the B operand from L2
 // three times as often: 64-cell blocks lose 5 % to 96-cell blocks at 100k cells.)
-template <int D, int TLB, int TLS>
+template <int D, int TLB, int TLS, bool C16 = false>
 __global__ void __launch_bounds__(CA_TB) k_fwd_cell_mix(const float* __restrict__ F, const float* __restrict__ etamax2,
                                                         const float* __restrict__ Vs, const unsigned short* __restrict__ Mq,
                                                         ca_cell_ptrs p, const float* __restrict__ alpha_u,
@@ -2233,10 +2264,10 @@ __global__ void __launch_bounds__(CA_TB) k_fwd_cell_mix(const float* __restrict_
   __shared__ double la[64];
   ca_log_softmax_alpha(alpha_u, C, la);
   if ((int)blockIdx.x < nbig)
-    ca_fwd_cell_body<D, TLB>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)blockIdx.x * (TLB * 16), blockIdx.x, comb, sm, la);
+    ca_fwd_cell_body<D, TLB, C16>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)blockIdx.x * (TLB * 16), blockIdx.x, comb, sm, la);
   else
-    ca_fwd_cell_body<D, TLS>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk,
-                             (int64_t)nbig * (TLB * 16) + (int64_t)((int)blockIdx.x - nbig) * (TLS * 16), blockIdx.x, comb, sm, la);
+    ca_fwd_cell_body<D, TLS, C16>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk,
+                                  (int64_t)nbig * (TLB * 16) + (int64_t)((int)blockIdx.x - nbig) * (TLS * 16), blockIdx.x, comb, sm, la);
 }
 
 
@@ -2776,8 +2807,11 @@ struct ca_ysride_args {
   int pers;                    // > 0: that many long-lived stream blocks lead the grid (see ca_yride_args::pers)
   ca_ovf_args ovf;
 };
-template <int D, int TLB, int TLS, int DEPTH>
-__global__ void __launch_bounds__(CA_TB, DEPTH == 1 ? 4 : 3) k_fwd_cell_mix_ys(const float* __restrict__ F, const float* __restrict__ etamax2,
+#ifndef CA_YS_RIDE_WAVES
+#define CA_YS_RIDE_WAVES 4   // waves per SIMD the merged launch's register budget is set for (lab: 3 = 168 VGPRs, three blocks per CU)
+#endif
+template <int D, int TLB, int TLS, int DEPTH, bool C16 = false>
+__global__ void __launch_bounds__(CA_TB, DEPTH == 1 ? CA_YS_RIDE_WAVES : 3) k_fwd_cell_mix_ys(const float* __restrict__ F, const float* __restrict__ etamax2,
                                                            const float* __restrict__ Vs, const unsigned short* __restrict__ Mq,
                                                            ca_cell_ptrs p, const float* __restrict__ alpha_u,
                                                            double* __restrict__ cell_part, int64_t N, int C, int K, int nk, int nbig,
@@ -2819,7 +2853,7 @@ __global__ void __launch_bounds__(CA_TB, DEPTH == 1 ? 4 : 3) k_fwd_cell_mix_ys(c
   double* la = sm + CA_TB;
   ca_log_softmax_alpha(alpha_u, C, la);
   if (nbig > 0 && idx >= nbig)
-    ca_fwd_cell_body<D, TLS>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)nbig * (TLB * 16) + (int64_t)(idx - nbig) * (TLS * 16), idx, comb, sm, la);
+    ca_fwd_cell_body<D, TLS, C16>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)nbig * (TLB * 16) + (int64_t)(idx - nbig) * (TLS * 16), idx, comb, sm, la);
   else
-    ca_fwd_cell_body<D, TLB>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)idx * (TLB * 16), idx, comb, sm, la);
+    ca_fwd_cell_body<D, TLB, C16>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)idx * (TLB * 16), idx, comb, sm, la);
 }

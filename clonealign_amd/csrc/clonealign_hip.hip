@@ -161,7 +161,7 @@ struct ca_engine {
   int fc_nbig = 0;                                     // > 0: k_fwd_cell_mix, that many blocks of 16 * fc_tl cells, the rest 32-cell blocks
   bool fwd_mfma = false; int fsplit = 1, fkchunk = 1, nk32 = 1; unsigned short* Mq = nullptr;   // matrix-core forward sweep
   // matrix-core backward sweep (k_bwd_mfma): bf16 parts of coef, its own cell split
-  bool bwd_mfma = false, bwd_frac = false; unsigned short* coefq = nullptr; int64_t N16 = 0, cchunk_m = 0; int csplit_m = 1, nwt = 0;
+  bool bwd_mfma = false, bwd_frac = false, c16 = false; unsigned short* coefq = nullptr; int64_t N16 = 0, cchunk_m = 0; int csplit_m = 1, nwt = 0;
   uint64_t draw = 0;  // built-in stream position
   // count-matrix products on the int8 matrix cores (ca_ymfma.hip.h): tiled copies, fixed-point parameter images
   bool y_mfma = false;
@@ -887,10 +887,10 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
       merged = is_sharded(h);
       if (merged) { bwd_tail.reduce_only = 1; bwd_tail.host_out = nullptr; }
     }
-#define CA_BWDM(DDV) do { if (h->bwd_frac) CA_BWDM_(DDV, true); else CA_BWDM_(DDV, false); } while (0)
-#define CA_BWDM_(DDV, FRV)                                                                                                  \
+#define CA_BWDM(DDV) do { if (h->c16) CA_BWDM_(DDV, false, true); else if (h->bwd_frac) CA_BWDM_(DDV, true, false); else CA_BWDM_(DDV, false, false); } while (0)
+#define CA_BWDM_(DDV, FRV, C16V)                                                                                            \
   LAUNCH(h, CA_KERNEL_BWD,                                                                                                 \
-         hipLaunchKernelGGL((k_bwd_mfma<TL, DDV, FRV>), dim3(xb + ((s == 0 && bwd_tail.enabled) ? 1 : 0), h->csplit_m), dim3(CA_TB), \
+         hipLaunchKernelGGL((k_bwd_mfma<TL, DDV, FRV, C16V>), dim3(xb + ((s == 0 && bwd_tail.enabled) ? 1 : 0), h->csplit_m), dim3(CA_TB), \
                             (size_t)h->cchunk_m * 4 * DDV * sizeof(float), h->stream,                                       \
                             h->coefq + (int64_t)s * h->N16 * 32, h->F, h->etamax2, h->Lb, mu32 + (int64_t)s * h->G, h->Vs,  \
                             h->V, h->gpart, h->dFpart, h->N, h->G, h->cchunk_m, h->S, s, 1, s == 0 ? 1 : 0,                 \
@@ -1123,14 +1123,18 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
     if (h->opt.ride_pattern < 0) ya.pers = std::min(-h->opt.ride_pattern, ya.nb_main);
     else if (h->opt.ride_pattern == 0 && ya.nb_main >= 2 * h->n_cu) ya.pers = h->n_cu;
     const dim3 grid(ya.pers > 0 ? (unsigned)(ya.pers + h->ncblk_f + (ya.nb_y - ya.nb_main)) : (unsigned)(h->ncblk_f + ya.nb_y));
-#define CA_FCYS(DV, TLBV, DPV)                                                                                                        \
-  LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell_mix_ys<DV, TLBV, 2, DPV>), grid, dim3(CA_TB), 0, h->stream, h->F, h->etamax2, h->Vs, \
+#define CA_FCYS(DV, TLBV, DPV, C16V)                                                                                                  \
+  LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell_mix_ys<DV, TLBV, 2, DPV, C16V>), grid, dim3(CA_TB), 0, h->stream, h->F, h->etamax2, h->Vs, \
                                               h->Mq, cp, h->alpha_u, h->cell_part, h->N, h->C, h->K, h->nk32, h->fc_nbig, h->ncblk_f, ya))
-#define CA_FCYS_D(TLBV, DPV) do { if (h->D == 1) CA_FCYS(1, TLBV, DPV); else CA_FCYS(2, TLBV, DPV); } while (0)
+#define CA_FCYS_D(TLBV, DPV) do { if (h->c16) { if (h->D == 1) CA_FCYS(1, TLBV, DPV, true); else CA_FCYS(2, TLBV, DPV, true); }  \
+                                  else { if (h->D == 1) CA_FCYS(1, TLBV, DPV, false); else CA_FCYS(2, TLBV, DPV, false); } } while (0)
     // (one piece in flight per wave: 128 VGPRs = four waves per SIMD like the vector stream's launch; two pieces, 162 VGPRs and
     //  three waves, measured 2824 against 2869 it/s at cfg-3 -- profiles/r03_ab_ystream.txt)
-    if (h->fc_tl == 6) CA_FCYS_D(6, 1);
-    else CA_FCYS_D(2, 1);
+#ifndef CA_YS_RIDE_DEPTH
+#define CA_YS_RIDE_DEPTH 1   // (lab: pieces in flight per stream wave)
+#endif
+    if (h->fc_tl == 6) CA_FCYS_D(6, CA_YS_RIDE_DEPTH);
+    else CA_FCYS_D(2, CA_YS_RIDE_DEPTH);
 #undef CA_FCYS_D
 #undef CA_FCYS
     CACK(ys_finish(h));
@@ -1196,7 +1200,19 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
   LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell_mix<DV, TLV, 2>), dim3(h->ncblk_f), dim3(CA_TB), 0, h->stream, h->F, \
                                               h->etamax2, h->Vs, h->Mq, cp, h->alpha_u, h->cell_part, h->N, h->C, h->K, h->nk32, h->fc_nbig))
 #define CA_FCMD(TLV) do { if (h->D == 1) CA_FCM(1, TLV); else CA_FCM(2, TLV); } while (0)
-    if (h->fc_nbig > 0) {
+    if (h->c16) {   // 9..16 clones: the two default block shapes
+#define CA_FC16(DV) do { if (h->fc_nbig > 0) \
+      LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell_mix<DV, 6, 2, true>), dim3(h->ncblk_f), dim3(CA_TB), 0, h->stream, h->F, \
+                                                  h->etamax2, h->Vs, h->Mq, cp, h->alpha_u, h->cell_part, h->N, h->C, h->K, h->nk32, h->fc_nbig)); \
+    else if (h->fc_tl == 6) \
+      LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell<DV, 6, true>), dim3(h->ncblk_f), dim3(CA_TB), 0, h->stream, h->F, h->etamax2, \
+                                                  h->Vs, h->Mq, cp, h->alpha_u, h->cell_part, h->N, h->C, h->K, h->nk32)); \
+    else \
+      LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell<DV, 2, true>), dim3(h->ncblk_f), dim3(CA_TB), 0, h->stream, h->F, h->etamax2, \
+                                                  h->Vs, h->Mq, cp, h->alpha_u, h->cell_part, h->N, h->C, h->K, h->nk32)); } while (0)
+      if (h->D == 1) CA_FC16(1); else CA_FC16(2);
+#undef CA_FC16
+    } else if (h->fc_nbig > 0) {
       switch (h->fc_tl) {
         case 4: CA_FCMD(4); break;
         case 5: CA_FCMD(5); break;
@@ -1322,11 +1338,20 @@ int wait_host_elbo(ca_engine* h, unsigned long long seq, const double* dev, doub
 // monitor pass on eps slot m; with next >= 0 (and the fused path available) also the forward half of the train
 // pass on slot `next`, which train_pass() then completes
 int monitor_pass(ca_engine* h, int64_t m, int64_t next, double* elbo_dst) {
+  if (h->fused_ok && h->c16) {   // 9..16 clones: one draw per sweep -- the monitor pass takes the sweep alone, nothing to look ahead to
+    CACK(fused_pass(h, m, m, elbo_dst));
+    h->look_valid = false;
+    return CA_OK;
+  }
   if (h->fused_ok && next >= 0) return fused_pass(h, m, next, elbo_dst);
   return run_pass(h, m, CA_MODE_ELBO, 0, elbo_dst);
 }
 int train_pass(ca_engine* h, int64_t slot) {
   if (h->look_valid && h->look_slot == slot) return train_from_lookahead(h, slot);
+  if (h->fused_ok && h->c16 && (h->bwd_mfma || !is_sharded(h))) {   // its forward half: the same sweep with this draw (the monitor half's ELBO is scratch)
+    CACK(fused_pass(h, slot, slot, h->terms_dev + 3));
+    return train_from_lookahead(h, slot);
+  }
   return run_pass(h, slot, CA_MODE_TRAIN, 1, nullptr);
 }
 
@@ -1733,7 +1758,8 @@ int create_impl(ca_engine* h, const ca_problem* p) {
       if ((double)f != v || (u & 0xFFFFu) != 0) { exact = false; break; }
     }
     h->bwd_frac = !exact;   // copy numbers that are not bf16-exact: the sweep's two-part form (k_bwd_mfma<.., FRAC>)
-    h->bwd_mfma = (D == 1 || D == 2) && h->nchunk == 1 && variant_on(h, CA_VAR_BWD_MFMA, "CA_BWD_MFMA");
+    // 9..16 clones (two clone chunks): the sweep's C16 form, integer copy numbers only (fractional ones would need 48 operand slots)
+    h->bwd_mfma = (D == 1 || D == 2) && (h->nchunk == 1 || (h->nchunk == 2 && exact && S == 1)) && variant_on(h, CA_VAR_BWD_MFMA, "CA_BWD_MFMA");
     h->N16 = (Nn + 15) / 16 * 16;
     if (h->bwd_mfma) {
       h->nwt = cdiv(G, CA_BWD_TL * 16);
@@ -1796,7 +1822,14 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   // ---- pass buffers
   CACK(dalloc(h, &h->mu32, (int64_t)S * G));
   CACK(dalloc(h, &h->Mb, (int64_t)S * h->nchunk * G * CA_CW));
-  h->fused_ok = (S == 1 && C <= CA_CW) && variant_on(h, CA_VAR_FUSED, "CA_FUSED");
+  // 9..16 clones (c16): the fused machinery with ONE draw per sweep in all sixteen operand columns -- only in its default form
+  // (matrix-core sweeps, sweep + cell epilogue in one kernel); otherwise such problems take the plain passes as before
+  h->c16 = S == 1 && C > CA_CW && C <= 2 * CA_CW && (D == 1 || D == 2) && h->bwd_mfma && h->tail_fuse &&
+           variant_on(h, CA_VAR_FWD_MFMA, "CA_FWD_MFMA") && variant_on(h, CA_VAR_FWD_CELL, "CA_FWD_CELL");
+  if (h->nchunk == 2 && !h->c16) h->bwd_mfma = false;
+  h->fused_ok = (S == 1 && (C <= CA_CW || h->c16)) && variant_on(h, CA_VAR_FUSED, "CA_FUSED");
+  if (!h->fused_ok) { if (h->nchunk == 2) h->bwd_mfma = false; h->c16 = false; }
+  if (h->c16) h->pair_elbo = false;   // (two draws per sweep need two column halves)
   if (h->fused_ok) {
     h->frow = (2 * C <= 8) ? 8 : 16;
     // matrix-core forward sweep (k_fwd_mfma): D in {1, 2}; few gene slices, streamed through LDS
@@ -1814,6 +1847,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
       //  39 us against 35, every block re-reads the B operand)
       h->fc_tl = (h->fwd_cell && cdiv(Nn, 64) < 2 * h->n_cu) ? 2 : 6;
       if (const int t = tune_val(h, CA_TUNE_FC_TL, "CA_FC_TL")) { if (t == 1 || t == 2 || t == 4 || t == 5 || t == 6 || t == 8) h->fc_tl = t; }
+      if (h->c16 && h->fc_tl != 2) h->fc_tl = 6;   // (the sixteen-clone kernels exist for the two default block shapes)
       h->ncblk_f = cdiv(Nn, 16 * h->fc_tl);
       // two block sizes in one launch (k_fwd_cell_mix)
       if (h->fwd_cell && (h->fc_tl == 4 || h->fc_tl == 5 || h->fc_tl == 6 || h->fc_tl == 8) && (D == 1 || D == 2)) {
@@ -1946,7 +1980,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     h->y_dev_bytes += h->ys_N64 * h->Gp;
   }
   // the Y stream rides on the forward sweep's launch: 1-byte storage, K = 1, the fused sweep with its default block shapes
-  h->ride_ok = h->ystore == CA_YSTORE_U8 && K == 1 && h->fused_ok && h->fwd_cell && (h->fc_tl == 6 || h->fc_tl == 8 || (h->fc_tl == 2 && h->fc_nbig == 0)) &&
+  h->ride_ok = h->ystore == CA_YSTORE_U8 && K == 1 && h->fused_ok && !h->c16 && h->fwd_cell && (h->fc_tl == 6 || h->fc_tl == 8 || (h->fc_tl == 2 && h->fc_nbig == 0)) &&
                !h->y_mfma && !h->y_ys && variant_on(h, CA_VAR_Y_RIDE, "CA_Y_RIDE");
   constexpr bool kRideSeqDefault = false;
   h->ride_seq = h->ride_ok && variant_on(h, CA_VAR_RIDE_SEQ, "CA_RIDE_SEQ") && (kRideSeqDefault || variantx_on(h, CA_VARX_RIDE_SEQ, "CA_RIDE_SEQ_ON"));
@@ -2562,6 +2596,7 @@ int ca_final_elbo(ca_handle h, int32_t n_rep, const float* eps_stream, int64_t n
   const bool pairs = h->fused_ok && h->fwd_cell && !is_sharded(h) && h->pair_elbo;
   for (int i = 0; i < n_rep; ++i) {
     if (pairs && i + 1 < n_rep) { CACK(fused_pass(h, i, i + 1, h->elbo_dev + i, h->elbo_dev + i + 1)); ++i; }
+    else if (h->fused_ok && h->c16) { CACK(monitor_pass(h, i, -1, h->elbo_dev + i)); CACK(flush_mon_tail(h)); }   // one draw per matrix-core sweep
     else CACK(run_pass(h, i, CA_MODE_ELBO, 0, h->elbo_dev + i));
   }
   std::vector<double> v((size_t)n_rep);
