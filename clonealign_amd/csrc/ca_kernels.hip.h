@@ -691,7 +691,9 @@ __device__ __forceinline__ void ca_gene_pre_fused_body(const float* __restrict__
                                                           const float* __restrict__ V, int D, int K, const double* __restrict__ YtX,
                                                           float* __restrict__ muA, float* __restrict__ muB, float* __restrict__ Mb,
                                                           double* __restrict__ gene_partA, double* __restrict__ gene_partB, int G,
-                                                          int mrow, int C, unsigned short* __restrict__ Mq, double* sm, int blk) {
+                                                          int mrow, int C, unsigned short* __restrict__ Mq, double* sm, int blk, int s2 = 0) {
+  // s2 (round 3): the two "draws" are the two SAMPLES of one pass with mc_samples = 2 (R/inference-tflow.R:268-269, :306-308): the
+  // per-gene terms of the ELBO are then their mean (as k_gene_pre leaves them), in gene_partA
   const int g = blk * CA_TB + threadIdx.x;
   const bool ok = g < G;
   double t[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
@@ -741,7 +743,8 @@ __device__ __forceinline__ void ca_gene_pre_fused_body(const float* __restrict__
     if (threadIdx.x == 0) {
       double* ga = gene_partA + (int64_t)blk * W_;
       double* gb = gene_partB + (int64_t)blk * W_;
-      ga[0] = six[0]; ga[1] = six[1]; ga[2] = six[2];
+      if (s2) { ga[0] = 0.5 * (six[0] + six[3]); ga[1] = 0.5 * (six[1] + six[4]); ga[2] = 0.5 * (six[2] + six[5]); }
+      else { ga[0] = six[0]; ga[1] = six[1]; ga[2] = six[2]; }
       gb[0] = six[3]; gb[1] = six[4]; gb[2] = six[5];
     }
   }
@@ -761,9 +764,9 @@ __global__ void __launch_bounds__(CA_TB) k_gene_pre_fused(const float* __restric
                                                           const float* __restrict__ V, int D, int K, const double* __restrict__ YtX,
                                                           float* __restrict__ muA, float* __restrict__ muB, float* __restrict__ Mb,
                                                           double* __restrict__ gene_partA, double* __restrict__ gene_partB, int G,
-                                                          int mrow, int C, unsigned short* __restrict__ Mq) {
+                                                          int mrow, int C, unsigned short* __restrict__ Mq, int s2) {
   __shared__ double sm[CA_TB];
-  ca_gene_pre_fused_body(loc, ls, epsA, epsB, colsum, Lb, V, D, K, YtX, muA, muB, Mb, gene_partA, gene_partB, G, mrow, C, Mq, sm, blockIdx.x);
+  ca_gene_pre_fused_body(loc, ls, epsA, epsB, colsum, Lb, V, D, K, YtX, muA, muB, Mb, gene_partA, gene_partB, G, mrow, C, Mq, sm, blockIdx.x, s2);
 }
 // the same per-gene prologue for the NEXT (monitor, train) eps pair, as extra blocks of the per-cell kernel of a train pass
 // (k_adam_cell): the per-gene variables are final once k_final_gene has run, so the following fused pass starts at its sweep
@@ -771,7 +774,7 @@ struct ca_pre_args {
   int nblk;   // 0: none
   const float* loc; const float* ls; const float* epsA; const float* epsB; const double* colsum; const float* Lb; const float* V;
   const double* YtX; float* muA; float* muB; float* Mb; double* gene_partA; double* gene_partB; unsigned short* Mq;
-  int G, D, K, mrow, C;
+  int G, D, K, mrow, C, s2;
 };
 // psi's gradient and Adam step, as extra blocks of the per-gene kernel (k_final_gene): psi is all the Y stream needs, so the
 // side stream can start on the next pass's Y kernel while the main stream is still updating the q(z) logits
@@ -1919,6 +1922,9 @@ struct ca_cell_ptrs {
   const double* A; const double* cn; const double* s64; const float* etamax2; const float* glogit; const float* F;
   float* coef; float* dgl; unsigned short* coefq;
   double* ee_partB;   // non-null: also the second draw's expected log-likelihood per block (two ELBOs from one sweep: ca_final_elbo)
+  int s2;             // 1: the two column halves are the two SAMPLES of one pass (mc_samples = 2): log-likelihood from the mean of log Z,
+                      //    coef for both samples (second one N x 8 floats / N16 x 32 bf16 further on, the layout the S loops use)
+  int64_t N16;
 };
 template <int CP>
 __device__ __forceinline__ void ca_cell_fused_group(const ca_cell_ptrs& p, const double* la, int64_t n, int64_t N, int C, int D, int K,
@@ -1947,8 +1953,25 @@ __device__ __forceinline__ void ca_cell_fused_group(const ca_cell_ptrs& p, const
   const double sn = p.s64[nn];
   const double em = (D > 0) ? (double)p.etamax2[nn] * CA_LN2 : 0.0;
   const double Anc = p.A[nn * C + cc];
-  const double llpA = Anc - sn * (log(ZA) + em);
-  const double llpB = Anc - sn * (log(ZB) + em);
+  double llpA = Anc - sn * (log(ZA) + em);
+  double llpB = Anc - sn * (log(ZB) + em);
+  if (CP != 16 && p.s2) {   // (uniform) two samples of one pass: ll' = A - s mean_s log Z_s (:306-308), coef_s = -gamma s / (2 Z_s)
+    llpA = llpB = 0.5 * (llpA + llpB);
+    if (ok) {
+      const float c0 = (float)(-gam * sn / (2.0 * ZA)), c1 = (float)(-gam * sn / (2.0 * ZB));
+      p.coef[nn * CA_CW + cc] = c0;
+      p.coef[(N + nn) * CA_CW + cc] = c1;
+      if (p.coefq) {
+        unsigned short p1, p2, p3;
+        ca_split3(c0, p1, p2, p3);
+        unsigned short* qp = p.coefq + (nn * 4) * 8 + cc;
+        qp[0] = p1; qp[8] = p2; qp[16] = p3;
+        ca_split3(c1, p1, p2, p3);
+        qp = p.coefq + ((p.N16 + nn) * 4) * 8 + cc;
+        qp[0] = p1; qp[8] = p2; qp[16] = p3;
+      }
+    }
+  } else
   if (ok) {
     const float cfv = (float)(-gam * sn / ZB);
     if constexpr (CP == 16) {   // 9..16 clones: coef in clone chunks of 8 like Lb; two bf16 parts, slot = 2 * part + chunk (k_bwd_mfma<.., C16>)
@@ -2608,7 +2631,7 @@ __global__ void __launch_bounds__(CA_TB) k_adam_cell(const float* __restrict__ F
     if (b < pre.nblk) {   // the next eps pair's per-gene prologue (ca_pre_args)
       __shared__ double smp[CA_TB];
       ca_gene_pre_fused_body(pre.loc, pre.ls, pre.epsA, pre.epsB, pre.colsum, pre.Lb, pre.V, pre.D, pre.K, pre.YtX, pre.muA, pre.muB, pre.Mb,
-                             pre.gene_partA, pre.gene_partB, pre.G, pre.mrow, pre.C, pre.Mq, smp, b);
+                             pre.gene_partA, pre.gene_partB, pre.G, pre.mrow, pre.C, pre.Mq, smp, b, pre.s2);
     } else {              // chi / alpha gradients and Adam, the range of V' (ca_final_small_body)
       if (tail.enabled) ca_final_small_body(tail);
     }

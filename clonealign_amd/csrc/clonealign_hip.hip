@@ -161,7 +161,7 @@ struct ca_engine {
   int fc_nbig = 0;                                     // > 0: k_fwd_cell_mix, that many blocks of 16 * fc_tl cells, the rest 32-cell blocks
   bool fwd_mfma = false; int fsplit = 1, fkchunk = 1, nk32 = 1; unsigned short* Mq = nullptr;   // matrix-core forward sweep
   // matrix-core backward sweep (k_bwd_mfma): bf16 parts of coef, its own cell split
-  bool bwd_mfma = false, bwd_frac = false, c16 = false; unsigned short* coefq = nullptr; int64_t N16 = 0, cchunk_m = 0; int csplit_m = 1, nwt = 0;
+  bool bwd_mfma = false, bwd_frac = false, c16 = false, s2 = false; unsigned short* coefq = nullptr; int64_t N16 = 0, cchunk_m = 0; int csplit_m = 1, nwt = 0;
   uint64_t draw = 0;  // built-in stream position
   // count-matrix products on the int8 matrix cores (ca_ymfma.hip.h): tiled copies, fixed-point parameter images
   bool y_mfma = false;
@@ -982,10 +982,15 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
   // the next fused pass's per-gene prologue, when the loop has announced its eps slots: extra blocks of the per-cell kernel
   ca_pre_args pre;
   memset(&pre, 0, sizeof(pre));
-  if (apply && h->pre_ok && h->hint_A >= 0 && h->hint_B >= 0 && h->fused_ok && h->gene_part_alt) {
+  // (the hints are PASS slots: one draw per sweep for 9..16 clones -- the monitor pass alone; two samples per pass for mc_samples = 2)
+  int64_t hA = h->hint_A, hB = h->hint_B;
+  if (h->c16) hB = hA;
+  if (h->s2) { hA = 2 * h->hint_A; hB = hA + 1; }
+  if (apply && h->pre_ok && h->hint_A >= 0 && hB >= 0 && h->fused_ok && h->gene_part_alt) {
     pre.nblk = h->ngblk;
-    pre.loc = h->loc; pre.ls = h->ls; pre.epsA = h->eps_dev + h->hint_A * (int64_t)h->G; pre.epsB = h->eps_dev + h->hint_B * (int64_t)h->G;
-    pre.colsum = h->colsum; pre.Lb = h->Lb; pre.V = h->V; pre.YtX = h->YtX; pre.muA = h->mu32; pre.muB = h->mu32B; pre.Mb = h->Mb2;
+    pre.loc = h->loc; pre.ls = h->ls; pre.epsA = h->eps_dev + hA * (int64_t)h->G; pre.epsB = h->eps_dev + hB * (int64_t)h->G;
+    pre.colsum = h->colsum; pre.Lb = h->Lb; pre.V = h->V; pre.YtX = h->YtX; pre.muA = h->mu32; pre.muB = h->s2 ? h->mu32 + h->G : h->mu32B; pre.Mb = h->Mb2;
+    pre.s2 = h->s2 ? 1 : 0;
     pre.gene_partA = h->gene_part_alt; pre.gene_partB = h->gene_partB_alt; pre.Mq = h->fwd_mfma ? h->Mq : nullptr;
     pre.G = h->G; pre.D = h->D; pre.K = h->K; pre.mrow = h->frow; pre.C = h->C;
   }
@@ -1003,7 +1008,7 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
                             h->N, h->C, h->D, apply, lr_t, (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps,
                             h->vmm_part, h->ngblk, h->etamax2, small_args(h, h->gene_part, apply ? 1 : 0, lr_t, elbo_dst, false),
                             N256, pre, ysq));
-  if (pre.nblk) { h->pre_valid = true; h->pre_A = h->hint_A; h->pre_B = h->hint_B; }
+  if (pre.nblk) { h->pre_valid = true; h->pre_A = hA; h->pre_B = hB; }
   h->hint_A = h->hint_B = -1;
   if (apply) {
     if (h->ys_steps >= 0) h->ys_steps += 1;
@@ -1093,8 +1098,8 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
   } else {
     LAUNCH(h, CA_KERNEL_OTHER,
            hipLaunchKernelGGL(k_gene_pre_fused, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->loc, h->ls, epsA, epsB, h->colsum, h->Lb,
-                              h->V, h->D, h->K, h->YtX, h->mu32, h->mu32B, h->Mb2, h->gene_part, h->gene_partB, h->G, h->frow, h->C,
-                              h->fwd_mfma ? h->Mq : nullptr));
+                              h->V, h->D, h->K, h->YtX, h->mu32, h->s2 ? h->mu32 + h->G : h->mu32B, h->Mb2, h->gene_part, h->gene_partB, h->G,
+                              h->frow, h->C, h->fwd_mfma ? h->Mq : nullptr, h->s2 ? 1 : 0));
   }
   h->pre_valid = false;
   // the Y products of this parameter state: riding on the sweep's own launch (below), or from the side stream / in line
@@ -1104,6 +1109,7 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
   cp.A = h->A; cp.cn = h->cn; cp.s64 = h->s64; cp.etamax2 = h->etamax2; cp.glogit = h->glogit; cp.F = h->F;
   cp.coef = h->coef; cp.dgl = h->dgl; cp.coefq = h->bwd_mfma ? h->coefq : nullptr;
   cp.ee_partB = (elbo_dstB && h->fwd_cell) ? h->ee_partB : nullptr;
+  cp.s2 = h->s2 ? 1 : 0; cp.N16 = h->N16;
   int CP = 1;
   while (CP < h->C) CP <<= 1;
   int cell_blocks = h->ncblk;
@@ -1288,12 +1294,14 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
 
 // Train pass whose forward half was already done by fused_pass(.., slotB): backward sweep + Adam.
 int train_from_lookahead(ca_engine* h, int64_t slot) {
-  if (!h->look_valid || h->look_slot != slot) { h->err = "internal: no look-ahead forward for this eps slot"; return CA_ERR_STATE; }
+  // (s2: `slot` is the PASS, its two samples are draws 2 slot and 2 slot + 1 and the look-ahead bookkeeping is in draws)
+  const int64_t want = h->s2 ? 2 * slot + 1 : slot;
+  if (!h->look_valid || h->look_slot != want) { h->err = "internal: no look-ahead forward for this eps slot"; return CA_ERR_STATE; }
   h->look_valid = false;
-  const bool have_bwd = h->bwd_ready && h->bwd_slot == slot;
+  const bool have_bwd = h->bwd_ready && h->bwd_slot == want;
   h->bwd_ready = false;
-  if (!have_bwd) CACK(train_bwd(h, h->mu32B, true));
-  return train_update(h, h->eps_dev + slot * (int64_t)h->G, 1, nullptr);
+  if (!have_bwd) CACK(train_bwd(h, h->s2 ? h->mu32 : h->mu32B, true));
+  return train_update(h, h->eps_dev + slot * (int64_t)h->S * h->G, 1, nullptr);
 }
 
 // ca_run: issue the backward half of the NEXT train pass (its forward half came with the monitor pass just queued)
@@ -1338,8 +1346,8 @@ int wait_host_elbo(ca_engine* h, unsigned long long seq, const double* dev, doub
 // monitor pass on eps slot m; with next >= 0 (and the fused path available) also the forward half of the train
 // pass on slot `next`, which train_pass() then completes
 int monitor_pass(ca_engine* h, int64_t m, int64_t next, double* elbo_dst) {
-  if (h->fused_ok && h->c16) {   // 9..16 clones: one draw per sweep -- the monitor pass takes the sweep alone, nothing to look ahead to
-    CACK(fused_pass(h, m, m, elbo_dst));
+  if (h->fused_ok && (h->c16 || h->s2)) {   // 9..16 clones: one draw per sweep; mc_samples = 2: the pass's two samples in the two column
+    CACK(h->s2 ? fused_pass(h, 2 * m, 2 * m + 1, elbo_dst) : fused_pass(h, m, m, elbo_dst));   // halves -- the monitor pass takes the sweep alone
     h->look_valid = false;
     return CA_OK;
   }
@@ -1348,8 +1356,9 @@ int monitor_pass(ca_engine* h, int64_t m, int64_t next, double* elbo_dst) {
 }
 int train_pass(ca_engine* h, int64_t slot) {
   if (h->look_valid && h->look_slot == slot) return train_from_lookahead(h, slot);
-  if (h->fused_ok && h->c16 && (h->bwd_mfma || !is_sharded(h))) {   // its forward half: the same sweep with this draw (the monitor half's ELBO is scratch)
-    CACK(fused_pass(h, slot, slot, h->terms_dev + 3));
+  if (h->fused_ok && (h->c16 || h->s2) && (h->bwd_mfma || !is_sharded(h))) {   // its forward half: the same sweep with this pass's draw(s)
+    h->mon_tail.enabled = 0;   // (a monitor tail still pending belongs to a ca_iterate pass whose ELBO nobody reads; ca_run has flushed its own)
+    CACK(h->s2 ? fused_pass(h, 2 * slot, 2 * slot + 1, h->terms_dev + 3) : fused_pass(h, slot, slot, h->terms_dev + 3));   // (the monitor role's ELBO is scratch)
     return train_from_lookahead(h, slot);
   }
   return run_pass(h, slot, CA_MODE_TRAIN, 1, nullptr);
@@ -1827,9 +1836,12 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   h->c16 = S == 1 && C > CA_CW && C <= 2 * CA_CW && (D == 1 || D == 2) && h->bwd_mfma && h->tail_fuse &&
            variant_on(h, CA_VAR_FWD_MFMA, "CA_FWD_MFMA") && variant_on(h, CA_VAR_FWD_CELL, "CA_FWD_CELL");
   if (h->nchunk == 2 && !h->c16) h->bwd_mfma = false;
-  h->fused_ok = (S == 1 && (C <= CA_CW || h->c16)) && variant_on(h, CA_VAR_FUSED, "CA_FUSED");
-  if (!h->fused_ok) { if (h->nchunk == 2) h->bwd_mfma = false; h->c16 = false; }
-  if (h->c16) h->pair_elbo = false;   // (two draws per sweep need two column halves)
+  // mc_samples = 2 (s2): the two column halves carry the two SAMPLES of one pass; same conditions, up to eight clones
+  h->s2 = S == 2 && C <= CA_CW && (D == 1 || D == 2) && h->bwd_mfma && h->tail_fuse &&
+          variant_on(h, CA_VAR_FWD_MFMA, "CA_FWD_MFMA") && variant_on(h, CA_VAR_FWD_CELL, "CA_FWD_CELL");
+  h->fused_ok = ((S == 1 && (C <= CA_CW || h->c16)) || h->s2) && variant_on(h, CA_VAR_FUSED, "CA_FUSED");
+  if (!h->fused_ok) { if (h->nchunk == 2) h->bwd_mfma = false; h->c16 = false; h->s2 = false; }
+  if (h->c16 || h->s2) h->pair_elbo = false;   // (two draws per sweep need two column halves of their own)
   if (h->fused_ok) {
     h->frow = (2 * C <= 8) ? 8 : 16;
     // matrix-core forward sweep (k_fwd_mfma): D in {1, 2}; few gene slices, streamed through LDS
@@ -1848,6 +1860,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
       h->fc_tl = (h->fwd_cell && cdiv(Nn, 64) < 2 * h->n_cu) ? 2 : 6;
       if (const int t = tune_val(h, CA_TUNE_FC_TL, "CA_FC_TL")) { if (t == 1 || t == 2 || t == 4 || t == 5 || t == 6 || t == 8) h->fc_tl = t; }
       if (h->c16 && h->fc_tl != 2) h->fc_tl = 6;   // (the sixteen-clone kernels exist for the two default block shapes)
+      if (h->s2 && !h->fwd_cell) { h->s2 = false; h->fused_ok = false; }
       h->ncblk_f = cdiv(Nn, 16 * h->fc_tl);
       // two block sizes in one launch (k_fwd_cell_mix)
       if (h->fwd_cell && (h->fc_tl == 4 || h->fc_tl == 5 || h->fc_tl == 6 || h->fc_tl == 8) && (D == 1 || D == 2)) {
@@ -2566,7 +2579,7 @@ int ca_iterate(ca_handle h, int32_t n_iter, const float* eps_stream, int64_t n_d
   // separate cell epilogue, the Y stream in line: 0.65 ms at cfg-3, 4 % of a 20-iteration call) its forward half takes the fused
   // matrix-core sweep with its own draw in both column halves; the monitor half's ELBO goes to a scratch slot.
   // (sharded with the general backward sweep the extra monitor tail would cost a collective of its own: plain kernels there)
-  if (n_iter > 0 && h->fused_ok && !h->look_valid && (h->bwd_mfma || !is_sharded(h)))
+  if (n_iter > 0 && h->fused_ok && !h->c16 && !h->s2 && !h->look_valid && (h->bwd_mfma || !is_sharded(h)))
     CACK(fused_pass(h, 0, 0, h->elbo_dev + n_iter));
   for (int i = 0; i < n_iter; ++i) {
     // (the last monitor pass has no train pass to share its sweep with: its own draw in both halves, as above -- the plain
@@ -2596,7 +2609,7 @@ int ca_final_elbo(ca_handle h, int32_t n_rep, const float* eps_stream, int64_t n
   const bool pairs = h->fused_ok && h->fwd_cell && !is_sharded(h) && h->pair_elbo;
   for (int i = 0; i < n_rep; ++i) {
     if (pairs && i + 1 < n_rep) { CACK(fused_pass(h, i, i + 1, h->elbo_dev + i, h->elbo_dev + i + 1)); ++i; }
-    else if (h->fused_ok && h->c16) { CACK(monitor_pass(h, i, -1, h->elbo_dev + i)); CACK(flush_mon_tail(h)); }   // one draw per matrix-core sweep
+    else if (h->fused_ok && (h->c16 || h->s2)) { CACK(monitor_pass(h, i, -1, h->elbo_dev + i)); CACK(flush_mon_tail(h)); }   // one pass per matrix-core sweep
     else CACK(run_pass(h, i, CA_MODE_ELBO, 0, h->elbo_dev + i));
   }
   std::vector<double> v((size_t)n_rep);

@@ -618,3 +618,50 @@ def test_nine_to_sixteen_clones_run_the_matrix_core_sweeps(shape):
         assert np.abs(fe - fo).max() <= 1e-5 * np.abs(fo).max()
     finally:
         eng.close()
+
+
+@pytest.mark.parametrize("shape", [dict(N=700, G=1100, C=5, K=1, S=2), dict(N=333, G=95, C=8, K=1, S=2), dict(N=520, G=300, C=6, K=1, P=1, S=2),
+                                   dict(N=257, G=161, C=2, K=2, S=2), dict(N=1200, G=400, C=4, K=1, S=2, extra=True),
+                                   dict(N=40_100, G=700, C=7, K=1, S=2)],
+                         ids=["c5", "c8_ragged", "k1p1", "k2", "allele", "c7_40k"])
+def test_two_mc_samples_run_the_matrix_core_sweeps(shape):
+    """mc_samples = 2 (R/clonealign.R:184-203, R/inference-tflow.R:268-269,306-308) fell to the plain VALU passes up to round 2.  Round 3:
+    the two column halves of the forward sweep carry the two SAMPLES of one pass (as they carry two draws of consecutive passes for
+    S = 1), the cell epilogue takes the mean of log Z over them and leaves coef for both, the backward sweep runs once per sample as
+    before, the per-gene ELBO terms are the mean of the two samples'.  Against the oracle, like the S = 1 path."""
+    from clonealign_amd.engine import HipEngine
+    from clonealign_amd.inference import run_vi_loop
+    from clonealign_amd.rng import EpsStream
+    from oracle.fused_numpy import FusedModel
+    case = make_case(seed=67, **shape)
+    eng, ora = HipEngine(**case), FusedModel(**case, dtype="float32")
+    try:
+        info = eng.info()
+        assert (info["fused_sweep"], info["fwd_mfma"], info["bwd_mfma"], info["fwd_cell"]) == (1, 1, 1, 1), info
+        G = ora.G
+        st = perturbed_state({n: getattr(ora, n).shape for n in ora.VAR_NAMES}, amp=0.2)
+        for n, v in st.items():
+            setattr(ora, n, v.astype(ora.pdt))
+            eng.set(n, v)
+        n_iter = 5
+        epss = np.stack([eps_for(2, G, 100 + i) for i in range(2 * n_iter)])
+        last = eng.iterate(n_iter, epss)
+        for i in range(n_iter):
+            ora.step(epss[2 * i])
+            e = ora.elbo(epss[2 * i + 1])
+        assert abs(last - e) <= 2e-5 * abs(e), (last, e)
+        p = eng.get_state()
+        for n in ora.VAR_NAMES:
+            if n == "gamma_logits":      # (see test_nine_to_sixteen_clones...: a few Adam-chaotic coordinates among N x C)
+                d = np.abs(p[n] - np.asarray(getattr(ora, n), dtype=np.float64)) / np.abs(getattr(ora, n)).max()
+                assert (d > 1e-4).sum() <= max(2, d.size // 20000) and d.max() < 5e-3, (int((d > 1e-4).sum()), d.max())
+                continue
+            assert _rel(p[n], getattr(ora, n)) < 1e-4, (n, _rel(p[n], getattr(ora, n)))
+        tr = np.asarray(eng.run(EpsStream(5, 2, G), 4, 1e-12))
+        to = np.asarray(run_vi_loop(ora, EpsStream(5, 2, G), 4, 1e-12))
+        assert tr.shape == to.shape and np.abs(tr - to).max() <= 1e-5 * np.abs(to).max(), (tr, to)
+        fe = eng.final_elbo(np.stack([eps_for(2, G, 70 + i) for i in range(3)]), 3)
+        fo = np.array([ora.elbo(eps_for(2, G, 70 + i)) for i in range(3)])
+        assert np.abs(fe - fo).max() <= 1e-5 * np.abs(fo).max()
+    finally:
+        eng.close()
