@@ -613,6 +613,70 @@ __global__ void __launch_bounds__(1024) k_colsum(const float* __restrict__ part,
   if (ty == 0 && c < cols) out[c] = sm[0][tx];
 }
 
+// The count-matrix stream's finisher (k_yfinish, K = 1) as EXTRA BLOCKS of the backward sweep's launch instead of a launch of its own
+// between the two sweeps (round 3).  Nothing the sweep reads depends on it, what follows the sweep does.
+//   column jobs: k_colsum's sums of the Y^T psi slab, ONE WAVE per 64 columns; each lane walks its column's rows in k_colsum's own
+//     order -- sixteen row lanes of four chains each, the overflow list's chunk sums on row lane 0, the same pairwise tree -- so the
+//     result is bitwise k_colsum's.  No LDS, no barrier.
+//   row jobs: k_yw_dot's block of CA_TB cells (YW from the segment shares, the block's share of sum_n psi_n (YW)_n).
+struct ca_yfin_args {
+  int ncol, nrow;              // 64-column waves, CA_TB-cell blocks (0, 0: none)
+  const float* part; double* out; int rows; int64_t ld; int cols;
+  const int* col_chunk_ptr; const float* csum; int G;
+  const float* YWpart; int nseg; const float* F; int D; int64_t N; float* YW; double* yw_part;
+};
+__device__ __forceinline__ void ca_yfin_col_wave(const ca_yfin_args& a, int job) {
+  constexpr int RL = 16;
+  const int c = job * 64 + (int)(threadIdx.x & 63);
+  if (c >= a.cols) return;
+  // row lanes in bit-reversed order (0, 8, 4, 12, 2, 10, 6, 14, then the odd ones), eight at a time -- the sweep's register budget --
+  // so that each half folds into one subtree of k_colsum's LDS tree: ((x0 + x1) + (x2 + x3)) + ((x4 + x5) + (x6 + x7))
+  double half[2];
+#pragma unroll 1
+  for (int i8 = 0; i8 < 2; ++i8) {
+    double x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ty = ((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | i8;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+      int r = ty;
+      for (; r + 3 * RL < a.rows; r += 4 * RL) {
+        const float v0 = a.part[(int64_t)r * a.ld + c], v1 = a.part[(int64_t)(r + RL) * a.ld + c];
+        const float v2 = a.part[(int64_t)(r + 2 * RL) * a.ld + c], v3 = a.part[(int64_t)(r + 3 * RL) * a.ld + c];
+        a0 += (double)v0; a1 += (double)v1; a2 += (double)v2; a3 += (double)v3;
+      }
+      // the (at most three) rows left go to the first chain in order: loaded together, rows past the end skipped
+      float t[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int rr = r + i * RL;
+        t[i] = a.part[(int64_t)(rr < a.rows ? rr : 0) * a.ld + c];
+      }
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        if (r + i * RL < a.rows) a0 += (double)t[i];
+      a0 += a2; a1 += a3;
+      if (ty == 0 && a.csum && c < a.G)
+        for (int ch = a.col_chunk_ptr[c]; ch < a.col_chunk_ptr[c + 1]; ++ch) a1 += (double)a.csum[ch];
+      x[k] = a0 + a1;
+    }
+    half[i8] = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+  }
+  a.out[c] = half[0] + half[1];
+}
+__device__ __forceinline__ void ca_yfin_row_block(const ca_yfin_args& a, int blk, double* sm) {
+  const int64_t n = (int64_t)blk * CA_TB + threadIdx.x;
+  double acc = 0.0;
+  if (n < a.N) {
+    double yw = 0.0;
+    for (int sg = 0; sg < a.nseg; ++sg) yw += (double)a.YWpart[(int64_t)sg * a.N + n];
+    a.YW[n] = (float)yw;
+    acc += (double)a.F[n * a.D] * yw;
+  }
+  const double r = ca_block_sum(acc, sm);
+  if (threadIdx.x == 0) a.yw_part[blk] = r;
+}
+
 // PCA init: scores of one pass, A[n][k] = sum_seg YWpart[seg][n][k] - c[k]
 __global__ void k_pca_rows(const float* __restrict__ YWpart, const double* __restrict__ c, float* __restrict__ A, int64_t N, int q,
                            int nseg) {
@@ -1319,6 +1383,13 @@ __device__ __forceinline__ void ca_final_small_body(const ca_small_args& sa) {
     if (threadIdx.x == 0) sa.red[0] = r;
     __threadfence_block();
     __syncthreads();
+  } else if (sa.yw_part) {   // second stage of a split tail: the cell partials are in red already (reduce_only stage on the backward
+    double ya = 0.0;         // sweep), the psi.(YW) partials were not there yet (they are made by extra blocks of that same launch)
+    for (int b = threadIdx.x; b < sa.n_yw; b += CA_TB) ya += sa.yw_part[b];
+    const double r = ca_block_sum(ya, sm);
+    if (threadIdx.x == 0) sa.red[0] += r;
+    __threadfence_block();
+    __syncthreads();
   }
   if (sa.reduce_only) return;   // (uniform) sharded runs: the ELBO is assembled after the all-reduce
   const int W_ = 3 + sa.K;
@@ -1369,6 +1440,22 @@ __device__ __forceinline__ void ca_split3(float x, unsigned short& p1, unsigned 
   p3 = ca_bf16_rn(x);
 }
 
+// Progress priority (lab, -DCA_PROG_PRIO=1|2): the SIMD's arbiter serves the OLDEST ready wave first, so of four co-resident sweep
+// blocks the first retires at 35 % of the round and the last runs alone at the end (tools/stamps.py).  A wave that lowers its own
+// priority as it advances (3 in its first quarter ... 0 in its last) hands the issue slots to the waves behind it.
+#ifdef CA_PROG_PRIO
+#define CA_PRIO_STEP(i, qstep)                                                   \
+  do {                                                                           \
+    if ((i) == 0) __builtin_amdgcn_s_setprio(3);                                  \
+    else if ((i) == (qstep)) __builtin_amdgcn_s_setprio(2);                       \
+    else if ((i) == 2 * (qstep)) __builtin_amdgcn_s_setprio(1);                   \
+    else if ((i) == 3 * (qstep)) __builtin_amdgcn_s_setprio(0);                   \
+  } while (0)
+#define CA_PRIO_DONE() __builtin_amdgcn_s_setprio(CA_PROG_PRIO == 2 ? 3 : 0)
+#else
+#define CA_PRIO_STEP(i, qstep) do { } while (0)
+#define CA_PRIO_DONE() do { } while (0)
+#endif
 #ifndef CA_BWD_TL
 #define CA_BWD_TL 4   // gene tiles of 16 per wave in the backward sweep
 #endif
@@ -1388,10 +1475,30 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
                                                     const float* __restrict__ Vs, const float* __restrict__ V,
                                                     float* __restrict__ gpart /*[csplit][G][S+DD]*/, float* __restrict__ dFpart /*[gridDim.x][N][DD]*/,
                                                     int64_t N, int G, int64_t cchunk, int S, int sidx, int first_s, int first,
-                                                    ca_small_args tail, int xblocks) {
+                                                    ca_small_args tail, int yblocks, ca_yfin_args yfin) {
   extern __shared__ float ca_lds[];   // [4 waves][cchunk][DD]: per-wave d/dF of the block's cell slice, summed at the end
-  if ((int)blockIdx.x >= xblocks) {   // the extra block column: its first block assembles the pending monitor pass's ELBO
-    if (blockIdx.y == 0 && tail.enabled) ca_final_small_body(tail);   // (130 us of sweep to hide its fp64 chains under)
+  // Extra block ROWS behind the sweep's own (blockIdx.y >= yblocks), so that they are dispatched LAST: the sweep's grid is exactly one
+  // resident round, and extra blocks anywhere earlier in the dispatch order -- even ones that return at once -- take the first slots
+  // of sweep blocks that then start late and finish 30 us after the rest (cfg-3: 145 -> 177 us).  Behind the sweep they get the
+  // slots of the first blocks to retire, a third of the way through.
+  if ((int)blockIdx.y >= yblocks) {   // the first of them assembles the pending monitor pass's ELBO (its fp64 chains hide under the sweep)
+    const int e = ((int)blockIdx.y - yblocks) * (int)gridDim.x + (int)blockIdx.x;
+    if (e == 0) { if (tail.enabled) ca_final_small_body(tail); return; }
+    // ... the others finish the riding count-matrix stream's two products (ca_yfin_args).  At raised priority: the SIMD's arbiter
+    // serves the oldest wave first, and beside sweep waves that are older and never short of instructions these few loads and adds
+    // took 30 us to get through -- holding the slots of sweep blocks that then started that much later (cfg-3: sweep 145 -> 175 us)
+    __builtin_amdgcn_s_setprio(3);
+    const int ncolblk = (yfin.ncol + CA_TB / 64 - 1) / (CA_TB / 64);
+#ifdef CA_LAB_YFIN   // (timing lab: 1 = column jobs only, 2 = row jobs only, 3 = the extra blocks do nothing)
+    if (CA_LAB_YFIN == 3 || (CA_LAB_YFIN == 1 && e - 1 >= ncolblk) || (CA_LAB_YFIN == 2 && e - 1 < ncolblk)) return;
+#endif
+    if (e - 1 < ncolblk) {
+      const int job = (e - 1) * (CA_TB / 64) + (int)(threadIdx.x >> 6);
+      if (job < yfin.ncol) ca_yfin_col_wave(yfin, job);
+    } else if (e - 1 - ncolblk < yfin.nrow) {
+      __shared__ double ca_yfin_sm[CA_TB / 64];
+      ca_yfin_row_block(yfin, e - 1 - ncolblk, ca_yfin_sm);
+    }
     return;
   }
   const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
@@ -1471,7 +1578,11 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
     for (int d = 0; d < DD; ++d) fc_r[d_][d] = F[(bl + j) * DD + d];
     ec_r[d_] = etamax2[bl + j];
   }
+  [[maybe_unused]] const int prio_q = (int)(((n1 - n0 + 16 * PD - 1) / (16 * PD) + 3) / 4);
+  [[maybe_unused]] int prio_i = 0;
   for (int64_t b00 = n0; active && b00 < n1; b00 += 16 * PD) {
+  CA_PRIO_STEP(prio_i, prio_q);
+  ++prio_i;
 #pragma unroll
   for (int d_ = 0; d_ < PD; ++d_) {
     const int64_t b0 = b00 + 16 * d_;
@@ -1521,6 +1632,7 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
     }   // b0 < n1
   }     // ring slot
   }
+  CA_PRIO_DONE();
   __syncthreads();
   const int64_t wstride = cchunk * DD;
   for (int64_t i = threadIdx.x; i < (n1 - n0) * DD; i += CA_TB) {
@@ -2201,7 +2313,11 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
     const int k0 = wv + 4 * s_;
     fetch(s_, k0 < nk ? k0 : (nk - 1));
   }
+  [[maybe_unused]] const int prio_q = ((nk - wv + 4 * PF - 1) / (4 * PF) + 3) / 4;
+  [[maybe_unused]] int prio_i = 0;
   for (int ks0 = wv; ks0 < nk; ks0 += 4 * PF) {
+  CA_PRIO_STEP(prio_i, prio_q);
+  ++prio_i;
 #pragma unroll
   for (int s_ = 0; s_ < PF; ++s_) {
     const int ks = ks0 + 4 * s_;
@@ -2237,6 +2353,7 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
     }   // ks < nk
   }     // ring slot
   }
+  CA_PRIO_DONE();
 #pragma unroll
   for (int t = 0; t < TL; ++t) comb[(wv * TL + t) * 64 + lane] = acc[t];
   __syncthreads();

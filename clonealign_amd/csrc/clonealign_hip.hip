@@ -151,6 +151,9 @@ struct ca_engine {
   double *gene_part_alt = nullptr, *gene_partB_alt = nullptr;
   bool bwd_ready = false; int64_t bwd_slot = -1;
   double* yw_part = nullptr; int n_yw = 0;   // block partials of sum_n psi_n.(YW)_n (k_yw_dot)
+  // the riding int8 stream without a finisher launch between the sweeps: its two finishing sums ride on the backward sweep as extra
+  // blocks (ca_yfin_args); until that sweep is issued they are pending, and any other consumer gets the launch (yfin_flush)
+  bool yfin_split = false, yfin_pending = false;
   ca_small_args mon_tail;          // pending ELBO assembly of a fused monitor pass: rides on the next backward sweep
   bool tail_fuse = true;
   double* host_dev = nullptr;      // device view of host_pinned
@@ -482,6 +485,7 @@ int refresh_derived(ca_engine* h) {
     LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_etamax, dim3(cdiv(h->N, CA_TB)), dim3(CA_TB), 0, h->stream, h->F, h->vmm, h->etamax2, h->N, h->D));
   }
   h->ycache_valid = false;
+  h->yfin_pending = false;
   h->look_valid = false;
   return CA_OK;
 }
@@ -579,12 +583,31 @@ ca_ovf_args ys_ovf(ca_engine* h) {
 }
 // finisher of the one-copy stream: the vector stream's own (k_yfinish) over the float partial slabs the stream left; advances
 // the quantiser's slot ring
-int ys_finish(ca_engine* h) {
+int yfin_flush(ca_engine* h) {
+  if (!h->yfin_pending) return CA_OK;
+  h->yfin_pending = false;
   const int nb_col = cdiv((int64_t)h->Gp, 64);
   LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_yfinish, dim3(nb_col + h->n_yw), dim3(1024), 0, h->stream, h->YTpart, h->red + h->off_y, h->ys_nrg,
                                                 (int64_t)h->Gp, h->Gp, h->n_ovf > 0 ? h->ovf_col_chunk_ptr : nullptr,
                                                 h->n_ovf > 0 ? h->ovf_csum : nullptr, 1, h->G, nb_col, h->YWpart,
                                                 h->ys_nseg + (h->n_ovf > 0 ? 1 : 0), h->F, h->D, h->N, h->YW, h->yw_part));
+  return CA_OK;
+}
+// the same sums as extra blocks of the backward sweep (k_bwd_mfma)
+ca_yfin_args yfin_args(ca_engine* h) {
+  ca_yfin_args a;
+  memset(&a, 0, sizeof(a));
+  a.ncol = cdiv((int64_t)h->Gp, 64); a.nrow = h->n_yw;
+  a.part = h->YTpart; a.out = h->red + h->off_y; a.rows = h->ys_nrg; a.ld = h->Gp; a.cols = h->Gp; a.G = h->G;
+  if (h->n_ovf > 0) { a.col_chunk_ptr = h->ovf_col_chunk_ptr; a.csum = h->ovf_csum; }
+  a.YWpart = h->YWpart; a.nseg = h->ys_nseg + (h->n_ovf > 0 ? 1 : 0); a.F = h->F; a.D = h->D; a.N = h->N; a.YW = h->YW; a.yw_part = h->yw_part;
+  return a;
+}
+// the stream's slabs are complete (launch issued): finisher now, or left pending for the backward sweep that follows in the loop;
+// advances the quantiser's slot ring
+int ys_finish(ca_engine* h, bool defer = false) {
+  h->yfin_pending = true;
+  if (!defer) CACK(yfin_flush(h));
   h->ys_slot = (h->ys_slot + 1) % 3;
   h->ys_steps = 0;
   h->ys_quant_ready = false;
@@ -624,7 +647,8 @@ int ensure_ycache(ca_engine* h) {
     }
     return CA_OK;
   }
-  if (h->ycache_valid || h->K == 0) { h->ycache_valid = true; return CA_OK; }
+  if (h->ycache_valid || h->K == 0) { h->ycache_valid = true; return yfin_flush(h); }
+  h->yfin_pending = false;
   if (h->y_ys) return ycache_ys(h);
   if (h->y_mfma) return ycache_mfma(h);
   dim3 grid((unsigned)((int64_t)h->nrg * h->nseg));
@@ -857,6 +881,7 @@ int mon_tail_local_sums(ca_engine* h) {
 int flush_mon_tail(ca_engine* h) {
   if (!h->mon_tail.enabled) return CA_OK;
   CACK(wait_y(h, false));
+  if (h->mon_tail.yw_part) CACK(yfin_flush(h));
   if (is_sharded(h) && h->mon_tail.cell_part) {   // local sums, then the (3 + C)-double all-reduce of a monitor pass
     CACK(mon_tail_local_sums(h));
     CACK(allreduce(h, h->red, 3 + h->C));
@@ -880,21 +905,36 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
     // then carries them together with this pass's gene sums and the ELBO is assembled after it (k_final_gene's extra
     // block, or ca_run's flush).  Both need the Y stream's psi.(YW) partials: the side stream is awaited here, one
     // kernel later than the cell epilogue that used to need it.
+    // The riding count-matrix stream's finishing sums are further extra blocks of this launch.  The pending monitor tail needs one of
+    // them (the psi.(YW) partials), so it moves on to the per-gene kernel's extra block (train_update) when they ride here.
+    ca_yfin_args yfin;
+    memset(&yfin, 0, sizeof(yfin));
+    if (is_sharded(h)) CACK(yfin_flush(h));   // (sharded: the tail's local sums go into this pass's all-reduce, so they stay here)
+    if (h->yfin_pending) { yfin = yfin_args(h); h->yfin_pending = false; }
     ca_small_args bwd_tail = no_small_args();
+    bool split_tail = false;
     if (h->mon_tail.enabled && h->mon_tail.cell_part) {
       CACK(wait_y(h, false));   // the psi.(YW) partials; the column products may still be streaming beside this sweep
       bwd_tail = h->mon_tail;
       merged = is_sharded(h);
       if (merged) { bwd_tail.reduce_only = 1; bwd_tail.host_out = nullptr; }
+      // the psi.(YW) partials are being made by this very launch: the cell partials are reduced here, the rest of the tail
+      // (their sum, the assembly) follows on the per-gene kernel's extra block
+      split_tail = !merged && yfin.nrow > 0 && bwd_tail.yw_part != nullptr;
+      if (split_tail) { bwd_tail.reduce_only = 1; bwd_tail.host_out = nullptr; bwd_tail.yw_part = nullptr; }
     }
+    const int nextra = (bwd_tail.enabled || yfin.nrow) ? 1 + cdiv(yfin.ncol, CA_TB / 64) + yfin.nrow : 0;
+    const int yextra = cdiv(nextra, xb);   // extra block rows behind the sweep's
+    ca_yfin_args no_yfin;
+    memset(&no_yfin, 0, sizeof(no_yfin));
 #define CA_BWDM(DDV) do { if (h->c16) CA_BWDM_(DDV, false, true); else if (h->bwd_frac) CA_BWDM_(DDV, true, false); else CA_BWDM_(DDV, false, false); } while (0)
 #define CA_BWDM_(DDV, FRV, C16V)                                                                                            \
   LAUNCH(h, CA_KERNEL_BWD,                                                                                                 \
-         hipLaunchKernelGGL((k_bwd_mfma<TL, DDV, FRV, C16V>), dim3(xb + ((s == 0 && bwd_tail.enabled) ? 1 : 0), h->csplit_m), dim3(CA_TB), \
+         hipLaunchKernelGGL((k_bwd_mfma<TL, DDV, FRV, C16V>), dim3(xb, h->csplit_m + (s == 0 ? yextra : 0)), dim3(CA_TB), \
                             (size_t)h->cchunk_m * 4 * DDV * sizeof(float), h->stream,                                       \
                             h->coefq + (int64_t)s * h->N16 * 32, h->F, h->etamax2, h->Lb, mu32 + (int64_t)s * h->G, h->Vs,  \
                             h->V, h->gpart, h->dFpart, h->N, h->G, h->cchunk_m, h->S, s, 1, s == 0 ? 1 : 0,                 \
-                            s == 0 ? bwd_tail : no_small_args(), xb))
+                            s == 0 ? bwd_tail : no_small_args(), h->csplit_m, s == 0 ? yfin : no_yfin))
     for (int s = 0; s < h->S; ++s) {
       if (h->D == 1) CA_BWDM(1);
       else CA_BWDM(2);
@@ -903,6 +943,7 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
 #undef CA_BWDM_
     if (bwd_tail.enabled) {
       if (merged) { h->mon_tail.cell_part = nullptr; h->mon_tail.yw_part = nullptr; }   // local sums done; assembly still pending
+      else if (split_tail) h->mon_tail.cell_part = nullptr;
       else h->mon_tail.enabled = 0;
     }
     // (summing the sweep's partials inside k_final_gene instead -- one thread per gene, csplit_m loads in a row -- was
@@ -914,6 +955,7 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
                                 h->red + h->off_g, h->csplit_m, (int64_t)h->G * W_, h->G * W_));
   } else {
     h->fold_now = false;
+    CACK(yfin_flush(h));
     CACK(flush_mon_tail(h));
     for (int s = 0; s < h->S; ++s)
       for (int ch = 0; ch < h->nchunk; ++ch) {
@@ -953,6 +995,7 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
   // A pending monitor pass's ELBO is assembled by one extra block of the per-gene kernel (ca_final_small_body: the
   // reduction of the cell / psi.(YW) partials unless train_bwd did it for the all-reduce, then the assembly) BEFORE the
   // O(K + C) update, which rides on the per-cell kernel the same way.
+  CACK(yfin_flush(h));   // (nothing pending when a backward sweep preceded)
   ca_small_args mon = no_small_args();
   if (h->mon_tail.enabled) { mon = h->mon_tail; h->mon_tail.enabled = 0; }
   // psi's own step: extra blocks of the per-gene kernel (it needs the sweep's dF partials and YW, nothing per-gene)
@@ -1015,6 +1058,7 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
     h->b1p *= (float)h->opt.beta1;
     h->b2p *= (float)h->opt.beta2;
     h->ycache_valid = false;   // V', its range and etamax2 were refreshed inside the step's own kernels
+    h->yfin_pending = false;
     h->look_valid = false;
   }
   return CA_OK;
@@ -1143,7 +1187,7 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
     else CA_FCYS_D(2, CA_YS_RIDE_DEPTH);
 #undef CA_FCYS_D
 #undef CA_FCYS
-    CACK(ys_finish(h));
+    CACK(ys_finish(h, h->yfin_split && !is_sharded(h)));
   } else if (h->fwd_cell && ride) {   // ... and the Y stream's blocks interleaved with the sweep's in the same grid
     cell_blocks = h->ncblk_f;
     ca_yride_args ya;
@@ -1999,6 +2043,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   h->ride_seq = h->ride_ok && variant_on(h, CA_VAR_RIDE_SEQ, "CA_RIDE_SEQ") && (kRideSeqDefault || variantx_on(h, CA_VARX_RIDE_SEQ, "CA_RIDE_SEQ_ON"));
   h->ride_ys = h->y_ys && h->fused_ok && h->fwd_cell && (h->fc_tl == 6 || (h->fc_tl == 2 && h->fc_nbig == 0)) &&
                variant_on(h, CA_VAR_Y_RIDE, "CA_Y_RIDE");
+  h->yfin_split = h->ride_ys && h->bwd_mfma && h->tail_fuse && variant_on(h, CA_VAR_YFIN_RIDE, "CA_YFIN_RIDE");
   h->off_g = 3 + C;
   h->off_y = h->off_g + (int64_t)G * (S + D);
   h->red_n = h->off_y + (int64_t)G * K;

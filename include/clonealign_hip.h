@@ -94,6 +94,9 @@ enum ca_variant {
                                  through the transposing LDS read ds_read_b64_tr_b8 (ca_ymfma.hip.h; K = 1): the default since round 3, when its
                                  blocks ride on the forward sweep as long-lived stream blocks and its quantiser on the per-cell Adam kernel.
                                  Off: the vector stream (k_ypass / k_fwd_cell_mix_y) */
+  CA_VAR_YFIN_RIDE = 1 << 15, /* the riding int8 stream's finishing sums (Y^T psi column sums, YW and the psi.(YW) partials) as extra blocks of the
+                                 backward sweep's launch; the pending monitor pass's ELBO is then assembled one kernel later (per-gene kernel).
+                                 Off: a finisher launch (k_yfinish) between the two sweeps */
   CA_VAR_RIDE_SEQ = 1 << 13   /* off: the riding stream as blocks of its own interleaved in the sweep's grid (k_fwd_cell_mix_y), never fused in
                                  sequence into the sweep's blocks (k_fwd_cell_seq_y; see CA_VARX_RIDE_SEQ) */
 };

@@ -536,13 +536,16 @@ def test_riding_dispatch_order_does_not_change_a_single_bit(shape):
     epss = np.stack([eps_for(1, G, 300 + i) for i in range(10)])
     for stream in ("int8", "vector"):          # the default int8 matrix-core stream (y_mfma1) and the vector stream it replaced
       ref = None
-      for pat in (None, "1:1", "3:2", "16:8", "1:200", "255:1", -3, -64, "seq", "mixed"):
+      for pat in (None, "1:1", "3:2", "16:8", "1:200", "255:1", -3, -64, "seq", "mixed", "fin"):
         # (negative: that many long-lived stream blocks lead the grid.  "seq" / "mixed", vector stream only: fused in sequence into the
-        #  sweep's own blocks, k_fwd_cell_seq_y, or as blocks of their own in the same grid, k_fwd_cell_mix_y)
-        if stream == "int8" and pat in ("seq", "mixed"):
+        #  sweep's own blocks, k_fwd_cell_seq_y, or as blocks of their own in the same grid, k_fwd_cell_mix_y.  "fin", int8 stream only:
+        #  the stream's finishing sums as a launch of their own between the sweeps, k_yfinish, instead of extra blocks of the backward
+        #  sweep -- the same additions in the same order, and the monitor pass's ELBO assembled in one stage instead of two)
+        if (stream == "int8" and pat in ("seq", "mixed")) or (stream == "vector" and pat == "fin"):
             continue
         voff = () if stream == "int8" else ("y_mfma1",)
         kw = (dict(variant_on=("ride_seq",), variant_off=voff) if pat == "seq" else dict(variant_off=voff + ("ride_seq",)) if pat == "mixed" else
+              dict(variant_off=voff + ("yfin_ride",)) if pat == "fin" else
               dict(variant_off=voff, tune=({} if pat is None else {"ride_pattern": pat})))
         eng = HipEngine(**case, **kw)
         try:
