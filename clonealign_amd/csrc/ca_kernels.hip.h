@@ -1410,15 +1410,18 @@ __device__ __forceinline__ void ca_final_small_body(const ca_small_args& sa) {
     if (threadIdx.x == 0) gs[j] = r;
   }
   // range of the updated V' over the gene blocks (k_vmm_final folded in)
-  if (sa.apply && sa.vmm_part && (int)threadIdx.x < sa.D) {
-    const int d = threadIdx.x;
-    float mn = INFINITY, mx2 = -INFINITY;
-    for (int b = 0; b < sa.ngblk; ++b) {
-      mn = fminf(mn, sa.vmm_part[((int64_t)b * 2 + 0) * sa.D + d]);
-      mx2 = fmaxf(mx2, sa.vmm_part[((int64_t)b * 2 + 1) * sa.D + d]);
+  if (sa.apply && sa.vmm_part && threadIdx.x >= CA_TB - 64) {   // the last wave: a lane per gene block, then butterflies
+    const int ln = threadIdx.x & 63;
+    for (int d = 0; d < sa.D; ++d) {
+      float mn = INFINITY, mx2 = -INFINITY;
+      for (int b = ln; b < sa.ngblk; b += 64) {
+        mn = fminf(mn, sa.vmm_part[((int64_t)b * 2 + 0) * sa.D + d]);
+        mx2 = fmaxf(mx2, sa.vmm_part[((int64_t)b * 2 + 1) * sa.D + d]);
+      }
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { mn = fminf(mn, __shfl_xor(mn, o, 64)); mx2 = fmaxf(mx2, __shfl_xor(mx2, o, 64)); }
+      if (ln == 0) { sa.vmm[d] = mn; sa.vmm[sa.D + d] = mx2; }
     }
-    sa.vmm[d] = mn;
-    sa.vmm[sa.D + d] = mx2;
   }
   __syncthreads();
   if (threadIdx.x < 64) ca_final_small_wave0(sa, gs);
@@ -2597,7 +2600,14 @@ __device__ __forceinline__ void ca_psi_adam_body(const ca_psi_args& a, int blk, 
   if (n >= a.N) return;
   for (int k = 0; k < a.K; ++k) {
     double dF = 0.0;
-    for (int t = 0; t < a.ntile; ++t) dF += (double)a.dFpart[((int64_t)t * a.N + n) * a.D + k];
+    for (int t0 = 0; t0 < a.ntile; t0 += 10) {   // ten loads in flight (a plain loop waits for each: 20 L2 round trips), added in tile order
+      float v[10];
+#pragma unroll
+      for (int i = 0; i < 10; ++i) v[i] = a.dFpart[((int64_t)(t0 + i < a.ntile ? t0 + i : a.ntile - 1) * a.N + n) * a.D + k];
+#pragma unroll
+      for (int i = 0; i < 10; ++i)
+        if (t0 + i < a.ntile) dF += (double)v[i];
+    }
     const float gp = (float)((double)a.YW[n * a.K + k] + dF - (double)a.F[n * a.D + k]);
     a.g_psi[n * a.K + k] = gp;
     if (apply) {
@@ -2626,8 +2636,22 @@ __device__ __forceinline__ void ca_final_gene_body(const double* __restrict__ re
   // small problems: the backward sweep's cell-split partials are summed here (fixed order, fp64) instead of by a k_colsum
   // launch of their own -- one launch and its gap less per iteration where launches are what an iteration costs
   // (computed where it is used, once per column: an indexed local array would live in scratch memory)
+  double rg2[2] = {0.0, 0.0};
+  const bool two = gfold && W_ == 2;   // the common case (one sample, one latent dimension): both columns from one 8-byte load, twenty
+  if (two) {                            // slices in flight -- two dependent rounds at 38 slices instead of ten (5 us of this kernel's 8)
+    for (int sp0 = 0; sp0 < nfold; sp0 += 20) {
+      float2 v[20];
+#pragma unroll
+      for (int i = 0; i < 20; ++i)
+        v[i] = *reinterpret_cast<const float2*>(gfold + ((int64_t)(sp0 + i < nfold ? sp0 + i : nfold - 1) * G + g) * 2);
+#pragma unroll
+      for (int i = 0; i < 20; ++i)
+        if (sp0 + i < nfold) { rg2[0] += (double)v[i].x; rg2[1] += (double)v[i].y; }
+    }
+  }
   auto rgv = [&](int w) -> double {
     if (!gfold) return red_g[(int64_t)g * W_ + w];
+    if (two) return w == 0 ? rg2[0] : rg2[1];
     double a = 0.0;
     for (int sp0 = 0; sp0 < nfold; sp0 += 8) {   // eight loads in flight, added in slice order
       float v[8];
@@ -2707,15 +2731,20 @@ __global__ void __launch_bounds__(CA_TB) k_final_gene(const double* __restrict__
                                                       float* __restrict__ Vs, float* __restrict__ vmm_part,
                                                       int G, int S, int D, int K, int apply, float lr_t, float b1, float b2, float aeps, ca_small_args mon, int gblocks,
                                                       ca_psi_args psi, const float* __restrict__ gfold, int nfold) {
+#ifndef CA_LAB_SKIP
+#define CA_LAB_SKIP 0   // (timing lab, results WRONG: bit 0 monitor block, 1 psi blocks, 2 gene blocks of k_final_gene; 3 small block, 4 prologue
+#endif                  //  blocks, 5 quantiser blocks, 6 cell blocks of k_adam_cell return at once)
   if ((int)blockIdx.x >= gblocks) {
     int b = (int)blockIdx.x - gblocks;
     if (mon.enabled) {   // one extra block: the pending monitor pass's ELBO (ca_final_small_body), beside the gene blocks
-      if (b == 0) { ca_final_small_body(mon); return; }
+      if (b == 0) { if (!(CA_LAB_SKIP & 1)) ca_final_small_body(mon); return; }
       --b;
     }
+    if (CA_LAB_SKIP & 2) return;
     if (b < psi.nblk) ca_psi_adam_body(psi, b, apply, lr_t, b1, b2, aeps);
     return;
   }
+  if (CA_LAB_SKIP & 4) return;
   __shared__ float smin[CA_TB], smax[CA_TB];
   ca_final_gene_body(red_g, red_y, eps, colsum, YtX, vchi, loc, ls, V, m_loc, v_loc, m_ls, v_ls, m_V, v_V, g_loc, g_ls, g_V, Vs, vmm_part, G, S, D, K,
                      apply, lr_t, b1, b2, aeps, smin, smax, gfold, nfold);
@@ -2739,12 +2768,15 @@ __global__ void __launch_bounds__(CA_TB) k_adam_cell(const float* __restrict__ F
   // the int8 count-matrix stream (ca_ys_quant_body), when that stream is in use: W and psi are final once k_final_gene has run.
   const int nx = pre.nblk + 1;
   if ((int)blockIdx.x >= nx + cblocks) {
+    if (CA_LAB_SKIP & 32) return;
     __shared__ float smq[2 * (CA_YM_TB / 64)];
     ca_ys_quant_body((int)blockIdx.x - nx - cblocks, ysq, smq);
     return;
   }
   if ((int)blockIdx.x < nx) {
     const int b = (int)blockIdx.x;
+    if ((CA_LAB_SKIP & 16) && b < pre.nblk) return;
+    if ((CA_LAB_SKIP & 8) && b >= pre.nblk) return;
     if (b < pre.nblk) {   // the next eps pair's per-gene prologue (ca_pre_args)
       __shared__ double smp[CA_TB];
       ca_gene_pre_fused_body(pre.loc, pre.ls, pre.epsA, pre.epsB, pre.colsum, pre.Lb, pre.V, pre.D, pre.K, pre.YtX, pre.muA, pre.muB, pre.Mb,
@@ -2756,6 +2788,7 @@ __global__ void __launch_bounds__(CA_TB) k_adam_cell(const float* __restrict__ F
   }
   const int cblk = (int)blockIdx.x - nx;   // cell block
   (void)cblocks;
+  if (CA_LAB_SKIP & 64) return;
   // q(z) logits: an elementwise step over the flat [N * C] arrays, 16 bytes per lane (a lane per cell would fetch C
   // strided floats per array: 2.4 TB/s at 100k x 8)
   if (apply) {
@@ -2784,15 +2817,17 @@ __global__ void __launch_bounds__(CA_TB) k_adam_cell(const float* __restrict__ F
   }
   // range of the updated V' over the gene blocks, per block (k_vmm_final folded in: same min / max as the extra block's)
   __shared__ float vmm[2 * 8];
-  if (apply && D > 0 && D <= 8 && (int)threadIdx.x < D) {
-    const int d = threadIdx.x;
-    float mn = INFINITY, mx = -INFINITY;
-    for (int b = 0; b < ngblk; ++b) {
-      mn = fminf(mn, vmm_part[((int64_t)b * 2 + 0) * D + d]);
-      mx = fmaxf(mx, vmm_part[((int64_t)b * 2 + 1) * D + d]);
+  if (apply && D > 0 && D <= 8 && (int)threadIdx.x < 64) {   // wave 0: a lane per gene block, then butterflies (min / max: any order)
+    for (int d = 0; d < D; ++d) {
+      float mn = INFINITY, mx = -INFINITY;
+      for (int b = threadIdx.x; b < ngblk; b += 64) {
+        mn = fminf(mn, vmm_part[((int64_t)b * 2 + 0) * D + d]);
+        mx = fmaxf(mx, vmm_part[((int64_t)b * 2 + 1) * D + d]);
+      }
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
+      if (threadIdx.x == 0) { vmm[d] = mn; vmm[D + d] = mx; }
     }
-    vmm[d] = mn;
-    vmm[D + d] = mx;
   }
   __syncthreads();
   const int64_t n = (int64_t)cblk * CA_TB + threadIdx.x;
