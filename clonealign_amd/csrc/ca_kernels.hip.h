@@ -1505,7 +1505,7 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
     return;
   }
   const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
-  const int wv = threadIdx.x >> 6;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (scalar: the slice's bounds and the loop's branches then are)
   const int wtile = blockIdx.x * (CA_TB / 64) + wv;
   const int gbase = wtile * TL * 16;
   const bool active = gbase < G;
@@ -1568,39 +1568,46 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
   // The operands of the next PD batches are in flight while the current one is in the pipes (cell arrays padded to 16): a
   // batch is 380 issue cycles = 0.6 us of wall time at three waves per SIMD, one batch of look-ahead left the wave parked on
   // s_waitcnt for 31 % of its cycles (SQ_WAIT_ANY, profiles/r01_v11_sq_counters.json) and far more beside an HBM stream.
+  // Indices are 32-bit and relative to the slice, bases are the slice's (uniform) and lane offsets 32-bit: the loads take the
+  // scalar-base form and the loop's compares are scalar -- with 64-bit cell indices every batch paid four 64-bit adds, three
+  // 64-bit compares and their moves on the VALU, 14 of its 84 issue slots (round 3, from the ISA).
   constexpr int PD = CA_BWD_PD;
   const int qc = (FRAC && q == 2) ? 0 : q;   // which part of coef this lane group carries (FRAC: c1, c2, c1 again)
+  const int len = active ? (int)(n1 - n0) : 0;
+  const unsigned short* cqb = cq + n0 * 32;
+  const float* Fb = F + n0 * DD;
+  const float* eb = etamax2 + n0;
+  const unsigned lo_c = (unsigned)((j * 4 + qc) * 8), lo_f = (unsigned)(j * DD), lo_e = (unsigned)j;
+  const int jl = len - j;                    // cell r + j is inside the slice iff r < jl
+  float* myd_lane = myd + j * DD;
   uint4 craw_r[PD];
   float fc_r[PD][DD], ec_r[PD];
+  auto fetch = [&](int slot, int r) {        // r: uniform, a multiple of 16, inside the padded arrays
+    const unsigned short* pc = cqb + (int64_t)r * 32;
+    const float* pf = Fb + (int64_t)r * DD;
+    const float* pe = eb + r;
+    craw_r[slot] = *reinterpret_cast<const uint4*>(pc + lo_c);
 #pragma unroll
-  for (int d_ = 0; d_ < PD; ++d_) {
-    const int64_t bb = n0 + 16 * d_;
-    const int64_t bl = (active && bb < n1) ? bb : (N > 0 ? ((n0 < N) ? n0 : 0) : 0);   // past the slice: re-read its first batch (never used)
-    craw_r[d_] = *reinterpret_cast<const uint4*>(cq + ((bl + j) * 4 + qc) * 8);
+    for (int d = 0; d < DD; ++d) fc_r[slot][d] = pf[lo_f + d];
+    ec_r[slot] = pe[lo_e];
+  };
 #pragma unroll
-    for (int d = 0; d < DD; ++d) fc_r[d_][d] = F[(bl + j) * DD + d];
-    ec_r[d_] = etamax2[bl + j];
-  }
-  [[maybe_unused]] const int prio_q = (int)(((n1 - n0 + 16 * PD - 1) / (16 * PD) + 3) / 4);
+  for (int d_ = 0; d_ < PD; ++d_) fetch(d_, 16 * d_ < len ? 16 * d_ : 0);   // past the slice: re-read its first batch (never used)
+  [[maybe_unused]] const int prio_q = ((len + 16 * PD - 1) / (16 * PD) + 3) / 4;
   [[maybe_unused]] int prio_i = 0;
-  for (int64_t b00 = n0; active && b00 < n1; b00 += 16 * PD) {
+  for (int r00 = 0; r00 < len; r00 += 16 * PD) {
   CA_PRIO_STEP(prio_i, prio_q);
   ++prio_i;
 #pragma unroll
   for (int d_ = 0; d_ < PD; ++d_) {
-    const int64_t b0 = b00 + 16 * d_;
-    if (b0 < n1) {   // wave-uniform
+    const int r0 = r00 + 16 * d_;
+    if (r0 < len) {   // wave-uniform
     const uint4 craw = craw_r[d_];
     float fc[DD];
 #pragma unroll
     for (int d = 0; d < DD; ++d) fc[d] = fc_r[d_][d];
     const float ec = ec_r[d_];
-    if (b0 + 16 * PD < n1) {
-      craw_r[d_] = *reinterpret_cast<const uint4*>(cq + ((b0 + 16 * PD + j) * 4 + qc) * 8);
-#pragma unroll
-      for (int d = 0; d < DD; ++d) fc_r[d_][d] = F[(b0 + 16 * PD + j) * DD + d];
-      ec_r[d_] = etamax2[b0 + 16 * PD + j];
-    }
+    if (r0 + 16 * PD < len) fetch(d_, r0 + 16 * PD);
     const ca_bf16x8 Cf = __builtin_bit_cast(ca_bf16x8, craw);
     ca_f32x2 dF[DD];
 #pragma unroll
@@ -1608,7 +1615,7 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
 #pragma unroll
     for (int m = 0; m < TL; ++m) {
       ca_f32x4 t = {0.f, 0.f, 0.f, 0.f};
-      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Lf[m], Cf, t, 0, 0, 0);   // t[r]: gene gbase+16m+4q+r, cell b0+j
+      t = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Lf[m], Cf, t, 0, 0, 0);   // t[r]: gene gbase+16m+4q+r, cell n0+r0+j
       const ca_f32x2 t2[2] = {{t[0], t[1]}, {t[2], t[3]}};
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
@@ -1625,14 +1632,13 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
         }
       }
     }
-    const int64_t n = b0 + j;
 #pragma unroll
     for (int d = 0; d < DD; ++d) {
       float dd = dF[d].x + dF[d].y;
       dd = ca_sum_xor16_32(dd);   // over the four lane groups q (v_permlane16/32_swap: no LDS round trip, no lgkmcnt wait per batch)
-      if (q == 0 && n < n1) myd[(n - n0) * DD + d] = dd;
+      if (q == 0 && r0 < jl) myd_lane[r0 * DD + d] = dd;
     }
-    }   // b0 < n1
+    }   // r0 < len
   }     // ring slot
   }
   CA_PRIO_DONE();

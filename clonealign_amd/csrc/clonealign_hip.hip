@@ -1832,8 +1832,11 @@ int create_impl(ca_engine* h, const ca_problem* p) {
       h->csplit_m = (int)std::max<int64_t>(h->csplit_m, (Nn * D + 4079) / 4080);   // LDS: 4 waves x cchunk x D floats <= 64 KB
       h->cchunk_m = ((Nn + h->csplit_m - 1) / h->csplit_m + 15) / 16 * 16;
       h->csplit_m = cdiv(Nn, h->cchunk_m);
-      // launches, not bandwidth, are what an iteration costs below ~32k cells: fold the column sums of the sweep's partials
-      h->fold_gsum = (Nn <= 32768 || variantx_on(h, CA_VARX_FOLD_ALWAYS, "CA_FOLD_ALWAYS")) && S + D <= 12 && h->tail_fuse &&
+      // fold the column sums of the sweep's partials into the per-gene kernel: a launch and its gap less.  Up to 32k cells in round 2
+      // (the fold's loads went out eight at a time, one column after the other: slower than the k_colsum launch above that);
+      // with both columns from one load and twenty slices in flight it is level or ahead wherever the slice count is the one
+      // resident round (cfg-3 +0.3 %, 50k cells +0.6 %, 200k +0.2 %); long shards with many more slices keep the launch
+      h->fold_gsum = (Nn <= 32768 || (h->csplit_m <= 64 && S + D == 2) || variantx_on(h, CA_VARX_FOLD_ALWAYS, "CA_FOLD_ALWAYS")) && S + D <= 12 && h->tail_fuse &&
                      variant_on(h, CA_VAR_FOLD_GSUM, "CA_FOLD_GSUM");
       CACK(dalloc(h, &h->coefq, (int64_t)S * h->N16 * 32));
     }
