@@ -1598,9 +1598,12 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
   for (int r00 = 0; r00 < len; r00 += 16 * PD) {
   CA_PRIO_STEP(prio_i, prio_q);
   ++prio_i;
+  [[maybe_unused]] float ddv[PD][DD];
 #pragma unroll
   for (int d_ = 0; d_ < PD; ++d_) {
     const int r0 = r00 + 16 * d_;
+#pragma unroll
+    for (int d = 0; d < DD; ++d) ddv[d_][d] = 0.f;
     if (r0 < len) {   // wave-uniform
     const uint4 craw = craw_r[d_];
     float fc[DD];
@@ -1612,17 +1615,28 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
     ca_f32x2 dF[DD];
 #pragma unroll
     for (int d = 0; d < DD; ++d) dF[d] = (ca_f32x2){0.f, 0.f};
-    // all of the batch's matrix-core products first: issued one by one in front of their consumers (the compiler's order) each was
-    // waited for with s_nop (22 idle issue cycles per batch, and only three waves per SIMD to fill them; cfg-3 3570 -> 3665 it/s)
+    // The batch's matrix-core products are issued AHEAD of their consumers: in the compiler's order each sat right in front of its
+    // consumer and was waited for with s_nop (22 idle issue cycles per batch, and only three waves per SIMD to fill them; cfg-3
+    // 3570 -> 3665 it/s).  CA_BWD_AHEAD products in flight: all four (default), or two with the next one issued as one is consumed.
+#ifndef CA_BWD_AHEAD
+#define CA_BWD_AHEAD TL
+#endif
+    constexpr int AH = CA_BWD_AHEAD < TL ? CA_BWD_AHEAD : TL;
     ca_f32x4 tt[TL];
 #pragma unroll
-    for (int m = 0; m < TL; ++m) {
+    for (int m = 0; m < AH; ++m) {
       tt[m] = (ca_f32x4){0.f, 0.f, 0.f, 0.f};
       tt[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Lf[m], Cf, tt[m], 0, 0, 0);   // tt[m][r]: gene gbase+16m+4q+r, cell n0+r0+j
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int m = 0; m < TL; ++m) {
+      if constexpr (AH < TL) {
+        if (m + AH < TL) {
+          tt[m + AH] = (ca_f32x4){0.f, 0.f, 0.f, 0.f};
+          tt[m + AH] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Lf[m + AH], Cf, tt[m + AH], 0, 0, 0);
+        }
+      }
       const ca_f32x4 t = tt[m];
       const ca_f32x2 t2[2] = {{t[0], t[1]}, {t[2], t[3]}};
 #pragma unroll
@@ -1639,15 +1653,35 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
           dF[d] = u * mv[m][h][d] + dF[d];
         }
       }
+      if constexpr (AH < TL) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int d = 0; d < DD; ++d) {
       float dd = dF[d].x + dF[d].y;
-      dd = ca_sum_xor16_32(dd);   // over the four lane groups q (v_permlane16/32_swap: no LDS round trip, no lgkmcnt wait per batch)
-      if (q == 0 && r0 < jl) myd_lane[r0 * DD + d] = dd;
+      if constexpr (PD == 2) {
+        ddv[d_][d] = dd;
+      } else {
+        dd = ca_sum_xor16_32(dd);   // over the four lane groups q (v_permlane16/32_swap: no LDS round trip, no lgkmcnt wait per batch)
+        if (q == 0 && r0 < jl) myd_lane[r0 * DD + d] = dd;
+      }
     }
     }   // r0 < len
   }     // ring slot
+  if constexpr (PD == 2) {
+    // d/dF of the ring's two batches, summed over the four lane groups q TOGETHER: one v_permlane16_swap exchanges the odd rows of
+    // batch 0 with the even rows of batch 1, so one add gives (q0 + q1), (q2 + q3) of both; the 32-lane swap then finishes both.
+    // Rows 0 / 1 end up with batch 0 / 1: lane l < 32 holds cell r00 + l.  Same additions in the same order as one batch at a
+    // time (ca_sum_xor16_32), half the swaps and adds, one LDS write instead of two.
+    typedef unsigned v2u __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int d = 0; d < DD; ++d) {
+      v2u r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ddv[0][d]), __float_as_uint(ddv[1][d]), false, false);
+      const float c = __uint_as_float(r.x) + __uint_as_float(r.y);
+      r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c), __float_as_uint(c), false, false);
+      const float tot = __uint_as_float(r.x) + __uint_as_float(r.y);
+      if (lane < 32 && r00 + lane < len) myd[(r00 + lane) * DD + d] = tot;
+    }
+  }
   }
   CA_PRIO_DONE();
   __syncthreads();
