@@ -1443,10 +1443,18 @@ __device__ __forceinline__ void ca_split3(float x, unsigned short& p1, unsigned 
   p3 = ca_bf16_rn(x);
 }
 
-// Progress priority (lab, -DCA_PROG_PRIO=1|2): the SIMD's arbiter serves the OLDEST ready wave first, so of four co-resident sweep
-// blocks the first retires at 35 % of the round and the last runs alone at the end (tools/stamps.py).  A wave that lowers its own
-// priority as it advances (3 in its first quarter ... 0 in its last) hands the issue slots to the waves behind it.
-#ifdef CA_PROG_PRIO
+// Progress priority (round 3).  The SIMD's arbiter serves the OLDEST ready wave first, so of the co-resident sweep blocks of a CU the
+// first retires at a third of the round and the last runs alone at the end, one wave per SIMD on an issue port that wants three
+// (tools/stamps.py: 4 x 96-cell blocks per CU end at 62 / 90 / 120 / 150 us).  A wave that lowers its own priority as it advances
+// (s_setprio 3 in its first quarter ... 0 in its last) hands the issue slots to the waves behind it, and the blocks of a round end
+// together.  The riding count-matrix stream's waves (HBM-bound, few instructions) and the finisher's extra blocks stay at 3.
+// CA_PROG_PRIO: 0 off, 1 on, 2 on and the phase after the loop (accumulator combine, cell epilogue / partial writes) back at 3.
+// Measured: neutral while the backward sweep still waited on its matrix-core products and 64-bit index arithmetic (3150 vs 3141 it/s),
+// +3.6 % after those were gone (98 304 cells: 3683 -> 3816 it/s; profiles/r03_ab_ystream.txt section 15).
+#ifndef CA_PROG_PRIO
+#define CA_PROG_PRIO 2
+#endif
+#if CA_PROG_PRIO
 #define CA_PRIO_STEP(i, qstep)                                                   \
   do {                                                                           \
     if ((i) == 0) __builtin_amdgcn_s_setprio(3);                                  \
@@ -1455,9 +1463,11 @@ __device__ __forceinline__ void ca_split3(float x, unsigned short& p1, unsigned 
     else if ((i) == 3 * (qstep)) __builtin_amdgcn_s_setprio(0);                   \
   } while (0)
 #define CA_PRIO_DONE() __builtin_amdgcn_s_setprio(CA_PROG_PRIO == 2 ? 3 : 0)
+#define CA_PRIO_STREAM() __builtin_amdgcn_s_setprio(3)
 #else
 #define CA_PRIO_STEP(i, qstep) do { } while (0)
 #define CA_PRIO_DONE() do { } while (0)
+#define CA_PRIO_STREAM() do { } while (0)
 #endif
 #ifndef CA_BWD_TL
 #define CA_BWD_TL 4   // gene tiles of 16 per wave in the backward sweep
@@ -2328,7 +2338,8 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
   // C16 (round 3): 9..16 clones.  The sixteen operand columns then belong to ONE draw (clones 0..15) instead of two draws of up to
   // eight clones, the epilogue works with sixteen lanes per cell, and monitor and train passes each take a sweep of their own.
   constexpr int CP = C16 ? 16 : 8;         // lanes per cell in the epilogue
-  const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (scalar: the k-loop's bounds, branches and operand bases then are)
   float f[TL][D], em[TL];
   ca_f32x4 acc[TL];
 #pragma unroll
@@ -2346,46 +2357,30 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
   const ca_bf16x2 neg_lo = __builtin_bit_cast(ca_bf16x2, m0), neg_hi = __builtin_bit_cast(ca_bf16x2, m1);
   const uint4* Bq = reinterpret_cast<const uint4*>(Mq);
   constexpr int NV4 = 2 * D;   // float4 per lane and k-step: V'[8 genes][D]
-#ifndef CA_FWD_PF
-#define CA_FWD_PF 1   // k-steps of operands in flight per wave
-#endif
-  constexpr int PF = CA_FWD_PF;
-  uint4 b1r[PF], b2r[PF];
-  float4 vr[PF][NV4];
-  auto fetch = [&](int slot, int ks) {
-    b1r[slot] = Bq[(int64_t)ks * 128 + lane];
-    b2r[slot] = Bq[(int64_t)ks * 128 + 64 + lane];
+  // One k-step of operands in flight, in TWO register sets used alternately (the loop runs two k-steps per trip): the step at hand
+  // reads its set in place while the next one's loads land in the other.  With one set the operands had to be copied out before the
+  // refill was issued -- 12 moves per k-step on the issue port the sweep is bound by.
+  uint4 b1r[2], b2r[2];
+  float4 vr[2][NV4];
+  auto fetch = [&](int set, int ks) {
+    const uint4* bp = Bq + (int64_t)ks * 128;
+    b1r[set] = bp[lane];
+    b2r[set] = bp[64 + lane];
     const float4* vp = reinterpret_cast<const float4*>(Vs + ((int64_t)ks * 32 + 8 * q) * D);
 #pragma unroll
-    for (int i = 0; i < NV4; ++i) vr[slot][i] = vp[i];
+    for (int i = 0; i < NV4; ++i) vr[set][i] = vp[i];
   };
-#pragma unroll
-  for (int s_ = 0; s_ < PF; ++s_) {
-    const int k0 = wv + 4 * s_;
-    fetch(s_, k0 < nk ? k0 : (nk - 1));
-  }
-  [[maybe_unused]] const int prio_q = ((nk - wv + 4 * PF - 1) / (4 * PF) + 3) / 4;
-  [[maybe_unused]] int prio_i = 0;
-  for (int ks0 = wv; ks0 < nk; ks0 += 4 * PF) {
-  CA_PRIO_STEP(prio_i, prio_q);
-  ++prio_i;
-#pragma unroll
-  for (int s_ = 0; s_ < PF; ++s_) {
-    const int ks = ks0 + 4 * s_;
-    if (ks < nk) {   // wave-uniform
-    const ca_bf16x8 B1 = __builtin_bit_cast(ca_bf16x8, b1r[s_]), B2 = __builtin_bit_cast(ca_bf16x8, b2r[s_]);
-    float vf[8 * D];
-#pragma unroll
-    for (int i = 0; i < NV4; ++i) { vf[4 * i] = vr[s_][i].x; vf[4 * i + 1] = vr[s_][i].y; vf[4 * i + 2] = vr[s_][i].z; vf[4 * i + 3] = vr[s_][i].w; }
-    if (ks + 4 * PF < nk) fetch(s_, ks + 4 * PF);
+  auto step = [&](int set) {
+    const ca_bf16x8 B1 = __builtin_bit_cast(ca_bf16x8, b1r[set]), B2 = __builtin_bit_cast(ca_bf16x8, b2r[set]);
+    auto vf = [&](int i) -> float { const float4& w = vr[set][i >> 2]; return (i & 3) == 0 ? w.x : (i & 3) == 1 ? w.y : (i & 3) == 2 ? w.z : w.w; };
 #pragma unroll
     for (int t = 0; t < TL; ++t) {
       unsigned hi[4], lo[4];
 #pragma unroll
       for (int pp = 0; pp < 4; ++pp) {
-        ca_f32x2 eta = (ca_f32x2){vf[(2 * pp) * D], vf[(2 * pp + 1) * D]} * f[t][0] - em[t];
+        ca_f32x2 eta = (ca_f32x2){vf((2 * pp) * D), vf((2 * pp + 1) * D)} * f[t][0] - em[t];
 #pragma unroll
-        for (int d = 1; d < D; ++d) eta = (ca_f32x2){vf[(2 * pp) * D + d], vf[(2 * pp + 1) * D + d]} * f[t][d] + eta;
+        for (int d = 1; d < D; ++d) eta = (ca_f32x2){vf((2 * pp) * D + d), vf((2 * pp + 1) * D + d)} * f[t][d] + eta;
         const float e0 = __builtin_amdgcn_exp2f(eta.x), e1 = __builtin_amdgcn_exp2f(eta.y);
         hi[pp] = ca_pk_bf16(e0, e1);
         const ca_bf16x2 hb = __builtin_bit_cast(ca_bf16x2, hi[pp]);
@@ -2401,8 +2396,20 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
       a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B1, a, 0, 0, 0);
       acc[t] = a;
     }
-    }   // ks < nk
-  }     // ring slot
+  };
+  fetch(0, wv < nk ? wv : nk - 1);
+  [[maybe_unused]] const int prio_q = ((nk - wv + 7) / 8 + 3) / 4;
+  [[maybe_unused]] int prio_i = 0;
+  for (int ks = wv; ks < nk; ks += 8) {   // wave-uniform bounds
+    CA_PRIO_STEP(prio_i, prio_q);
+    ++prio_i;
+    const bool more = ks + 4 < nk;
+    if (more) fetch(1, ks + 4);
+    step(0);
+    if (more) {
+      if (ks + 8 < nk) fetch(0, ks + 8);
+      step(1);
+    }
   }
   CA_PRIO_DONE();
 #pragma unroll
@@ -2523,6 +2530,8 @@ __global__ void __launch_bounds__(CA_TB, CA_RIDE_WAVES) k_fwd_cell_mix_y(const f
   if (!sweep) {
 #ifdef CA_LAB_YPRIO
     __builtin_amdgcn_s_setprio(CA_LAB_YPRIO);
+#else
+    CA_PRIO_STREAM();
 #endif
     if (y.pers > 0 && idx < y.pers) {
       for (int u = idx; u < y.nb_main; u += y.pers)
@@ -2594,6 +2603,8 @@ __global__ void __launch_bounds__(CA_TB, CA_RIDE_WAVES) k_fwd_cell_seq_y(const f
   if (unit >= 0 && (!sweep_blk || first)) {
 #ifdef CA_LAB_YPRIO
     __builtin_amdgcn_s_setprio(CA_LAB_YPRIO);
+#else
+    CA_PRIO_STREAM();
 #endif
     ca_ypass_body<uint8_t, 1, 0>(unit, y.Y, y.F, y.Dstride, y.V, 0, y.YWpart, y.YTpart, N, y.G, y.Gp, y.nseg, y.nrb, y.TR, 1, y.ovf, y.nb_main,
                                  reinterpret_cast<float (*)[64][17]>(smem));
@@ -2615,6 +2626,8 @@ __global__ void __launch_bounds__(CA_TB, CA_RIDE_WAVES) k_fwd_cell_seq_y(const f
       __syncthreads();
 #ifdef CA_LAB_YPRIO
       __builtin_amdgcn_s_setprio(CA_LAB_YPRIO);
+#else
+      CA_PRIO_STREAM();
 #endif
       ca_ypass_body<uint8_t, 1, 0>(unit, y.Y, y.F, y.Dstride, y.V, 0, y.YWpart, y.YTpart, N, y.G, y.Gp, y.nseg, y.nrb, y.TR, 1, y.ovf, y.nb_main,
                                    reinterpret_cast<float (*)[64][17]>(smem));
@@ -3051,15 +3064,23 @@ __global__ void __launch_bounds__(CA_TB, DEPTH == 1 ? CA_YS_RIDE_WAVES : 3) k_fw
   } else {
     sweep = ca_ride_split((int)blockIdx.x, nf, y.nb_y, y.pat_a, y.pat_b, idx);
   }
+#ifdef CA_LAB_STAMPS
+  const unsigned long long st0_ = __builtin_amdgcn_s_memrealtime();
+#define CA_YS_LEAVE() goto ca_ys_out
+#else
+#define CA_YS_LEAVE() return
+#endif
   if (!sweep) {
     if (idx >= y.nb_main) {   // the overflow list's blocks: cell side (an extra segment of YWpart), then gene side (chunk sums)
       const int b = idx - y.nb_main;
       if (b < y.ovf.nb_rows) ca_ovf_rows_body(b, y.ovf.rowptr, y.ovf.col, y.ovf.val, y.V, y.Df, y.ovf.YWextra, N, 1, 0);
       else ca_ovf_chunks_body(b - y.ovf.nb_rows, y.ovf.chunk_start, y.ovf.row2, y.ovf.val2, y.F, y.Df, y.ovf.csum, y.ovf.nchunk, 1, 0);
-      return;
+      CA_YS_LEAVE();
     }
 #ifdef CA_LAB_YPRIO
     __builtin_amdgcn_s_setprio(CA_LAB_YPRIO);
+#else
+    CA_PRIO_STREAM();
 #endif
     if (y.pers > 0) {
       for (int u = idx; u < y.nb_main; u += y.pers) {
@@ -3069,14 +3090,27 @@ __global__ void __launch_bounds__(CA_TB, DEPTH == 1 ? CA_YS_RIDE_WAVES : 3) k_fw
     } else {
       ca_ys_mfma_body<DEPTH>(idx, y.Ys, y.io, N, y.Gp, y.RS, smem);
     }
-    return;
+    CA_YS_LEAVE();
   }
-  ca_f32x4* comb = reinterpret_cast<ca_f32x4*>(smem);
-  double* sm = reinterpret_cast<double*>(smem + sizeof(ca_f32x4) * 4 * TLB * 64);
-  double* la = sm + CA_TB;
-  ca_log_softmax_alpha(alpha_u, C, la);
-  if (nbig > 0 && idx >= nbig)
-    ca_fwd_cell_body<D, TLS, C16>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)nbig * (TLB * 16) + (int64_t)(idx - nbig) * (TLS * 16), idx, comb, sm, la);
-  else
-    ca_fwd_cell_body<D, TLB, C16>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)idx * (TLB * 16), idx, comb, sm, la);
+  {
+    ca_f32x4* comb = reinterpret_cast<ca_f32x4*>(smem);
+    double* sm = reinterpret_cast<double*>(smem + sizeof(ca_f32x4) * 4 * TLB * 64);
+    double* la = sm + CA_TB;
+    ca_log_softmax_alpha(alpha_u, C, la);
+    if (nbig > 0 && idx >= nbig)
+      ca_fwd_cell_body<D, TLS, C16>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)nbig * (TLB * 16) + (int64_t)(idx - nbig) * (TLS * 16), idx, comb, sm, la);
+    else
+      ca_fwd_cell_body<D, TLB, C16>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)idx * (TLB * 16), idx, comb, sm, la);
+  }
+#undef CA_YS_LEAVE
+#ifdef CA_LAB_STAMPS
+ca_ys_out:
+  __syncthreads();
+  if (threadIdx.x == 0 && blockIdx.x < 8192) {   // (timing lab: same record as k_fwd_cell_mix_y's; kind 0 = stream / overflow, 1 = big, 2 = small sweep block)
+    unsigned long long* st = ca_lab_stamps + 4 * (size_t)blockIdx.x;
+    st[0] = st0_; st[1] = __builtin_amdgcn_s_memrealtime();
+    st[2] = ((unsigned long long)(sweep ? (nbig > 0 && idx >= nbig ? 2 : 1) : 0) << 32) | (unsigned)idx;
+    st[3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
+  }
+#endif
 }
