@@ -97,6 +97,26 @@ __device__ __forceinline__ unsigned short ca_bf16_rn(float f) {
 __device__ __forceinline__ double ca_softplus_d(double x) { return x > 0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
 __device__ __forceinline__ double ca_sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
 
+#ifdef CA_LAB_STAMPS   // timing lab only (tools/stamps_small.py): {start, end, kind, 1} of every block of the two small kernels of the last iteration
+__device__ unsigned long long ca_lab_stamps2[4096 * 4];
+struct ca_lab_stamp {
+  unsigned long long t0; int slot, kind;
+  __device__ ca_lab_stamp(int slot_, int kind_) : t0(__builtin_amdgcn_s_memrealtime()), slot(slot_), kind(kind_) {}
+  __device__ ~ca_lab_stamp() {
+    if (threadIdx.x == 0 && slot < 4096) {
+      unsigned long long* st = ca_lab_stamps2 + 4 * (size_t)slot;
+      st[0] = t0; st[1] = __builtin_amdgcn_s_memrealtime(); st[2] = (unsigned long long)kind; st[3] = 1;
+    }
+  }
+};
+#define CA_LAB_STAMP(slot, kind) ca_lab_stamp ca_lab_stamp_((slot), (kind))
+// checkpoints inside a block (thread 0): slot 3072 + 8 * block + i
+#define CA_LAB_CP(blk, i) do { if (threadIdx.x == 0 && (blk) < 64) { __builtin_amdgcn_s_waitcnt(0); ca_lab_stamps2[4 * (3072 + 8 * (blk) + (i))] = __builtin_amdgcn_s_memrealtime(); ca_lab_stamps2[4 * (3072 + 8 * (blk) + (i)) + 3] = 2; } } while (0)
+#else
+#define CA_LAB_STAMP(slot, kind) do { } while (0)
+#define CA_LAB_CP(blk, i) do { } while (0)
+#endif
+
 // ------------------------------------------------------------------ count-matrix element decode
 template <typename YT> struct YVec;
 template <> struct YVec<float> {
@@ -761,14 +781,21 @@ __device__ __forceinline__ void ca_gene_pre_fused_body(const float* __restrict__
   const int g = blk * CA_TB + threadIdx.x;
   const bool ok = g < G;
   double t[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+  float wk0 = 0.f;   // W_g0, for the sum of squares below (loaded with everything else)
   if (ok) {
-    const double l = (double)loc[g], lsd = (double)ls[g], sd = exp(lsd), cs = colsum[g];
+    // all operands in one batch in front of the first use (one wave per SIMD here: a dependent round of loads is 1.5 us)
+    const float loc_g = loc[g], ls_g = ls[g], eA = epsA[g], eB = epsB[g];
+    const double cs = colsum[g];
+    const float4 lr0 = *reinterpret_cast<const float4*>(Lb + (int64_t)g * CA_CW), lr1 = *reinterpret_cast<const float4*>(Lb + (int64_t)g * CA_CW + 4);
+    if (K > 0) wk0 = V[(int64_t)g * D];
+    const float lrow[CA_CW] = {lr0.x, lr0.y, lr0.z, lr0.w, lr1.x, lr1.y, lr1.z, lr1.w};
+    const double l = (double)loc_g, lsd = (double)ls_g, sd = exp(lsd);
     double bx = 0.0;
     for (int p = K; p < D; ++p) bx += (double)V[(int64_t)g * D + p] * YtX[(int64_t)g * (D - K) + (p - K)];
-    const float* lp = Lb + (int64_t)g * CA_CW;
+    const float* lp = lrow;
     const bool c16 = C > CA_CW;   // 9..16 clones: ONE draw per sweep, its clones 8.. in the second column half (copy numbers: second chunk of Lb)
     for (int w = 0; w < 2; ++w) {
-      const double e = (double)(w ? epsB : epsA)[g];
+      const double e = (double)(w ? eB : eA);
       const double x = l + sd * e;
       const double mu = ca_softplus_d(x), lm = log(mu);
       const float muf = (float)mu;
@@ -776,24 +803,32 @@ __device__ __forceinline__ void ca_gene_pre_fused_body(const float* __restrict__
       if (Mq && c16) {
         if (w == 0) {
           unsigned short* mq = Mq + ((int64_t)(g >> 5) * 128 + 16 * ((g & 31) >> 3)) * 8 + (g & 7);
-          for (int c = 0; c < C; ++c) {
-            const float x = (c < CA_CW ? lp[c] : Lb[((int64_t)G + g) * CA_CW + (c - CA_CW)]) * muf;
+#pragma unroll
+          for (int c = 0; c < 2 * CA_CW; ++c) {   // (compile-time indices: the copy-number row is in registers)
+            if (c < C) {
+              const float x = (c < CA_CW ? lp[c < CA_CW ? c : 0] : Lb[((int64_t)G + g) * CA_CW + (c - CA_CW)]) * muf;
+              const unsigned short p1 = ca_bf16_rn(x);
+              mq[c * 8] = p1;
+              mq[(64 + c) * 8] = ca_bf16_rn(x - __uint_as_float((unsigned)p1 << 16));
+            }
+          }
+        }
+      } else if (Mq) {   // two bf16 parts in the B-operand layout of k_fwd_mfma: [g / 32][part][16 (g % 32) / 8 + column][g % 8]
+        unsigned short* mq = Mq + ((int64_t)(g >> 5) * 128 + 16 * ((g & 31) >> 3) + w * C) * 8 + (g & 7);
+#pragma unroll
+        for (int c = 0; c < CA_CW; ++c) {
+          if (c < C) {
+            const float x = lp[c] * muf;
             const unsigned short p1 = ca_bf16_rn(x);
             mq[c * 8] = p1;
             mq[(64 + c) * 8] = ca_bf16_rn(x - __uint_as_float((unsigned)p1 << 16));
           }
         }
-      } else if (Mq) {   // two bf16 parts in the B-operand layout of k_fwd_mfma: [g / 32][part][16 (g % 32) / 8 + column][g % 8]
-        unsigned short* mq = Mq + ((int64_t)(g >> 5) * 128 + 16 * ((g & 31) >> 3) + w * C) * 8 + (g & 7);
-        for (int c = 0; c < C; ++c) {
-          const float x = lp[c] * muf;
-          const unsigned short p1 = ca_bf16_rn(x);
-          mq[c * 8] = p1;
-          mq[(64 + c) * 8] = ca_bf16_rn(x - __uint_as_float((unsigned)p1 << 16));
-        }
       } else {
         float* mp = Mb + (int64_t)g * mrow + w * C;
-        for (int c = 0; c < C; ++c) mp[c] = lp[c] * muf;
+#pragma unroll
+        for (int c = 0; c < CA_CW; ++c)
+          if (c < C) mp[c] = lp[c] * muf;
       }
       t[w][0] = cs * lm + bx;
       t[w][1] = -0.5 * lm * lm - 0.5 * CA_LOG2PI;
@@ -801,18 +836,22 @@ __device__ __forceinline__ void ca_gene_pre_fused_body(const float* __restrict__
     }
   }
   const int W_ = 3 + K;
+  // the six term sums and (up to two) sums of squared loadings in ONE pass through the block reduction: one pair of barriers
+  double w1sq = 0.0;
+  if (K > 1 && ok) { const double w1 = (double)V[(int64_t)g * D + 1]; w1sq = w1 * w1; }
   {
-    double six[6] = {t[0][0], t[0][1], t[0][2], t[1][0], t[1][1], t[1][2]};
-    ca_block_sum_n<6>(six, sm);
+    double eight[8] = {t[0][0], t[0][1], t[0][2], t[1][0], t[1][1], t[1][2], ok ? (double)wk0 * (double)wk0 : 0.0, w1sq};
+    ca_block_sum_n<8>(eight, sm);
     if (threadIdx.x == 0) {
       double* ga = gene_partA + (int64_t)blk * W_;
       double* gb = gene_partB + (int64_t)blk * W_;
-      if (s2) { ga[0] = 0.5 * (six[0] + six[3]); ga[1] = 0.5 * (six[1] + six[4]); ga[2] = 0.5 * (six[2] + six[5]); }
-      else { ga[0] = six[0]; ga[1] = six[1]; ga[2] = six[2]; }
-      gb[0] = six[3]; gb[1] = six[4]; gb[2] = six[5];
+      if (s2) { ga[0] = 0.5 * (eight[0] + eight[3]); ga[1] = 0.5 * (eight[1] + eight[4]); ga[2] = 0.5 * (eight[2] + eight[5]); }
+      else { ga[0] = eight[0]; ga[1] = eight[1]; ga[2] = eight[2]; }
+      gb[0] = eight[3]; gb[1] = eight[4]; gb[2] = eight[5];
+      for (int k = 0; k < K && k < 2; ++k) { ga[3 + k] = eight[6 + k]; gb[3 + k] = eight[6 + k]; }
     }
   }
-  for (int k = 0; k < K; ++k) {
+  for (int k = 2; k < K; ++k) {
     const double wv = ok ? (double)V[(int64_t)g * D + k] : 0.0;
     const double wsum = ca_block_sum(wv * wv, sm);
     if (threadIdx.x == 0) {
@@ -1253,7 +1292,19 @@ struct ca_small_args {
 };
 
 // wave 0 of the O(K + C) body: one lane per clone / latent dimension
-__device__ __forceinline__ void ca_final_small_wave0(const ca_small_args& sa, const double* gs) {
+// operands of wave 0 that nothing in the body produces: loaded at the body's entry, so that their latency is behind the block
+// reductions in front of wave 0's own fp64 chains (4 of this block's 7 us, tools/stamps_small.py)
+struct ca_small_pre { float au, vch, m_v, v_v, m_a, v_a; };
+__device__ __forceinline__ ca_small_pre ca_final_small_preload(const ca_small_args& sa) {
+  ca_small_pre q = {-INFINITY, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int c = threadIdx.x;
+  if (c < 64) {
+    if (c < sa.C && sa.C <= 64) { q.au = sa.alpha_u[c]; if (sa.apply) { q.m_a = sa.m_a[c]; q.v_a = sa.v_a[c]; } }
+    if (c < sa.K) { q.vch = sa.vchi[c]; if (sa.apply) { q.m_v = sa.m_v[c]; q.v_v = sa.v_v[c]; } }
+  }
+  return q;
+}
+__device__ __forceinline__ void ca_final_small_wave0(const ca_small_args& sa, const double* gs, const ca_small_pre& pq) {
   // One lane per clone (and per latent dimension): the fp64 exp/log chains of this kernel are long, so they
   // run side by side in wave 0 and meet through xor-shuffles.  (C <= 64 here; larger C takes the loop form.)
   const int c = threadIdx.x;
@@ -1270,7 +1321,7 @@ __device__ __forceinline__ void ca_final_small_wave0(const ca_small_args& sa, co
   };
   double dir_sum, dla_c = 0.0, al_c = 0.0, dla_sum;
   if (sa.C <= 64) {
-    const double au = c < sa.C ? (double)sa.alpha_u[c] : -INFINITY;
+    const double au = c < sa.C ? (double)pq.au : -INFINITY;
     const double mx = wmax(au);
     const double se = wsum(c < sa.C ? exp(au - mx) : 0.0);
     const double lse = mx + log(se);
@@ -1293,12 +1344,12 @@ __device__ __forceinline__ void ca_final_small_wave0(const ca_small_args& sa, co
   // chi terms: lane k < K
   double ep_k = 0.0;
   if (c < sa.K) {
-    const double v = (double)sa.vchi[c], chi = exp(v);
+    const double v = (double)pq.vch, chi = exp(v);
     ep_k = -0.5 * chi * gs[3 + c] + (double)sa.G * (0.5 * v - 0.5 * CA_LOG2PI) + (v - chi);
     const double gv = -0.5 * chi * gs[3 + c] + 0.5 * (double)sa.G + 1.0 - chi;
     sa.g_v[c] = (float)gv;
     if (sa.apply) {
-      float th = sa.vchi[c], m = sa.m_v[c], vv = sa.v_v[c];
+      float th = pq.vch, m = pq.m_v, vv = pq.v_v;
       ca_adam(th, m, vv, -(float)gv, sa.lr_t, sa.b1, sa.b2, sa.aeps);
       sa.vchi[c] = th; sa.m_v[c] = m; sa.v_v[c] = vv;
     }
@@ -1321,7 +1372,7 @@ __device__ __forceinline__ void ca_final_small_wave0(const ca_small_args& sa, co
       const float ga = (float)(dla_c - al_c * dla_sum);
       sa.g_a[c] = ga;
       if (sa.apply) {
-        float th = sa.alpha_u[c], m = sa.m_a[c], vv = sa.v_a[c];
+        float th = pq.au, m = pq.m_a, vv = pq.v_a;
         ca_adam(th, m, vv, -ga, sa.lr_t, sa.b1, sa.b2, sa.aeps);
         sa.alpha_u[c] = th; sa.m_a[c] = m; sa.v_a[c] = vv;
       }
@@ -1348,6 +1399,7 @@ __device__ __forceinline__ void ca_final_small_wave0(const ca_small_args& sa, co
 __device__ __forceinline__ void ca_final_small_body(const ca_small_args& sa) {
   __shared__ double sm[CA_TB];
   __shared__ double gs[3 + 16];
+  const ca_small_pre pq = sa.reduce_only ? ca_small_pre{-INFINITY, 0.f, 0.f, 0.f, 0.f, 0.f} : ca_final_small_preload(sa);
   if (sa.cell_part) {   // k_reduce_part folded in (same fixed order: strided partial sums, then the block tree)
     const int Wc = 3 + sa.C;
     for (int j0 = 0; j0 < Wc; j0 += 4) {   // four columns per pass (one pair of barriers, interleaved butterflies)
@@ -1424,7 +1476,7 @@ __device__ __forceinline__ void ca_final_small_body(const ca_small_args& sa) {
     }
   }
   __syncthreads();
-  if (threadIdx.x < 64) ca_final_small_wave0(sa, gs);
+  if (threadIdx.x < 64) ca_final_small_wave0(sa, gs, pq);
 }
 
 // ------------------------------------------------------------------ backward sweep on the matrix cores
@@ -2660,19 +2712,21 @@ __device__ __forceinline__ void ca_psi_adam_body(const ca_psi_args& a, int blk, 
   const int64_t n = (int64_t)blk * CA_TB + threadIdx.x;
   if (n >= a.N) return;
   for (int k = 0; k < a.K; ++k) {
+    // (everything this lane reads, in one batch in front of the first use: a dependent round of loads is 1.5 us here)
+    const float yw_k = a.YW[n * a.K + k], f_k = a.F[n * a.D + k], m_k = a.m_psi[n * a.K + k], v_k = a.v_psi[n * a.K + k];
     double dF = 0.0;
-    for (int t0 = 0; t0 < a.ntile; t0 += 10) {   // ten loads in flight (a plain loop waits for each: 20 L2 round trips), added in tile order
-      float v[10];
+    for (int t0 = 0; t0 < a.ntile; t0 += 20) {   // twenty loads in flight (a plain loop waits for each: 20 round trips), added in tile order
+      float v[20];
 #pragma unroll
-      for (int i = 0; i < 10; ++i) v[i] = a.dFpart[((int64_t)(t0 + i < a.ntile ? t0 + i : a.ntile - 1) * a.N + n) * a.D + k];
+      for (int i = 0; i < 20; ++i) v[i] = a.dFpart[((int64_t)(t0 + i < a.ntile ? t0 + i : a.ntile - 1) * a.N + n) * a.D + k];
 #pragma unroll
-      for (int i = 0; i < 10; ++i)
+      for (int i = 0; i < 20; ++i)
         if (t0 + i < a.ntile) dF += (double)v[i];
     }
-    const float gp = (float)((double)a.YW[n * a.K + k] + dF - (double)a.F[n * a.D + k]);
+    const float gp = (float)((double)yw_k + dF - (double)f_k);
     a.g_psi[n * a.K + k] = gp;
     if (apply) {
-      float th = a.F[n * a.D + k], m = a.m_psi[n * a.K + k], v = a.v_psi[n * a.K + k];
+      float th = f_k, m = m_k, v = v_k;
       ca_adam(th, m, v, -gp, lr_t, b1, b2, aeps);
       a.F[n * a.D + k] = th; a.m_psi[n * a.K + k] = m; a.v_psi[n * a.K + k] = v;
     }
@@ -2691,22 +2745,34 @@ __device__ __forceinline__ void ca_final_gene_body(const double* __restrict__ re
                                                       const float* __restrict__ gfold /*[nfold][G][S+D] or null*/, int nfold) {
   const int g = blockIdx.x * CA_TB + threadIdx.x;
   const bool ok = g < G;
+  float Vnew0 = 0.f;   // the first loading after this step (kept in a register for the log2 image below)
   if (ok) {
-  const double l = (double)loc[g], lsd = (double)ls[g], sd = exp(lsd), cs = colsum[g];
+  // Every operand whose address does not depend on a result is loaded HERE, in one batch: this block is one wave per SIMD, and each
+  // dependent round of loads costs it 1.5 us after the sweeps have been through the caches and the TLB (block stamps,
+  // tools/stamps_small.py: the gene blocks, at four rounds, were the 8 us this kernel took).
+  const float loc_g = loc[g], ls_g = ls[g];
+  const double cs = colsum[g];
+  const float e0f = eps[g];
+  const float mloc_g = m_loc[g], vloc_g = v_loc[g], mls_g = m_ls[g], vls_g = v_ls[g];
+  float V0 = 0.f, mV0 = 0.f, vV0 = 0.f, vchi0 = 0.f;
+  double ry0 = 0.0;
+  if (D > 0) { V0 = V[(int64_t)g * D]; mV0 = m_V[(int64_t)g * D]; vV0 = v_V[(int64_t)g * D]; }
+  if (K > 0) { vchi0 = vchi[0]; ry0 = red_y[(int64_t)g * K]; }
+  const double l = (double)loc_g, lsd = (double)ls_g, sd = exp(lsd);
   const int W_ = S + D;
   // small problems: the backward sweep's cell-split partials are summed here (fixed order, fp64) instead of by a k_colsum
   // launch of their own -- one launch and its gap less per iteration where launches are what an iteration costs
   // (computed where it is used, once per column: an indexed local array would live in scratch memory)
   double rg2[2] = {0.0, 0.0};
-  const bool two = gfold && W_ == 2;   // the common case (one sample, one latent dimension): both columns from one 8-byte load, twenty
-  if (two) {                            // slices in flight -- two dependent rounds at 38 slices instead of ten (5 us of this kernel's 8)
-    for (int sp0 = 0; sp0 < nfold; sp0 += 20) {
-      float2 v[20];
+  const bool two = gfold && W_ == 2;   // the common case (one sample, one latent dimension): both columns from one 8-byte load, forty
+  if (two) {                            // slices in flight -- ONE round at the 38 slices of a resident round of sweep blocks (a round of
+    for (int sp0 = 0; sp0 < nfold; sp0 += 40) {   // these loads is 1.4 us: the slices come from the other XCDs' sweep blocks; checkpoints in
+      float2 v[40];                                // tools/stamps_small.py), where eight at a time, one column after the other, took ten
 #pragma unroll
-      for (int i = 0; i < 20; ++i)
+      for (int i = 0; i < 40; ++i)
         v[i] = *reinterpret_cast<const float2*>(gfold + ((int64_t)(sp0 + i < nfold ? sp0 + i : nfold - 1) * G + g) * 2);
 #pragma unroll
-      for (int i = 0; i < 20; ++i)
+      for (int i = 0; i < 40; ++i)
         if (sp0 + i < nfold) { rg2[0] += (double)v[i].x; rg2[1] += (double)v[i].y; }
     }
   }
@@ -2725,9 +2791,12 @@ __device__ __forceinline__ void ca_final_gene_body(const double* __restrict__ re
   };
   double gl = 0.0, gs = 0.0;
   for (int s = 0; s < S; ++s) {
-    const double e = (double)eps[(int64_t)s * G + g];
+    const double e = s == 0 ? (double)e0f : (double)eps[(int64_t)s * G + g];
     const double x = l + sd * e;
-    const double mu = ca_softplus_d(x), lm = log(mu), sig = ca_sigmoid_d(x);
+    // softplus and sigmoid from ONE exp: t = exp(-|x|); softplus = max(x, 0) + log1p(t); sigmoid = 1 / (1 + t) or t / (1 + t)
+    const double tx = exp(-fabs(x));
+    const double mu = (x > 0 ? x : 0.0) + log1p(tx), lm = log(mu);
+    const double sig = (x >= 0 ? 1.0 : tx) / (1.0 + tx);
     const double dmu = cs / ((double)S * mu) + rgv(s) - lm / ((double)S * mu);
     const double dx = dmu * sig + (1.0 - sig) / (double)S;
     gl += dx;
@@ -2737,22 +2806,24 @@ __device__ __forceinline__ void ca_final_gene_body(const double* __restrict__ re
   g_loc[g] = (float)gl;
   g_ls[g] = (float)gs;
   if (apply) {
-    float th = loc[g], m = m_loc[g], v = v_loc[g];
+    float th = loc_g, m = mloc_g, v = vloc_g;
     ca_adam(th, m, v, -(float)gl, lr_t, b1, b2, aeps);
     loc[g] = th; m_loc[g] = m; v_loc[g] = v;
-    th = ls[g]; m = m_ls[g]; v = v_ls[g];
+    th = ls_g; m = mls_g; v = vls_g;
     ca_adam(th, m, v, -(float)gs, lr_t, b1, b2, aeps);
     ls[g] = th; m_ls[g] = m; v_ls[g] = v;
   }
   for (int d = 0; d < D; ++d) {
     double gv = rgv(S + d);
-    if (d < K) gv += red_y[(int64_t)g * K + d] - exp((double)vchi[d]) * (double)V[(int64_t)g * D + d];
+    const float Vd = d == 0 ? V0 : V[(int64_t)g * D + d];
+    if (d < K) gv += (d == 0 ? ry0 : red_y[(int64_t)g * K + d]) - exp((double)(d == 0 ? vchi0 : vchi[d])) * (double)Vd;
     else gv += YtX[(int64_t)g * (D - K) + (d - K)];
     g_V[(int64_t)g * D + d] = (float)gv;
     if (apply) {
-      float th = V[(int64_t)g * D + d], m = m_V[(int64_t)g * D + d], v = v_V[(int64_t)g * D + d];
+      float th = Vd, m = d == 0 ? mV0 : m_V[(int64_t)g * D + d], v = d == 0 ? vV0 : v_V[(int64_t)g * D + d];
       ca_adam(th, m, v, -(float)gv, lr_t, b1, b2, aeps);
       V[(int64_t)g * D + d] = th; m_V[(int64_t)g * D + d] = m; v_V[(int64_t)g * D + d] = v;
+      if (d == 0) Vnew0 = th;
     }
   }
   }
@@ -2761,7 +2832,7 @@ __device__ __forceinline__ void ca_final_gene_body(const double* __restrict__ re
   for (int d = 0; d < D; ++d) {
     float v = 0.f;
     if (ok) {
-      v = V[(int64_t)g * D + d] * CA_LOG2E_F;
+      v = (d == 0 ? Vnew0 : V[(int64_t)g * D + d]) * CA_LOG2E_F;
       Vs[(int64_t)g * D + d] = v;
       if (g == G - 1)   // pad to a multiple of 32 genes with the last gene's loading (k_fwd_cell reads whole k-steps)
         for (int gp = G; gp < ((G + 31) / 32) * 32; ++gp) Vs[(int64_t)gp * D + d] = v;
@@ -2795,6 +2866,7 @@ __global__ void __launch_bounds__(CA_TB) k_final_gene(const double* __restrict__
 #ifndef CA_LAB_SKIP
 #define CA_LAB_SKIP 0   // (timing lab, results WRONG: bit 0 monitor block, 1 psi blocks, 2 gene blocks of k_final_gene; 3 small block, 4 prologue
 #endif                  //  blocks, 5 quantiser blocks, 6 cell blocks of k_adam_cell return at once)
+  CA_LAB_STAMP((int)blockIdx.x, (int)blockIdx.x < gblocks ? 0 : (mon.enabled && (int)blockIdx.x == gblocks) ? 1 : 2);
   if ((int)blockIdx.x >= gblocks) {
     int b = (int)blockIdx.x - gblocks;
     if (mon.enabled) {   // one extra block: the pending monitor pass's ELBO (ca_final_small_body), beside the gene blocks
@@ -2828,6 +2900,7 @@ __global__ void __launch_bounds__(CA_TB) k_adam_cell(const float* __restrict__ F
   // the bandwidth-bound cell blocks after them -- the chains are what the kernel's duration hangs on.  Last: the quantiser of
   // the int8 count-matrix stream (ca_ys_quant_body), when that stream is in use: W and psi are final once k_final_gene has run.
   const int nx = pre.nblk + 1;
+  CA_LAB_STAMP(1024 + (int)blockIdx.x, (int)blockIdx.x < pre.nblk ? 3 : (int)blockIdx.x < nx ? 4 : (int)blockIdx.x < nx + cblocks ? 5 : 6);
   if ((int)blockIdx.x >= nx + cblocks) {
     if (CA_LAB_SKIP & 32) return;
     __shared__ float smq[2 * (CA_YM_TB / 64)];
