@@ -549,6 +549,25 @@ struct ca_ysq_args {
 };
 __device__ __forceinline__ void ca_ys_quant_body(int blk, const ca_ysq_args& a, float* sm /* >= 2 * (CA_YM_TB / 64) floats */) {
   const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
+  // this wave's 64-step of an image: its sixteen entries per lane (and the lane's own entry, for the step's exact maximum) are
+  // loaded FIRST -- their addresses do not depend on the exponents, so the round trip runs beside the reduction below
+  const int64_t st = (int64_t)blk * (CA_YM_TB / 64) + wv;      // one wave per 64-step of an image
+  const bool live = st < a.GS + a.NS;
+  const bool isw = !live || st < a.GS;
+  const float* src = isw ? a.V : a.F;
+  const int ld = isw ? a.Dv : a.Df;
+  const int64_t rows = isw ? a.G : a.N, step = live ? (isw ? st : st - a.GS) : 0;
+  float vals[16], own = 0.f;
+  {
+    const int64_t r0 = step * 64 + 16 * (l >> 4);
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      const int64_t r = r0 + b;
+      vals[b] = (live && r < rows) ? src[r * ld] : 0.f;
+    }
+    const int64_t r = step * 64 + l;
+    if (live && r < rows) own = src[r * ld];
+  }
   // largest magnitudes of the state amax_in describes
   float mw = 0.f, mp = 0.f;
   for (int i = tid; i < a.n_in; i += CA_YM_TB) { mw = fmaxf(mw, a.amax_in[2 * i]); mp = fmaxf(mp, a.amax_in[2 * i + 1]); }
@@ -561,31 +580,29 @@ __device__ __forceinline__ void ca_ys_quant_body(int blk, const ca_ysq_args& a, 
   __syncthreads();
   const int ew = ca_fix_exp(mw + a.slack_w), ep = ca_fix_exp(mp + a.slack_p);
   if (blk == 0 && tid == 0) { a.exps[0] = ew; a.exps[1] = ep; }
-  const int64_t st = (int64_t)blk * (CA_YM_TB / 64) + wv;      // one wave per 64-step of an image
   float m = 0.f;
-  bool isw = true;
-  if (st < a.GS + a.NS) {
-    isw = st < a.GS;
-    const float* src = isw ? a.V : a.F;
-    const int ld = isw ? a.Dv : a.Df;
-    const int64_t rows = isw ? a.G : a.N, step = isw ? st : st - a.GS;
+  if (live) {
     const float sc = ldexpf(1.f, isw ? ew : ep);
-    const uint4 v = ca_quant16(src, ld, rows, 1, step, l, sc, 1);
+    // ca_quant16(src, ld, rows, 1, step, l, sc, 1) on the entries already in registers: digit p = l & 3 of each
+    const int p = l & 3;
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      const int x = (int)rintf(fminf(fmaxf(vals[b] * sc, -2147483000.f), 2147483000.f));
+      w[b >> 2] |= ((unsigned)ca_digit(x, p) & 0xFFu) << (8 * (b & 3));
+    }
+    const uint4 v = {w[0], w[1], w[2], w[3]};
     (isw ? a.Wr : a.Pr)[step * 64 + l] = v;
     int sd = 0;   // digit sums of the step (lanes with column p = l & 3 in the first group hold digit p for the 16 entries of group q)
-    {
-      const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int d = 0; d < 4; ++d)
+    for (int d = 0; d < 4; ++d)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) sd += (int)(signed char)((w[d] >> (8 * b)) & 0xFFu);
-    }
+      for (int b = 0; b < 4; ++b) sd += (int)(signed char)((w[d] >> (8 * b)) & 0xFFu);
     sd += __shfl_xor(sd, 16, 64);
     sd += __shfl_xor(sd, 32, 64);
     if (l < 4) (isw ? a.Wsum : a.Psum)[step * 4 + l] = sd;
     // exact maximum of this step's 64 entries, one per lane
-    const int64_t r = step * 64 + l;
-    if (r < rows) m = fabsf(src[r * ld]);
+    m = fabsf(own);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   }

@@ -18,6 +18,16 @@ def pytest_sessionstart(session):
     into the library with the hash of the sources).  Same makefiles as ``__graft_entry__.build()``."""
     if os.environ.get("PYTEST_XDIST_WORKER"):
         return
+    # GPU runs: torch's bundled HIP runtime has to be the FIRST one initialised in this process (see below); a run that starts
+    # with tests which only load the engine (pytest tests/test_gpu_parity.py tests/test_gpu_scale.py) otherwise leaves the
+    # torch-using tests after them with "No HIP GPUs are available"
+    if "not gpu" not in (session.config.option.markexpr or ""):
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except Exception:
+            pass
     import subprocess
     # (makefiles only, in child processes: loading the engine here would bring the system HIP runtime into this process
     #  before the tests that import torch load torch's bundled one, and the second runtime then sees no device)
