@@ -1886,9 +1886,11 @@ __global__ void __launch_bounds__(CA_TB) k_allele_loglik(const double* __restric
 // log_alpha = log_softmax(alpha_unconstr) (R/inference-tflow.R:255) into LDS, by wave 0: one lane per clone, the C
 // exponentials side by side (they were a serial chain on thread 0: ~2 us at the head of every cell-epilogue block)
 __device__ __forceinline__ void ca_log_softmax_alpha(const float* __restrict__ alpha_u, int C, double* la) {
-  if (threadIdx.x >= 64) return;
+  // (the block's LAST wave: in the fused sweep wave 0 has one k-step more than the others whenever the k-step count is 4 n + 1,
+  //  and this fp64 chain stood in front of its loop)
+  if (threadIdx.x < CA_TB - 64) return;
   if (C <= 64) {
-    const int c = threadIdx.x;
+    const int c = threadIdx.x - (CA_TB - 64);
     const double au = c < C ? (double)alpha_u[c] : -INFINITY;
     double mx = au;
 #pragma unroll
@@ -1897,7 +1899,7 @@ __device__ __forceinline__ void ca_log_softmax_alpha(const float* __restrict__ a
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) se += __shfl_xor(se, o, 64);
     if (c < C) la[c] = au - (mx + log(se));
-  } else if (threadIdx.x == 0) {
+  } else if (threadIdx.x == CA_TB - 64) {
     double mx = -INFINITY;
     for (int c = 0; c < C; ++c) mx = fmax(mx, (double)alpha_u[c]);
     double se = 0.0;
@@ -2244,13 +2246,12 @@ __device__ __forceinline__ void ca_cell_fused_finish(const ca_cell_acc& acc, dou
     const double rb = ca_block_sum(acc.eeB, sm);
     if (threadIdx.x == 0) ee_partB[blk] = rb;
   }
-  const double r0 = ca_block_sum(acc.ee, sm);
-  const double r1 = ca_block_sum(acc.pr, sm);
-  const double r2 = ca_block_sum(acc.q, sm);
+  double r3[3] = {acc.ee, acc.pr, acc.q};   // one pass through the block reduction (same additions as three calls, one pair of barriers)
+  ca_block_sum_n<3>(r3, sm);
   if (threadIdx.x == 0) {
-    cell_part[(int64_t)blk * W_ + 0] = r0;
-    cell_part[(int64_t)blk * W_ + 1] = r1;
-    cell_part[(int64_t)blk * W_ + 2] = r2;
+    cell_part[(int64_t)blk * W_ + 0] = r3[0];
+    cell_part[(int64_t)blk * W_ + 1] = r3[1];
+    cell_part[(int64_t)blk * W_ + 2] = r3[2];
   }
   __syncthreads();
   sm[threadIdx.x] = acc.gsumc;
