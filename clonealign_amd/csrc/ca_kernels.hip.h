@@ -800,17 +800,15 @@ __device__ __forceinline__ void ca_gene_pre_fused_body(const float* __restrict__
       const double mu = ca_softplus_d(x), lm = log(mu);
       const float muf = (float)mu;
       (w ? muB : muA)[g] = muf;
-      if (Mq && c16) {
-        if (w == 0) {
-          unsigned short* mq = Mq + ((int64_t)(g >> 5) * 128 + 16 * ((g & 31) >> 3)) * 8 + (g & 7);
+      if (Mq && c16) {   // sixteen columns per draw: the second draw's image follows the first one's ([2][nk][2][64][8])
+        unsigned short* mq = Mq + (int64_t)w * ((G + 31) / 32) * 1024 + ((int64_t)(g >> 5) * 128 + 16 * ((g & 31) >> 3)) * 8 + (g & 7);
 #pragma unroll
-          for (int c = 0; c < 2 * CA_CW; ++c) {   // (compile-time indices: the copy-number row is in registers)
-            if (c < C) {
-              const float x = (c < CA_CW ? lp[c < CA_CW ? c : 0] : Lb[((int64_t)G + g) * CA_CW + (c - CA_CW)]) * muf;
-              const unsigned short p1 = ca_bf16_rn(x);
-              mq[c * 8] = p1;
-              mq[(64 + c) * 8] = ca_bf16_rn(x - __uint_as_float((unsigned)p1 << 16));
-            }
+        for (int c = 0; c < 2 * CA_CW; ++c) {   // (compile-time indices: the copy-number row is in registers)
+          if (c < C) {
+            const float x = (c < CA_CW ? lp[c < CA_CW ? c : 0] : Lb[((int64_t)G + g) * CA_CW + (c - CA_CW)]) * muf;
+            const unsigned short p1 = ca_bf16_rn(x);
+            mq[c * 8] = p1;
+            mq[(64 + c) * 8] = ca_bf16_rn(x - __uint_as_float((unsigned)p1 << 16));
           }
         }
       } else if (Mq) {   // two bf16 parts in the B-operand layout of k_fwd_mfma: [g / 32][part][16 (g % 32) / 8 + column][g % 8]
@@ -2415,10 +2413,23 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
   // refill was issued -- 12 moves per k-step on the issue port the sweep is bound by.
   uint4 b1r[2], b2r[2];
   float4 vr[2][NV4];
+  // C16: the second draw's sixteen columns are a second pair of B operands (its image follows the first draw's) and a second set of
+  // accumulators -- six MFMAs per tile and k-step on ONE exp and one bf16 split, instead of a sweep per draw
+  [[maybe_unused]] uint4 b1s[2], b2s[2];
+  [[maybe_unused]] ca_f32x4 accB[TL];
+  if constexpr (C16) {
+#pragma unroll
+    for (int t = 0; t < TL; ++t) accB[t] = (ca_f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   auto fetch = [&](int set, int ks) {
     const uint4* bp = Bq + (int64_t)ks * 128;
     b1r[set] = bp[lane];
     b2r[set] = bp[64 + lane];
+    if constexpr (C16) {
+      const uint4* bs = Bq + ((int64_t)nk + ks) * 128;
+      b1s[set] = bs[lane];
+      b2s[set] = bs[64 + lane];
+    }
     const float4* vp = reinterpret_cast<const float4*>(Vs + ((int64_t)ks * 32 + 8 * q) * D);
 #pragma unroll
     for (int i = 0; i < NV4; ++i) vr[set][i] = vp[i];
@@ -2448,6 +2459,14 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
       a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B2, a, 0, 0, 0);
       a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B1, a, 0, 0, 0);
       acc[t] = a;
+      if constexpr (C16) {
+        const ca_bf16x8 S1 = __builtin_bit_cast(ca_bf16x8, b1s[set]), S2 = __builtin_bit_cast(ca_bf16x8, b2s[set]);
+        ca_f32x4 b = accB[t];
+        b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2, S1, b, 0, 0, 0);
+        b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, S2, b, 0, 0, 0);
+        b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, S1, b, 0, 0, 0);
+        accB[t] = b;
+      }
     }
   };
   fetch(0, wv < nk ? wv : nk - 1);
@@ -2474,16 +2493,38 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
   const int c = threadIdx.x % CP;
   const int cc = c < C ? c : C - 1;
   ca_cell_acc cacc = {0.0, 0.0, 0.0, 0.0, 0.0};
-  for (int g0 = 0; g0 < TL * 16; g0 += CPB) {
+  // C16: the combine buffer holds one draw's accumulators at a time -- the first draw's Z go to registers (TL values per thread:
+  // sixteen cells per pass of the block), then the second draw's accumulators take the buffer
+  [[maybe_unused]] double ZAr[TL];
+  if constexpr (C16) {
+    static_assert(CPB == 16, "one 16-cell tile per pass of the block");
+#pragma unroll
+    for (int t = 0; t < TL; ++t) {
+      const int row = (int)threadIdx.x / CP, qq = row >> 2, r = row & 3, la_ = 16 * qq + cc;
+      auto cz = [&](int w) { return (double)comb[(w * TL + t) * 64 + la_][r]; };
+      ZAr[t] = (cz(0) + cz(1)) + (cz(2) + cz(3));
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TL; ++t) comb[(wv * TL + t) * 64 + lane] = accB[t];
+    __syncthreads();
+  }
+  auto cells = [&](int g0, double ZA16) {
     const int lc = g0 + (int)threadIdx.x / CP;       // local cell
     const bool inb = lc < TL * 16;
     const int lcc = inb ? lc : 0;
     const int t = lcc >> 4, row = lcc & 15, qq = row >> 2, r = row & 3;
     const int la_ = 16 * qq + cc, lb_ = C16 ? la_ : 16 * qq + C + cc;
     auto cz = [&](int w, int col) { return (double)comb[(w * TL + t) * 64 + col][r]; };
-    const double ZA = (cz(0, la_) + cz(1, la_)) + (cz(2, la_) + cz(3, la_));
+    const double ZA = C16 ? ZA16 : (cz(0, la_) + cz(1, la_)) + (cz(2, la_) + cz(3, la_));
     const double ZB = (cz(0, lb_) + cz(1, lb_)) + (cz(2, lb_) + cz(3, lb_));
     ca_cell_fused_group<CP>(p, la, inb ? cell0 + lc : N, N, C, D, K, ZA, ZB, cacc);
+  };
+  if constexpr (C16) {
+#pragma unroll
+    for (int t = 0; t < TL; ++t) cells(16 * t, ZAr[t]);   // (compile-time index into the registers)
+  } else {
+    for (int g0 = 0; g0 < TL * 16; g0 += CPB) cells(g0, 0.0);
   }
   ca_cell_fused_finish<CP>(cacc, sm, cell_part, blk, C, p.ee_partB);
 }
@@ -3121,7 +3162,7 @@ struct ca_ysride_args {
 #define CA_YS_RIDE_WAVES 4   // waves per SIMD the merged launch's register budget is set for (lab: 3 = 168 VGPRs, three blocks per CU)
 #endif
 template <int D, int TLB, int TLS, int DEPTH, bool C16 = false>
-__global__ void __launch_bounds__(CA_TB, DEPTH == 1 ? CA_YS_RIDE_WAVES : 3) k_fwd_cell_mix_ys(const float* __restrict__ F, const float* __restrict__ etamax2,
+__global__ void __launch_bounds__(CA_TB, (DEPTH == 1 && !C16) ? CA_YS_RIDE_WAVES : 3) k_fwd_cell_mix_ys(const float* __restrict__ F, const float* __restrict__ etamax2,
                                                            const float* __restrict__ Vs, const unsigned short* __restrict__ Mq,
                                                            ca_cell_ptrs p, const float* __restrict__ alpha_u,
                                                            double* __restrict__ cell_part, int64_t N, int C, int K, int nk, int nbig,

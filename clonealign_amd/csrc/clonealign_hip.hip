@@ -1025,9 +1025,8 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
   // the next fused pass's per-gene prologue, when the loop has announced its eps slots: extra blocks of the per-cell kernel
   ca_pre_args pre;
   memset(&pre, 0, sizeof(pre));
-  // (the hints are PASS slots: one draw per sweep for 9..16 clones -- the monitor pass alone; two samples per pass for mc_samples = 2)
+  // (the hints are PASS slots; two samples per pass for mc_samples = 2)
   int64_t hA = h->hint_A, hB = h->hint_B;
-  if (h->c16) hB = hA;
   if (h->s2) { hA = 2 * h->hint_A; hB = hA + 1; }
   if (apply && h->pre_ok && h->hint_A >= 0 && hB >= 0 && h->fused_ok && h->gene_part_alt) {
     pre.nblk = h->ngblk;
@@ -1390,18 +1389,24 @@ int wait_host_elbo(ca_engine* h, unsigned long long seq, const double* dev, doub
 // monitor pass on eps slot m; with next >= 0 (and the fused path available) also the forward half of the train
 // pass on slot `next`, which train_pass() then completes
 int monitor_pass(ca_engine* h, int64_t m, int64_t next, double* elbo_dst) {
-  if (h->fused_ok && (h->c16 || h->s2)) {   // 9..16 clones: one draw per sweep; mc_samples = 2: the pass's two samples in the two column
-    CACK(h->s2 ? fused_pass(h, 2 * m, 2 * m + 1, elbo_dst) : fused_pass(h, m, m, elbo_dst));   // halves -- the monitor pass takes the sweep alone
+  if (h->fused_ok && h->s2) {   // mc_samples = 2: the pass's two samples in the two column halves -- the monitor pass takes the sweep alone
+    CACK(fused_pass(h, 2 * m, 2 * m + 1, elbo_dst));
     h->look_valid = false;
     return CA_OK;
   }
   if (h->fused_ok && next >= 0) return fused_pass(h, m, next, elbo_dst);
+  if (h->fused_ok && h->c16) {   // (9..16 clones have no plain matrix-core pass: the fused sweep with this draw in both roles)
+    CACK(fused_pass(h, m, m, elbo_dst));
+    h->look_valid = false;
+    return CA_OK;
+  }
   return run_pass(h, m, CA_MODE_ELBO, 0, elbo_dst);
 }
 int train_pass(ca_engine* h, int64_t slot) {
   if (h->look_valid && h->look_slot == slot) return train_from_lookahead(h, slot);
   if (h->fused_ok && (h->c16 || h->s2) && (h->bwd_mfma || !is_sharded(h))) {   // its forward half: the same sweep with this pass's draw(s)
-    h->mon_tail.enabled = 0;   // (a monitor tail still pending belongs to a ca_iterate pass whose ELBO nobody reads; ca_run has flushed its own)
+    if (h->c16) CACK(flush_mon_tail(h));   // (9..16 clones: a pending tail is a real monitor pass's)
+    h->mon_tail.enabled = 0;   // (mc_samples = 2: a tail still pending belongs to a ca_iterate pass whose ELBO nobody reads; ca_run has flushed its own)
     CACK(h->s2 ? fused_pass(h, 2 * slot, 2 * slot + 1, h->terms_dev + 3) : fused_pass(h, slot, slot, h->terms_dev + 3));   // (the monitor role's ELBO is scratch)
     return train_from_lookahead(h, slot);
   }
@@ -1888,7 +1893,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
           variant_on(h, CA_VAR_FWD_MFMA, "CA_FWD_MFMA") && variant_on(h, CA_VAR_FWD_CELL, "CA_FWD_CELL");
   h->fused_ok = ((S == 1 && (C <= CA_CW || h->c16)) || h->s2) && variant_on(h, CA_VAR_FUSED, "CA_FUSED");
   if (!h->fused_ok) { if (h->nchunk == 2) h->bwd_mfma = false; h->c16 = false; h->s2 = false; }
-  if (h->c16 || h->s2) h->pair_elbo = false;   // (two draws per sweep need two column halves of their own)
+  if (h->s2) h->pair_elbo = false;   // (two draws per sweep need two column halves of their own)
   if (h->fused_ok) {
     h->frow = (2 * C <= 8) ? 8 : 16;
     // matrix-core forward sweep (k_fwd_mfma): D in {1, 2}; few gene slices, streamed through LDS
@@ -1939,7 +1944,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
       h->fkchunk = cdiv(h->nk32, h->fsplit);
       h->fsplit = cdiv(h->nk32, h->fkchunk);
       zsplit = h->fsplit;
-      CACK(dalloc(h, &h->Mq, (int64_t)h->nk32 * 2 * 64 * 8));   // zero-filled: padding genes and columns stay 0
+      CACK(dalloc(h, &h->Mq, (int64_t)h->nk32 * 2 * 64 * 8 * (h->c16 ? 2 : 1)));   // zero-filled: padding genes and columns stay 0 (9..16 clones: one image per draw)
     } else {
       CACK(dalloc(h, &h->Mb2, (int64_t)G * h->frow));
     }
@@ -2630,7 +2635,7 @@ int ca_iterate(ca_handle h, int32_t n_iter, const float* eps_stream, int64_t n_d
   // separate cell epilogue, the Y stream in line: 0.65 ms at cfg-3, 4 % of a 20-iteration call) its forward half takes the fused
   // matrix-core sweep with its own draw in both column halves; the monitor half's ELBO goes to a scratch slot.
   // (sharded with the general backward sweep the extra monitor tail would cost a collective of its own: plain kernels there)
-  if (n_iter > 0 && h->fused_ok && !h->c16 && !h->s2 && !h->look_valid && (h->bwd_mfma || !is_sharded(h)))
+  if (n_iter > 0 && h->fused_ok && !h->s2 && !h->look_valid && (h->bwd_mfma || !is_sharded(h)))
     CACK(fused_pass(h, 0, 0, h->elbo_dev + n_iter));
   for (int i = 0; i < n_iter; ++i) {
     // (the last monitor pass has no train pass to share its sweep with: its own draw in both halves, as above -- the plain
