@@ -1183,6 +1183,7 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
 #define CA_YS_RIDE_DEPTH 1   // (lab: pieces in flight per stream wave)
 #endif
     if (h->fc_tl == 6) CA_FCYS_D(6, CA_YS_RIDE_DEPTH);
+    else if (h->fc_tl == 1 && !h->c16) { if (h->D == 1) CA_FCYS(1, 1, CA_YS_RIDE_DEPTH, false); else CA_FCYS(2, 1, CA_YS_RIDE_DEPTH, false); }
     else CA_FCYS_D(2, CA_YS_RIDE_DEPTH);
 #undef CA_FCYS_D
 #undef CA_FCYS
@@ -1910,6 +1911,11 @@ int create_impl(ca_engine* h, const ca_problem* p) {
       // (16-cell blocks, fc_tl = 1, were tried for shards below 16k cells -- twice the waves per SIMD -- and lost: 12.5k cells
       //  39 us against 35, every block re-reads the B operand)
       h->fc_tl = (h->fwd_cell && cdiv(Nn, 64) < 2 * h->n_cu) ? 2 : 6;
+      // fewer 32-cell blocks than CUs: 16-cell blocks, where the int8 stream rides (round 3, with this round's kernels: 6250 cells
+      // 17.2k -> 18.8k it/s; at 12.5k cells and at 10k x 2k they still lose, 13.7k vs 14.2k and 21.7k vs 22.1k)
+      if (h->fwd_cell && h->fc_tl == 2 && cdiv(Nn, 32) < h->n_cu && h->ystore == CA_YSTORE_U8 && K == 1 && !h->c16 && h->fused_ok &&
+          variant_on(h, CA_VAR_Y_MFMA1, "CA_Y_MFMA1") && variant_on(h, CA_VAR_Y_RIDE, "CA_Y_RIDE") && !variantx_on(h, CA_VARX_Y_MFMA2, "CA_Y_MFMA2"))
+        h->fc_tl = 1;   // (only where the int8 stream will ride: the other streams' merged kernels exist for 32- and 96-cell blocks)
       if (const int t = tune_val(h, CA_TUNE_FC_TL, "CA_FC_TL")) { if (t == 1 || t == 2 || t == 4 || t == 5 || t == 6 || t == 8) h->fc_tl = t; }
       if (h->c16 && h->fc_tl != 2) h->fc_tl = 6;   // (the sixteen-clone kernels exist for the two default block shapes)
       if (h->s2 && !h->fwd_cell) { h->s2 = false; h->fused_ok = false; }
@@ -2049,7 +2055,8 @@ int create_impl(ca_engine* h, const ca_problem* p) {
                !h->y_mfma && !h->y_ys && variant_on(h, CA_VAR_Y_RIDE, "CA_Y_RIDE");
   constexpr bool kRideSeqDefault = false;
   h->ride_seq = h->ride_ok && variant_on(h, CA_VAR_RIDE_SEQ, "CA_RIDE_SEQ") && (kRideSeqDefault || variantx_on(h, CA_VARX_RIDE_SEQ, "CA_RIDE_SEQ_ON"));
-  h->ride_ys = h->y_ys && h->fused_ok && h->fwd_cell && (h->fc_tl == 6 || (h->fc_tl == 2 && h->fc_nbig == 0)) &&
+  const bool tl1_ok = h->fc_tl == 1 && h->fc_nbig == 0 && !h->c16;
+  h->ride_ys = h->y_ys && h->fused_ok && h->fwd_cell && (h->fc_tl == 6 || tl1_ok || (h->fc_tl == 2 && h->fc_nbig == 0)) &&
                variant_on(h, CA_VAR_Y_RIDE, "CA_Y_RIDE");
   h->yfin_split = h->ride_ys && h->bwd_mfma && h->tail_fuse && variant_on(h, CA_VAR_YFIN_RIDE, "CA_YFIN_RIDE");
   h->off_g = 3 + C;
