@@ -2411,8 +2411,9 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
   // One k-step of operands in flight, in TWO register sets used alternately (the loop runs two k-steps per trip): the step at hand
   // reads its set in place while the next one's loads land in the other.  With one set the operands had to be copied out before the
   // refill was issued -- 12 moves per k-step on the issue port the sweep is bound by.
-  uint4 b1r[2], b2r[2];
-  float4 vr[2][NV4];
+  constexpr int NS = (TL <= 2 && !C16) ? 4 : 2;   // operand register sets (32- and 16-cell blocks: three k-steps in flight, see below)
+  uint4 b1r[NS], b2r[NS];
+  float4 vr[NS][NV4];
   // C16: the second draw's sixteen columns are a second pair of B operands (its image follows the first draw's) and a second set of
   // accumulators -- six MFMAs per tile and k-step on ONE exp and one bf16 split, instead of a sweep per draw
   [[maybe_unused]] uint4 b1s[2], b2s[2];
@@ -2469,19 +2470,84 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
       }
     }
   };
-  fetch(0, wv < nk ? wv : nk - 1);
-  [[maybe_unused]] const int prio_q = ((nk - wv + 7) / 8 + 3) / 4;
-  [[maybe_unused]] int prio_i = 0;
-  for (int ks = wv; ks < nk; ks += 8) {   // wave-uniform bounds
-    CA_PRIO_STEP(prio_i, prio_q);
-    ++prio_i;
-    const bool more = ks + 4 < nk;
-    if (more) fetch(1, ks + 4);
-    step(0);
-    if (more) {
-      if (ks + 8 < nk) fetch(0, ks + 8);
-      step(1);
+  // The loop body is ONE basic block: a pair of k-steps, no branch inside (the last pair and the odd last k-step are peeled, so
+  // every load is consumed; the priority changes between four loops instead of inside one).  With branches in the body the
+  // compiler's wait-count pass met the loop header with loads outstanding from several paths and waited for ALL of them at the top of
+  // every k-step (s_waitcnt vmcnt(0) ... vmcnt(2) where vmcnt(4) would do) -- the operands fetched one step earlier were then waited for
+  // right away.  With four or five waves per SIMD (cfg-3) others fill that; a small shard's one or two waves ran every k-step at the L2's
+  // latency: 1370 cycles against 420 of issue (profiles/r03_ab_ystream.txt section 16).
+  const int nkw = nk > wv ? (nk - wv + 3) / 4 : 0;          // this wave's k-steps: wv, wv + 4, ...
+  if constexpr (NS == 4) {
+    // Small blocks compute 0.2 us per k-step, a third of an L2 round trip: THREE k-steps of operands in flight, four register sets
+    // in rotation, four k-steps per trip of a branch-free loop.  Refills past the end re-read the last k-step (never used); the
+    // explicit wait behind the loop makes sure they have landed before their registers mean anything else.
+    auto kc = [&](int i) { return wv + 4 * (i < nkw ? i : nkw - 1); };
+    if (nkw > 0) { fetch(0, kc(0)); fetch(1, kc(1)); fetch(2, kc(2)); }
+    const int ntrip = nkw >> 2;
+    int ti = 0;
+#if CA_PROG_PRIO
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      const int tend = qd == 3 ? ntrip : (ntrip * (qd + 1)) / 4;
+      if (qd == 0) __builtin_amdgcn_s_setprio(3);
+      else if (qd == 1) __builtin_amdgcn_s_setprio(2);
+      else if (qd == 2) __builtin_amdgcn_s_setprio(1);
+      else __builtin_amdgcn_s_setprio(0);
+#else
+    {
+      const int tend = ntrip;
+#endif
+      for (; ti < tend; ++ti) {
+        const int i0 = 4 * ti;
+        fetch(3, kc(i0 + 3)); __builtin_amdgcn_sched_barrier(0); step(0); __builtin_amdgcn_sched_barrier(0);
+        fetch(0, kc(i0 + 4)); __builtin_amdgcn_sched_barrier(0); step(1); __builtin_amdgcn_sched_barrier(0);
+        fetch(1, kc(i0 + 5)); __builtin_amdgcn_sched_barrier(0); step(2); __builtin_amdgcn_sched_barrier(0);
+        fetch(2, kc(i0 + 6)); __builtin_amdgcn_sched_barrier(0); step(3); __builtin_amdgcn_sched_barrier(0);
+      }
     }
+    const int rem = nkw - 4 * ntrip;   // 0 .. 3 k-steps left, their operands in sets 0, 1, 2
+    if (rem > 0) step(0);
+    if (rem > 1) step(1);
+    if (rem > 2) step(2);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+  const int npair = nkw >> 1, nloop = npair > 0 ? npair - 1 : 0;   // pairs in the loops; the last pair follows them
+  auto kof = [&](int i) { return wv + 4 * i; };
+  if (nkw > 0) fetch(0, kof(0));
+  int pi = 0;
+#if CA_PROG_PRIO
+#pragma unroll
+  for (int qd = 0; qd < 4; ++qd) {
+    const int pend = qd == 3 ? nloop : (nloop * (qd + 1)) / 4;
+    if (qd == 0) __builtin_amdgcn_s_setprio(3);
+    else if (qd == 1) __builtin_amdgcn_s_setprio(2);
+    else if (qd == 2) __builtin_amdgcn_s_setprio(1);
+    else __builtin_amdgcn_s_setprio(0);
+#else
+  {
+    const int pend = nloop;
+#endif
+    for (; pi < pend; ++pi) {
+      fetch(1, kof(2 * pi + 1));
+      __builtin_amdgcn_sched_barrier(0);   // (the loads stay IN FRONT of the k-step they run beside: the scheduler otherwise sinks them
+      step(0);                             //  to their first use, which is the end of a prefetch)
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(0, kof(2 * pi + 2));
+      __builtin_amdgcn_sched_barrier(0);
+      step(1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (npair > 0) {   // the last pair: its refill only if an odd k-step follows
+    fetch(1, kof(2 * nloop + 1));
+    __builtin_amdgcn_sched_barrier(0);
+    step(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (nkw & 1) fetch(0, kof(nkw - 1));
+    __builtin_amdgcn_sched_barrier(0);
+    step(1);
+  }
+  if (nkw & 1) step(0);
   }
   CA_PRIO_DONE();
 #pragma unroll
