@@ -97,7 +97,7 @@ def _bench(world, extra, same_device=True):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2",
            "--repeats", "2", "--cells", "20000", "--genes", "1000", "--clones", "4", "--no-cpu-baseline", "--busy-seconds", "0", *extra]
-    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420, cwd=ROOT)   # (a run takes 15-60 s)
 
 
 def test_bench_two_ranks_use_a_device_transport_and_fail_loudly_without_one():
