@@ -51,6 +51,32 @@ def algorithmic_work(kernel, N, G, C, K, fused=False, steps=1, ride=False):
     return "hbm", 0.0
 
 
+def agreed_calls(budget_ms, call_ms, cap=4096):
+    """How many equal calls fill ``budget_ms`` when one takes ``call_ms`` -- a pure function of two numbers every rank holds
+    identically (call_ms is the all-reduced MAX), so a loop of collective calls sized by it has the same length on every rank."""
+    if not (call_ms > 0.0):
+        return 1
+    return int(min(max(1, -(-budget_ms // call_ms)), cap))
+
+
+def run_agreed_calls(call, budget_ms, dist=None):
+    """Fill about ``budget_ms`` with equal calls of ``call`` -- which may be COLLECTIVE (every rank must make the same number of
+    them): one call is timed, the slowest rank's time is agreed on (all-reduce MAX over ``dist``, the control-plane group), the
+    count follows from that one number, the remaining calls run.  Returns the number of calls made (the same on every rank)."""
+    t0 = time.perf_counter()
+    call()
+    call_ms = (time.perf_counter() - t0) * 1e3
+    if dist is not None:
+        import torch
+        t = torch.tensor([call_ms], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        call_ms = float(t[0])
+    n = agreed_calls(budget_ms, call_ms)
+    for _ in range(n - 1):
+        call()
+    return n
+
+
 def pmc_traffic(build_id, kernel_class):
     """HBM bytes per launch of a kernel class from the PMC passes committed under profiles/ -- only from a file that was
     collected on THIS build of the library (matching ca_build_id) and only under the class's own key; else None."""
@@ -329,13 +355,15 @@ def main():
     #     322 us right after an idle gap to 289 us 30 ms later, the merged forward launch from 151 to 135 us.  W = 5 warm-up steps are
     #     1.6 ms of work, and a 20-step timed region is 6 ms: without this the whole region sits on the ramp and measures the power
     #     management, not the kernels.  The same iterations, the same arguments as the timed call; `preheat_ms` is in the output.
-    pre_it, t_pre = 0, time.perf_counter()
+    #     At world > 1 every ca_iterate call is collective (one all-reduce per pass), so the NUMBER of pre-heat calls must be the same
+    #     on every rank: one call is timed, the slowest rank's time is agreed on (gloo MAX) and the call count follows from it --
+    #     a loop that lets each rank's own clock decide ran one call more on one rank than on its peer (r03: CA_ERR_COMM after 10 s).
+    pre_it, pre_calls, t_pre = 0, 0, time.perf_counter()
     if args.preheat_ms > 0:
         barrier()
         t_pre = time.perf_counter()
-        while (time.perf_counter() - t_pre) * 1e3 < args.preheat_ms:
-            eng.iterate(args.steps, eps_t)
-            pre_it += args.steps
+        pre_calls = run_agreed_calls(lambda: eng.iterate(args.steps, eps_t), args.preheat_ms, dist if world > 1 else None)
+        pre_it = pre_calls * args.steps
     pre_ms = (time.perf_counter() - t_pre) * 1e3
     # --- timed: `repeats` regions of exactly `steps` iterations, each bracketed by barrier + synchronize on both sides and
     #     maxed over the ranks; the quoted value is the MEDIAN region (a 20-step region at cfg-3 is only 6 ms long)
@@ -495,7 +523,7 @@ def main():
                               "what": "ca_reinit (initial values, fresh Adam state), ca_run + 20 final ELBOs, eps generated by the "
                                       "built-in Philox stream (inside the time)"},
         }
-        out["preheat"] = {"ms": pre_ms, "iterations": pre_it,
+        out["preheat"] = {"ms": pre_ms, "iterations": pre_it, "calls": pre_calls,
                           "what": "untimed iterations between the --warmup steps and the timed regions (clock ramp; see --preheat-ms)"}
         if busy_it:
             out["untimed_busy_tail"] = {"seconds": busy_s, "iterations": busy_it, "it_per_s": busy_it / busy_s,
@@ -529,4 +557,10 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except SystemExit:
+        raise
+    except BaseException as ex:   # a launcher prints only its own traceback: say which rank failed and why, then fail the same way
+        print(f"[rank {os.environ.get('RANK', '0')}] bench.py: {type(ex).__name__}: {ex}", file=sys.stderr, flush=True)
+        raise

@@ -134,7 +134,7 @@ struct ca_engine {
   double* red = nullptr; int64_t red_n = 0, off_g = 0, off_y = 0;
   double* elbo_dev = nullptr; int64_t elbo_cap = 0; double* terms_dev = nullptr;
   double* host_pinned = nullptr;  // 8 doubles
-  bool ycache_valid = false, sums_global = false;
+  bool ycache_valid = false, sums_global = false, sums_started = false;
   // fused two-eps sweep (monitor pass of iteration i + forward half of train pass i+1, same parameters)
   bool fused_ok = false, look_valid = false; int64_t look_slot = 0; int frow = 8;
   float *Mb2 = nullptr, *mu32B = nullptr, *Zpart2 = nullptr; double* gene_partB = nullptr;
@@ -830,6 +830,9 @@ int allreduce(ca_engine* h, double* buf, int64_t n) {
 // the per-gene count totals are sums over ALL cells: reduced once, when the transport is set
 int setup_global_sums(ca_engine* h) {
   if (h->sums_global) return CA_OK;
+  // a transport that died between the two reductions leaves colsum reduced and YtX not: no second transport may reduce colsum again
+  if (h->sums_started) { h->err = "an earlier transport failed inside the setup reductions; this engine cannot take another one -- destroy it"; return CA_ERR_STATE; }
+  h->sums_started = true;
   CACK(allreduce(h, h->colsum, h->G));
   if (h->P > 0 && h->K > 0) CACK(allreduce(h, h->YtX, (int64_t)h->G * h->P));
   SYNC(h);
@@ -1472,13 +1475,13 @@ int stage_eps(ca_engine* h, const float* eps_stream, int64_t have, int64_t need)
     // host threads -- same values whatever the thread count -- straight into a pinned staging buffer the engine keeps
     // (pageable memory cost 1.5 ms of copy for 8 MB; with 16 threads the 402 draws of a default fit took 3.3 ms in all)
     const size_t bytes = (size_t)need * per * sizeof(float);
+    if (h->ev_stage) HIPCK(h, hipEventSynchronize(h->ev_stage));   // the copy that last read the buffer is done BEFORE it is freed or refilled
     if (bytes > h->eps_stage_bytes) {
       if (h->eps_stage) HIPCK(h, hipHostFree(h->eps_stage));
       h->eps_stage = nullptr; h->eps_stage_bytes = 0;
       HIPCK(h, hipHostMalloc((void**)&h->eps_stage, bytes));
       h->eps_stage_bytes = bytes;
     }
-    if (h->ev_stage) HIPCK(h, hipEventSynchronize(h->ev_stage));
     float* out = h->eps_stage;
     const int64_t nt = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(need / 4, 48), (int64_t)std::thread::hardware_concurrency() / 2));
     if (nt > 1 && need * per >= (1 << 16)) {
@@ -2340,6 +2343,8 @@ int ca_get_info(ca_handle h, ca_info* i) {
   i->y_ride = (h->ride_ok || h->ride_ys) ? 1 : 0;
   i->transport = (h->p2p && h->p2p->connected) ? CA_TRANSPORT_P2P : h->comm ? CA_TRANSPORT_RCCL : h->host_ar ? CA_TRANSPORT_HOST : CA_TRANSPORT_NONE;
   i->red_n = h->red_n;
+  i->fwd_block_cells = (h->fused_ok && h->fwd_cell) ? 16 * h->fc_tl : 0; i->fwd_blocks_big = h->fc_nbig;
+  i->fold_gsum = (h->fold_gsum && !is_sharded(h)) ? 1 : 0; i->yfin_split = (h->yfin_split && !is_sharded(h)) ? 1 : 0;
   return CA_OK;
 }
 
@@ -2361,6 +2366,7 @@ int ca_comm_unique_id(char id[128]) {
 
 int ca_comm_init(ca_handle h, const char id[128]) {
   if (!h || !id) return CA_ERR_INVALID;
+  CACK(comm_check(h));   // a peer-to-peer transport that timed out leaves the engine dead: no falling back on the same handle
   if (!g_rccl.load()) { h->err = g_rccl.err; return CA_ERR_COMM; }
   HIPCK(h, hipSetDevice(h->device));
   ca_nccl_uid u;
@@ -2530,6 +2536,7 @@ int ca_comm_benchmark(ca_handle h, int32_t transport, int32_t n_calls, int64_t n
 
 int ca_set_host_allreduce(ca_handle h, ca_host_allreduce_fn fn, void* user) {
   if (!h || !fn) return CA_ERR_INVALID;
+  CACK(comm_check(h));
   HIPCK(h, hipSetDevice(h->device));
   h->host_ar = fn;
   h->host_ar_user = user;

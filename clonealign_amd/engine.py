@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libclonealign_hip.so")
 CA_OK = 0
 CA_ERR_NAN = 4
 CA_INTERRUPTED = 7
-CA_ABI_VERSION = 3
+CA_ABI_VERSION = 4
 P2P_HANDLE_BYTES = 128
 CA_F64, CA_F32, CA_I32, CA_U16, CA_U8 = 0, 1, 2, 3, 4
 CA_ROW_MAJOR, CA_COL_MAJOR = 0, 1
@@ -60,7 +60,8 @@ class CaInfo(C.Structure):
                 ("y_device_bytes", C.c_int64), ("device_bytes", C.c_int64), ("gsplit", C.c_int32),
                 ("csplit", C.c_int32), ("n_cu", C.c_int32), ("fused_sweep", C.c_int32), ("fwd_mfma", C.c_int32),
                 ("bwd_mfma", C.c_int32), ("fsplit", C.c_int32), ("fwd_cell", C.c_int32), ("y_mfma", C.c_int32),
-                ("transport", C.c_int32), ("y_ride", C.c_int32), ("red_n", C.c_int64)]
+                ("transport", C.c_int32), ("y_ride", C.c_int32), ("red_n", C.c_int64),
+                ("fwd_block_cells", C.c_int32), ("fwd_blocks_big", C.c_int32), ("fold_gsum", C.c_int32), ("yfin_split", C.c_int32)]
 
 
 class CaPreprocessParams(C.Structure):

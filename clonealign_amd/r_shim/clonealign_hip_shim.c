@@ -2,7 +2,7 @@
  * R-side binding of libclonealign_hip.so: the `.Call` stub a clonealign maintainer adds under src/.
  * The build image has no R toolchain, so the suite compiles it against a minimal stand-in for the R API
  * (tests/r_stub/, tests/test_shim_compiles.py) and drives C_clonealign_fit from a C harness on the GPU box
- * (tests/test_gpu_shim.py); it is the reference-side half of the boundary documented in INTEGRATION.md and mirrors,
+ * (tests/test_gpu_boundary.py); it is the reference-side half of the boundary documented in INTEGRATION.md and mirrors,
  * call for call, what clonealign_amd/engine.py does through ctypes with layout="col".
  *
  * Replaces the body of inference_tflow() between R/inference-tflow.R:240 (graph build) and :457
@@ -119,7 +119,8 @@ SEXP C_clonealign_fit(SEXP Y, SEXP L, SEXP psi0, SEXP loc0, SEXP X, SEXP extra, 
  *     psi0       list of R numeric matrices N x K (one per restart: pcs + rnorm noise, :204-208), or NULL when psi_noise is given
  *     psi_noise  list of R numeric matrices N x K: psi is then initialised ON THE DEVICE (ca_init_psi_pca: prcomp + scale of
  *                :204-208 by subspace iteration over the resident counts) plus this noise (the reference's rnorm(.., 0, 0.05))
- *     eps        list of R numeric vectors, each (2 + 2 max_iter + 20) S G rnorm() draws, or NULL (built-in stream, seeded per restart)
+ *     eps        list of R numeric vectors, each (2 + 2 max_iter + 20) S G rnorm() draws, or NULL: the engines' built-in Philox stream,
+ *                seeded PER DEVICE (seed + 1000003 d); a device's stream simply continues across its restarts (ca_reinit keeps it)
  *     want_sums  TRUE: each fit also carries T (G x C) and Syy (G), the sums compute_correlations() (:318-334) needs, taken on the
  *                device for the cells assigned with probability >= clone_call_probability (:22-29)
  *   returns a list of R fits, each list(mu, clone_probs, s, alpha, beta, psi, W, chi, elbo, final_elbos[, T, Syy])
@@ -191,6 +192,9 @@ static void* worker_main(void* arg_) {
   }
 done:
 #undef WFAIL
+  /* a failed device dooms the whole call (the R thread raises the error once everybody has joined): make the siblings stop at their
+   * next poll instead of running their remaining restarts into results that will be thrown away */
+  if (a->rc != CA_OK && a->rc != CA_INTERRUPTED) *a->cancel = 1;
   if (h) ca_destroy(h);
   free(epsf); free(call); free(zeros);
   return NULL;
@@ -295,8 +299,12 @@ SEXP C_clonealign_multifit(SEXP Y, SEXP L, SEXP psi0, SEXP psi_noise, SEXP loc0,
   }
   if (started < n_workers) { UNPROTECT(1); Rf_error("clonealign_multifit: cannot start a worker thread"); }
   if (interrupted) { UNPROTECT(1); Rf_error("clonealign: interrupted"); }
-  for (int d = 0; d < n_workers; ++d)
-    if (wa[d].rc != CA_OK) { char msg[600]; snprintf(msg, sizeof(msg), "device %d: %s", wa[d].o.device, wa[d].err); UNPROTECT(1); Rf_error("clonealign_multifit: %s", msg); }
+  for (int pass = 0; pass < 2; ++pass)                       /* the device that FAILED first; siblings it stopped report CA_INTERRUPTED */
+    for (int d = 0; d < n_workers; ++d)
+      if (wa[d].rc != CA_OK && (pass == 1 || wa[d].rc != CA_INTERRUPTED)) {
+        char msg[600]; snprintf(msg, sizeof(msg), "device %d: %s", wa[d].o.device, wa[d].rc == CA_INTERRUPTED ? "stopped" : wa[d].err);
+        UNPROTECT(1); Rf_error("clonealign_multifit: %s", msg);
+      }
   for (int r = 0; r < n_fits; ++r) {                         /* the trace is as long as the loop ran (:414 may stop it early) */
     SEXP f = VECTOR_ELT(fits, r);
     SET_VECTOR_ELT(f, 8, Rf_xlengthgets(VECTOR_ELT(f, 8), outs[r].n_elbo));

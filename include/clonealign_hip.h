@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CA_ABI_VERSION 3
+#define CA_ABI_VERSION 4
 
 typedef struct ca_engine* ca_handle;
 
@@ -164,6 +164,11 @@ typedef struct ca_info {
   int32_t transport;         /* 0 none, 1 RCCL all-reduce, 2 host callback, 3 one-shot peer-to-peer (ca_transport) */
   int32_t y_ride;            /* 1: the Y stream's blocks ride on the fused forward sweep's launch (k_fwd_cell_mix_y): no launch of its own */
   int64_t red_n;             /* doubles all-reduced per train pass (= sharding.reduce_plan(...)["total"]) */
+  /* ABI 4: which decomposition the shape selected (the tests assert that their shapes cross every threshold) */
+  int32_t fwd_block_cells;   /* cells per block of the fused forward sweep: 16, 32 or 96 (0: no fused forward sweep) */
+  int32_t fwd_blocks_big;    /* > 0: mixed launch, that many blocks of fwd_block_cells cells, the rest 32-cell blocks */
+  int32_t fold_gsum;         /* 1: the backward sweep's per-gene partials are summed inside the per-gene kernel (unsharded small problems) */
+  int32_t yfin_split;        /* 1: the Y stream's finishing step is split between the forward and backward launches */
 } ca_info;
 enum ca_transport { CA_TRANSPORT_NONE = 0, CA_TRANSPORT_RCCL = 1, CA_TRANSPORT_HOST = 2, CA_TRANSPORT_P2P = 3 };
 

@@ -18,8 +18,10 @@ party arithmetic is restated from the published definitions:
   * TransformedDistribution(Normal, Softplus).log_prob(y) = Normal.log_prob(x) + softplus(-x),
     x = softplus^-1(y)                                                               (:260-266,332)
   * tf.train.AdamOptimizer (TF1 form, epsilon outside the bias correction)          (:345-346)
+Each of these formulas is checked to 1e-12 against torch.distributions objects mirroring the tfd$ calls one to one and
+against scipy.stats, and the Adam rule against a decimal-arithmetic table: tests/test_oracle_pin.py.
 The only numeric known-answer the reference ships is the rendered vignette run
-(docs/introduction_to_clonealign.html:816-819,908): see tests/test_oracle_vignette_kat.py.
+(docs/introduction_to_clonealign.html:816-819,908): see tests/test_host_api.py::test_vignette_known_answer_soft.
 Otherwise: **parity unpinned** against the TensorFlow path itself.
 """
 import math

@@ -1,4 +1,4 @@
-/* C harness that calls the R shim's .Call entry point exactly as R would (tests/test_gpu_shim.py loads it with ctypes).
+/* C harness that calls the R shim's .Call entry point exactly as R would (tests/test_gpu_boundary.py loads it with ctypes).
  * Inputs are column-major, like R matrices.  Returns 0, or 1 with the Rf_error() text in err. */
 #include <setjmp.h>
 #include <stdio.h>

@@ -11,6 +11,8 @@ import sys
 import numpy as np
 import pytest
 
+from tests._cases import child_report
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SHAPE = ["--cells", "6000", "--genes", "700", "--clones", "5", "--iters", "6"]
@@ -22,9 +24,9 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run(world, transport, out, same_device):
+def _launch(world, transport, out, same_device, shape=None, extra=()):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    script = [os.path.join(ROOT, "tools", "dist_check.py"), "--transport", transport, "--out", str(out), *SHAPE]
+    script = [os.path.join(ROOT, "tools", "dist_check.py"), "--transport", transport, "--out", str(out), *(shape or SHAPE), *extra]
     if same_device:
         script.append("--same-device")
     if world == 1:
@@ -32,8 +34,12 @@ def _run(world, transport, out, same_device):
     else:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port()), *script]
-    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+
+
+def _run(world, transport, out, same_device, shape=None):
+    r = _launch(world, transport, out, same_device, shape)
+    assert r.returncode == 0, child_report(r)
     return json.load(open(out))
 
 
@@ -47,7 +53,7 @@ def single(tmp_path_factory):
     return _run(1, "none", tmp_path_factory.mktemp("dist") / "one.json", True)["ranks"][0]
 
 
-def _check(res, single, transport):
+def _check(res, single, transport, cells=6000):
     ranks = res["ranks"]
     assert [r["transport"] for r in ranks] == [transport] * len(ranks)
     # the engine's all-reduce payload is the plan shared with the host side (clonealign_amd/sharding.py)
@@ -64,7 +70,7 @@ def _check(res, single, transport):
     for n, v in ranks[0]["rep"].items():
         a, b = np.array(v), np.array(single["rep"][n])
         assert np.abs(a - b).max() <= 1e-5 * max(np.abs(b).max(), 1e-30), n
-    assert ranks[0]["lo"] == 0 and ranks[-1]["hi"] == 6000 and all(a["hi"] == b["lo"] for a, b in zip(ranks, ranks[1:]))
+    assert ranks[0]["lo"] == 0 and ranks[-1]["hi"] == cells and all(a["hi"] == b["lo"] for a, b in zip(ranks, ranks[1:]))
 
 
 def test_two_ranks_on_one_gpu_peer_to_peer_allreduce(tmp_path, single):
@@ -80,6 +86,53 @@ def test_two_ranks_on_one_gpu_host_callback_over_gloo(tmp_path, single):
     _check(_run(2, "host", tmp_path / "host.json", True), single, "host")
 
 
+# Per-rank shard sizes on BOTH sides of every threshold of the engine's kernel selection (clonealign_hip.hip create_impl: forward
+# blocks of 16 cells below 8192 cells per rank, 32 below 32768, 96 above; the small-problem folds are off when sharded), each
+# against the one-handle fit of the same cells -- which itself takes a different decomposition.
+THRESHOLD_SHAPES = {
+    "2x3k_blocks16": (2, ["--cells", "6000", "--genes", "700", "--clones", "5", "--iters", "6"], 16),
+    "2x10k_blocks32": (2, ["--cells", "20000", "--genes", "400", "--clones", "4", "--iters", "4"], 32),
+    "3x33k_blocks96": (3, ["--cells", "100000", "--genes", "300", "--clones", "8", "--iters", "3"], 96),
+    "2x50k_blocks96": (2, ["--cells", "100000", "--genes", "260", "--clones", "3", "--iters", "3"], 96),
+}
+
+
+@pytest.mark.parametrize("name", list(THRESHOLD_SHAPES))
+def test_ranks_on_one_gpu_at_shard_sizes_across_the_kernel_selection_thresholds(tmp_path, name):
+    world, shape, block = THRESHOLD_SHAPES[name]
+    cells = int(shape[1])
+    one = _run(1, "none", tmp_path / "one.json", True, shape)["ranks"][0]
+    res = _run(world, "p2p", tmp_path / "p2p.json", True, shape)
+    assert [r["fwd_block_cells"] for r in res["ranks"]] == [block] * world, [r["fwd_block_cells"] for r in res["ranks"]]
+    _check(res, one, "p2p", cells)
+
+
+def test_eight_ranks_on_one_gpu_with_the_cfg4_gene_count(tmp_path):
+    """W = 8 flag lanes / inbox slabs and the all-reduce payload of BASELINE.json configs[3] (G = 5000, C = 8: 15 011 doubles per
+    train pass) -- eight PROCESSES sharing device 0, 1000 cells each, against the one-handle fit."""
+    shape = ["--cells", "8000", "--genes", "5000", "--clones", "8", "--iters", "3"]
+    one = _run(1, "none", tmp_path / "one.json", True, shape)["ranks"][0]
+    res = _run(8, "p2p", tmp_path / "p2p8.json", True, shape)
+    assert len(res["ranks"]) == 8 and res["ranks"][0]["red_n"] == 3 + 8 + 5000 * 2 + 5000
+    _check(res, one, "p2p", 8000)
+
+
+@pytest.mark.parametrize("world,who", [(2, 0), (3, 2)])
+def test_a_rank_that_makes_one_collective_call_too_many_fails_within_the_time_limit(tmp_path, world, who):
+    """The failure mode of r03's red record, as a test: one rank enters a collective call its peers never make.  The device-side
+    wait gives up after comm_timeout_ms (1.5 s here), the call returns CA_ERR_COMM, that process exits non-zero, the launcher
+    takes the others down -- nothing hangs, nothing reports a number."""
+    import time
+    t0 = time.perf_counter()
+    r = _launch(world, "p2p", tmp_path / "x.json", True, extra=["--extra-call-rank", str(who), "--comm-timeout-ms", "1500"])
+    dt = time.perf_counter() - t0
+    assert r.returncode != 0, child_report(r)
+    said = [l for l in r.stderr.splitlines() if l.startswith(f"[rank {who}] dist_check: extra collective call failed")]
+    assert said and "code 5" in said[0] and "did not arrive" in said[0], child_report(r)
+    assert float(said[0].split("after ")[1].split(" s")[0]) < 6.0, said[0]
+    assert not os.path.exists(tmp_path / "x.json") and dt < 240, dt
+
+
 @pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs (RCCL refuses two ranks on one device)")
 def test_two_gpus_rccl_allreduce(tmp_path, single):
     _check(_run(2, "rccl", tmp_path / "rccl.json", False), single, "rccl")
@@ -90,13 +143,13 @@ def test_two_gpus_peer_to_peer_allreduce(tmp_path, single):
     _check(_run(2, "p2p", tmp_path / "p2p2.json", False), single, "p2p")
 
 
-def _bench(world, extra, same_device=True):
+def _bench(world, extra, same_device=True, shape=("--cells", "20000", "--genes", "1000", "--clones", "4")):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     if same_device:
         env["CLONEALIGN_BENCH_DEVICE"] = "0"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2",
-           "--repeats", "2", "--cells", "20000", "--genes", "1000", "--clones", "4", "--no-cpu-baseline", "--busy-seconds", "0", *extra]
+           "--repeats", "2", *shape, "--no-cpu-baseline", "--busy-seconds", "0", *extra]
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420, cwd=ROOT)   # (a run takes 15-60 s)
 
 
@@ -105,7 +158,7 @@ def test_bench_two_ranks_use_a_device_transport_and_fail_loudly_without_one():
     asking for RCCL -- which refuses two ranks on one device -- must exit non-zero instead of quietly measuring a host path,
     and only --allow-host-fallback lets such a run through (marked as what it is)."""
     r = _bench(2, [])
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert r.returncode == 0, child_report(r)
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["collective"] == "p2p" and line["config"]["collectives_tried"] == ["p2p"]
     assert line["scaling"] == "strong" and line["value"] > 0 and line["repeats"]["n"] == 2
@@ -114,9 +167,24 @@ def test_bench_two_ranks_use_a_device_transport_and_fail_loudly_without_one():
         r = _bench(2, ["--collective", "rccl"])
         assert r.returncode != 0 and "refusing to report" in r.stderr
         r = _bench(2, ["--collective", "rccl", "--allow-host-fallback"])
-        assert r.returncode == 0, r.stderr[-2000:]
+        assert r.returncode == 0, child_report(r)
         line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
         assert line["config"]["collective"] == "gloo-host-fallback" and line["config"]["collectives_tried"] == ["rccl", "host"]
+
+
+def test_bench_preheat_makes_the_same_number_of_collective_calls_on_every_rank():
+    """the clock pre-heat is a loop of collective calls; its length must be agreed on, not decided by each
+    rank's own clock.  A long pre-heat of short calls (about 150 calls here) gives a per-rank clock every chance to disagree;
+    three ranks, 96-cell blocks (34k cells per rank), then two ranks again."""
+    r = _bench(3, ["--preheat-ms", "400"], shape=("--cells", "102000", "--genes", "300", "--clones", "8"))
+    assert r.returncode == 0, child_report(r)
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 3 and line["config"]["collective"] == "p2p" and line["preheat"]["calls"] >= 2
+    assert line["preheat"]["iterations"] == line["preheat"]["calls"] * 6
+    r = _bench(2, ["--preheat-ms", "300"])
+    assert r.returncode == 0, child_report(r)
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["preheat"]["calls"] >= 20, line["preheat"]
 
 
 @pytest.mark.skipif(_gpus() < 8, reason="needs an 8-GPU node (BASELINE.json configs[3]: 100k x 5k x 8 cell-sharded over 8 MI355X)")
@@ -128,7 +196,7 @@ def test_bench_on_eight_gpus_uses_a_device_collective_and_replicas_agree(tmp_pat
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1800, cwd=ROOT)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert r.returncode == 0, child_report(r)
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 8 and line["config"]["collective"] in {"p2p", "rccl"}, line["config"]
     assert line["config"]["allreduce_doubles_per_train_pass"] == 3 + 8 + 5000 * 2 + 5000

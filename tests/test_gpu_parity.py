@@ -26,6 +26,11 @@ CASES = {
 }
 
 
+# clone_assignment (R/inference-tflow.R:22-29) against the oracle: the bound of each comparison is the count OBSERVED on the
+# shipped build (profiles/r04_labels.txt lists every observation with the flipped cells' max-gamma on both sides); 0 = exact
+LABEL_BOUND = {"cfg1_fit": 2, "cfg1_golden": 2}
+
+
 def _mk(name, **eng_kw):
     from clonealign_amd.engine import HipEngine
     from oracle.fused_numpy import FusedModel
@@ -135,11 +140,10 @@ def test_example_sce_full_fit_matches_oracle():
     for k in ("mu", "alpha", "psi", "W", "chi", "clone_probs"):
         assert _rel(pg[k], po[k]) < 1e-4, k
     # labels: a flip is possible only where the oracle itself sits within 1e-3 of the 0.95 threshold; counted and bounded
-    from tests._cases import label_flips
-    flips, far = label_flips(pg["clone_probs"], po["clone_probs"])
+    from tests._cases import record_labels
+    flips, far = record_labels("cfg-1 example_sce, clonealign() 200 iterations, engine vs fused oracle (float32 variables)", pg["clone_probs"], po["clone_probs"])
     n_lab = int((fit_g["clone"] != fit_o["clone"]).sum())
-    print(f"example_sce, 200 iterations: {flips} of 200 labels differ from the oracle's ({far} outside the 1e-3 margin)")
-    assert far == 0 and flips == n_lab and flips <= 2
+    assert far == 0 and flips == n_lab and flips <= LABEL_BOUND["cfg1_fit"]
 
 
 @pytest.mark.parametrize("name,n_iter", [("cfg1", 200), ("tiny_k0", 12), ("tiny_full", 12)])
@@ -158,11 +162,10 @@ def test_engine_replays_golden_vectors(name, n_iter):
         for k, v in p.items():
             assert _rel(v, g["param_" + k]) < 1e-4, k
         if name == "cfg1":
-            from tests._cases import label_flips
+            from tests._cases import record_labels
             lab = clone_assignment(p["clone_probs"], ["A", "B", "C"])
-            flips, far = label_flips(p["clone_probs"], g["param_clone_probs"])
-            print(f"golden cfg1: {flips} of 200 labels differ from the golden's ({far} outside the 1e-3 margin)")
-            assert far == 0 and flips == int((lab != g["clone"]).sum()) and flips <= 2
+            flips, far = record_labels("cfg-1 golden replay, 200 iterations, engine vs committed float64 golden", p["clone_probs"], g["param_clone_probs"])
+            assert far == 0 and flips == int((lab != g["clone"]).sum()) and flips <= LABEL_BOUND["cfg1_golden"]
     finally:
         eng.close()
 

@@ -96,3 +96,48 @@ def test_cell_range_partitions_exactly():
             assert max(sz) - min(sz) <= 1
     with pytest.raises(ValueError):
         cell_range(10, 2, 2)
+
+
+def _bench_mod():
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    return b
+
+
+def test_agreed_calls_is_a_pure_function_of_agreed_numbers():
+    b = _bench_mod()
+    assert b.agreed_calls(60.0, 1.4) == 43 and b.agreed_calls(60.0, 100.0) == 1 and b.agreed_calls(60.0, 0.0) == 1
+    assert b.agreed_calls(1e9, 1.0) == 4096 and b.agreed_calls(60.0, float("nan")) == 1
+
+
+def _preheat_worker(rank, world, port, outdir):
+    """bench.py's pre-heat with a collective call whose duration differs per rank and per call: each rank's OWN clock would stop
+    the loop at a different count (the r03 failure); the agreed count must be equal, and no collective is left unmatched."""
+    import time
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    b = _bench_mod()
+    made = []
+    rng = np.random.default_rng(rank)
+
+    def call():
+        time.sleep(float(rng.uniform(0.0, 0.004)) * (1 + rank))     # host-side skew in front of the collective
+        t = torch.ones(4)
+        dist.all_reduce(t)                                           # the collective: returns only when every rank is in it
+        made.append(float(t[0]))
+    counts = [b.run_agreed_calls(call, 40.0, dist) for _ in range(5)]
+    dist.barrier()
+    np.savez(os.path.join(outdir, f"pre{rank}.npz"), counts=np.array(counts), made=len(made))
+    dist.destroy_process_group()
+
+
+def test_bench_preheat_call_count_is_agreed_over_two_ranks(tmp_path):
+    import torch.multiprocessing as mp
+    mp.spawn(_preheat_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = (np.load(tmp_path / f"pre{i}.npz") for i in range(2))
+    assert np.array_equal(a["counts"], b["counts"]) and int(a["made"]) == int(b["made"]) == int(a["counts"].sum())
+    assert (a["counts"] >= 2).all()

@@ -1,7 +1,7 @@
 """The R-side `.Call` shim (clonealign_amd/r_shim/clonealign_hip_shim.c) compiles cleanly against include/clonealign_hip.h.
 
 The image has no R toolchain, so the R API is a minimal stand-in (tests/r_stub/Rinternals.h: declarations only for the calls
-the shim makes).  This is the CPU half; tests/test_gpu_shim.py calls the compiled entry point on the GPU box."""
+the shim makes).  This is the CPU half; tests/test_gpu_boundary.py calls the compiled entry point on the GPU box."""
 import ctypes
 import os
 import subprocess

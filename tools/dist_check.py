@@ -27,6 +27,10 @@ def main():
     ap.add_argument("--seed", type=int, default=5)
     ap.add_argument("--same-device", action="store_true")
     ap.add_argument("--out", required=True)
+    ap.add_argument("--extra-call-rank", type=int, default=-1,
+                    help="fault injection: this rank makes ONE collective call (ca_elbo) more than its peers after the fit; the call must "
+                         "end in CA_ERR_COMM within --comm-timeout-ms and the process must exit non-zero")
+    ap.add_argument("--comm-timeout-ms", type=int, default=0)
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
@@ -60,13 +64,27 @@ def main():
                 dist.all_reduce(t)
                 buf[:] = t.numpy()
             kw["host_allreduce"] = gloo_sum
-    eng = HipEngine(case["Y"][lo:hi], case["L"], case["psi0"][lo:hi], case["loc0"], 1, 1, device=local, rank=rank, world=world, **kw)
+    eng = HipEngine(case["Y"][lo:hi], case["L"], case["psi0"][lo:hi], case["loc0"], 1, 1, device=local, rank=rank, world=world,
+                    comm_timeout_ms=args.comm_timeout_ms, **kw)
     eps = np.stack([eps_for(1, args.genes, 300 + i) for i in range(2 + 2 * args.iters + 4)])
     trace = eng.run(eps, args.iters, 1e-12)
     finals = eng.final_elbo(eps[2 + 2 * args.iters:], 4)
     info = eng.info()
+    if rank == args.extra_call_rank and world > 1:
+        import time
+        from clonealign_amd.engine import EngineError
+        t0 = time.perf_counter()
+        try:
+            eng.elbo(eps[0])
+        except EngineError as ex:
+            print(f"[rank {rank}] dist_check: extra collective call failed after {time.perf_counter() - t0:.2f} s with code {ex.code}: {ex}",
+                  file=sys.stderr, flush=True)
+            raise SystemExit(7)
+        print(f"[rank {rank}] dist_check: the extra collective call RETURNED (no peer took part in it)", file=sys.stderr, flush=True)
+        raise SystemExit(0)
     rep = {n: eng.get(n).tolist() for n in ("W", "loc", "ls", "alpha_unconstr", "v")}
     mine = dict(rank=rank, trace=trace.tolist(), finals=finals.tolist(), transport=info["transport_name"], red_n=int(info["red_n"]),
+                fwd_block_cells=int(info["fwd_block_cells"]),
                 rep=rep, psi_head=eng.get("psi")[:5, 0].tolist(), lo=lo, hi=hi)
     eng.close()
     if world > 1:
