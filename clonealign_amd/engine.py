@@ -196,7 +196,7 @@ class HipEngine:
                  layout="row", cell_index=None, gene_index=None, variant_off=(), variant_on=(), tune=None, verbose=False,
                  comm_timeout_ms=0, defer_transport=False):
         """``layout``: "row" (C / numpy order) or "col" -- every matrix is then handed over column-major (Fortran order),
-        which is what the R caller has (R/inference-tflow.R:190-191,355) and what r_shim/clonealign_hip_shim.c passes; the
+        which is what the R caller has (R/inference-tflow.R:190-191,355) and what r_shim/src/clonealign_hip_shim.c passes; the
         ``get``/``set`` matrices use the same layout.  ``cell_index`` / ``gene_index``: Y is the RAW matrix and the fit uses
         these rows / columns of it (ca_problem.cell_index / gene_index); L, psi0, loc0, X, extra_loglik are for the selection.
         ``p2p_exchange(handle: bytes) -> list[bytes]`` (world > 1): an all-gather of the ranks' P2P_HANDLE_BYTES-byte handles in

@@ -355,12 +355,4 @@ SEXP C_clonealign_allele_loglik(SEXP clone_allele, SEXP cov, SEXP ref, SEXP devi
   return out;
 }
 
-static const R_CallMethodDef CallEntries[] = {{"C_clonealign_fit", (DL_FUNC)&C_clonealign_fit, 12},
-                                              {"C_clonealign_multifit", (DL_FUNC)&C_clonealign_multifit, 16},
-                                              {"C_clonealign_preprocess", (DL_FUNC)&C_clonealign_preprocess, 9},
-                                              {"C_clonealign_allele_loglik", (DL_FUNC)&C_clonealign_allele_loglik, 4},
-                                              {NULL, NULL, 0}};
-void R_init_clonealign(DllInfo* dll) {
-  R_registerRoutines(dll, NULL, CallEntries, NULL, NULL);
-  R_useDynamicSymbols(dll, FALSE);
-}
+/* registration table: src/init.c */

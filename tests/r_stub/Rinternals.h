@@ -1,4 +1,4 @@
-/* Minimal stand-in for the subset of R's C API that clonealign_amd/r_shim/clonealign_hip_shim.c uses.
+/* Minimal stand-in for the subset of R's C API that clonealign_amd/r_shim/src/clonealign_hip_shim.c uses.
  * TEST INFRASTRUCTURE ONLY (this image has no R): it lets the suite compile the shim and drive C_clonealign_fit from a
  * C harness (tests/r_stub/harness.c).  Semantics follow "Writing R Extensions" section 5.9/6 for the calls listed; nothing here is
  * taken from R's sources. */

@@ -2,7 +2,7 @@
 interrupt hook and the row / column selection at upload.
 
 R hands `Y_dat`, `L_dat`, `pcs`, `x` column-major (R/inference-tflow.R:190-191,355) and expects column-major results; the
-shim (clonealign_amd/r_shim/clonealign_hip_shim.c) therefore sets CA_COL_MAJOR for every matrix.  Everything here is
+shim (clonealign_amd/r_shim/src/clonealign_hip_shim.c) therefore sets CA_COL_MAJOR for every matrix.  Everything here is
 compared with the row-major engine bit for bit: the layout only changes how the host buffers are indexed."""
 import ctypes as C
 import os

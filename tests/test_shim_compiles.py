@@ -1,4 +1,4 @@
-"""The R-side `.Call` shim (clonealign_amd/r_shim/clonealign_hip_shim.c) compiles cleanly against include/clonealign_hip.h.
+"""The R-side `.Call` shim (clonealign_amd/r_shim/src/clonealign_hip_shim.c + src/init.c) compiles cleanly against include/clonealign_hip.h.
 
 The image has no R toolchain, so the R API is a minimal stand-in (tests/r_stub/Rinternals.h: declarations only for the calls
 the shim makes).  This is the CPU half; tests/test_gpu_boundary.py calls the compiled entry point on the GPU box."""
@@ -7,13 +7,51 @@ import os
 import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SHIM = os.path.join(ROOT, "clonealign_amd", "r_shim", "clonealign_hip_shim.c")
+SRC_DIR = os.path.join(ROOT, "clonealign_amd", "r_shim", "src")
+SHIM = os.path.join(SRC_DIR, "clonealign_hip_shim.c")
+INIT = os.path.join(SRC_DIR, "init.c")
 
 
 def test_shim_is_valid_c_against_the_header():
-    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "tests", "r_stub"),
-                        "-I", os.path.join(ROOT, "include"), SHIM], capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
+    for src in (SHIM, INIT):
+        r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "tests", "r_stub"),
+                            "-I", os.path.join(ROOT, "include"), src], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+
+
+def test_registration_table_matches_the_entry_points_and_the_r_calls():
+    """src/init.c registers every SEXP entry point of the shim with the number of arguments its definition takes, and every
+    .Call in R/inference-hip.R names a registered routine and passes that many arguments."""
+    import re
+    shim, init = open(SHIM).read(), open(INIT).read()
+    rsrc = open(os.path.join(ROOT, "clonealign_amd", "r_shim", "R", "inference-hip.R")).read()
+    defs = {m.group(1): m.group(2).count("SEXP") for m in re.finditer(r"^SEXP (C_clonealign_\w+)\(([^)]*)\)\s*\{", shim, re.S | re.M)}
+    table = {m.group(1): int(m.group(2)) for m in re.finditer(r'\{"(C_clonealign_\w+)", \(DL_FUNC\)&\1, (\d+)\}', init)}
+    assert defs == table and len(table) == 4, (defs, table)
+    assert "R_init_clonealign" in init and "R_useDynamicSymbols(dll, FALSE)" in init and "R_init_clonealign" not in shim
+
+    def n_args(text, start):                    # arguments of the call whose '(' is at `start`, commas at depth 1 only
+        depth, n, i = 0, 1, start
+        while True:
+            c = text[i]
+            if c in "([":
+                depth += 1
+            elif c in ")]":
+                depth -= 1
+                if depth == 0:
+                    return n
+            elif c == "," and depth == 1:
+                n += 1
+            i += 1
+    calls = [(m.group(1), n_args(rsrc, m.start(0) + len(".Call"))) for m in re.finditer(r'\.Call\("(C_clonealign_\w+)"', rsrc)]
+    assert {c for c, _ in calls} == set(table), calls
+    for name, n in calls:                       # .Call(name, <args...>, PACKAGE = "clonealign")
+        assert n - 2 == table[name], (name, n - 2, table[name])
+
+
+def test_makevars_links_the_engine_library_by_its_c_abi_only():
+    mk = open(os.path.join(SRC_DIR, "Makevars")).read()
+    assert "-lclonealign_hip" in mk and "-I$(CLONEALIGN_HIP)/include" in mk and "init.o" in mk and "hipcc" not in mk.split("PKG_CPPFLAGS")[1]
 
 
 def test_shim_uses_the_column_major_boundary_and_the_interrupt_hook():

@@ -14,6 +14,6 @@ for i in $(seq 1 "$runs"); do
   rc=$?
   t1=$(date +%s.%N)
   [ $rc -ne 0 ] && fail=$((fail+1))
-  echo "run $i rc=$rc $(echo "$t1 - $t0" | bc) s  $(grep -h -E '^\[rank|EngineError|CA_ERR|SystemExit' "$out/run_$i.err" | grep -v elastic | head -3 | tr '\n' '|')"
+  echo "run $i rc=$rc $(python3 -c "print(round($t1 - $t0, 1))") s  $(grep -h -E '^\[rank|EngineError|CA_ERR|SystemExit' "$out/run_$i.err" | grep -v elastic | head -3 | tr '\n' '|')"
 done
 echo "failed $fail of $runs"
