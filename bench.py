@@ -133,10 +133,15 @@ def parity_check(eng, Ycells, L, psi0, loc0, K, iters=2):
         to = np.asarray(run_vi_loop(ora, EpsStream(77, 1, G), iters, 1e-12))
         se, so = eng.get_state(), ora.get_state()
         perr = max(float(np.abs(se[n] - so[n]).max(initial=0) / max(np.abs(so[n]).max(initial=0), 1e-30)) for n in so)
+        # clone_assignment (R/inference-tflow.R:22-29) on both posteriors: argmax if max >= 0.95 else "unassigned"
+        pe, po = eng.get("clone_probs"), ora.get_params()["clone_probs"]
+        le = np.where(pe.max(1) >= 0.95, pe.argmax(1), -1)
+        lo_ = np.where(po.max(1) >= 0.95, po.argmax(1), -1)
+        flips = int((le != lo_).sum())
     finally:
         ora.close()
     return {"iters": iters, "cells": int(Ycells.shape[0]), "max_rel_elbo": float(np.abs(tr - to).max() / np.abs(to).max()),
-            "max_rel_param": perr, "elbo_engine": tr.tolist(), "elbo_oracle": to.tolist(), "seconds": time.perf_counter() - t0,
+            "max_rel_param": perr, "label_flips": flips, "labels_unassigned_oracle": int((lo_ < 0).sum()), "elbo_engine": tr.tolist(), "elbo_oracle": to.tolist(), "seconds": time.perf_counter() - t0,
             "what": "ca_run on the bench engine (restarted from its initial values) vs oracle/c/clonealign_oracle.c (float64 arithmetic, "
                     "float32 variables) on the same cells, same eps stream; not part of any timed region"}
 
@@ -384,6 +389,27 @@ def main():
         regions.append(dt)
     dt = float(np.median(regions))
     kt_timed = eng.kernel_times(reset=True)
+    # the same call at the reference's default max_iter = 200 (one region): a ca_iterate call of k steps makes k + 1 forward sweeps
+    # (first and last carry one draw), so a 20-step region pays 21/20 of the steady-state sweep cost -- this shows the difference
+    steady = None
+    if args.steps != 200:
+        eps_s = rng.normal(size=(400, 1, G)).astype(np.float32)
+        eng.set_profile(0)
+        eng.iterate(200, eps_s)
+        barrier()
+        t0 = time.perf_counter()
+        eng.iterate(200, eps_s)
+        eng.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        ds = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([ds], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            ds = float(t[0])
+        steady = {"steps": 200, "value": 200 / ds, "ms_per_step": ds / 200 * 1e3,
+                  "what": "one ca_iterate(200) region, same barriers; not the headline (the headline is the --steps region above)"}
     # a monitor pass on its own (plain forward + its (3 + C)-double all-reduce + read-back): the latency floor of one collective
     mon_us = None
     if world > 1:
@@ -470,18 +496,23 @@ def main():
             canon = n_loc * G * 4.0 + (n_loc + G) * K * 4.0 * 2
             ytraffic, ysrc = pmc_traffic(build, "fwd" if ride else "ypass") if same_workload else (None, None)
             ystream = {"bound": "hbm", "kernel": "ypass (blocks inside the forward sweep's launch)" if ride else "ypass", "achieved": canon / y_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                       "frac": canon / y_s / 1e9 / PEAK_HBM_GBS, "traffic": ytraffic, "traffic_source": ysrc, "launch_ms": y_s * 1e3,
+                       "frac_canonical": canon / y_s / 1e9 / PEAK_HBM_GBS, "traffic": ytraffic, "traffic_source": ysrc, "launch_ms": y_s * 1e3,
                        "stored_GBps": n_loc * G * float(info["y_bytes_per_elem"]) / y_s / 1e9,
-                       "note": "canonical 4 B per count (the reference feeds float32); the matrix is stored at "
-                               f"{info['y_bytes_per_elem']} B per count, so frac > 1 means fewer bytes moved than the canonical "
-                               "stream, not more than the memory system delivers (stored_GBps is the physical rate)"}
+                       "frac_stored": n_loc * G * float(info["y_bytes_per_elem"]) / y_s / 1e9 / PEAK_HBM_GBS,
+                       "note": "achieved / frac_canonical count the canonical 4 B per count (the reference feeds float32, SURVEY.md section 8d) "
+                               f"-- bytes this build does NOT move: the matrix is stored at {info['y_bytes_per_elem']} B per count.  "
+                               "stored_GBps / frac_stored are the physical rate of the stream over the launch it rides in"}
         step_s = dt / args.steps
         it_flops = N * G * (8.0 * C + 12.0 * K + 3.0)                       # SURVEY.md section 8d, whole iteration, all ranks
         it_bytes = N * G * 4.0 + N * (8.0 * C + 6.0 * K + 2.0) * 4.0
+        it_bytes_stored = N * G * float(info["y_bytes_per_elem"]) + N * (8.0 * C + 6.0 * K + 2.0) * 4.0   # the same formula at the stored width
+        meas = [pmc_traffic(build, k)[0] for k in ("fwd", "bwd")] if same_workload else [None]
+        it_bytes_measured = float(sum(meas)) if all(m is not None for m in meas) else None               # PMC: forward (+ riding Y stream) + backward launch
         out = {
             "metric": "ELBO iterations/sec", "value": args.steps / dt, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 (bf16x3-split MFMA contraction, fp32 accumulate)" if info.get("fwd_mfma") else "f32",
             "data": "synthetic",
             "config": {"workload": f"synthetic {N} cells x {G} genes x {C} clones, K={K}, S=1, cell-sharded over "
                                    f"{world} GPU(s) (BASELINE.json configs[{2 if world == 1 else 3}])",
@@ -513,8 +544,14 @@ def main():
                                    "frac_of_fp32_peak": it_flops / step_s / 1e12 / (PEAK_F32_TFLOPS * world),
                                    "achieved_GBps_canonical": it_bytes / step_s / 1e9,
                                    "frac_of_hbm_peak_canonical": it_bytes / step_s / 1e9 / (PEAK_HBM_GBS * world),
+                                   "bytes_stored": it_bytes_stored,
+                                   "frac_of_hbm_peak_stored": it_bytes_stored / step_s / 1e9 / (PEAK_HBM_GBS * world),
+                                   "bytes_measured_pmc": it_bytes_measured,
+                                   "frac_of_hbm_peak_measured": None if it_bytes_measured is None else it_bytes_measured / step_s / 1e9 / (PEAK_HBM_GBS * world),
                                    "what": "whole iteration (train + monitor pass) against both roofs: N G (8C + 12K + 3) flop and "
-                                           "N G 4 + N (8C + 6K + 2) 4 canonical bytes (SURVEY.md section 8d) over ms_per_step"},
+                                           "N G 4 + N (8C + 6K + 2) 4 canonical bytes (SURVEY.md section 8d) over ms_per_step.  The canonical bytes are an "
+                                           "accounting convention (float32 counts): bytes_stored is the same formula at the width the matrix is held at, "
+                                           "bytes_measured_pmc the two sweeps' HBM traffic from the PMC pass of this build -- what the memory system actually moves"},
             "kernel_ms_per_iter_warmup": {k: v[0] / max(args.warmup, 1) for k, v in kt.items()},
             "roofline_ystream": ystream,
             "final_elbo": last,
@@ -525,6 +562,8 @@ def main():
         }
         out["preheat"] = {"ms": pre_ms, "iterations": pre_it, "calls": pre_calls,
                           "what": "untimed iterations between the --warmup steps and the timed regions (clock ramp; see --preheat-ms)"}
+        if steady is not None:
+            out["steady_state_200"] = steady
         if busy_it:
             out["untimed_busy_tail"] = {"seconds": busy_s, "iterations": busy_it, "it_per_s": busy_it / busy_s,
                                         "what": "untimed ca_iterate calls after the measurements (see --busy-seconds); not part of value"}
