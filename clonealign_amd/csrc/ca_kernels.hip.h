@@ -769,6 +769,11 @@ __global__ void __launch_bounds__(CA_TB) k_gene_pre(const float* __restrict__ lo
 // Fused two-eps variant (S == 1, one clone chunk): both draws A (monitor pass) and B (next train pass) in one
 // launch; M row = [mu_A L (C cols) | mu_B L (C cols)], per-draw mu and gene partials kept apart.  With Mq the row
 // goes out as two bf16 parts in the operand layout of the matrix-core sweep instead (k_fwd_mfma).
+struct ca_gene_pre_ops { float loc, ls, eA, eB, wk0; double cs; float4 lr0, lr1; };   // one gene's operands of the prologue
+__device__ __forceinline__ void ca_gene_pre_fused_core(const ca_gene_pre_ops& o, const float* __restrict__ Lb, const float* __restrict__ V, int D, int K,
+                                                          const double* __restrict__ YtX, float* __restrict__ muA, float* __restrict__ muB,
+                                                          float* __restrict__ Mb, double* __restrict__ gene_partA, double* __restrict__ gene_partB, int G,
+                                                          int mrow, int C, unsigned short* __restrict__ Mq, double* sm, int blk, int s2);
 __device__ __forceinline__ void ca_gene_pre_fused_body(const float* __restrict__ loc, const float* __restrict__ ls,
                                                           const float* __restrict__ epsA, const float* __restrict__ epsB,
                                                           const double* __restrict__ colsum, const float* __restrict__ Lb,
@@ -780,14 +785,30 @@ __device__ __forceinline__ void ca_gene_pre_fused_body(const float* __restrict__
   // per-gene terms of the ELBO are then their mean (as k_gene_pre leaves them), in gene_partA
   const int g = blk * CA_TB + threadIdx.x;
   const bool ok = g < G;
-  double t[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
-  float wk0 = 0.f;   // W_g0, for the sum of squares below (loaded with everything else)
+  ca_gene_pre_ops o = {0.f, 0.f, 0.f, 0.f, 0.f, 0.0, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   if (ok) {
     // all operands in one batch in front of the first use (one wave per SIMD here: a dependent round of loads is 1.5 us)
-    const float loc_g = loc[g], ls_g = ls[g], eA = epsA[g], eB = epsB[g];
-    const double cs = colsum[g];
-    const float4 lr0 = *reinterpret_cast<const float4*>(Lb + (int64_t)g * CA_CW), lr1 = *reinterpret_cast<const float4*>(Lb + (int64_t)g * CA_CW + 4);
-    if (K > 0) wk0 = V[(int64_t)g * D];
+    o.loc = loc[g]; o.ls = ls[g]; o.eA = epsA[g]; o.eB = epsB[g];
+    o.cs = colsum[g];
+    o.lr0 = *reinterpret_cast<const float4*>(Lb + (int64_t)g * CA_CW); o.lr1 = *reinterpret_cast<const float4*>(Lb + (int64_t)g * CA_CW + 4);
+    if (K > 0) o.wk0 = V[(int64_t)g * D];
+  }
+  ca_gene_pre_fused_core(o, Lb, V, D, K, YtX, muA, muB, Mb, gene_partA, gene_partB, G, mrow, C, Mq, sm, blk, s2);
+}
+// ... the same on operands that are in registers already: the merged update (k_update_merged) goes from a gene's Adam step straight on to
+// the next eps pair's prologue for that gene -- no second kernel, no reload of loc / ls / W (same arithmetic on the same floats: bitwise the same)
+__device__ __forceinline__ void ca_gene_pre_fused_core(const ca_gene_pre_ops& o, const float* __restrict__ Lb, const float* __restrict__ V, int D, int K,
+                                                          const double* __restrict__ YtX, float* __restrict__ muA, float* __restrict__ muB,
+                                                          float* __restrict__ Mb, double* __restrict__ gene_partA, double* __restrict__ gene_partB, int G,
+                                                          int mrow, int C, unsigned short* __restrict__ Mq, double* sm, int blk, int s2) {
+  const int g = blk * CA_TB + threadIdx.x;
+  const bool ok = g < G;
+  double t[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+  const float wk0 = o.wk0;   // W_g0, for the sum of squares below
+  if (ok) {
+    const float loc_g = o.loc, ls_g = o.ls, eA = o.eA, eB = o.eB;
+    const double cs = o.cs;
+    const float4 lr0 = o.lr0, lr1 = o.lr1;
     const float lrow[CA_CW] = {lr0.x, lr0.y, lr0.z, lr0.w, lr1.x, lr1.y, lr1.z, lr1.w};
     const double l = (double)loc_g, lsd = (double)ls_g, sd = exp(lsd);
     double bx = 0.0;
@@ -1287,6 +1308,8 @@ struct ca_small_args {
   int reduce_only;          // stop after the cell-partial reduction (sharded: the sums are all-reduced before the ELBO assembly)
   const double* yw_part; int n_yw;      // with cell_part: block partials of sum_n psi_n.(YW)_n (k_yw_dot), added to red[0]
   const double* ee_part; int n_ee;      // without cell_part: block partials of the OTHER draw's EE_p_y cell sum (pair sweep), replace red[0]
+  float *vchi_out, *alpha_out;          // round 4 (k_update_merged): the stepped chi / alpha go HERE (null: in place) -- the gene blocks and the monitor
+                                        // block of the same launch still read the values the gradients were taken at; the host swaps the buffers
 };
 
 // wave 0 of the O(K + C) body: one lane per clone / latent dimension
@@ -1349,7 +1372,7 @@ __device__ __forceinline__ void ca_final_small_wave0(const ca_small_args& sa, co
     if (sa.apply) {
       float th = pq.vch, m = pq.m_v, vv = pq.v_v;
       ca_adam(th, m, vv, -(float)gv, sa.lr_t, sa.b1, sa.b2, sa.aeps);
-      sa.vchi[c] = th; sa.m_v[c] = m; sa.v_v[c] = vv;
+      (sa.vchi_out ? sa.vchi_out : sa.vchi)[c] = th; sa.m_v[c] = m; sa.v_v[c] = vv;
     }
   }
   const double ep_chi = wsum(ep_k);
@@ -1372,7 +1395,7 @@ __device__ __forceinline__ void ca_final_small_wave0(const ca_small_args& sa, co
       if (sa.apply) {
         float th = pq.au, m = pq.m_a, vv = pq.v_a;
         ca_adam(th, m, vv, -ga, sa.lr_t, sa.b1, sa.b2, sa.aeps);
-        sa.alpha_u[c] = th; sa.m_a[c] = m; sa.v_a[c] = vv;
+        (sa.alpha_out ? sa.alpha_out : sa.alpha_u)[c] = th; sa.m_a[c] = m; sa.v_a[c] = vv;
       }
     }
   } else if (c == 0) {
@@ -1389,7 +1412,7 @@ __device__ __forceinline__ void ca_final_small_wave0(const ca_small_args& sa, co
       for (int j = 0; j < sa.C; ++j) {
         float th = sa.alpha_u[j], m = sa.m_a[j], vv = sa.v_a[j];
         ca_adam(th, m, vv, -sa.g_a[j], sa.lr_t, sa.b1, sa.b2, sa.aeps);
-        sa.alpha_u[j] = th; sa.m_a[j] = m; sa.v_a[j] = vv;
+        (sa.alpha_out ? sa.alpha_out : sa.alpha_u)[j] = th; sa.m_a[j] = m; sa.v_a[j] = vv;
       }
   }
 }
@@ -2150,6 +2173,11 @@ struct ca_cell_ptrs {
   int s2;             // 1: the two column halves are the two SAMPLES of one pass (mc_samples = 2): log-likelihood from the mean of log Z,
                       //    coef for both samples (second one N x 8 floats / N16 x 32 bf16 further on, the layout the S loops use)
   int64_t N16;
+  // round 4: after a merged update (k_update_merged) nobody has made the exponent bound of the new state yet: the sweep's blocks take it
+  // themselves -- the range of V' from the per-gene blocks' pairs (vmm_part, what k_vmm_final / k_adam_cell reduce), then
+  // sum_d max(F_nd Vmin_d, F_nd Vmax_d) exactly as k_etamax forms it -- and leave it in etamax_w (= etamax2) for their own cell
+  // epilogue and for the backward sweep.  vmm_part = null: etamax2 is current, read it.
+  const float* vmm_part; int ngblk; float* etamax_w;
 };
 template <int CP>
 __device__ __forceinline__ void ca_cell_fused_group(const ca_cell_ptrs& p, const double* la, int64_t n, int64_t N, int C, int D, int K,
@@ -2393,13 +2421,35 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (scalar: the k-loop's bounds, branches and operand bases then are)
   float f[TL][D], em[TL];
   ca_f32x4 acc[TL];
+  float vmn[D], vmx[D];   // (merged update: range of V' over the gene blocks, every wave for itself -- min / max: any order gives the same)
+  if (p.vmm_part) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      float mn = INFINITY, mx = -INFINITY;
+      for (int b = lane; b < p.ngblk; b += 64) {
+        mn = fminf(mn, p.vmm_part[((int64_t)b * 2 + 0) * D + d]);
+        mx = fmaxf(mx, p.vmm_part[((int64_t)b * 2 + 1) * D + d]);
+      }
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
+      vmn[d] = mn; vmx[d] = mx;
+    }
+  }
 #pragma unroll
   for (int t = 0; t < TL; ++t) {
     const int64_t n = cell0 + 16 * t + j;
     const int64_t nn = n < N ? n : N - 1;
 #pragma unroll
     for (int d = 0; d < D; ++d) f[t][d] = F[nn * D + d];
-    em[t] = etamax2[nn];
+    if (p.vmm_part) {
+      float e = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) e += fmaxf(f[t][d] * vmn[d], f[t][d] * vmx[d]);   // (k_etamax's arithmetic)
+      em[t] = e;
+      if (wv == 0 && q == 0 && n < N) p.etamax_w[n] = e;   // for this block's epilogue (behind the barriers below) and the backward sweep
+    } else {
+      em[t] = etamax2[nn];
+    }
     acc[t] = (ca_f32x4){0.f, 0.f, 0.f, 0.f};
   }
   unsigned m0, m1;   // (-1, 0) and (0, -1) as bf16 pairs, see k_fwd_mfma
@@ -2816,8 +2866,10 @@ __global__ void __launch_bounds__(CA_TB) k_reduce_part(const double* __restrict_
 
 // ------------------------------------------------------------------ per-gene gradients + Adam
 // d ELBO / d loc, ls (through mu = softplus(loc + exp(ls) eps)), W, beta; minimises -ELBO.
-__device__ __forceinline__ void ca_psi_adam_body(const ca_psi_args& a, int blk, int apply, float lr_t, float b1, float b2, float aeps) {
+__device__ __forceinline__ void ca_psi_adam_body(const ca_psi_args& a, int blk, int apply, float lr_t, float b1, float b2, float aeps,
+                                                 float* psi0_new = nullptr /* merged update: the cell's stepped psi_0 (0 past the last cell) */) {
   const int64_t n = (int64_t)blk * CA_TB + threadIdx.x;
+  if (psi0_new) *psi0_new = 0.f;
   if (n >= a.N) return;
   for (int k = 0; k < a.K; ++k) {
     // (everything this lane reads, in one batch in front of the first use: a dependent round of loads is 1.5 us here)
@@ -2837,10 +2889,12 @@ __device__ __forceinline__ void ca_psi_adam_body(const ca_psi_args& a, int blk, 
       float th = f_k, m = m_k, v = v_k;
       ca_adam(th, m, v, -gp, lr_t, b1, b2, aeps);
       a.F[n * a.D + k] = th; a.m_psi[n * a.K + k] = m; a.v_psi[n * a.K + k] = v;
+      if (k == 0 && psi0_new) *psi0_new = th;
     }
   }
 }
 
+struct ca_gene_new { float loc, ls, V0; double cs; };   // a gene's stepped loc / ls / first loading (and its count total), in registers
 __device__ __forceinline__ void ca_final_gene_body(const double* __restrict__ red_g /*[G][S+D]*/, const double* __restrict__ red_y /*[G][K]*/,
                                                       const float* __restrict__ eps, const double* __restrict__ colsum,
                                                       const double* __restrict__ YtX, const float* __restrict__ vchi,
@@ -2850,7 +2904,8 @@ __device__ __forceinline__ void ca_final_gene_body(const double* __restrict__ re
                                                       float* __restrict__ g_loc, float* __restrict__ g_ls, float* __restrict__ g_V,
                                                       float* __restrict__ Vs, float* __restrict__ vmm_part,
                                                       int G, int S, int D, int K, int apply, float lr_t, float b1, float b2, float aeps, float* smin, float* smax,
-                                                      const float* __restrict__ gfold /*[nfold][G][S+D] or null*/, int nfold) {
+                                                      const float* __restrict__ gfold /*[nfold][G][S+D] or null*/, int nfold,
+                                                      ca_gene_new* nw = nullptr /* merged update: the stepped values stay in registers */) {
   const int g = blockIdx.x * CA_TB + threadIdx.x;
   const bool ok = g < G;
   float Vnew0 = 0.f;   // the first loading after this step (kept in a register for the log2 image below)
@@ -2917,9 +2972,11 @@ __device__ __forceinline__ void ca_final_gene_body(const double* __restrict__ re
     float th = loc_g, m = mloc_g, v = vloc_g;
     ca_adam(th, m, v, -(float)gl, lr_t, b1, b2, aeps);
     loc[g] = th; m_loc[g] = m; v_loc[g] = v;
+    if (nw) { nw->loc = th; nw->cs = cs; }
     th = ls_g; m = mls_g; v = vls_g;
     ca_adam(th, m, v, -(float)gs, lr_t, b1, b2, aeps);
     ls[g] = th; m_ls[g] = m; v_ls[g] = v;
+    if (nw) nw->ls = th;
   }
   for (int d = 0; d < D; ++d) {
     double gv = rgv(S + d);
@@ -2935,6 +2992,7 @@ __device__ __forceinline__ void ca_final_gene_body(const double* __restrict__ re
     }
   }
   }
+  if (nw) nw->V0 = Vnew0;
   if (!apply) return;
   // the updated loadings in log2 units and their per-block range (k_vprep fused in; same arithmetic)
   for (int d = 0; d < D; ++d) {
@@ -2999,6 +3057,33 @@ __global__ void __launch_bounds__(CA_TB) k_final_small(ca_small_args a) { ca_fin
 // ------------------------------------------------------------------ count-matrix products on the int8 matrix cores
 #include "ca_ymfma.hip.h"
 
+// q(z) logits: an elementwise Adam step over the flat [N * C] arrays, 16 bytes per lane; cell block `cblk` = cells 256 cblk ...
+__device__ __forceinline__ void ca_logit_adam_body(int cblk, float* __restrict__ glogit, const float* __restrict__ dgl, float* __restrict__ m_gl,
+                                                   float* __restrict__ v_gl, int64_t N, int C, float lr_t, float b1, float b2, float aeps) {
+  const int64_t e0 = (int64_t)cblk * CA_TB * C, tot = N * (int64_t)C;
+  const int64_t e1 = e0 + (int64_t)CA_TB * C < tot ? e0 + (int64_t)CA_TB * C : tot;   // e0 is a multiple of 4 (CA_TB = 256)
+  for (int64_t i = e0 + 4 * (int64_t)threadIdx.x; i < e1; i += 4 * CA_TB) {
+    if (i + 4 <= e1) {
+      float4 th = *reinterpret_cast<const float4*>(glogit + i), m = *reinterpret_cast<const float4*>(m_gl + i);
+      float4 v = *reinterpret_cast<const float4*>(v_gl + i);
+      const float4 g = *reinterpret_cast<const float4*>(dgl + i);
+      ca_adam(th.x, m.x, v.x, -g.x, lr_t, b1, b2, aeps);
+      ca_adam(th.y, m.y, v.y, -g.y, lr_t, b1, b2, aeps);
+      ca_adam(th.z, m.z, v.z, -g.z, lr_t, b1, b2, aeps);
+      ca_adam(th.w, m.w, v.w, -g.w, lr_t, b1, b2, aeps);
+      *reinterpret_cast<float4*>(glogit + i) = th;
+      *reinterpret_cast<float4*>(m_gl + i) = m;
+      *reinterpret_cast<float4*>(v_gl + i) = v;
+    } else {
+      for (int64_t k = i; k < e1; ++k) {
+        float th = glogit[k], m = m_gl[k], v = v_gl[k];
+        ca_adam(th, m, v, -dgl[k], lr_t, b1, b2, aeps);
+        glogit[k] = th; m_gl[k] = m; v_gl[k] = v;
+      }
+    }
+  }
+}
+
 __global__ void __launch_bounds__(CA_TB) k_adam_cell(const float* __restrict__ F, float* __restrict__ glogit, const float* __restrict__ dgl,
                                                      float* __restrict__ m_gl, float* __restrict__ v_gl, int64_t N, int C, int D,
                                                      int apply, float lr_t, float b1, float b2, float aeps,
@@ -3033,30 +3118,7 @@ __global__ void __launch_bounds__(CA_TB) k_adam_cell(const float* __restrict__ F
   if (CA_LAB_SKIP & 64) return;
   // q(z) logits: an elementwise step over the flat [N * C] arrays, 16 bytes per lane (a lane per cell would fetch C
   // strided floats per array: 2.4 TB/s at 100k x 8)
-  if (apply) {
-    const int64_t e0 = (int64_t)cblk * CA_TB * C, tot = N * (int64_t)C;
-    const int64_t e1 = e0 + (int64_t)CA_TB * C < tot ? e0 + (int64_t)CA_TB * C : tot;   // e0 is a multiple of 4 (CA_TB = 256)
-    for (int64_t i = e0 + 4 * (int64_t)threadIdx.x; i < e1; i += 4 * CA_TB) {
-      if (i + 4 <= e1) {
-        float4 th = *reinterpret_cast<const float4*>(glogit + i), m = *reinterpret_cast<const float4*>(m_gl + i);
-        float4 v = *reinterpret_cast<const float4*>(v_gl + i);
-        const float4 g = *reinterpret_cast<const float4*>(dgl + i);
-        ca_adam(th.x, m.x, v.x, -g.x, lr_t, b1, b2, aeps);
-        ca_adam(th.y, m.y, v.y, -g.y, lr_t, b1, b2, aeps);
-        ca_adam(th.z, m.z, v.z, -g.z, lr_t, b1, b2, aeps);
-        ca_adam(th.w, m.w, v.w, -g.w, lr_t, b1, b2, aeps);
-        *reinterpret_cast<float4*>(glogit + i) = th;
-        *reinterpret_cast<float4*>(m_gl + i) = m;
-        *reinterpret_cast<float4*>(v_gl + i) = v;
-      } else {
-        for (int64_t k = i; k < e1; ++k) {
-          float th = glogit[k], m = m_gl[k], v = v_gl[k];
-          ca_adam(th, m, v, -dgl[k], lr_t, b1, b2, aeps);
-          glogit[k] = th; m_gl[k] = m; v_gl[k] = v;
-        }
-      }
-    }
-  }
+  if (apply) ca_logit_adam_body(cblk, glogit, dgl, m_gl, v_gl, N, C, lr_t, b1, b2, aeps);
   // range of the updated V' over the gene blocks, per block (k_vmm_final folded in: same min / max as the extra block's)
   __shared__ float vmm[2 * 8];
   if (apply && D > 0 && D <= 8 && (int)threadIdx.x < 64) {   // wave 0: a lane per gene block, then butterflies (min / max: any order)
@@ -3084,6 +3146,76 @@ __global__ void __launch_bounds__(CA_TB) k_adam_cell(const float* __restrict__ F
   }
 }
 
+
+// ------------------------------------------------------------------ the whole update half of a train pass in ONE launch (round 4)
+// k_final_gene + k_adam_cell were two launches because three things waited for ALL gene blocks: the next eps pair's per-gene prologue, the
+// int8 stream's quantiser (both only need THEIR gene's / cell's stepped values) and the per-cell exponent bound (needs the range of V' over
+// all genes).  Here a gene block goes from its Adam step straight on to the prologue and to its four 64-steps of the W image with the
+// stepped values still in registers; a psi block does the same for the psi image; the exponent bound is taken by the next forward sweep's
+// blocks themselves (ca_cell_ptrs::vmm_part); the q(z) logits (they depend on the forward sweep only) and the chi / alpha step are further
+// blocks of this launch -- chi and alpha go to alternate buffers, because the gene blocks and the pending monitor pass's block still read
+// the values the gradients belong to.  One launch, one latency chain and one kernel boundary less per iteration; the arithmetic of every
+// piece is the two-launch form's, on the same floats (tests: bitwise equal with the variant switched off).
+// Block order = dispatch order: the latency chains (gene blocks, monitor block, chi / alpha block) first, then psi, then the logits.
+struct ca_merge_args {
+  ca_pre_args pre;         // the next (monitor, train) eps pair's prologue: pre.nblk == gene blocks
+  ca_ysq_args ysq;         // nblk > 0: the int8 stream's images, made in the gene / psi blocks (pairs of maxima: gene blocks, then psi blocks)
+  ca_small_args tail;      // the chi / alpha step (vchi_out / alpha_out set)
+  float* glogit; const float* dgl; float* m_gl; float* v_gl; int C; int ncell;   // q(z) logits: ncell blocks of 256 cells
+};
+__global__ void __launch_bounds__(CA_TB) k_update_merged(const double* __restrict__ red_g /*[G][S+D]*/, const double* __restrict__ red_y /*[G][K]*/,
+                                                         const float* __restrict__ eps, const double* __restrict__ colsum,
+                                                         const double* __restrict__ YtX, const float* __restrict__ vchi,
+                                                         float* __restrict__ loc, float* __restrict__ ls, float* __restrict__ V,
+                                                         float* __restrict__ m_loc, float* __restrict__ v_loc, float* __restrict__ m_ls,
+                                                         float* __restrict__ v_ls, float* __restrict__ m_V, float* __restrict__ v_V,
+                                                         float* __restrict__ g_loc, float* __restrict__ g_ls, float* __restrict__ g_V,
+                                                         float* __restrict__ Vs, float* __restrict__ vmm_part,
+                                                         int G, int S, int D, int K, float lr_t, float b1, float b2, float aeps, ca_small_args mon, int gblocks,
+                                                         ca_psi_args psi, const float* __restrict__ gfold, int nfold, ca_merge_args mg) {
+  [[maybe_unused]] const int nmon = mon.enabled ? 1 : 0;
+  const int bx = (int)blockIdx.x;
+  CA_LAB_STAMP(bx, bx < gblocks ? 0 : bx < gblocks + nmon ? 1 : bx == gblocks + nmon ? 4 : bx < gblocks + nmon + 1 + psi.nblk ? 2 : 5);
+  __shared__ float smq[2 * (CA_YM_TB / 64)];
+  if (bx < gblocks) {
+    if (CA_LAB_SKIP & 4) return;
+    __shared__ float smin[CA_TB], smax[CA_TB];
+    __shared__ double smp[CA_TB];
+    const int g = bx * CA_TB + (int)threadIdx.x;
+    const bool ok = g < G;
+    // the prologue's operands that nothing here produces (the next pair's two draws, the gene's copy numbers): issued with the block's first batch of loads
+    ca_gene_pre_ops o = {0.f, 0.f, 0.f, 0.f, 0.f, 0.0, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (ok) {
+      o.eA = mg.pre.epsA[g]; o.eB = mg.pre.epsB[g];
+      o.lr0 = *reinterpret_cast<const float4*>(mg.pre.Lb + (int64_t)g * CA_CW); o.lr1 = *reinterpret_cast<const float4*>(mg.pre.Lb + (int64_t)g * CA_CW + 4);
+    }
+    ca_gene_new nw = {0.f, 0.f, 0.f, 0.0};
+    ca_final_gene_body(red_g, red_y, eps, colsum, YtX, vchi, loc, ls, V, m_loc, v_loc, m_ls, v_ls, m_V, v_V, g_loc, g_ls, g_V, Vs, vmm_part, G, S, D, K,
+                       1, lr_t, b1, b2, aeps, smin, smax, gfold, nfold, &nw);
+    o.loc = nw.loc; o.ls = nw.ls; o.cs = nw.cs; o.wk0 = K > 0 ? nw.V0 : 0.f;
+    ca_gene_pre_fused_core(o, mg.pre.Lb, V, D, K, YtX, mg.pre.muA, mg.pre.muB, mg.pre.Mb, mg.pre.gene_partA, mg.pre.gene_partB, G, mg.pre.mrow,
+                           mg.pre.C, mg.pre.Mq, smp, bx, mg.pre.s2);
+    if (mg.ysq.nblk) ca_ys_quant_inreg(mg.ysq, true, bx, nw.V0, bx, bx == 0, smq);
+    return;
+  }
+  int b = bx - gblocks;
+  if (mon.enabled) {   // the pending monitor pass's ELBO (ca_final_small_body), beside the gene blocks
+    if (b == 0) { if (!(CA_LAB_SKIP & 1)) ca_final_small_body(mon); return; }
+    --b;
+  }
+  if (b == 0) { if (!(CA_LAB_SKIP & 8) && mg.tail.enabled) ca_final_small_body(mg.tail); return; }   // chi / alpha step
+  --b;
+  if (b < psi.nblk) {
+    if (CA_LAB_SKIP & 2) return;
+    float pn = 0.f;
+    ca_psi_adam_body(psi, b, 1, lr_t, b1, b2, aeps, &pn);
+    if (mg.ysq.nblk) ca_ys_quant_inreg(mg.ysq, false, b, pn, gblocks + b, false, smq);
+    return;
+  }
+  b -= psi.nblk;
+  if (CA_LAB_SKIP & 64) return;
+  if (b < mg.ncell) ca_logit_adam_body(b, mg.glogit, mg.dgl, mg.m_gl, mg.v_gl, psi.N, mg.C, lr_t, b1, b2, aeps);
+}
 
 // Column products, engine form: the sweep of ca_yt_block plus, as extra blocks of the launch, the gene side of the overflow
 // list (per-chunk sums of the counts above 255; they depend on psi only).

@@ -547,27 +547,11 @@ struct ca_ysq_args {
   float* amax_out;                // [nblk][2]
   int* exps; uint4* Wr; uint4* Pr; int* Wsum; int* Psum;
 };
-__device__ __forceinline__ void ca_ys_quant_body(int blk, const ca_ysq_args& a, float* sm /* >= 2 * (CA_YM_TB / 64) floats */) {
+// One wave's 64-step of an image from entries that are in registers: vals[b] = entry 16 (l >> 4) + b of the step, own = entry l.
+// Block-level: every thread of the block calls it (two barriers); `out` = this block's pair in amax_out.
+__device__ __forceinline__ void ca_ys_quant_core(const ca_ysq_args& a, bool live, bool isw, int64_t step, const float (&vals)[16], float own,
+                                                 int out, bool write_exps, float* sm /* >= 2 * (CA_YM_TB / 64) floats */) {
   const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
-  // this wave's 64-step of an image: its sixteen entries per lane (and the lane's own entry, for the step's exact maximum) are
-  // loaded FIRST -- their addresses do not depend on the exponents, so the round trip runs beside the reduction below
-  const int64_t st = (int64_t)blk * (CA_YM_TB / 64) + wv;      // one wave per 64-step of an image
-  const bool live = st < a.GS + a.NS;
-  const bool isw = !live || st < a.GS;
-  const float* src = isw ? a.V : a.F;
-  const int ld = isw ? a.Dv : a.Df;
-  const int64_t rows = isw ? a.G : a.N, step = live ? (isw ? st : st - a.GS) : 0;
-  float vals[16], own = 0.f;
-  {
-    const int64_t r0 = step * 64 + 16 * (l >> 4);
-#pragma unroll
-    for (int b = 0; b < 16; ++b) {
-      const int64_t r = r0 + b;
-      vals[b] = (live && r < rows) ? src[r * ld] : 0.f;
-    }
-    const int64_t r = step * 64 + l;
-    if (live && r < rows) own = src[r * ld];
-  }
   // largest magnitudes of the state amax_in describes
   float mw = 0.f, mp = 0.f;
   for (int i = tid; i < a.n_in; i += CA_YM_TB) { mw = fmaxf(mw, a.amax_in[2 * i]); mp = fmaxf(mp, a.amax_in[2 * i + 1]); }
@@ -579,7 +563,7 @@ __device__ __forceinline__ void ca_ys_quant_body(int blk, const ca_ysq_args& a, 
   mp = fmaxf(fmaxf(sm[1], sm[3]), fmaxf(sm[5], sm[7]));
   __syncthreads();
   const int ew = ca_fix_exp(mw + a.slack_w), ep = ca_fix_exp(mp + a.slack_p);
-  if (blk == 0 && tid == 0) { a.exps[0] = ew; a.exps[1] = ep; }
+  if (write_exps && tid == 0) { a.exps[0] = ew; a.exps[1] = ep; }
   float m = 0.f;
   if (live) {
     const float sc = ldexpf(1.f, isw ? ew : ep);
@@ -609,9 +593,44 @@ __device__ __forceinline__ void ca_ys_quant_body(int blk, const ca_ysq_args& a, 
   if (l == 0) { sm[2 * wv] = isw ? m : 0.f; sm[2 * wv + 1] = isw ? 0.f : m; }
   __syncthreads();
   if (tid == 0) {
-    a.amax_out[2 * blk] = fmaxf(fmaxf(sm[0], sm[2]), fmaxf(sm[4], sm[6]));
-    a.amax_out[2 * blk + 1] = fmaxf(fmaxf(sm[1], sm[3]), fmaxf(sm[5], sm[7]));
+    a.amax_out[2 * out] = fmaxf(fmaxf(sm[0], sm[2]), fmaxf(sm[4], sm[6]));
+    a.amax_out[2 * out + 1] = fmaxf(fmaxf(sm[1], sm[3]), fmaxf(sm[5], sm[7]));
   }
+}
+__device__ __forceinline__ void ca_ys_quant_body(int blk, const ca_ysq_args& a, float* sm /* >= 2 * (CA_YM_TB / 64) floats */) {
+  const int tid = threadIdx.x, l = tid & 63, wv = tid >> 6;
+  // this wave's 64-step of an image: its sixteen entries per lane (and the lane's own entry, for the step's exact maximum) are
+  // loaded FIRST -- their addresses do not depend on the exponents, so the round trip runs beside the reduction in the core
+  const int64_t st = (int64_t)blk * (CA_YM_TB / 64) + wv;      // one wave per 64-step of an image
+  const bool live = st < a.GS + a.NS;
+  const bool isw = !live || st < a.GS;
+  const float* src = isw ? a.V : a.F;
+  const int ld = isw ? a.Dv : a.Df;
+  const int64_t rows = isw ? a.G : a.N, step = live ? (isw ? st : st - a.GS) : 0;
+  float vals[16], own = 0.f;
+  {
+    const int64_t r0 = step * 64 + 16 * (l >> 4);
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      const int64_t r = r0 + b;
+      vals[b] = (live && r < rows) ? src[r * ld] : 0.f;
+    }
+    const int64_t r = step * 64 + l;
+    if (live && r < rows) own = src[r * ld];
+  }
+  ca_ys_quant_core(a, live, isw, step, vals, own, blk, blk == 0, sm);
+}
+// The same images made where the entries are BORN (round 4, k_update_merged): a block of 256 genes (cells) has just stepped W_g0 (psi_n0),
+// one entry per lane = four 64-steps of the W (psi) image; the sixteen entries a lane packs come from its wave-mates by shuffle.
+// `own` = this lane's entry (0 past the last row).  Same arithmetic on the same floats as ca_ys_quant_body reading them back.
+__device__ __forceinline__ void ca_ys_quant_inreg(const ca_ysq_args& a, bool isw, int blk, float own, int out, bool write_exps, float* sm) {
+  const int l = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t step = (int64_t)blk * (CA_YM_TB / 64) + wv;
+  const bool live = step < (isw ? (int64_t)a.GS : a.NS);
+  float vals[16];
+#pragma unroll
+  for (int b = 0; b < 16; ++b) vals[b] = __shfl(own, 16 * (l >> 4) + b, 64);
+  ca_ys_quant_core(a, live, isw, live ? step : 0, vals, own, out, write_exps, sm);
 }
 __global__ void __launch_bounds__(CA_YM_TB) k_ys_quant(ca_ysq_args a) {
   __shared__ float sm[2 * (CA_YM_TB / 64)];

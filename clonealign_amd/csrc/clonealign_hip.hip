@@ -119,6 +119,10 @@ struct ca_engine {
   float* loc_init = nullptr;   // loc as ca_create left it (loc0, or the device-side mu_guess): ca_reinit's default
   float *vchi = nullptr, *m_v = nullptr, *v_v = nullptr;            // [K]
   float *alpha_u = nullptr, *m_a = nullptr, *v_a = nullptr;         // [C]
+  // round 4 (merged update, k_update_merged): the chi / alpha step writes the alternate buffers and the host swaps them in; the exponent
+  // bound of the stepped state is then made by the next forward sweep itself (em_stale: nobody has made it yet)
+  float *vchi_alt = nullptr, *alpha_u_alt = nullptr;
+  bool upd_merge = false, em_stale = false;
   double dir_const = 0.0;
   float b1p = 0.f, b2p = 0.f;  // running beta powers, float32 like TF's beta*_power variables
   // ---- gradients (d ELBO / d var)
@@ -175,7 +179,8 @@ struct ca_engine {
   bool y_ys = false; uint8_t* Ys = nullptr; uint4 *Wr = nullptr, *Pr = nullptr; int *Wsum = nullptr, *Psum = nullptr;
   int* ys_exps = nullptr;        // [3][2]: rotating slots, see ca_ys_quant_body
   unsigned* ys_amax = nullptr;   // [2]: exact maxima of a fresh state (k_ym_absmax), float bit patterns
-  float* ys_amaxp = nullptr; int ys_nq = 0;   // [3][ys_nq][2]: per-block maxima each quantiser run leaves for the next one
+  float* ys_amaxp = nullptr; int ys_nq = 0;   // [3][ys_ncap][2]: per-block maxima each quantiser run leaves for the next one
+  int ys_ncap = 0, ys_namax[3] = {0, 0, 0};   // pairs a slot can hold / holds (a merged update leaves one pair per gene block and per psi block)
   bool ys_quant_ready = false;   // the images of the CURRENT parameter state were made by the quantiser riding on k_adam_cell
   int ys_slot = 0, ys_steps = -1, ys_RS = 256, ys_nrg = 0, ys_nseg = 0; int64_t ys_N64 = 0; float ys_step_bound = -1.f;
   // one-shot peer-to-peer all-reduce (ca_p2p_export / ca_p2p_connect)
@@ -472,6 +477,18 @@ int wait_y(ca_engine* h, bool all) {
   return CA_OK;
 }
 
+// After a merged update (k_update_merged) the per-cell exponent bound of the stepped state has not been made: the fused forward sweep's
+// blocks make it themselves (ca_cell_ptrs::vmm_part); every OTHER consumer of etamax2 calls this first (the two small kernels of setup).
+int ensure_etamax(ca_engine* h) {
+  if (!h->em_stale) return CA_OK;
+  if (h->D > 0) {
+    LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_vmm_final, dim3(1), dim3(64), 0, h->stream, h->vmm_part, h->vmm, h->ngblk, h->D));
+    LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_etamax, dim3(cdiv(h->N, CA_TB)), dim3(CA_TB), 0, h->stream, h->F, h->vmm, h->etamax2, h->N, h->D));
+  }
+  h->em_stale = false;
+  return CA_OK;
+}
+
 // ---- derived state that depends on the parameters only (not on eps) -------------------------
 int refresh_derived(ca_engine* h) {
   CACK(wait_y(h, true));
@@ -484,6 +501,7 @@ int refresh_derived(ca_engine* h) {
     LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_vmm_final, dim3(1), dim3(64), 0, h->stream, h->vmm_part, h->vmm, h->ngblk, h->D));
     LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_etamax, dim3(cdiv(h->N, CA_TB)), dim3(CA_TB), 0, h->stream, h->F, h->vmm, h->etamax2, h->N, h->D));
   }
+  h->em_stale = false;
   h->ycache_valid = false;
   h->yfin_pending = false;
   h->look_valid = false;
@@ -542,12 +560,13 @@ ca_ysq_args ys_quant_args(ca_engine* h, int steps, bool* lagged) {
   a.V = h->V; a.Dv = h->D; a.G = h->G; a.GS = h->Gp / 64; a.F = h->F; a.Df = h->D; a.N = h->N; a.NS = h->ys_N64 / 64;
   *lagged = steps >= 0 && steps <= 4 && h->ys_step_bound > 0.f;
   if (*lagged) {
-    a.amax_in = h->ys_amaxp + (int64_t)s0 * h->ys_nq * 2; a.n_in = h->ys_nq;
+    a.amax_in = h->ys_amaxp + (int64_t)s0 * h->ys_ncap * 2; a.n_in = h->ys_namax[s0];
     a.slack_w = a.slack_p = (float)steps * h->ys_step_bound;
   } else {
     a.amax_in = reinterpret_cast<const float*>(h->ys_amax); a.n_in = 1;
   }
-  a.amax_out = h->ys_amaxp + (int64_t)s1 * h->ys_nq * 2;
+  a.amax_out = h->ys_amaxp + (int64_t)s1 * h->ys_ncap * 2;
+  h->ys_namax[s1] = h->ys_nq;   // (what a run of the quantiser's own blocks leaves; the merged update overrides it)
   a.exps = h->ys_exps + 2 * s0; a.Wr = h->Wr; a.Pr = h->Pr; a.Wsum = h->Wsum; a.Psum = h->Psum;
   return a;
 }
@@ -858,6 +877,7 @@ ca_small_args small_args(ca_engine* h, const double* gene_part, int apply, float
   a.host_out = nullptr; a.host_flag = nullptr; a.host_seq = 0; a.reduce_only = 0;
   a.yw_part = nullptr; a.n_yw = 0;
   a.ee_part = nullptr; a.n_ee = 0;
+  a.vchi_out = nullptr; a.alpha_out = nullptr;
   if (!apply && elbo_dst && h->host_seq_next && h->host_dev) {   // monitor pass inside ca_run: mirror the ELBO to the host
     a.host_out = h->host_dev + 32;
     a.host_flag = reinterpret_cast<unsigned long long*>(h->host_dev + 33);
@@ -1009,6 +1029,61 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
     psi.N = h->N; psi.D = h->D; psi.K = h->K; psi.ntile = h->bwd_mfma ? cdiv(h->nwt, CA_TB / 64) : h->ntile;
   }
   h->pre_valid = false;
+  // Round 4: the whole update half in ONE launch (k_update_merged) whenever the loop has announced the next eps pair, the fused forward
+  // sweep that follows can make the exponent bound itself (fwd_cell) and K >= 1 -- see the kernel.  Everything else (call-by-call API,
+  // the last step of a run, the VALU / two-kernel forward paths) keeps the two launches below.
+  {
+    int64_t mA = h->hint_A, mB = h->hint_B;
+    if (h->s2) { mA = 2 * h->hint_A; mB = mA + 1; }
+    if (apply && h->upd_merge && !elbo_dst && h->pre_ok && h->hint_A >= 0 && mB >= 0 && h->fused_ok && h->gene_part_alt && h->fwd_cell && h->K > 0) {
+      ca_merge_args mg;
+      memset(&mg, 0, sizeof(mg));
+      ca_pre_args& pre = mg.pre;
+      pre.nblk = h->ngblk;
+      pre.loc = h->loc; pre.ls = h->ls; pre.epsA = h->eps_dev + mA * (int64_t)h->G; pre.epsB = h->eps_dev + mB * (int64_t)h->G;
+      pre.colsum = h->colsum; pre.Lb = h->Lb; pre.V = h->V; pre.YtX = h->YtX; pre.muA = h->mu32; pre.muB = h->s2 ? h->mu32 + h->G : h->mu32B; pre.Mb = h->Mb2;
+      pre.s2 = h->s2 ? 1 : 0;
+      pre.gene_partA = h->gene_part_alt; pre.gene_partB = h->gene_partB_alt; pre.Mq = h->fwd_mfma ? h->Mq : nullptr;
+      pre.G = h->G; pre.D = h->D; pre.K = h->K; pre.mrow = h->frow; pre.C = h->C;
+      if (h->y_ys && !h->ys_quant_ready) {   // the int8 stream's images of the stepped W and psi (exponents from the lagged maxima, as on k_adam_cell)
+        bool lagged = false;
+        const ca_ysq_args a = ys_quant_args(h, h->ys_steps >= 0 ? h->ys_steps + 1 : -1, &lagged);
+        if (lagged) {
+          mg.ysq = a; mg.ysq.nblk = h->ngblk + N256;
+          h->ys_namax[(h->ys_slot + 1) % 3] = h->ngblk + N256;   // one pair per gene block, then one per psi block
+          h->ys_quant_ready = true;
+        }
+      }
+      mg.tail = small_args(h, h->gene_part, 1, lr_t, nullptr, false);
+      mg.tail.terms_out = nullptr;                 // (the pending monitor pass's block of this launch owns the ELBO terms)
+      mg.tail.vmm_part = nullptr; mg.tail.vmm = nullptr;   // the range of V' is the next sweep's business
+      mg.tail.vchi_out = h->vchi_alt; mg.tail.alpha_out = h->alpha_u_alt;
+      mg.glogit = h->glogit; mg.dgl = h->dgl; mg.m_gl = h->m_gl; mg.v_gl = h->v_gl; mg.C = h->C; mg.ncell = N256;
+      LAUNCH(h, CA_KERNEL_OTHER,
+             hipLaunchKernelGGL(k_update_merged, dim3(h->ngblk + (mon.enabled ? 1 : 0) + 1 + psi.nblk + N256), dim3(CA_TB), 0, h->stream,
+                                h->red + h->off_g, h->red + h->off_y, eps, h->colsum, h->YtX, h->vchi, h->loc, h->ls, h->V, h->m_loc, h->v_loc,
+                                h->m_ls, h->v_ls, h->m_V, h->v_V, h->g_loc, h->g_ls, h->g_V, h->Vs, h->vmm_part, h->G, h->S, h->D, h->K, lr_t,
+                                (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, mon, h->ngblk, psi,
+                                h->fold_now ? h->gpart : nullptr, h->csplit_m, mg));
+      h->fold_now = false;
+      if (h->async_y && !h->ride_ok && !h->ride_ys) {   // side-stream Y pass (2- / 4-byte storage, K != 1): psi is final from here, as below
+        HIPCK(h, hipEventRecord(h->ev_params, h->stream));
+        h->y_defer = true;
+      }
+      std::swap(h->vchi, h->vchi_alt);
+      std::swap(h->alpha_u, h->alpha_u_alt);
+      h->em_stale = true;
+      h->pre_valid = true; h->pre_A = mA; h->pre_B = mB;
+      h->hint_A = h->hint_B = -1;
+      if (h->ys_steps >= 0) h->ys_steps += 1;
+      h->b1p *= (float)h->opt.beta1;
+      h->b2p *= (float)h->opt.beta2;
+      h->ycache_valid = false;
+      h->yfin_pending = false;
+      h->look_valid = false;
+      return CA_OK;
+    }
+  }
   LAUNCH(h, CA_KERNEL_OTHER,
          hipLaunchKernelGGL(k_final_gene, dim3(h->ngblk + (mon.enabled ? 1 : 0) + psi.nblk), dim3(CA_TB), 0, h->stream, h->red + h->off_g,
                             h->red + h->off_y, eps, h->colsum, h->YtX, h->vchi, h->loc, h->ls, h->V, h->m_loc, h->v_loc, h->m_ls,
@@ -1078,6 +1153,7 @@ int train_tail(ca_engine* h, const float* eps, const float* mu32, int apply, dou
 int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_dst) {
   const float* eps = h->eps_dev + eps_slot * (int64_t)h->S * h->G;
   CACK(flush_mon_tail(h));
+  CACK(ensure_etamax(h));
   if (mode != CA_MODE_TRAIN) h->hint_A = h->hint_B = -1;
   h->pre_valid = false;   // this pass rewrites mu32 and the current per-gene partials
   LAUNCH(h, CA_KERNEL_OTHER,
@@ -1154,6 +1230,9 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
   ca_cell_ptrs cp;
   cp.A = h->A; cp.cn = h->cn; cp.s64 = h->s64; cp.etamax2 = h->etamax2; cp.glogit = h->glogit; cp.F = h->F;
   cp.coef = h->coef; cp.dgl = h->dgl; cp.coefq = h->bwd_mfma ? h->coefq : nullptr;
+  cp.vmm_part = nullptr; cp.ngblk = 0; cp.etamax_w = nullptr;
+  if (h->em_stale && h->fwd_cell && h->D > 0) { cp.vmm_part = h->vmm_part; cp.ngblk = h->ngblk; cp.etamax_w = h->etamax2; h->em_stale = false; }
+  else CACK(ensure_etamax(h));
   cp.ee_partB = (elbo_dstB && h->fwd_cell) ? h->ee_partB : nullptr;
   cp.s2 = h->s2 ? 1 : 0; cp.N16 = h->N16;
   int CP = 1;
@@ -1739,6 +1818,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   h->mon_tail = no_small_args();
   h->tail_fuse = variant_on(h, CA_VAR_TAIL_FUSE, "CA_TAIL_FUSE");
   h->pre_ok = variant_on(h, CA_VAR_PRE, "CA_PRE");
+  h->upd_merge = h->tail_fuse && h->pre_ok && variant_on(h, CA_VAR_UPDATE_MERGE, "CA_UPDATE_MERGE");
   h->pair_elbo = variant_on(h, CA_VAR_PAIR_ELBO, "CA_PAIR_ELBO");
   CACK(upload_y(h, p));
   const int G = h->G, C = h->C, K = h->K, P = h->P, S = h->S, D = h->D;
@@ -1870,6 +1950,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   CACK(dalloc(h, &h->vchi, std::max(K, 1))); CACK(dalloc(h, &h->m_v, std::max(K, 1))); CACK(dalloc(h, &h->v_v, std::max(K, 1)));
   CACK(dalloc(h, &h->g_v, std::max(K, 1)));
   CACK(dalloc(h, &h->alpha_u, C)); CACK(dalloc(h, &h->m_a, C)); CACK(dalloc(h, &h->v_a, C)); CACK(dalloc(h, &h->g_a, C));
+  CACK(dalloc(h, &h->vchi_alt, std::max(K, 1))); CACK(dalloc(h, &h->alpha_u_alt, C));
   {
     std::vector<float> Fh((size_t)Nn * std::max(D, 1), 0.f);
     if (D > 0) {
@@ -2036,7 +2117,8 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     CACK(dalloc(h, &h->ys_exps, 6));
     CACK(dalloc(h, &h->ys_amax, 2));
     h->ys_nq = cdiv((int64_t)(h->Gp / 64) + h->ys_N64 / 64, CA_YM_TB / 64);
-    CACK(dalloc(h, &h->ys_amaxp, (int64_t)3 * h->ys_nq * 2));
+    h->ys_ncap = std::max(h->ys_nq, h->ngblk + cdiv(Nn, CA_TB)) + 2;
+    CACK(dalloc(h, &h->ys_amaxp, (int64_t)3 * h->ys_ncap * 2));
     hipLaunchKernelGGL(k_bias_y, dim3(cdiv(h->ys_N64 * (h->Gp / 16), CA_YM_TB)), dim3(CA_YM_TB), 0, h->stream, (const uint8_t*)h->Y, (uint4*)h->Ys, Nn,
                        h->ys_N64, h->Gp);
     HIPCK(h, hipGetLastError());
@@ -2345,6 +2427,7 @@ int ca_get_info(ca_handle h, ca_info* i) {
   i->red_n = h->red_n;
   i->fwd_block_cells = (h->fused_ok && h->fwd_cell) ? 16 * h->fc_tl : 0; i->fwd_blocks_big = h->fc_nbig;
   i->fold_gsum = (h->fold_gsum && !is_sharded(h)) ? 1 : 0; i->yfin_split = (h->yfin_split && !is_sharded(h)) ? 1 : 0;
+  i->update_merge = (h->upd_merge && h->fused_ok && h->fwd_cell && h->K > 0) ? 1 : 0;
   return CA_OK;
 }
 

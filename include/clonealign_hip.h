@@ -87,6 +87,8 @@ enum ca_variant {
   CA_VAR_PRE = 1 << 6,        /* next pass's per-gene prologue on the per-cell Adam kernel */
   CA_VAR_PAIR_ELBO = 1 << 7,  /* final ELBOs two draws per sweep */
   CA_VAR_PREP_FAST = 1 << 8,  /* wave-per-cell fit-constant kernel for u8 storage */
+  CA_VAR_UPDATE_MERGE = 1 << 9, /* the update half of a train pass of the loop as ONE launch (k_update_merged: per-gene step + next prologue + int8 images, psi,
+                                  q(z) logits, chi / alpha), the exponent bound taken by the next forward sweep; off: k_final_gene + k_adam_cell */
   CA_VAR_P2P = 1 << 10,       /* one-shot peer-to-peer all-reduce (else ncclAllReduce) after ca_comm_init() */
   CA_VAR_FOLD_GSUM = 1 << 11, /* small problems: backward-sweep partials summed inside the per-gene kernel (else a k_colsum launch) */
   CA_VAR_Y_RIDE = 1 << 12,    /* the Y stream's blocks ride on the forward sweep's launch (else side stream / in line) */
@@ -169,6 +171,8 @@ typedef struct ca_info {
   int32_t fwd_blocks_big;    /* > 0: mixed launch, that many blocks of fwd_block_cells cells, the rest 32-cell blocks */
   int32_t fold_gsum;         /* 1: the backward sweep's per-gene partials are summed inside the per-gene kernel (unsharded small problems) */
   int32_t yfin_split;        /* 1: the Y stream's finishing step is split between the forward and backward launches */
+  int32_t update_merge;      /* 1: the loop's update half is one launch (CA_VAR_UPDATE_MERGE) */
+  int32_t reserved0;
 } ca_info;
 enum ca_transport { CA_TRANSPORT_NONE = 0, CA_TRANSPORT_RCCL = 1, CA_TRANSPORT_HOST = 2, CA_TRANSPORT_P2P = 3 };
 

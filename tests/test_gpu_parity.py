@@ -671,3 +671,118 @@ def test_two_mc_samples_run_the_matrix_core_sweeps(shape):
         assert np.abs(fe - fo).max() <= 1e-5 * np.abs(fo).max()
     finally:
         eng.close()
+
+
+MERGE_SHAPES = {
+    "u8_k1": dict(N=3000, G=700, C=5, K=1),                      # the default: int8 stream riding, images made in the gene / psi blocks
+    "u8_k1_ragged_two_block_sizes": dict(N=40_100, G=1100, C=8, K=1),
+    "tiny_more_genes_than_cells": dict(N=33, G=1030, C=3, K=1),
+    "k2_p1": dict(N=2100, G=600, C=6, K=2, P=1),                 # D = 3: loadings past the first come back from memory
+    "k1_p1": dict(N=1500, G=333, C=4, K=1, P=1),
+    "c11": dict(N=700, G=1100, C=11, K=1),                       # sixteen-clone kernels
+    "s2": dict(N=520, G=300, C=6, K=1, S=2),                     # two samples per pass
+    "extra": dict(N=400, G=257, C=3, K=1, extra=True),
+}
+
+
+@pytest.mark.parametrize("name", list(MERGE_SHAPES))
+@pytest.mark.parametrize("mode", ["default", "vector_stream", "u16_side_stream", "no_fold", "yfin_launch"])
+def test_merged_update_launch_is_bitwise_the_two_launch_update(name, mode):
+    """Round 4: the update half of a loop iteration is ONE launch (k_update_merged: a gene's Adam step, the next eps pair's prologue and its
+    part of the int8 images in one thread; psi likewise; the q(z) logits and the chi / alpha step as further blocks; the exponent bound taken
+    by the next forward sweep's blocks).  Every piece does the arithmetic of k_final_gene + k_adam_cell on the same floats, so the whole
+    loop -- ca_run with its stop rule and speculative backward sweep, ca_iterate, the final ELBOs, every variable and Adam slot that can be
+    fetched -- must agree BIT FOR BIT with the variant switched off, on every kind of forward sweep / Y stream the loop takes."""
+    from clonealign_amd.engine import HipEngine
+    from clonealign_amd.rng import EpsStream
+    shape = MERGE_SHAPES[name]
+    case = make_case(seed=41, **shape)
+    rng = np.random.default_rng(5)
+    idx = rng.integers(0, case["Y"].size, size=max(3, case["Y"].size // 7000))
+    case["Y"].reshape(-1)[idx] += rng.integers(200, 900, size=idx.size)            # overflow list
+    G, S = case["Y"].shape[1], shape.get("S", 1)
+    kw = {"default": {}, "vector_stream": dict(variant_off=("y_mfma1",)), "u16_side_stream": dict(y_storage="u16", variant_on=("async_small",)),
+          "no_fold": dict(variant_off=("fold_gsum",)), "yfin_launch": dict(variant_off=("yfin_ride",))}[mode]
+    outs = []
+    for merged in (True, False):
+        k2 = dict(kw)
+        if not merged:
+            k2["variant_off"] = tuple(k2.get("variant_off", ())) + ("update_merge",)
+        eng = HipEngine(**case, **k2)
+        try:
+            assert eng.info()["update_merge"] == (1 if merged else 0)
+            tr = np.asarray(eng.run(EpsStream(11, S, G), 7, 1e-12))
+            mid = eng.get_state()
+            fin = eng.final_elbo(np.stack([eps_for(S, G, 500 + i) for i in range(4)]), 4)
+            last = eng.iterate(4, np.stack([eps_for(S, G, 600 + i) for i in range(8)]))
+            e1 = eng.elbo(eps_for(S, G, 3))          # a plain pass right after the loop: the exponent bound must be current there too
+            eng.step(eps_for(S, G, 4))               # ... and the call-by-call update (two launches) after merged ones
+            e2 = eng.elbo(eps_for(S, G, 5))
+            outs.append((tr, mid, fin, last, e1, e2, eng.get_state(), eng.get("clone_probs"), eng.get_params()))
+        finally:
+            eng.close()
+    a, b = outs
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and a[3] == b[3] and a[4] == b[4] and a[5] == b[5], (a[0], b[0])
+    for st in (1, 6):
+        for n in b[st]:
+            assert np.array_equal(a[st][n], b[st][n]), (st, n)
+    assert np.array_equal(a[7], b[7])
+    for n in b[8]:
+        assert np.array_equal(a[8][n], b[8][n]), n
+
+
+def test_merged_update_survives_a_cancelled_run_and_a_restart():
+    """The merged update leaves the exponent bound to the NEXT forward sweep and chi / alpha in swapped buffers: a run that is cancelled
+    right after an update (poll hook), parameter fetches, ca_set_param and ca_reinit in between must all see a consistent state --
+    checked against the two-launch engine doing the same sequence."""
+    from clonealign_amd.engine import HipEngine
+    from clonealign_amd.rng import EpsStream
+    case = make_case(seed=43, N=900, G=410, C=4, K=1)
+    G = 410
+    outs = []
+    for voff in ((), ("update_merge",)):
+        eng = HipEngine(**case, variant_off=voff)
+        try:
+            seen = []
+            tr = eng.run(EpsStream(3, 1, G), 20, 1e-12, poll=lambda i, e: (seen.append(e), i >= 3)[1])
+            p1 = eng.get_params()
+            fin = eng.final_elbo(np.stack([eps_for(1, G, 50 + i) for i in range(3)]), 3)
+            st = eng.get_state()
+            eng.set("alpha_unconstr", st["alpha_unconstr"] + 0.25)
+            e1 = eng.elbo(eps_for(1, G, 9))
+            it = eng.iterate(3, np.stack([eps_for(1, G, 70 + i) for i in range(6)]))
+            eng.reinit(case["psi0"], case["loc0"])
+            tr2 = np.asarray(eng.run(EpsStream(4, 1, G), 5, 1e-12))
+            outs.append((np.asarray(tr), p1, fin, e1, it, tr2, eng.get_state()))
+        finally:
+            eng.close()
+    a, b = outs
+    assert len(a[0]) == 4 and np.array_equal(a[0], b[0]) and np.array_equal(a[2], b[2]) and a[3] == b[3] and a[4] == b[4] and np.array_equal(a[5], b[5])
+    for n in b[1]:
+        assert np.array_equal(a[1][n], b[1][n]), n
+    for n in b[6]:
+        assert np.array_equal(a[6][n], b[6][n]), n
+
+
+def test_clone_labels_exact_where_many_cells_sit_near_the_threshold():
+    """north_star: 'clone assignments exactly'.  The benchmark's synthetic cells are decisive (every max gamma ends at 1.0), so this case
+    is made hard on purpose: 4000 shallow cells (about 30 counts each) whose posteriors spread over the whole interval, 60 iterations of
+    the loop under a shared eps stream -- the labels of R/inference-tflow.R:22-29 must equal the float32-variable oracle's for EVERY cell."""
+    from clonealign_amd.engine import HipEngine
+    from clonealign_amd.inference import run_vi_loop
+    from clonealign_amd.rng import EpsStream
+    from oracle.fused_numpy import FusedModel
+    from tests._cases import record_labels
+    case = make_case(seed=8, N=4000, G=150, C=4, K=1, scale=0.05)
+    eng, ora = HipEngine(**case), FusedModel(**case, dtype="float32")
+    try:
+        te = np.asarray(eng.run(EpsStream(21, 1, 150), 60, 1e-12))
+        to = np.asarray(run_vi_loop(ora, EpsStream(21, 1, 150), 60, 1e-12))
+        assert np.abs(te - to).max() <= 1e-5 * np.abs(to).max()
+        pe, po = eng.get("clone_probs"), ora.get_params()["clone_probs"]
+        mx = po.max(1)
+        assert ((mx > 0.5) & (mx < 0.95)).sum() > 400 and (mx >= 0.95).sum() > 400     # the case IS spread over the threshold
+        flips, far = record_labels("hard: 4000 shallow cells x 150 x 4, ca_run 60 iterations, engine vs fused oracle (float32 variables)", pe, po)
+        assert far == 0 and flips == 0
+    finally:
+        eng.close(); ora.close()
