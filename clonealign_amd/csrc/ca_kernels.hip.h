@@ -89,6 +89,10 @@ __device__ __forceinline__ void ca_block_sum_n(double (&v)[NV], double* sm /* >=
   }
 }
 
+// order-preserving image of a float in a signed int (and back: the map is its own inverse): integer atomicMin / atomicMax on the images
+// give the float min / max exactly
+__device__ __forceinline__ int ca_f2ord(float f) { const int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
+__device__ __forceinline__ float ca_ord2f(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
 __device__ __forceinline__ unsigned short ca_bf16_rn(float f) {
   unsigned u = __float_as_uint(f);
   u += 0x7FFFu + ((u >> 16) & 1u);
@@ -797,15 +801,11 @@ __device__ __forceinline__ void ca_gene_pre_fused_body(const float* __restrict__
 }
 // ... the same on operands that are in registers already: the merged update (k_update_merged) goes from a gene's Adam step straight on to
 // the next eps pair's prologue for that gene -- no second kernel, no reload of loc / ls / W (same arithmetic on the same floats: bitwise the same)
-__device__ __forceinline__ void ca_gene_pre_fused_core(const ca_gene_pre_ops& o, const float* __restrict__ Lb, const float* __restrict__ V, int D, int K,
-                                                          const double* __restrict__ YtX, float* __restrict__ muA, float* __restrict__ muB,
-                                                          float* __restrict__ Mb, double* __restrict__ gene_partA, double* __restrict__ gene_partB, int G,
-                                                          int mrow, int C, unsigned short* __restrict__ Mq, double* sm, int blk, int s2) {
-  const int g = blk * CA_TB + threadIdx.x;
-  const bool ok = g < G;
-  double t[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
-  const float wk0 = o.wk0;   // W_g0, for the sum of squares below
-  if (ok) {
+// one draw of the prologue for one gene (w = 0: the monitor pass's eps, 1: the next train pass's): mu, its row of the sweep's B operand,
+// the gene's three ELBO terms.  Per lane, no block-level operation (the merged update gives the two draws to two waves).
+__device__ __forceinline__ void ca_gene_pre_draw(int w, int g, const ca_gene_pre_ops& o, const float* __restrict__ Lb, const float* __restrict__ V, int D, int K,
+                                                    const double* __restrict__ YtX, float* __restrict__ muA, float* __restrict__ muB,
+                                                    float* __restrict__ Mb, int G, int mrow, int C, unsigned short* __restrict__ Mq, double (&t)[3]) {
     const float loc_g = o.loc, ls_g = o.ls, eA = o.eA, eB = o.eB;
     const double cs = o.cs;
     const float4 lr0 = o.lr0, lr1 = o.lr1;
@@ -815,7 +815,7 @@ __device__ __forceinline__ void ca_gene_pre_fused_core(const ca_gene_pre_ops& o,
     for (int p = K; p < D; ++p) bx += (double)V[(int64_t)g * D + p] * YtX[(int64_t)g * (D - K) + (p - K)];
     const float* lp = lrow;
     const bool c16 = C > CA_CW;   // 9..16 clones: ONE draw per sweep, its clones 8.. in the second column half (copy numbers: second chunk of Lb)
-    for (int w = 0; w < 2; ++w) {
+    {
       const double e = (double)(w ? eB : eA);
       const double x = l + sd * e;
       const double mu = ca_softplus_d(x), lm = log(mu);
@@ -849,10 +849,22 @@ __device__ __forceinline__ void ca_gene_pre_fused_core(const ca_gene_pre_ops& o,
         for (int c = 0; c < CA_CW; ++c)
           if (c < C) mp[c] = lp[c] * muf;
       }
-      t[w][0] = cs * lm + bx;
-      t[w][1] = -0.5 * lm * lm - 0.5 * CA_LOG2PI;
-      t[w][2] = -0.5 * e * e - lsd - 0.5 * CA_LOG2PI + (mu - x);
+      t[0] = cs * lm + bx;
+      t[1] = -0.5 * lm * lm - 0.5 * CA_LOG2PI;
+      t[2] = -0.5 * e * e - lsd - 0.5 * CA_LOG2PI + (mu - x);
     }
+}
+__device__ __forceinline__ void ca_gene_pre_fused_core(const ca_gene_pre_ops& o, const float* __restrict__ Lb, const float* __restrict__ V, int D, int K,
+                                                          const double* __restrict__ YtX, float* __restrict__ muA, float* __restrict__ muB,
+                                                          float* __restrict__ Mb, double* __restrict__ gene_partA, double* __restrict__ gene_partB, int G,
+                                                          int mrow, int C, unsigned short* __restrict__ Mq, double* sm, int blk, int s2) {
+  const int g = blk * CA_TB + threadIdx.x;
+  const bool ok = g < G;
+  double t[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+  const float wk0 = o.wk0;   // W_g0, for the sum of squares below
+  if (ok) {
+    ca_gene_pre_draw(0, g, o, Lb, V, D, K, YtX, muA, muB, Mb, G, mrow, C, Mq, t[0]);
+    ca_gene_pre_draw(1, g, o, Lb, V, D, K, YtX, muA, muB, Mb, G, mrow, C, Mq, t[1]);
   }
   const int W_ = 3 + K;
   // the six term sums and (up to two) sums of squared loadings in ONE pass through the block reduction: one pair of barriers
@@ -2174,10 +2186,11 @@ struct ca_cell_ptrs {
                       //    coef for both samples (second one N x 8 floats / N16 x 32 bf16 further on, the layout the S loops use)
   int64_t N16;
   // round 4: after a merged update (k_update_merged) nobody has made the exponent bound of the new state yet: the sweep's blocks take it
-  // themselves -- the range of V' from the per-gene blocks' pairs (vmm_part, what k_vmm_final / k_adam_cell reduce), then
-  // sum_d max(F_nd Vmin_d, F_nd Vmax_d) exactly as k_etamax forms it -- and leave it in etamax_w (= etamax2) for their own cell
-  // epilogue and for the backward sweep.  vmm_part = null: etamax2 is current, read it.
-  const float* vmm_part; int ngblk; float* etamax_w;
+  // themselves -- the range of V' (the gene blocks of the merged update leave it with one atomic min / max each: 2 D words, one
+  // uniform load here instead of a per-cell load of etamax2), then sum_d max(F_nd Vmin_d, F_nd Vmax_d) exactly as k_etamax forms
+  // it -- and leave it in etamax_w (= etamax2) for their own cell epilogue and for the backward sweep.  vmm_at = null: etamax2 is
+  // current, read it.
+  const int* vmm_at; float* etamax_w;   // vmm_at: [2][8] order-preserving ints of min / max (ca_f2ord), see k_update_merged
 };
 template <int CP>
 __device__ __forceinline__ void ca_cell_fused_group(const ca_cell_ptrs& p, const double* la, int64_t n, int64_t N, int C, int D, int K,
@@ -2421,36 +2434,31 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (scalar: the k-loop's bounds, branches and operand bases then are)
   float f[TL][D], em[TL];
   ca_f32x4 acc[TL];
-  float vmn[D], vmx[D];   // (merged update: range of V' over the gene blocks, every wave for itself -- min / max: any order gives the same)
-  if (p.vmm_part) {
+  float vmn[D], vmx[D];   // (merged update: range of V' over all genes)
+  if (p.vmm_at) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-      float mn = INFINITY, mx = -INFINITY;
-      for (int b = lane; b < p.ngblk; b += 64) {
-        mn = fminf(mn, p.vmm_part[((int64_t)b * 2 + 0) * D + d]);
-        mx = fmaxf(mx, p.vmm_part[((int64_t)b * 2 + 1) * D + d]);
-      }
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) { mn = fminf(mn, __shfl_xor(mn, o, 64)); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
-      vmn[d] = mn; vmx[d] = mx;
-    }
+    for (int d = 0; d < D; ++d) { vmn[d] = ca_ord2f(p.vmm_at[d]); vmx[d] = ca_ord2f(p.vmm_at[8 + d]); }
   }
+  // (all loads of the head in ONE batch, whichever way the bound comes: a branch inside the tile loop would put a round trip per tile here)
 #pragma unroll
   for (int t = 0; t < TL; ++t) {
     const int64_t n = cell0 + 16 * t + j;
     const int64_t nn = n < N ? n : N - 1;
 #pragma unroll
     for (int d = 0; d < D; ++d) f[t][d] = F[nn * D + d];
-    if (p.vmm_part) {
+    em[t] = p.vmm_at ? 0.f : etamax2[nn];
+    acc[t] = (ca_f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  if (p.vmm_at) {
+#pragma unroll
+    for (int t = 0; t < TL; ++t) {
+      const int64_t n = cell0 + 16 * t + j;
       float e = 0.f;
 #pragma unroll
       for (int d = 0; d < D; ++d) e += fmaxf(f[t][d] * vmn[d], f[t][d] * vmx[d]);   // (k_etamax's arithmetic)
       em[t] = e;
       if (wv == 0 && q == 0 && n < N) p.etamax_w[n] = e;   // for this block's epilogue (behind the barriers below) and the backward sweep
-    } else {
-      em[t] = etamax2[nn];
     }
-    acc[t] = (ca_f32x4){0.f, 0.f, 0.f, 0.f};
   }
   unsigned m0, m1;   // (-1, 0) and (0, -1) as bf16 pairs, see k_fwd_mfma
   asm volatile("s_mov_b32 %0, 0x0000bf80" : "=s"(m0));
@@ -2895,6 +2903,17 @@ __device__ __forceinline__ void ca_psi_adam_body(const ca_psi_args& a, int blk, 
 }
 
 struct ca_gene_new { float loc, ls, V0; double cs; };   // a gene's stepped loc / ls / first loading (and its count total), in registers
+__device__ __forceinline__ float ca_final_gene_step(int g, bool ok, const double* __restrict__ red_g, const double* __restrict__ red_y,
+                                                     const float* __restrict__ eps, const double* __restrict__ colsum,
+                                                     const double* __restrict__ YtX, const float* __restrict__ vchi,
+                                                     float* __restrict__ loc, float* __restrict__ ls, float* __restrict__ V,
+                                                     float* __restrict__ m_loc, float* __restrict__ v_loc, float* __restrict__ m_ls,
+                                                     float* __restrict__ v_ls, float* __restrict__ m_V, float* __restrict__ v_V,
+                                                     float* __restrict__ g_loc, float* __restrict__ g_ls, float* __restrict__ g_V,
+                                                     int G, int S, int D, int K, int apply, float lr_t, float b1, float b2, float aeps,
+                                                     const float* __restrict__ gfold, int nfold, ca_gene_new* nw);
+__device__ __forceinline__ void ca_final_gene_range(int g, bool ok, float Vnew0, const float* __restrict__ V, float* __restrict__ Vs,
+                                                     float* __restrict__ vmm_part, int G, int D, int blk, float* smin, float* smax);
 __device__ __forceinline__ void ca_final_gene_body(const double* __restrict__ red_g /*[G][S+D]*/, const double* __restrict__ red_y /*[G][K]*/,
                                                       const float* __restrict__ eps, const double* __restrict__ colsum,
                                                       const double* __restrict__ YtX, const float* __restrict__ vchi,
@@ -2908,7 +2927,22 @@ __device__ __forceinline__ void ca_final_gene_body(const double* __restrict__ re
                                                       ca_gene_new* nw = nullptr /* merged update: the stepped values stay in registers */) {
   const int g = blockIdx.x * CA_TB + threadIdx.x;
   const bool ok = g < G;
-  float Vnew0 = 0.f;   // the first loading after this step (kept in a register for the log2 image below)
+  const float Vnew0 = ca_final_gene_step(g, ok, red_g, red_y, eps, colsum, YtX, vchi, loc, ls, V, m_loc, v_loc, m_ls, v_ls, m_V, v_V, g_loc, g_ls, g_V,
+                                         G, S, D, K, apply, lr_t, b1, b2, aeps, gfold, nfold, nw);
+  if (!apply) return;
+  ca_final_gene_range(g, ok, Vnew0, V, Vs, vmm_part, G, D, (int)blockIdx.x, smin, smax);
+}
+// one gene's gradients and Adam step (per lane, no block-level operation): returns the stepped first loading
+__device__ __forceinline__ float ca_final_gene_step(int g, bool ok, const double* __restrict__ red_g, const double* __restrict__ red_y,
+                                                     const float* __restrict__ eps, const double* __restrict__ colsum,
+                                                     const double* __restrict__ YtX, const float* __restrict__ vchi,
+                                                     float* __restrict__ loc, float* __restrict__ ls, float* __restrict__ V,
+                                                     float* __restrict__ m_loc, float* __restrict__ v_loc, float* __restrict__ m_ls,
+                                                     float* __restrict__ v_ls, float* __restrict__ m_V, float* __restrict__ v_V,
+                                                     float* __restrict__ g_loc, float* __restrict__ g_ls, float* __restrict__ g_V,
+                                                     int G, int S, int D, int K, int apply, float lr_t, float b1, float b2, float aeps,
+                                                     const float* __restrict__ gfold, int nfold, ca_gene_new* nw) {
+  float Vnew0 = 0.f;   // the first loading after this step (kept in a register for the log2 image)
   if (ok) {
   // Every operand whose address does not depend on a result is loaded HERE, in one batch: this block is one wave per SIMD, and each
   // dependent round of loads costs it 1.5 us after the sweeps have been through the caches and the TLB (block stamps,
@@ -2993,8 +3027,12 @@ __device__ __forceinline__ void ca_final_gene_body(const double* __restrict__ re
   }
   }
   if (nw) nw->V0 = Vnew0;
-  if (!apply) return;
-  // the updated loadings in log2 units and their per-block range (k_vprep fused in; same arithmetic)
+  return Vnew0;
+}
+// the stepped loadings in log2 units and their per-block range (k_vprep fused in; same arithmetic); block-level: the four waves of a
+// 256-gene block (threads 0 .. 255 by `wave4`, the wave's place among them) meet through LDS
+__device__ __forceinline__ void ca_final_gene_range(int g, bool ok, float Vnew0, const float* __restrict__ V, float* __restrict__ Vs,
+                                                     float* __restrict__ vmm_part, int G, int D, int blk, float* smin, float* smax) {
   for (int d = 0; d < D; ++d) {
     float v = 0.f;
     if (ok) {
@@ -3013,8 +3051,8 @@ __device__ __forceinline__ void ca_final_gene_body(const double* __restrict__ re
     if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = mn; smax[threadIdx.x >> 6] = mx; }
     __syncthreads();
     if (threadIdx.x == 0) {
-      vmm_part[((int64_t)blockIdx.x * 2 + 0) * D + d] = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
-      vmm_part[((int64_t)blockIdx.x * 2 + 1) * D + d] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+      vmm_part[((int64_t)blk * 2 + 0) * D + d] = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
+      vmm_part[((int64_t)blk * 2 + 1) * D + d] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
     }
   }
 }
@@ -3162,59 +3200,149 @@ struct ca_merge_args {
   ca_ysq_args ysq;         // nblk > 0: the int8 stream's images, made in the gene / psi blocks (pairs of maxima: gene blocks, then psi blocks)
   ca_small_args tail;      // the chi / alpha step (vchi_out / alpha_out set)
   float* glogit; const float* dgl; float* m_gl; float* v_gl; int C; int ncell;   // q(z) logits: ncell blocks of 256 cells
+  int* vmm_at; int* vmm_at_next;   // range of V' over ALL genes as ordered ints [2][8]: every gene block folds its own in with one atomic min / max per
+                                   // dimension (the next sweep reads 2 D words); the chi / alpha block resets the buffer of the NEXT merged update
 };
-__global__ void __launch_bounds__(CA_TB) k_update_merged(const double* __restrict__ red_g /*[G][S+D]*/, const double* __restrict__ red_y /*[G][K]*/,
-                                                         const float* __restrict__ eps, const double* __restrict__ colsum,
-                                                         const double* __restrict__ YtX, const float* __restrict__ vchi,
-                                                         float* __restrict__ loc, float* __restrict__ ls, float* __restrict__ V,
-                                                         float* __restrict__ m_loc, float* __restrict__ v_loc, float* __restrict__ m_ls,
-                                                         float* __restrict__ v_ls, float* __restrict__ m_V, float* __restrict__ v_V,
-                                                         float* __restrict__ g_loc, float* __restrict__ g_ls, float* __restrict__ g_V,
-                                                         float* __restrict__ Vs, float* __restrict__ vmm_part,
-                                                         int G, int S, int D, int K, float lr_t, float b1, float b2, float aeps, ca_small_args mon, int gblocks,
-                                                         ca_psi_args psi, const float* __restrict__ gfold, int nfold, ca_merge_args mg) {
+#define CA_UM_TB 1024   // threads of a k_update_merged block: a gene block is 256 genes x four ROLES (below); every other kind of block uses its first 256
+__global__ void __launch_bounds__(CA_UM_TB) k_update_merged(const double* __restrict__ red_g /*[G][S+D]*/, const double* __restrict__ red_y /*[G][K]*/,
+                                                            const float* __restrict__ eps, const double* __restrict__ colsum,
+                                                            const double* __restrict__ YtX, const float* __restrict__ vchi,
+                                                            float* __restrict__ loc, float* __restrict__ ls, float* __restrict__ V,
+                                                            float* __restrict__ m_loc, float* __restrict__ v_loc, float* __restrict__ m_ls,
+                                                            float* __restrict__ v_ls, float* __restrict__ m_V, float* __restrict__ v_V,
+                                                            float* __restrict__ g_loc, float* __restrict__ g_ls, float* __restrict__ g_V,
+                                                            float* __restrict__ Vs, float* __restrict__ vmm_part,
+                                                            int G, int S, int D, int K, float lr_t, float b1, float b2, float aeps, ca_small_args mon, int gblocks,
+                                                            ca_psi_args psi, const float* __restrict__ gfold, int nfold, ca_merge_args mg) {
   [[maybe_unused]] const int nmon = mon.enabled ? 1 : 0;
   const int bx = (int)blockIdx.x;
   CA_LAB_STAMP(bx, bx < gblocks ? 0 : bx < gblocks + nmon ? 1 : bx == gblocks + nmon ? 4 : bx < gblocks + nmon + 1 + psi.nblk ? 2 : 5);
-  __shared__ float smq[2 * (CA_YM_TB / 64)];
   if (bx < gblocks) {
+    // A gene's chain here is: its Adam step (one round of loads, then fp64 exp / log1p / log and three Adam steps: 5 us at one wave per
+    // SIMD), THEN the two draws of the next prologue (2.7 us each: softplus, log, the operand row) and its part of the W image (2 us) --
+    // 12.5 us when one thread does them in a row (block stamps, profiles/r04_update_merge.txt).  The three pieces behind the step need
+    // only the stepped loc / ls / W_g0, so sixteen waves share a block of 256 genes: waves 0-3 take the step, hand the three floats over
+    // through LDS and go on to V' (log2 units, range) and the sums of squares; waves 4-7 take draw A of the same genes, 8-11 draw B,
+    // 12-15 the W image.  Every block-level sum keeps the order of the 256-thread form: butterflies inside a 64-gene wave, then the
+    // four gene groups in order -- bitwise the same partials.
     if (CA_LAB_SKIP & 4) return;
-    __shared__ float smin[CA_TB], smax[CA_TB];
-    __shared__ double smp[CA_TB];
-    const int g = bx * CA_TB + (int)threadIdx.x;
+    __shared__ float h_loc[CA_TB], h_ls[CA_TB], h_v0[CA_TB];
+    __shared__ double smt[4][8];
+    __shared__ float smn[8][4], smx[8][4], sma[4];
+    const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6, role = wv >> 2, grp = wv & 3;
+    const int g = bx * CA_TB + grp * 64 + l;
     const bool ok = g < G;
-    // the prologue's operands that nothing here produces (the next pair's two draws, the gene's copy numbers): issued with the block's first batch of loads
     ca_gene_pre_ops o = {0.f, 0.f, 0.f, 0.f, 0.f, 0.0, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    if (ok) {
-      o.eA = mg.pre.epsA[g]; o.eB = mg.pre.epsB[g];
+    float V0n = 0.f;
+    CA_LAB_CP(bx, 0);
+    if (role == 0) {
+      ca_gene_new nw = {0.f, 0.f, 0.f, 0.0};
+      V0n = ca_final_gene_step(g, ok, red_g, red_y, eps, colsum, YtX, vchi, loc, ls, V, m_loc, v_loc, m_ls, v_ls, m_V, v_V, g_loc, g_ls, g_V,
+                               G, S, D, K, 1, lr_t, b1, b2, aeps, gfold, nfold, &nw);
+      h_loc[grp * 64 + l] = nw.loc; h_ls[grp * 64 + l] = nw.ls; h_v0[grp * 64 + l] = V0n;
+    } else if (role < 3 && ok) {   // the draws' operands that nothing here produces: in flight while the step runs
+      o.eA = mg.pre.epsA[g]; o.eB = mg.pre.epsB[g]; o.cs = colsum[g];
       o.lr0 = *reinterpret_cast<const float4*>(mg.pre.Lb + (int64_t)g * CA_CW); o.lr1 = *reinterpret_cast<const float4*>(mg.pre.Lb + (int64_t)g * CA_CW + 4);
     }
-    ca_gene_new nw = {0.f, 0.f, 0.f, 0.0};
-    ca_final_gene_body(red_g, red_y, eps, colsum, YtX, vchi, loc, ls, V, m_loc, v_loc, m_ls, v_ls, m_V, v_V, g_loc, g_ls, g_V, Vs, vmm_part, G, S, D, K,
-                       1, lr_t, b1, b2, aeps, smin, smax, gfold, nfold, &nw);
-    o.loc = nw.loc; o.ls = nw.ls; o.cs = nw.cs; o.wk0 = K > 0 ? nw.V0 : 0.f;
-    ca_gene_pre_fused_core(o, mg.pre.Lb, V, D, K, YtX, mg.pre.muA, mg.pre.muB, mg.pre.Mb, mg.pre.gene_partA, mg.pre.gene_partB, G, mg.pre.mrow,
-                           mg.pre.C, mg.pre.Mq, smp, bx, mg.pre.s2);
-    if (mg.ysq.nblk) ca_ys_quant_inreg(mg.ysq, true, bx, nw.V0, bx, bx == 0, smq);
+    __syncthreads();
+    CA_LAB_CP(bx, 1);
+    if (role == 0) {
+      // the stepped loadings in log2 units and their range over the block (ca_final_gene_range's arithmetic, wave level)
+      for (int d = 0; d < D && d < 8; ++d) {
+        float v = 0.f;
+        if (ok) {
+          v = (d == 0 ? V0n : V[(int64_t)g * D + d]) * CA_LOG2E_F;
+          Vs[(int64_t)g * D + d] = v;
+          if (g == G - 1)
+            for (int gp = G; gp < ((G + 31) / 32) * 32; ++gp) Vs[(int64_t)gp * D + d] = v;
+        }
+        float mn = ok ? v : INFINITY, mx = ok ? v : -INFINITY;
+#pragma unroll
+        for (int q = 1; q < 64; q <<= 1) { mn = fminf(mn, __shfl_xor(mn, q, 64)); mx = fmaxf(mx, __shfl_xor(mx, q, 64)); }
+        if (l == 0) { smn[d][grp] = mn; smx[d][grp] = mx; }
+      }
+      // sums of squared loadings (terms 6 and 7 of the prologue's block sums)
+      const float wk0 = K > 0 ? V0n : 0.f;
+      double e6 = ok ? (double)wk0 * (double)wk0 : 0.0, e7 = 0.0;
+      if (K > 1 && ok) { const double w1 = (double)V[(int64_t)g * D + 1]; e7 = w1 * w1; }
+#pragma unroll
+      for (int q = 1; q < 64; q <<= 1) { e6 += __shfl_xor(e6, q, 64); e7 += __shfl_xor(e7, q, 64); }
+      if (l == 0) { smt[grp][6] = e6; smt[grp][7] = e7; }
+    } else if (role < 3) {
+      double t[3] = {0.0, 0.0, 0.0};
+      if (ok) {
+        o.loc = h_loc[grp * 64 + l]; o.ls = h_ls[grp * 64 + l];
+        ca_gene_pre_draw(role - 1, g, o, mg.pre.Lb, V, D, K, YtX, mg.pre.muA, mg.pre.muB, mg.pre.Mb, G, mg.pre.mrow, mg.pre.C, mg.pre.Mq, t);
+      }
+#pragma unroll
+      for (int q = 1; q < 64; q <<= 1) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t[i] += __shfl_xor(t[i], q, 64);
+      }
+      if (l == 0) { smt[grp][3 * (role - 1) + 0] = t[0]; smt[grp][3 * (role - 1) + 1] = t[1]; smt[grp][3 * (role - 1) + 2] = t[2]; }
+    } else {
+      float m = 0.f;
+      if (mg.ysq.nblk) {
+        const int64_t step = (int64_t)bx * (CA_TB / 64) + grp;
+        const bool live = step < (int64_t)mg.ysq.GS;
+        m = ca_ys_quant_wave(mg.ysq, live, true, live ? step : 0, h_v0[grp * 64 + l], bx == 0 && grp == 0);
+      }
+      if (l == 0) sma[grp] = m;
+    }
+    __syncthreads();
+    CA_LAB_CP(bx, 2);
+    if (tid == 0) {
+      double e[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { double r = smt[0][i]; r += smt[1][i]; r += smt[2][i]; r += smt[3][i]; e[i] = r; }
+      const int W_ = 3 + K;
+      double* ga = mg.pre.gene_partA + (int64_t)bx * W_;
+      double* gb = mg.pre.gene_partB + (int64_t)bx * W_;
+      if (mg.pre.s2) { ga[0] = 0.5 * (e[0] + e[3]); ga[1] = 0.5 * (e[1] + e[4]); ga[2] = 0.5 * (e[2] + e[5]); }
+      else { ga[0] = e[0]; ga[1] = e[1]; ga[2] = e[2]; }
+      gb[0] = e[3]; gb[1] = e[4]; gb[2] = e[5];
+      for (int k = 0; k < K && k < 2; ++k) { ga[3 + k] = e[6 + k]; gb[3 + k] = e[6 + k]; }
+      for (int d = 0; d < D && d < 8; ++d) {
+        vmm_part[((int64_t)bx * 2 + 0) * D + d] = fminf(fminf(smn[d][0], smn[d][1]), fminf(smn[d][2], smn[d][3]));
+        vmm_part[((int64_t)bx * 2 + 1) * D + d] = fmaxf(fmaxf(smx[d][0], smx[d][1]), fmaxf(smx[d][2], smx[d][3]));
+        atomicMin(mg.vmm_at + d, ca_f2ord(fminf(fminf(smn[d][0], smn[d][1]), fminf(smn[d][2], smn[d][3]))));
+        atomicMax(mg.vmm_at + 8 + d, ca_f2ord(fmaxf(fmaxf(smx[d][0], smx[d][1]), fmaxf(smx[d][2], smx[d][3]))));
+      }
+      if (mg.ysq.nblk) {
+        mg.ysq.amax_out[2 * bx] = fmaxf(fmaxf(sma[0], sma[1]), fmaxf(sma[2], sma[3]));
+        mg.ysq.amax_out[2 * bx + 1] = 0.f;
+      }
+    }
+    CA_LAB_CP(bx, 3);
     return;
   }
+  if ((int)threadIdx.x >= CA_TB) return;   // every other kind of block is a 256-thread block
+  __shared__ float smq[2 * (CA_YM_TB / 64)];
   int b = bx - gblocks;
   if (mon.enabled) {   // the pending monitor pass's ELBO (ca_final_small_body), beside the gene blocks
-    if (b == 0) { if (!(CA_LAB_SKIP & 1)) ca_final_small_body(mon); return; }
+    if (b == 0) { CA_LAB_CP(40, 0); if (!(CA_LAB_SKIP & 1)) ca_final_small_body(mon); CA_LAB_CP(40, 1); return; }
     --b;
   }
-  if (b == 0) { if (!(CA_LAB_SKIP & 8) && mg.tail.enabled) ca_final_small_body(mg.tail); return; }   // chi / alpha step
+  if (b == 0) {   // chi / alpha step
+    if (threadIdx.x < 8) { mg.vmm_at_next[threadIdx.x] = ca_f2ord(INFINITY); mg.vmm_at_next[8 + threadIdx.x] = ca_f2ord(-INFINITY); }
+    CA_LAB_CP(41, 0); if (!(CA_LAB_SKIP & 8) && mg.tail.enabled) ca_final_small_body(mg.tail); CA_LAB_CP(41, 1); return;
+  }
   --b;
   if (b < psi.nblk) {
     if (CA_LAB_SKIP & 2) return;
     float pn = 0.f;
+    if (b == 0) CA_LAB_CP(42, 0);
     ca_psi_adam_body(psi, b, 1, lr_t, b1, b2, aeps, &pn);
+    if (b == 0) CA_LAB_CP(42, 1);
     if (mg.ysq.nblk) ca_ys_quant_inreg(mg.ysq, false, b, pn, gblocks + b, false, smq);
+    if (b == 0) CA_LAB_CP(42, 2);
     return;
   }
   b -= psi.nblk;
   if (CA_LAB_SKIP & 64) return;
+  if (b == 0) CA_LAB_CP(43, 0);
   if (b < mg.ncell) ca_logit_adam_body(b, mg.glogit, mg.dgl, mg.m_gl, mg.v_gl, psi.N, mg.C, lr_t, b1, b2, aeps);
+  if (b == 0) CA_LAB_CP(43, 1);
 }
 
 // Column products, engine form: the sweep of ca_yt_block plus, as extra blocks of the launch, the gene side of the overflow

@@ -620,6 +620,46 @@ __device__ __forceinline__ void ca_ys_quant_body(int blk, const ca_ysq_args& a, 
   }
   ca_ys_quant_core(a, live, isw, step, vals, own, blk, blk == 0, sm);
 }
+// Wave-level form of ca_ys_quant_core for ONE 64-step whose entries are in registers (round 4, the gene blocks of k_update_merged): no
+// block-level operation; returns the step's exact maximum (wave-uniform).  The exponents come from the same maxima (a maximum does not
+// depend on the order it is taken in), everything else is the core's arithmetic.
+__device__ __forceinline__ float ca_ys_quant_wave(const ca_ysq_args& a, bool live, bool isw, int64_t step, float own, bool write_exps) {
+  const int l = threadIdx.x & 63;
+  float vals[16];
+#pragma unroll
+  for (int b = 0; b < 16; ++b) vals[b] = __shfl(own, 16 * (l >> 4) + b, 64);
+  float mw = 0.f, mp = 0.f;
+  for (int i = l; i < a.n_in; i += 64) { mw = fmaxf(mw, a.amax_in[2 * i]); mp = fmaxf(mp, a.amax_in[2 * i + 1]); }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { mw = fmaxf(mw, __shfl_xor(mw, o, 64)); mp = fmaxf(mp, __shfl_xor(mp, o, 64)); }
+  const int ew = ca_fix_exp(mw + a.slack_w), ep = ca_fix_exp(mp + a.slack_p);
+  if (write_exps && l == 0) { a.exps[0] = ew; a.exps[1] = ep; }
+  float m = 0.f;
+  if (live) {
+    const float sc = ldexpf(1.f, isw ? ew : ep);
+    const int p = l & 3;
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int b = 0; b < 16; ++b) {
+      const int x = (int)rintf(fminf(fmaxf(vals[b] * sc, -2147483000.f), 2147483000.f));
+      w[b >> 2] |= ((unsigned)ca_digit(x, p) & 0xFFu) << (8 * (b & 3));
+    }
+    const uint4 v = {w[0], w[1], w[2], w[3]};
+    (isw ? a.Wr : a.Pr)[step * 64 + l] = v;
+    int sd = 0;
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) sd += (int)(signed char)((w[d] >> (8 * b)) & 0xFFu);
+    sd += __shfl_xor(sd, 16, 64);
+    sd += __shfl_xor(sd, 32, 64);
+    if (l < 4) (isw ? a.Wsum : a.Psum)[step * 4 + l] = sd;
+    m = fabsf(own);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  }
+  return m;
+}
 // The same images made where the entries are BORN (round 4, k_update_merged): a block of 256 genes (cells) has just stepped W_g0 (psi_n0),
 // one entry per lane = four 64-steps of the W (psi) image; the sixteen entries a lane packs come from its wave-mates by shuffle.
 // `own` = this lane's entry (0 past the last row).  Same arithmetic on the same floats as ca_ys_quant_body reading them back.

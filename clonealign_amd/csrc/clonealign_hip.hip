@@ -123,6 +123,7 @@ struct ca_engine {
   // bound of the stepped state is then made by the next forward sweep itself (em_stale: nobody has made it yet)
   float *vchi_alt = nullptr, *alpha_u_alt = nullptr;
   bool upd_merge = false, em_stale = false;
+  int* vmm_at = nullptr; int vmm_at_idx = 0; bool vmm_at_ready = false;   // [2][16] ordered-int range of V' (k_update_merged), the buffer in use alternates
   double dir_const = 0.0;
   float b1p = 0.f, b2p = 0.f;  // running beta powers, float32 like TF's beta*_power variables
   // ---- gradients (d ELBO / d var)
@@ -1059,8 +1060,16 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
       mg.tail.vmm_part = nullptr; mg.tail.vmm = nullptr;   // the range of V' is the next sweep's business
       mg.tail.vchi_out = h->vchi_alt; mg.tail.alpha_out = h->alpha_u_alt;
       mg.glogit = h->glogit; mg.dgl = h->dgl; mg.m_gl = h->m_gl; mg.v_gl = h->v_gl; mg.C = h->C; mg.ncell = N256;
+      if (!h->vmm_at_ready) {   // first merged update of this engine: both range buffers at (+inf, -inf); from here on every launch resets the next one's
+        int init[32];
+        for (int i = 0; i < 32; ++i) init[i] = (i & 8) ? (int)0x807FFFFF /* ca_f2ord(-inf) */ : (int)0x7F800000 /* ca_f2ord(+inf) */;
+        HIPCK(h, hipMemcpyAsync(h->vmm_at, init, sizeof(init), hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));   // (the source is on this stack frame)
+        h->vmm_at_ready = true;
+      }
+      mg.vmm_at = h->vmm_at + 16 * h->vmm_at_idx; mg.vmm_at_next = h->vmm_at + 16 * (1 - h->vmm_at_idx);
       LAUNCH(h, CA_KERNEL_OTHER,
-             hipLaunchKernelGGL(k_update_merged, dim3(h->ngblk + (mon.enabled ? 1 : 0) + 1 + psi.nblk + N256), dim3(CA_TB), 0, h->stream,
+             hipLaunchKernelGGL(k_update_merged, dim3(h->ngblk + (mon.enabled ? 1 : 0) + 1 + psi.nblk + N256), dim3(CA_UM_TB), 0, h->stream,
                                 h->red + h->off_g, h->red + h->off_y, eps, h->colsum, h->YtX, h->vchi, h->loc, h->ls, h->V, h->m_loc, h->v_loc,
                                 h->m_ls, h->v_ls, h->m_V, h->v_V, h->g_loc, h->g_ls, h->g_V, h->Vs, h->vmm_part, h->G, h->S, h->D, h->K, lr_t,
                                 (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, mon, h->ngblk, psi,
@@ -1073,6 +1082,7 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
       std::swap(h->vchi, h->vchi_alt);
       std::swap(h->alpha_u, h->alpha_u_alt);
       h->em_stale = true;
+      h->vmm_at_idx = 1 - h->vmm_at_idx;   // (the buffer this launch filled is the other one from now on: vmm_at_cur below)
       h->pre_valid = true; h->pre_A = mA; h->pre_B = mB;
       h->hint_A = h->hint_B = -1;
       if (h->ys_steps >= 0) h->ys_steps += 1;
@@ -1230,8 +1240,8 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
   ca_cell_ptrs cp;
   cp.A = h->A; cp.cn = h->cn; cp.s64 = h->s64; cp.etamax2 = h->etamax2; cp.glogit = h->glogit; cp.F = h->F;
   cp.coef = h->coef; cp.dgl = h->dgl; cp.coefq = h->bwd_mfma ? h->coefq : nullptr;
-  cp.vmm_part = nullptr; cp.ngblk = 0; cp.etamax_w = nullptr;
-  if (h->em_stale && h->fwd_cell && h->D > 0) { cp.vmm_part = h->vmm_part; cp.ngblk = h->ngblk; cp.etamax_w = h->etamax2; h->em_stale = false; }
+  cp.vmm_at = nullptr; cp.etamax_w = nullptr;
+  if (h->em_stale && h->fwd_cell && h->D > 0) { cp.vmm_at = h->vmm_at + 16 * (1 - h->vmm_at_idx); cp.etamax_w = h->etamax2; h->em_stale = false; }
   else CACK(ensure_etamax(h));
   cp.ee_partB = (elbo_dstB && h->fwd_cell) ? h->ee_partB : nullptr;
   cp.s2 = h->s2 ? 1 : 0; cp.N16 = h->N16;
@@ -1951,6 +1961,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   CACK(dalloc(h, &h->g_v, std::max(K, 1)));
   CACK(dalloc(h, &h->alpha_u, C)); CACK(dalloc(h, &h->m_a, C)); CACK(dalloc(h, &h->v_a, C)); CACK(dalloc(h, &h->g_a, C));
   CACK(dalloc(h, &h->vchi_alt, std::max(K, 1))); CACK(dalloc(h, &h->alpha_u_alt, C));
+  CACK(dalloc(h, &h->vmm_at, 32));
   {
     std::vector<float> Fh((size_t)Nn * std::max(D, 1), 0.f);
     if (D > 0) {

@@ -9,8 +9,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-KINDS = {0: "final_gene: gene", 1: "final_gene: monitor tail", 2: "final_gene: psi", 3: "adam_cell: gene prologue", 4: "adam_cell: small (chi/alpha)",
-         5: "adam_cell: cell", 6: "adam_cell: quantiser"}
+KINDS = {0: "gene (+ prologue + W image when merged)", 1: "monitor tail", 2: "psi (+ psi image when merged)", 3: "adam_cell: gene prologue", 4: "small (chi/alpha)",
+         5: "cell (q(z) logits)", 6: "adam_cell: quantiser"}
 
 
 def main():
@@ -36,9 +36,11 @@ def main():
     assert lib.ca_lab_read_stamps2(buf.ctypes.data_as(C.c_void_p), nb) == 0
     eng.close()
     checkpoints(buf)
-    for lo, hi, name in ((0, 1024, "k_final_gene"), (1024, 4096, "k_adam_cell")):
+    for lo, hi, name in ((0, 1024, "k_final_gene / k_update_merged"), (1024, 3072, "k_adam_cell")):
         b = buf[lo:hi]
-        b = b[b[:, 3] > 0]
+        b = b[b[:, 3] == 1]
+        if len(b) == 0:
+            continue
         t0 = b[:, 0].min()
         start = (b[:, 0] - t0).astype(np.float64) / 100.0
         end = (b[:, 1] - t0).astype(np.float64) / 100.0
@@ -52,10 +54,9 @@ def main():
 
 def checkpoints(buf):
     cp = buf[3072:3072 + 8 * 64].reshape(64, 8, 4)
-    for name, blocks in (("gene block (entry, loads + exp(ls), fold, fp64 terms, Adam + V, ...)", range(0, 20)),
-                         ("gene prologue (entry, loads + exp(ls), terms + operand stores, block sum)", range(20, 40)),
-                         ("monitor tail (entry, first reductions, gene sums, K sums + range, wave 0 done)", [40]),
-                         ("chi / alpha block (same points)", [41])):
+    for name, blocks in (("merged gene block (entry, after the Adam step + V' range, after the prologue, after the W image)", range(0, 20)),
+                         ("monitor tail block (entry, done)", [40]), ("chi / alpha block (entry, done)", [41]),
+                         ("first psi block (entry, after the step, after the psi image)", [42]), ("first logits block (entry, done)", [43])):
         rows = []
         for b in blocks:
             if cp[b, 0, 3] == 2:
