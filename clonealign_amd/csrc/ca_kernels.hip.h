@@ -805,7 +805,8 @@ __device__ __forceinline__ void ca_gene_pre_fused_body(const float* __restrict__
 // the gene's three ELBO terms.  Per lane, no block-level operation (the merged update gives the two draws to two waves).
 __device__ __forceinline__ void ca_gene_pre_draw(int w, int g, const ca_gene_pre_ops& o, const float* __restrict__ Lb, const float* __restrict__ V, int D, int K,
                                                     const double* __restrict__ YtX, float* __restrict__ muA, float* __restrict__ muB,
-                                                    float* __restrict__ Mb, int G, int mrow, int C, unsigned short* __restrict__ Mq, double (&t)[3]) {
+                                                    float* __restrict__ Mb, int G, int mrow, int C, unsigned short* __restrict__ Mq, double (&t)[3],
+                                                    double* __restrict__ aux = nullptr, int64_t aux_ld = 0) {
     const float loc_g = o.loc, ls_g = o.ls, eA = o.eA, eB = o.eB;
     const double cs = o.cs;
     const float4 lr0 = o.lr0, lr1 = o.lr1;
@@ -818,9 +819,21 @@ __device__ __forceinline__ void ca_gene_pre_draw(int w, int g, const ca_gene_pre
     {
       const double e = (double)(w ? eB : eA);
       const double x = l + sd * e;
-      const double mu = ca_softplus_d(x), lm = log(mu);
+      // softplus with its exp kept: t = exp(-|x|), softplus = max(x, 0) + log1p(t) -- the very doubles ca_softplus_d(x) gives
+      // (x > 0: x + log1p(exp(-x)); else 0 + log1p(exp(x))), and t is what the sigmoid below wants
+      const double tx = exp(-fabs(x));
+      const double mu = (x > 0 ? x : 0.0) + log1p(tx), lm = log(mu);
       const float muf = (float)mu;
       (w ? muB : muA)[g] = muf;
+      if (aux) {
+        // Round 4: this draw is the eps of the NEXT train pass, and everything in that pass's per-gene gradient that does not depend on
+        // the backward sweep is known here: exp(ls), the sigmoid, cs / mu, log(mu) / mu, (1 - sigmoid) -- ca_final_gene_step's own
+        // expressions (S = 1), kept as doubles so that the step after the sweep is a load, three additions and the Adam arithmetic
+        // instead of an fp64 exp / log1p / log / four divisions chain on the iteration's critical path
+        const double sig = (x >= 0 ? 1.0 : tx) / (1.0 + tx);
+        aux[g] = sd; aux[aux_ld + g] = sig; aux[2 * aux_ld + g] = cs / (1.0 * mu); aux[3 * aux_ld + g] = lm / (1.0 * mu);
+        aux[4 * aux_ld + g] = (1.0 - sig) / 1.0;
+      }
       if (Mq && c16) {   // sixteen columns per draw: the second draw's image follows the first one's ([2][nk][2][64][8])
         unsigned short* mq = Mq + (int64_t)w * ((G + 31) / 32) * 1024 + ((int64_t)(g >> 5) * 128 + 16 * ((g & 31) >> 3)) * 8 + (g & 7);
 #pragma unroll
@@ -2911,7 +2924,8 @@ __device__ __forceinline__ float ca_final_gene_step(int g, bool ok, const double
                                                      float* __restrict__ v_ls, float* __restrict__ m_V, float* __restrict__ v_V,
                                                      float* __restrict__ g_loc, float* __restrict__ g_ls, float* __restrict__ g_V,
                                                      int G, int S, int D, int K, int apply, float lr_t, float b1, float b2, float aeps,
-                                                     const float* __restrict__ gfold, int nfold, ca_gene_new* nw);
+                                                     const float* __restrict__ gfold, int nfold, ca_gene_new* nw,
+                                                     const double* __restrict__ aux = nullptr, int64_t aux_ld = 0);
 __device__ __forceinline__ void ca_final_gene_range(int g, bool ok, float Vnew0, const float* __restrict__ V, float* __restrict__ Vs,
                                                      float* __restrict__ vmm_part, int G, int D, int blk, float* smin, float* smax);
 __device__ __forceinline__ void ca_final_gene_body(const double* __restrict__ red_g /*[G][S+D]*/, const double* __restrict__ red_y /*[G][K]*/,
@@ -2941,7 +2955,8 @@ __device__ __forceinline__ float ca_final_gene_step(int g, bool ok, const double
                                                      float* __restrict__ v_ls, float* __restrict__ m_V, float* __restrict__ v_V,
                                                      float* __restrict__ g_loc, float* __restrict__ g_ls, float* __restrict__ g_V,
                                                      int G, int S, int D, int K, int apply, float lr_t, float b1, float b2, float aeps,
-                                                     const float* __restrict__ gfold, int nfold, ca_gene_new* nw) {
+                                                     const float* __restrict__ gfold, int nfold, ca_gene_new* nw,
+                                                     const double* __restrict__ aux, int64_t aux_ld) {
   float Vnew0 = 0.f;   // the first loading after this step (kept in a register for the log2 image)
   if (ok) {
   // Every operand whose address does not depend on a result is loaded HERE, in one batch: this block is one wave per SIMD, and each
@@ -2955,7 +2970,10 @@ __device__ __forceinline__ float ca_final_gene_step(int g, bool ok, const double
   double ry0 = 0.0;
   if (D > 0) { V0 = V[(int64_t)g * D]; mV0 = m_V[(int64_t)g * D]; vV0 = v_V[(int64_t)g * D]; }
   if (K > 0) { vchi0 = vchi[0]; ry0 = red_y[(int64_t)g * K]; }
-  const double l = (double)loc_g, lsd = (double)ls_g, sd = exp(lsd);
+  // (aux: the sweep-independent part of this gene's gradient as the prologue of this pass's eps left it, ca_gene_pre_draw; S = 1)
+  double a_sd = 0.0, a_sig = 0.0, a_q1 = 0.0, a_q2 = 0.0, a_q3 = 0.0;
+  if (aux) { a_sd = aux[g]; a_sig = aux[aux_ld + g]; a_q1 = aux[2 * aux_ld + g]; a_q2 = aux[3 * aux_ld + g]; a_q3 = aux[4 * aux_ld + g]; }
+  const double l = (double)loc_g, lsd = (double)ls_g, sd = aux ? a_sd : exp(lsd);
   const int W_ = S + D;
   // small problems: the backward sweep's cell-split partials are summed here (fixed order, fp64) instead of by a k_colsum
   // launch of their own -- one launch and its gap less per iteration where launches are what an iteration costs
@@ -2989,13 +3007,18 @@ __device__ __forceinline__ float ca_final_gene_step(int g, bool ok, const double
   double gl = 0.0, gs = 0.0;
   for (int s = 0; s < S; ++s) {
     const double e = s == 0 ? (double)e0f : (double)eps[(int64_t)s * G + g];
-    const double x = l + sd * e;
-    // softplus and sigmoid from ONE exp: t = exp(-|x|); softplus = max(x, 0) + log1p(t); sigmoid = 1 / (1 + t) or t / (1 + t)
-    const double tx = exp(-fabs(x));
-    const double mu = (x > 0 ? x : 0.0) + log1p(tx), lm = log(mu);
-    const double sig = (x >= 0 ? 1.0 : tx) / (1.0 + tx);
-    const double dmu = cs / ((double)S * mu) + rgv(s) - lm / ((double)S * mu);
-    const double dx = dmu * sig + (1.0 - sig) / (double)S;
+    double sig, q1, q2, q3;
+    if (aux) { sig = a_sig; q1 = a_q1; q2 = a_q2; q3 = a_q3; }
+    else {
+      const double x = l + sd * e;
+      // softplus and sigmoid from ONE exp: t = exp(-|x|); softplus = max(x, 0) + log1p(t); sigmoid = 1 / (1 + t) or t / (1 + t)
+      const double tx = exp(-fabs(x));
+      const double mu = (x > 0 ? x : 0.0) + log1p(tx), lm = log(mu);
+      sig = (x >= 0 ? 1.0 : tx) / (1.0 + tx);
+      q1 = cs / ((double)S * mu); q2 = lm / ((double)S * mu); q3 = (1.0 - sig) / (double)S;
+    }
+    const double dmu = q1 + rgv(s) - q2;
+    const double dx = dmu * sig + q3;
     gl += dx;
     gs += dx * e * sd;
   }
@@ -3200,6 +3223,8 @@ struct ca_merge_args {
   ca_ysq_args ysq;         // nblk > 0: the int8 stream's images, made in the gene / psi blocks (pairs of maxima: gene blocks, then psi blocks)
   ca_small_args tail;      // the chi / alpha step (vchi_out / alpha_out set)
   float* glogit; const float* dgl; float* m_gl; float* v_gl; int C; int ncell;   // q(z) logits: ncell blocks of 256 cells
+  const double* aux_in; double* aux_out; int64_t aux_ld;   // [5][aux_ld] doubles per gene: the sweep-independent part of the NEXT step's gradient (ca_gene_pre_draw);
+                                                           // aux_in: what the prologue of THIS pass's eps left (null: the step computes it), aux_out: for the next step
   int* vmm_at; int* vmm_at_next;   // range of V' over ALL genes as ordered ints [2][8]: every gene block folds its own in with one atomic min / max per
                                    // dimension (the next sweep reads 2 D words); the chi / alpha block resets the buffer of the NEXT merged update
 };
@@ -3238,7 +3263,7 @@ __global__ void __launch_bounds__(CA_UM_TB) k_update_merged(const double* __rest
     if (role == 0) {
       ca_gene_new nw = {0.f, 0.f, 0.f, 0.0};
       V0n = ca_final_gene_step(g, ok, red_g, red_y, eps, colsum, YtX, vchi, loc, ls, V, m_loc, v_loc, m_ls, v_ls, m_V, v_V, g_loc, g_ls, g_V,
-                               G, S, D, K, 1, lr_t, b1, b2, aeps, gfold, nfold, &nw);
+                               G, S, D, K, 1, lr_t, b1, b2, aeps, gfold, nfold, &nw, mg.aux_in, mg.aux_ld);
       h_loc[grp * 64 + l] = nw.loc; h_ls[grp * 64 + l] = nw.ls; h_v0[grp * 64 + l] = V0n;
     } else if (role < 3 && ok) {   // the draws' operands that nothing here produces: in flight while the step runs
       o.eA = mg.pre.epsA[g]; o.eB = mg.pre.epsB[g]; o.cs = colsum[g];
@@ -3272,7 +3297,8 @@ __global__ void __launch_bounds__(CA_UM_TB) k_update_merged(const double* __rest
       double t[3] = {0.0, 0.0, 0.0};
       if (ok) {
         o.loc = h_loc[grp * 64 + l]; o.ls = h_ls[grp * 64 + l];
-        ca_gene_pre_draw(role - 1, g, o, mg.pre.Lb, V, D, K, YtX, mg.pre.muA, mg.pre.muB, mg.pre.Mb, G, mg.pre.mrow, mg.pre.C, mg.pre.Mq, t);
+        ca_gene_pre_draw(role - 1, g, o, mg.pre.Lb, V, D, K, YtX, mg.pre.muA, mg.pre.muB, mg.pre.Mb, G, mg.pre.mrow, mg.pre.C, mg.pre.Mq, t,
+                         role == 2 ? mg.aux_out : nullptr, mg.aux_ld);
       }
 #pragma unroll
       for (int q = 1; q < 64; q <<= 1) {

@@ -123,6 +123,8 @@ struct ca_engine {
   // bound of the stepped state is then made by the next forward sweep itself (em_stale: nobody has made it yet)
   float *vchi_alt = nullptr, *alpha_u_alt = nullptr;
   bool upd_merge = false, em_stale = false;
+  double* gaux = nullptr; int64_t gaux_slot = -1;   // [2][5][G]: ca_merge_args::aux_in / aux_out, ping-pong; gaux_slot: the eps draw the current half belongs to (-1: none)
+  int gaux_idx = 0;
   int* vmm_at = nullptr; int vmm_at_idx = 0; bool vmm_at_ready = false;   // [2][16] ordered-int range of V' (k_update_merged), the buffer in use alternates
   double dir_const = 0.0;
   float b1p = 0.f, b2p = 0.f;  // running beta powers, float32 like TF's beta*_power variables
@@ -503,6 +505,7 @@ int refresh_derived(ca_engine* h) {
     LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_etamax, dim3(cdiv(h->N, CA_TB)), dim3(CA_TB), 0, h->stream, h->F, h->vmm, h->etamax2, h->N, h->D));
   }
   h->em_stale = false;
+  h->gaux_slot = -1;
   h->ycache_valid = false;
   h->yfin_pending = false;
   h->look_valid = false;
@@ -1068,6 +1071,12 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
         h->vmm_at_ready = true;
       }
       mg.vmm_at = h->vmm_at + 16 * h->vmm_at_idx; mg.vmm_at_next = h->vmm_at + 16 * (1 - h->vmm_at_idx);
+      // the sweep-independent part of the per-gene gradient: left by the prologue that made this pass's eps draw (if it was a merged
+      // update's, with the parameters still the ones it saw), and made for the next train pass's draw by this launch's prologue
+      mg.aux_ld = h->G;
+      const int64_t this_draw = (eps - h->eps_dev) / (int64_t)h->G;
+      mg.aux_in = (h->S == 1 && h->gaux_slot >= 0 && h->gaux_slot == this_draw) ? h->gaux + (int64_t)h->gaux_idx * 5 * h->G : nullptr;
+      mg.aux_out = h->S == 1 ? h->gaux + (int64_t)(1 - h->gaux_idx) * 5 * h->G : nullptr;
       LAUNCH(h, CA_KERNEL_OTHER,
              hipLaunchKernelGGL(k_update_merged, dim3(h->ngblk + (mon.enabled ? 1 : 0) + 1 + psi.nblk + N256), dim3(CA_UM_TB), 0, h->stream,
                                 h->red + h->off_g, h->red + h->off_y, eps, h->colsum, h->YtX, h->vchi, h->loc, h->ls, h->V, h->m_loc, h->v_loc,
@@ -1083,6 +1092,7 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
       std::swap(h->alpha_u, h->alpha_u_alt);
       h->em_stale = true;
       h->vmm_at_idx = 1 - h->vmm_at_idx;   // (the buffer this launch filled is the other one from now on: vmm_at_cur below)
+      h->gaux_idx = 1 - h->gaux_idx; h->gaux_slot = h->S == 1 ? mB : -1;
       h->pre_valid = true; h->pre_A = mA; h->pre_B = mB;
       h->hint_A = h->hint_B = -1;
       if (h->ys_steps >= 0) h->ys_steps += 1;
@@ -1094,6 +1104,7 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
       return CA_OK;
     }
   }
+  if (apply) h->gaux_slot = -1;   // the per-gene parameters change without a prologue that leaves the next step's sweep-independent part
   LAUNCH(h, CA_KERNEL_OTHER,
          hipLaunchKernelGGL(k_final_gene, dim3(h->ngblk + (mon.enabled ? 1 : 0) + psi.nblk), dim3(CA_TB), 0, h->stream, h->red + h->off_g,
                             h->red + h->off_y, eps, h->colsum, h->YtX, h->vchi, h->loc, h->ls, h->V, h->m_loc, h->v_loc, h->m_ls,
@@ -1537,6 +1548,7 @@ int ensure_elbo_cap(ca_engine* h, int64_t n) {
 int stage_eps(ca_engine* h, const float* eps_stream, int64_t have, int64_t need) {
   const int64_t per = (int64_t)h->S * h->G;
   h->look_valid = false;   // the staged eps slots are about to change
+  h->gaux_slot = -1;
   CACK(ensure_eps_cap(h, std::max<int64_t>(need, 1)));
   if (eps_stream) {
     if (have < need) {
@@ -1962,6 +1974,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   CACK(dalloc(h, &h->alpha_u, C)); CACK(dalloc(h, &h->m_a, C)); CACK(dalloc(h, &h->v_a, C)); CACK(dalloc(h, &h->g_a, C));
   CACK(dalloc(h, &h->vchi_alt, std::max(K, 1))); CACK(dalloc(h, &h->alpha_u_alt, C));
   CACK(dalloc(h, &h->vmm_at, 32));
+  CACK(dalloc(h, &h->gaux, (int64_t)2 * 5 * G));
   {
     std::vector<float> Fh((size_t)Nn * std::max(D, 1), 0.f);
     if (D > 0) {
