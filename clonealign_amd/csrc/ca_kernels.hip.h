@@ -2887,9 +2887,12 @@ __global__ void __launch_bounds__(CA_TB) k_reduce_part(const double* __restrict_
 
 // ------------------------------------------------------------------ per-gene gradients + Adam
 // d ELBO / d loc, ls (through mu = softplus(loc + exp(ls) eps)), W, beta; minimises -ELBO.
+__device__ __forceinline__ void ca_psi_adam_body_at(const ca_psi_args& a, int64_t n, int apply, float lr_t, float b1, float b2, float aeps, float* psi0_new);
 __device__ __forceinline__ void ca_psi_adam_body(const ca_psi_args& a, int blk, int apply, float lr_t, float b1, float b2, float aeps,
                                                  float* psi0_new = nullptr /* merged update: the cell's stepped psi_0 (0 past the last cell) */) {
-  const int64_t n = (int64_t)blk * CA_TB + threadIdx.x;
+  ca_psi_adam_body_at(a, (int64_t)blk * CA_TB + threadIdx.x, apply, lr_t, b1, b2, aeps, psi0_new);
+}
+__device__ __forceinline__ void ca_psi_adam_body_at(const ca_psi_args& a, int64_t n, int apply, float lr_t, float b1, float b2, float aeps, float* psi0_new) {
   if (psi0_new) *psi0_new = 0.f;
   if (n >= a.N) return;
   for (int k = 0; k < a.K; ++k) {
@@ -3120,10 +3123,11 @@ __global__ void __launch_bounds__(CA_TB) k_final_small(ca_small_args a) { ca_fin
 
 // q(z) logits: an elementwise Adam step over the flat [N * C] arrays, 16 bytes per lane; cell block `cblk` = cells 256 cblk ...
 __device__ __forceinline__ void ca_logit_adam_body(int cblk, float* __restrict__ glogit, const float* __restrict__ dgl, float* __restrict__ m_gl,
-                                                   float* __restrict__ v_gl, int64_t N, int C, float lr_t, float b1, float b2, float aeps) {
+                                                   float* __restrict__ v_gl, int64_t N, int C, float lr_t, float b1, float b2, float aeps, int tix = -1) {
+  if (tix < 0) tix = (int)threadIdx.x;   // (thread's place among the 256 of the piece)
   const int64_t e0 = (int64_t)cblk * CA_TB * C, tot = N * (int64_t)C;
   const int64_t e1 = e0 + (int64_t)CA_TB * C < tot ? e0 + (int64_t)CA_TB * C : tot;   // e0 is a multiple of 4 (CA_TB = 256)
-  for (int64_t i = e0 + 4 * (int64_t)threadIdx.x; i < e1; i += 4 * CA_TB) {
+  for (int64_t i = e0 + 4 * (int64_t)tix; i < e1; i += 4 * CA_TB) {
     if (i + 4 <= e1) {
       float4 th = *reinterpret_cast<const float4*>(glogit + i), m = *reinterpret_cast<const float4*>(m_gl + i);
       float4 v = *reinterpret_cast<const float4*>(v_gl + i);
@@ -3241,7 +3245,7 @@ __global__ void __launch_bounds__(CA_UM_TB) k_update_merged(const double* __rest
                                                             ca_psi_args psi, const float* __restrict__ gfold, int nfold, ca_merge_args mg) {
   [[maybe_unused]] const int nmon = mon.enabled ? 1 : 0;
   const int bx = (int)blockIdx.x;
-  CA_LAB_STAMP(bx, bx < gblocks ? 0 : bx < gblocks + nmon ? 1 : bx == gblocks + nmon ? 4 : bx < gblocks + nmon + 1 + psi.nblk ? 2 : 5);
+  CA_LAB_STAMP(bx, bx < gblocks ? 0 : bx < gblocks + nmon ? 1 : bx == gblocks + nmon ? 4 : bx < gblocks + nmon + 1 + (psi.nblk + 3) / 4 ? 2 : 5);
   if (bx < gblocks) {
     // A gene's chain here is: its Adam step (one round of loads, then fp64 exp / log1p / log and three Adam steps: 5 us at one wave per
     // SIMD), THEN the two draws of the next prologue (2.7 us each: softplus, log, the operand row) and its part of the W image (2 us) --
@@ -3342,32 +3346,48 @@ __global__ void __launch_bounds__(CA_UM_TB) k_update_merged(const double* __rest
     CA_LAB_CP(bx, 3);
     return;
   }
-  if ((int)threadIdx.x >= CA_TB) return;   // every other kind of block is a 256-thread block
-  __shared__ float smq[2 * (CA_YM_TB / 64)];
   int b = bx - gblocks;
-  if (mon.enabled) {   // the pending monitor pass's ELBO (ca_final_small_body), beside the gene blocks
-    if (b == 0) { CA_LAB_CP(40, 0); if (!(CA_LAB_SKIP & 1)) ca_final_small_body(mon); CA_LAB_CP(40, 1); return; }
-    --b;
-  }
-  if (b == 0) {   // chi / alpha step
+  if (b < nmon + 1) {   // the two O(K + C) blocks are 256-thread blocks: the pending monitor pass's ELBO, then the chi / alpha step
+    if ((int)threadIdx.x >= CA_TB) return;
+    if (mon.enabled && b == 0) { CA_LAB_CP(40, 0); if (!(CA_LAB_SKIP & 1)) ca_final_small_body(mon); CA_LAB_CP(40, 1); return; }
     if (threadIdx.x < 8) { mg.vmm_at_next[threadIdx.x] = ca_f2ord(INFINITY); mg.vmm_at_next[8 + threadIdx.x] = ca_f2ord(-INFINITY); }
-    CA_LAB_CP(41, 0); if (!(CA_LAB_SKIP & 8) && mg.tail.enabled) ca_final_small_body(mg.tail); CA_LAB_CP(41, 1); return;
+    CA_LAB_CP(41, 0); if (!(CA_LAB_SKIP & 8) && mg.tail.enabled) ca_final_small_body(mg.tail); CA_LAB_CP(41, 1);
+    return;
   }
-  --b;
-  if (b < psi.nblk) {
+  b -= nmon + 1;
+  // psi and q(z)-logit blocks: FOUR 256-cell pieces per 1024-thread block (a quarter-filled block costs the dispatcher sixteen wave slots
+  // all the same: 800 of them at cfg-3 took 15 us to get through).  Piece index = what a 256-thread block's index was.
+  const int sub = (int)threadIdx.x >> 8, npsi4 = (psi.nblk + 3) / 4;
+  if (b < npsi4) {
     if (CA_LAB_SKIP & 2) return;
+    __shared__ float smw[CA_UM_TB / 64];
+    const int pb = 4 * b + sub;              // 256-cell piece
     float pn = 0.f;
     if (b == 0) CA_LAB_CP(42, 0);
-    ca_psi_adam_body(psi, b, 1, lr_t, b1, b2, aeps, &pn);
+    if (pb < psi.nblk) {
+      ca_psi_args q = psi;
+      ca_psi_adam_body_at(q, (int64_t)pb * CA_TB + ((int)threadIdx.x & (CA_TB - 1)), 1, lr_t, b1, b2, aeps, &pn);
+    }
     if (b == 0) CA_LAB_CP(42, 1);
-    if (mg.ysq.nblk) ca_ys_quant_inreg(mg.ysq, false, b, pn, gblocks + b, false, smq);
+    if (mg.ysq.nblk) {   // the psi image: one wave per 64-step (ca_ys_quant_wave), the piece's pair of maxima from its four waves
+      const int wv = (int)threadIdx.x >> 6;
+      const int64_t step = (int64_t)pb * (CA_TB / 64) + (wv & 3);
+      const bool live = pb < psi.nblk && step < mg.ysq.NS;
+      const float m = ca_ys_quant_wave(mg.ysq, live, false, live ? step : 0, pn, false);
+      if ((threadIdx.x & 63) == 0) smw[wv] = m;
+      __syncthreads();
+      if ((threadIdx.x & (CA_TB - 1)) == 0 && pb < psi.nblk) {
+        mg.ysq.amax_out[2 * (gblocks + pb)] = 0.f;
+        mg.ysq.amax_out[2 * (gblocks + pb) + 1] = fmaxf(fmaxf(smw[4 * sub], smw[4 * sub + 1]), fmaxf(smw[4 * sub + 2], smw[4 * sub + 3]));
+      }
+    }
     if (b == 0) CA_LAB_CP(42, 2);
     return;
   }
-  b -= psi.nblk;
+  b -= npsi4;
   if (CA_LAB_SKIP & 64) return;
   if (b == 0) CA_LAB_CP(43, 0);
-  if (b < mg.ncell) ca_logit_adam_body(b, mg.glogit, mg.dgl, mg.m_gl, mg.v_gl, psi.N, mg.C, lr_t, b1, b2, aeps);
+  if (4 * b + sub < mg.ncell) ca_logit_adam_body(4 * b + sub, mg.glogit, mg.dgl, mg.m_gl, mg.v_gl, psi.N, mg.C, lr_t, b1, b2, aeps, (int)threadIdx.x & (CA_TB - 1));
   if (b == 0) CA_LAB_CP(43, 1);
 }
 

@@ -1078,7 +1078,7 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
       mg.aux_in = (h->S == 1 && h->gaux_slot >= 0 && h->gaux_slot == this_draw) ? h->gaux + (int64_t)h->gaux_idx * 5 * h->G : nullptr;
       mg.aux_out = h->S == 1 ? h->gaux + (int64_t)(1 - h->gaux_idx) * 5 * h->G : nullptr;
       LAUNCH(h, CA_KERNEL_OTHER,
-             hipLaunchKernelGGL(k_update_merged, dim3(h->ngblk + (mon.enabled ? 1 : 0) + 1 + psi.nblk + N256), dim3(CA_UM_TB), 0, h->stream,
+             hipLaunchKernelGGL(k_update_merged, dim3(h->ngblk + (mon.enabled ? 1 : 0) + 1 + cdiv(psi.nblk, 4) + cdiv(N256, 4)), dim3(CA_UM_TB), 0, h->stream,
                                 h->red + h->off_g, h->red + h->off_y, eps, h->colsum, h->YtX, h->vchi, h->loc, h->ls, h->V, h->m_loc, h->v_loc,
                                 h->m_ls, h->v_ls, h->m_V, h->v_V, h->g_loc, h->g_ls, h->g_V, h->Vs, h->vmm_part, h->G, h->S, h->D, h->K, lr_t,
                                 (float)h->opt.beta1, (float)h->opt.beta2, (float)h->opt.adam_eps, mon, h->ngblk, psi,

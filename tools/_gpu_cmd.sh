@@ -1,5 +1,9 @@
 mkdir -p gpurun_out/r4
-python -m pytest tests -x -q -m gpu > gpurun_out/r4/gputest3.txt 2>&1; tail -6 gpurun_out/r4/gputest3.txt
-python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r4/bench_a.json 2> gpurun_out/r4/bench_a.err
-python -c "
-import json; d=json.loads(open('gpurun_out/r4/bench_a.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'], d.get('steady_state_200'), d['parity_check']['max_rel_elbo'], d['parity_check']['label_flips'], d['dtype'])"
+python -m pytest tests/test_gpu_parity.py -x -q -k "merged_update" > gpurun_out/r4/merge_tests4.txt 2>&1; tail -4 gpurun_out/r4/merge_tests4.txt
+for cfg in "12500 5000 8" "10000 2000 4" "100000 5000 8" "50000 5000 8"; do
+  for rep in 1 2; do
+  echo "== $cfg merged"; python tools/lab_time.py $cfg 2>&1 | tail -1
+  echo "== $cfg two-launch"; CLONEALIGN_DEBUG_ENV=1 CA_UPDATE_MERGE=0 python tools/lab_time.py $cfg 2>&1 | tail -1
+  done
+done > gpurun_out/r4/merge_time4.txt 2>&1
+cat gpurun_out/r4/merge_time4.txt

@@ -1,5 +1,5 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-OUT=$R/gpurun_out/r3/small_tl
+OUT=$R/gpurun_out/r4/small_tl
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace -d $OUT/a -o a --output-format csv -- python3 $R/bench.py --steps 300 --warmup 20 --no-cpu-baseline --busy-seconds 0 --cells 12500 > $OUT/a.log 2>&1
