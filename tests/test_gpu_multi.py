@@ -187,6 +187,18 @@ def test_bench_preheat_makes_the_same_number_of_collective_calls_on_every_rank()
     assert line["preheat"]["calls"] >= 20, line["preheat"]
 
 
+def test_bench_eight_ranks_on_one_device_run_the_driver_command_shape():
+    """The driver's scaling command at W = 8 -- `bench.py --gpus 8 --steps K --warmup W` under torch.distributed.run -- with every rank on
+    device 0 and a small matrix: transport bring-up over eight processes, agreed pre-heat, timed regions, the all-reduce benchmark, the fit
+    with its stop rule on eight replicas.  (The numbers mean nothing: eight processes time-slice one GPU.)"""
+    r = _bench(8, ["--preheat-ms", "30"], shape=("--cells", "24000", "--genes", "600", "--clones", "8"))
+    assert r.returncode == 0, child_report(r)
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 8 and line["config"]["collective"] == "p2p" and line["scaling"] == "strong"
+    assert line["config"]["allreduce_doubles_per_train_pass"] == 3 + 8 + 600 * 2 + 600 and line["allreduce_us"]["p2p"] > 0
+    assert line["fit_wallclock"]["iterations"] >= 10 and np.isfinite(line["final_elbo"])
+
+
 @pytest.mark.skipif(_gpus() < 8, reason="needs an 8-GPU node (BASELINE.json configs[3]: 100k x 5k x 8 cell-sharded over 8 MI355X)")
 def test_bench_on_eight_gpus_uses_a_device_collective_and_replicas_agree(tmp_path):
     """The driver's scaling run, as a test for the day a node is available: bench.py --gpus 8 --steps 20 at the full BASELINE

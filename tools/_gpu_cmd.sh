@@ -1,9 +1,6 @@
 mkdir -p gpurun_out/r4
-python -m pytest tests/test_gpu_parity.py -x -q -k "merged_update" > gpurun_out/r4/merge_tests4.txt 2>&1; tail -4 gpurun_out/r4/merge_tests4.txt
-for cfg in "12500 5000 8" "10000 2000 4" "100000 5000 8" "50000 5000 8"; do
-  for rep in 1 2; do
-  echo "== $cfg merged"; python tools/lab_time.py $cfg 2>&1 | tail -1
-  echo "== $cfg two-launch"; CLONEALIGN_DEBUG_ENV=1 CA_UPDATE_MERGE=0 python tools/lab_time.py $cfg 2>&1 | tail -1
-  done
-done > gpurun_out/r4/merge_time4.txt 2>&1
-cat gpurun_out/r4/merge_time4.txt
+for e in "" "CA_UPDATE_MERGE=0" "CA_Y_MFMA1=1,CA_Y_RIDE=1" "CA_BWD_MFMA=0" "CA_FWD_MFMA=0"; do
+  echo "### extra env: $e"
+  FUZZ_ONLY=256 FUZZ_ENV="$e" python tools/fuzz_parity.py 300 401 2>&1 | grep -v amdgpu.ids | tail -4
+done > gpurun_out/r4/fuzz_replay_256.txt 2>&1
+cat gpurun_out/r4/fuzz_replay_256.txt

@@ -21,7 +21,8 @@ n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 VARIANTS = [{}, {}, {}, {}, {"CA_FWD_CELL": "0"}, {"CA_FWD_MFMA": "0"}, {"CA_BWD_MFMA": "0"}, {"CA_ASYNC_Y": "0"}, {"CA_PRE": "0"},
             {"CA_TAIL_FUSE": "0"}, {"CA_FC_TL": "4", "CA_FC_NBIG": "2"}, {"CA_PAIR_ELBO": "0"},
-            {"CA_Y_MFMA1": "0"}, {"CA_Y_MFMA1": "0", "CA_RIDE_SEQ_ON": "1"}, {"CA_Y_MFMA1": "0", "CA_Y_RIDE": "0"}, {"CA_Y_RIDE": "0"}]   # round 3: the vector stream and its riding forms
+            {"CA_Y_MFMA1": "0"}, {"CA_Y_MFMA1": "0", "CA_RIDE_SEQ_ON": "1"}, {"CA_Y_MFMA1": "0", "CA_Y_RIDE": "0"}, {"CA_Y_RIDE": "0"},
+            {"CA_UPDATE_MERGE": "0"}, {"CA_UPDATE_MERGE": "0", "CA_Y_MFMA1": "0"}]   # round 4: the two-launch update (the default is the merged launch)   # round 3: the vector stream and its riding forms
 fails = 0
 for it in range(n_cases):
     N = int(rng.integers(1, 900))
@@ -40,6 +41,14 @@ for it in range(n_cases):
     if rng.random() < 0.4:          # counts above 255: overflow list next to 1-byte storage
         idx = rng.integers(0, case["Y"].size, size=max(1, case["Y"].size // 3000))
         case["Y"].reshape(-1)[idx] += rng.integers(200, 2000, size=idx.size)
+    # replay of one case: FUZZ_ONLY=<index> runs only that case (the random stream is consumed as in the full sweep); FUZZ_ENV="A=1,B=0" adds switches
+    only = os.environ.get("FUZZ_ONLY")
+    if only is not None and int(only) != it:
+        rng.integers(1, 6)
+        continue
+    if only is not None:
+        env.update(kv.split("=") for kv in os.environ.get("FUZZ_ENV", "").split(",") if kv)
+        print("replaying case", it, kw, env)
     env = dict(env, CLONEALIGN_DEBUG_ENV="1")      # the library reads CA_* from the environment only in this debug mode
     old = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
@@ -63,6 +72,8 @@ for it in range(n_cases):
             # differences of its variable after a few steps (seen: W 2.8e-4 of 0.2); the ELBO trace is the tight check
             if a.size and np.abs(a - b).max() > 5e-3 * max(np.abs(b).max(), 1e-2):
                 why.append("%s %.2e of %.2e" % (n, float(np.abs(a - b).max()), float(np.abs(b).max())))
+        if only is not None:
+            print("trace engine", tr.tolist(), "oracle", to.tolist(), "rel", float(np.abs(tr - to).max() / np.abs(to).max()))
         if why:
             fails += 1
             print("FAIL", kw, env, "iters", n_iter, "trace diff", float(np.abs(tr - to).max() / np.abs(to).max()), "|", "; ".join(why))
