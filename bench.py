@@ -193,6 +193,7 @@ def main():
     ap.add_argument("--allow-host-fallback", action="store_true",
                     help="at --gpus > 1, let the run continue on the gloo host all-reduce when no device transport comes up "
                          "(the result is then NOT a measurement of the device data path)")
+    ap.add_argument("--selftest-fail", default="", help="test hook: treat the known-answer all-reduce test of this transport (p2p | rccl) as failed on rank 0")
     ap.add_argument("--preheat-ms", type=float, default=60.0,
                     help="untimed iterations run for this long right before the timed regions (after the --warmup steps): the GPU's clocks need "
                          "~30 ms of load to ramp; 0 = none")
@@ -264,7 +265,7 @@ def main():
                          variant_on=tuple(v for v in args.variant_on.split(",") if v),
                          tune={k: (v if ":" in v else int(v)) for k, v in (kv.split("=") for kv in args.tune.split(",") if kv)}, **kw)
 
-    collective, tried = "none", []
+    collective, tried, selftest = "none", [], {}
     if world == 1:
         eng = make_engine()
     else:
@@ -309,6 +310,22 @@ def main():
             flag = torch.tensor([ok], dtype=torch.int32)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             tried.append(tr)
+            if int(flag[0]) == 1:
+                # it came up everywhere: before it carries a number, it must ADD -- known-answer all-reduces of the train pass's payload
+                # (the peer-to-peer transport has never run across xGMI on any box this build has seen; every rank takes part, then the
+                # ranks agree on the verdict)
+                try:
+                    bad = e_new.comm_selftest(6)
+                except Exception as ex:  # noqa: BLE001
+                    bad = -1
+                    print(f"[rank {rank}] transport {tr}: known-answer test failed to run: {ex}", file=sys.stderr, flush=True)
+                if args.selftest_fail == tr and rank == 0:
+                    bad = 1
+                if bad:
+                    print(f"[rank {rank}] transport {tr}: known-answer all-reduce wrong ({bad} sums)", file=sys.stderr, flush=True)
+                flag = torch.tensor([0 if bad else 1], dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                selftest[tr] = bool(int(flag[0]))
             if int(flag[0]) == 1:
                 eng, collective = e_new, tr
                 break
@@ -521,7 +538,7 @@ def main():
                        "fused_sweep": bool(info.get("fused_sweep")), "fwd_mfma": bool(info.get("fwd_mfma")),
                        "bwd_mfma": bool(info.get("bwd_mfma")), "y_mfma": bool(info.get("y_mfma")),
                        "parallelism": f"cells/{world}" if world > 1 else "single", "collective": collective,
-                       "collectives_tried": tried, "allreduce_doubles_per_train_pass": int(info["red_n"]),
+                       "collectives_tried": tried, "allreduce_selftest": selftest, "allreduce_doubles_per_train_pass": int(info["red_n"]),
                        "build_id": build, **({"foreign_library": True} if foreign else {})},
             "repeats": {"n": len(regions), "ms_per_step_median": step_s * 1e3, "ms_per_step_min": min(regions) / args.steps * 1e3,
                         "ms_per_step_max": max(regions) / args.steps * 1e3,

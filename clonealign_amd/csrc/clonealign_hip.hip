@@ -2641,6 +2641,34 @@ int ca_comm_benchmark(ca_handle h, int32_t transport, int32_t n_calls, int64_t n
   return rc;
 }
 
+int ca_comm_selftest(ca_handle h, int32_t n_rounds, int64_t n_doubles, int64_t* n_bad) {
+  if (!h || !n_bad || n_rounds < 1 || n_doubles < 1) return CA_ERR_INVALID;
+  HIPCK(h, hipSetDevice(h->device));
+  *n_bad = 0;
+  const double W = (double)std::max(h->opt.world, 1), tri = W * (W + 1.0) / 2.0;
+  double* buf = nullptr;
+  HIPCK(h, hipMalloc((void**)&buf, (size_t)n_doubles * sizeof(double)));
+  std::vector<double> host((size_t)n_doubles);
+  int rc = CA_OK;
+  auto pattern = [](int64_t i, int r) { return (double)((i * 7 + (int64_t)r * 13) % 251 + 1); };
+  auto run = [&]() -> int {
+    for (int r = 0; r < n_rounds; ++r) {
+      for (int64_t i = 0; i < n_doubles; ++i) host[(size_t)i] = (double)(h->opt.rank + 1) * pattern(i, r) + 0.5 * r;
+      HIPCK(h, hipMemcpyAsync(buf, host.data(), (size_t)n_doubles * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      CACK(allreduce(h, buf, n_doubles));
+      HIPCK(h, hipMemcpyAsync(host.data(), buf, (size_t)n_doubles * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      SYNC(h);
+      for (int64_t i = 0; i < n_doubles; ++i)
+        if (host[(size_t)i] != tri * pattern(i, r) + W * 0.5 * r) *n_bad += 1;
+    }
+    return CA_OK;
+  };
+  rc = run();
+  hipFree(buf);
+  if (rc == CA_OK && *n_bad) h->err = "all-reduce known-answer test: " + std::to_string(*n_bad) + " of " + std::to_string((int64_t)n_rounds * n_doubles) + " sums are wrong";
+  return rc;
+}
+
 int ca_set_host_allreduce(ca_handle h, ca_host_allreduce_fn fn, void* user) {
   if (!h || !fn) return CA_ERR_INVALID;
   CACK(comm_check(h));

@@ -32,7 +32,7 @@ TRANSPORT_NAME = {0: "none", 1: "rccl", 2: "host", 3: "p2p"}
 
 EXPORTS = (
     "ca_abi_version", "ca_build_id", "ca_device_count", "ca_default_options", "ca_create", "ca_destroy", "ca_last_error", "ca_get_info",
-    "ca_synchronize", "ca_comm_unique_id", "ca_comm_init", "ca_p2p_export", "ca_p2p_connect", "ca_p2p_commit", "ca_comm_benchmark", "ca_set_host_allreduce", "ca_gamma_init", "ca_elbo", "ca_elbo_terms",
+    "ca_synchronize", "ca_comm_unique_id", "ca_comm_init", "ca_p2p_export", "ca_p2p_connect", "ca_p2p_commit", "ca_comm_benchmark", "ca_comm_selftest", "ca_set_host_allreduce", "ca_gamma_init", "ca_elbo", "ca_elbo_terms",
     "ca_step", "ca_gradients", "ca_run", "ca_run_ex", "ca_iterate", "ca_final_elbo", "ca_init_psi_pca", "ca_clone_gene_sums", "ca_get_param", "ca_set_param",
     "ca_get_gradient", "ca_reinit", "ca_get_kernel_times", "ca_reset_kernel_times", "ca_set_profile", "ca_eps_draw", "ca_allele_loglik", "ca_preprocess",
 )
@@ -106,6 +106,7 @@ def load_library(path=None):
     lib.ca_p2p_connect.argtypes = [C.c_void_p, C.c_char_p]
     lib.ca_p2p_commit.argtypes = [C.c_void_p, C.c_int32]
     lib.ca_comm_benchmark.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64, C.POINTER(C.c_double)]
+    lib.ca_comm_selftest.argtypes = [C.c_void_p, C.c_int32, C.c_int64, C.POINTER(C.c_int64)]
     lib.ca_set_host_allreduce.argtypes = [C.c_void_p, HOST_ALLREDUCE_FN, C.c_void_p]
     lib.ca_gamma_init.argtypes = [C.c_void_p, C.c_void_p]
     lib.ca_elbo.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]
@@ -328,6 +329,13 @@ class HipEngine:
         n = int(self.info()["red_n"] if n_doubles is None else n_doubles)
         self._ck(self.lib.ca_comm_benchmark(self.h, {"rccl": 1, "p2p": 3}[transport], int(n_calls), n, C.byref(us)))
         return us.value
+
+    def comm_selftest(self, n_rounds=4, n_doubles=None):
+        """Known-answer test of the active all-reduce (ca_comm_selftest); returns the number of wrong sums (0 = good); collective."""
+        bad = C.c_int64()
+        n = int(self.info()["red_n"] if n_doubles is None else n_doubles)
+        self._ck(self.lib.ca_comm_selftest(self.h, int(n_rounds), n, C.byref(bad)))
+        return bad.value
 
     # -------------------------------------------------------------- plumbing
     def _ck(self, rc):

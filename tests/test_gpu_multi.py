@@ -56,6 +56,7 @@ def single(tmp_path_factory):
 def _check(res, single, transport, cells=6000):
     ranks = res["ranks"]
     assert [r["transport"] for r in ranks] == [transport] * len(ranks)
+    assert [r["selftest_bad"] for r in ranks] == [0] * len(ranks)      # known-answer all-reduces (ca_comm_selftest) on the transport in use
     # the engine's all-reduce payload is the plan shared with the host side (clonealign_amd/sharding.py)
     assert all(r["red_n"] == res["plan"]["total"] for r in ranks)
     t0 = np.array(ranks[0]["trace"])
@@ -161,8 +162,12 @@ def test_bench_two_ranks_use_a_device_transport_and_fail_loudly_without_one():
     assert r.returncode == 0, child_report(r)
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["collective"] == "p2p" and line["config"]["collectives_tried"] == ["p2p"]
+    assert line["config"]["allreduce_selftest"] == {"p2p": True}
     assert line["scaling"] == "strong" and line["value"] > 0 and line["repeats"]["n"] == 2
     assert line["config"]["allreduce_doubles_per_train_pass"] == 3 + 4 + 1000 * 2 + 1000
+    # a transport that comes up but does not ADD is not used: one rank's failed known-answer test moves every rank on (here: to nothing)
+    r = _bench(2, ["--collective", "p2p", "--selftest-fail", "p2p"])
+    assert r.returncode != 0 and "known-answer all-reduce wrong" in r.stderr and "refusing to report" in r.stderr, child_report(r)
     if _gpus() < 2:
         r = _bench(2, ["--collective", "rccl"])
         assert r.returncode != 0 and "refusing to report" in r.stderr

@@ -66,6 +66,7 @@ def main():
             kw["host_allreduce"] = gloo_sum
     eng = HipEngine(case["Y"][lo:hi], case["L"], case["psi0"][lo:hi], case["loc0"], 1, 1, device=local, rank=rank, world=world,
                     comm_timeout_ms=args.comm_timeout_ms, **kw)
+    selftest_bad = eng.comm_selftest(5) if world > 1 else 0     # known-answer all-reduces on the transport in use, before the fit
     eps = np.stack([eps_for(1, args.genes, 300 + i) for i in range(2 + 2 * args.iters + 4)])
     trace = eng.run(eps, args.iters, 1e-12)
     finals = eng.final_elbo(eps[2 + 2 * args.iters:], 4)
@@ -84,7 +85,7 @@ def main():
         raise SystemExit(0)
     rep = {n: eng.get(n).tolist() for n in ("W", "loc", "ls", "alpha_unconstr", "v")}
     mine = dict(rank=rank, trace=trace.tolist(), finals=finals.tolist(), transport=info["transport_name"], red_n=int(info["red_n"]),
-                fwd_block_cells=int(info["fwd_block_cells"]),
+                fwd_block_cells=int(info["fwd_block_cells"]), selftest_bad=int(selftest_bad),
                 rep=rep, psi_head=eng.get("psi")[:5, 0].tolist(), lo=lo, hi=hi)
     eng.close()
     if world > 1:
