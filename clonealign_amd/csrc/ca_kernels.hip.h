@@ -3425,78 +3425,107 @@ __global__ void __launch_bounds__(CA_TB) k_yt_finish(const int* __restrict__ out
 }
 
 // ------------------------------------------------------------------ one-shot peer-to-peer all-reduce
-// Slab of a rank (fine-grained device memory, IPC-mapped by every peer):
-//   inbox[parity 2][source rank W][cap doubles]   then   flag[parity 2][source rank W] (uint64, holds the sequence number)
-// Call `seq` (1, 2, ...) uses parity seq & 1.  A rank is at most one call ahead of any peer: it raises its flag for seq + 1
-// only after it has summed seq, and a peer can only overwrite the parity of seq with seq + 2 after seeing that flag.
+// Round 4: the flag travels IN the data.  Slab of a rank (fine-grained device memory, IPC-mapped by every peer):
+//   inbox[parity 2][source rank W][cap entries], one entry = 16 bytes = {low half of the double, tag} {high half, tag}, each 8-byte half
+//   written with ONE store (8-byte stores are single transactions on the device and over xGMI / PCIe) and read with one load; tag = the low
+//   32 bits of the call's sequence number.  A receiver polls the entry itself until both tags are the call's: an entry is complete when it
+//   can be read as complete -- no fence behind the data, no flag to raise after it, no arrival counter to find the last block, no barrier.
+// Rounds 2-3 had data, then a system-scope release fence per block, an arrival counter, the last block's fence and flag stores, an acquire
+// spin, a third fence and the loads: five dependent round trips of uncached memory and three L2 write-backs.  Measured on ONE device, a rank
+// of a sharded fit at 12.5k x 5k x 8 (tools/shard_seq_time.py; profiles/r04_p2p_allreduce.txt): that kernel took 22 us of an 84 us
+// iteration (63 us unsharded); ablations put 8.6 us of it on the fences and most of the rest on the chain.
+// Call `seq` (1, 2, ...) uses parity seq & 1.  A rank is at most one call ahead of any peer: it can only publish seq + 1 after it has read
+// every peer's seq, and a peer overwrites parity seq & 1 with seq + 2 only after it has read this rank's seq + 1 -- which this rank publishes
+// after it is done reading seq.  The slab starts zeroed and sequence numbers start at 1, so tag 0 never matches.
 struct ca_p2p_args {
   double* const* peers;          // [W] slab base of every rank as mapped in THIS process (own included)
   int rank, world;
   int64_t cap;
   unsigned long long seq;
-  unsigned int* arrive;          // device counter, monotonic: block arrivals of all calls so far
-  unsigned int arrive_target;    // value of *arrive when every block of this call has published
   unsigned long long* err;       // pinned host word of this rank: 0, or the sequence number of the first call that gave up
-  unsigned long long timeout_ticks;   // s_memrealtime ticks (100 MHz) a block waits for the peers' flags before it gives up
+  unsigned int* err_local;       // the same fact in device memory: what a call looks at when it starts (a read of the pinned word is a PCIe round trip)
+  unsigned long long timeout_ticks;   // s_memrealtime ticks (100 MHz) a thread waits for a peer's entry before it gives up
+  // What used to be two launches in front of the collective rides in it.  (a) entries [fold_lo, fold_lo + fold_n) of buf are
+  // the column sums of the backward sweep's nslice partial slabs gpart[slice][fold_n] -- summed here in slice order (fp64) instead of
+  // by a k_colsum launch; (b) entry yw_index also gets the sum of n_yw block partials (psi.(YW) of a pending monitor pass, made by
+  // blocks of the backward sweep's launch).  Every rank does the same additions, so the replicas stay bit-identical.
+  const float* gpart; int nslice; int64_t fold_lo, fold_n;
+  const double* yw_part; int n_yw; int64_t yw_index;
 };
-__device__ __forceinline__ double* ca_p2p_inbox(double* slab, int64_t cap, int world, int par, int src) {
-  return slab + ((int64_t)par * world + src) * cap;
-}
-__device__ __forceinline__ unsigned long long* ca_p2p_flag(double* slab, int64_t cap, int world, int par, int src) {
-  return reinterpret_cast<unsigned long long*>(slab + 2 * (int64_t)world * cap) + (int64_t)par * world + src;
+__device__ __forceinline__ unsigned long long* ca_p2p_entry(double* slab, int64_t cap, int world, int par, int src, int64_t i) {
+  return reinterpret_cast<unsigned long long*>(slab) + 2 * ((((int64_t)par * world + src) * cap) + i);
 }
 // The wait for the peers is BOUNDED: a dead or desynchronised peer must end in CA_ERR_COMM on the host, not in a GPU spin that
-// nothing can interrupt.  A block that has waited timeout_ticks writes the call's sequence number to the rank's error word
-// (pinned host memory, checked by the host at every synchronisation point) and returns without touching buf; every later
-// call on a failed transport returns at once, so work already queued behind it drains quickly.  Recovery = a fresh engine.
+// nothing can interrupt.  A thread that has waited timeout_ticks for an entry writes the call's sequence number to the rank's error word
+// (pinned host memory, checked by the host at every synchronisation point) and returns; the call's buffer is then partly summed and the
+// engine is dead.  Every later call on a failed transport returns at once, so work already queued behind it drains quickly.
+#ifndef CA_P2P_LAB
+#define CA_P2P_LAB 0   // (timing lab of the round-3 form; unused by this one)
+#endif
 __global__ void __launch_bounds__(CA_TB) k_p2p_allreduce(double* __restrict__ buf, int64_t n, ca_p2p_args a) {
-  __shared__ unsigned int last, bad;
-  if (threadIdx.x == 0) {
-    bad = __hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0ull;
-    last = 0u;
-  }
+  __shared__ unsigned int bad;
+  if (threadIdx.x == 0) bad = __hip_atomic_load(a.err_local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
   __syncthreads();
   if (bad) return;
   const int par = (int)(a.seq & 1ull);
+  const unsigned long long tag = (a.seq & 0xFFFFFFFFull) << 32;
   const int64_t i0 = (int64_t)blockIdx.x * CA_TB + threadIdx.x, stride = (int64_t)gridDim.x * CA_TB;
-  // 1. publish: my summands into my inbox on every rank (plain stores into fine-grained memory; xGMI writes for remote peers)
-  for (int p = 0; p < a.world; ++p) {
-    double* dst = ca_p2p_inbox(a.peers[p], a.cap, a.world, par, a.rank);
-    for (int64_t i = i0; i < n; i += stride) dst[i] = buf[i];
+  // 0. (riding) the psi.(YW) partial sum for entry yw_index: by the block that owns that entry (uniform per block)
+  double yw_sum = 0.0;
+  if (a.yw_part && a.yw_index >= 0 && a.yw_index < n && (a.yw_index / CA_TB) % gridDim.x == blockIdx.x) {
+    __shared__ double smy[CA_TB];
+    double ya = 0.0;
+    for (int b = threadIdx.x; b < a.n_yw; b += CA_TB) ya += a.yw_part[b];
+    yw_sum = ca_block_sum(ya, smy);
   }
-  __threadfence_system();
-  __syncthreads();
-  if (threadIdx.x == 0) last = atomicAdd(a.arrive, 1u) + 1u == a.arrive_target;
-  __syncthreads();
-  if (last) {   // every block's stores are out (each fenced before its arrival): raise my flag on every rank
-    __threadfence_system();
-    if ((int)threadIdx.x < a.world)
-      __hip_atomic_store(ca_p2p_flag(a.peers[threadIdx.x], a.cap, a.world, par, a.rank), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
-  // 2. wait for the W flags of MY slab, one lane per source rank (world <= CA_TB, checked by ca_p2p_export)
   double* mine = a.peers[a.rank];
-  if ((int)threadIdx.x < a.world) {
-    unsigned long long* f = ca_p2p_flag(mine, a.cap, a.world, par, threadIdx.x);
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
-      __builtin_amdgcn_s_sleep(2);
-      if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) { atomicOr(&bad, 1u); break; }
+  for (int64_t i = i0; i < n; i += stride) {
+    // 1. my summand ...
+    double v;
+    if (a.gpart && i >= a.fold_lo && i < a.fold_lo + a.fold_n) {   // column sum of the sweep's slabs, slice order, 8 loads in flight
+      v = 0.0;
+      const float* gp = a.gpart + (i - a.fold_lo);
+      for (int sp0 = 0; sp0 < a.nslice; sp0 += 8) {
+        float t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = gp[(int64_t)(sp0 + q < a.nslice ? sp0 + q : a.nslice - 1) * a.fold_n];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v += (sp0 + q < a.nslice) ? (double)t[q] : 0.0;
+      }
+    } else {
+      v = buf[i];
+    }
+    if (a.yw_part && i == a.yw_index) v += yw_sum;
+    // ... into my inbox on every rank: two 8-byte stores per peer, each carrying its half of the double and the call's tag
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    const unsigned long long w0 = (bits & 0xFFFFFFFFull) | tag, w1 = (bits >> 32) | tag;
+    for (int p = 0; p < a.world; ++p) {
+      unsigned long long* e = ca_p2p_entry(a.peers[p], a.cap, a.world, par, a.rank, i);
+      __hip_atomic_store(e, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(e + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
-  __syncthreads();
-  if (bad) {
-    if (threadIdx.x == 0) {
-      unsigned long long expect = 0ull;
-      __hip_atomic_compare_exchange_strong(a.err, &expect, a.seq, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    return;
-  }
-  __threadfence_system();
-  // 3. the same W additions in the same order on every rank
+  // 2. the same W additions in the same order on every rank, each summand taken as soon as it can be read complete
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
   for (int64_t i = i0; i < n; i += stride) {
     double s = 0.0;
-    for (int r = 0; r < a.world; ++r)
-      s += __hip_atomic_load(ca_p2p_inbox(mine, a.cap, a.world, par, r) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    for (int r = 0; r < a.world; ++r) {
+      const unsigned long long* e = ca_p2p_entry(mine, a.cap, a.world, par, r, i);
+      unsigned long long w0 = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      unsigned long long w1 = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      while (((w0 ^ tag) >> 32) != 0ull || ((w1 ^ tag) >> 32) != 0ull) {
+        if (__builtin_amdgcn_s_memrealtime() - t0 > a.timeout_ticks) {
+          unsigned long long expect = 0ull;
+          __hip_atomic_compare_exchange_strong(a.err, &expect, a.seq, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(a.err_local, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          return;
+        }
+        __builtin_amdgcn_s_sleep(1);
+        w0 = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        w1 = __hip_atomic_load(e + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      s += __longlong_as_double((long long)((w0 & 0xFFFFFFFFull) | (w1 << 32)));
+    }
     buf[i] = s;
   }
 }

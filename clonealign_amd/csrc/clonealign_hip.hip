@@ -69,12 +69,12 @@ struct ca_p2p {
   double* slab = nullptr; size_t slab_bytes = 0; int64_t cap = 0;
   std::vector<void*> opened;             // peers' slabs as mapped here (nullptr for ranks of this process' own slab)
   double** peers_dev = nullptr;          // device array [world]
-  unsigned int* arrive = nullptr; unsigned int arrived = 0;
   unsigned long long seq = 0;
   bool mapped = false;                   // ca_p2p_connect has mapped every peer's slab
   bool connected = false;                // ca_p2p_commit(1): the transport is the engine's all-reduce
   unsigned long long* err_host = nullptr;   // pinned: 0, or the sequence number of the first call whose wait for a peer ran out
   unsigned long long* err_dev = nullptr;    // the same word as the device sees it
+  unsigned int* err_local = nullptr;        // device memory: non-zero once a call has given up (what the next calls check at entry)
   unsigned long long timeout_ticks = 0;     // bound of the device-side wait, s_memrealtime ticks (100 MHz)
 };
 struct ca_p2p_wire {   // what travels in a CA_P2P_HANDLE_BYTES handle
@@ -123,6 +123,7 @@ struct ca_engine {
   // bound of the stepped state is then made by the next forward sweep itself (em_stale: nobody has made it yet)
   float *vchi_alt = nullptr, *alpha_u_alt = nullptr;
   bool upd_merge = false, em_stale = false;
+  bool p2p_ride = false;   // sharded over the peer-to-peer transport: the sweep's column sums and the stream's finishing sums ride (allreduce(), train_bwd)
   double* gaux = nullptr; int64_t gaux_slot = -1;   // [2][5][G]: ca_merge_args::aux_in / aux_out, ping-pong; gaux_slot: the eps draw the current half belongs to (-1: none)
   int gaux_idx = 0;
   int* vmm_at = nullptr; int vmm_at_idx = 0; bool vmm_at_ready = false;   // [2][16] ordered-int range of V' (k_update_merged), the buffer in use alternates
@@ -220,7 +221,7 @@ namespace {
 int comm_check(ca_engine* h) {
   if (h->p2p && h->p2p->err_host && *reinterpret_cast<volatile unsigned long long*>(h->p2p->err_host) != 0ull) {
     h->err = "peer-to-peer all-reduce #" + std::to_string(*reinterpret_cast<volatile unsigned long long*>(h->p2p->err_host)) +
-             ": a peer's flag did not arrive within the time limit (peer lost or out of step); this engine's transport is dead -- "
+             ": a peer's data did not arrive within the time limit (peer lost or out of step); this engine's transport is dead -- "
              "destroy the engine and start over in a fresh process";
     return CA_ERR_COMM;
   }
@@ -814,7 +815,13 @@ void sym_eig(std::vector<double> T, int q, std::vector<double>& lam, std::vector
   W = W2;
 }
 
-int allreduce(ca_engine* h, double* buf, int64_t n) {
+// work that rides in the peer-to-peer all-reduce's launch instead of getting launches of its own in front of it (ca_p2p_args)
+struct ca_ar_ride {
+  const float* gpart = nullptr; int nslice = 0; int64_t fold_lo = 0, fold_n = 0;
+  const double* yw_part = nullptr; int n_yw = 0; int64_t yw_index = -1;
+};
+inline bool p2p_ride_ok(const ca_engine* h, int64_t n) { return h->p2p && h->p2p->connected && h->p2p_ride && n <= h->p2p->cap; }
+int allreduce(ca_engine* h, double* buf, int64_t n, const ca_ar_ride* ride = nullptr) {
   if (h->opt.world <= 1 && !h->comm && !h->host_ar && !(h->p2p && h->p2p->connected)) return CA_OK;   // a 1-rank communicator still reduces (tests)
   if (h->p2p && h->p2p->connected) {
     ca_p2p* pp = h->p2p;
@@ -822,9 +829,14 @@ int allreduce(ca_engine* h, double* buf, int64_t n) {
       const int64_t m = std::min<int64_t>(pp->cap, n - o);
       const int nblk = (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(m, CA_TB), 64));
       ca_p2p_args a;
+      memset(&a, 0, sizeof(a));
       a.peers = pp->peers_dev; a.rank = h->opt.rank; a.world = h->opt.world; a.cap = pp->cap;
-      a.seq = ++pp->seq; a.arrive = pp->arrive; a.err = pp->err_dev; a.timeout_ticks = pp->timeout_ticks;
-      pp->arrived += (unsigned)nblk; a.arrive_target = pp->arrived;
+      a.seq = ++pp->seq; a.err = pp->err_dev; a.err_local = pp->err_local; a.timeout_ticks = pp->timeout_ticks;
+      a.yw_index = -1;
+      if (ride) {   // (only ever with n <= cap: one piece, p2p_ride_ok)
+        a.gpart = ride->gpart; a.nslice = ride->nslice; a.fold_lo = ride->fold_lo; a.fold_n = ride->fold_n;
+        a.yw_part = ride->yw_part; a.n_yw = ride->n_yw; a.yw_index = ride->yw_index;
+      }
       LAUNCH(h, CA_KERNEL_OTHER, hipLaunchKernelGGL(k_p2p_allreduce, dim3(nblk), dim3(CA_TB), 0, h->stream, buf + o, m, a));
     }
     return CA_OK;
@@ -891,7 +903,6 @@ ca_small_args small_args(ca_engine* h, const double* gene_part, int apply, float
   return a;
 }
 // a fused monitor pass leaves its ELBO assembly for the next backward sweep; if none is coming, run it now
-int allreduce(ca_engine* h, double* buf, int64_t n);
 inline bool is_sharded(const ca_engine* h) { return h->opt.world > 1 || h->comm || h->host_ar || (h->p2p && h->p2p->connected); }
 // Reduce a pending monitor tail's cell partials (and psi.(YW) partials) for a sharded run: red[0 .. 3 + C) local sums,
 // ready for the all-reduce.  The Y stream (side stream) must have delivered the psi.(YW) partials first.
@@ -923,7 +934,8 @@ inline ca_small_args no_small_args() { ca_small_args a; memset(&a, 0, sizeof(a))
 // variable, so ca_run may issue it before it knows whether the loop goes on (train_bwd_speculative).
 int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
   const int W_ = h->S + h->D;
-  bool merged = false;
+  bool merged = false, ride_ar = false;
+  ca_ar_ride ride;
   if (h->bwd_mfma) {
     constexpr int TL = CA_BWD_TL;
     const int xb = cdiv(h->nwt, CA_TB / 64);
@@ -936,7 +948,11 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
     // them (the psi.(YW) partials), so it moves on to the per-gene kernel's extra block (train_update) when they ride here.
     ca_yfin_args yfin;
     memset(&yfin, 0, sizeof(yfin));
-    if (is_sharded(h)) CACK(yfin_flush(h));   // (sharded: the tail's local sums go into this pass's all-reduce, so they stay here)
+    // Sharded over the peer-to-peer transport (round 4): the stream's finisher rides here as it does unsharded, the psi.(YW) partial sum a
+    // pending monitor pass needs is added to its cell sum INSIDE the all-reduce's launch, and so are the column sums of this sweep's
+    // slabs -- fwd, bwd, all-reduce, update: four launches where there were six.  Other transports keep the launches.
+    ride_ar = is_sharded(h) && p2p_ride_ok(h, h->red_n);
+    if (is_sharded(h) && !ride_ar) CACK(yfin_flush(h));   // (the tail's local sums go into this pass's all-reduce, so they stay here)
     if (h->yfin_pending) { yfin = yfin_args(h); h->yfin_pending = false; }
     ca_small_args bwd_tail = no_small_args();
     bool split_tail = false;
@@ -945,6 +961,10 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
       bwd_tail = h->mon_tail;
       merged = is_sharded(h);
       if (merged) { bwd_tail.reduce_only = 1; bwd_tail.host_out = nullptr; }
+      if (merged && ride_ar && yfin.nrow > 0 && bwd_tail.yw_part) {   // the partials are made by this very launch: their sum rides in the all-reduce
+        ride.yw_part = bwd_tail.yw_part; ride.n_yw = bwd_tail.n_yw; ride.yw_index = 0;
+        bwd_tail.yw_part = nullptr;
+      }
       // the psi.(YW) partials are being made by this very launch: the cell partials are reduced here, the rest of the tail
       // (their sum, the assembly) follows on the per-gene kernel's extra block
       split_tail = !merged && yfin.nrow > 0 && bwd_tail.yw_part != nullptr;
@@ -976,7 +996,8 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
     // (summing the sweep's partials inside k_final_gene instead -- one thread per gene, csplit_m loads in a row -- was
     //  slower than this parallel launch at 100k cells: 2219 -> 2190 it/s; small unsharded problems fold it: fold_gsum)
     h->fold_now = h->fold_gsum && !is_sharded(h);
-    if (!h->fold_now)
+    if (ride_ar) { ride.gpart = h->gpart; ride.nslice = h->csplit_m; ride.fold_n = (int64_t)h->G * W_; }
+    else if (!h->fold_now)
       LAUNCH(h, CA_KERNEL_OTHER,
              hipLaunchKernelGGL(k_colsum, dim3(cdiv((int64_t)h->G * W_, 64)), dim3(1024), 0, h->stream, h->gpart,
                                 h->red + h->off_g, h->csplit_m, (int64_t)h->G * W_, h->G * W_));
@@ -1005,8 +1026,8 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
   CACK(wait_y(h, true));
   // sharded loop: a pending monitor pass's cell sums travel with this pass's gene sums -- ONE all-reduce per iteration;
   // the ELBO is assembled after it (k_final_gene's extra block, or ca_run's flush)
-  if (cell_sums_global && !merged) CACK(allreduce(h, h->red + h->off_g, h->red_n - h->off_g));
-  else CACK(allreduce(h, h->red, h->red_n));
+  if (cell_sums_global && !merged) { ride.fold_lo = 0; CACK(allreduce(h, h->red + h->off_g, h->red_n - h->off_g, ride_ar ? &ride : nullptr)); }
+  else { ride.fold_lo = h->off_g; CACK(allreduce(h, h->red, h->red_n, ride_ar ? &ride : nullptr)); }
   if (is_sharded(h)) h->ycache_valid = false;   // red_y now holds the GLOBAL sum
   return CA_OK;
 }
@@ -1290,7 +1311,7 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
     else CA_FCYS_D(2, CA_YS_RIDE_DEPTH);
 #undef CA_FCYS_D
 #undef CA_FCYS
-    CACK(ys_finish(h, h->yfin_split && !is_sharded(h)));
+    CACK(ys_finish(h, h->yfin_split && (!is_sharded(h) || p2p_ride_ok(h, h->red_n))));
   } else if (h->fwd_cell && ride) {   // ... and the Y stream's blocks interleaved with the sweep's in the same grid
     cell_blocks = h->ncblk_f;
     ca_yride_args ya;
@@ -1841,6 +1862,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   h->tail_fuse = variant_on(h, CA_VAR_TAIL_FUSE, "CA_TAIL_FUSE");
   h->pre_ok = variant_on(h, CA_VAR_PRE, "CA_PRE");
   h->upd_merge = h->tail_fuse && h->pre_ok && variant_on(h, CA_VAR_UPDATE_MERGE, "CA_UPDATE_MERGE");
+  h->p2p_ride = h->tail_fuse && variant_on(h, CA_VAR_P2P_RIDE, "CA_P2P_RIDE");
   h->pair_elbo = variant_on(h, CA_VAR_PAIR_ELBO, "CA_PAIR_ELBO");
   CACK(upload_y(h, p));
   const int G = h->G, C = h->C, K = h->K, P = h->P, S = h->S, D = h->D;
@@ -2421,9 +2443,9 @@ int ca_destroy(ca_handle h) {
   if (h->p2p) {
     for (void* q : h->p2p->opened) if (q) hipIpcCloseMemHandle(q);
     if (h->p2p->err_host) hipHostFree(h->p2p->err_host);
+    if (h->p2p->err_local) hipFree(h->p2p->err_local);
     if (h->p2p->slab) hipFree(h->p2p->slab);
     if (h->p2p->peers_dev) hipFree(h->p2p->peers_dev);
-    if (h->p2p->arrive) hipFree(h->p2p->arrive);
     delete h->p2p;
   }
   for (auto& e : h->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
@@ -2496,7 +2518,7 @@ int ca_p2p_export(ca_handle h, char handle[CA_P2P_HANDLE_BYTES]) {
     const int W = h->opt.world;
     // room for everything one call reduces: the train pass's summands, the setup sums, the PCA / correlation packs
     pp->cap = std::max<int64_t>(std::max<int64_t>(h->red_n, (int64_t)h->G * (h->C + 2) + 64), 4096);
-    pp->slab_bytes = ((size_t)2 * W * pp->cap + (size_t)2 * W) * sizeof(double);
+    pp->slab_bytes = (size_t)2 * W * pp->cap * 16;   // [parity 2][source W][cap] entries of 16 bytes: two halves of a double, each with the call's tag (k_p2p_allreduce)
     // Fine-grained memory or nothing: the slab is written by remote peers over xGMI and polled here, which ordinary
     // (coarse-grained) device memory does not keep coherent -- a stale flag would be a hang or a wrong sum.  The caller moves
     // on to RCCL when this fails.
@@ -2506,12 +2528,12 @@ int ca_p2p_export(ca_handle h, char handle[CA_P2P_HANDLE_BYTES]) {
       h->err = "peer-to-peer transport: fine-grained device memory unavailable (hipExtMallocWithFlags(hipDeviceMallocFinegrained) failed)";
       return CA_ERR_COMM;
     }
-    auto fail = [&](const std::string& m) { if (pp->err_host) hipHostFree(pp->err_host); if (pp->peers_dev) hipFree(pp->peers_dev);
-                                            if (pp->arrive) hipFree(pp->arrive); hipFree(pp->slab); delete pp; h->err = m; return CA_ERR_HIP; };
+    auto fail = [&](const std::string& m) { if (pp->err_host) hipHostFree(pp->err_host); if (pp->err_local) hipFree(pp->err_local); if (pp->peers_dev) hipFree(pp->peers_dev);
+                                            hipFree(pp->slab); delete pp; h->err = m; return CA_ERR_HIP; };
     if (hipMemset(pp->slab, 0, pp->slab_bytes) != hipSuccess) return fail("hipMemset of the p2p slab failed");
     if (hipMalloc((void**)&pp->peers_dev, (size_t)W * sizeof(double*)) != hipSuccess) return fail("hipMalloc (p2p peer table) failed");
-    if (hipMalloc((void**)&pp->arrive, sizeof(unsigned int)) != hipSuccess) return fail("hipMalloc (p2p arrival counter) failed");
-    if (hipMemset(pp->arrive, 0, sizeof(unsigned int)) != hipSuccess) return fail("hipMemset (p2p arrival counter) failed");
+    if (hipMalloc((void**)&pp->err_local, sizeof(unsigned int)) != hipSuccess) return fail("hipMalloc (p2p error flag) failed");
+    if (hipMemset(pp->err_local, 0, sizeof(unsigned int)) != hipSuccess) return fail("hipMemset (p2p error flag) failed");
     if (hipHostMalloc((void**)&pp->err_host, sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) return fail("hipHostMalloc (p2p error word) failed");
     *pp->err_host = 0ull;
     if (hipHostGetDevicePointer((void**)&pp->err_dev, pp->err_host, 0) != hipSuccess) return fail("hipHostGetDevicePointer (p2p error word) failed");

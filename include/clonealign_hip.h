@@ -89,6 +89,8 @@ enum ca_variant {
   CA_VAR_PREP_FAST = 1 << 8,  /* wave-per-cell fit-constant kernel for u8 storage */
   CA_VAR_UPDATE_MERGE = 1 << 9, /* the update half of a train pass of the loop as ONE launch (k_update_merged: per-gene step + next prologue + int8 images, psi,
                                   q(z) logits, chi / alpha), the exponent bound taken by the next forward sweep; off: k_final_gene + k_adam_cell */
+  CA_VAR_P2P_RIDE = 1 << 16,  /* sharded over the peer-to-peer transport: the backward sweep's column sums, the stream's finishing sums and the pending monitor
+                                 pass's psi.(YW) sum ride in the sweep's and the all-reduce's launches (4 launches per iteration); off: k_yfinish + k_colsum launches */
   CA_VAR_P2P = 1 << 10,       /* one-shot peer-to-peer all-reduce (else ncclAllReduce) after ca_comm_init() */
   CA_VAR_FOLD_GSUM = 1 << 11, /* small problems: backward-sweep partials summed inside the per-gene kernel (else a k_colsum launch) */
   CA_VAR_Y_RIDE = 1 << 12,    /* the Y stream's blocks ride on the forward sweep's launch (else side stream / in line) */

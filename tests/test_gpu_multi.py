@@ -108,6 +108,24 @@ def test_ranks_on_one_gpu_at_shard_sizes_across_the_kernel_selection_thresholds(
     _check(res, one, "p2p", cells)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_work_riding_in_the_all_reduce_launch_equals_the_separate_launches(tmp_path, world):
+    """Round 4, sharded over the peer-to-peer transport: the backward sweep's column sums, the int8 stream's finishing sums and a pending
+    monitor pass's psi.(YW) sum ride in the sweep's and the all-reduce's launches (four launches per iteration instead of six).  Against the
+    separate launches (variant p2p_ride off): same fit to fp64 summation order (1e-10 on the ELBO trace), replicas bit-identical either way,
+    both equal to the one-handle fit."""
+    shape = ["--cells", "9000", "--genes", "800", "--clones", "6", "--iters", "8"]
+    one = _run(1, "none", tmp_path / "one.json", True, shape)["ranks"][0]
+    on = _run(world, "p2p", tmp_path / "on.json", True, shape)
+    r = _launch(world, "p2p", tmp_path / "off.json", True, shape, extra=["--variant-off", "p2p_ride"])
+    assert r.returncode == 0, child_report(r)
+    off = json.load(open(tmp_path / "off.json"))
+    _check(on, one, "p2p", 9000)
+    _check(off, one, "p2p", 9000)
+    a, b = np.array(on["ranks"][0]["trace"]), np.array(off["ranks"][0]["trace"])
+    assert a.shape == b.shape and np.abs(a - b).max() <= 1e-10 * np.abs(b).max(), (a, b)
+
+
 def test_eight_ranks_on_one_gpu_with_the_cfg4_gene_count(tmp_path):
     """W = 8 flag lanes / inbox slabs and the all-reduce payload of BASELINE.json configs[3] (G = 5000, C = 8: 15 011 doubles per
     train pass) -- eight PROCESSES sharing device 0, 1000 cells each, against the one-handle fit."""

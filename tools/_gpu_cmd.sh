@@ -1,6 +1,5 @@
-mkdir -p gpurun_out/r4
-for e in "" "CA_UPDATE_MERGE=0" "CA_Y_MFMA1=1,CA_Y_RIDE=1" "CA_BWD_MFMA=0" "CA_FWD_MFMA=0"; do
-  echo "### extra env: $e"
-  FUZZ_ONLY=256 FUZZ_ENV="$e" python tools/fuzz_parity.py 300 401 2>&1 | grep -v amdgpu.ids | tail -4
-done > gpurun_out/r4/fuzz_replay_256.txt 2>&1
-cat gpurun_out/r4/fuzz_replay_256.txt
+for cfg in "12500 5000 8" "25000 5000 8" "50000 5000 8"; do
+  python tools/shard_seq_time.py $cfg 2>&1 | tail -1
+  python tools/shard_seq_time.py $cfg --variant-off p2p_ride 2>&1 | tail -1
+done
+python -m pytest tests/test_gpu_multi.py tests/test_gpu_sharding.py -x -q 2>&1 | grep -E "passed|failed|rror|assert" | tail -8

@@ -31,6 +31,7 @@ def main():
                     help="fault injection: this rank makes ONE collective call (ca_elbo) more than its peers after the fit; the call must "
                          "end in CA_ERR_COMM within --comm-timeout-ms and the process must exit non-zero")
     ap.add_argument("--comm-timeout-ms", type=int, default=0)
+    ap.add_argument("--variant-off", default="", help="comma-separated engine variants to switch off (engine.VARIANTS)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
@@ -65,7 +66,7 @@ def main():
                 buf[:] = t.numpy()
             kw["host_allreduce"] = gloo_sum
     eng = HipEngine(case["Y"][lo:hi], case["L"], case["psi0"][lo:hi], case["loc0"], 1, 1, device=local, rank=rank, world=world,
-                    comm_timeout_ms=args.comm_timeout_ms, **kw)
+                    comm_timeout_ms=args.comm_timeout_ms, variant_off=tuple(v for v in args.variant_off.split(",") if v), **kw)
     selftest_bad = eng.comm_selftest(5) if world > 1 else 0     # known-answer all-reduces on the transport in use, before the fit
     eps = np.stack([eps_for(1, args.genes, 300 + i) for i in range(2 + 2 * args.iters + 4)])
     trace = eng.run(eps, args.iters, 1e-12)
