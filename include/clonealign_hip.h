@@ -143,7 +143,7 @@ typedef struct ca_options {
                                      * (from two units per CU up; below that the 2:1 interleave).  < 0: that many long-lived stream blocks.
                                      * > 0: (a << 8) | b = a sweep blocks, then b single-unit stream blocks, ...; periods that divide 8 put the
                                      * two kinds on disjoint XCDs.  Results do not depend on it (tests/test_gpu_parity.py) */
-  int32_t comm_timeout_ms;          /* peer-to-peer all-reduce: how long a rank waits on the device for its peers' flags before the call
+  int32_t comm_timeout_ms;          /* peer-to-peer all-reduce: how long a rank waits on the device for its peers' data before the call
                                      * gives up and the engine reports CA_ERR_COMM (0 = 10 000 ms) */
   int32_t reserved[3];
 } ca_options;
@@ -211,10 +211,10 @@ int ca_synchronize(ca_handle h);
 int ca_comm_unique_id(char id[128]);
 int ca_comm_init(ca_handle h, const char id[128]);
 /* One-shot peer-to-peer all-reduce over xGMI: the per-iteration payload is ~120 KB, i.e. latency-bound, so
- * instead of a ring every rank WRITES its summands into an inbox slab of every peer (IPC-mapped device memory), raises a
- * sequence flag there, waits for the W flags of its own slab and adds the W inboxes in rank order 0..W-1 -- the same additions
- * in the same order on every rank, so the replicas stay bit-identical, in one kernel on the engine's stream, no host round
- * trip.  Setup: every rank exports a handle, the caller exchanges them out of band (like the RCCL id: torch.distributed /
+ * instead of a ring every rank WRITES its summands into an inbox slab of every peer (IPC-mapped device memory) and adds the W
+ * inboxes of its own slab in rank order 0..W-1 -- the same additions in the same order on every rank, so the replicas stay
+ * bit-identical, in one kernel on the engine's stream, no host round trip.  Since round 4 every 8-byte store carries half a double
+ * and the call's 32-bit tag: a summand is complete when it can be READ complete -- no fence, no flag, no counter (k_p2p_allreduce).  Setup: every rank exports a handle, the caller exchanges them out of band (like the RCCL id: torch.distributed /
  * MPI all-gather), every rank connects.  Needs peer access between the devices (same node); ranks may share a device. */
 #define CA_P2P_HANDLE_BYTES 128
 /* Setup is two-phase so that a one-sided failure cannot leave the other ranks waiting on the device:
@@ -227,8 +227,8 @@ int ca_comm_init(ca_handle h, const char id[128]);
  *   3. the caller agrees over its control plane whether step 2 succeeded on EVERY rank, then every rank calls
  *      ca_p2p_commit(h, all_ok): 1 makes the transport the engine's all-reduce and reduces the setup sums (the first call that
  *      waits for peers); 0 drops the mappings (next: ca_comm_init, or a host callback).
- * The device-side wait for the peers' flags is bounded (ca_options.comm_timeout_ms): when it runs out the call leaves its buffer
- * alone, every later all-reduce on this engine returns at once, and the next API call that synchronises returns CA_ERR_COMM.
+ * The device-side wait for the peers' data is bounded (ca_options.comm_timeout_ms): when it runs out the call gives up (its buffer
+ * is then partly summed), every later all-reduce on this engine returns at once, and the next API call that synchronises returns CA_ERR_COMM.
  * The engine is then dead: destroy it (a fresh process is the recovery).  Calls that reduce are collective: every rank must make
  * the same sequence of ca_* calls, and a ca_run_ex poll hook must take the same decision on every rank. */
 int ca_p2p_export(ca_handle h, char handle[CA_P2P_HANDLE_BYTES]);
@@ -240,7 +240,7 @@ int ca_comm_benchmark(ca_handle h, int32_t transport, int32_t n_calls, int64_t n
 /* Known-answer test of the engine's ACTIVE all-reduce (whatever ca_info.transport says): n_rounds all-reduces of n_doubles doubles whose
  * summands are (rank + 1) * pattern(i, round) + round / 2 -- every partial sum is an integer or a half, exact in a double in any order -- checked
  * on the host against W (W + 1) / 2 * pattern + W * round / 2.  *n_bad = entries that came back wrong (0 = the transport adds what it should: both
- * inbox parities and the sequence flags of the peer-to-peer form are exercised from the second round on).  Collective.  The first time a transport
+ * inbox parities and the sequence tags of the peer-to-peer form are exercised from the second round on).  Collective.  The first time a transport
  * runs on hardware it has never run on (peer-to-peer across xGMI), this is what a launcher asks before it trusts it (bench.py does). */
 int ca_comm_selftest(ca_handle h, int32_t n_rounds, int64_t n_doubles, int64_t* n_bad);
 /* Alternative transport for world > 1 (MPI, gloo, tests): the engine hands the summand buffer to the
