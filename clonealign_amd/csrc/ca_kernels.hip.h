@@ -3229,9 +3229,39 @@ struct ca_merge_args {
   float* glogit; const float* dgl; float* m_gl; float* v_gl; int C; int ncell;   // q(z) logits: ncell blocks of 256 cells
   const double* aux_in; double* aux_out; int64_t aux_ld;   // [5][aux_ld] doubles per gene: the sweep-independent part of the NEXT step's gradient (ca_gene_pre_draw);
                                                            // aux_in: what the prologue of THIS pass's eps left (null: the step computes it), aux_out: for the next step
+  // ca_run's gate (round 4): the launch is queued BEFORE the host has seen the ELBO the stop rule needs -- that ELBO is assembled by this
+  // launch's own monitor block, which is not gated -- and every other block waits here for the host's decision: word = (gate_seq << 1) | go in
+  // pinned host memory.  go = 0 (the loop stops, or the poll hook said so) or a wait past gate_timeout: the block returns without a single store.
+  const unsigned long long* gate; unsigned long long gate_seq, gate_timeout; unsigned long long* gate_err;
+  unsigned long long* gate_local;   // device memory: ONE block (the chi / alpha block) polls the host's word over PCIe and passes it on here; the others poll this
   int* vmm_at; int* vmm_at_next;   // range of V' over ALL genes as ordered ints [2][8]: every gene block folds its own in with one atomic min / max per
                                    // dimension (the next sweep reads 2 D words); the chi / alpha block resets the buffer of the NEXT merged update
 };
+// every thread of the block calls it; true = go on (no gate, or the host said go).  relay: this block is the one that reads the host's word
+// (pinned memory, a PCIe round trip per look) and passes it on through device memory; two hundred blocks polling the host's line themselves
+// made a ca_run iteration 160 us LONGER (gpurun_out/r4/run_gate1.txt)
+__device__ __forceinline__ bool ca_gate_wait(const ca_merge_args& mg, bool relay) {
+  if (!mg.gate) return true;
+  __shared__ unsigned gate_go;
+  if (threadIdx.x == 0) {
+    unsigned go = 0u;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (;;) {
+      const unsigned long long w = relay ? __hip_atomic_load(mg.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
+                                         : __hip_atomic_load(mg.gate_local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((w >> 1) == mg.gate_seq) { go = (unsigned)(w & 1ull); break; }
+      if (__builtin_amdgcn_s_memrealtime() - t0 > mg.gate_timeout) {   // the host never answered: no store is made, and the host is told
+        __hip_atomic_store(mg.gate_err, mg.gate_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        break;
+      }
+      if (relay) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(16);
+    }
+    if (relay) __hip_atomic_store(mg.gate_local, (mg.gate_seq << 1) | (unsigned long long)go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    gate_go = go;
+  }
+  __syncthreads();
+  return gate_go != 0u;
+}
 #define CA_UM_TB 1024   // threads of a k_update_merged block: a gene block is 256 genes x four ROLES (below); every other kind of block uses its first 256
 __global__ void __launch_bounds__(CA_UM_TB) k_update_merged(const double* __restrict__ red_g /*[G][S+D]*/, const double* __restrict__ red_y /*[G][K]*/,
                                                             const float* __restrict__ eps, const double* __restrict__ colsum,
@@ -3255,6 +3285,7 @@ __global__ void __launch_bounds__(CA_UM_TB) k_update_merged(const double* __rest
     // 12-15 the W image.  Every block-level sum keeps the order of the 256-thread form: butterflies inside a 64-gene wave, then the
     // four gene groups in order -- bitwise the same partials.
     if (CA_LAB_SKIP & 4) return;
+    if (!ca_gate_wait(mg, false)) return;
     __shared__ float h_loc[CA_TB], h_ls[CA_TB], h_v0[CA_TB];
     __shared__ double smt[4][8];
     __shared__ float smn[8][4], smx[8][4], sma[4];
@@ -3349,12 +3380,14 @@ __global__ void __launch_bounds__(CA_UM_TB) k_update_merged(const double* __rest
   int b = bx - gblocks;
   if (b < nmon + 1) {   // the two O(K + C) blocks are 256-thread blocks: the pending monitor pass's ELBO, then the chi / alpha step
     if ((int)threadIdx.x >= CA_TB) return;
-    if (mon.enabled && b == 0) { CA_LAB_CP(40, 0); if (!(CA_LAB_SKIP & 1)) ca_final_small_body(mon); CA_LAB_CP(40, 1); return; }
+    if (mon.enabled && b == 0) { CA_LAB_CP(40, 0); if (!(CA_LAB_SKIP & 1)) ca_final_small_body(mon); CA_LAB_CP(40, 1); return; }   // (never gated: it makes the ELBO the host decides on)
+    if (!ca_gate_wait(mg, true)) return;
     if (threadIdx.x < 8) { mg.vmm_at_next[threadIdx.x] = ca_f2ord(INFINITY); mg.vmm_at_next[8 + threadIdx.x] = ca_f2ord(-INFINITY); }
     CA_LAB_CP(41, 0); if (!(CA_LAB_SKIP & 8) && mg.tail.enabled) ca_final_small_body(mg.tail); CA_LAB_CP(41, 1);
     return;
   }
   b -= nmon + 1;
+  if (!ca_gate_wait(mg, false)) return;
   // psi and q(z)-logit blocks: FOUR 256-cell pieces per 1024-thread block (a quarter-filled block costs the dispatcher sixteen wave slots
   // all the same: 800 of them at cfg-3 took 15 us to get through).  Piece index = what a 256-thread block's index was.
   const int sub = (int)threadIdx.x >> 8, npsi4 = (psi.nblk + 3) / 4;

@@ -123,6 +123,9 @@ struct ca_engine {
   // bound of the stepped state is then made by the next forward sweep itself (em_stale: nobody has made it yet)
   float *vchi_alt = nullptr, *alpha_u_alt = nullptr;
   bool upd_merge = false, em_stale = false;
+  // ca_run: the update half of train pass i + 1 is queued before the host has seen ELBO i and gated on a word the host writes (ca_merge_args::gate)
+  bool run_gate = false, gate_req = false, gate_armed = false;
+  unsigned long long gate_seq = 0; unsigned long long* gate_local = nullptr;
   bool p2p_ride = false;   // sharded over the peer-to-peer transport: the sweep's column sums and the stream's finishing sums ride (allreduce(), train_bwd)
   double* gaux = nullptr; int64_t gaux_slot = -1;   // [2][5][G]: ca_merge_args::aux_in / aux_out, ping-pong; gaux_slot: the eps draw the current half belongs to (-1: none)
   int gaux_idx = 0;
@@ -1033,6 +1036,12 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
 }
 
 // update half: per-gene / per-cell gradients from the reduced sums, Adam when `apply`
+// will the update half of a train pass take the one-launch form (k_update_merged)?  (the loop has announced the next eps pair, the fused forward
+// sweep that follows can make the exponent bound itself, K >= 1)
+inline bool update_merges(const ca_engine* h, int apply, const double* elbo_dst) {
+  const int64_t mB = h->s2 ? 2 * h->hint_A + 1 : h->hint_B;
+  return apply && h->upd_merge && !elbo_dst && h->pre_ok && h->hint_A >= 0 && mB >= 0 && h->fused_ok && h->gene_part_alt && h->fwd_cell && h->K > 0;
+}
 int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
   const int N256 = cdiv(h->N, CA_TB);
   float lr_t = 0.f;
@@ -1060,9 +1069,19 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
   {
     int64_t mA = h->hint_A, mB = h->hint_B;
     if (h->s2) { mA = 2 * h->hint_A; mB = mA + 1; }
-    if (apply && h->upd_merge && !elbo_dst && h->pre_ok && h->hint_A >= 0 && mB >= 0 && h->fused_ok && h->gene_part_alt && h->fwd_cell && h->K > 0) {
+    if (update_merges(h, apply, elbo_dst)) {
       ca_merge_args mg;
       memset(&mg, 0, sizeof(mg));
+      h->gate_armed = false;
+      if (h->gate_req && h->host_dev) {   // ca_run: wait on the device for the host's decision (every block but the monitor block)
+        // (the gate word and the error word each in a cache line of their own: doubles 32 / 33 are the ELBO and its flag, which the host spins on)
+        mg.gate = reinterpret_cast<const unsigned long long*>(h->host_dev + 48); mg.gate_seq = ++h->gate_seq;
+        mg.gate_err = reinterpret_cast<unsigned long long*>(h->host_dev + 56);
+        mg.gate_local = h->gate_local;
+        mg.gate_timeout = 10ull * 100000000ull;   // 10 s of s_memrealtime ticks: only a host that died between the launch and its answer gets there
+        h->gate_armed = true;
+      }
+      h->gate_req = false;
       ca_pre_args& pre = mg.pre;
       pre.nblk = h->ngblk;
       pre.loc = h->loc; pre.ls = h->ls; pre.epsA = h->eps_dev + mA * (int64_t)h->G; pre.epsB = h->eps_dev + mB * (int64_t)h->G;
@@ -1863,6 +1882,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   h->pre_ok = variant_on(h, CA_VAR_PRE, "CA_PRE");
   h->upd_merge = h->tail_fuse && h->pre_ok && variant_on(h, CA_VAR_UPDATE_MERGE, "CA_UPDATE_MERGE");
   h->p2p_ride = h->tail_fuse && variant_on(h, CA_VAR_P2P_RIDE, "CA_P2P_RIDE");
+  h->run_gate = h->upd_merge && variant_on(h, CA_VAR_RUN_GATE, "CA_RUN_GATE");
   h->pair_elbo = variant_on(h, CA_VAR_PAIR_ELBO, "CA_PAIR_ELBO");
   CACK(upload_y(h, p));
   const int G = h->G, C = h->C, K = h->K, P = h->P, S = h->S, D = h->D;
@@ -1996,6 +2016,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   CACK(dalloc(h, &h->alpha_u, C)); CACK(dalloc(h, &h->m_a, C)); CACK(dalloc(h, &h->v_a, C)); CACK(dalloc(h, &h->g_a, C));
   CACK(dalloc(h, &h->vchi_alt, std::max(K, 1))); CACK(dalloc(h, &h->alpha_u_alt, C));
   CACK(dalloc(h, &h->vmm_at, 32));
+  CACK(dalloc(h, &h->gate_local, 2));
   CACK(dalloc(h, &h->gaux, (int64_t)2 * 5 * G));
   {
     std::vector<float> Fh((size_t)Nn * std::max(D, 1), 0.f);
@@ -2747,6 +2768,41 @@ int ca_gradients(ca_handle h, const float* eps, double* elbo) {
   return CA_OK;
 }
 
+// ca_run's gated update: what the host's bookkeeping of a step changes (train_from_lookahead + the merged branch of train_update) -- taken before
+// the launch is queued, put back when the host's answer is "stop" (the launch then stores nothing)
+struct gate_snapshot {
+  bool look_valid, bwd_ready, pre_valid, em_stale, y_defer, ys_quant_ready, ycache_valid, yfin_pending, fold_now;
+  int64_t pre_A, pre_B, hint_A, hint_B, gaux_slot;
+  int vmm_at_idx, gaux_idx, ys_steps, ys_namax[3];
+  float b1p, b2p;
+  float *vchi, *vchi_alt, *alpha_u, *alpha_u_alt;
+  void take(const ca_engine* h) {
+    look_valid = h->look_valid; bwd_ready = h->bwd_ready; pre_valid = h->pre_valid; em_stale = h->em_stale; y_defer = h->y_defer;
+    ys_quant_ready = h->ys_quant_ready; ycache_valid = h->ycache_valid; yfin_pending = h->yfin_pending; fold_now = h->fold_now;
+    pre_A = h->pre_A; pre_B = h->pre_B; hint_A = h->hint_A; hint_B = h->hint_B; gaux_slot = h->gaux_slot;
+    vmm_at_idx = h->vmm_at_idx; gaux_idx = h->gaux_idx; ys_steps = h->ys_steps;
+    for (int i = 0; i < 3; ++i) ys_namax[i] = h->ys_namax[i];
+    b1p = h->b1p; b2p = h->b2p;
+    vchi = h->vchi; vchi_alt = h->vchi_alt; alpha_u = h->alpha_u; alpha_u_alt = h->alpha_u_alt;
+  }
+  void restore(ca_engine* h) const {
+    h->look_valid = look_valid; h->bwd_ready = bwd_ready; h->pre_valid = pre_valid; h->em_stale = em_stale; h->y_defer = y_defer;
+    h->ys_quant_ready = ys_quant_ready; h->ycache_valid = ycache_valid; h->yfin_pending = yfin_pending; h->fold_now = fold_now;
+    h->pre_A = pre_A; h->pre_B = pre_B; h->hint_A = -1; h->hint_B = -1; h->gaux_slot = gaux_slot;
+    h->vmm_at_idx = vmm_at_idx; h->gaux_idx = gaux_idx; h->ys_steps = ys_steps;
+    for (int i = 0; i < 3; ++i) h->ys_namax[i] = ys_namax[i];
+    h->b1p = b1p; h->b2p = b2p;
+    h->vchi = vchi; h->vchi_alt = vchi_alt; h->alpha_u = alpha_u; h->alpha_u_alt = alpha_u_alt;
+  }
+};
+// the host's answer to the launch queued last: go (1) or stop (0)
+inline void gate_answer(ca_engine* h, int go) {
+  volatile unsigned long long* w = reinterpret_cast<volatile unsigned long long*>(h->host_pinned + 48);
+  std::atomic_thread_fence(std::memory_order_release);
+  *w = (h->gate_seq << 1) | (unsigned long long)(go ? 1 : 0);
+  std::atomic_thread_fence(std::memory_order_seq_cst);
+}
+
 int ca_run(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_stream, int64_t n_draws, double* trace, int32_t* n_elbo) {
   return ca_run_ex(h, max_iter, rel_tol, eps_stream, n_draws, trace, n_elbo, nullptr, nullptr);
 }
@@ -2772,15 +2828,46 @@ int ca_run_ex(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_st
   if (poll && poll(user, 0, val) != 0) { h->err = "interrupted by the poll callback"; return CA_INTERRUPTED; }
   double diffs[10];
   for (double& d : diffs) d = 1e3;                                      // :379
+  // Round 4: the host's look at every ELBO no longer costs a launch and a round trip.  Until now an iteration of this loop was ... backward sweep,
+  // k_final_small (the ELBO, 7.4 us), THEN the host read it, decided, and only then queued the update (11 us of idle GPU: tools/gaps.py on the
+  // bench trace) -- 19 us per iteration that ca_iterate does not pay.  Now the update half of train pass i + 1 is queued right behind the
+  // backward sweep: its monitor block assembles ELBO i and mirrors it to the host, every other block waits on the device for the word the host
+  // writes once it has decided (ca_merge_args::gate).  "Stop" (tolerance, poll hook, NaN) makes the queued launch a no-op and the host takes
+  // back the bookkeeping of the step it had queued: the state is what the lock-step loop leaves, bit for bit (tests).
+  bool queued = false;   // the update half of train pass i was queued (gated, answered "go") by the previous turn of the loop
   for (int i = 1; i <= max_iter; ++i) {
-    h->hint_A = 2 * (int64_t)i + 1; h->hint_B = i < max_iter ? 2 * (int64_t)i + 2 : -1;
-    CACK(train_pass(h, 2 * (int64_t)i));                                // :401
+    if (!queued) {
+      h->hint_A = 2 * (int64_t)i + 1; h->hint_B = i < max_iter ? 2 * (int64_t)i + 2 : -1;
+      CACK(train_pass(h, 2 * (int64_t)i));                              // :401
+    }
+    queued = false;
     h->host_seq_next = ++h->host_seq;
     CACK(monitor_pass(h, 2 * (int64_t)i + 1, i < max_iter ? 2 * (int64_t)i + 2 : -1, h->elbo_dev + i));   // :403
     double nv;
     CACK(train_bwd_speculative(h));     // backward half of train pass i+1 runs while the host looks at ELBO i
-    CACK(flush_mon_tail(h));
-    CACK(wait_host_elbo(h, h->host_seq, h->elbo_dev + i, &nv));
+    // the gated update of train pass i + 1 (needs: a next pass, its look-ahead forward and backward halves in place, the one-launch update)
+    gate_snapshot snap;
+    bool gated = false;
+    if (h->run_gate && i < max_iter && h->bwd_ready && h->look_valid && h->look_slot == 2 * (int64_t)(i + 1) && (!h->mon_tail.enabled || h->mon_tail.host_out)) {
+      h->hint_A = 2 * (int64_t)(i + 1) + 1; h->hint_B = i + 1 < max_iter ? 2 * (int64_t)(i + 1) + 2 : -1;
+      if (update_merges(h, 1, nullptr)) {
+        snap.take(h);
+        h->gate_req = true;
+        const int rc = train_pass(h, 2 * (int64_t)(i + 1));
+        gated = h->gate_armed;
+        h->gate_armed = false;
+        if (rc != CA_OK) { if (gated) gate_answer(h, 0); return rc; }
+      } else {
+        h->hint_A = h->hint_B = -1;
+      }
+    }
+    if (!gated) CACK(flush_mon_tail(h));
+    int rc = wait_host_elbo(h, h->host_seq, h->elbo_dev + i, &nv);
+    if (rc == CA_OK && *reinterpret_cast<volatile unsigned long long*>(h->host_pinned + 56) != 0ull) {
+      h->err = "ca_run: a gated update gave up waiting for the host's answer (launch #" + std::to_string(*reinterpret_cast<volatile unsigned long long*>(h->host_pinned + 56)) + "); the engine's state is undefined";
+      rc = CA_ERR_STATE;
+    }
+    if (rc != CA_OK) { if (gated) { gate_answer(h, 0); snap.restore(h); } return rc; }
     const double diff = (nv - val) / std::fabs(val);
     for (int j = 0; j < 9; ++j) diffs[j] = diffs[j + 1];
     diffs[9] = diff;
@@ -2789,9 +2876,17 @@ int ca_run_ex(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_st
     double mean = 0.0;
     for (double d : diffs) mean += std::fabs(d);
     mean /= 10.0;
-    if (std::isnan(mean)) { h->err = "missing value where TRUE/FALSE needed"; return CA_ERR_NAN; }  // R's if (NA) at :414
-    if (poll && poll(user, i, nv) != 0) { h->err = "interrupted by the poll callback"; return CA_INTERRUPTED; }
-    if (mean < rel_tol) break;                                          // :414-415
+    int stop = 0;   // 0 go on, else the return code (CA_OK = converged)
+    if (std::isnan(mean)) { h->err = "missing value where TRUE/FALSE needed"; stop = CA_ERR_NAN; }  // R's if (NA) at :414
+    else if (poll && poll(user, i, nv) != 0) { h->err = "interrupted by the poll callback"; stop = CA_INTERRUPTED; }
+    else if (mean < rel_tol) stop = -1;                                 // :414-415
+    if (gated) {
+      gate_answer(h, stop == 0 ? 1 : 0);
+      if (stop == 0) queued = true;
+      else snap.restore(h);
+    }
+    if (stop > 0) return stop;
+    if (stop < 0) break;
   }
   return CA_OK;
 }

@@ -786,3 +786,40 @@ def test_clone_labels_exact_where_many_cells_sit_near_the_threshold():
         assert far == 0 and flips == 0
     finally:
         eng.close(); ora.close()
+
+
+@pytest.mark.parametrize("shape", [dict(N=900, G=410, C=4, K=1), dict(N=33, G=1030, C=3, K=1), dict(N=700, G=1100, C=11, K=1), dict(N=2100, G=600, C=6, K=2, P=1)],
+                         ids=["small", "tiny", "c11", "k2p1_not_gated"])
+def test_ca_run_with_the_update_queued_ahead_of_the_decision_is_the_lock_step_loop(shape):
+    """Round 4: ca_run queues the update half of train pass i + 1 BEFORE the host has seen ELBO i; the launch waits on the device for the
+    host's go / stop word, and on "stop" it stores nothing and the host takes its bookkeeping of that step back.  Whatever ends the loop --
+    max_iter, the window-10 tolerance (R/inference-tflow.R:414), the poll hook -- trace, variables, Adam state (through further steps) and
+    every later call must be what the lock-step loop (variant run_gate off) gives, bit for bit."""
+    from clonealign_amd.engine import HipEngine
+    from clonealign_amd.rng import EpsStream
+    case = make_case(seed=47, **shape)
+    G = case["Y"].shape[1]
+    outs = []
+    for voff in ((), ("run_gate",)):
+        eng = HipEngine(**case, variant_off=voff)
+        try:
+            t1 = np.asarray(eng.run(EpsStream(5, 1, G), 9, 1e-12))                      # ends at max_iter
+            s1 = eng.get_state()
+            t2 = np.asarray(eng.run(EpsStream(6, 1, G), 60, 3e-2))                      # ends by the tolerance, as soon as the window allows
+            s2 = eng.get_state()
+            t3 = np.asarray(eng.run(EpsStream(7, 1, G), 40, 1e-12, poll=lambda i, e: i >= 4))   # ends by the hook
+            s3 = eng.get_state()
+            fin = eng.final_elbo(np.stack([eps_for(1, G, 80 + i) for i in range(4)]), 4)
+            it = eng.iterate(3, np.stack([eps_for(1, G, 90 + i) for i in range(6)]))
+            t4 = np.asarray(eng.run(EpsStream(8, 1, G), 3, 1e-12))
+            outs.append((t1, s1, t2, s2, t3, s3, fin, it, t4, eng.get_state()))
+        finally:
+            eng.close()
+    a, b = outs
+    assert len(a[0]) == 10 and 11 <= len(a[2]) < 61 and len(a[4]) == 5
+    for i in (0, 2, 4, 6, 8):
+        assert np.array_equal(a[i], b[i]), (i, a[i], b[i])
+    assert a[7] == b[7]
+    for i in (1, 3, 5, 9):
+        for n in b[i]:
+            assert np.array_equal(a[i][n], b[i][n]), (i, n)
