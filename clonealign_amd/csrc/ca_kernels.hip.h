@@ -923,6 +923,22 @@ struct ca_pre_args {
   const double* YtX; float* muA; float* muB; float* Mb; double* gene_partA; double* gene_partB; unsigned short* Mq;
   int G, D, K, mrow, C, s2;
 };
+// ca_run's gate, per lane (round 4): a block of the gated update does its loads and its arithmetic first and asks HERE, right before its first
+// store, whether the host said go.  Every lane of a wave reads the same word with the same instruction, so the lanes agree without talking.
+struct ca_gate { const unsigned long long* word; unsigned long long seq, timeout; unsigned long long* err; };   // word = null: no gate
+__device__ __forceinline__ bool ca_gate_spin(const ca_gate& gt) {
+  if (!gt.word) return true;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  for (;;) {
+    const unsigned long long w = __hip_atomic_load(gt.word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((w >> 1) == gt.seq) return (w & 1ull) != 0ull;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > gt.timeout) {
+      __hip_atomic_store(gt.err, gt.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      return false;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
 // psi's gradient and Adam step, as extra blocks of the per-gene kernel (k_final_gene): psi is all the Y stream needs, so the
 // side stream can start on the next pass's Y kernel while the main stream is still updating the q(z) logits
 struct ca_psi_args {
@@ -2887,14 +2903,16 @@ __global__ void __launch_bounds__(CA_TB) k_reduce_part(const double* __restrict_
 
 // ------------------------------------------------------------------ per-gene gradients + Adam
 // d ELBO / d loc, ls (through mu = softplus(loc + exp(ls) eps)), W, beta; minimises -ELBO.
-__device__ __forceinline__ void ca_psi_adam_body_at(const ca_psi_args& a, int64_t n, int apply, float lr_t, float b1, float b2, float aeps, float* psi0_new);
+__device__ __forceinline__ bool ca_psi_adam_body_at(const ca_psi_args& a, int64_t n, int apply, float lr_t, float b1, float b2, float aeps, float* psi0_new,
+                                                    const ca_gate* gt = nullptr);
 __device__ __forceinline__ void ca_psi_adam_body(const ca_psi_args& a, int blk, int apply, float lr_t, float b1, float b2, float aeps,
                                                  float* psi0_new = nullptr /* merged update: the cell's stepped psi_0 (0 past the last cell) */) {
   ca_psi_adam_body_at(a, (int64_t)blk * CA_TB + threadIdx.x, apply, lr_t, b1, b2, aeps, psi0_new);
 }
-__device__ __forceinline__ void ca_psi_adam_body_at(const ca_psi_args& a, int64_t n, int apply, float lr_t, float b1, float b2, float aeps, float* psi0_new) {
+__device__ __forceinline__ bool ca_psi_adam_body_at(const ca_psi_args& a, int64_t n, int apply, float lr_t, float b1, float b2, float aeps, float* psi0_new,
+                                                    const ca_gate* gt) {
   if (psi0_new) *psi0_new = 0.f;
-  if (n >= a.N) return;
+  if (n >= a.N) return true;
   for (int k = 0; k < a.K; ++k) {
     // (everything this lane reads, in one batch in front of the first use: a dependent round of loads is 1.5 us here)
     const float yw_k = a.YW[n * a.K + k], f_k = a.F[n * a.D + k], m_k = a.m_psi[n * a.K + k], v_k = a.v_psi[n * a.K + k];
@@ -2908,6 +2926,7 @@ __device__ __forceinline__ void ca_psi_adam_body_at(const ca_psi_args& a, int64_
         if (t0 + i < a.ntile) dF += (double)v[i];
     }
     const float gp = (float)((double)yw_k + dF - (double)f_k);
+    if (gt && k == 0 && !ca_gate_spin(*gt)) return false;   // (gated update: loads and arithmetic are done, nothing is stored yet)
     a.g_psi[n * a.K + k] = gp;
     if (apply) {
       float th = f_k, m = m_k, v = v_k;
@@ -2916,9 +2935,10 @@ __device__ __forceinline__ void ca_psi_adam_body_at(const ca_psi_args& a, int64_
       if (k == 0 && psi0_new) *psi0_new = th;
     }
   }
+  return true;
 }
 
-struct ca_gene_new { float loc, ls, V0; double cs; };   // a gene's stepped loc / ls / first loading (and its count total), in registers
+struct ca_gene_new { float loc, ls, V0; double cs; int stopped; };   // a gene's stepped loc / ls / first loading (and its count total), in registers
 __device__ __forceinline__ float ca_final_gene_step(int g, bool ok, const double* __restrict__ red_g, const double* __restrict__ red_y,
                                                      const float* __restrict__ eps, const double* __restrict__ colsum,
                                                      const double* __restrict__ YtX, const float* __restrict__ vchi,
@@ -2928,7 +2948,7 @@ __device__ __forceinline__ float ca_final_gene_step(int g, bool ok, const double
                                                      float* __restrict__ g_loc, float* __restrict__ g_ls, float* __restrict__ g_V,
                                                      int G, int S, int D, int K, int apply, float lr_t, float b1, float b2, float aeps,
                                                      const float* __restrict__ gfold, int nfold, ca_gene_new* nw,
-                                                     const double* __restrict__ aux = nullptr, int64_t aux_ld = 0);
+                                                     const double* __restrict__ aux = nullptr, int64_t aux_ld = 0, const ca_gate* gt = nullptr);
 __device__ __forceinline__ void ca_final_gene_range(int g, bool ok, float Vnew0, const float* __restrict__ V, float* __restrict__ Vs,
                                                      float* __restrict__ vmm_part, int G, int D, int blk, float* smin, float* smax);
 __device__ __forceinline__ void ca_final_gene_body(const double* __restrict__ red_g /*[G][S+D]*/, const double* __restrict__ red_y /*[G][K]*/,
@@ -2959,7 +2979,7 @@ __device__ __forceinline__ float ca_final_gene_step(int g, bool ok, const double
                                                      float* __restrict__ g_loc, float* __restrict__ g_ls, float* __restrict__ g_V,
                                                      int G, int S, int D, int K, int apply, float lr_t, float b1, float b2, float aeps,
                                                      const float* __restrict__ gfold, int nfold, ca_gene_new* nw,
-                                                     const double* __restrict__ aux, int64_t aux_ld) {
+                                                     const double* __restrict__ aux, int64_t aux_ld, const ca_gate* gt) {
   float Vnew0 = 0.f;   // the first loading after this step (kept in a register for the log2 image)
   if (ok) {
   // Every operand whose address does not depend on a result is loaded HERE, in one batch: this block is one wave per SIMD, and each
@@ -3026,6 +3046,7 @@ __device__ __forceinline__ float ca_final_gene_step(int g, bool ok, const double
     gs += dx * e * sd;
   }
   gs += 1.0;
+  if (gt && !ca_gate_spin(*gt)) { if (nw) nw->stopped = 1; return 0.f; }   // (gated update: everything is loaded and summed, nothing is stored yet)
   g_loc[g] = (float)gl;
   g_ls[g] = (float)gs;
   if (apply) {
@@ -3285,7 +3306,8 @@ __global__ void __launch_bounds__(CA_UM_TB) k_update_merged(const double* __rest
     // 12-15 the W image.  Every block-level sum keeps the order of the 256-thread form: butterflies inside a 64-gene wave, then the
     // four gene groups in order -- bitwise the same partials.
     if (CA_LAB_SKIP & 4) return;
-    if (!ca_gate_wait(mg, false)) return;
+    const ca_gate gt = {mg.gate ? mg.gate_local : nullptr, mg.gate_seq, mg.gate_timeout, mg.gate_err};
+    __shared__ int stop_s;
     __shared__ float h_loc[CA_TB], h_ls[CA_TB], h_v0[CA_TB];
     __shared__ double smt[4][8];
     __shared__ float smn[8][4], smx[8][4], sma[4];
@@ -3296,16 +3318,18 @@ __global__ void __launch_bounds__(CA_UM_TB) k_update_merged(const double* __rest
     float V0n = 0.f;
     CA_LAB_CP(bx, 0);
     if (role == 0) {
-      ca_gene_new nw = {0.f, 0.f, 0.f, 0.0};
+      ca_gene_new nw = {0.f, 0.f, 0.f, 0.0, 0};
       V0n = ca_final_gene_step(g, ok, red_g, red_y, eps, colsum, YtX, vchi, loc, ls, V, m_loc, v_loc, m_ls, v_ls, m_V, v_V, g_loc, g_ls, g_V,
-                               G, S, D, K, 1, lr_t, b1, b2, aeps, gfold, nfold, &nw, mg.aux_in, mg.aux_ld);
+                               G, S, D, K, 1, lr_t, b1, b2, aeps, gfold, nfold, &nw, mg.aux_in, mg.aux_ld, &gt);
       h_loc[grp * 64 + l] = nw.loc; h_ls[grp * 64 + l] = nw.ls; h_v0[grp * 64 + l] = V0n;
+      if (l == 0 && ok) stop_s = nw.stopped;   // (the four waves that hold genes write the same answer; lane 0 holds a gene whenever its wave does)
     } else if (role < 3 && ok) {   // the draws' operands that nothing here produces: in flight while the step runs
       o.eA = mg.pre.epsA[g]; o.eB = mg.pre.epsB[g]; o.cs = colsum[g];
       o.lr0 = *reinterpret_cast<const float4*>(mg.pre.Lb + (int64_t)g * CA_CW); o.lr1 = *reinterpret_cast<const float4*>(mg.pre.Lb + (int64_t)g * CA_CW + 4);
     }
     __syncthreads();
     CA_LAB_CP(bx, 1);
+    if (mg.gate && stop_s) return;   // the host said stop: this launch stores nothing
     if (role == 0) {
       // the stepped loadings in log2 units and their range over the block (ca_final_gene_range's arithmetic, wave level)
       for (int d = 0; d < D && d < 8; ++d) {
@@ -3387,7 +3411,6 @@ __global__ void __launch_bounds__(CA_UM_TB) k_update_merged(const double* __rest
     return;
   }
   b -= nmon + 1;
-  if (!ca_gate_wait(mg, false)) return;
   // psi and q(z)-logit blocks: FOUR 256-cell pieces per 1024-thread block (a quarter-filled block costs the dispatcher sixteen wave slots
   // all the same: 800 of them at cfg-3 took 15 us to get through).  Piece index = what a 256-thread block's index was.
   const int sub = (int)threadIdx.x >> 8, npsi4 = (psi.nblk + 3) / 4;
@@ -3398,8 +3421,8 @@ __global__ void __launch_bounds__(CA_UM_TB) k_update_merged(const double* __rest
     float pn = 0.f;
     if (b == 0) CA_LAB_CP(42, 0);
     if (pb < psi.nblk) {
-      ca_psi_args q = psi;
-      ca_psi_adam_body_at(q, (int64_t)pb * CA_TB + ((int)threadIdx.x & (CA_TB - 1)), 1, lr_t, b1, b2, aeps, &pn);
+      const ca_gate gt = {mg.gate ? mg.gate_local : nullptr, mg.gate_seq, mg.gate_timeout, mg.gate_err};
+      if (!ca_psi_adam_body_at(psi, (int64_t)pb * CA_TB + ((int)threadIdx.x & (CA_TB - 1)), 1, lr_t, b1, b2, aeps, &pn, &gt)) return;
     }
     if (b == 0) CA_LAB_CP(42, 1);
     if (mg.ysq.nblk) {   // the psi image: one wave per 64-step (ca_ys_quant_wave), the piece's pair of maxima from its four waves
@@ -3418,6 +3441,7 @@ __global__ void __launch_bounds__(CA_UM_TB) k_update_merged(const double* __rest
     return;
   }
   b -= npsi4;
+  if (!ca_gate_wait(mg, false)) return;
   if (CA_LAB_SKIP & 64) return;
   if (b == 0) CA_LAB_CP(43, 0);
   if (4 * b + sub < mg.ncell) ca_logit_adam_body(4 * b + sub, mg.glogit, mg.dgl, mg.m_gl, mg.v_gl, psi.N, mg.C, lr_t, b1, b2, aeps, (int)threadIdx.x & (CA_TB - 1));
