@@ -20,6 +20,7 @@ case["Y"].reshape(-1)[idx] += rng.integers(200, 900, size=idx.size)
 G = case["Y"].shape[1]
 epss = np.stack([eps_for(1, G, 300 + i) for i in range(10)])
 res = Counter()
+state_hashes = {}
 for loop in range(loops):
     for stream in ("int8", "vector"):
         for pat in (None, "1:1", "3:2", "16:8", "1:200", "255:1", -3, -64, "seq", "mixed", "fin"):
@@ -37,9 +38,12 @@ for loop in range(loops):
                 eng.close()
             key = (stream, str(pat), round(last, 3))
             res[key] += 1
+            import hashlib
+            hs = hashlib.sha1(b"".join(np.ascontiguousarray(st[n]).tobytes() for n in sorted(st))).hexdigest()[:12]
+            state_hashes.setdefault(stream, Counter())[hs] += 1
             if abs(last + 132399942.666) > 1.0:
-                print("DEVIATION loop", loop, stream, pat, last, {n: float(np.abs(v).sum()) for n, v in st.items() if n in ("loc", "ls", "W", "alpha_unconstr", "v")})
+                print("DEVIATION loop", loop, stream, pat, last, "state hash", hs, "(the stream's hashes so far:", dict(state_hashes[stream]), ")")
 vals = Counter()
 for (s, p, v), n in res.items():
     vals[v] += n
-print("results:", dict(vals), "extra variants off:", extra)
+print("results:", dict(vals), "state hashes:", {k: dict(v) for k, v in state_hashes.items()}, "extra variants off:", extra)
