@@ -245,7 +245,12 @@ int dalloc(ca_engine* h, T** p, int64_t n) {
     h->err = std::string("hipMalloc of ") + std::to_string(n * sizeof(T)) + " bytes: " + hipGetErrorString(e);
     return CA_ERR_NOMEM;
   }
+  // Zeroed, and the zeroing DONE before anybody can touch the buffer.  The engine's streams are non-blocking streams: a hipMemcpy on the NULL stream
+  // into a buffer whose hipMemsetAsync is still queued on h->stream is not ordered behind it.  Alone on the GPU the memset ran at once and the
+  // order came out right by luck; with ANOTHER PROCESS keeping the GPU busy it ran late and zeroed what had just been uploaded -- the overflow
+  // list of a 1-byte matrix, i.e. wrong fit constants for every cell with a count above 255 (round 4: profiles/r04_flake.txt).
   e = hipMemsetAsync(q, 0, (size_t)n * sizeof(T), h->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
   if (e != hipSuccess) { h->err = hipGetErrorString(e); return CA_ERR_HIP; }
   h->allocs.push_back(q);
   h->dev_bytes += n * (int64_t)sizeof(T);
@@ -1743,15 +1748,16 @@ int scan_and_convert(ca_engine* h, const ST* src_dev, int64_t sn, int64_t sg) {
     CACK(dalloc(h, &h->ovf_chunk_start, (int64_t)chunk_start.size()));
     CACK(dalloc(h, &h->ovf_col_chunk_ptr, h->G + 1));
     CACK(dalloc(h, &h->ovf_csum, (int64_t)h->n_ovf_chunk * std::max(h->K, 1)));
-    HIPCK(h, hipMemcpy(h->ovf_chunk_start, chunk_start.data(), chunk_start.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-    HIPCK(h, hipMemcpy(h->ovf_col_chunk_ptr, col_chunk_ptr.data(), col_chunk_ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCK(h, hipMemcpyAsync(h->ovf_chunk_start, chunk_start.data(), chunk_start.size() * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipMemcpyAsync(h->ovf_col_chunk_ptr, col_chunk_ptr.data(), col_chunk_ptr.size() * sizeof(int), hipMemcpyHostToDevice, h->stream));
     CACK(dalloc(h, &h->ovf_col, nz)); CACK(dalloc(h, &h->ovf_row2, nz));
     CACK(dalloc(h, &h->ovf_val, nz)); CACK(dalloc(h, &h->ovf_val2, nz));
-    HIPCK(h, hipMemcpy(h->ovf_rowptr, rowptr.data(), rowptr.size() * sizeof(int64_t), hipMemcpyHostToDevice));
-    HIPCK(h, hipMemcpy(h->ovf_col, c1.data(), nz * sizeof(int), hipMemcpyHostToDevice));
-    HIPCK(h, hipMemcpy(h->ovf_row2, r2.data(), nz * sizeof(int), hipMemcpyHostToDevice));
-    HIPCK(h, hipMemcpy(h->ovf_val, v1.data(), nz * sizeof(float), hipMemcpyHostToDevice));
-    HIPCK(h, hipMemcpy(h->ovf_val2, v2.data(), nz * sizeof(float), hipMemcpyHostToDevice));
+    HIPCK(h, hipMemcpyAsync(h->ovf_rowptr, rowptr.data(), rowptr.size() * sizeof(int64_t), hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipMemcpyAsync(h->ovf_col, c1.data(), nz * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipMemcpyAsync(h->ovf_row2, r2.data(), nz * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipMemcpyAsync(h->ovf_val, v1.data(), nz * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipMemcpyAsync(h->ovf_val2, v2.data(), nz * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    SYNC(h);   // (the sources are this function's vectors; and every copy above is ordered on the engine's stream, behind the buffers' zeroing)
     return CA_OK;
   }
   if (store == CA_YSTORE_U8) hipLaunchKernelGGL((k_convert_y<ST, uint8_t>), grid, dim3(CA_TB), 0, h->stream, src_dev, (uint8_t*)h->Y, h->N, h->G, h->Gp, sn, sg, flags);
@@ -2555,6 +2561,7 @@ int ca_p2p_export(ca_handle h, char handle[CA_P2P_HANDLE_BYTES]) {
     if (hipMalloc((void**)&pp->peers_dev, (size_t)W * sizeof(double*)) != hipSuccess) return fail("hipMalloc (p2p peer table) failed");
     if (hipMalloc((void**)&pp->err_local, sizeof(unsigned int)) != hipSuccess) return fail("hipMalloc (p2p error flag) failed");
     if (hipMemset(pp->err_local, 0, sizeof(unsigned int)) != hipSuccess) return fail("hipMemset (p2p error flag) failed");
+    if (hipDeviceSynchronize() != hipSuccess) return fail("hipDeviceSynchronize (p2p setup) failed");   // (NULL-stream memsets are not ordered against the engine's non-blocking stream)
     if (hipHostMalloc((void**)&pp->err_host, sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) return fail("hipHostMalloc (p2p error word) failed");
     *pp->err_host = 0ull;
     if (hipHostGetDevicePointer((void**)&pp->err_dev, pp->err_host, 0) != hipSuccess) return fail("hipHostGetDevicePointer (p2p error word) failed");

@@ -823,3 +823,45 @@ def test_ca_run_with_the_update_queued_ahead_of_the_decision_is_the_lock_step_lo
     for i in (1, 3, 5, 9):
         for n in b[i]:
             assert np.array_equal(a[i][n], b[i][n]), (i, n)
+
+
+def test_results_do_not_depend_on_another_process_sharing_the_gpu():
+    """Round 4 (profiles/r04_flake.txt): the engine's streams are non-blocking streams, and the overflow list of a 1-byte matrix used to be uploaded with
+    NULL-stream copies into buffers whose zeroing was still QUEUED on the engine's stream -- unordered.  Alone on the GPU the zeroing ran at once; with
+    another process keeping the GPU busy it ran late and wiped the list: wrong fit constants for every cell with a count above 255, a different (and
+    deterministic-looking) fit.  Engines built and run while a co-tenant saturates the GPU must give what they give alone, bit for bit."""
+    import subprocess
+    import sys
+    import time
+    from clonealign_amd.engine import HipEngine
+    case = make_case(seed=77, N=40_100, G=1100, C=8, K=1)
+    rng = np.random.default_rng(3)
+    idx = rng.integers(0, case["Y"].size, size=max(3, case["Y"].size // 5000))
+    case["Y"].reshape(-1)[idx] += rng.integers(200, 900, size=idx.size)
+    G = 1100
+    epss = np.stack([eps_for(1, G, 300 + i) for i in range(6)])
+
+    def fit():
+        eng = HipEngine(**case)
+        try:
+            assert eng.info()["y_storage_name"] == "u8"
+            eng.gamma_init(eps_for(1, G, 0))
+            e0 = eng.elbo(eps_for(1, G, 1))
+            last = eng.iterate(3, epss)
+            return e0, last, eng.get_state()
+        finally:
+            eng.close()
+    alone = fit()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    co = subprocess.Popen([sys.executable, os.path.join(root, "tools", "corun.py"), "40"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    try:
+        time.sleep(10.0)            # (the co-tenant imports torch and fills the GPU with matrix products)
+        assert co.poll() is None
+        for _ in range(12):
+            got = fit()
+            assert got[0] == alone[0] and got[1] == alone[1]
+            for n in alone[2]:
+                assert np.array_equal(got[2][n], alone[2][n]), n
+    finally:
+        co.kill()
+        co.wait()

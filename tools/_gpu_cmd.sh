@@ -1,2 +1,2 @@
 rocm-smi --showuniqueid 2>/dev/null | grep -i "unique id:" | head -1
-python tools/repro_flake3.py 60 2>&1 | tail -12
+python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|rror|^E  " | tail -8
