@@ -1,3 +1,4 @@
-python tools/fuzz_parity.py 300 501 2>&1 | grep -v amdgpu > gpurun_out/r4/fuzz_parity_300_501.log; grep -E "FAIL|ERROR|agree" gpurun_out/r4/fuzz_parity_300_501.log | cut -c1-400
-python tools/fuzz_sharded.py 40 2>&1 | grep -v amdgpu > gpurun_out/r4/fuzz_sharded_40b.log; tail -1 gpurun_out/r4/fuzz_sharded_40b.log
-python tools/fuzz_large.py 6 23 2>&1 | grep -v amdgpu > gpurun_out/r4/fuzz_large_6_23.log; tail -1 gpurun_out/r4/fuzz_large_6_23.log
+python tools/corun.py 420 6144 &
+sleep 8
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_scale.py tests/test_gpu_boundary.py tests/test_gpu_sharding.py -x -q -m gpu 2>&1 | grep -E "passed|failed|rror|^E  |^FAILED" | tail -10
+kill %1 2>/dev/null; wait
