@@ -1,4 +1,6 @@
-python tools/corun.py 420 6144 &
-sleep 8
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_scale.py tests/test_gpu_boundary.py tests/test_gpu_sharding.py -x -q -m gpu 2>&1 | grep -E "passed|failed|rror|^E  |^FAILED" | tail -10
-kill %1 2>/dev/null; wait
+export CLONEALIGN_DEBUG_ENV=1
+for shape in "12500 5000 8" "10000 2000 4" "25000 5000 8" "100000 5000 8"; do
+  for w in 0 -1 16 0 -1; do
+    echo -n "== $shape warm=$w  "; CA_FWD_WARM=$w python3 tools/lab_time.py $shape 2>&1 | grep -v amdgpu | tail -1
+  done
+done
