@@ -116,7 +116,11 @@ struct ca_lab_stamp {
 #define CA_LAB_STAMP(slot, kind) ca_lab_stamp ca_lab_stamp_((slot), (kind))
 // checkpoints inside a block (thread 0): slot 3072 + 8 * block + i
 #define CA_LAB_CP(blk, i) do { if (threadIdx.x == 0 && (blk) < 64) { __builtin_amdgcn_s_waitcnt(0); ca_lab_stamps2[4 * (3072 + 8 * (blk) + (i))] = __builtin_amdgcn_s_memrealtime(); ca_lab_stamps2[4 * (3072 + 8 * (blk) + (i)) + 3] = 2; } } while (0)
+// phases inside a forward sweep block (wave 0): slot = sweep block index, i = 0 entry, 1 head done, 2 k-loop done, 3 past the combine barrier
+__device__ unsigned long long ca_lab_stamps3[2048 * 4];
+#define CA_LAB_PH(blk, i) do { if (threadIdx.x == 0 && (blk) < 2048) ca_lab_stamps3[4 * (blk) + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
+#define CA_LAB_PH(blk, i) do { } while (0)
 #define CA_LAB_STAMP(slot, kind) do { } while (0)
 #define CA_LAB_CP(blk, i) do { } while (0)
 #endif
@@ -2463,6 +2467,7 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (scalar: the k-loop's bounds, branches and operand bases then are)
   float f[TL][D], em[TL];
   ca_f32x4 acc[TL];
+  CA_LAB_PH(blk, 0);
   float vmn[D], vmx[D];   // (merged update: range of V' over all genes)
   if (p.vmm_at) {
 #pragma unroll
@@ -2489,6 +2494,10 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
       if (wv == 0 && q == 0 && n < N) p.etamax_w[n] = e;   // for this block's epilogue (behind the barriers below) and the backward sweep
     }
   }
+#ifdef CA_LAB_STAMPS
+  asm volatile("" ::"v"(em[0]));
+  CA_LAB_PH(blk, 1);
+#endif
   unsigned m0, m1;   // (-1, 0) and (0, -1) as bf16 pairs, see k_fwd_mfma
   asm volatile("s_mov_b32 %0, 0x0000bf80" : "=s"(m0));
   asm volatile("s_mov_b32 %0, 0xbf800000" : "=s"(m1));
@@ -2637,9 +2646,14 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
   if (nkw & 1) step(0);
   }
   CA_PRIO_DONE();
+#ifdef CA_LAB_STAMPS
+  asm volatile("" ::"v"(acc[0][0]));
+  CA_LAB_PH(blk, 2);
+#endif
 #pragma unroll
   for (int t = 0; t < TL; ++t) comb[(wv * TL + t) * 64 + lane] = acc[t];
   __syncthreads();
+  CA_LAB_PH(blk, 3);
   // ---- cell epilogue for the block's cells; Z[cell][column] = sum over the four waves of comb[w][tile][16 q + column][r]
   //      with cell = 16 tile + 4 q + r (accumulator layout of the 16x16 MFMA)
   constexpr int CPB = CA_TB / CP;

@@ -2397,6 +2397,9 @@ int ca_abi_version(void) { return CA_ABI_VERSION; }
 int ca_lab_read_stamps(unsigned long long* out, int n_blocks) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(ca_lab_stamps), (size_t)n_blocks * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
 }
+int ca_lab_read_stamps3(unsigned long long* out, int n_blocks) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(ca_lab_stamps3), (size_t)n_blocks * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
+}
 int ca_lab_read_stamps2(unsigned long long* out, int n_blocks) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(ca_lab_stamps2), (size_t)n_blocks * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
 }

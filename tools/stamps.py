@@ -38,6 +38,20 @@ def main():
     nb = 8192
     buf = np.zeros((nb, 4), dtype=np.uint64)
     assert lib.ca_lab_read_stamps(buf.ctypes.data_as(C.c_void_p), nb) == 0
+    ph = np.zeros((2048, 4), dtype=np.uint64)
+    if hasattr(lib, "ca_lab_read_stamps3") and lib.ca_lab_read_stamps3(ph.ctypes.data_as(C.c_void_p), 2048) == 0:
+        # phases of the sweep blocks (wave 0): entry -> head done -> k-loop done -> past the combine barrier (-> block end from the block records)
+        idx_of = {int(r[2] & np.uint64(0xFFFFFFFF)): r for r in buf[buf[:, 1] > 0] if int(r[2] >> np.uint64(32)) != 0}
+        rows = []
+        for i in range(2048):
+            if ph[i, 0] > 0 and i in idx_of:
+                r = idx_of[i]
+                rows.append([(float(ph[i, 1]) - float(ph[i, 0])) / 100, (float(ph[i, 2]) - float(ph[i, 1])) / 100, (float(ph[i, 3]) - float(ph[i, 2])) / 100,
+                             (float(r[1]) - float(ph[i, 3])) / 100, (float(r[1]) - float(r[0])) / 100])
+        if rows:
+            a = np.array(rows)
+            for j, nm in enumerate(("head", "k-loop (wave 0)", "wait at the combine barrier", "cell epilogue", "whole block")):
+                print(f"  sweep block phase {nm:28s} us: min {a[:, j].min():6.2f} med {np.median(a[:, j]):6.2f} p90 {np.percentile(a[:, j], 90):6.2f} max {a[:, j].max():6.2f}")
     eng.close()
     live = buf[:, 1] > 0
     b = buf[live]
