@@ -1,3 +1,7 @@
-bash tools/lab_stamps.sh "" --cells 12500 2>&1 | grep -v amdgpu | head -12
-bash tools/lab_stamps.sh "" --cells 10000 --genes 2000 --clones 4 2>&1 | grep -v amdgpu | head -12
-bash tools/lab_stamps.sh "" --cells 100000 2>&1 | grep -v amdgpu | head -12
+R=$(pwd); cd /tmp; export TMPDIR=/tmp
+for shape in "12500 5000 8" "100000 5000 8"; do
+  rm -rf /tmp/ft; rocprofv3 --kernel-trace -d /tmp/ft -o t --output-format csv -- python3 $R/tools/fit_time.py $shape > /tmp/ft.log 2>&1
+  tail -4 /tmp/ft.log | cut -c1-200
+  f=$(find /tmp/ft -name "*kernel_trace.csv" | head -1)
+  echo "== $shape"; python3 $R/tools/timeline.py $f 3000 | head -12; python3 $R/tools/gaps.py $f | head -12
+done
