@@ -1,7 +1,6 @@
-R=$(pwd); cd /tmp; export TMPDIR=/tmp
-for shape in "12500 5000 8" "100000 5000 8"; do
-  rm -rf /tmp/ft; rocprofv3 --kernel-trace -d /tmp/ft -o t --output-format csv -- python3 $R/tools/fit_time.py $shape > /tmp/ft.log 2>&1
-  tail -4 /tmp/ft.log | cut -c1-200
-  f=$(find /tmp/ft -name "*kernel_trace.csv" | head -1)
-  echo "== $shape"; python3 $R/tools/timeline.py $f 3000 | head -12; python3 $R/tools/gaps.py $f | head -12
-done
+rocm-smi --showuniqueid 2>/dev/null | grep -i "unique" | head -1
+python3 -c "from clonealign_amd import engine as E; print('ca_build_id', E.build_id())"
+git_rev=$(cat .git_rev 2>/dev/null); echo "sources: $git_rev"
+python3 -m pytest tests -x -q -m gpu 2>&1 | tail -6
+echo "== __graft_entry__.smoke()"
+python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
