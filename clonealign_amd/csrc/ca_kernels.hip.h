@@ -2225,7 +2225,7 @@ struct ca_cell_ptrs {
   // current, read it.
   const int* vmm_at; float* etamax_w;   // vmm_at: [2][8] order-preserving ints of min / max (ca_f2ord), see k_update_merged
 };
-template <int CP>
+template <int CP, bool WR = true>   // WR = false (mc_samples = 2, four draws in one sweep): the monitor pass's pair of samples -- sums only, no coef / d logits
 __device__ __forceinline__ void ca_cell_fused_group(const ca_cell_ptrs& p, const double* la, int64_t n, int64_t N, int C, int D, int K,
                                                     double ZA, double ZB, ca_cell_acc& acc) {
   const int c = threadIdx.x % CP;
@@ -2256,7 +2256,7 @@ __device__ __forceinline__ void ca_cell_fused_group(const ca_cell_ptrs& p, const
   double llpB = Anc - sn * (log(ZB) + em);
   if (CP != 16 && p.s2) {   // (uniform) two samples of one pass: ll' = A - s mean_s log Z_s (:306-308), coef_s = -gamma s / (2 Z_s)
     llpA = llpB = 0.5 * (llpA + llpB);
-    if (ok) {
+    if (WR && ok) {
       const float c0 = (float)(-gam * sn / (2.0 * ZA)), c1 = (float)(-gam * sn / (2.0 * ZB));
       p.coef[nn * CA_CW + cc] = c0;
       p.coef[(N + nn) * CA_CW + cc] = c1;
@@ -2295,7 +2295,7 @@ __device__ __forceinline__ void ca_cell_fused_group(const ca_cell_ptrs& p, const
   const bool live = ok && gam != 0.0;   // see k_cell_par: only the entropy term is guarded against gamma == 0
   const double gfB = (live || (ok && !isfinite(llpB))) ? gam * fB : 0.0;
   const double fbarB = gsum(gfB);
-  if (ok) p.dgl[nn * C + cc] = (float)(live || !isfinite(llpB) ? gam * (fB - fbarB) : 0.0);
+  if (WR && ok) p.dgl[nn * C + cc] = (float)(live || !isfinite(llpB) ? gam * (fB - fbarB) : 0.0);
   if (ok) { acc.ee += gam * llpA; acc.pr += gam * la[cc]; acc.eeB += gam * llpB; }
   if (live) acc.q += gam * lg;
   acc.gsumc += gam;
@@ -2453,7 +2453,11 @@ __global__ void __launch_bounds__(1024) k_yfinish(const float* __restrict__ part
 // launch and one inter-kernel gap less.  Sweep alone 119 us against 108 us for k_fwd_mfma (tools/fwd_mfma_lab.hip,
 // "block-split"), paid back by the 42 us cell epilogue launch it replaces.  Vs must be padded to a multiple of 32 genes
 // (last gene replicated, see k_final_gene / k_vprep); Mq is zero there.
-template <int D, int TL, bool C16 = false>
+// S2F (round 4, mc_samples = 2): FOUR draws in one sweep -- the operand image at Mq carries the two samples of the monitor pass in its column
+// halves (as the two-sample sweep always had them), a second image behind it (the sixteen-clone kernels' second operand set: second pair of
+// B operands, second set of accumulators, six MFMAs per tile and k-step on one exp and one bf16 split) the two samples of the NEXT train
+// pass.  The epilogue runs the two-sample cell group twice: sums only for the monitor pair, coef / d logits for the train pair.
+template <int D, int TL, bool C16 = false, bool S2F = false>
 __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, const float* __restrict__ etamax2,
                                                  const float* __restrict__ Vs /*[nk * 32][D]*/,
                                                  const unsigned short* __restrict__ Mq /*[nk][2][64][8] bf16*/, const ca_cell_ptrs& p,
@@ -2462,6 +2466,8 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
                                                  double* sm, const double* la) {
   // C16 (round 3): 9..16 clones.  The sixteen operand columns then belong to ONE draw (clones 0..15) instead of two draws of up to
   // eight clones, the epilogue works with sixteen lanes per cell, and monitor and train passes each take a sweep of their own.
+  static_assert(!(C16 && S2F), "one or the other");
+  constexpr bool TWO = C16 || S2F;         // two operand sets
   constexpr int CP = C16 ? 16 : 8;         // lanes per cell in the epilogue
   const int lane = threadIdx.x & 63, j = lane & 15, q = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));   // (scalar: the k-loop's bounds, branches and operand bases then are)
@@ -2507,14 +2513,14 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
   // One k-step of operands in flight, in TWO register sets used alternately (the loop runs two k-steps per trip): the step at hand
   // reads its set in place while the next one's loads land in the other.  With one set the operands had to be copied out before the
   // refill was issued -- 12 moves per k-step on the issue port the sweep is bound by.
-  constexpr int NS = (TL <= 2 && !C16) ? 4 : 2;   // operand register sets (32- and 16-cell blocks: three k-steps in flight, see below)
+  constexpr int NS = (TL <= 2 && !TWO) ? 4 : 2;   // operand register sets (32- and 16-cell blocks: three k-steps in flight, see below)
   uint4 b1r[NS], b2r[NS];
   float4 vr[NS][NV4];
   // C16: the second draw's sixteen columns are a second pair of B operands (its image follows the first draw's) and a second set of
   // accumulators -- six MFMAs per tile and k-step on ONE exp and one bf16 split, instead of a sweep per draw
   [[maybe_unused]] uint4 b1s[2], b2s[2];
   [[maybe_unused]] ca_f32x4 accB[TL];
-  if constexpr (C16) {
+  if constexpr (TWO) {
 #pragma unroll
     for (int t = 0; t < TL; ++t) accB[t] = (ca_f32x4){0.f, 0.f, 0.f, 0.f};
   }
@@ -2522,7 +2528,7 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
     const uint4* bp = Bq + (int64_t)ks * 128;
     b1r[set] = bp[lane];
     b2r[set] = bp[64 + lane];
-    if constexpr (C16) {
+    if constexpr (TWO) {
       const uint4* bs = Bq + ((int64_t)nk + ks) * 128;
       b1s[set] = bs[lane];
       b2s[set] = bs[64 + lane];
@@ -2556,7 +2562,7 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
       a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B2, a, 0, 0, 0);
       a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1, B1, a, 0, 0, 0);
       acc[t] = a;
-      if constexpr (C16) {
+      if constexpr (TWO) {
         const ca_bf16x8 S1 = __builtin_bit_cast(ca_bf16x8, b1s[set]), S2 = __builtin_bit_cast(ca_bf16x8, b2s[set]);
         ca_f32x4 b = accB[t];
         b = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2, S1, b, 0, 0, 0);
@@ -2690,13 +2696,42 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
   if constexpr (C16) {
 #pragma unroll
     for (int t = 0; t < TL; ++t) cells(16 * t, ZAr[t]);   // (compile-time index into the registers)
+  } else if constexpr (S2F) {
+    // the monitor pair's Z (first operand set) out of the combine buffer into registers, then the train pair's accumulators take the buffer
+    constexpr int NP = (TL * 16 + CPB - 1) / CPB;
+    double Z1a[NP], Z1b[NP];
+    auto zof = [&](int g0, double& za, double& zb) {
+      const int lc = g0 + (int)threadIdx.x / CP;
+      const int lcc = lc < TL * 16 ? lc : 0;
+      const int t = lcc >> 4, row = lcc & 15, qq = row >> 2, r = row & 3;
+      const int la_ = 16 * qq + cc, lb_ = 16 * qq + C + cc;
+      auto cz = [&](int w, int col) { return (double)comb[(w * TL + t) * 64 + col][r]; };
+      za = (cz(0, la_) + cz(1, la_)) + (cz(2, la_) + cz(3, la_));
+      zb = (cz(0, lb_) + cz(1, lb_)) + (cz(2, lb_) + cz(3, lb_));
+    };
+#pragma unroll
+    for (int i = 0; i < NP; ++i) zof(i * CPB, Z1a[i], Z1b[i]);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < TL; ++t) comb[(wv * TL + t) * 64 + lane] = accB[t];
+    __syncthreads();
+    ca_cell_acc scratch = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int lc = i * CPB + (int)threadIdx.x / CP;
+      const int64_t n = lc < TL * 16 ? cell0 + lc : N;
+      ca_cell_fused_group<CP, false>(p, la, n, N, C, D, K, Z1a[i], Z1b[i], cacc);     // monitor pass: the sums of its ELBO
+      double za, zb;
+      zof(i * CPB, za, zb);
+      ca_cell_fused_group<CP, true>(p, la, n, N, C, D, K, za, zb, scratch);           // next train pass: coef for both samples, d logits
+    }
   } else {
     for (int g0 = 0; g0 < TL * 16; g0 += CPB) cells(g0, 0.0);
   }
   ca_cell_fused_finish<CP>(cacc, sm, cell_part, blk, C, p.ee_partB);
 }
 
-template <int D, int TL, bool C16 = false>
+template <int D, int TL, bool C16 = false, bool S2F = false>
 __global__ void __launch_bounds__(CA_TB) k_fwd_cell(const float* __restrict__ F, const float* __restrict__ etamax2,
                                                     const float* __restrict__ Vs, const unsigned short* __restrict__ Mq, ca_cell_ptrs p,
                                                     const float* __restrict__ alpha_u, double* __restrict__ cell_part, int64_t N,
@@ -2705,7 +2740,7 @@ __global__ void __launch_bounds__(CA_TB) k_fwd_cell(const float* __restrict__ F,
   __shared__ double sm[CA_TB];
   __shared__ double la[64];
   ca_log_softmax_alpha(alpha_u, C, la);    // wave 0; visible to all after the body's barrier
-  ca_fwd_cell_body<D, TL, C16>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)blockIdx.x * (TL * 16), blockIdx.x, comb, sm, la);
+  ca_fwd_cell_body<D, TL, C16, S2F>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)blockIdx.x * (TL * 16), blockIdx.x, comb, sm, la);
 }
 
 // Two block sizes in one launch: the first `nbig` blocks (one resident round: CUs x blocks per CU) own 16 * TLB cells each, the
@@ -2713,7 +2748,7 @@ __global__ void __launch_bounds__(CA_TB) k_fwd_cell(const float* __restrict__ F,
 // big ones free: the ragged end of the kernel -- CUs left with one wave per SIMD, or none, while the last big blocks finish --
 // shrinks from one big block's duration to one small block's.  (Small blocks everywhere would re-read the B operand from L2
 // three times as often: 64-cell blocks lose 5 % to 96-cell blocks at 100k cells.)
-template <int D, int TLB, int TLS, bool C16 = false>
+template <int D, int TLB, int TLS, bool C16 = false, bool S2F = false>
 __global__ void __launch_bounds__(CA_TB) k_fwd_cell_mix(const float* __restrict__ F, const float* __restrict__ etamax2,
                                                         const float* __restrict__ Vs, const unsigned short* __restrict__ Mq,
                                                         ca_cell_ptrs p, const float* __restrict__ alpha_u,
@@ -2723,10 +2758,10 @@ __global__ void __launch_bounds__(CA_TB) k_fwd_cell_mix(const float* __restrict_
   __shared__ double la[64];
   ca_log_softmax_alpha(alpha_u, C, la);
   if ((int)blockIdx.x < nbig)
-    ca_fwd_cell_body<D, TLB, C16>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)blockIdx.x * (TLB * 16), blockIdx.x, comb, sm, la);
+    ca_fwd_cell_body<D, TLB, C16, S2F>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)blockIdx.x * (TLB * 16), blockIdx.x, comb, sm, la);
   else
-    ca_fwd_cell_body<D, TLS, C16>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk,
-                                  (int64_t)nbig * (TLB * 16) + (int64_t)((int)blockIdx.x - nbig) * (TLS * 16), blockIdx.x, comb, sm, la);
+    ca_fwd_cell_body<D, TLS, C16, S2F>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk,
+                                       (int64_t)nbig * (TLB * 16) + (int64_t)((int)blockIdx.x - nbig) * (TLS * 16), blockIdx.x, comb, sm, la);
 }
 
 
@@ -3633,8 +3668,8 @@ struct ca_ysride_args {
 #ifndef CA_YS_RIDE_WAVES
 #define CA_YS_RIDE_WAVES 4   // waves per SIMD the merged launch's register budget is set for (lab: 3 = 168 VGPRs, three blocks per CU)
 #endif
-template <int D, int TLB, int TLS, int DEPTH, bool C16 = false>
-__global__ void __launch_bounds__(CA_TB, (DEPTH == 1 && !C16) ? CA_YS_RIDE_WAVES : 3) k_fwd_cell_mix_ys(const float* __restrict__ F, const float* __restrict__ etamax2,
+template <int D, int TLB, int TLS, int DEPTH, bool C16 = false, bool S2F = false>
+__global__ void __launch_bounds__(CA_TB, (DEPTH == 1 && !C16 && !S2F) ? CA_YS_RIDE_WAVES : 3) k_fwd_cell_mix_ys(const float* __restrict__ F, const float* __restrict__ etamax2,
                                                            const float* __restrict__ Vs, const unsigned short* __restrict__ Mq,
                                                            ca_cell_ptrs p, const float* __restrict__ alpha_u,
                                                            double* __restrict__ cell_part, int64_t N, int C, int K, int nk, int nbig,
@@ -3685,9 +3720,9 @@ __global__ void __launch_bounds__(CA_TB, (DEPTH == 1 && !C16) ? CA_YS_RIDE_WAVES
     double* la = sm + CA_TB;
     ca_log_softmax_alpha(alpha_u, C, la);
     if (nbig > 0 && idx >= nbig)
-      ca_fwd_cell_body<D, TLS, C16>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)nbig * (TLB * 16) + (int64_t)(idx - nbig) * (TLS * 16), idx, comb, sm, la);
+      ca_fwd_cell_body<D, TLS, C16, S2F>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)nbig * (TLB * 16) + (int64_t)(idx - nbig) * (TLS * 16), idx, comb, sm, la);
     else
-      ca_fwd_cell_body<D, TLB, C16>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)idx * (TLB * 16), idx, comb, sm, la);
+      ca_fwd_cell_body<D, TLB, C16, S2F>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)idx * (TLB * 16), idx, comb, sm, la);
   }
 #undef CA_YS_LEAVE
 #ifdef CA_LAB_STAMPS

@@ -175,7 +175,8 @@ struct ca_engine {
   int fc_nbig = 0;                                     // > 0: k_fwd_cell_mix, that many blocks of 16 * fc_tl cells, the rest 32-cell blocks
   bool fwd_mfma = false; int fsplit = 1, fkchunk = 1, nk32 = 1; unsigned short* Mq = nullptr;   // matrix-core forward sweep
   // matrix-core backward sweep (k_bwd_mfma): bf16 parts of coef, its own cell split
-  bool bwd_mfma = false, bwd_frac = false, c16 = false, s2 = false; unsigned short* coefq = nullptr; int64_t N16 = 0, cchunk_m = 0; int csplit_m = 1, nwt = 0;
+  bool bwd_mfma = false, bwd_frac = false, c16 = false, s2 = false, s2f = false;   // s2f: mc_samples = 2 with monitor + next train pass in one sweep (CA_VAR_S2_FUSE)
+  unsigned short* coefq = nullptr; int64_t N16 = 0, cchunk_m = 0; int csplit_m = 1, nwt = 0;
   uint64_t draw = 0;  // built-in stream position
   // count-matrix products on the int8 matrix cores (ca_ymfma.hip.h): tiled copies, fixed-point parameter images
   bool y_mfma = false;
@@ -1276,7 +1277,9 @@ int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_d
 
 // Monitor pass for eps slot A fused with the forward half of the NEXT train pass (eps slot B): one sweep,
 // one exp per (cell, gene) for both (same parameters, R/inference-tflow.R:401,403 of consecutive iterations).
-int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, double* elbo_dstB = nullptr) {
+int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, double* elbo_dstB = nullptr, int64_t trainA = -1) {
+  // trainA >= 0 (mc_samples = 2, h->s2f): slotA / slotB are the monitor pass's two samples, trainA / trainA + 1 the next train pass's -- four draws, one sweep
+  const bool s2f = trainA >= 0;
   const float* epsA = h->eps_dev + slotA * (int64_t)h->G;
   const float* epsB = h->eps_dev + slotB * (int64_t)h->G;
   if (elbo_dstB) CACK(flush_mon_tail(h));   // pair sweeps come from outside the loop: nothing may be left pending
@@ -1288,6 +1291,13 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
            hipLaunchKernelGGL(k_gene_pre_fused, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->loc, h->ls, epsA, epsB, h->colsum, h->Lb,
                               h->V, h->D, h->K, h->YtX, h->mu32, h->s2 ? h->mu32 + h->G : h->mu32B, h->Mb2, h->gene_part, h->gene_partB, h->G,
                               h->frow, h->C, h->fwd_mfma ? h->Mq : nullptr, h->s2 ? 1 : 0));
+  }
+  if (s2f) {   // the train pair's prologue: second operand image, mu of both samples where the backward sweeps read it (the monitor pair's mu is nobody's)
+    const float* epsTA = h->eps_dev + trainA * (int64_t)h->G;
+    LAUNCH(h, CA_KERNEL_OTHER,
+           hipLaunchKernelGGL(k_gene_pre_fused, dim3(h->ngblk), dim3(CA_TB), 0, h->stream, h->loc, h->ls, epsTA, epsTA + h->G, h->colsum, h->Lb,
+                              h->V, h->D, h->K, h->YtX, h->mu32, h->mu32 + h->G, h->Mb2, h->gene_partB, h->gene_partB, h->G,
+                              h->frow, h->C, h->Mq + (int64_t)h->nk32 * 1024, 1));
   }
   h->pre_valid = false;
   // the Y products of this parameter state: riding on the sweep's own launch (below), or from the side stream / in line
@@ -1320,18 +1330,19 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
     if (h->opt.ride_pattern < 0) ya.pers = std::min(-h->opt.ride_pattern, ya.nb_main);
     else if (h->opt.ride_pattern == 0 && ya.nb_main >= 2 * h->n_cu) ya.pers = h->n_cu;
     const dim3 grid(ya.pers > 0 ? (unsigned)(ya.pers + h->ncblk_f + (ya.nb_y - ya.nb_main)) : (unsigned)(h->ncblk_f + ya.nb_y));
-#define CA_FCYS(DV, TLBV, DPV, C16V)                                                                                                  \
-  LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell_mix_ys<DV, TLBV, 2, DPV, C16V>), grid, dim3(CA_TB), 0, h->stream, h->F, h->etamax2, h->Vs, \
+#define CA_FCYS(DV, TLBV, DPV, C16V, S2FV)                                                                                            \
+  LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell_mix_ys<DV, TLBV, 2, DPV, C16V, S2FV>), grid, dim3(CA_TB), 0, h->stream, h->F, h->etamax2, h->Vs, \
                                               h->Mq, cp, h->alpha_u, h->cell_part, h->N, h->C, h->K, h->nk32, h->fc_nbig, h->ncblk_f, ya))
-#define CA_FCYS_D(TLBV, DPV) do { if (h->c16) { if (h->D == 1) CA_FCYS(1, TLBV, DPV, true); else CA_FCYS(2, TLBV, DPV, true); }  \
-                                  else { if (h->D == 1) CA_FCYS(1, TLBV, DPV, false); else CA_FCYS(2, TLBV, DPV, false); } } while (0)
+#define CA_FCYS_D(TLBV, DPV) do { if (h->c16) { if (h->D == 1) CA_FCYS(1, TLBV, DPV, true, false); else CA_FCYS(2, TLBV, DPV, true, false); }  \
+                                  else if (s2f) { if (h->D == 1) CA_FCYS(1, TLBV, DPV, false, true); else CA_FCYS(2, TLBV, DPV, false, true); } \
+                                  else { if (h->D == 1) CA_FCYS(1, TLBV, DPV, false, false); else CA_FCYS(2, TLBV, DPV, false, false); } } while (0)
     // (one piece in flight per wave: 128 VGPRs = four waves per SIMD like the vector stream's launch; two pieces, 162 VGPRs and
     //  three waves, measured 2824 against 2869 it/s at cfg-3 -- profiles/r03_ab_ystream.txt)
 #ifndef CA_YS_RIDE_DEPTH
 #define CA_YS_RIDE_DEPTH 1   // (lab: pieces in flight per stream wave)
 #endif
     if (h->fc_tl == 6) CA_FCYS_D(6, CA_YS_RIDE_DEPTH);
-    else if (h->fc_tl == 1 && !h->c16) { if (h->D == 1) CA_FCYS(1, 1, CA_YS_RIDE_DEPTH, false); else CA_FCYS(2, 1, CA_YS_RIDE_DEPTH, false); }
+    else if (h->fc_tl == 1 && !h->c16) { if (h->D == 1) CA_FCYS(1, 1, CA_YS_RIDE_DEPTH, false, false); else CA_FCYS(2, 1, CA_YS_RIDE_DEPTH, false, false); }
     else CA_FCYS_D(2, CA_YS_RIDE_DEPTH);
 #undef CA_FCYS_D
 #undef CA_FCYS
@@ -1410,6 +1421,18 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
                                                   h->Vs, h->Mq, cp, h->alpha_u, h->cell_part, h->N, h->C, h->K, h->nk32)); } while (0)
       if (h->D == 1) CA_FC16(1); else CA_FC16(2);
 #undef CA_FC16
+    } else if (s2f) {   // mc_samples = 2, four draws: the same two block shapes
+#define CA_FCS2(DV) do { if (h->fc_nbig > 0) \
+      LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell_mix<DV, 6, 2, false, true>), dim3(h->ncblk_f), dim3(CA_TB), 0, h->stream, h->F, \
+                                                  h->etamax2, h->Vs, h->Mq, cp, h->alpha_u, h->cell_part, h->N, h->C, h->K, h->nk32, h->fc_nbig)); \
+    else if (h->fc_tl == 6) \
+      LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell<DV, 6, false, true>), dim3(h->ncblk_f), dim3(CA_TB), 0, h->stream, h->F, h->etamax2, \
+                                                  h->Vs, h->Mq, cp, h->alpha_u, h->cell_part, h->N, h->C, h->K, h->nk32)); \
+    else \
+      LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_cell<DV, 2, false, true>), dim3(h->ncblk_f), dim3(CA_TB), 0, h->stream, h->F, h->etamax2, \
+                                                  h->Vs, h->Mq, cp, h->alpha_u, h->cell_part, h->N, h->C, h->K, h->nk32)); } while (0)
+      if (h->D == 1) CA_FCS2(1); else CA_FCS2(2);
+#undef CA_FCS2
     } else if (h->fc_nbig > 0) {
       switch (h->fc_tl) {
         case 4: CA_FCMD(4); break;
@@ -1479,7 +1502,7 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
     return CA_OK;
   }
   h->look_valid = true;
-  h->look_slot = slotB;
+  h->look_slot = s2f ? trainA + 1 : slotB;
   h->bwd_ready = false;
   return CA_OK;
 }
@@ -1501,7 +1524,7 @@ int train_from_lookahead(ca_engine* h, int64_t slot) {
 // draining the GPU every iteration.  If the loop stops, the sweep's scratch results are simply never used.
 int train_bwd_speculative(ca_engine* h) {
   if (!h->look_valid) return CA_OK;
-  CACK(train_bwd(h, h->mu32B, true));
+  CACK(train_bwd(h, h->s2 ? h->mu32 : h->mu32B, true));
   h->bwd_ready = true;
   h->bwd_slot = h->look_slot;
   return CA_OK;
@@ -1538,7 +1561,9 @@ int wait_host_elbo(ca_engine* h, unsigned long long seq, const double* dev, doub
 // monitor pass on eps slot m; with next >= 0 (and the fused path available) also the forward half of the train
 // pass on slot `next`, which train_pass() then completes
 int monitor_pass(ca_engine* h, int64_t m, int64_t next, double* elbo_dst) {
-  if (h->fused_ok && h->s2) {   // mc_samples = 2: the pass's two samples in the two column halves -- the monitor pass takes the sweep alone
+  if (h->fused_ok && h->s2) {   // mc_samples = 2: the pass's two samples in the two column halves
+    // ... and the next train pass's two samples in a second operand set of the same sweep (round 4), or the sweep alone
+    if (h->s2f && next >= 0 && next != m) return fused_pass(h, 2 * m, 2 * m + 1, elbo_dst, nullptr, 2 * next);
     CACK(fused_pass(h, 2 * m, 2 * m + 1, elbo_dst));
     h->look_valid = false;
     return CA_OK;
@@ -1552,7 +1577,7 @@ int monitor_pass(ca_engine* h, int64_t m, int64_t next, double* elbo_dst) {
   return run_pass(h, m, CA_MODE_ELBO, 0, elbo_dst);
 }
 int train_pass(ca_engine* h, int64_t slot) {
-  if (h->look_valid && h->look_slot == slot) return train_from_lookahead(h, slot);
+  if (h->look_valid && h->look_slot == (h->s2 ? 2 * slot + 1 : slot)) return train_from_lookahead(h, slot);
   if (h->fused_ok && (h->c16 || h->s2) && (h->bwd_mfma || !is_sharded(h))) {   // its forward half: the same sweep with this pass's draw(s)
     if (h->c16) CACK(flush_mon_tail(h));   // (9..16 clones: a pending tail is a real monitor pass's)
     h->mon_tail.enabled = 0;   // (mc_samples = 2: a tail still pending belongs to a ca_iterate pass whose ELBO nobody reads; ca_run has flushed its own)
@@ -2074,7 +2099,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
           variant_on(h, CA_VAR_Y_MFMA1, "CA_Y_MFMA1") && variant_on(h, CA_VAR_Y_RIDE, "CA_Y_RIDE") && !variantx_on(h, CA_VARX_Y_MFMA2, "CA_Y_MFMA2"))
         h->fc_tl = 1;   // (only where the int8 stream will ride: the other streams' merged kernels exist for 32- and 96-cell blocks)
       if (const int t = tune_val(h, CA_TUNE_FC_TL, "CA_FC_TL")) { if (t == 1 || t == 2 || t == 4 || t == 5 || t == 6 || t == 8) h->fc_tl = t; }
-      if (h->c16 && h->fc_tl != 2) h->fc_tl = 6;   // (the sixteen-clone kernels exist for the two default block shapes)
+      if ((h->c16 || h->s2) && h->fc_tl != 2) h->fc_tl = 6;   // (the two-operand-set kernels -- sixteen clones, four draws of mc_samples = 2 -- exist for the two default block shapes)
       if (h->s2 && !h->fwd_cell) { h->s2 = false; h->fused_ok = false; }
       h->ncblk_f = cdiv(Nn, 16 * h->fc_tl);
       // two block sizes in one launch (k_fwd_cell_mix)
@@ -2107,7 +2132,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
       h->fkchunk = cdiv(h->nk32, h->fsplit);
       h->fsplit = cdiv(h->nk32, h->fkchunk);
       zsplit = h->fsplit;
-      CACK(dalloc(h, &h->Mq, (int64_t)h->nk32 * 2 * 64 * 8 * (h->c16 ? 2 : 1)));   // zero-filled: padding genes and columns stay 0 (9..16 clones: one image per draw)
+      CACK(dalloc(h, &h->Mq, (int64_t)h->nk32 * 2 * 64 * 8 * ((h->c16 || h->s2) ? 2 : 1)));   // zero-filled: padding genes and columns stay 0 (9..16 clones: one image per draw)
     } else {
       CACK(dalloc(h, &h->Mb2, (int64_t)G * h->frow));
     }
@@ -2217,6 +2242,8 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   h->ride_ys = h->y_ys && h->fused_ok && h->fwd_cell && (h->fc_tl == 6 || tl1_ok || (h->fc_tl == 2 && h->fc_nbig == 0)) &&
                variant_on(h, CA_VAR_Y_RIDE, "CA_Y_RIDE");
   h->yfin_split = h->ride_ys && h->bwd_mfma && h->tail_fuse && variant_on(h, CA_VAR_YFIN_RIDE, "CA_YFIN_RIDE");
+  // mc_samples = 2, four draws per sweep: where the sweep is the cell kernel and the stream either rides as the int8 stream or not at all
+  h->s2f = h->s2 && h->fused_ok && h->fwd_cell && (h->fc_tl == 2 || h->fc_tl == 6) && (h->ride_ys || !h->ride_ok) && variant_on(h, CA_VAR_S2_FUSE, "CA_S2_FUSE");
   h->off_g = 3 + C;
   h->off_y = h->off_g + (int64_t)G * (S + D);
   h->red_n = h->off_y + (int64_t)G * K;

@@ -93,6 +93,8 @@ enum ca_variant {
                                  pass's psi.(YW) sum ride in the sweep's and the all-reduce's launches (4 launches per iteration); off: k_yfinish + k_colsum launches */
   CA_VAR_RUN_GATE = 1 << 17,  /* ca_run: the update half of the next train pass is queued before the host has seen the ELBO its stop rule needs and waits ON THE
                                  DEVICE for the host's go / stop word (no launch latency between the decision and the update); off: queued after the decision */
+  CA_VAR_S2_FUSE = 1 << 18,   /* mc_samples = 2: the monitor pass's two samples and the next train pass's two samples in ONE forward sweep (two operand sets,
+                                 four draws on one exp per (cell, gene)); off: a sweep per pass */
   CA_VAR_P2P = 1 << 10,       /* one-shot peer-to-peer all-reduce (else ncclAllReduce) after ca_comm_init() */
   CA_VAR_FOLD_GSUM = 1 << 11, /* small problems: backward-sweep partials summed inside the per-gene kernel (else a k_colsum launch) */
   CA_VAR_Y_RIDE = 1 << 12,    /* the Y stream's blocks ride on the forward sweep's launch (else side stream / in line) */

@@ -673,6 +673,42 @@ def test_two_mc_samples_run_the_matrix_core_sweeps(shape):
         eng.close()
 
 
+@pytest.mark.parametrize("shape", [dict(N=700, G=1100, C=5, K=1, S=2), dict(N=333, G=95, C=8, K=1, S=2), dict(N=520, G=300, C=6, K=1, P=1, S=2),
+                                   dict(N=40_100, G=700, C=7, K=1, S=2), dict(N=9000, G=500, C=3, K=1, S=2, extra=True)],
+                         ids=["c5", "c8_ragged", "k1p1", "c7_40k_two_block_sizes", "allele_9k"])
+@pytest.mark.parametrize("mode", ["default", "side_stream", "two_launch_update"])
+def test_two_mc_samples_four_draws_in_one_sweep_are_the_sweep_per_pass(shape, mode):
+    """Round 4: with mc_samples = 2 the monitor pass's two samples and the NEXT train pass's two samples share one forward sweep (a second
+    operand image and a second set of accumulators, as the sixteen-clone kernels have them: four draws on one exp per (cell, gene)).  Every
+    column of the contraction is the same sequence of matrix-core products as in the sweep a pass had to itself, so the whole loop --
+    ca_iterate, ca_run with its stop rule and speculative backward sweeps, the final ELBOs, every variable -- is BIT FOR BIT the loop with
+    the variant off, whichever way the count-matrix stream travels."""
+    from clonealign_amd.engine import HipEngine
+    from clonealign_amd.rng import EpsStream
+    case = make_case(seed=71, **shape)
+    off = {"default": (), "side_stream": ("y_ride",), "two_launch_update": ("update_merge",)}[mode]
+    G = case["Y"].shape[1]
+    epss = np.stack([eps_for(2, G, 300 + i) for i in range(12)])
+    out = []
+    for fuse in (True, False):
+        eng = HipEngine(**case, variant_off=off + (() if fuse else ("s2_fuse",)))
+        try:
+            info = eng.info()
+            assert (info["fused_sweep"], info["fwd_cell"]) == (1, 1), info
+            last = eng.iterate(5, epss[:10])
+            tr = np.asarray(eng.run(EpsStream(9, 2, G), 6, 1e-12))
+            last2 = eng.iterate(1, epss[:2])
+            fe = eng.final_elbo(epss[:3], 3)
+            st = eng.get_state()
+            out.append((last, tr, last2, fe, st))
+        finally:
+            eng.close()
+    a, b = out
+    assert a[0] == b[0] and np.array_equal(a[1], b[1]) and a[2] == b[2] and np.array_equal(a[3], b[3]), (a[:4], b[:4])
+    for n in a[4]:
+        assert np.array_equal(np.asarray(a[4][n]), np.asarray(b[4][n])), n
+
+
 MERGE_SHAPES = {
     "u8_k1": dict(N=3000, G=700, C=5, K=1),                      # the default: int8 stream riding, images made in the gene / psi blocks
     "u8_k1_ragged_two_block_sizes": dict(N=40_100, G=1100, C=8, K=1),

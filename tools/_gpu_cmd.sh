@@ -1,6 +1,3 @@
-rocm-smi --showuniqueid 2>/dev/null | grep -i "unique" | head -1
-python3 -c "from clonealign_amd import engine as E; print('ca_build_id', E.build_id())"
-git_rev=$(cat .git_rev 2>/dev/null); echo "sources: $git_rev"
-python3 -m pytest tests -x -q -m gpu 2>&1 | tail -6
-echo "== __graft_entry__.smoke()"
-python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
+python3 -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "mc_samples or s2 or k2p1s2x" 2>&1 | tail -8
+python3 tools/s2_time.py 2>&1 | grep -v amdgpu | tail -3
+python3 tools/s2_time.py 12500 5000 8 2 2>&1 | grep -v amdgpu | tail -3
