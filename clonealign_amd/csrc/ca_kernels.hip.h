@@ -1599,15 +1599,22 @@ __device__ __forceinline__ void ca_split3(float x, unsigned short& p1, unsigned 
 // forward sweep's own accuracy.  Integer copy numbers keep the exact three-part form.
 // C16 (round 3): 9..16 clones with integer copy numbers.  The 32 operand slots carry two bf16 parts of coef for sixteen clones,
 // slot group q = 2 * part + chunk (what the sixteen-lane cell epilogue writes), against L of clone chunk q & 1 in both parts.
-template <int TL, int DD, bool FRAC = false, bool C16 = false>
+// S2 (round 4, mc_samples = 2): BOTH samples of a train pass in one sweep.  exp(eta) does not depend on the sample (same psi, same W): one
+// exponential per (cell, gene) serves two products -- the second sample brings its own coef operand (cq1), its own mu (mu1), its own matrix-core
+// products and its own accumulators, and everything is summed in the order the sweep-per-sample form sums it (sample 0's partial first, then
+// sample 1's added to it): bit for bit the two sweeps.  d/dF needs a second set of per-wave LDS slices (the host halves the cell slice).
+template <int TL, int DD, bool FRAC = false, bool C16 = false, bool S2 = false>
 __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __restrict__ cq /*[N16][4][8] bf16 parts of coef*/,
                                                     const float* __restrict__ F /*[N16][DD]*/, const float* __restrict__ etamax2 /*[N16]*/,
                                                     const float* __restrict__ Lb /*[G][8]*/, const float* __restrict__ mu,
                                                     const float* __restrict__ Vs, const float* __restrict__ V,
                                                     float* __restrict__ gpart /*[csplit][G][S+DD]*/, float* __restrict__ dFpart /*[gridDim.x][N][DD]*/,
                                                     int64_t N, int G, int64_t cchunk, int S, int sidx, int first_s, int first,
-                                                    ca_small_args tail, int yblocks, ca_yfin_args yfin) {
-  extern __shared__ float ca_lds[];   // [4 waves][cchunk][DD]: per-wave d/dF of the block's cell slice, summed at the end
+                                                    ca_small_args tail, int yblocks, ca_yfin_args yfin,
+                                                    const unsigned short* __restrict__ cq1 = nullptr, const float* __restrict__ mu1 = nullptr) {
+  static_assert(!(S2 && C16), "two samples: up to eight clones");
+  constexpr int NSM = S2 ? 2 : 1;     // samples per sweep
+  extern __shared__ float ca_lds[];   // [NSM][4 waves][cchunk][DD]: per-wave d/dF of the block's cell slice, summed at the end
   // Extra block ROWS behind the sweep's own (blockIdx.y >= yblocks), so that they are dispatched LAST: the sweep's grid is exactly one
   // resident round, and extra blocks anywhere earlier in the dispatch order -- even ones that return at once -- take the first slots
   // of sweep blocks that then start late and finish 30 us after the rest (cfg-3: 145 -> 177 us).  Behind the sweep they get the
@@ -1638,7 +1645,7 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
   const int gbase = wtile * TL * 16;
   const bool active = gbase < G;
   ca_bf16x8 Lf[TL];
-  ca_f32x2 vs[TL][2][DD], mv[TL][2][DD], accU[TL][2], accUF[TL][2][DD];
+  ca_f32x2 vs[TL][2][DD], mv[NSM][TL][2][DD], accU[NSM][TL][2], accUF[NSM][TL][2][DD];
 #pragma unroll
   for (int m = 0; m < TL; ++m) {
     {  // MFMA A operand: lane (row j, k-group q) holds L[gene gbase+16m+j][0..8), once per coef part (q < 3).
@@ -1664,34 +1671,45 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
     }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {  // this lane's output rows: genes gbase + 16m + 4q + {2h, 2h+1}
-      float a[DD][2], b[DD][2];
+      float a[DD][2], b[NSM][DD][2];
 #pragma unroll
       for (int x = 0; x < 2; ++x) {
         const int g = gbase + 16 * m + 4 * q + 2 * h + x;
         const bool ok = g < G;
         const int gg = ok ? g : G - 1;
-        const float muv = mu[gg];
+        float muv[NSM];
+        muv[0] = mu[gg];
+        if constexpr (S2) muv[1] = mu1[gg];
 #pragma unroll
         for (int d = 0; d < DD; ++d) {
           const float vsv = Vs[(int64_t)gg * DD + d], vv = V[(int64_t)gg * DD + d];
           a[d][x] = vsv;             // rows past G keep a real gene's loading (exponent <= 0, never inf); their t is 0
-          b[d][x] = ok ? muv * vv : 0.f;
+#pragma unroll
+          for (int sm_ = 0; sm_ < NSM; ++sm_) b[sm_][d][x] = ok ? muv[sm_] * vv : 0.f;
         }
       }
-      accU[m][h] = (ca_f32x2){0.f, 0.f};
+#pragma unroll
+      for (int sm_ = 0; sm_ < NSM; ++sm_) accU[sm_][m][h] = (ca_f32x2){0.f, 0.f};
 #pragma unroll
       for (int d = 0; d < DD; ++d) {
         vs[m][h][d] = (ca_f32x2){a[d][0], a[d][1]};
-        mv[m][h][d] = (ca_f32x2){b[d][0], b[d][1]};
-        accUF[m][h][d] = (ca_f32x2){0.f, 0.f};
+#pragma unroll
+        for (int sm_ = 0; sm_ < NSM; ++sm_) {
+          mv[sm_][m][h][d] = (ca_f32x2){b[sm_][d][0], b[sm_][d][1]};
+          accUF[sm_][m][h][d] = (ca_f32x2){0.f, 0.f};
+        }
       }
     }
   }
   const int64_t n0 = (int64_t)blockIdx.y * cchunk;
   const int64_t n1 = (n0 + cchunk < N) ? n0 + cchunk : N;
   float* myd = ca_lds + (int64_t)wv * cchunk * DD;
+  constexpr int NWV = CA_TB / 64;
   if (!active)
-    for (int64_t i = lane; i < (n1 - n0) * DD; i += 64) myd[i] = 0.f;
+    for (int64_t i = lane; i < (n1 - n0) * DD; i += 64) {
+      myd[i] = 0.f;
+      if constexpr (S2) myd[(int64_t)NWV * cchunk * DD + i] = 0.f;
+    }
   // MFMA B operand: lane (column j, k-group q) holds part q of coef[cell b0+j][0..8): 16 bytes, 1 KiB per wave.
   // The operands of the next PD batches are in flight while the current one is in the pipes (cell arrays padded to 16): a
   // batch is 380 issue cycles = 0.6 us of wall time at three waves per SIMD, one batch of look-ahead left the wave parked on
@@ -1703,18 +1721,20 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
   const int qc = (FRAC && q == 2) ? 0 : q;   // which part of coef this lane group carries (FRAC: c1, c2, c1 again)
   const int len = active ? (int)(n1 - n0) : 0;
   const unsigned short* cqb = cq + n0 * 32;
+  [[maybe_unused]] const unsigned short* cqb1 = S2 ? cq1 + n0 * 32 : nullptr;
   const float* Fb = F + n0 * DD;
   const float* eb = etamax2 + n0;
   const unsigned lo_c = (unsigned)((j * 4 + qc) * 8), lo_f = (unsigned)(j * DD), lo_e = (unsigned)j;
   const int jl = len - j;                    // cell r + j is inside the slice iff r < jl
   float* myd_lane = myd + j * DD;
-  uint4 craw_r[PD];
+  uint4 craw_r[NSM][PD];
   float fc_r[PD][DD], ec_r[PD];
   auto fetch = [&](int slot, int r) {        // r: uniform, a multiple of 16, inside the padded arrays
     const unsigned short* pc = cqb + (int64_t)r * 32;
     const float* pf = Fb + (int64_t)r * DD;
     const float* pe = eb + r;
-    craw_r[slot] = *reinterpret_cast<const uint4*>(pc + lo_c);
+    craw_r[0][slot] = *reinterpret_cast<const uint4*>(pc + lo_c);
+    if constexpr (S2) craw_r[1][slot] = *reinterpret_cast<const uint4*>(cqb1 + (int64_t)r * 32 + lo_c);
 #pragma unroll
     for (int d = 0; d < DD; ++d) fc_r[slot][d] = pf[lo_f + d];
     ec_r[slot] = pe[lo_e];
@@ -1726,23 +1746,31 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
   for (int r00 = 0; r00 < len; r00 += 16 * PD) {
   CA_PRIO_STEP(prio_i, prio_q);
   ++prio_i;
-  [[maybe_unused]] float ddv[PD][DD];
+  [[maybe_unused]] float ddv[NSM][PD][DD];
 #pragma unroll
   for (int d_ = 0; d_ < PD; ++d_) {
     const int r0 = r00 + 16 * d_;
 #pragma unroll
-    for (int d = 0; d < DD; ++d) ddv[d_][d] = 0.f;
+    for (int sm_ = 0; sm_ < NSM; ++sm_)
+#pragma unroll
+      for (int d = 0; d < DD; ++d) ddv[sm_][d_][d] = 0.f;
     if (r0 < len) {   // wave-uniform
-    const uint4 craw = craw_r[d_];
+    uint4 craw[NSM];
+#pragma unroll
+    for (int sm_ = 0; sm_ < NSM; ++sm_) craw[sm_] = craw_r[sm_][d_];
     float fc[DD];
 #pragma unroll
     for (int d = 0; d < DD; ++d) fc[d] = fc_r[d_][d];
     const float ec = ec_r[d_];
     if (r0 + 16 * PD < len) fetch(d_, r0 + 16 * PD);
-    const ca_bf16x8 Cf = __builtin_bit_cast(ca_bf16x8, craw);
-    ca_f32x2 dF[DD];
+    ca_bf16x8 Cf[NSM];
+    ca_f32x2 dF[NSM][DD];
 #pragma unroll
-    for (int d = 0; d < DD; ++d) dF[d] = (ca_f32x2){0.f, 0.f};
+    for (int sm_ = 0; sm_ < NSM; ++sm_) {
+      Cf[sm_] = __builtin_bit_cast(ca_bf16x8, craw[sm_]);
+#pragma unroll
+      for (int d = 0; d < DD; ++d) dF[sm_][d] = (ca_f32x2){0.f, 0.f};
+    }
     // The batch's matrix-core products are issued AHEAD of their consumers: in the compiler's order each sat right in front of its
     // consumer and was waited for with s_nop (22 idle issue cycles per batch, and only three waves per SIMD to fill them; cfg-3
     // 3570 -> 3665 it/s).  CA_BWD_AHEAD products in flight: all four (default), or two with the next one issued as one is consumed.
@@ -1750,47 +1778,58 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
 #define CA_BWD_AHEAD TL
 #endif
     constexpr int AH = CA_BWD_AHEAD < TL ? CA_BWD_AHEAD : TL;
-    ca_f32x4 tt[TL];
+    ca_f32x4 tt[NSM][TL];
 #pragma unroll
     for (int m = 0; m < AH; ++m) {
-      tt[m] = (ca_f32x4){0.f, 0.f, 0.f, 0.f};
-      tt[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Lf[m], Cf, tt[m], 0, 0, 0);   // tt[m][r]: gene gbase+16m+4q+r, cell n0+r0+j
+#pragma unroll
+      for (int sm_ = 0; sm_ < NSM; ++sm_) {
+        tt[sm_][m] = (ca_f32x4){0.f, 0.f, 0.f, 0.f};
+        tt[sm_][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Lf[m], Cf[sm_], tt[sm_][m], 0, 0, 0);   // tt[.][m][r]: gene gbase+16m+4q+r, cell n0+r0+j
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int m = 0; m < TL; ++m) {
       if constexpr (AH < TL) {
         if (m + AH < TL) {
-          tt[m + AH] = (ca_f32x4){0.f, 0.f, 0.f, 0.f};
-          tt[m + AH] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Lf[m + AH], Cf, tt[m + AH], 0, 0, 0);
+#pragma unroll
+          for (int sm_ = 0; sm_ < NSM; ++sm_) {
+            tt[sm_][m + AH] = (ca_f32x4){0.f, 0.f, 0.f, 0.f};
+            tt[sm_][m + AH] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Lf[m + AH], Cf[sm_], tt[sm_][m + AH], 0, 0, 0);
+          }
         }
       }
-      const ca_f32x4 t = tt[m];
-      const ca_f32x2 t2[2] = {{t[0], t[1]}, {t[2], t[3]}};
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         ca_f32x2 eta = vs[m][h][0] * fc[0] - ec;
 #pragma unroll
         for (int d = 1; d < DD; ++d) eta = vs[m][h][d] * fc[d] + eta;
         const ca_f32x2 ex = {__builtin_amdgcn_exp2f(eta.x), __builtin_amdgcn_exp2f(eta.y)};
-        const ca_f32x2 u = ex * t2[h];
-        accU[m][h] += u;
 #pragma unroll
-        for (int d = 0; d < DD; ++d) {
-          accUF[m][h][d] = u * fc[d] + accUF[m][h][d];
-          dF[d] = u * mv[m][h][d] + dF[d];
+        for (int sm_ = 0; sm_ < NSM; ++sm_) {
+          const ca_f32x4 t = tt[sm_][m];
+          const ca_f32x2 t2 = h == 0 ? (ca_f32x2){t[0], t[1]} : (ca_f32x2){t[2], t[3]};
+          const ca_f32x2 u = ex * t2;
+          accU[sm_][m][h] += u;
+#pragma unroll
+          for (int d = 0; d < DD; ++d) {
+            accUF[sm_][m][h][d] = u * fc[d] + accUF[sm_][m][h][d];
+            dF[sm_][d] = u * mv[sm_][m][h][d] + dF[sm_][d];
+          }
         }
       }
       if constexpr (AH < TL) __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
+    for (int sm_ = 0; sm_ < NSM; ++sm_)
+#pragma unroll
     for (int d = 0; d < DD; ++d) {
-      float dd = dF[d].x + dF[d].y;
+      float dd = dF[sm_][d].x + dF[sm_][d].y;
       if constexpr (PD == 2) {
-        ddv[d_][d] = dd;
+        ddv[sm_][d_][d] = dd;
       } else {
         dd = ca_sum_xor16_32(dd);   // over the four lane groups q (v_permlane16/32_swap: no LDS round trip, no lgkmcnt wait per batch)
-        if (q == 0 && r0 < jl) myd_lane[r0 * DD + d] = dd;
+        if (q == 0 && r0 < jl) myd_lane[(int64_t)sm_ * NWV * cchunk * DD + r0 * DD + d] = dd;
       }
     }
     }   // r0 < len
@@ -1802,12 +1841,14 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
     // time (ca_sum_xor16_32), half the swaps and adds, one LDS write instead of two.
     typedef unsigned v2u __attribute__((ext_vector_type(2)));
 #pragma unroll
+    for (int sm_ = 0; sm_ < NSM; ++sm_)
+#pragma unroll
     for (int d = 0; d < DD; ++d) {
-      v2u r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ddv[0][d]), __float_as_uint(ddv[1][d]), false, false);
+      v2u r = __builtin_amdgcn_permlane16_swap(__float_as_uint(ddv[sm_][0][d]), __float_as_uint(ddv[sm_][1][d]), false, false);
       const float c = __uint_as_float(r.x) + __uint_as_float(r.y);
       r = __builtin_amdgcn_permlane32_swap(__float_as_uint(c), __float_as_uint(c), false, false);
       const float tot = __uint_as_float(r.x) + __uint_as_float(r.y);
-      if (lane < 32 && r00 + lane < len) myd[(r00 + lane) * DD + d] = tot;
+      if (lane < 32 && r00 + lane < len) myd[(int64_t)sm_ * NWV * cchunk * DD + (r00 + lane) * DD + d] = tot;
     }
   }
   }
@@ -1815,7 +1856,11 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
   __syncthreads();
   const int64_t wstride = cchunk * DD;
   for (int64_t i = threadIdx.x; i < (n1 - n0) * DD; i += CA_TB) {
-    const float d = (ca_lds[i] + ca_lds[wstride + i]) + (ca_lds[2 * wstride + i] + ca_lds[3 * wstride + i]);
+    float d = (ca_lds[i] + ca_lds[wstride + i]) + (ca_lds[2 * wstride + i] + ca_lds[3 * wstride + i]);
+    if constexpr (S2) {   // (sample 0's sum, then sample 1's added to it: what the second sweep did through memory)
+      const float* l1 = ca_lds + 4 * wstride;
+      d = d + ((l1[i] + l1[wstride + i]) + (l1[2 * wstride + i] + l1[3 * wstride + i]));
+    }
     float* p = dFpart + ((int64_t)blockIdx.x * N + n0) * DD + i;
     *p = first ? d : (*p + d);
   }
@@ -1830,19 +1875,32 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
         v += ca_dpp_pull<0xB1, 0xF>(v); v += ca_dpp_pull<0x4E, 0xF>(v); v += ca_dpp_pull<0x141, 0xF>(v); v += ca_dpp_pull<0x140, 0xF>(v);
         return v;
       };
-      const float a0 = row16(accU[m][h].x), a1 = row16(accU[m][h].y);
-      float bx[DD], by[DD];
+      float a0[NSM], a1[NSM], bx[NSM][DD], by[NSM][DD];
 #pragma unroll
-      for (int d = 0; d < DD; ++d) { bx[d] = row16(accUF[m][h][d].x); by[d] = row16(accUF[m][h][d].y); }
+      for (int sm_ = 0; sm_ < NSM; ++sm_) {
+        a0[sm_] = row16(accU[sm_][m][h].x); a1[sm_] = row16(accU[sm_][m][h].y);
+#pragma unroll
+        for (int d = 0; d < DD; ++d) { bx[sm_][d] = row16(accUF[sm_][m][h][d].x); by[sm_][d] = row16(accUF[sm_][m][h][d].y); }
+      }
       if (j < 2) {
         const int g = gbase + 16 * m + 4 * q + 2 * h + j;
         if (g < G) {
           float* gp = gpart + ((int64_t)blockIdx.y * G + g) * W_;
-          const float su = j ? a1 : a0;
+          const float su = j ? a1[0] : a0[0];
           gp[sidx] = first_s ? su : gp[sidx] + su;
+          if constexpr (S2) gp[sidx + 1] = j ? a1[1] : a0[1];
 #pragma unroll
           for (int d = 0; d < DD; ++d) {
-            const float suf = mu[g] * (j ? by[d] : bx[d]);
+            // (products rounded on their own, then added: the sum over the samples is the same float whether the second sample's term comes
+            //  from this sweep or from a second one through memory -- no fused multiply-add across that boundary)
+            //  (the empty asm makes the product an opaque value: __fmul_rn is a plain multiplication to this compiler and would be contracted)
+            float suf = mu[g] * (j ? by[0][d] : bx[0][d]);
+            asm volatile("" : "+v"(suf));
+            if constexpr (S2) {
+              float suf1 = mu1[g] * (j ? by[1][d] : bx[1][d]);
+              asm volatile("" : "+v"(suf1));
+              suf = suf + suf1;
+            }
             gp[S + d] = first ? suf : gp[S + d] + suf;
           }
         }

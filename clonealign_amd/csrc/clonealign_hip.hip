@@ -983,15 +983,19 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
     const int yextra = cdiv(nextra, xb);   // extra block rows behind the sweep's
     ca_yfin_args no_yfin;
     memset(&no_yfin, 0, sizeof(no_yfin));
-#define CA_BWDM(DDV) do { if (h->c16) CA_BWDM_(DDV, false, true); else if (h->bwd_frac) CA_BWDM_(DDV, true, false); else CA_BWDM_(DDV, false, false); } while (0)
-#define CA_BWDM_(DDV, FRV, C16V)                                                                                            \
+    // mc_samples = 2 (round 4): both samples in ONE sweep (k_bwd_mfma<.., S2>: one exp per (cell, gene) for the two of them)
+    const bool s2b = h->s2f && h->S == 2 && !h->c16;
+#define CA_BWDM(DDV) do { if (h->c16) CA_BWDM_(DDV, false, true, false); else if (s2b) { if (h->bwd_frac) CA_BWDM_(DDV, true, false, true); else CA_BWDM_(DDV, false, false, true); } \
+                          else if (h->bwd_frac) CA_BWDM_(DDV, true, false, false); else CA_BWDM_(DDV, false, false, false); } while (0)
+#define CA_BWDM_(DDV, FRV, C16V, S2V)                                                                                       \
   LAUNCH(h, CA_KERNEL_BWD,                                                                                                 \
-         hipLaunchKernelGGL((k_bwd_mfma<TL, DDV, FRV, C16V>), dim3(xb, h->csplit_m + (s == 0 ? yextra : 0)), dim3(CA_TB), \
-                            (size_t)h->cchunk_m * 4 * DDV * sizeof(float), h->stream,                                       \
+         hipLaunchKernelGGL((k_bwd_mfma<TL, DDV, FRV, C16V, S2V>), dim3(xb, h->csplit_m + (s == 0 ? yextra : 0)), dim3(CA_TB), \
+                            (size_t)h->cchunk_m * 4 * DDV * sizeof(float) * (S2V ? 2 : 1), h->stream,                       \
                             h->coefq + (int64_t)s * h->N16 * 32, h->F, h->etamax2, h->Lb, mu32 + (int64_t)s * h->G, h->Vs,  \
                             h->V, h->gpart, h->dFpart, h->N, h->G, h->cchunk_m, h->S, s, 1, s == 0 ? 1 : 0,                 \
-                            s == 0 ? bwd_tail : no_small_args(), h->csplit_m, s == 0 ? yfin : no_yfin))
-    for (int s = 0; s < h->S; ++s) {
+                            s == 0 ? bwd_tail : no_small_args(), h->csplit_m, s == 0 ? yfin : no_yfin,                      \
+                            S2V ? h->coefq + h->N16 * 32 : nullptr, S2V ? mu32 + h->G : nullptr))
+    for (int s = 0; s < (s2b ? 1 : h->S); ++s) {
       if (h->D == 1) CA_BWDM(1);
       else CA_BWDM(2);
     }
@@ -2013,7 +2017,8 @@ int create_impl(ca_engine* h, const ca_problem* p) {
         h->csplit_m = pick_split(xb, (int64_t)per_cu * h->n_cu, smax, 1e-4);
       }
       if (const int t = tune_val(h, CA_TUNE_CSPLIT_M, "CA_CSPLIT_M")) h->csplit_m = std::max(1, t);
-      h->csplit_m = (int)std::max<int64_t>(h->csplit_m, (Nn * D + 4079) / 4080);   // LDS: 4 waves x cchunk x D floats <= 64 KB
+      if (S == 2) h->csplit_m *= 2;   // (mc_samples = 2: the two-sample sweep keeps a second set of d/dF slices in LDS -- half the cells per slice, with or without it)
+      h->csplit_m = (int)std::max<int64_t>(h->csplit_m, (Nn * D * (S == 2 ? 2 : 1) + 4079) / 4080);   // LDS: [samples x] 4 waves x cchunk x D floats <= 64 KB
       h->cchunk_m = ((Nn + h->csplit_m - 1) / h->csplit_m + 15) / 16 * 16;
       h->csplit_m = cdiv(Nn, h->cchunk_m);
       // fold the column sums of the sweep's partials into the per-gene kernel: a launch and its gap less.  Up to 32k cells in round 2
