@@ -2017,7 +2017,9 @@ int create_impl(ca_engine* h, const ca_problem* p) {
         h->csplit_m = pick_split(xb, (int64_t)per_cu * h->n_cu, smax, 1e-4);
       }
       if (const int t = tune_val(h, CA_TUNE_CSPLIT_M, "CA_CSPLIT_M")) h->csplit_m = std::max(1, t);
-      if (S == 2) h->csplit_m *= 2;   // (mc_samples = 2: the two-sample sweep keeps a second set of d/dF slices in LDS -- half the cells per slice, with or without it)
+      // mc_samples = 2: the two-sample sweep keeps a second set of d/dF slices in LDS; where that would leave fewer than three blocks per CU
+      // (more than 48 KB a block) the cell slices are halved -- two whole rounds where there was one -- with or without the variant
+      if (S == 2 && (int64_t)2 * 4 * (((Nn + h->csplit_m - 1) / h->csplit_m + 15) / 16 * 16) * D * 4 > 48 * 1024) h->csplit_m *= 2;
       h->csplit_m = (int)std::max<int64_t>(h->csplit_m, (Nn * D * (S == 2 ? 2 : 1) + 4079) / 4080);   // LDS: [samples x] 4 waves x cchunk x D floats <= 64 KB
       h->cchunk_m = ((Nn + h->csplit_m - 1) / h->csplit_m + 15) / 16 * 16;
       h->csplit_m = cdiv(Nn, h->cchunk_m);
