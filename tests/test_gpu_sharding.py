@@ -150,6 +150,62 @@ def test_two_shards_whole_loop_matches_single_handle(kw):
             assert np.abs(st[n] - st_ref[n][lo:hi]).max(initial=0) <= 5e-5 * max(np.abs(st_ref[n]).max(initial=0), 1e-30), n
 
 
+@pytest.mark.parametrize("kw", [dict(N=640, G=300, C=6, K=1, S=2), dict(N=9000, G=500, C=4, K=1, S=2, extra=True)])
+def test_two_shards_whole_loop_with_two_mc_samples_matches_single_handle(kw):
+    """mc_samples = 2 sharded: since round 4 the monitor pass's two samples share a forward sweep with the next train pass's two, so a pending
+    monitor tail now meets a (two-sample) backward sweep's all-reduce on this path too.  ca_run, ca_iterate and the final ELBOs on two shards
+    through the host hook against the single handle; replicas bit-identical."""
+    from clonealign_amd.engine import HipEngine
+    from clonealign_amd.rng import EpsStream
+    case = make_case(seed=13, **kw)
+    N, G = case["Y"].shape[0], case["Y"].shape[1]
+    n_iter = 5
+
+    def drive(eng):
+        assert eng.info()["fused_sweep"] == 1
+        tr = eng.run(EpsStream(81, 2, G), n_iter, 1e-12)
+        last = eng.iterate(3, np.stack([eps_for(2, G, 600 + i) for i in range(6)]))
+        fin = eng.final_elbo(EpsStream(82, 2, G), 3)
+        return np.asarray(tr), last, np.asarray(fin), eng.get_state()
+
+    ref = HipEngine(**case)
+    tr_ref, last_ref, fin_ref, st_ref = drive(ref)
+    ref.close()
+    ar = _HostAllreduce(2)
+    out, err = [None, None], []
+
+    def worker(rank):
+        try:
+            lo, hi = cell_range(N, rank, 2)
+            shard = dict(case)
+            for k in ("Y", "psi0", "X", "extra_loglik"):
+                if shard.get(k) is not None:
+                    shard[k] = shard[k][lo:hi]
+            eng = HipEngine(**shard, rank=rank, world=2, host_allreduce=ar.make(rank))
+            out[rank] = drive(eng) + ((lo, hi),)
+            eng.close()
+        except Exception as e:  # noqa: BLE001
+            err.append(e)
+            ar.bar.abort()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not err, err
+    for r in range(2):
+        tr, last, fin, st, (lo, hi) = out[r]
+        assert len(tr) == n_iter + 1
+        assert np.abs(tr - tr_ref).max() <= 2e-6 * np.abs(tr_ref).max()
+        assert abs(last - last_ref) <= 2e-6 * abs(last_ref)
+        assert np.abs(fin - fin_ref).max() <= 2e-6 * np.abs(fin_ref).max()
+        assert np.array_equal(tr, out[0][0]) and last == out[0][1]
+        for n in ("W", "v", "beta", "alpha_unconstr", "loc", "ls"):
+            assert np.abs(st[n] - st_ref[n]).max(initial=0) <= 5e-5 * max(np.abs(st_ref[n]).max(initial=0), 1e-30), n
+            assert np.array_equal(st[n], out[0][3][n])
+        for n in ("psi", "gamma_logits"):
+            assert np.abs(st[n] - st_ref[n][lo:hi]).max(initial=0) <= 5e-5 * max(np.abs(st_ref[n]).max(initial=0), 1e-30), n
+
+
 def test_rccl_communicator_of_one_rank_runs():
     """ncclCommInitRank with one rank on the visible GPU: the RCCL code path (dlopen, init, all-reduce, destroy)."""
     from clonealign_amd.engine import HipEngine, comm_unique_id

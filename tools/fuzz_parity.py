@@ -22,7 +22,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 VARIANTS = [{}, {}, {}, {}, {"CA_FWD_CELL": "0"}, {"CA_FWD_MFMA": "0"}, {"CA_BWD_MFMA": "0"}, {"CA_ASYNC_Y": "0"}, {"CA_PRE": "0"},
             {"CA_TAIL_FUSE": "0"}, {"CA_FC_TL": "4", "CA_FC_NBIG": "2"}, {"CA_PAIR_ELBO": "0"},
             {"CA_Y_MFMA1": "0"}, {"CA_Y_MFMA1": "0", "CA_RIDE_SEQ_ON": "1"}, {"CA_Y_MFMA1": "0", "CA_Y_RIDE": "0"}, {"CA_Y_RIDE": "0"},
-            {"CA_UPDATE_MERGE": "0"}, {"CA_UPDATE_MERGE": "0", "CA_Y_MFMA1": "0"}]   # round 4: the two-launch update (the default is the merged launch)   # round 3: the vector stream and its riding forms
+            {"CA_UPDATE_MERGE": "0"}, {"CA_UPDATE_MERGE": "0", "CA_Y_MFMA1": "0"}, {"CA_S2_FUSE": "0"}]   # round 4: the two-launch update (the default is the merged launch)   # round 3: the vector stream and its riding forms
 fails = 0
 for it in range(n_cases):
     N = int(rng.integers(1, 900))
