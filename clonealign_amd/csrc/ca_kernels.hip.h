@@ -2282,6 +2282,10 @@ struct ca_cell_ptrs {
   // it -- and leave it in etamax_w (= etamax2) for their own cell epilogue and for the backward sweep.  vmm_at = null: etamax2 is
   // current, read it.
   const int* vmm_at; float* etamax_w;   // vmm_at: [2][8] order-preserving ints of min / max (ca_f2ord), see k_update_merged
+  // ca_run (round 4): this sweep was queued BEHIND a gated update (k_update_merged, ca_merge_args::gate) and before the host had decided.  That launch
+  // is complete when this one starts, and the word its relay block left in device memory says how it went: anything but `gate_go` (stop, or
+  // the host never answered) and every block of this launch returns at once -- nothing read, nothing stored.  null: an ordinary launch.
+  const unsigned long long* gate; unsigned long long gate_go;
 };
 template <int CP, bool WR = true>   // WR = false (mc_samples = 2, four draws in one sweep): the monitor pass's pair of samples -- sums only, no coef / d logits
 __device__ __forceinline__ void ca_cell_fused_group(const ca_cell_ptrs& p, const double* la, int64_t n, int64_t N, int C, int D, int K,
@@ -3735,6 +3739,11 @@ __global__ void __launch_bounds__(CA_TB, (DEPTH == 1 && !C16 && !S2F) ? CA_YS_RI
   constexpr size_t FW = sizeof(ca_f32x4) * 4 * TLB * 64 + sizeof(double) * (CA_TB + 64);
   constexpr size_t SM = FW > (size_t)CA_YS_LDS_BYTES ? FW : (size_t)CA_YS_LDS_BYTES;
   __shared__ __attribute__((aligned(16))) unsigned char smem[SM];
+  if (p.gate) {   // (uniform: a kernel argument) queued ahead of the host's decision -- see ca_cell_ptrs::gate
+    // (a plain, uniform load -- one scalar read per wave: the word was written by the PREVIOUS launch of this stream, and that launch is complete;
+    //  a device-scope atomic load here went to memory from every lane of every block and cost the small shapes more than the gap it removed)
+    if (*p.gate != p.gate_go) return;
+  }
   int idx;
   bool sweep;
   if (y.pers > 0) {

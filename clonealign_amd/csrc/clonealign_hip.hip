@@ -125,6 +125,7 @@ struct ca_engine {
   bool upd_merge = false, em_stale = false;
   // ca_run: the update half of train pass i + 1 is queued before the host has seen ELBO i and gated on a word the host writes (ca_merge_args::gate)
   bool run_gate = false, gate_req = false, gate_armed = false;
+  bool fwd_gate = false;   // ca_run: the forward sweep being queued is behind a gated update and must look at that launch's answer (ca_cell_ptrs::gate)
   unsigned long long gate_seq = 0; unsigned long long* gate_local = nullptr;
   bool p2p_ride = false;   // sharded over the peer-to-peer transport: the sweep's column sums and the stream's finishing sums ride (allreduce(), train_bwd)
   double* gaux = nullptr; int64_t gaux_slot = -1;   // [2][5][G]: ca_merge_args::aux_in / aux_out, ping-pong; gaux_slot: the eps draw the current half belongs to (-1: none)
@@ -1311,6 +1312,11 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
   cp.A = h->A; cp.cn = h->cn; cp.s64 = h->s64; cp.etamax2 = h->etamax2; cp.glogit = h->glogit; cp.F = h->F;
   cp.coef = h->coef; cp.dgl = h->dgl; cp.coefq = h->bwd_mfma ? h->coefq : nullptr;
   cp.vmm_at = nullptr; cp.etamax_w = nullptr;
+  cp.gate = nullptr; cp.gate_go = 0ull;
+  if (h->fwd_gate) {
+    if (!(h->fwd_cell && ride && h->ride_ys) || !h->gate_local) { h->err = "internal: a forward sweep queued ahead of the host's decision must be the one-launch form"; return CA_ERR_STATE; }
+    cp.gate = h->gate_local; cp.gate_go = (h->gate_seq << 1) | 1ull;
+  }
   if (h->em_stale && h->fwd_cell && h->D > 0) { cp.vmm_at = h->vmm_at + 16 * (1 - h->vmm_at_idx); cp.etamax_w = h->etamax2; h->em_stale = false; }
   else CACK(ensure_etamax(h));
   cp.ee_partB = (elbo_dstB && h->fwd_cell) ? h->ee_partB : nullptr;
@@ -2839,6 +2845,34 @@ struct gate_snapshot {
     h->vchi = vchi; h->vchi_alt = vchi_alt; h->alpha_u = alpha_u; h->alpha_u_alt = alpha_u_alt;
   }
 };
+// ... and what queuing the NEXT forward sweep behind that launch changes (fused_pass in its one-launch form): taken after the update is queued, put back
+// first when the answer is "stop" (every block of the sweep then returns at its first instruction)
+struct fwd_snapshot {
+  double *gene_part, *gene_part_alt, *gene_partB, *gene_partB_alt;
+  bool pre_valid, em_stale, yfin_pending, ys_quant_ready, ycache_valid, look_valid, bwd_ready;
+  int ys_slot, ys_steps;
+  int64_t look_slot;
+  unsigned long long host_seq, host_seq_next;
+  ca_small_args mon_tail;
+  void take(const ca_engine* h) {
+    gene_part = h->gene_part; gene_part_alt = h->gene_part_alt; gene_partB = h->gene_partB; gene_partB_alt = h->gene_partB_alt;
+    pre_valid = h->pre_valid; em_stale = h->em_stale; yfin_pending = h->yfin_pending; ys_quant_ready = h->ys_quant_ready; ycache_valid = h->ycache_valid;
+    look_valid = h->look_valid; bwd_ready = h->bwd_ready; ys_slot = h->ys_slot; ys_steps = h->ys_steps; look_slot = h->look_slot;
+    host_seq = h->host_seq; host_seq_next = h->host_seq_next; mon_tail = h->mon_tail;
+  }
+  void restore(ca_engine* h) const {
+    h->gene_part = gene_part; h->gene_part_alt = gene_part_alt; h->gene_partB = gene_partB; h->gene_partB_alt = gene_partB_alt;
+    h->pre_valid = pre_valid; h->em_stale = em_stale; h->yfin_pending = yfin_pending; h->ys_quant_ready = ys_quant_ready; h->ycache_valid = ycache_valid;
+    h->look_valid = look_valid; h->bwd_ready = bwd_ready; h->ys_slot = ys_slot; h->ys_steps = ys_steps; h->look_slot = look_slot;
+    h->host_seq = host_seq; h->host_seq_next = host_seq_next; h->mon_tail = mon_tail;
+  }
+};
+// will fused_pass(slotA, slotB) be exactly ONE launch, the merged forward sweep with the int8 stream riding (k_fwd_cell_mix_ys)?  (prologue and quantised
+// images made by the merged update, exponent bound taken by the sweep itself, finisher left for the backward sweep, ELBO assembly left pending)
+inline bool fwd_is_one_launch(const ca_engine* h, int64_t slotA, int64_t slotB) {
+  return h->fused_ok && !h->s2 && h->fwd_cell && h->ride_ys && !h->ycache_valid && !h->y_defer && !h->y_pending && h->pre_valid && h->pre_A == slotA &&
+         h->pre_B == slotB && h->ys_quant_ready && h->yfin_split && h->em_stale && h->D > 0 && h->tail_fuse && !is_sharded(h) && h->gate_local;
+}
 // the host's answer to the launch queued last: go (1) or stop (0)
 inline void gate_answer(ca_engine* h, int go) {
   volatile unsigned long long* w = reinterpret_cast<volatile unsigned long long*>(h->host_pinned + 48);
@@ -2879,14 +2913,18 @@ int ca_run_ex(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_st
   // writes once it has decided (ca_merge_args::gate).  "Stop" (tolerance, poll hook, NaN) makes the queued launch a no-op and the host takes
   // back the bookkeeping of the step it had queued: the state is what the lock-step loop leaves, bit for bit (tests).
   bool queued = false;   // the update half of train pass i was queued (gated, answered "go") by the previous turn of the loop
+  bool fwd_queued = false;   // ... and the forward sweep of monitor pass i / train pass i + 1 behind it
   for (int i = 1; i <= max_iter; ++i) {
     if (!queued) {
       h->hint_A = 2 * (int64_t)i + 1; h->hint_B = i < max_iter ? 2 * (int64_t)i + 2 : -1;
       CACK(train_pass(h, 2 * (int64_t)i));                              // :401
     }
     queued = false;
-    h->host_seq_next = ++h->host_seq;
-    CACK(monitor_pass(h, 2 * (int64_t)i + 1, i < max_iter ? 2 * (int64_t)i + 2 : -1, h->elbo_dev + i));   // :403
+    if (!fwd_queued) {
+      h->host_seq_next = ++h->host_seq;
+      CACK(monitor_pass(h, 2 * (int64_t)i + 1, i < max_iter ? 2 * (int64_t)i + 2 : -1, h->elbo_dev + i));   // :403
+    }
+    fwd_queued = false;
     double nv;
     CACK(train_bwd_speculative(h));     // backward half of train pass i+1 runs while the host looks at ELBO i
     // the gated update of train pass i + 1 (needs: a next pass, its look-ahead forward and backward halves in place, the one-launch update)
@@ -2906,12 +2944,26 @@ int ca_run_ex(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_st
       }
     }
     if (!gated) CACK(flush_mon_tail(h));
-    int rc = wait_host_elbo(h, h->host_seq, h->elbo_dev + i, &nv);
+    const unsigned long long seq_i = h->host_seq;   // the flag ELBO i comes with
+    // ... and the forward sweep that follows the gated update (monitor pass i + 1 with the forward half of train pass i + 2), queued behind it before the
+    // host has seen ELBO i: the launch latency between the host's "go" and that sweep (4-5 us per iteration on small problems) is gone
+    fwd_snapshot fsnap;
+    bool fwd_ahead = false;
+    if (gated && i + 1 < max_iter && fwd_is_one_launch(h, 2 * (int64_t)(i + 1) + 1, 2 * (int64_t)(i + 1) + 2)) {
+      fsnap.take(h);
+      h->host_seq_next = ++h->host_seq;
+      h->fwd_gate = true;
+      const int rcf = monitor_pass(h, 2 * (int64_t)(i + 1) + 1, 2 * (int64_t)(i + 1) + 2, h->elbo_dev + i + 1);
+      h->fwd_gate = false;
+      if (rcf != CA_OK) { gate_answer(h, 0); fsnap.restore(h); snap.restore(h); return rcf; }
+      fwd_ahead = true;
+    }
+    int rc = wait_host_elbo(h, seq_i, h->elbo_dev + i, &nv);
     if (rc == CA_OK && *reinterpret_cast<volatile unsigned long long*>(h->host_pinned + 56) != 0ull) {
       h->err = "ca_run: a gated update gave up waiting for the host's answer (launch #" + std::to_string(*reinterpret_cast<volatile unsigned long long*>(h->host_pinned + 56)) + "); the engine's state is undefined";
       rc = CA_ERR_STATE;
     }
-    if (rc != CA_OK) { if (gated) { gate_answer(h, 0); snap.restore(h); } return rc; }
+    if (rc != CA_OK) { if (gated) { gate_answer(h, 0); if (fwd_ahead) fsnap.restore(h); snap.restore(h); } return rc; }
     const double diff = (nv - val) / std::fabs(val);
     for (int j = 0; j < 9; ++j) diffs[j] = diffs[j + 1];
     diffs[9] = diff;
@@ -2926,8 +2978,8 @@ int ca_run_ex(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_st
     else if (mean < rel_tol) stop = -1;                                 // :414-415
     if (gated) {
       gate_answer(h, stop == 0 ? 1 : 0);
-      if (stop == 0) queued = true;
-      else snap.restore(h);
+      if (stop == 0) { queued = true; fwd_queued = fwd_ahead; }
+      else { if (fwd_ahead) fsnap.restore(h); snap.restore(h); }
     }
     if (stop > 0) return stop;
     if (stop < 0) break;
