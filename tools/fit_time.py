@@ -23,7 +23,7 @@ if col is None:
     col = col.cpu().numpy()
 loc0 = safe_inverse_softplus(np.maximum(col / N, 1e-6))
 psi0 = np.random.default_rng(1).normal(size=(N, 1))
-eps = np.random.default_rng(2).normal(size=(2 + 2 * 200, 1, G)).astype(np.float32)
+eps = np.random.default_rng(2).normal(size=(2 + 2 * 400, 1, G)).astype(np.float32)
 for label, src in (("caller's eps", eps), ("built-in stream", None), ("caller's eps", eps), ("built-in stream", None)):
     eng = HipEngine(None, aux["L"], psi0, loc0, 1, 1, y_device_ptr=Yd.data_ptr(), y_device_dtype=np.int32, shape=(N, G))
     ts, tl = [], []
@@ -38,4 +38,13 @@ for label, src in (("caller's eps", eps), ("built-in stream", None), ("caller's 
         ts.append(t2 - t0); tl.append(t1 - t0)
     print(f"{N}x{G}x{C} {label:22s} ca_run {np.median(tl) * 1e3:7.2f} ms ({np.median(tl) / (len(tr) - 1) * 1e6:6.1f} us/iter, {len(tr) - 1} iterations)  "
           f"+ 20 final ELBOs {np.median(ts) * 1e3:7.2f} ms   last ELBO {tr[-1]:.6f}")
+    if src is not None:   # steady state of the loop: (400 iterations - 200 iterations) / 200, the start-up (gamma init, first passes) cancels
+        t = {}
+        for n_it in (200, 400, 200, 400):
+            eng.reinit(psi0, loc0)
+            eng.synchronize()
+            t0 = time.perf_counter()
+            eng.run(src, n_it, 0.0)
+            t[n_it] = min(t.get(n_it, 1e9), time.perf_counter() - t0)
+        print(f"{N}x{G}x{C} ca_run steady state {(t[400] - t[200]) / 200 * 1e6:6.1f} us per iteration")
     eng.close()
