@@ -125,6 +125,7 @@ struct ca_engine {
   bool upd_merge = false, em_stale = false;
   // ca_run: the update half of train pass i + 1 is queued before the host has seen ELBO i and gated on a word the host writes (ca_merge_args::gate)
   bool run_gate = false, gate_req = false, gate_armed = false;
+  bool run_fwd = false;    // ca_run: queue the forward sweep behind a gated update ahead of the host's decision (CA_VAR_RUN_FWD)
   bool fwd_gate = false;   // ca_run: the forward sweep being queued is behind a gated update and must look at that launch's answer (ca_cell_ptrs::gate)
   unsigned long long gate_seq = 0; unsigned long long* gate_local = nullptr;
   bool p2p_ride = false;   // sharded over the peer-to-peer transport: the sweep's column sums and the stream's finishing sums ride (allreduce(), train_bwd)
@@ -1924,6 +1925,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   h->upd_merge = h->tail_fuse && h->pre_ok && variant_on(h, CA_VAR_UPDATE_MERGE, "CA_UPDATE_MERGE");
   h->p2p_ride = h->tail_fuse && variant_on(h, CA_VAR_P2P_RIDE, "CA_P2P_RIDE");
   h->run_gate = h->upd_merge && variant_on(h, CA_VAR_RUN_GATE, "CA_RUN_GATE");
+  h->run_fwd = h->run_gate && variantx_on(h, CA_VARX_RUN_FWD, "CA_RUN_FWD");   // opt-in: see the header (no runtime call may block between a gated launch and its answer)
   h->pair_elbo = variant_on(h, CA_VAR_PAIR_ELBO, "CA_PAIR_ELBO");
   CACK(upload_y(h, p));
   const int G = h->G, C = h->C, K = h->K, P = h->P, S = h->S, D = h->D;
@@ -2949,7 +2951,7 @@ int ca_run_ex(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_st
     // host has seen ELBO i: the launch latency between the host's "go" and that sweep (4-5 us per iteration on small problems) is gone
     fwd_snapshot fsnap;
     bool fwd_ahead = false;
-    if (gated && i + 1 < max_iter && fwd_is_one_launch(h, 2 * (int64_t)(i + 1) + 1, 2 * (int64_t)(i + 1) + 2)) {
+    if (gated && h->run_fwd && i + 1 < max_iter && fwd_is_one_launch(h, 2 * (int64_t)(i + 1) + 1, 2 * (int64_t)(i + 1) + 2)) {
       fsnap.take(h);
       h->host_seq_next = ++h->host_seq;
       h->fwd_gate = true;

@@ -120,6 +120,11 @@ enum ca_variant_on {
                                  before or after its sweep (k_fwd_cell_seq_y), instead of separate stream blocks in the same grid */
   CA_VARX_P2P_SAME_DEVICE = 1 << 5, /* test rigs only: let ca_p2p_connect map a peer handle of the SAME process on the SAME device (refused
                                  otherwise: device-wide synchronising runtime calls of one handle would wait on the other's all-reduce) */
+  CA_VARX_RUN_FWD = 1 << 6,   /* ca_run with the gated update: the forward sweep behind it is queued before the host's decision as well (its blocks return at
+                                 their first instruction on "stop").  OPT-IN, and only for a process whose ONLY user of the GPU runtime is this engine's thread:
+                                 the sweep is queued while the gated update may already be waiting for the host, and a runtime call made in that window can block
+                                 behind another thread that holds a runtime lock while IT waits for the GPU (two engines of one process on one device did exactly
+                                 that: the update then gives up after its 10 s and ca_run returns CA_ERR_STATE).  Worth about 1 us per iteration. */
   CA_VARX_ASYNC_SMALL = 1 << 1 /* side stream also below 4e7 counts (small shards run the Y stream in line: the two cross-stream
                                  events cost more than the overlap returns there) */
 };

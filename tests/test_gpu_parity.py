@@ -836,8 +836,9 @@ def test_ca_run_with_the_update_queued_ahead_of_the_decision_is_the_lock_step_lo
     case = make_case(seed=47, **shape)
     G = case["Y"].shape[1]
     outs = []
-    for voff in ((), ("run_gate",)):
-        eng = HipEngine(**case, variant_off=voff)
+    # (third engine: the opt-in form that also queues the forward sweep behind the gated update ahead of the decision, CA_VARX_RUN_FWD)
+    for voff, von in (((), ()), (("run_gate",), ()), ((), ("run_fwd",))):
+        eng = HipEngine(**case, variant_off=voff, variant_on=von)
         try:
             t1 = np.asarray(eng.run(EpsStream(5, 1, G), 9, 1e-12))                      # ends at max_iter
             s1 = eng.get_state()
@@ -851,14 +852,15 @@ def test_ca_run_with_the_update_queued_ahead_of_the_decision_is_the_lock_step_lo
             outs.append((t1, s1, t2, s2, t3, s3, fin, it, t4, eng.get_state()))
         finally:
             eng.close()
-    a, b = outs
-    assert len(a[0]) == 10 and 11 <= len(a[2]) < 61 and len(a[4]) == 5
-    for i in (0, 2, 4, 6, 8):
-        assert np.array_equal(a[i], b[i]), (i, a[i], b[i])
-    assert a[7] == b[7]
-    for i in (1, 3, 5, 9):
-        for n in b[i]:
-            assert np.array_equal(a[i][n], b[i][n]), (i, n)
+    b = outs[1]
+    for a in (outs[0], outs[2]):
+        assert len(a[0]) == 10 and 11 <= len(a[2]) < 61 and len(a[4]) == 5
+        for i in (0, 2, 4, 6, 8):
+            assert np.array_equal(a[i], b[i]), (i, a[i], b[i])
+        assert a[7] == b[7]
+        for i in (1, 3, 5, 9):
+            for n in b[i]:
+                assert np.array_equal(a[i][n], b[i][n]), (i, n)
 
 
 def test_results_do_not_depend_on_another_process_sharing_the_gpu():

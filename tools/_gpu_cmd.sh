@@ -1,5 +1,5 @@
-for shape in "100000 5000 8" "12500 5000 8" "10000 2000 4"; do
-  python3 tools/fit_time.py $shape 2>&1 | grep -v amdgpu | grep "caller's eps\|steady" | tail -2
-  CLONEALIGN_DEBUG_ENV=1 CA_RUN_GATE=0 python3 tools/fit_time.py $shape 2>&1 | grep -v amdgpu | grep "steady" | tail -1
-  python3 tools/lab_time.py $shape 2>&1 | grep -v amdgpu | tail -1
+python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_boundary.py -x -q -m gpu -k "queued_ahead or multifit or cancelled" 2>&1 | tail -3
+for shape in "12500 5000 8" "10000 2000 4" "100000 5000 8"; do
+  python3 tools/fit_time.py $shape 2>&1 | grep -v amdgpu | grep "steady" | tail -1
+  FIT_VARIANT_ON=run_fwd python3 tools/fit_time.py $shape 2>&1 | grep -v amdgpu | grep "steady" | tail -1
 done

@@ -25,7 +25,8 @@ loc0 = safe_inverse_softplus(np.maximum(col / N, 1e-6))
 psi0 = np.random.default_rng(1).normal(size=(N, 1))
 eps = np.random.default_rng(2).normal(size=(2 + 2 * 400, 1, G)).astype(np.float32)
 for label, src in (("caller's eps", eps), ("built-in stream", None), ("caller's eps", eps), ("built-in stream", None)):
-    eng = HipEngine(None, aux["L"], psi0, loc0, 1, 1, y_device_ptr=Yd.data_ptr(), y_device_dtype=np.int32, shape=(N, G))
+    eng = HipEngine(None, aux["L"], psi0, loc0, 1, 1, y_device_ptr=Yd.data_ptr(), y_device_dtype=np.int32, shape=(N, G),
+                    variant_on=tuple(v for v in __import__("os").environ.get("FIT_VARIANT_ON", "").split(",") if v))
     ts, tl = [], []
     for rep in range(6):
         eng.reinit(psi0, loc0)
