@@ -1,5 +1,6 @@
-python3 -m pytest tests/test_gpu_parity.py tests/test_gpu_boundary.py -x -q -m gpu -k "queued_ahead or multifit or cancelled" 2>&1 | tail -3
-for shape in "12500 5000 8" "10000 2000 4" "100000 5000 8"; do
-  python3 tools/fit_time.py $shape 2>&1 | grep -v amdgpu | grep "steady" | tail -1
-  FIT_VARIANT_ON=run_fwd python3 tools/fit_time.py $shape 2>&1 | grep -v amdgpu | grep "steady" | tail -1
-done
+rocm-smi --showuniqueid 2>/dev/null | grep -i "unique id" | head -1
+python3 -c "from clonealign_amd import engine as E; print('ca_build_id', E.build_id())"
+echo "sources: $(cat .git_rev 2>/dev/null)"
+python3 -m pytest tests -x -q -m gpu -rs 2>&1 | grep -v "^RCCL version\|^HIP version\|^ROCm version\|^Hostname\|^Librccl\|amdgpu.ids" | tail -16
+echo "== __graft_entry__.smoke()"
+python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
