@@ -108,6 +108,15 @@ def test_ranks_on_one_gpu_at_shard_sizes_across_the_kernel_selection_thresholds(
     _check(res, one, "p2p", cells)
 
 
+def test_two_ranks_on_one_gpu_with_two_mc_samples(tmp_path):
+    """mc_samples = 2 across two processes over the peer-to-peer transport: the four-draw forward sweep, the two-sample backward sweep whose
+    column sums (three columns per gene: one per sample, one for W) are folded inside the all-reduce's launch, the pending monitor tail
+    travelling with the train pass's sums -- against the one-handle fit."""
+    shape = ["--cells", "9000", "--genes", "500", "--clones", "6", "--iters", "5", "--mc-samples", "2"]
+    one = _run(1, "none", tmp_path / "one.json", True, shape)["ranks"][0]
+    _check(_run(2, "p2p", tmp_path / "p2p.json", True, shape), one, "p2p", 9000)
+
+
 @pytest.mark.parametrize("world", [2, 3])
 def test_work_riding_in_the_all_reduce_launch_equals_the_separate_launches(tmp_path, world):
     """Round 4, sharded over the peer-to-peer transport: the backward sweep's column sums, the int8 stream's finishing sums and a pending

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--genes", type=int, default=700)
     ap.add_argument("--clones", type=int, default=5)
     ap.add_argument("--iters", type=int, default=6)
+    ap.add_argument("--mc-samples", type=int, default=1)
     ap.add_argument("--seed", type=int, default=5)
     ap.add_argument("--same-device", action="store_true")
     ap.add_argument("--out", required=True)
@@ -43,7 +44,8 @@ def main():
     from tests._cases import eps_for, make_case
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
-    case = make_case(seed=args.seed, N=args.cells, G=args.genes, C=args.clones, K=1)
+    S = args.mc_samples
+    case = make_case(seed=args.seed, N=args.cells, G=args.genes, C=args.clones, K=1, S=S)
     lo, hi = sharding.cell_range(args.cells, rank, world)
     kw = {}
     if world > 1:
@@ -65,10 +67,10 @@ def main():
                 dist.all_reduce(t)
                 buf[:] = t.numpy()
             kw["host_allreduce"] = gloo_sum
-    eng = HipEngine(case["Y"][lo:hi], case["L"], case["psi0"][lo:hi], case["loc0"], 1, 1, device=local, rank=rank, world=world,
+    eng = HipEngine(case["Y"][lo:hi], case["L"], case["psi0"][lo:hi], case["loc0"], 1, S, device=local, rank=rank, world=world,
                     comm_timeout_ms=args.comm_timeout_ms, variant_off=tuple(v for v in args.variant_off.split(",") if v), **kw)
     selftest_bad = eng.comm_selftest(5) if world > 1 else 0     # known-answer all-reduces on the transport in use, before the fit
-    eps = np.stack([eps_for(1, args.genes, 300 + i) for i in range(2 + 2 * args.iters + 4)])
+    eps = np.stack([eps_for(S, args.genes, 300 + i) for i in range(2 + 2 * args.iters + 4)])
     trace = eng.run(eps, args.iters, 1e-12)
     finals = eng.final_elbo(eps[2 + 2 * args.iters:], 4)
     info = eng.info()
@@ -97,7 +99,7 @@ def main():
     else:
         box = [mine]
     if rank == 0:
-        json.dump(dict(world=world, ranks=box, plan=sharding.reduce_plan(args.genes, args.clones, 1, 0, 1)), open(args.out, "w"))
+        json.dump(dict(world=world, ranks=box, plan=sharding.reduce_plan(args.genes, args.clones, 1, 0, S)), open(args.out, "w"))
 
 
 if __name__ == "__main__":
