@@ -76,7 +76,7 @@ for it in range(n_cases):
             print("trace engine", tr.tolist(), "oracle", to.tolist(), "rel", float(np.abs(tr - to).max() / np.abs(to).max()))
         if why:
             fails += 1
-            print("FAIL", kw, env, "iters", n_iter, "trace diff", float(np.abs(tr - to).max() / np.abs(to).max()), "|", "; ".join(why))
+            print("FAIL case", it, kw, env, "iters", n_iter, "trace diff", float(np.abs(tr - to).max() / np.abs(to).max()), "|", "; ".join(why))
     except Exception as exc:   # noqa: BLE001
         fails += 1
         print("ERROR", kw, env, repr(exc))
