@@ -173,6 +173,131 @@ def cpu_ref_dataflow(budget_s=10.0):
                     f"per iteration, {it} iterations in {dt:.1f} s"}
 
 
+def side_config(name, N, G, C, K=1, S=1, P=0, steps=200, regions=3, seed=20251, device=0, what=""):
+    """One more shape on the driver's clock, OUTSIDE the headline regions: a fresh synthetic problem of that shape (generated on the
+    GPU), a fresh engine, gamma init, 20 warm-up iterations, then `regions` regions of one ca_iterate(steps) call between
+    synchronisations; the median region is reported against the shape's own roof (the larger of the canonical
+    HBM time and the fp32 time of the iteration's algorithmic work)."""
+    import torch
+    import synth_data as synth
+    from clonealign_amd.engine import HipEngine
+    from clonealign_amd.hostprep import safe_inverse_softplus
+    dev = f"cuda:{device}"
+    Yd, aux = synth.make_problem_torch(N, G, C, seed=seed, device=dev)
+    rm = Yd.sum(1, keepdim=True).to(torch.float64) / G
+    col = torch.zeros(G, dtype=torch.float64, device=dev)
+    for b0 in range(0, N, 8192):
+        col += (Yd[b0:b0 + 8192].to(torch.float64) / rm[b0:b0 + 8192]).sum(0)
+    loc0 = safe_inverse_softplus(np.maximum(col.cpu().numpy() / N, 1e-6))
+    rng = np.random.default_rng(seed + 1)
+    psi0 = rng.normal(size=(N, K))
+    X = rng.normal(size=(N, P)) if P > 0 else None
+    torch.cuda.synchronize()
+    eng = HipEngine(None, aux["L"], psi0, loc0, K, S, X=X, y_device_ptr=Yd.data_ptr(), y_device_dtype=np.int32, shape=(N, G), device=device, profile=0)
+    try:
+        info = eng.info()
+        eng.gamma_init(rng.normal(size=(S, G)).astype(np.float32))
+        eps = rng.normal(size=(2 * steps, S, G)).astype(np.float32)
+        eng.iterate(min(steps, 20), eps[:2 * min(steps, 20)])
+        eng.synchronize()
+        ts = []
+        for _ in range(regions):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            last = eng.iterate(steps, eps)
+            eng.synchronize()
+            ts.append(time.perf_counter() - t0)
+        dt = float(np.median(ts)) / steps
+    finally:
+        eng.close()
+        del Yd
+        torch.cuda.empty_cache()
+    D = K + P if K > 0 else 0
+    flops = S * N * G * (8.0 * C + 12.0 * D + 3.0)
+    bytes_c = N * G * 4.0 + N * (8.0 * C + 6.0 * K + 2.0) * 4.0
+    t_roof = max(flops / (PEAK_F32_TFLOPS * 1e12), bytes_c / (PEAK_HBM_GBS * 1e9))
+    return {"workload": f"synthetic {N} cells x {G} genes x {C} clones, K={K}, P={P}, S={S}" + (f" ({what})" if what else ""),
+            "it_per_s": 1.0 / dt, "us_per_iter": dt * 1e6, "steps": steps, "regions": regions,
+            "roof_us": t_roof * 1e6, "frac_of_roof": t_roof / dt, "roof_is": "fp32" if flops / (PEAK_F32_TFLOPS * 1e12) >= bytes_c / (PEAK_HBM_GBS * 1e9) else "hbm",
+            "fwd_mfma": bool(info["fwd_mfma"]), "bwd_mfma": bool(info["bwd_mfma"]), "fused_sweep": bool(info["fused_sweep"]),
+            "fwd_block_cells": int(info["fwd_block_cells"]), "update_merge": bool(info["update_merge"]), "final_elbo_finite": bool(np.isfinite(last))}
+
+
+def sq_fractions(build_id, kernel_class):
+    """VALU-active and MFMA-busy fractions of a kernel class from the SQ counter pass committed under profiles/ for THIS build
+    (profiles/*_sq_counters.json); None when there is none.  The fp32 roof is soft for kernels whose contraction runs as bf16 MFMAs
+    (the backward sweep sits above it): these two say what actually binds."""
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        c = d.get("classes", {}).get(kernel_class)
+        if d.get("build_id") == build_id and c and "valu_active_frac" in c:
+            return {"valu_active_frac": c.get("valu_active_frac"), "mfma_busy_frac": c.get("mfma_busy_frac"), "file": os.path.basename(f)}
+    return None
+
+
+def visible_devices():
+    """HIP devices this environment shows, counted in a CHILD process (the launcher itself must never touch the GPU runtime:
+    its children are fresh processes, and nothing that initialised a GPU may be replaced or forked from)."""
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=900)
+    try:
+        return int(r.stdout.strip().splitlines()[-1])
+    except (ValueError, IndexError):
+        raise SystemExit(f"bench.py: cannot count the visible GPUs (rc {r.returncode}): {r.stderr.strip()[-300:]}")
+
+
+def self_launch(n_gpus, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset): THIS process becomes the launcher -- the
+    reference's only "many fits" entry is one call (run_clonealign(), R/clonealign.R:50-56), not a launcher recipe.  It imports
+    neither torch nor the engine; it starts N fresh rank processes of this same script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+    set, rendezvous on 127.0.0.1), lets rank 0's JSON line through on the inherited stdout, takes the others down when one fails,
+    and exits with the worst rank's code.  Never a silent 1-GPU run: fewer visible devices than ranks is an error unless the
+    plumbing-test override CLONEALIGN_BENCH_DEVICE puts every rank on one device."""
+    import socket
+    import subprocess
+    if "CLONEALIGN_BENCH_DEVICE" not in os.environ:
+        have = visible_devices()
+        if have < n_gpus:
+            print(f"bench.py: --gpus {n_gpus} but {have} GPU(s) visible; refusing to report a {n_gpus}-GPU number from fewer devices "
+                  "(CLONEALIGN_BENCH_DEVICE=<ordinal> puts every rank on one device for plumbing tests)", file=sys.stderr, flush=True)
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), LOCAL_WORLD_SIZE=str(n_gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", CLONEALIGN_BENCH_SELF_LAUNCHED="1")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n_gpus)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+    worst, t_fail = 0, None
+    while any(p.poll() is None for p in procs):
+        for p in procs:
+            rc = p.poll()
+            if rc is not None and rc != 0 and t_fail is None:
+                worst, t_fail = rc, time.time()
+        # a rank that failed leaves its peers in a barrier or in a device-side wait (bounded: comm_timeout_ms); give them that
+        # long to say why and go, then end exactly the processes started here
+        if t_fail is not None and time.time() - t_fail > 20.0:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            time.sleep(3.0)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.05)
+    for r, p in enumerate(procs):
+        if p.returncode != 0:
+            print(f"bench.py launcher: rank {r} exited with code {p.returncode}", file=sys.stderr, flush=True)
+            if worst == 0:
+                worst = p.returncode
+    return worst if worst >= 0 else 128 - worst   # (a signal's negative code as the shell would report it)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,15 +331,28 @@ def main():
     ap.add_argument("--variant-off", default="", help="comma-separated engine variants to switch off (engine.VARIANTS), for A/B runs")
     ap.add_argument("--variant-on", default="", help="comma-separated opt-in engine variants (engine.VARIANTS_ON), for A/B runs")
     ap.add_argument("--tune", default="", help="comma-separated name=value decomposition overrides (engine.TUNE), for A/B runs")
+    ap.add_argument("--steady-steps", type=int, default=-1,
+                    help="length of the extra one-region steady-state measurement after the headline regions; -1 = 200 unless --steps is 200 "
+                         "or a profiler is attached (its launches would mix into the per-launch statistics), 0 = none")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the 200-step regions of the other single-GPU BASELINE configurations (cfg-2, one cfg-5 restart, the 12.5k-cell shard) "
+                         "and of the VALU fallback shapes that follow the headline measurement (single GPU only)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if "CLONEALIGN_BENCH_DEVICE" in os.environ:   # plumbing test on a 1-GPU box: every rank on the same device
         local_rank = int(os.environ["CLONEALIGN_BENCH_DEVICE"])
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # no launcher around this process: be the launcher (before torch or the engine are imported -- nothing here has touched a GPU)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        # never a silent run at another width than the one asked for: `--gpus 8` under a 1-process launcher is an error, not a 1-GPU number
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch {args.gpus} ranks, or run `python bench.py --gpus {args.gpus}` "
+                         "bare and let it start them")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     # (CPU baseline placement: its float32 matrix is first touched inside the baseline's own OpenMP loop, static schedule, the same
     #  partition every pass uses -- oracle/c/clonealign_simd.c.  Pinning the team through OMP_PROC_BIND here was tried and removed:
@@ -409,13 +547,17 @@ def main():
     # the same call at the reference's default max_iter = 200 (one region): a ca_iterate call of k steps makes k + 1 forward sweeps
     # (first and last carry one draw), so a 20-step region pays 21/20 of the steady-state sweep cost -- this shows the difference
     steady = None
-    if args.steps != 200:
-        eps_s = rng.normal(size=(400, 1, G)).astype(np.float32)
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCPROF") for k in os.environ)
+    steady_steps = args.steady_steps if args.steady_steps >= 0 else (0 if (args.steps == 200 or profiled) else 200)
+    if steady_steps > 0:
+        # (under a profiler this region's 2 x steady_steps iterations -- steady_steps + 1 sweeps per call, another call shape -- would mix into the
+        #  per-launch statistics of the --steps regions: off by default there)
+        eps_s = rng.normal(size=(2 * steady_steps, 1, G)).astype(np.float32)
         eng.set_profile(0)
-        eng.iterate(200, eps_s)
+        eng.iterate(steady_steps, eps_s)
         barrier()
         t0 = time.perf_counter()
-        eng.iterate(200, eps_s)
+        eng.iterate(steady_steps, eps_s)
         eng.synchronize()
         torch.cuda.synchronize()
         if world > 1:
@@ -425,8 +567,8 @@ def main():
             t = torch.tensor([ds], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             ds = float(t[0])
-        steady = {"steps": 200, "value": 200 / ds, "ms_per_step": ds / 200 * 1e3,
-                  "what": "one ca_iterate(200) region, same barriers; not the headline (the headline is the --steps region above)"}
+        steady = {"steps": steady_steps, "value": steady_steps / ds, "ms_per_step": ds / steady_steps * 1e3,
+                  "what": f"one ca_iterate({steady_steps}) region, same barriers; not the headline (the headline is the --steps region above)"}
     # a monitor pass on its own (plain forward + its (3 + C)-double all-reduce + read-back): the latency floor of one collective
     mon_us = None
     if world > 1:
@@ -479,6 +621,29 @@ def main():
     finals = eng.final_elbo(None, 20)
     eng.synchronize()
     fit_s = time.perf_counter() - t1
+    # every other single-GPU BASELINE configuration on the same clock, after the headline and outside its regions: cfg-2, one
+    # restart of cfg-5, the shards of cfg-4 at 8 and 4 GPUs as one-device problems; and the argument space that still runs the plain VALU
+    # passes (mc_samples > 2, more than 16 clones, D = K + P >= 3), so that their cost is a number.  Skipped under a profiler (their
+    # launches would mix into the per-kernel statistics of the headline shape).
+    other, fallbacks = None, None
+    if world == 1 and rank == 0 and not args.no_other_configs and not profiled:
+        other, fallbacks = {}, {}
+        for nm, kw in (("cfg2", dict(N=10_000, G=2_000, C=4, what="BASELINE.json configs[1]")),
+                       ("cfg5_one_restart", dict(N=50_000, G=3_000, C=6, what="one restart of BASELINE.json configs[4]")),
+                       ("shard_12500", dict(N=12_500, G=5_000, C=8, what="one rank's shard of configs[3] at 8 GPUs, no collective")),
+                       ("shard_25000", dict(N=25_000, G=5_000, C=8, what="one rank's shard of configs[3] at 4 GPUs, no collective")),
+                       ("shard_50000", dict(N=50_000, G=5_000, C=8, what="one rank's shard of configs[3] at 2 GPUs, no collective"))):
+            try:
+                other[nm] = side_config(nm, device=local_rank, **kw)
+            except Exception as ex:  # noqa: BLE001
+                other[nm] = {"error": str(ex)[:200]}
+        for nm, kw in (("S3", dict(N=N, G=G, C=C, S=3, what="mc_samples = 3: plain passes")),
+                       ("C20", dict(N=N, G=G, C=20, what="20 clones: VALU sweeps")),
+                       ("K2P1", dict(N=N, G=G, C=C, K=2, P=1, what="D = K + P = 3: VALU sweeps"))):
+            try:
+                fallbacks[nm] = side_config(nm, device=local_rank, steps=40, regions=2, **kw)
+            except Exception as ex:  # noqa: BLE001
+                fallbacks[nm] = {"error": str(ex)[:200]}
     # keep the device demonstrably busy for a few seconds after the measurements (untimed): the timed regions of a 20-step run are
     # 35 ms inside a minute of CPU baseline, which a once-per-few-seconds utilisation sampler around the run never lands on
     busy_s, busy_it = 0.0, 0
@@ -547,6 +712,8 @@ def main():
             "roofline": {"bound": bound, "kernel": dominant, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
                          "launch_ms": per_launch_s * 1e3, "launches": int(launches),
+                         **({k: v for k, v in (sq_fractions(build, dominant) or {}).items() if k != "file"} if same_workload else {}),
+                         "sq_source": (sq_fractions(build, dominant) or {}).get("file") if same_workload else None,
                          "event_stride": 1 if args.no_live_events else EVENT_STRIDE,
                          "note": ("algorithmic fp32 flops of the fused two-eps sweep against the fp32 peak; the contraction "
                                   "itself runs as bf16 hi/lo MFMAs (fp32-accurate), the kernel is bound by VALU issue "
@@ -581,6 +748,9 @@ def main():
                           "what": "untimed iterations between the --warmup steps and the timed regions (clock ramp; see --preheat-ms)"}
         if steady is not None:
             out["steady_state_200"] = steady
+        if other is not None:
+            out["other_configs"] = other
+            out["fallbacks"] = fallbacks
         if busy_it:
             out["untimed_busy_tail"] = {"seconds": busy_s, "iterations": busy_it, "it_per_s": busy_it / busy_s,
                                         "what": "untimed ca_iterate calls after the measurements (see --busy-seconds); not part of value"}

@@ -181,6 +181,46 @@ def _bench(world, extra, same_device=True, shape=("--cells", "20000", "--genes",
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420, cwd=ROOT)   # (a run takes 15-60 s)
 
 
+def _bench_bare(world, extra=(), same_device=True, shape=("--cells", "20000", "--genes", "1000", "--clones", "4"), timeout=600):
+    """`python bench.py --gpus N ...` with NO launcher around it and no WORLD_SIZE in the environment -- the shape of the driver's 1-GPU
+    command: bench.py must start its N ranks itself."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CLONEALIGN_BENCH_DEVICE")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    if same_device:
+        env["CLONEALIGN_BENCH_DEVICE"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2", "--repeats", "2", *shape,
+           "--no-cpu-baseline", "--busy-seconds", "0", "--steady-steps", "0", *extra]
+    return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_bare_bench_command_starts_its_own_ranks(world):
+    """`python bench.py --gpus N` without torch.distributed.run around it used to run ONE rank and print n_gpus 1.  Now the
+    process becomes the launcher (before anything touches a GPU): N fresh ranks, rank 0's line relayed, the worst rank's exit code."""
+    r = _bench_bare(world, ["--preheat-ms", "30"], shape=("--cells", "24000", "--genes", "600", "--clones", "8") if world == 8 else ("--cells", "20000", "--genes", "1000", "--clones", "4"))
+    assert r.returncode == 0, child_report(r)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                      # exactly ONE JSON line: rank 0's
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == world and line["config"]["collective"] == "p2p" and line["scaling"] == "strong"
+    assert line["config"]["allreduce_selftest"] == {"p2p": True} and line["value"] > 0
+    assert line["config"]["parallelism"] == f"cells/{world}"
+
+
+def test_bare_bench_command_refuses_more_ranks_than_devices_and_relays_a_failing_rank():
+    """Never a silent run at another width: more ranks than visible devices (and no plumbing override) exits non-zero before any rank starts;
+    a wrapper that sets WORLD_SIZE to something else than --gpus is refused too; and when a rank fails the launcher exits non-zero."""
+    if _gpus() < 8:
+        r = _bench_bare(8, same_device=False)
+        assert r.returncode != 0 and "GPU(s) visible" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")], child_report(r)
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2"], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr, child_report(r)
+    r = _bench_bare(2, ["--collective", "p2p", "--selftest-fail", "p2p"])
+    assert r.returncode != 0 and "refusing to report" in r.stderr and "launcher: rank" in r.stderr, child_report(r)
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
 def test_bench_two_ranks_use_a_device_transport_and_fail_loudly_without_one():
     """bench.py --gpus 2 (both ranks on device 0 here): the all-reduce runs on the device (peer-to-peer), the JSON line says so;
     asking for RCCL -- which refuses two ranks on one device -- must exit non-zero instead of quietly measuring a host path,
@@ -236,9 +276,10 @@ def test_bench_on_eight_gpus_uses_a_device_collective_and_replicas_agree(tmp_pat
     """The driver's scaling run, as a test for the day a node is available: bench.py --gpus 8 --steps 20 at the full BASELINE
     size must come up on a DEVICE transport (peer-to-peer over xGMI, else RCCL), report the collective's own cost, and the
     8-rank fit of tools/dist_check.py must leave bit-identical replicas that match the one-handle fit."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=8", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"]
+    # the BARE command (no launcher, no WORLD_SIZE): bench.py starts its eight ranks itself, one per device
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CLONEALIGN_BENCH_DEVICE")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "20", "--warmup", "5"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1800, cwd=ROOT)
     assert r.returncode == 0, child_report(r)
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])

@@ -141,3 +141,37 @@ def test_bench_preheat_call_count_is_agreed_over_two_ranks(tmp_path):
     a, b = (np.load(tmp_path / f"pre{i}.npz") for i in range(2))
     assert np.array_equal(a["counts"], b["counts"]) and int(a["made"]) == int(b["made"]) == int(a["counts"].sum())
     assert (a["counts"] >= 2).all()
+
+
+def _bare_bench(args, **env_extra):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "CLONEALIGN_BENCH_DEVICE")}
+    env.update(env_extra)
+    return subprocess.run([sys.executable, os.path.join(root, "bench.py"), *args], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+
+
+def test_bare_bench_with_more_ranks_than_devices_is_refused_not_run_on_one():
+    """`python bench.py --gpus 8` with no launcher around it ran ONE rank and printed n_gpus 1.  It must start its
+    ranks itself or fail: here (no GPU) it refuses before any rank starts, and a WORLD_SIZE that contradicts --gpus is refused too."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("a multi-GPU box: the GPU suite runs the bare command for real")
+    r = _bare_bench(["--gpus", "2", "--steps", "2"])
+    assert r.returncode == 2 and "GPU(s) visible" in r.stderr and "{" not in r.stdout, (r.returncode, r.stderr[-500:])
+    r = _bare_bench(["--gpus", "4", "--steps", "2"], WORLD_SIZE="1", RANK="0")
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr and "{" not in r.stdout, (r.returncode, r.stderr[-500:])
+    r = _bare_bench(["--gpus", "1", "--steps", "2"], WORLD_SIZE="2", RANK="0")
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr, (r.returncode, r.stderr[-500:])
+
+
+def test_bare_bench_launcher_starts_fresh_ranks_and_exits_with_the_worst_code():
+    """The launcher half of bench.py on a box without GPUs: with the plumbing override it starts its two ranks (fresh processes, RANK /
+    WORLD_SIZE / MASTER_* set), each of which refuses to run without an MI355X -- the launcher reports both and exits non-zero."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box WITHOUT a GPU (the ranks must fail)")
+    r = _bare_bench(["--gpus", "2", "--steps", "2"], CLONEALIGN_BENCH_DEVICE="0")
+    assert r.returncode != 0 and "{" not in r.stdout
+    assert r.stderr.count("needs an MI355X") == 2 and "launcher: rank 0 exited" in r.stderr and "launcher: rank 1 exited" in r.stderr, r.stderr[-800:]

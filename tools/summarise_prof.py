@@ -35,9 +35,27 @@ def per_kernel(path):
 sq = per_kernel(glob.glob(os.path.join(src, "pmc_sq", "*counter_collection.csv"))[0])
 keep = {k: {c: sum(v) / len(v) for c, v in cs.items()} | {"launches": len(next(iter(cs.values())))}
         for k, cs in sq.items() if k.startswith("k_")}
+# average launch duration per kernel from the --stats pass of the same command (ns), for the busy fractions below
+dur_ns = {}
+for r in csv.DictReader(open(os.path.join(out, f"{tag}_kernel_stats.csv"))):
+    dur_ns[r["Name"].split("(")[0].replace("void ", "")] = float(r["AverageNs"])
+PREFIX = {"fwd": ("k_fwd_cell", "k_fwd_mfma", "k_fwd_lds"), "bwd": ("k_bwd_mfma", "k_bwd"), "ypass": ("k_ypass", "k_yw_mfma", "k_yt_mfma")}
+CLOCK_GHZ, N_SIMD = 2.4, 1024   # nominal shader clock (MI355X_MICROARCH.md); the chip runs nearer 2.0-2.1 GHz under these kernels, so the fractions are lower bounds
+sq_classes = {}
+for cls, pre in PREFIX.items():
+    cand = [(v.get("launches", 0), k) for k, v in keep.items() if k.startswith(pre) and k in dur_ns]
+    if not cand:
+        continue
+    k = max(cand)[1]
+    cyc = dur_ns[k] * CLOCK_GHZ * N_SIMD
+    sq_classes[cls] = {"kernel": k, "avg_us": dur_ns[k] / 1e3,
+                       # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs; SQ_VALU_MFMA_BUSY_CYCLES cycles summed over the SIMDs
+                       "valu_active_frac": 4.0 * keep[k].get("SQ_ACTIVE_INST_VALU", 0.0) / cyc,
+                       "mfma_busy_frac": keep[k].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / cyc}
 json.dump({"_doc": f"SQ counters per launch (mean over the sampled launches), one rocprofv3 --pmc pass of `bench.py --steps 6 --warmup 2 "
-                   f"--no-cpu-baseline`, MI355X, 100k x 5k x 8, build {tag}. Quad-cycle units summed over waves (MI355X_MICROARCH.md).",
-           "kernels": keep}, open(os.path.join(out, f"{tag}_sq_counters.json"), "w"), indent=1)
+                   f"--no-cpu-baseline`, MI355X, 100k x 5k x 8, build {tag}. Quad-cycle units summed over waves (MI355X_MICROARCH.md).  classes: "
+                   f"fractions of {N_SIMD} SIMDs x launch duration x {CLOCK_GHZ} GHz.",
+           "build_id": build_id, "classes": sq_classes, "kernels": keep}, open(os.path.join(out, f"{tag}_sq_counters.json"), "w"), indent=1)
 
 hbm = {}
 for which, sub, scale in (("fetch", "pmc_fetch", 2.0), ("write", "pmc_write", 1.0)):
@@ -49,7 +67,6 @@ for which, sub, scale in (("fetch", "pmc_fetch", 2.0), ("write", "pmc_write", 1.
 for k, d in hbm.items():
     d["hbm_bytes"] = d.get("fetch_bytes", 0.0) + d.get("write_bytes", 0.0)
 # per kernel class of bench.py's roofline objects: the kernel of that class with the most launches in the profiled run
-PREFIX = {"fwd": ("k_fwd_cell", "k_fwd_mfma", "k_fwd_lds"), "bwd": ("k_bwd_mfma", "k_bwd"), "ypass": ("k_ypass", "k_yw_mfma", "k_yt_mfma")}
 classes = {}
 for cls, pre in PREFIX.items():
     cand = [(keep.get(k, {}).get("launches", 0), k) for k in hbm if k.startswith(pre)]
