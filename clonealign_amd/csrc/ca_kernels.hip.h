@@ -101,28 +101,20 @@ __device__ __forceinline__ unsigned short ca_bf16_rn(float f) {
 __device__ __forceinline__ double ca_softplus_d(double x) { return x > 0 ? x + log1p(exp(-x)) : log1p(exp(x)); }
 __device__ __forceinline__ double ca_sigmoid_d(double x) { return 1.0 / (1.0 + exp(-x)); }
 
-#ifdef CA_LAB_STAMPS   // timing lab only (tools/stamps_small.py): {start, end, kind, 1} of every block of the two small kernels of the last iteration
-__device__ unsigned long long ca_lab_stamps2[4096 * 4];
-struct ca_lab_stamp {
-  unsigned long long t0; int slot, kind;
-  __device__ ca_lab_stamp(int slot_, int kind_) : t0(__builtin_amdgcn_s_memrealtime()), slot(slot_), kind(kind_) {}
-  __device__ ~ca_lab_stamp() {
-    if (threadIdx.x == 0 && slot < 4096) {
-      unsigned long long* st = ca_lab_stamps2 + 4 * (size_t)slot;
-      st[0] = t0; st[1] = __builtin_amdgcn_s_memrealtime(); st[2] = (unsigned long long)kind; st[3] = 1;
-    }
-  }
-};
-#define CA_LAB_STAMP(slot, kind) ca_lab_stamp ca_lab_stamp_((slot), (kind))
-// checkpoints inside a block (thread 0): slot 3072 + 8 * block + i
-#define CA_LAB_CP(blk, i) do { if (threadIdx.x == 0 && (blk) < 64) { __builtin_amdgcn_s_waitcnt(0); ca_lab_stamps2[4 * (3072 + 8 * (blk) + (i))] = __builtin_amdgcn_s_memrealtime(); ca_lab_stamps2[4 * (3072 + 8 * (blk) + (i)) + 3] = 2; } } while (0)
-// phases inside a forward sweep block (wave 0): slot = sweep block index, i = 0 entry, 1 head done, 2 k-loop done, 3 past the combine barrier
-__device__ unsigned long long ca_lab_stamps3[2048 * 4];
-#define CA_LAB_PH(blk, i) do { if (threadIdx.x == 0 && (blk) < 2048) ca_lab_stamps3[4 * (blk) + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+// Timing-lab hooks (block stamps: tools/stamps.py, tools/stamps_small.py).  The product build compiles them to nothing; their bodies live in
+// tools/lab/ca_lab_hooks.inc and come in only with -DCA_LAB (`make -C clonealign_amd/csrc lab`), a build whose ca_build_id() starts with "lab-"
+// and which bench.py therefore refuses.  No hook changes a result.
+#ifdef CA_LAB
+#include "../../tools/lab/ca_lab_hooks.inc"
 #else
-#define CA_LAB_PH(blk, i) do { } while (0)
 #define CA_LAB_STAMP(slot, kind) do { } while (0)
 #define CA_LAB_CP(blk, i) do { } while (0)
+#define CA_LAB_PH(blk, i) do { } while (0)
+#define CA_LAB_PH_AFTER(value, blk, i) do { } while (0)
+#define CA_LAB_BLOCK_T0() do { } while (0)
+#define CA_LAB_BLOCK_END(kind, idx) do { } while (0)
+#define CA_LAB_LEAVE(label) return
+#define CA_LAB_LABEL(label) do { } while (0)
 #endif
 
 // ------------------------------------------------------------------ count-matrix element decode
@@ -498,11 +490,7 @@ __device__ __forceinline__ void ca_ypass_body(int blk, const YT* __restrict__ Y,
       const int64_t r = r0 + (i < nrows ? i : (nrows > 0 ? nrows - 1 : 0));
       psv[k][hh] = F[r * Dstride + koff + k];
     }
-#if defined(CA_LAB_YL2)   // timing lab only (wrong results): every strip reads the first 512 rows -- the stream's loads hit L2 / MALL
-  const char* base = reinterpret_cast<const char*>(Y) + (r0 & 511) * (int64_t)Gp * (int64_t)sizeof(YT);
-#else
   const char* base = reinterpret_cast<const char*>(Y) + r0 * (int64_t)Gp * (int64_t)sizeof(YT);   // scalar
-#endif
   const int voff = col0 * (int)sizeof(YT);                                                          // per lane
   const int64_t pitch = (int64_t)Gp * (int64_t)sizeof(YT);
 #ifndef CA_YP_U
@@ -542,19 +530,12 @@ __device__ __forceinline__ void ca_ypass_body(int blk, const YT* __restrict__ Y,
           const float ps = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, i < 64 ? psv[k][0] : psv[k][1]), i & 63));
           float p0 = 0.f, p1 = 0.f;
 #pragma unroll
-#if defined(CA_LAB_YSKIP) && CA_LAB_YSKIP >= 2   // timing lab only (wrong results): no product at all, the loaded dwords are kept alive
-          for (int j = 0; j < VEC; j += 4) p0 += y[j];
-          acc[0][k] += ps;
-#else
           for (int j = 0; j < VEC; j += 2) {
             p0 = fmaf(y[j], w[j][k], p0);
             p1 = fmaf(y[j + 1], w[j + 1][k], p1);
-#if !defined(CA_LAB_YSKIP)                       // (CA_LAB_YSKIP = 1: no column product)
             acc[j][k] = fmaf(y[j], ps, acc[j][k]);
             acc[j + 1][k] = fmaf(y[j + 1], ps, acc[j + 1][k]);
-#endif
           }
-#endif
           const int tot = __builtin_amdgcn_readlane(__builtin_bit_cast(int, ca_wave_sum_lane63(p0 + p1)), 63);
           {   // keep[k] lane (i & 63) <- tot  (v_writelane_b32: value and lane select are both scalars, the select goes through m0)
             const int slot = i & 63;
@@ -928,7 +909,11 @@ struct ca_pre_args {
   int G, D, K, mrow, C, s2;
 };
 // ca_run's gate, per lane (round 4): a block of the gated update does its loads and its arithmetic first and asks HERE, right before its first
-// store, whether the host said go.  Every lane of a wave reads the same word with the same instruction, so the lanes agree without talking.
+// store, whether the launch goes on.  Every lane of a wave reads the same word with the same instruction, so the lanes agree without talking.
+// Round 5: the word is the RELAY block's verdict in device memory (ca_gate_wait) -- go, or "store nothing" (the host said stop, or the host did
+// not answer within the relay's short deadline) -- and ONLY the relay decides: a waiter's own deadline (`timeout`, the relay's plus ten
+// seconds) can run out only if the relay block never ran, which the block order rules out (it is dispatched first); it then reports a
+// fatal error (`err`), the one case the host cannot recover from.
 struct ca_gate { const unsigned long long* word; unsigned long long seq, timeout; unsigned long long* err; };   // word = null: no gate
 __device__ __forceinline__ bool ca_gate_spin(const ca_gate& gt) {
   if (!gt.word) return true;
@@ -1627,9 +1612,6 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
     // took 30 us to get through -- holding the slots of sweep blocks that then started that much later (cfg-3: sweep 145 -> 175 us)
     __builtin_amdgcn_s_setprio(3);
     const int ncolblk = (yfin.ncol + CA_TB / 64 - 1) / (CA_TB / 64);
-#ifdef CA_LAB_YFIN   // (timing lab: 1 = column jobs only, 2 = row jobs only, 3 = the extra blocks do nothing)
-    if (CA_LAB_YFIN == 3 || (CA_LAB_YFIN == 1 && e - 1 >= ncolblk) || (CA_LAB_YFIN == 2 && e - 1 < ncolblk)) return;
-#endif
     if (e - 1 < ncolblk) {
       const int job = (e - 1) * (CA_TB / 64) + (int)(threadIdx.x >> 6);
       if (job < yfin.ncol) ca_yfin_col_wave(yfin, job);
@@ -2562,10 +2544,7 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
       if (wv == 0 && q == 0 && n < N) p.etamax_w[n] = e;   // for this block's epilogue (behind the barriers below) and the backward sweep
     }
   }
-#ifdef CA_LAB_STAMPS
-  asm volatile("" ::"v"(em[0]));
-  CA_LAB_PH(blk, 1);
-#endif
+  CA_LAB_PH_AFTER(em[0], blk, 1);
   unsigned m0, m1;   // (-1, 0) and (0, -1) as bf16 pairs, see k_fwd_mfma
   asm volatile("s_mov_b32 %0, 0x0000bf80" : "=s"(m0));
   asm volatile("s_mov_b32 %0, 0xbf800000" : "=s"(m1));
@@ -2714,10 +2693,7 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
   if (nkw & 1) step(0);
   }
   CA_PRIO_DONE();
-#ifdef CA_LAB_STAMPS
-  asm volatile("" ::"v"(acc[0][0]));
-  CA_LAB_PH(blk, 2);
-#endif
+  CA_LAB_PH_AFTER(acc[0][0], blk, 2);
 #pragma unroll
   for (int t = 0; t < TL; ++t) comb[(wv * TL + t) * 64 + lane] = acc[t];
   __syncthreads();
@@ -2857,9 +2833,6 @@ __device__ __forceinline__ bool ca_ride_split(int b, int nf, int ny, int pa, int
 #ifndef CA_RIDE_WAVES
 #define CA_RIDE_WAVES 1   // (lab: minimum waves per SIMD the merged launch's register budget is set for)
 #endif
-#ifdef CA_LAB_STAMPS   // timing lab only: every block of the merged launch leaves {start, end, kind << 32 | index, HW_ID | XCC_ID << 32}
-__device__ unsigned long long ca_lab_stamps[8192 * 4];
-#endif
 template <int D, int TLB, int TLS>
 __global__ void __launch_bounds__(CA_TB, CA_RIDE_WAVES) k_fwd_cell_mix_y(const float* __restrict__ F, const float* __restrict__ etamax2,
                                                           const float* __restrict__ Vs, const unsigned short* __restrict__ Mq,
@@ -2870,9 +2843,7 @@ __global__ void __launch_bounds__(CA_TB, CA_RIDE_WAVES) k_fwd_cell_mix_y(const f
   constexpr size_t YW_ = sizeof(float) * (CA_TB / 64) * 64 * 17;
   __shared__ __attribute__((aligned(16))) unsigned char smem[FW > YW_ ? FW : YW_];
   int idx;
-#ifdef CA_LAB_STAMPS
-  const unsigned long long st0_ = __builtin_amdgcn_s_memrealtime();
-#endif
+  CA_LAB_BLOCK_T0();
   bool sweep;
   if (y.pers > 0) {
     // Long-lived stream blocks first: y.pers of them (two per CU) take the leading slots and walk through ALL units of the count
@@ -2886,11 +2857,7 @@ __global__ void __launch_bounds__(CA_TB, CA_RIDE_WAVES) k_fwd_cell_mix_y(const f
     sweep = ca_ride_split((int)blockIdx.x, nf, y.nb_y, y.pat_a, y.pat_b, idx);
   }
   if (!sweep) {
-#ifdef CA_LAB_YPRIO
-    __builtin_amdgcn_s_setprio(CA_LAB_YPRIO);
-#else
     CA_PRIO_STREAM();
-#endif
     if (y.pers > 0 && idx < y.pers) {
       for (int u = idx; u < y.nb_main; u += y.pers)
         ca_ypass_body<uint8_t, 1, 0>(u, y.Y, y.F, y.Dstride, y.V, 0, y.YWpart, y.YTpart, N, y.G, y.Gp, y.nseg, y.nrb, y.TR, 1, y.ovf, y.nb_main,
@@ -2908,15 +2875,7 @@ __global__ void __launch_bounds__(CA_TB, CA_RIDE_WAVES) k_fwd_cell_mix_y(const f
     else
       ca_fwd_cell_body<D, TLB>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)idx * (TLB * 16), idx, comb, sm, la);
   }
-#ifdef CA_LAB_STAMPS
-  __syncthreads();
-  if (threadIdx.x == 0 && blockIdx.x < 8192) {
-    unsigned long long* st = ca_lab_stamps + 4 * (size_t)blockIdx.x;
-    st[0] = st0_; st[1] = __builtin_amdgcn_s_memrealtime();
-    st[2] = ((unsigned long long)(sweep ? (nbig > 0 && idx >= nbig ? 2 : 1) : 0) << 32) | (unsigned)idx;
-    st[3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
-  }
-#endif
+  CA_LAB_BLOCK_END(sweep ? (nbig > 0 && idx >= nbig ? 2 : 1) : 0, idx);
 }
 
 // The Y stream FUSED IN SEQUENCE with the sweep (round 3): every sweep block also streams one unit of the count matrix (one gene
@@ -2938,9 +2897,7 @@ __global__ void __launch_bounds__(CA_TB, CA_RIDE_WAVES) k_fwd_cell_seq_y(const f
   constexpr size_t YW_ = sizeof(float) * (CA_TB / 64) * 64 * 17;
   __shared__ __attribute__((aligned(16))) unsigned char smem[FW > YW_ ? FW : YW_];
   const int b = (int)blockIdx.x;
-#ifdef CA_LAB_STAMPS
-  const unsigned long long st0_ = __builtin_amdgcn_s_memrealtime();
-#endif
+  CA_LAB_BLOCK_T0();
   const bool sweep_blk = b < nf;
   int unit;
   bool first = false;
@@ -2951,25 +2908,12 @@ __global__ void __launch_bounds__(CA_TB, CA_RIDE_WAVES) k_fwd_cell_seq_y(const f
     const int i = b >> 3;
     unit = b < y.nb_main ? b : -1;
     first = ((i ^ (i >> 5)) & 1) != 0;
-#if defined(CA_LAB_YSKIP) && CA_LAB_YSKIP == 3   // timing lab only (wrong results): no stream phase at all
-    unit = -1;
-#endif
-#if defined(CA_LAB_SEQ_ORDER)                   // timing lab only: 0 = every block sweeps first, 1 = every block streams first
-    first = CA_LAB_SEQ_ORDER != 0;
-#endif
   }
   if (unit >= 0 && (!sweep_blk || first)) {
-#ifdef CA_LAB_YPRIO
-    __builtin_amdgcn_s_setprio(CA_LAB_YPRIO);
-#else
     CA_PRIO_STREAM();
-#endif
     ca_ypass_body<uint8_t, 1, 0>(unit, y.Y, y.F, y.Dstride, y.V, 0, y.YWpart, y.YTpart, N, y.G, y.Gp, y.nseg, y.nrb, y.TR, 1, y.ovf, y.nb_main,
                                  reinterpret_cast<float (*)[64][17]>(smem));
     if (sweep_blk) __syncthreads();
-#ifdef CA_LAB_YPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
   }
   if (sweep_blk) {
     ca_f32x4* comb = reinterpret_cast<ca_f32x4*>(smem);
@@ -2982,24 +2926,12 @@ __global__ void __launch_bounds__(CA_TB, CA_RIDE_WAVES) k_fwd_cell_seq_y(const f
       ca_fwd_cell_body<D, TLB>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)b * (TLB * 16), b, comb, sm, la);
     if (unit >= 0 && !first) {
       __syncthreads();
-#ifdef CA_LAB_YPRIO
-      __builtin_amdgcn_s_setprio(CA_LAB_YPRIO);
-#else
       CA_PRIO_STREAM();
-#endif
       ca_ypass_body<uint8_t, 1, 0>(unit, y.Y, y.F, y.Dstride, y.V, 0, y.YWpart, y.YTpart, N, y.G, y.Gp, y.nseg, y.nrb, y.TR, 1, y.ovf, y.nb_main,
                                    reinterpret_cast<float (*)[64][17]>(smem));
     }
   }
-#ifdef CA_LAB_STAMPS
-  __syncthreads();
-  if (threadIdx.x == 0 && blockIdx.x < 8192) {
-    unsigned long long* st = ca_lab_stamps + 4 * (size_t)blockIdx.x;
-    st[0] = st0_; st[1] = __builtin_amdgcn_s_memrealtime();
-    st[2] = ((unsigned long long)(b >= nf ? 0 : (nbig > 0 && b >= nbig ? 2 : 1)) << 32) | (unsigned)b;
-    st[3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
-  }
-#endif
+  CA_LAB_BLOCK_END(b >= nf ? 0 : (nbig > 0 && b >= nbig ? 2 : 1), b);
 }
 
 // fixed-order reduction of block partials: out[j] = sum_b part[b][j]; one block per column j
@@ -3020,10 +2952,15 @@ __device__ __forceinline__ void ca_psi_adam_body(const ca_psi_args& a, int blk, 
                                                  float* psi0_new = nullptr /* merged update: the cell's stepped psi_0 (0 past the last cell) */) {
   ca_psi_adam_body_at(a, (int64_t)blk * CA_TB + threadIdx.x, apply, lr_t, b1, b2, aeps, psi0_new);
 }
-__device__ __forceinline__ bool ca_psi_adam_body_at(const ca_psi_args& a, int64_t n, int apply, float lr_t, float b1, float b2, float aeps, float* psi0_new,
+__device__ __forceinline__ bool ca_psi_adam_body_at(const ca_psi_args& a, int64_t n_, int apply, float lr_t, float b1, float b2, float aeps, float* psi0_new,
                                                     const ca_gate* gt) {
   if (psi0_new) *psi0_new = 0.f;
-  if (n >= a.N) return true;
+  // Lanes past the last cell run the same loads on the last cell's index and ask the gate with everybody else (they store nothing): the
+  // answer is then uniform over the block -- an early return here, in front of the gate, let the padding lanes of the last wave go on to
+  // the psi image after a "stop" (ADVICE r4).
+  const bool live = n_ < a.N;
+  if (!live && !gt) return true;
+  const int64_t n = live ? n_ : a.N - 1;
   for (int k = 0; k < a.K; ++k) {
     // (everything this lane reads, in one batch in front of the first use: a dependent round of loads is 1.5 us here)
     const float yw_k = a.YW[n * a.K + k], f_k = a.F[n * a.D + k], m_k = a.m_psi[n * a.K + k], v_k = a.v_psi[n * a.K + k];
@@ -3038,6 +2975,7 @@ __device__ __forceinline__ bool ca_psi_adam_body_at(const ca_psi_args& a, int64_
     }
     const float gp = (float)((double)yw_k + dF - (double)f_k);
     if (gt && k == 0 && !ca_gate_spin(*gt)) return false;   // (gated update: loads and arithmetic are done, nothing is stored yet)
+    if (!live) continue;
     a.g_psi[n * a.K + k] = gp;
     if (apply) {
       float th = f_k, m = m_k, v = v_k;
@@ -3225,21 +3163,16 @@ __global__ void __launch_bounds__(CA_TB) k_final_gene(const double* __restrict__
                                                       float* __restrict__ Vs, float* __restrict__ vmm_part,
                                                       int G, int S, int D, int K, int apply, float lr_t, float b1, float b2, float aeps, ca_small_args mon, int gblocks,
                                                       ca_psi_args psi, const float* __restrict__ gfold, int nfold) {
-#ifndef CA_LAB_SKIP
-#define CA_LAB_SKIP 0   // (timing lab, results WRONG: bit 0 monitor block, 1 psi blocks, 2 gene blocks of k_final_gene; 3 small block, 4 prologue
-#endif                  //  blocks, 5 quantiser blocks, 6 cell blocks of k_adam_cell return at once)
   CA_LAB_STAMP((int)blockIdx.x, (int)blockIdx.x < gblocks ? 0 : (mon.enabled && (int)blockIdx.x == gblocks) ? 1 : 2);
   if ((int)blockIdx.x >= gblocks) {
     int b = (int)blockIdx.x - gblocks;
     if (mon.enabled) {   // one extra block: the pending monitor pass's ELBO (ca_final_small_body), beside the gene blocks
-      if (b == 0) { if (!(CA_LAB_SKIP & 1)) ca_final_small_body(mon); return; }
+      if (b == 0) { ca_final_small_body(mon); return; }
       --b;
     }
-    if (CA_LAB_SKIP & 2) return;
     if (b < psi.nblk) ca_psi_adam_body(psi, b, apply, lr_t, b1, b2, aeps);
     return;
   }
-  if (CA_LAB_SKIP & 4) return;
   __shared__ float smin[CA_TB], smax[CA_TB];
   ca_final_gene_body(red_g, red_y, eps, colsum, YtX, vchi, loc, ls, V, m_loc, v_loc, m_ls, v_ls, m_V, v_V, g_loc, g_ls, g_V, Vs, vmm_part, G, S, D, K,
                      apply, lr_t, b1, b2, aeps, smin, smax, gfold, nfold);
@@ -3292,15 +3225,12 @@ __global__ void __launch_bounds__(CA_TB) k_adam_cell(const float* __restrict__ F
   const int nx = pre.nblk + 1;
   CA_LAB_STAMP(1024 + (int)blockIdx.x, (int)blockIdx.x < pre.nblk ? 3 : (int)blockIdx.x < nx ? 4 : (int)blockIdx.x < nx + cblocks ? 5 : 6);
   if ((int)blockIdx.x >= nx + cblocks) {
-    if (CA_LAB_SKIP & 32) return;
     __shared__ float smq[2 * (CA_YM_TB / 64)];
     ca_ys_quant_body((int)blockIdx.x - nx - cblocks, ysq, smq);
     return;
   }
   if ((int)blockIdx.x < nx) {
     const int b = (int)blockIdx.x;
-    if ((CA_LAB_SKIP & 16) && b < pre.nblk) return;
-    if ((CA_LAB_SKIP & 8) && b >= pre.nblk) return;
     if (b < pre.nblk) {   // the next eps pair's per-gene prologue (ca_pre_args)
       __shared__ double smp[CA_TB];
       ca_gene_pre_fused_body(pre.loc, pre.ls, pre.epsA, pre.epsB, pre.colsum, pre.Lb, pre.V, pre.D, pre.K, pre.YtX, pre.muA, pre.muB, pre.Mb,
@@ -3312,7 +3242,6 @@ __global__ void __launch_bounds__(CA_TB) k_adam_cell(const float* __restrict__ F
   }
   const int cblk = (int)blockIdx.x - nx;   // cell block
   (void)cblocks;
-  if (CA_LAB_SKIP & 64) return;
   // q(z) logits: an elementwise step over the flat [N * C] arrays, 16 bytes per lane (a lane per cell would fetch C
   // strided floats per array: 2.4 TB/s at 100k x 8)
   if (apply) ca_logit_adam_body(cblk, glogit, dgl, m_gl, v_gl, N, C, lr_t, b1, b2, aeps);
@@ -3362,33 +3291,52 @@ struct ca_merge_args {
   const double* aux_in; double* aux_out; int64_t aux_ld;   // [5][aux_ld] doubles per gene: the sweep-independent part of the NEXT step's gradient (ca_gene_pre_draw);
                                                            // aux_in: what the prologue of THIS pass's eps left (null: the step computes it), aux_out: for the next step
   // ca_run's gate (round 4): the launch is queued BEFORE the host has seen the ELBO the stop rule needs -- that ELBO is assembled by this
-  // launch's own monitor block, which is not gated -- and every other block waits here for the host's decision: word = (gate_seq << 1) | go in
-  // pinned host memory.  go = 0 (the loop stops, or the poll hook said so) or a wait past gate_timeout: the block returns without a single store.
-  const unsigned long long* gate; unsigned long long gate_seq, gate_timeout; unsigned long long* gate_err;
-  unsigned long long* gate_local;   // device memory: ONE block (the chi / alpha block) polls the host's word over PCIe and passes it on here; the others poll this
+  // launch's own monitor block, which is not gated -- and every other block waits for the decision.  Round 5: ONE block decides, the relay
+  // (the chi / alpha block; it and the monitor block are dispatched FIRST, so they run whatever the device's occupancy -- gene blocks that
+  // fill a small partition can no longer keep them out).  It polls the host's word (gate_seq << 1) | go in pinned memory for at most
+  // gate_timeout ticks (100 MHz; ~1 ms by default): "go", "stop", or -- no answer in time, the host is in a slow poll hook, was descheduled or
+  // is stopped in a debugger -- "gave up".  Its verdict goes to device memory for every other block (gate_local: go, or store nothing) and
+  // to the host (gate_ack: (gate_seq << 2) | 1 go, 0 stop, 2 gave up).  A launch that gave up stores NOTHING and is not an error: the host
+  // puts its bookkeeping of the step back and queues the update again after its decision (the lock-step loop), so a slow hook costs the
+  // GPU gate_timeout of one block's polling, then the device is idle, and the fit is unchanged bit for bit.
+  const unsigned long long* gate; unsigned long long gate_seq, gate_timeout; unsigned long long* gate_ack;
+  unsigned long long* gate_err;     // pinned: a waiter whose safety deadline (gate_timeout + 10 s) ran out -- the relay never ran; fatal, never seen
+  unsigned long long* gate_local;   // device memory: the relay's verdict, (gate_seq << 1) | go; the other blocks (and a forward sweep queued behind) read this
   int* vmm_at; int* vmm_at_next;   // range of V' over ALL genes as ordered ints [2][8]: every gene block folds its own in with one atomic min / max per
                                    // dimension (the next sweep reads 2 D words); the chi / alpha block resets the buffer of the NEXT merged update
 };
-// every thread of the block calls it; true = go on (no gate, or the host said go).  relay: this block is the one that reads the host's word
-// (pinned memory, a PCIe round trip per look) and passes it on through device memory; two hundred blocks polling the host's line themselves
-// made a ca_run iteration 160 us LONGER (gpurun_out/r4/run_gate1.txt)
+#define CA_GATE_WAITER_EXTRA (10ull * 100000000ull)   // a waiter's deadline over the relay's: 10 s of s_memrealtime ticks
+// every thread of the block calls it; true = go on (no gate, or the verdict is go).  relay: this block is the one that reads the host's word
+// (pinned memory, a PCIe round trip per look) and passes the verdict on through device memory; two hundred blocks polling the host's line
+// themselves made a ca_run iteration 160 us LONGER (gpurun_out/r4/run_gate1.txt)
 __device__ __forceinline__ bool ca_gate_wait(const ca_merge_args& mg, bool relay) {
   if (!mg.gate) return true;
   __shared__ unsigned gate_go;
   if (threadIdx.x == 0) {
     unsigned go = 0u;
     const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-    for (;;) {
-      const unsigned long long w = relay ? __hip_atomic_load(mg.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
-                                         : __hip_atomic_load(mg.gate_local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((w >> 1) == mg.gate_seq) { go = (unsigned)(w & 1ull); break; }
-      if (__builtin_amdgcn_s_memrealtime() - t0 > mg.gate_timeout) {   // the host never answered: no store is made, and the host is told
-        __hip_atomic_store(mg.gate_err, mg.gate_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        break;
+    if (relay) {
+      unsigned outcome = 2u;   // gave up
+      for (;;) {
+        const unsigned long long w = __hip_atomic_load(mg.gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((w >> 1) == mg.gate_seq) { outcome = (unsigned)(w & 1ull); break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > mg.gate_timeout) break;
+        __builtin_amdgcn_s_sleep(4);
       }
-      if (relay) __builtin_amdgcn_s_sleep(4); else __builtin_amdgcn_s_sleep(16);
+      go = outcome == 1u ? 1u : 0u;
+      __hip_atomic_store(mg.gate_local, (mg.gate_seq << 1) | (unsigned long long)go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(mg.gate_ack, (mg.gate_seq << 2) | (unsigned long long)outcome, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+      for (;;) {
+        const unsigned long long w = __hip_atomic_load(mg.gate_local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((w >> 1) == mg.gate_seq) { go = (unsigned)(w & 1ull); break; }
+        if (__builtin_amdgcn_s_memrealtime() - t0 > mg.gate_timeout + CA_GATE_WAITER_EXTRA) {   // (the relay never ran: see ca_gate)
+          __hip_atomic_store(mg.gate_err, mg.gate_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(16);
+      }
     }
-    if (relay) __hip_atomic_store(mg.gate_local, (mg.gate_seq << 1) | (unsigned long long)go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     gate_go = go;
   }
   __syncthreads();
@@ -3405,9 +3353,24 @@ __global__ void __launch_bounds__(CA_UM_TB) k_update_merged(const double* __rest
                                                             float* __restrict__ Vs, float* __restrict__ vmm_part,
                                                             int G, int S, int D, int K, float lr_t, float b1, float b2, float aeps, ca_small_args mon, int gblocks,
                                                             ca_psi_args psi, const float* __restrict__ gfold, int nfold, ca_merge_args mg) {
-  [[maybe_unused]] const int nmon = mon.enabled ? 1 : 0;
-  const int bx = (int)blockIdx.x;
-  CA_LAB_STAMP(bx, bx < gblocks ? 0 : bx < gblocks + nmon ? 1 : bx == gblocks + nmon ? 4 : bx < gblocks + nmon + 1 + (psi.nblk + 3) / 4 ? 2 : 5);
+  const int nmon = mon.enabled ? 1 : 0;
+  // Block order = dispatch order.  FIRST the two O(K + C) blocks: the pending monitor pass's ELBO (never gated: it makes the ELBO the host
+  // decides on) and the chi / alpha step, which is also the gate's relay -- every other block of a gated launch waits for ITS verdict, so
+  // it must get a slot whatever the device's occupancy (behind the gene blocks, a partition with fewer slots than gene blocks
+  // never dispatched it and every ca_run stalled for the gate's time limit).  Then the latency chains (gene blocks), psi, the logits.
+  if ((int)blockIdx.x < nmon + 1) {   // 256-thread blocks
+    const int b = (int)blockIdx.x;
+    CA_LAB_STAMP(gblocks + b, mon.enabled && b == 0 ? 1 : 4);
+    if ((int)threadIdx.x >= CA_TB) return;
+    if (mon.enabled && b == 0) { CA_LAB_CP(40, 0); ca_final_small_body(mon); CA_LAB_CP(40, 1); return; }
+    if (!ca_gate_wait(mg, true)) return;
+    if (threadIdx.x < 8) { mg.vmm_at_next[threadIdx.x] = ca_f2ord(INFINITY); mg.vmm_at_next[8 + threadIdx.x] = ca_f2ord(-INFINITY); }
+    CA_LAB_CP(41, 0); if (mg.tail.enabled) ca_final_small_body(mg.tail); CA_LAB_CP(41, 1);
+    return;
+  }
+  const int bx = (int)blockIdx.x - (nmon + 1);   // gene block index, then psi / logit pieces behind the gene blocks
+  CA_LAB_STAMP(bx < gblocks ? bx : bx + nmon + 1, bx < gblocks ? 0 : bx < gblocks + (psi.nblk + 3) / 4 ? 2 : 5);
+  const ca_gate gt = {mg.gate ? mg.gate_local : nullptr, mg.gate_seq, mg.gate_timeout + CA_GATE_WAITER_EXTRA, mg.gate_err};   // what the waiting blocks ask
   if (bx < gblocks) {
     // A gene's chain here is: its Adam step (one round of loads, then fp64 exp / log1p / log and three Adam steps: 5 us at one wave per
     // SIMD), THEN the two draws of the next prologue (2.7 us each: softplus, log, the operand row) and its part of the W image (2 us) --
@@ -3416,8 +3379,6 @@ __global__ void __launch_bounds__(CA_UM_TB) k_update_merged(const double* __rest
     // through LDS and go on to V' (log2 units, range) and the sums of squares; waves 4-7 take draw A of the same genes, 8-11 draw B,
     // 12-15 the W image.  Every block-level sum keeps the order of the 256-thread form: butterflies inside a 64-gene wave, then the
     // four gene groups in order -- bitwise the same partials.
-    if (CA_LAB_SKIP & 4) return;
-    const ca_gate gt = {mg.gate ? mg.gate_local : nullptr, mg.gate_seq, mg.gate_timeout, mg.gate_err};
     __shared__ int stop_s;
     __shared__ float h_loc[CA_TB], h_ls[CA_TB], h_v0[CA_TB];
     __shared__ double smt[4][8];
@@ -3513,26 +3474,15 @@ __global__ void __launch_bounds__(CA_UM_TB) k_update_merged(const double* __rest
     return;
   }
   int b = bx - gblocks;
-  if (b < nmon + 1) {   // the two O(K + C) blocks are 256-thread blocks: the pending monitor pass's ELBO, then the chi / alpha step
-    if ((int)threadIdx.x >= CA_TB) return;
-    if (mon.enabled && b == 0) { CA_LAB_CP(40, 0); if (!(CA_LAB_SKIP & 1)) ca_final_small_body(mon); CA_LAB_CP(40, 1); return; }   // (never gated: it makes the ELBO the host decides on)
-    if (!ca_gate_wait(mg, true)) return;
-    if (threadIdx.x < 8) { mg.vmm_at_next[threadIdx.x] = ca_f2ord(INFINITY); mg.vmm_at_next[8 + threadIdx.x] = ca_f2ord(-INFINITY); }
-    CA_LAB_CP(41, 0); if (!(CA_LAB_SKIP & 8) && mg.tail.enabled) ca_final_small_body(mg.tail); CA_LAB_CP(41, 1);
-    return;
-  }
-  b -= nmon + 1;
   // psi and q(z)-logit blocks: FOUR 256-cell pieces per 1024-thread block (a quarter-filled block costs the dispatcher sixteen wave slots
   // all the same: 800 of them at cfg-3 took 15 us to get through).  Piece index = what a 256-thread block's index was.
   const int sub = (int)threadIdx.x >> 8, npsi4 = (psi.nblk + 3) / 4;
   if (b < npsi4) {
-    if (CA_LAB_SKIP & 2) return;
     __shared__ float smw[CA_UM_TB / 64];
     const int pb = 4 * b + sub;              // 256-cell piece
     float pn = 0.f;
     if (b == 0) CA_LAB_CP(42, 0);
     if (pb < psi.nblk) {
-      const ca_gate gt = {mg.gate ? mg.gate_local : nullptr, mg.gate_seq, mg.gate_timeout, mg.gate_err};
       if (!ca_psi_adam_body_at(psi, (int64_t)pb * CA_TB + ((int)threadIdx.x & (CA_TB - 1)), 1, lr_t, b1, b2, aeps, &pn, &gt)) return;
     }
     if (b == 0) CA_LAB_CP(42, 1);
@@ -3553,7 +3503,6 @@ __global__ void __launch_bounds__(CA_UM_TB) k_update_merged(const double* __rest
   }
   b -= npsi4;
   if (!ca_gate_wait(mg, false)) return;
-  if (CA_LAB_SKIP & 64) return;
   if (b == 0) CA_LAB_CP(43, 0);
   if (4 * b + sub < mg.ncell) ca_logit_adam_body(4 * b + sub, mg.glogit, mg.dgl, mg.m_gl, mg.v_gl, psi.N, mg.C, lr_t, b1, b2, aeps, (int)threadIdx.x & (CA_TB - 1));
   if (b == 0) CA_LAB_CP(43, 1);
@@ -3753,12 +3702,8 @@ __global__ void __launch_bounds__(CA_TB, (DEPTH == 1 && !C16 && !S2F) ? CA_YS_RI
   } else {
     sweep = ca_ride_split((int)blockIdx.x, nf, y.nb_y, y.pat_a, y.pat_b, idx);
   }
-#ifdef CA_LAB_STAMPS
-  const unsigned long long st0_ = __builtin_amdgcn_s_memrealtime();
-#define CA_YS_LEAVE() goto ca_ys_out
-#else
-#define CA_YS_LEAVE() return
-#endif
+  CA_LAB_BLOCK_T0();
+#define CA_YS_LEAVE() CA_LAB_LEAVE(ca_ys_out)
   if (!sweep) {
     if (idx >= y.nb_main) {   // the overflow list's blocks: cell side (an extra segment of YWpart), then gene side (chunk sums)
       const int b = idx - y.nb_main;
@@ -3766,11 +3711,7 @@ __global__ void __launch_bounds__(CA_TB, (DEPTH == 1 && !C16 && !S2F) ? CA_YS_RI
       else ca_ovf_chunks_body(b - y.ovf.nb_rows, y.ovf.chunk_start, y.ovf.row2, y.ovf.val2, y.F, y.Df, y.ovf.csum, y.ovf.nchunk, 1, 0);
       CA_YS_LEAVE();
     }
-#ifdef CA_LAB_YPRIO
-    __builtin_amdgcn_s_setprio(CA_LAB_YPRIO);
-#else
     CA_PRIO_STREAM();
-#endif
     if (y.pers > 0) {
       for (int u = idx; u < y.nb_main; u += y.pers) {
         if (u != idx) __syncthreads();   // the previous unit's combine has been read by every wave before the LDS regions are reused
@@ -3792,14 +3733,6 @@ __global__ void __launch_bounds__(CA_TB, (DEPTH == 1 && !C16 && !S2F) ? CA_YS_RI
       ca_fwd_cell_body<D, TLB, C16, S2F>(F, etamax2, Vs, Mq, p, cell_part, N, C, K, nk, (int64_t)idx * (TLB * 16), idx, comb, sm, la);
   }
 #undef CA_YS_LEAVE
-#ifdef CA_LAB_STAMPS
-ca_ys_out:
-  __syncthreads();
-  if (threadIdx.x == 0 && blockIdx.x < 8192) {   // (timing lab: same record as k_fwd_cell_mix_y's; kind 0 = stream / overflow, 1 = big, 2 = small sweep block)
-    unsigned long long* st = ca_lab_stamps + 4 * (size_t)blockIdx.x;
-    st[0] = st0_; st[1] = __builtin_amdgcn_s_memrealtime();
-    st[2] = ((unsigned long long)(sweep ? (nbig > 0 && idx >= nbig ? 2 : 1) : 0) << 32) | (unsigned)idx;
-    st[3] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);
-  }
-#endif
+  CA_LAB_LABEL(ca_ys_out);
+  CA_LAB_BLOCK_END(sweep ? (nbig > 0 && idx >= nbig ? 2 : 1) : 0, idx);   // (kind 0 = stream / overflow, 1 = big, 2 = small sweep block)
 }

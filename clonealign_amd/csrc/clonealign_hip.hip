@@ -125,6 +125,11 @@ struct ca_engine {
   bool upd_merge = false, em_stale = false;
   // ca_run: the update half of train pass i + 1 is queued before the host has seen ELBO i and gated on a word the host writes (ca_merge_args::gate)
   bool run_gate = false, gate_req = false, gate_armed = false;
+  // round 5: the gated launch's relay block gives up after gate_ticks (a launch that stores nothing; not an error) -- gate_t0: host clock right before
+  // that launch was queued; gate_open / gate_snap: the window between queuing it and answering it, in which a poll hook may call back into the API
+  // (gate_close()); in_run: ca_run_ex is on this thread's stack (hooks may only call the read-only entry points)
+  unsigned long long gate_ticks = 100000ull; std::chrono::steady_clock::time_point gate_t0;
+  bool gate_open = false, gate_aborted = false, in_run = false; struct gate_snapshot* gate_snap = nullptr; struct fwd_snapshot* gate_fsnap = nullptr;
   bool run_fwd = false;    // ca_run: queue the forward sweep behind a gated update ahead of the host's decision (CA_VAR_RUN_FWD)
   bool fwd_gate = false;   // ca_run: the forward sweep being queued is behind a gated update and must look at that launch's answer (ca_cell_ptrs::gate)
   unsigned long long gate_seq = 0; unsigned long long* gate_local = nullptr;
@@ -314,9 +319,14 @@ int prof_end(ca_engine* h) {
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-// Configuration comes from ca_options (variant_off / tune).  The process environment is consulted ONLY when
-// CLONEALIGN_DEBUG_ENV is set (tools/tune.py, tools/fuzz_parity.py): NAME=0 switches a variant off, NAME=<n> sets a parameter.
+// Configuration comes from ca_options (variant_off / variant_on / tune).  The RELEASE library reads no tuning from the process
+// environment at all; a timing-lab build (-DCA_LAB, tools/lab/) consults it when CLONEALIGN_DEBUG_ENV is set (tools/tune.py,
+// tools/fuzz_parity.py): NAME=0 switches a variant off, NAME=<n> sets a parameter.
+#ifdef CA_LAB
 inline bool debug_env() { return getenv("CLONEALIGN_DEBUG_ENV") != nullptr; }
+#else
+constexpr bool debug_env() { return false; }
+#endif
 inline bool variant_on(const ca_engine* h, unsigned bit, const char* env) {
   if (h->opt.variant_off & bit) return false;
   if (debug_env()) if (const char* e = getenv(env)) return atoi(e) != 0;
@@ -1087,11 +1097,14 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
       h->gate_armed = false;
       if (h->gate_req && h->host_dev) {   // ca_run: wait on the device for the host's decision (every block but the monitor block)
         // (the gate word and the error word each in a cache line of their own: doubles 32 / 33 are the ELBO and its flag, which the host spins on)
+        // (pinned doubles: 32 / 33 the ELBO and its flag, which the host spins on; 40 the fatal word; 48 the host's answer; 56 the relay's verdict)
         mg.gate = reinterpret_cast<const unsigned long long*>(h->host_dev + 48); mg.gate_seq = ++h->gate_seq;
-        mg.gate_err = reinterpret_cast<unsigned long long*>(h->host_dev + 56);
+        mg.gate_ack = reinterpret_cast<unsigned long long*>(h->host_dev + 56);
+        mg.gate_err = reinterpret_cast<unsigned long long*>(h->host_dev + 40);
         mg.gate_local = h->gate_local;
-        mg.gate_timeout = 10ull * 100000000ull;   // 10 s of s_memrealtime ticks: only a host that died between the launch and its answer gets there
+        mg.gate_timeout = h->gate_ticks;   // the RELAY's patience (s_memrealtime ticks, 100 MHz): ~1 ms, then the launch stores nothing and the host re-queues it
         h->gate_armed = true;
+        h->gate_t0 = std::chrono::steady_clock::now();   // (before the launch below: the relay's clock starts no earlier)
       }
       h->gate_req = false;
       ca_pre_args& pre = mg.pre;
@@ -1925,6 +1938,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   h->upd_merge = h->tail_fuse && h->pre_ok && variant_on(h, CA_VAR_UPDATE_MERGE, "CA_UPDATE_MERGE");
   h->p2p_ride = h->tail_fuse && variant_on(h, CA_VAR_P2P_RIDE, "CA_P2P_RIDE");
   h->run_gate = h->upd_merge && variant_on(h, CA_VAR_RUN_GATE, "CA_RUN_GATE");
+  h->gate_ticks = 100ull * (unsigned long long)(h->opt.gate_timeout_us > 0 ? h->opt.gate_timeout_us : 1000);   // s_memrealtime: 100 MHz
   h->run_fwd = h->run_gate && variantx_on(h, CA_VARX_RUN_FWD, "CA_RUN_FWD");   // opt-in: see the header (no runtime call may block between a gated launch and its answer)
   h->pair_elbo = variant_on(h, CA_VAR_PAIR_ELBO, "CA_PAIR_ELBO");
   CACK(upload_y(h, p));
@@ -2432,394 +2446,6 @@ static int preprocess_t(const ST* src, int64_t N, int G, int C, int layout, cons
   return CA_OK;
 }
 
-extern "C" {
-
-int ca_abi_version(void) { return CA_ABI_VERSION; }
-#ifdef CA_LAB_STAMPS   // timing lab only (tools/stamps.py): per-block stamps of the last merged forward launch
-int ca_lab_read_stamps(unsigned long long* out, int n_blocks) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(ca_lab_stamps), (size_t)n_blocks * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
-}
-int ca_lab_read_stamps3(unsigned long long* out, int n_blocks) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(ca_lab_stamps3), (size_t)n_blocks * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
-}
-int ca_lab_read_stamps2(unsigned long long* out, int n_blocks) {
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(ca_lab_stamps2), (size_t)n_blocks * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : 2;
-}
-#endif
-#ifndef CA_BUILD_ID
-#define CA_BUILD_ID "unknown"
-#endif
-const char* ca_build_id(void) { return CA_BUILD_ID; }
-
-int ca_device_count(int32_t* n) {
-  int c = 0;
-  const hipError_t e = hipGetDeviceCount(&c);
-  if (e != hipSuccess) { (void)hipGetLastError(); c = 0; }
-  if (n) *n = c;
-  return e == hipSuccess ? CA_OK : CA_ERR_HIP;
-}
-
-int ca_default_options(ca_options* o) {
-  if (!o) return CA_ERR_INVALID;
-  memset(o, 0, sizeof(*o));
-  o->learning_rate = 0.1;
-  o->beta1 = 0.9; o->beta2 = 0.999; o->adam_eps = 1e-8;
-  o->seed = 0x5eed5eedull;
-  o->device = 0; o->y_storage = CA_YSTORE_AUTO; o->rank = 0; o->world = 1; o->profile = 0;
-  return CA_OK;
-}
-
-const char* ca_last_error(ca_handle h) { return h ? h->err.c_str() : g_last_error.c_str(); }
-
-int ca_create(const ca_problem* p, const ca_options* o, ca_handle* out) {
-  g_last_error.clear();
-  if (!p || !out) { g_last_error = "null argument"; return CA_ERR_INVALID; }
-  *out = nullptr;
-  ca_options opt;
-  if (o) opt = *o; else ca_default_options(&opt);
-  auto bad = [&](const char* m) { g_last_error = m; return CA_ERR_INVALID; };
-  if (p->N <= 0 || p->G <= 0 || p->C <= 0) return bad("N, G and C must be positive");
-  if (p->C > 256) return bad("C > 256 clones not supported");
-  if (p->K < 0 || p->P < 0 || p->S < 1) return bad("K >= 0, P >= 0, S >= 1 required");
-  const int D = p->K > 0 ? p->K + p->P : 0;
-  if (D > 8) return bad("K + P > 8 not supported");
-  if (!p->Y || !p->L) return bad("Y and L are required");
-  if (!p->loc0 && opt.world > 1) return bad("loc0 = NULL (data-driven initialisation on the device) needs all cells: pass loc0 when world > 1");
-  if (p->K > 0 && !p->psi0) return bad("psi0 is required when K > 0");
-  if (p->P > 0 && !p->X) return bad("X is required when P > 0");
-  if (opt.world < 1 || opt.rank < 0 || opt.rank >= opt.world) return bad("bad rank/world");
-  if ((p->cell_index || p->gene_index) && (p->N_src < p->N || p->G_src < p->G)) return bad("N_src / G_src must be at least N / G when a selection is given");
-  ca_engine* h = new ca_engine();
-  h->N = p->N; h->G = p->G; h->C = p->C; h->K = p->K; h->P = p->P; h->S = p->S; h->D = D;
-  h->layout = p->layout; h->opt = opt; h->device = opt.device;
-  int rc = create_impl(h, p);
-  if (rc != CA_OK) {
-    g_last_error = h->err;
-    ca_destroy(h);
-    return rc;
-  }
-  *out = h;
-  return CA_OK;
-}
-
-int ca_destroy(ca_handle h) {
-  if (!h) return CA_OK;
-  hipSetDevice(h->device);
-  if (h->stream) hipStreamSynchronize(h->stream);
-  if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
-  if (h->ev_params) hipEventDestroy(h->ev_params);
-  if (h->ev_ydone) hipEventDestroy(h->ev_ydone);
-  if (h->ev_ywdone) hipEventDestroy(h->ev_ywdone);
-  if (h->ev_stage) hipEventDestroy(h->ev_stage);
-  if (h->comm) g_rccl.CommDestroy(h->comm);
-  if (h->p2p) {
-    for (void* q : h->p2p->opened) if (q) hipIpcCloseMemHandle(q);
-    if (h->p2p->err_host) hipHostFree(h->p2p->err_host);
-    if (h->p2p->err_local) hipFree(h->p2p->err_local);
-    if (h->p2p->slab) hipFree(h->p2p->slab);
-    if (h->p2p->peers_dev) hipFree(h->p2p->peers_dev);
-    delete h->p2p;
-  }
-  for (auto& e : h->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
-  for (void* q : h->allocs) hipFree(q);
-  if (h->eps_dev) hipFree(h->eps_dev);
-  if (h->elbo_dev) hipFree(h->elbo_dev);
-  if (h->host_pinned) hipHostFree(h->host_pinned);
-  if (h->eps_stage) hipHostFree(h->eps_stage);
-  if (h->host_ar_buf) hipHostFree(h->host_ar_buf);
-  if (h->stream) hipStreamDestroy(h->stream);
-  delete h;
-  return CA_OK;
-}
-
-int ca_get_info(ca_handle h, ca_info* i) {
-  if (!h || !i) return CA_ERR_INVALID;
-  memset(i, 0, sizeof(*i));
-  i->N = h->N; i->G = h->G; i->C = h->C; i->K = h->K; i->P = h->P; i->S = h->S;
-  i->y_storage = h->ystore; i->y_bytes_per_elem = h->ybytes; i->y_device_bytes = h->y_dev_bytes; i->device_bytes = h->dev_bytes;
-  i->gsplit = h->gsplit; i->csplit = h->csplit; i->n_cu = h->n_cu; i->fused_sweep = h->fused_ok ? 1 : 0;
-  i->fwd_mfma = (h->fused_ok && h->fwd_mfma) ? 1 : 0; i->bwd_mfma = h->bwd_mfma ? 1 : 0; i->fsplit = h->fsplit; i->fwd_cell = (h->fused_ok && h->fwd_cell) ? 1 : 0;
-  i->y_mfma = h->y_ys ? 2 : h->y_mfma ? 1 : 0;
-  i->y_ride = (h->ride_ok || h->ride_ys) ? 1 : 0;
-  i->transport = (h->p2p && h->p2p->connected) ? CA_TRANSPORT_P2P : h->comm ? CA_TRANSPORT_RCCL : h->host_ar ? CA_TRANSPORT_HOST : CA_TRANSPORT_NONE;
-  i->red_n = h->red_n;
-  i->fwd_block_cells = (h->fused_ok && h->fwd_cell) ? 16 * h->fc_tl : 0; i->fwd_blocks_big = h->fc_nbig;
-  i->fold_gsum = (h->fold_gsum && !is_sharded(h)) ? 1 : 0; i->yfin_split = (h->yfin_split && !is_sharded(h)) ? 1 : 0;
-  i->update_merge = (h->upd_merge && h->fused_ok && h->fwd_cell && h->K > 0) ? 1 : 0;
-  return CA_OK;
-}
-
-int ca_synchronize(ca_handle h) {
-  if (!h) return CA_ERR_INVALID;
-  HIPCK(h, hipSetDevice(h->device));
-  SYNC(h);
-  return CA_OK;
-}
-
-int ca_comm_unique_id(char id[128]) {
-  if (!g_rccl.load()) { g_last_error = g_rccl.err; return CA_ERR_COMM; }
-  ca_nccl_uid u;
-  int rc = g_rccl.GetUniqueId(&u);
-  if (rc != 0) { g_last_error = "ncclGetUniqueId failed"; return CA_ERR_COMM; }
-  memcpy(id, u.internal, 128);
-  return CA_OK;
-}
-
-int ca_comm_init(ca_handle h, const char id[128]) {
-  if (!h || !id) return CA_ERR_INVALID;
-  CACK(comm_check(h));   // a peer-to-peer transport that timed out leaves the engine dead: no falling back on the same handle
-  if (!g_rccl.load()) { h->err = g_rccl.err; return CA_ERR_COMM; }
-  HIPCK(h, hipSetDevice(h->device));
-  ca_nccl_uid u;
-  memcpy(u.internal, id, 128);
-  int rc = g_rccl.CommInitRank(&h->comm, h->opt.world, u, h->opt.rank);
-  if (rc != 0) {
-    h->err = std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
-    h->comm = nullptr;
-    return CA_ERR_COMM;
-  }
-  return setup_global_sums(h);
-}
-
-int ca_p2p_export(ca_handle h, char handle[CA_P2P_HANDLE_BYTES]) {
-  if (!h || !handle) return CA_ERR_INVALID;
-  HIPCK(h, hipSetDevice(h->device));
-  if (h->opt.world > CA_TB) { h->err = "peer-to-peer transport: at most " + std::to_string(CA_TB) + " ranks (one flag lane per rank)"; return CA_ERR_COMM; }
-  if (!h->p2p) {
-    ca_p2p* pp = new ca_p2p();
-    const int W = h->opt.world;
-    // room for everything one call reduces: the train pass's summands, the setup sums, the PCA / correlation packs
-    pp->cap = std::max<int64_t>(std::max<int64_t>(h->red_n, (int64_t)h->G * (h->C + 2) + 64), 4096);
-    pp->slab_bytes = (size_t)2 * W * pp->cap * 16;   // [parity 2][source W][cap] entries of 16 bytes: two halves of a double, each with the call's tag (k_p2p_allreduce)
-    // Fine-grained memory or nothing: the slab is written by remote peers over xGMI and polled here, which ordinary
-    // (coarse-grained) device memory does not keep coherent -- a stale flag would be a hang or a wrong sum.  The caller moves
-    // on to RCCL when this fails.
-    if (hipExtMallocWithFlags((void**)&pp->slab, pp->slab_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
-      (void)hipGetLastError();
-      delete pp;
-      h->err = "peer-to-peer transport: fine-grained device memory unavailable (hipExtMallocWithFlags(hipDeviceMallocFinegrained) failed)";
-      return CA_ERR_COMM;
-    }
-    auto fail = [&](const std::string& m) { if (pp->err_host) hipHostFree(pp->err_host); if (pp->err_local) hipFree(pp->err_local); if (pp->peers_dev) hipFree(pp->peers_dev);
-                                            hipFree(pp->slab); delete pp; h->err = m; return CA_ERR_HIP; };
-    if (hipMemset(pp->slab, 0, pp->slab_bytes) != hipSuccess) return fail("hipMemset of the p2p slab failed");
-    if (hipMalloc((void**)&pp->peers_dev, (size_t)W * sizeof(double*)) != hipSuccess) return fail("hipMalloc (p2p peer table) failed");
-    if (hipMalloc((void**)&pp->err_local, sizeof(unsigned int)) != hipSuccess) return fail("hipMalloc (p2p error flag) failed");
-    if (hipMemset(pp->err_local, 0, sizeof(unsigned int)) != hipSuccess) return fail("hipMemset (p2p error flag) failed");
-    if (hipDeviceSynchronize() != hipSuccess) return fail("hipDeviceSynchronize (p2p setup) failed");   // (NULL-stream memsets are not ordered against the engine's non-blocking stream)
-    if (hipHostMalloc((void**)&pp->err_host, sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) return fail("hipHostMalloc (p2p error word) failed");
-    *pp->err_host = 0ull;
-    if (hipHostGetDevicePointer((void**)&pp->err_dev, pp->err_host, 0) != hipSuccess) return fail("hipHostGetDevicePointer (p2p error word) failed");
-    const int ms = h->opt.comm_timeout_ms > 0 ? h->opt.comm_timeout_ms : 10000;
-    pp->timeout_ticks = (unsigned long long)ms * 100000ull;   // s_memrealtime counts at 100 MHz
-    h->p2p = pp;
-  }
-  ca_p2p_wire w;
-  memset(&w, 0, sizeof(w));
-  HIPCK(h, hipIpcGetMemHandle(&w.mem, h->p2p->slab));
-  w.cap = h->p2p->cap; w.rank = h->opt.rank; w.world = h->opt.world; w.device = h->device; w.pid = (int32_t)getpid();
-  w.local_ptr = (uint64_t)(uintptr_t)h->p2p->slab;
-  memset(handle, 0, CA_P2P_HANDLE_BYTES);
-  memcpy(handle, &w, sizeof(w));
-  return CA_OK;
-}
-
-static void p2p_unmap(ca_p2p* pp) {
-  for (void*& q : pp->opened) if (q) { hipIpcCloseMemHandle(q); q = nullptr; }
-  (void)hipGetLastError();
-  pp->mapped = false;
-}
-
-// Phase 1: map every peer's slab.  Touches no peer and launches nothing, so a rank whose peer failed does not end up waiting for
-// it: the caller agrees on every rank's result over its control plane and then calls ca_p2p_commit on all ranks.
-int ca_p2p_connect(ca_handle h, const char* handles) {
-  if (!h || !handles) return CA_ERR_INVALID;
-  if (!h->p2p) { h->err = "ca_p2p_connect before ca_p2p_export"; return CA_ERR_STATE; }
-  if (!variant_on(h, CA_VAR_P2P, "CA_P2P")) { h->err = "peer-to-peer transport switched off (CA_VAR_P2P)"; return CA_ERR_COMM; }
-  HIPCK(h, hipSetDevice(h->device));
-  ca_p2p* pp = h->p2p;
-  if (pp->connected) { h->err = "ca_p2p_connect: the transport is already committed"; return CA_ERR_STATE; }
-  const int W = h->opt.world;
-  std::vector<double*> peers((size_t)W, nullptr);
-  p2p_unmap(pp);
-  pp->opened.assign((size_t)W, nullptr);
-  auto fail = [&](const std::string& m) { p2p_unmap(pp); h->err = m; return CA_ERR_COMM; };
-  for (int r = 0; r < W; ++r) {
-    ca_p2p_wire w;
-    memcpy(&w, handles + (size_t)r * CA_P2P_HANDLE_BYTES, sizeof(w));
-    if (w.rank != r || w.world != W || w.cap != pp->cap)
-      return fail("p2p handle " + std::to_string(r) + " does not match this problem (rank / world / payload size)");
-    if (r == h->opt.rank) { peers[r] = pp->slab; continue; }
-    if (w.device != h->device) {
-      int can = 0;
-      if (hipDeviceCanAccessPeer(&can, h->device, w.device) != hipSuccess || !can) {
-        (void)hipGetLastError();
-        return fail("no peer access from device " + std::to_string(h->device) + " to device " + std::to_string(w.device));
-      }
-      const hipError_t e = hipDeviceEnablePeerAccess(w.device, 0);
-      (void)hipGetLastError();
-      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
-    }
-    if (w.pid == (int32_t)getpid()) {   // a handle of THIS process (one R session driving several devices): the slab's own address
-      // ... but not two ranks of one process on ONE device: the runtime's device-wide synchronising calls (hipFree, hipMalloc of
-      // a grown eps buffer, ...) made for one handle wait for every kernel on the device, also the other handle's all-reduce
-      // kernel -- which waits for this rank.  Measured: the second all-reduce of such a pair ran into the device-side time
-      // limit (tests/test_gpu_sharding.py).  Separate processes sharing a device are fine (their runtimes do not see each other).
-      if (w.device == h->device && !(h->opt.variant_on & CA_VARX_P2P_SAME_DEVICE))
-        return fail("peer-to-peer transport: ranks " + std::to_string(h->opt.rank) + " and " + std::to_string(r) + " are handles of one process on one "
-                    "device; use one rank per device (or one process per rank)");
-      peers[r] = (double*)(uintptr_t)w.local_ptr;
-      continue;
-    }
-    void* q = nullptr;
-    const hipError_t e = hipIpcOpenMemHandle(&q, w.mem, hipIpcMemLazyEnablePeerAccess);
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
-      return fail(std::string("hipIpcOpenMemHandle (rank ") + std::to_string(r) + "): " + hipGetErrorString(e));
-    }
-    pp->opened[r] = q;
-    peers[r] = (double*)q;
-  }
-  if (hipMemcpy(pp->peers_dev, peers.data(), (size_t)W * sizeof(double*), hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy (p2p peer table) failed");
-  pp->mapped = true;
-  return CA_OK;
-}
-
-// Phase 2, collective: all_ranks_ok = 1 only if ca_p2p_connect returned CA_OK on EVERY rank (the caller's control plane says
-// so).  Then the transport becomes the engine's all-reduce and the setup sums are reduced -- the first call that waits for
-// peers.  all_ranks_ok = 0: the mappings are dropped and the engine is left without a transport (next: ca_comm_init).
-int ca_p2p_commit(ca_handle h, int32_t all_ranks_ok) {
-  if (!h) return CA_ERR_INVALID;
-  if (!h->p2p) { h->err = "ca_p2p_commit before ca_p2p_export"; return CA_ERR_STATE; }
-  HIPCK(h, hipSetDevice(h->device));
-  ca_p2p* pp = h->p2p;
-  if (!all_ranks_ok) { p2p_unmap(pp); pp->connected = false; return CA_OK; }
-  if (!pp->mapped) { h->err = "ca_p2p_commit(1) without a successful ca_p2p_connect on this rank"; return CA_ERR_STATE; }
-  pp->connected = true;
-  return setup_global_sums(h);
-}
-
-// Times n_calls all-reduces of n_doubles doubles on one of the engine's device transports, back to back on the engine's stream
-// (HIP events around the batch).  Collective: every rank calls it with the same arguments.  The buffer is scratch.
-int ca_comm_benchmark(ca_handle h, int32_t transport, int32_t n_calls, int64_t n_doubles, double* us_per_call) {
-  if (!h || !us_per_call || n_calls < 1 || n_doubles < 1) return CA_ERR_INVALID;
-  HIPCK(h, hipSetDevice(h->device));
-  const bool want_p2p = transport == CA_TRANSPORT_P2P;
-  if (want_p2p && !(h->p2p && h->p2p->connected)) { h->err = "ca_comm_benchmark: no committed peer-to-peer transport"; return CA_ERR_STATE; }
-  if (transport == CA_TRANSPORT_RCCL && !h->comm) { h->err = "ca_comm_benchmark: no RCCL communicator (ca_comm_init)"; return CA_ERR_STATE; }
-  if (!want_p2p && transport != CA_TRANSPORT_RCCL) { h->err = "ca_comm_benchmark: transport must be CA_TRANSPORT_P2P or CA_TRANSPORT_RCCL"; return CA_ERR_INVALID; }
-  double* buf = nullptr;
-  HIPCK(h, hipMalloc((void**)&buf, (size_t)n_doubles * sizeof(double)));
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  auto cleanup = [&]() { if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); hipFree(buf); };
-  int rc = CA_OK;
-  // the RCCL leg runs with the peer-to-peer transport hidden from allreduce()
-  const bool was = h->p2p && h->p2p->connected;
-  if (!want_p2p && was) h->p2p->connected = false;
-  auto run = [&]() -> int {
-    HIPCK(h, hipMemsetAsync(buf, 0, (size_t)n_doubles * sizeof(double), h->stream));
-    HIPCK(h, hipEventCreate(&e0)); HIPCK(h, hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) CACK(allreduce(h, buf, n_doubles));   // warm-up (RCCL builds its channels on first use)
-    HIPCK(h, hipEventRecord(e0, h->stream));
-    for (int i = 0; i < n_calls; ++i) CACK(allreduce(h, buf, n_doubles));
-    HIPCK(h, hipEventRecord(e1, h->stream));
-    HIPCK(h, hipStreamSynchronize(h->stream));
-    CACK(comm_check(h));
-    float ms = 0.f;
-    HIPCK(h, hipEventElapsedTime(&ms, e0, e1));
-    *us_per_call = (double)ms * 1e3 / n_calls;
-    return CA_OK;
-  };
-  rc = run();
-  if (!want_p2p && was) h->p2p->connected = true;
-  cleanup();
-  return rc;
-}
-
-int ca_comm_selftest(ca_handle h, int32_t n_rounds, int64_t n_doubles, int64_t* n_bad) {
-  if (!h || !n_bad || n_rounds < 1 || n_doubles < 1) return CA_ERR_INVALID;
-  HIPCK(h, hipSetDevice(h->device));
-  *n_bad = 0;
-  const double W = (double)std::max(h->opt.world, 1), tri = W * (W + 1.0) / 2.0;
-  double* buf = nullptr;
-  HIPCK(h, hipMalloc((void**)&buf, (size_t)n_doubles * sizeof(double)));
-  std::vector<double> host((size_t)n_doubles);
-  int rc = CA_OK;
-  auto pattern = [](int64_t i, int r) { return (double)((i * 7 + (int64_t)r * 13) % 251 + 1); };
-  auto run = [&]() -> int {
-    for (int r = 0; r < n_rounds; ++r) {
-      for (int64_t i = 0; i < n_doubles; ++i) host[(size_t)i] = (double)(h->opt.rank + 1) * pattern(i, r) + 0.5 * r;
-      HIPCK(h, hipMemcpyAsync(buf, host.data(), (size_t)n_doubles * sizeof(double), hipMemcpyHostToDevice, h->stream));
-      CACK(allreduce(h, buf, n_doubles));
-      HIPCK(h, hipMemcpyAsync(host.data(), buf, (size_t)n_doubles * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-      SYNC(h);
-      for (int64_t i = 0; i < n_doubles; ++i)
-        if (host[(size_t)i] != tri * pattern(i, r) + W * 0.5 * r) *n_bad += 1;
-    }
-    return CA_OK;
-  };
-  rc = run();
-  hipFree(buf);
-  if (rc == CA_OK && *n_bad) h->err = "all-reduce known-answer test: " + std::to_string(*n_bad) + " of " + std::to_string((int64_t)n_rounds * n_doubles) + " sums are wrong";
-  return rc;
-}
-
-int ca_set_host_allreduce(ca_handle h, ca_host_allreduce_fn fn, void* user) {
-  if (!h || !fn) return CA_ERR_INVALID;
-  CACK(comm_check(h));
-  HIPCK(h, hipSetDevice(h->device));
-  h->host_ar = fn;
-  h->host_ar_user = user;
-  return setup_global_sums(h);
-}
-
-static int stage_one(ca_handle h, const float* eps) { return stage_eps(h, eps, 1, 1); }
-
-int ca_gamma_init(ca_handle h, const float* eps) {
-  if (!h) return CA_ERR_INVALID;
-  HIPCK(h, hipSetDevice(h->device));
-  CACK(stage_one(h, eps));
-  CACK(run_pass(h, 0, CA_MODE_GINIT, 0, nullptr));
-  SYNC(h);
-  return CA_OK;
-}
-
-int ca_elbo(ca_handle h, const float* eps, double* elbo) {
-  if (!h || !elbo) return CA_ERR_INVALID;
-  HIPCK(h, hipSetDevice(h->device));
-  CACK(stage_one(h, eps));
-  CACK(run_pass(h, 0, CA_MODE_ELBO, 0, h->elbo_dev));
-  return read_doubles(h, h->elbo_dev, elbo, 1);
-}
-
-int ca_elbo_terms(ca_handle h, const float* eps, double terms[3]) {
-  if (!h || !terms) return CA_ERR_INVALID;
-  HIPCK(h, hipSetDevice(h->device));
-  CACK(stage_one(h, eps));
-  CACK(run_pass(h, 0, CA_MODE_ELBO, 0, h->elbo_dev));
-  return read_doubles(h, h->terms_dev, terms, 3);
-}
-
-int ca_step(ca_handle h, const float* eps) {
-  if (!h) return CA_ERR_INVALID;
-  HIPCK(h, hipSetDevice(h->device));
-  CACK(stage_one(h, eps));
-  CACK(run_pass(h, 0, CA_MODE_TRAIN, 1, h->elbo_dev));
-  SYNC(h);
-  return CA_OK;
-}
-
-int ca_gradients(ca_handle h, const float* eps, double* elbo) {
-  if (!h) return CA_ERR_INVALID;
-  HIPCK(h, hipSetDevice(h->device));
-  CACK(stage_one(h, eps));
-  CACK(run_pass(h, 0, CA_MODE_TRAIN, 0, h->elbo_dev));
-  double e;
-  CACK(read_doubles(h, h->elbo_dev, &e, 1));
-  if (elbo) *elbo = e;
-  return CA_OK;
-}
-
 // ca_run's gated update: what the host's bookkeeping of a step changes (train_from_lookahead + the merged branch of train_update) -- taken before
 // the launch is queued, put back when the host's answer is "stop" (the launch then stores nothing)
 struct gate_snapshot {
@@ -2882,19 +2508,468 @@ inline void gate_answer(ca_engine* h, int go) {
   *w = (h->gate_seq << 1) | (unsigned long long)(go ? 1 : 0);
   std::atomic_thread_fence(std::memory_order_seq_cst);
 }
+// Answer the gated launch and learn what it DID: 1 = it ran (the answer was "go" and reached the relay block in time), 0 = it stored nothing
+// (answer "stop", or the relay had given up before the answer came: a slow poll hook, a descheduled or stopped host).  The relay's clock
+// starts no earlier than gate_t0, so an answer written within half its patience has been seen; otherwise its verdict is read from the
+// pinned word it leaves (it always leaves one: it either sees the answer or runs out of patience).  Negative: an error (stream failure).
+int gate_resolve(ca_engine* h, int go) {
+  gate_answer(h, go);
+  if (!go) return 0;
+  const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h->gate_t0).count();
+  if (us < 0.5 * (double)h->gate_ticks / 100.0) return 1;
+  volatile unsigned long long* ack = reinterpret_cast<volatile unsigned long long*>(h->host_pinned + 56);
+  unsigned spins = 0;
+  auto t_next = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+  for (;;) {
+    const unsigned long long a = *ack;
+    if ((a >> 2) == h->gate_seq) return (a & 3ull) == 1ull ? 1 : 0;
+    if ((++spins & 0x3FFu) == 0 && std::chrono::steady_clock::now() >= t_next) {   // (the launch may still be waiting for its turn: a big backward sweep, a co-tenant)
+      t_next = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+      const hipError_t q = hipStreamQuery(h->stream);
+      if (q == hipSuccess) {
+        const unsigned long long a2 = *ack;
+        if ((a2 >> 2) == h->gate_seq) return (a2 & 3ull) == 1ull ? 1 : 0;
+        h->err = "ca_run: the gated update completed without leaving its verdict";
+        return -CA_ERR_STATE;
+      }
+      if (q != hipErrorNotReady) { h->err = std::string("hipStreamQuery: ") + hipGetErrorString(q); return -CA_ERR_HIP; }
+    }
+  }
+}
+// A poll hook (or anything else on this thread) enters a read-only API call while a gated launch waits for the host: close the window first -- answer
+// "store nothing", wait for the stream (the launch ends at once), put the host's bookkeeping of the queued step back.  ca_run then sees gate_aborted
+// and queues the update again after its decision (the lock-step order); the variables a hook reads are those after the last completed iteration.
+int gate_close(ca_engine* h) {
+  if (!h->gate_open) return CA_OK;
+  h->gate_open = false; h->gate_aborted = true;
+  gate_answer(h, 0);
+  HIPCK(h, hipStreamSynchronize(h->stream));
+  if (h->gate_fsnap) h->gate_fsnap->restore(h);
+  if (h->gate_snap) h->gate_snap->restore(h);
+  return CA_OK;
+}
+#define CA_NOT_IN_RUN(h)                                                                                                                  \
+  do {                                                                                                                                    \
+    if ((h) && (h)->in_run) {                                                                                                             \
+      (h)->err = "this call changes the engine's state and cannot be made from a ca_run_ex poll hook (read-only calls can: ca_get_param, " \
+                 "ca_get_gradient, ca_get_info, ca_synchronize, ca_get_kernel_times)";                                                   \
+      return CA_ERR_STATE;                                                                                                                \
+    }                                                                                                                                     \
+  } while (0)
+
+
+extern "C" {
+
+int ca_abi_version(void) { return CA_ABI_VERSION; }
+#ifdef CA_LAB   // timing-lab builds only: readers of the block stamps (tools/lab/)
+#include "../../tools/lab/ca_lab_host.inc"
+#endif
+#ifndef CA_BUILD_ID
+#define CA_BUILD_ID "unknown"
+#endif
+#ifdef CA_LAB
+const char* ca_build_id(void) { return "lab-" CA_BUILD_ID; }   // never the tree's id: bench.py and the tests refuse a lab build
+#else
+const char* ca_build_id(void) { return CA_BUILD_ID; }
+#endif
+
+int ca_device_count(int32_t* n) {
+  int c = 0;
+  const hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) { (void)hipGetLastError(); c = 0; }
+  if (n) *n = c;
+  return e == hipSuccess ? CA_OK : CA_ERR_HIP;
+}
+
+int ca_default_options(ca_options* o) {
+  if (!o) return CA_ERR_INVALID;
+  memset(o, 0, sizeof(*o));
+  o->learning_rate = 0.1;
+  o->beta1 = 0.9; o->beta2 = 0.999; o->adam_eps = 1e-8;
+  o->seed = 0x5eed5eedull;
+  o->device = 0; o->y_storage = CA_YSTORE_AUTO; o->rank = 0; o->world = 1; o->profile = 0;
+  return CA_OK;
+}
+
+const char* ca_last_error(ca_handle h) { return h ? h->err.c_str() : g_last_error.c_str(); }
+
+int ca_create(const ca_problem* p, const ca_options* o, ca_handle* out) {
+  g_last_error.clear();
+  if (!p || !out) { g_last_error = "null argument"; return CA_ERR_INVALID; }
+  *out = nullptr;
+  ca_options opt;
+  if (o) opt = *o; else ca_default_options(&opt);
+  auto bad = [&](const char* m) { g_last_error = m; return CA_ERR_INVALID; };
+  if (p->N <= 0 || p->G <= 0 || p->C <= 0) return bad("N, G and C must be positive");
+  if (p->C > 256) return bad("C > 256 clones not supported");
+  if (p->K < 0 || p->P < 0 || p->S < 1) return bad("K >= 0, P >= 0, S >= 1 required");
+  const int D = p->K > 0 ? p->K + p->P : 0;
+  if (D > 8) return bad("K + P > 8 not supported");
+  if (!p->Y || !p->L) return bad("Y and L are required");
+  if (!p->loc0 && opt.world > 1) return bad("loc0 = NULL (data-driven initialisation on the device) needs all cells: pass loc0 when world > 1");
+  if (p->K > 0 && !p->psi0) return bad("psi0 is required when K > 0");
+  if (p->P > 0 && !p->X) return bad("X is required when P > 0");
+  if (opt.world < 1 || opt.rank < 0 || opt.rank >= opt.world) return bad("bad rank/world");
+  if ((p->cell_index || p->gene_index) && (p->N_src < p->N || p->G_src < p->G)) return bad("N_src / G_src must be at least N / G when a selection is given");
+  ca_engine* h = new ca_engine();
+  h->N = p->N; h->G = p->G; h->C = p->C; h->K = p->K; h->P = p->P; h->S = p->S; h->D = D;
+  h->layout = p->layout; h->opt = opt; h->device = opt.device;
+  int rc = create_impl(h, p);
+  if (rc != CA_OK) {
+    g_last_error = h->err;
+    ca_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return CA_OK;
+}
+
+int ca_destroy(ca_handle h) {
+  if (!h) return CA_OK;
+  CA_NOT_IN_RUN(h);
+  hipSetDevice(h->device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
+  if (h->ev_params) hipEventDestroy(h->ev_params);
+  if (h->ev_ydone) hipEventDestroy(h->ev_ydone);
+  if (h->ev_ywdone) hipEventDestroy(h->ev_ywdone);
+  if (h->ev_stage) hipEventDestroy(h->ev_stage);
+  if (h->comm) g_rccl.CommDestroy(h->comm);
+  if (h->p2p) {
+    for (void* q : h->p2p->opened) if (q) hipIpcCloseMemHandle(q);
+    if (h->p2p->err_host) hipHostFree(h->p2p->err_host);
+    if (h->p2p->err_local) hipFree(h->p2p->err_local);
+    if (h->p2p->slab) hipFree(h->p2p->slab);
+    if (h->p2p->peers_dev) hipFree(h->p2p->peers_dev);
+    delete h->p2p;
+  }
+  for (auto& e : h->ev_pool) { hipEventDestroy(e.a); hipEventDestroy(e.b); }
+  for (void* q : h->allocs) hipFree(q);
+  if (h->eps_dev) hipFree(h->eps_dev);
+  if (h->elbo_dev) hipFree(h->elbo_dev);
+  if (h->host_pinned) hipHostFree(h->host_pinned);
+  if (h->eps_stage) hipHostFree(h->eps_stage);
+  if (h->host_ar_buf) hipHostFree(h->host_ar_buf);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+  return CA_OK;
+}
+
+int ca_get_info(ca_handle h, ca_info* i) {
+  if (!h || !i) return CA_ERR_INVALID;
+  memset(i, 0, sizeof(*i));
+  i->N = h->N; i->G = h->G; i->C = h->C; i->K = h->K; i->P = h->P; i->S = h->S;
+  i->y_storage = h->ystore; i->y_bytes_per_elem = h->ybytes; i->y_device_bytes = h->y_dev_bytes; i->device_bytes = h->dev_bytes;
+  i->gsplit = h->gsplit; i->csplit = h->csplit; i->n_cu = h->n_cu; i->fused_sweep = h->fused_ok ? 1 : 0;
+  i->fwd_mfma = (h->fused_ok && h->fwd_mfma) ? 1 : 0; i->bwd_mfma = h->bwd_mfma ? 1 : 0; i->fsplit = h->fsplit; i->fwd_cell = (h->fused_ok && h->fwd_cell) ? 1 : 0;
+  i->y_mfma = h->y_ys ? 2 : h->y_mfma ? 1 : 0;
+  i->y_ride = (h->ride_ok || h->ride_ys) ? 1 : 0;
+  i->transport = (h->p2p && h->p2p->connected) ? CA_TRANSPORT_P2P : h->comm ? CA_TRANSPORT_RCCL : h->host_ar ? CA_TRANSPORT_HOST : CA_TRANSPORT_NONE;
+  i->red_n = h->red_n;
+  i->fwd_block_cells = (h->fused_ok && h->fwd_cell) ? 16 * h->fc_tl : 0; i->fwd_blocks_big = h->fc_nbig;
+  i->fold_gsum = (h->fold_gsum && !is_sharded(h)) ? 1 : 0; i->yfin_split = (h->yfin_split && !is_sharded(h)) ? 1 : 0;
+  i->update_merge = (h->upd_merge && h->fused_ok && h->fwd_cell && h->K > 0) ? 1 : 0;
+  return CA_OK;
+}
+
+int ca_stream_busy(ca_handle h, int32_t* busy) {
+  if (!h || !busy) return CA_ERR_INVALID;
+  const hipError_t q = hipStreamQuery(h->stream);
+  if (q != hipSuccess && q != hipErrorNotReady) HIPCK(h, q);
+  *busy = q == hipErrorNotReady ? 1 : 0;
+  if (q == hipErrorNotReady) (void)hipGetLastError();
+  return CA_OK;
+}
+
+int ca_synchronize(ca_handle h) {
+  if (!h) return CA_ERR_INVALID;
+  HIPCK(h, hipSetDevice(h->device));
+  CACK(gate_close(h));   // (called from a ca_run_ex poll hook while a gated launch waits: close that window first)
+  SYNC(h);
+  return CA_OK;
+}
+
+int ca_comm_unique_id(char id[128]) {
+  if (!g_rccl.load()) { g_last_error = g_rccl.err; return CA_ERR_COMM; }
+  ca_nccl_uid u;
+  int rc = g_rccl.GetUniqueId(&u);
+  if (rc != 0) { g_last_error = "ncclGetUniqueId failed"; return CA_ERR_COMM; }
+  memcpy(id, u.internal, 128);
+  return CA_OK;
+}
+
+int ca_comm_init(ca_handle h, const char id[128]) {
+  if (!h || !id) return CA_ERR_INVALID;
+  CA_NOT_IN_RUN(h);
+  CACK(comm_check(h));   // a peer-to-peer transport that timed out leaves the engine dead: no falling back on the same handle
+  if (!g_rccl.load()) { h->err = g_rccl.err; return CA_ERR_COMM; }
+  HIPCK(h, hipSetDevice(h->device));
+  ca_nccl_uid u;
+  memcpy(u.internal, id, 128);
+  int rc = g_rccl.CommInitRank(&h->comm, h->opt.world, u, h->opt.rank);
+  if (rc != 0) {
+    h->err = std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error");
+    h->comm = nullptr;
+    return CA_ERR_COMM;
+  }
+  return setup_global_sums(h);
+}
+
+int ca_p2p_export(ca_handle h, char handle[CA_P2P_HANDLE_BYTES]) {
+  if (!h || !handle) return CA_ERR_INVALID;
+  CA_NOT_IN_RUN(h);
+  HIPCK(h, hipSetDevice(h->device));
+  if (h->opt.world > CA_TB) { h->err = "peer-to-peer transport: at most " + std::to_string(CA_TB) + " ranks (one flag lane per rank)"; return CA_ERR_COMM; }
+  if (!h->p2p) {
+    ca_p2p* pp = new ca_p2p();
+    const int W = h->opt.world;
+    // room for everything one call reduces: the train pass's summands, the setup sums, the PCA / correlation packs
+    pp->cap = std::max<int64_t>(std::max<int64_t>(h->red_n, (int64_t)h->G * (h->C + 2) + 64), 4096);
+    pp->slab_bytes = (size_t)2 * W * pp->cap * 16;   // [parity 2][source W][cap] entries of 16 bytes: two halves of a double, each with the call's tag (k_p2p_allreduce)
+    // Fine-grained memory or nothing: the slab is written by remote peers over xGMI and polled here, which ordinary
+    // (coarse-grained) device memory does not keep coherent -- a stale flag would be a hang or a wrong sum.  The caller moves
+    // on to RCCL when this fails.
+    if (hipExtMallocWithFlags((void**)&pp->slab, pp->slab_bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+      (void)hipGetLastError();
+      delete pp;
+      h->err = "peer-to-peer transport: fine-grained device memory unavailable (hipExtMallocWithFlags(hipDeviceMallocFinegrained) failed)";
+      return CA_ERR_COMM;
+    }
+    auto fail = [&](const std::string& m) { if (pp->err_host) hipHostFree(pp->err_host); if (pp->err_local) hipFree(pp->err_local); if (pp->peers_dev) hipFree(pp->peers_dev);
+                                            hipFree(pp->slab); delete pp; h->err = m; return CA_ERR_HIP; };
+    if (hipMemset(pp->slab, 0, pp->slab_bytes) != hipSuccess) return fail("hipMemset of the p2p slab failed");
+    if (hipMalloc((void**)&pp->peers_dev, (size_t)W * sizeof(double*)) != hipSuccess) return fail("hipMalloc (p2p peer table) failed");
+    if (hipMalloc((void**)&pp->err_local, sizeof(unsigned int)) != hipSuccess) return fail("hipMalloc (p2p error flag) failed");
+    if (hipMemset(pp->err_local, 0, sizeof(unsigned int)) != hipSuccess) return fail("hipMemset (p2p error flag) failed");
+    if (hipDeviceSynchronize() != hipSuccess) return fail("hipDeviceSynchronize (p2p setup) failed");   // (NULL-stream memsets are not ordered against the engine's non-blocking stream)
+    if (hipHostMalloc((void**)&pp->err_host, sizeof(unsigned long long), hipHostMallocMapped) != hipSuccess) return fail("hipHostMalloc (p2p error word) failed");
+    *pp->err_host = 0ull;
+    if (hipHostGetDevicePointer((void**)&pp->err_dev, pp->err_host, 0) != hipSuccess) return fail("hipHostGetDevicePointer (p2p error word) failed");
+    const int ms = h->opt.comm_timeout_ms > 0 ? h->opt.comm_timeout_ms : 10000;
+    pp->timeout_ticks = (unsigned long long)ms * 100000ull;   // s_memrealtime counts at 100 MHz
+    h->p2p = pp;
+  }
+  ca_p2p_wire w;
+  memset(&w, 0, sizeof(w));
+  HIPCK(h, hipIpcGetMemHandle(&w.mem, h->p2p->slab));
+  w.cap = h->p2p->cap; w.rank = h->opt.rank; w.world = h->opt.world; w.device = h->device; w.pid = (int32_t)getpid();
+  w.local_ptr = (uint64_t)(uintptr_t)h->p2p->slab;
+  memset(handle, 0, CA_P2P_HANDLE_BYTES);
+  memcpy(handle, &w, sizeof(w));
+  return CA_OK;
+}
+
+static void p2p_unmap(ca_p2p* pp) {
+  for (void*& q : pp->opened) if (q) { hipIpcCloseMemHandle(q); q = nullptr; }
+  (void)hipGetLastError();
+  pp->mapped = false;
+}
+
+// Phase 1: map every peer's slab.  Touches no peer and launches nothing, so a rank whose peer failed does not end up waiting for
+// it: the caller agrees on every rank's result over its control plane and then calls ca_p2p_commit on all ranks.
+int ca_p2p_connect(ca_handle h, const char* handles) {
+  if (!h || !handles) return CA_ERR_INVALID;
+  CA_NOT_IN_RUN(h);
+  if (!h->p2p) { h->err = "ca_p2p_connect before ca_p2p_export"; return CA_ERR_STATE; }
+  if (!variant_on(h, CA_VAR_P2P, "CA_P2P")) { h->err = "peer-to-peer transport switched off (CA_VAR_P2P)"; return CA_ERR_COMM; }
+  HIPCK(h, hipSetDevice(h->device));
+  ca_p2p* pp = h->p2p;
+  if (pp->connected) { h->err = "ca_p2p_connect: the transport is already committed"; return CA_ERR_STATE; }
+  const int W = h->opt.world;
+  std::vector<double*> peers((size_t)W, nullptr);
+  p2p_unmap(pp);
+  pp->opened.assign((size_t)W, nullptr);
+  auto fail = [&](const std::string& m) { p2p_unmap(pp); h->err = m; return CA_ERR_COMM; };
+  for (int r = 0; r < W; ++r) {
+    ca_p2p_wire w;
+    memcpy(&w, handles + (size_t)r * CA_P2P_HANDLE_BYTES, sizeof(w));
+    if (w.rank != r || w.world != W || w.cap != pp->cap)
+      return fail("p2p handle " + std::to_string(r) + " does not match this problem (rank / world / payload size)");
+    if (r == h->opt.rank) { peers[r] = pp->slab; continue; }
+    if (w.device != h->device) {
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, h->device, w.device) != hipSuccess || !can) {
+        (void)hipGetLastError();
+        return fail("no peer access from device " + std::to_string(h->device) + " to device " + std::to_string(w.device));
+      }
+      const hipError_t e = hipDeviceEnablePeerAccess(w.device, 0);
+      (void)hipGetLastError();
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) return fail(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e));
+    }
+    if (w.pid == (int32_t)getpid()) {   // a handle of THIS process (one R session driving several devices): the slab's own address
+      // ... but not two ranks of one process on ONE device: the runtime's device-wide synchronising calls (hipFree, hipMalloc of
+      // a grown eps buffer, ...) made for one handle wait for every kernel on the device, also the other handle's all-reduce
+      // kernel -- which waits for this rank.  Measured: the second all-reduce of such a pair ran into the device-side time
+      // limit (tests/test_gpu_sharding.py).  Separate processes sharing a device are fine (their runtimes do not see each other).
+      if (w.device == h->device && !(h->opt.variant_on & CA_VARX_P2P_SAME_DEVICE))
+        return fail("peer-to-peer transport: ranks " + std::to_string(h->opt.rank) + " and " + std::to_string(r) + " are handles of one process on one "
+                    "device; use one rank per device (or one process per rank)");
+      peers[r] = (double*)(uintptr_t)w.local_ptr;
+      continue;
+    }
+    void* q = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&q, w.mem, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      return fail(std::string("hipIpcOpenMemHandle (rank ") + std::to_string(r) + "): " + hipGetErrorString(e));
+    }
+    pp->opened[r] = q;
+    peers[r] = (double*)q;
+  }
+  if (hipMemcpy(pp->peers_dev, peers.data(), (size_t)W * sizeof(double*), hipMemcpyHostToDevice) != hipSuccess) return fail("hipMemcpy (p2p peer table) failed");
+  pp->mapped = true;
+  return CA_OK;
+}
+
+// Phase 2, collective: all_ranks_ok = 1 only if ca_p2p_connect returned CA_OK on EVERY rank (the caller's control plane says
+// so).  Then the transport becomes the engine's all-reduce and the setup sums are reduced -- the first call that waits for
+// peers.  all_ranks_ok = 0: the mappings are dropped and the engine is left without a transport (next: ca_comm_init).
+int ca_p2p_commit(ca_handle h, int32_t all_ranks_ok) {
+  if (!h) return CA_ERR_INVALID;
+  CA_NOT_IN_RUN(h);
+  if (!h->p2p) { h->err = "ca_p2p_commit before ca_p2p_export"; return CA_ERR_STATE; }
+  HIPCK(h, hipSetDevice(h->device));
+  ca_p2p* pp = h->p2p;
+  if (!all_ranks_ok) { p2p_unmap(pp); pp->connected = false; return CA_OK; }
+  if (!pp->mapped) { h->err = "ca_p2p_commit(1) without a successful ca_p2p_connect on this rank"; return CA_ERR_STATE; }
+  pp->connected = true;
+  return setup_global_sums(h);
+}
+
+// Times n_calls all-reduces of n_doubles doubles on one of the engine's device transports, back to back on the engine's stream
+// (HIP events around the batch).  Collective: every rank calls it with the same arguments.  The buffer is scratch.
+int ca_comm_benchmark(ca_handle h, int32_t transport, int32_t n_calls, int64_t n_doubles, double* us_per_call) {
+  if (!h || !us_per_call || n_calls < 1 || n_doubles < 1) return CA_ERR_INVALID;
+  CA_NOT_IN_RUN(h);
+  HIPCK(h, hipSetDevice(h->device));
+  const bool want_p2p = transport == CA_TRANSPORT_P2P;
+  if (want_p2p && !(h->p2p && h->p2p->connected)) { h->err = "ca_comm_benchmark: no committed peer-to-peer transport"; return CA_ERR_STATE; }
+  if (transport == CA_TRANSPORT_RCCL && !h->comm) { h->err = "ca_comm_benchmark: no RCCL communicator (ca_comm_init)"; return CA_ERR_STATE; }
+  if (!want_p2p && transport != CA_TRANSPORT_RCCL) { h->err = "ca_comm_benchmark: transport must be CA_TRANSPORT_P2P or CA_TRANSPORT_RCCL"; return CA_ERR_INVALID; }
+  double* buf = nullptr;
+  HIPCK(h, hipMalloc((void**)&buf, (size_t)n_doubles * sizeof(double)));
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  auto cleanup = [&]() { if (e0) hipEventDestroy(e0); if (e1) hipEventDestroy(e1); hipFree(buf); };
+  int rc = CA_OK;
+  // the RCCL leg runs with the peer-to-peer transport hidden from allreduce()
+  const bool was = h->p2p && h->p2p->connected;
+  if (!want_p2p && was) h->p2p->connected = false;
+  auto run = [&]() -> int {
+    HIPCK(h, hipMemsetAsync(buf, 0, (size_t)n_doubles * sizeof(double), h->stream));
+    HIPCK(h, hipEventCreate(&e0)); HIPCK(h, hipEventCreate(&e1));
+    for (int i = 0; i < 3; ++i) CACK(allreduce(h, buf, n_doubles));   // warm-up (RCCL builds its channels on first use)
+    HIPCK(h, hipEventRecord(e0, h->stream));
+    for (int i = 0; i < n_calls; ++i) CACK(allreduce(h, buf, n_doubles));
+    HIPCK(h, hipEventRecord(e1, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    CACK(comm_check(h));
+    float ms = 0.f;
+    HIPCK(h, hipEventElapsedTime(&ms, e0, e1));
+    *us_per_call = (double)ms * 1e3 / n_calls;
+    return CA_OK;
+  };
+  rc = run();
+  if (!want_p2p && was) h->p2p->connected = true;
+  cleanup();
+  return rc;
+}
+
+int ca_comm_selftest(ca_handle h, int32_t n_rounds, int64_t n_doubles, int64_t* n_bad) {
+  if (!h || !n_bad || n_rounds < 1 || n_doubles < 1) return CA_ERR_INVALID;
+  CA_NOT_IN_RUN(h);
+  HIPCK(h, hipSetDevice(h->device));
+  *n_bad = 0;
+  const double W = (double)std::max(h->opt.world, 1), tri = W * (W + 1.0) / 2.0;
+  double* buf = nullptr;
+  HIPCK(h, hipMalloc((void**)&buf, (size_t)n_doubles * sizeof(double)));
+  std::vector<double> host((size_t)n_doubles);
+  int rc = CA_OK;
+  auto pattern = [](int64_t i, int r) { return (double)((i * 7 + (int64_t)r * 13) % 251 + 1); };
+  auto run = [&]() -> int {
+    for (int r = 0; r < n_rounds; ++r) {
+      for (int64_t i = 0; i < n_doubles; ++i) host[(size_t)i] = (double)(h->opt.rank + 1) * pattern(i, r) + 0.5 * r;
+      HIPCK(h, hipMemcpyAsync(buf, host.data(), (size_t)n_doubles * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      CACK(allreduce(h, buf, n_doubles));
+      HIPCK(h, hipMemcpyAsync(host.data(), buf, (size_t)n_doubles * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+      SYNC(h);
+      for (int64_t i = 0; i < n_doubles; ++i)
+        if (host[(size_t)i] != tri * pattern(i, r) + W * 0.5 * r) *n_bad += 1;
+    }
+    return CA_OK;
+  };
+  rc = run();
+  hipFree(buf);
+  if (rc == CA_OK && *n_bad) h->err = "all-reduce known-answer test: " + std::to_string(*n_bad) + " of " + std::to_string((int64_t)n_rounds * n_doubles) + " sums are wrong";
+  return rc;
+}
+
+int ca_set_host_allreduce(ca_handle h, ca_host_allreduce_fn fn, void* user) {
+  if (!h || !fn) return CA_ERR_INVALID;
+  CA_NOT_IN_RUN(h);
+  CACK(comm_check(h));
+  HIPCK(h, hipSetDevice(h->device));
+  h->host_ar = fn;
+  h->host_ar_user = user;
+  return setup_global_sums(h);
+}
+
+static int stage_one(ca_handle h, const float* eps) { return stage_eps(h, eps, 1, 1); }
+
+int ca_gamma_init(ca_handle h, const float* eps) {
+  if (!h) return CA_ERR_INVALID;
+  CA_NOT_IN_RUN(h);
+  HIPCK(h, hipSetDevice(h->device));
+  CACK(stage_one(h, eps));
+  CACK(run_pass(h, 0, CA_MODE_GINIT, 0, nullptr));
+  SYNC(h);
+  return CA_OK;
+}
+
+int ca_elbo(ca_handle h, const float* eps, double* elbo) {
+  if (!h || !elbo) return CA_ERR_INVALID;
+  CA_NOT_IN_RUN(h);
+  HIPCK(h, hipSetDevice(h->device));
+  CACK(stage_one(h, eps));
+  CACK(run_pass(h, 0, CA_MODE_ELBO, 0, h->elbo_dev));
+  return read_doubles(h, h->elbo_dev, elbo, 1);
+}
+
+int ca_elbo_terms(ca_handle h, const float* eps, double terms[3]) {
+  if (!h || !terms) return CA_ERR_INVALID;
+  CA_NOT_IN_RUN(h);
+  HIPCK(h, hipSetDevice(h->device));
+  CACK(stage_one(h, eps));
+  CACK(run_pass(h, 0, CA_MODE_ELBO, 0, h->elbo_dev));
+  return read_doubles(h, h->terms_dev, terms, 3);
+}
+
+int ca_step(ca_handle h, const float* eps) {
+  if (!h) return CA_ERR_INVALID;
+  CA_NOT_IN_RUN(h);
+  HIPCK(h, hipSetDevice(h->device));
+  CACK(stage_one(h, eps));
+  CACK(run_pass(h, 0, CA_MODE_TRAIN, 1, h->elbo_dev));
+  SYNC(h);
+  return CA_OK;
+}
+
+int ca_gradients(ca_handle h, const float* eps, double* elbo) {
+  if (!h) return CA_ERR_INVALID;
+  CA_NOT_IN_RUN(h);
+  HIPCK(h, hipSetDevice(h->device));
+  CACK(stage_one(h, eps));
+  CACK(run_pass(h, 0, CA_MODE_TRAIN, 0, h->elbo_dev));
+  double e;
+  CACK(read_doubles(h, h->elbo_dev, &e, 1));
+  if (elbo) *elbo = e;
+  return CA_OK;
+}
 
 int ca_run(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_stream, int64_t n_draws, double* trace, int32_t* n_elbo) {
   return ca_run_ex(h, max_iter, rel_tol, eps_stream, n_draws, trace, n_elbo, nullptr, nullptr);
 }
 
-int ca_run_ex(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_stream, int64_t n_draws, double* trace, int32_t* n_elbo,
-              ca_poll_fn poll, void* user) {
-  if (!h || !trace || !n_elbo || max_iter < 0) return CA_ERR_INVALID;
-  HIPCK(h, hipSetDevice(h->device));
-  const int64_t need = 2 + 2 * (int64_t)max_iter;
-  CACK(stage_eps(h, eps_stream, n_draws, need));
-  CACK(ensure_elbo_cap(h, 1 + (int64_t)max_iter));
-  *n_elbo = 0;
+static int run_loop(ca_engine* h, int32_t max_iter, double rel_tol, double* trace, int32_t* n_elbo, ca_poll_fn poll, void* user) {
   CACK(run_pass(h, 0, CA_MODE_GINIT, 0, nullptr));                      // :368-369
   h->host_seq_next = ++h->host_seq;
   CACK(monitor_pass(h, 1, max_iter >= 1 ? 2 : -1, h->elbo_dev));        // :372 (+ forward half of the first train pass)
@@ -2911,10 +2986,14 @@ int ca_run_ex(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_st
   // Round 4: the host's look at every ELBO no longer costs a launch and a round trip.  Until now an iteration of this loop was ... backward sweep,
   // k_final_small (the ELBO, 7.4 us), THEN the host read it, decided, and only then queued the update (11 us of idle GPU: tools/gaps.py on the
   // bench trace) -- 19 us per iteration that ca_iterate does not pay.  Now the update half of train pass i + 1 is queued right behind the
-  // backward sweep: its monitor block assembles ELBO i and mirrors it to the host, every other block waits on the device for the word the host
-  // writes once it has decided (ca_merge_args::gate).  "Stop" (tolerance, poll hook, NaN) makes the queued launch a no-op and the host takes
-  // back the bookkeeping of the step it had queued: the state is what the lock-step loop leaves, bit for bit (tests).
-  bool queued = false;   // the update half of train pass i was queued (gated, answered "go") by the previous turn of the loop
+  // backward sweep: its monitor block assembles ELBO i and mirrors it to the host, every other block waits on the device for the verdict of
+  // the launch's relay block, which polls the word the host writes once it has decided (ca_merge_args::gate).  "Stop" (tolerance, poll hook,
+  // NaN) makes the queued launch a no-op and the host takes back the bookkeeping of the step it had queued: the state is what the lock-step
+  // loop leaves, bit for bit (tests).
+  // Round 5: so does NO ANSWER within the relay's patience (~1 ms: a poll hook that shows a progress bar, sits in a debugger or sleeps; a
+  // descheduled or stopped process) -- the launch gives up, stores nothing, the device goes idle, and once the host has decided it queues
+  // the update again the lock-step way.  A slow hook costs that iteration the gate, never the fit (r4: CA_ERR_STATE after a 10 s GPU spin).
+  bool queued = false;   // the update half of train pass i was queued (gated, and it ran) by the previous turn of the loop
   bool fwd_queued = false;   // ... and the forward sweep of monitor pass i / train pass i + 1 behind it
   for (int i = 1; i <= max_iter; ++i) {
     if (!queued) {
@@ -2960,12 +3039,16 @@ int ca_run_ex(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_st
       if (rcf != CA_OK) { gate_answer(h, 0); fsnap.restore(h); snap.restore(h); return rcf; }
       fwd_ahead = true;
     }
+    // from here to the answer a gated launch waits on the device (at most the relay's patience): the window a re-entrant API call must close first
+    h->gate_aborted = false;
+    if (gated) { h->gate_snap = &snap; h->gate_fsnap = fwd_ahead ? &fsnap : nullptr; h->gate_open = true; }
+    auto undo = [&]() { if (h->gate_open) { h->gate_open = false; if (fwd_ahead) fsnap.restore(h); snap.restore(h); } };   // (gate_close() has done it otherwise)
     int rc = wait_host_elbo(h, seq_i, h->elbo_dev + i, &nv);
-    if (rc == CA_OK && *reinterpret_cast<volatile unsigned long long*>(h->host_pinned + 56) != 0ull) {
-      h->err = "ca_run: a gated update gave up waiting for the host's answer (launch #" + std::to_string(*reinterpret_cast<volatile unsigned long long*>(h->host_pinned + 56)) + "); the engine's state is undefined";
+    if (rc == CA_OK && *reinterpret_cast<volatile unsigned long long*>(h->host_pinned + 40) != 0ull) {
+      h->err = "ca_run: blocks of a gated update never got their relay block's verdict (launch #" + std::to_string(*reinterpret_cast<volatile unsigned long long*>(h->host_pinned + 40)) + "); the engine's state is undefined";
       rc = CA_ERR_STATE;
     }
-    if (rc != CA_OK) { if (gated) { gate_answer(h, 0); if (fwd_ahead) fsnap.restore(h); snap.restore(h); } return rc; }
+    if (rc != CA_OK) { if (gated) { gate_answer(h, 0); undo(); } return rc; }
     const double diff = (nv - val) / std::fabs(val);
     for (int j = 0; j < 9; ++j) diffs[j] = diffs[j + 1];
     diffs[9] = diff;
@@ -2979,9 +3062,13 @@ int ca_run_ex(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_st
     else if (poll && poll(user, i, nv) != 0) { h->err = "interrupted by the poll callback"; stop = CA_INTERRUPTED; }
     else if (mean < rel_tol) stop = -1;                                 // :414-415
     if (gated) {
-      gate_answer(h, stop == 0 ? 1 : 0);
-      if (stop == 0) { queued = true; fwd_queued = fwd_ahead; }
-      else { if (fwd_ahead) fsnap.restore(h); snap.restore(h); }
+      int ran = 0;
+      if (h->gate_open) {
+        ran = gate_resolve(h, stop == 0 ? 1 : 0);
+        if (ran < 0) { undo(); return -ran; }
+      }   // (else: the hook called back into the API and gate_close() answered "store nothing" and restored the bookkeeping)
+      if (ran == 1) { h->gate_open = false; queued = true; fwd_queued = fwd_ahead; }
+      else undo();   // the launch stored nothing: converged / interrupted, or the relay had given up -- then the next turn queues the update itself
     }
     if (stop > 0) return stop;
     if (stop < 0) break;
@@ -2989,8 +3076,24 @@ int ca_run_ex(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_st
   return CA_OK;
 }
 
+int ca_run_ex(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_stream, int64_t n_draws, double* trace, int32_t* n_elbo,
+              ca_poll_fn poll, void* user) {
+  if (!h || !trace || !n_elbo || max_iter < 0) return CA_ERR_INVALID;
+  CA_NOT_IN_RUN(h);
+  HIPCK(h, hipSetDevice(h->device));
+  const int64_t need = 2 + 2 * (int64_t)max_iter;
+  CACK(stage_eps(h, eps_stream, n_draws, need));
+  CACK(ensure_elbo_cap(h, 1 + (int64_t)max_iter));
+  *n_elbo = 0;
+  h->in_run = true;
+  const int rc = run_loop(h, max_iter, rel_tol, trace, n_elbo, poll, user);
+  h->in_run = false; h->gate_open = false; h->gate_snap = nullptr; h->gate_fsnap = nullptr;
+  return rc;
+}
+
 int ca_iterate(ca_handle h, int32_t n_iter, const float* eps_stream, int64_t n_draws, double* last_elbo) {
   if (!h || n_iter < 0) return CA_ERR_INVALID;
+  CA_NOT_IN_RUN(h);
   HIPCK(h, hipSetDevice(h->device));
   CACK(stage_eps(h, eps_stream, n_draws, 2 * (int64_t)n_iter));
   CACK(ensure_elbo_cap(h, std::max(1, n_iter) + 1));
@@ -3021,6 +3124,7 @@ int ca_iterate(ca_handle h, int32_t n_iter, const float* eps_stream, int64_t n_d
 
 int ca_final_elbo(ca_handle h, int32_t n_rep, const float* eps_stream, int64_t n_draws, double* values, double* mean, double* sd) {
   if (!h || n_rep < 1) return CA_ERR_INVALID;
+  CA_NOT_IN_RUN(h);
   HIPCK(h, hipSetDevice(h->device));
   CACK(stage_eps(h, eps_stream, n_draws, n_rep));
   CACK(ensure_elbo_cap(h, n_rep));
@@ -3058,6 +3162,7 @@ static int allreduce_host_vec(ca_engine* h, std::vector<double>& v, double* dev_
 
 int ca_init_psi_pca(ca_handle h, const double* noise, int32_t n_iter, uint64_t seed, double* pcs_out) {
   if (!h) return CA_ERR_INVALID;
+  CA_NOT_IN_RUN(h);
   if (h->K == 0) return CA_OK;
   HIPCK(h, hipSetDevice(h->device));
   CACK(wait_y(h, true));
@@ -3200,6 +3305,7 @@ int ca_init_psi_pca(ca_handle h, const double* noise, int32_t n_iter, uint64_t s
 
 int ca_clone_gene_sums(ca_handle h, const int32_t* clone_of_cell, double* Tout, double* Syy) {
   if (!h || !clone_of_cell || !Tout || !Syy) return CA_ERR_INVALID;
+  CA_NOT_IN_RUN(h);
   HIPCK(h, hipSetDevice(h->device));
   CACK(wait_y(h, true));
   const int64_t N = h->N; const int G = h->G, Gp = h->Gp, C = h->C;
@@ -3255,6 +3361,7 @@ int ca_clone_gene_sums(ca_handle h, const int32_t* clone_of_cell, double* Tout, 
 static int get_generic(ca_handle h, const char* name, double* out, bool grad) {
   if (!h || !name || !out) return CA_ERR_INVALID;
   HIPCK(h, hipSetDevice(h->device));
+  CACK(gate_close(h));   // (called from a ca_run_ex poll hook while a gated launch waits: close that window first)
   ParamRef r;
   if (!find_param(h, name, grad, r)) { h->err = std::string("unknown parameter name: ") + name; return CA_ERR_INVALID; }
   if (r.rows * r.cols == 0) return CA_OK;
@@ -3294,6 +3401,7 @@ int ca_get_gradient(ca_handle h, const char* name, double* out) { return get_gen
 
 int ca_set_param(ca_handle h, const char* name, const double* in) {
   if (!h || !name || !in) return CA_ERR_INVALID;
+  CA_NOT_IN_RUN(h);
   HIPCK(h, hipSetDevice(h->device));
   ParamRef r;
   if (!find_param(h, name, false, r) || r.xform != 0 || r.d) { h->err = std::string("cannot set parameter: ") + name; return CA_ERR_INVALID; }
@@ -3314,6 +3422,7 @@ int ca_set_param(ca_handle h, const char* name, const double* in) {
 // fit constants and the column sums stay resident.
 int ca_reinit(ca_handle h, const double* psi0, const double* loc0) {
   if (!h) return CA_ERR_INVALID;
+  CA_NOT_IN_RUN(h);
   if (h->K > 0 && !psi0) { h->err = "psi0 is required when K > 0"; return CA_ERR_INVALID; }
   HIPCK(h, hipSetDevice(h->device));
   CACK(wait_y(h, true));
@@ -3355,6 +3464,7 @@ int ca_reinit(ca_handle h, const double* psi0, const double* loc0) {
 int ca_get_kernel_times(ca_handle h, double ms[CA_KERNEL_COUNT], int64_t launches[CA_KERNEL_COUNT]) {
   if (!h) return CA_ERR_INVALID;
   HIPCK(h, hipSetDevice(h->device));
+  CACK(gate_close(h));   // (called from a ca_run_ex poll hook while a gated launch waits: close that window first)
   CACK(prof_flush(h));
   for (int i = 0; i < CA_KERNEL_COUNT; ++i) {
     if (ms) ms[i] = h->k_ms[i];

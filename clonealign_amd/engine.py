@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libclonealign_hip.so")
 CA_OK = 0
 CA_ERR_NAN = 4
 CA_INTERRUPTED = 7
-CA_ABI_VERSION = 4
+CA_ABI_VERSION = 5
 P2P_HANDLE_BYTES = 128
 CA_F64, CA_F32, CA_I32, CA_U16, CA_U8 = 0, 1, 2, 3, 4
 CA_ROW_MAJOR, CA_COL_MAJOR = 0, 1
@@ -32,7 +32,7 @@ TRANSPORT_NAME = {0: "none", 1: "rccl", 2: "host", 3: "p2p"}
 
 EXPORTS = (
     "ca_abi_version", "ca_build_id", "ca_device_count", "ca_default_options", "ca_create", "ca_destroy", "ca_last_error", "ca_get_info",
-    "ca_synchronize", "ca_comm_unique_id", "ca_comm_init", "ca_p2p_export", "ca_p2p_connect", "ca_p2p_commit", "ca_comm_benchmark", "ca_comm_selftest", "ca_set_host_allreduce", "ca_gamma_init", "ca_elbo", "ca_elbo_terms",
+    "ca_synchronize", "ca_stream_busy", "ca_comm_unique_id", "ca_comm_init", "ca_p2p_export", "ca_p2p_connect", "ca_p2p_commit", "ca_comm_benchmark", "ca_comm_selftest", "ca_set_host_allreduce", "ca_gamma_init", "ca_elbo", "ca_elbo_terms",
     "ca_step", "ca_gradients", "ca_run", "ca_run_ex", "ca_iterate", "ca_final_elbo", "ca_init_psi_pca", "ca_clone_gene_sums", "ca_get_param", "ca_set_param",
     "ca_get_gradient", "ca_reinit", "ca_get_kernel_times", "ca_reset_kernel_times", "ca_set_profile", "ca_eps_draw", "ca_allele_loglik", "ca_preprocess",
 )
@@ -51,7 +51,7 @@ class CaOptions(C.Structure):
                 ("adam_eps", C.c_double), ("seed", C.c_uint64), ("device", C.c_int32),
                 ("y_storage", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32), ("profile", C.c_int32),
                 ("variant_off", C.c_uint32), ("tune", C.c_int32 * 8), ("variant_on", C.c_uint32),
-                ("ride_pattern", C.c_int32), ("comm_timeout_ms", C.c_int32), ("reserved", C.c_int32 * 3)]
+                ("ride_pattern", C.c_int32), ("comm_timeout_ms", C.c_int32), ("gate_timeout_us", C.c_int32), ("reserved", C.c_int32 * 2)]
 
 
 class CaInfo(C.Structure):
@@ -100,6 +100,7 @@ def load_library(path=None):
     lib.ca_destroy.argtypes = [C.c_void_p]
     lib.ca_get_info.argtypes = [C.c_void_p, C.POINTER(CaInfo)]
     lib.ca_synchronize.argtypes = [C.c_void_p]
+    lib.ca_stream_busy.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     lib.ca_comm_unique_id.argtypes = [C.c_char_p]
     lib.ca_comm_init.argtypes = [C.c_void_p, C.c_char_p]
     lib.ca_p2p_export.argtypes = [C.c_void_p, C.c_char_p]
@@ -196,7 +197,7 @@ class HipEngine:
                  device=0, y_storage="auto", seed=0x5EED5EED, rank=0, world=1, profile=False,
                  y_device_ptr=None, y_device_dtype=None, shape=None, comm_id=None, host_allreduce=None, p2p_exchange=None,
                  layout="row", cell_index=None, gene_index=None, variant_off=(), variant_on=(), tune=None, verbose=False,
-                 comm_timeout_ms=0, defer_transport=False):
+                 comm_timeout_ms=0, defer_transport=False, gate_timeout_us=0):
         """``layout``: "row" (C / numpy order) or "col" -- every matrix is then handed over column-major (Fortran order),
         which is what the R caller has (R/inference-tflow.R:190-191,355) and what r_shim/src/clonealign_hip_shim.c passes; the
         ``get``/``set`` matrices use the same layout.  ``cell_index`` / ``gene_index``: Y is the RAW matrix and the fit uses
@@ -204,6 +205,8 @@ class HipEngine:
         ``p2p_exchange(handle: bytes) -> list[bytes]`` (world > 1): an all-gather of the ranks' P2P_HANDLE_BYTES-byte handles in
         rank order (torch.distributed / MPI); selects the one-shot peer-to-peer all-reduce (ca_p2p_export / ca_p2p_connect).
         ``comm_timeout_ms``: bound of the peer-to-peer all-reduce's device-side wait for its peers (0 = 10 s; ca_options).
+        ``gate_timeout_us``: how long ``run``'s queued-ahead update waits on the device for the host's decision before it gives up and is
+        queued again afterwards (0 = 1000 us; ca_options).
         ``variant_off``: names from VARIANTS (or a bitmask) to switch off; ``variant_on``: names from VARIANTS_ON to switch on;
         ``tune``: {name from TUNE: value}."""
         self.lib = load_library()
@@ -258,6 +261,7 @@ class HipEngine:
         opt.rank, opt.world = int(rank), int(world)
         opt.profile = 0x1F if profile is True else int(profile)
         opt.comm_timeout_ms = int(comm_timeout_ms)
+        opt.gate_timeout_us = int(gate_timeout_us)
         voff = int(variant_off) if isinstance(variant_off, int) else sum(VARIANTS[v] for v in variant_off)
         opt.variant_off = (voff | (OPT_VERBOSE if verbose else 0)) & 0xFFFFFFFF
         opt.variant_on = int(variant_on) if isinstance(variant_on, int) else sum(VARIANTS_ON[v] for v in variant_on)
@@ -399,7 +403,9 @@ class HipEngine:
 
         ``poll(iteration, elbo)`` (optional) is called once per ELBO value as the host learns it (0 = the initial
         ELBO); a truthy return stops the loop after that iteration (ca_run_ex, CA_INTERRUPTED): the trace so far is
-        returned and ``self.interrupted`` is set."""
+        returned and ``self.interrupted`` is set.  The hook may be slow and may call the read-only methods (``get``,
+        ``get_params``, ``info``, ``synchronize``, ``stream_busy``): it sees the variables after that iteration, and the fit is
+        the same bit for bit (include/clonealign_hip.h, ca_poll_fn); methods that change the engine's state raise from inside it."""
         need = 2 + 2 * int(max_iter)
         start = getattr(eps_stream, "draw", None)
         _k, p, n = self._stream(eps_stream, need)
@@ -466,6 +472,12 @@ class HipEngine:
 
     def synchronize(self):
         self._ck(self.lib.ca_synchronize(self.h))
+
+    def stream_busy(self):
+        """True while work queued on the engine's stream has not completed (ca_stream_busy; never blocks)."""
+        b = C.c_int32()
+        self._ck(self.lib.ca_stream_busy(self.h, C.byref(b)))
+        return bool(b.value)
 
     # -------------------------------------------------------------- fetch / poke
     def _shape(self, name):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CA_ABI_VERSION 4
+#define CA_ABI_VERSION 5
 
 typedef struct ca_engine* ca_handle;
 
@@ -92,7 +92,8 @@ enum ca_variant {
   CA_VAR_P2P_RIDE = 1 << 16,  /* sharded over the peer-to-peer transport: the backward sweep's column sums, the stream's finishing sums and the pending monitor
                                  pass's psi.(YW) sum ride in the sweep's and the all-reduce's launches (4 launches per iteration); off: k_yfinish + k_colsum launches */
   CA_VAR_RUN_GATE = 1 << 17,  /* ca_run: the update half of the next train pass is queued before the host has seen the ELBO its stop rule needs and waits ON THE
-                                 DEVICE for the host's go / stop word (no launch latency between the decision and the update); off: queued after the decision */
+                                 DEVICE for the host's go / stop word (no launch latency between the decision and the update) -- for gate_timeout_us at most, then
+                                 it gives up, stores nothing and is queued again after the decision; off: always queued after the decision */
   CA_VAR_S2_FUSE = 1 << 18,   /* mc_samples = 2: the monitor pass's two samples and the next train pass's two samples in ONE forward sweep (two operand sets,
                                  four draws on one exp per (cell, gene)); off: a sweep per pass */
   CA_VAR_P2P = 1 << 10,       /* one-shot peer-to-peer all-reduce (else ncclAllReduce) after ca_comm_init() */
@@ -154,7 +155,10 @@ typedef struct ca_options {
                                      * two kinds on disjoint XCDs.  Results do not depend on it (tests/test_gpu_parity.py) */
   int32_t comm_timeout_ms;          /* peer-to-peer all-reduce: how long a rank waits on the device for its peers' data before the call
                                      * gives up and the engine reports CA_ERR_COMM (0 = 10 000 ms) */
-  int32_t reserved[3];
+  int32_t gate_timeout_us;          /* ca_run with the gated update (CA_VAR_RUN_GATE): how long the queued update's relay block polls for the host's
+                                     * go / stop word before the launch gives up -- it then stores nothing, the device goes idle, and the host queues
+                                     * the update again after its decision (0 = 1000 us).  Not an error and not a result: only who waits for whom */
+  int32_t reserved[2];
 } ca_options;
 /* (The same switches can be set from the environment -- CA_FUSED=0, CA_CSPLIT=12, ... -- but ONLY when
  *  CLONEALIGN_DEBUG_ENV is set: the library reads no configuration from the process environment otherwise.) */
@@ -214,6 +218,9 @@ int ca_destroy(ca_handle h);
 const char* ca_last_error(ca_handle h); /* h may be NULL: error of the last failed ca_create on this thread */
 int ca_get_info(ca_handle h, ca_info* info);
 int ca_synchronize(ca_handle h);
+/* *busy = 1 while work queued on the engine's stream has not completed, else 0; never blocks, never changes anything (a poll hook can
+ * watch the device drain while it holds the loop up). */
+int ca_stream_busy(ca_handle h, int32_t* busy);
 
 /* cell-sharded multi-GPU (one process per GPU): RCCL communicator over xGMI.
  * Rank 0 calls ca_comm_unique_id() and distributes the 128 bytes out of band. */
@@ -281,6 +288,13 @@ int ca_run(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_strea
  * while the GPU already works on the backward sweep of the next train pass.  A non-zero return stops the loop exactly
  * like the convergence test does: the variables are those after iteration i, the trace has i + 1 values, and the call
  * returns CA_INTERRUPTED.  An R shim calls R_CheckUserInterrupt() through R_ToplevelExec() here. */
+/* What a hook may do (ABI 5).  It may take as long as it likes -- a progress bar, a debugger, a sleep: the update the engine had queued
+ * ahead of the hook's decision waits on the device for ca_options.gate_timeout_us at most, then gives up without storing anything and is
+ * queued again after the hook returns; the fit is the same bit for bit, only that iteration loses the overlap.  It may call the read-only
+ * entry points on this handle -- ca_get_param, ca_get_gradient, ca_get_info, ca_synchronize, ca_get_kernel_times, ca_stream_busy -- and sees
+ * the variables after iteration `iter` (the first such call ends the queued update's wait the same way).  Every call that changes the
+ * engine's state (ca_step, ca_set_param, ca_reinit, ca_run, ca_destroy, the ca_comm_* family ...) returns CA_ERR_STATE from inside a hook.
+ * Sharded fits: the hook must take the same decision on every rank. */
 typedef int (*ca_poll_fn)(void* user, int32_t iter, double elbo);
 int ca_run_ex(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_stream, int64_t n_draws,
               double* elbo_trace, int32_t* n_elbo, ca_poll_fn poll, void* user);

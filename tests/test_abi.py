@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), s
     assert set(syms) == set(engine.EXPORTS)
-    assert lib.ca_abi_version() == engine.CA_ABI_VERSION == 4
+    assert lib.ca_abi_version() == engine.CA_ABI_VERSION == 5
 
 
 PROBE = r"""
@@ -35,7 +35,7 @@ int main(void) {
   printf("ca_problem %zu\nca_options %zu\nca_info %zu\nca_preprocess_params %zu\n", sizeof(ca_problem), sizeof(ca_options),
          sizeof(ca_info), sizeof(ca_preprocess_params));
   F(ca_problem, Y); F(ca_problem, extra_loglik); F(ca_problem, N_src); F(ca_problem, G_src); F(ca_problem, cell_index); F(ca_problem, gene_index);
-  F(ca_options, seed); F(ca_options, profile); F(ca_options, variant_off); F(ca_options, tune); F(ca_options, variant_on); F(ca_options, ride_pattern); F(ca_options, comm_timeout_ms); F(ca_options, reserved);
+  F(ca_options, seed); F(ca_options, profile); F(ca_options, variant_off); F(ca_options, tune); F(ca_options, variant_on); F(ca_options, ride_pattern); F(ca_options, comm_timeout_ms); F(ca_options, gate_timeout_us); F(ca_options, reserved);
   F(ca_info, y_device_bytes); F(ca_info, fwd_cell); F(ca_info, y_mfma); F(ca_info, transport); F(ca_info, y_ride); F(ca_info, red_n); F(ca_info, fwd_block_cells); F(ca_info, yfin_split);
   printf("version %d\n", CA_ABI_VERSION);
   return 0;
@@ -75,13 +75,29 @@ def test_library_is_built_from_the_sources_in_the_tree():
 
 
 def test_library_reads_no_tuning_from_the_environment():
-    """ADVICE/VERDICT r1: the CA_* switches live in ca_options; getenv for them is reached only behind CLONEALIGN_DEBUG_ENV.
-    The two names read unconditionally are not tuning: CLONEALIGN_RCCL_LIB (which librccl to dlopen -- a deployment path, tried
-    before the standard names, clonealign_hip.hip `load_rccl`) and CA_VERBOSE (diagnostics to stderr)."""
+    """ADVICE/VERDICT r1, r4: the CA_* switches live in ca_options.  The release library never reads tuning from the environment: the
+    getenv calls for it exist only in timing-lab builds (-DCA_LAB: `debug_env()` is the constant false otherwise).  The two names read
+    unconditionally are not tuning: CLONEALIGN_RCCL_LIB (which librccl to dlopen -- a deployment path, tried before the standard
+    names) and CA_VERBOSE (diagnostics to stderr, itself behind debug_env())."""
     src = open(os.path.join(ROOT, "clonealign_amd", "csrc", "clonealign_hip.hip")).read()
     uses = re.findall(r'getenv\("([A-Z_]+)"\)', src)
     assert set(uses) <= {"CLONEALIGN_DEBUG_ENV", "CLONEALIGN_RCCL_LIB", "CA_VERBOSE"}, uses
-    assert src.count("getenv(env)") == 3 and "debug_env()" in src
+    assert src.count("getenv(env)") == 3 and "constexpr bool debug_env() { return false; }" in src
+    lab = src[src.index("#ifdef CA_LAB\ninline bool debug_env()"):]
+    assert lab.index('getenv("CLONEALIGN_DEBUG_ENV")') < lab.index("#else")
+
+
+def test_product_kernels_carry_no_switchable_wrong_answer_paths():
+    """timing-lab code lives under tools/lab/ and comes into the kernels only through hooks that a -DCA_LAB build fills
+    in (block stamps; such a build reports a "lab-" build id, which bench.py refuses).  No #if on a CA_LAB_* macro is left in the product
+    sources, and nothing under tools/lab/ alters a result."""
+    for f in ("ca_kernels.hip.h", "ca_ymfma.hip.h", "clonealign_hip.hip"):
+        src = open(os.path.join(ROOT, "clonealign_amd", "csrc", f)).read()
+        assert not re.findall(r"#\s*if[^\n]*CA_LAB_", src), f
+        assert "wrong results" not in src and "results WRONG" not in src, f
+    hooks = open(os.path.join(ROOT, "tools", "lab", "ca_lab_hooks.inc")).read()
+    assert "s_memrealtime" in hooks and "return;" not in hooks
+    assert 'return "lab-" CA_BUILD_ID' in open(os.path.join(ROOT, "clonealign_amd", "csrc", "clonealign_hip.hip")).read()
 
 
 def test_create_fails_loudly_without_gpu_or_with_bad_args():

@@ -863,6 +863,95 @@ def test_ca_run_with_the_update_queued_ahead_of_the_decision_is_the_lock_step_lo
                 assert np.array_equal(a[i][n], b[i][n]), (i, n)
 
 
+def test_a_slow_or_re_entrant_poll_hook_costs_time_not_the_fit():
+    """VERDICT r4 #3 / ADVICE r4: the update queued ahead of the host's decision used to spin on the GPU while the poll hook ran -- for up to
+    10 s, after which ca_run returned CA_ERR_STATE ("the engine's state is undefined").  Now the queued launch's relay block waits for
+    ca_options.gate_timeout_us (1 ms) at most, gives up without storing anything, the device goes IDLE, and the host queues the update again
+    after the hook: a hook that sleeps, and one that calls back into the read-only API (get / synchronize: they end the wait themselves), must
+    give the lock-step loop's trace and variables bit for bit; the engine's stream must be drained while the hook sleeps; calls that change
+    the engine's state are refused from inside a hook."""
+    import time
+    from clonealign_amd.engine import EngineError, HipEngine
+    from clonealign_amd.rng import EpsStream
+    case = make_case(seed=48, N=2500, G=700, C=5, K=1)
+    G = case["Y"].shape[1]
+    ref_eng = HipEngine(**case, variant_off=("run_gate",))
+    try:
+        ref = np.asarray(ref_eng.run(EpsStream(9, 1, G), 8, 1e-12))
+        ref_state = ref_eng.get_state()
+    finally:
+        ref_eng.close()
+    seen = {}
+
+    def sleepy(i, e):
+        if i == 3:
+            time.sleep(0.05)                       # 50 x the relay's patience
+            seen["busy_after_sleep"] = eng.stream_busy()
+            time.sleep(0.4)
+        return False
+
+    def nosy(i, e):
+        if i in (2, 5):
+            seen[f"W{i}"] = eng.get("W").copy()    # closes the gated launch's wait, then reads the variables after iteration i
+            eng.synchronize()
+            seen[f"info{i}"] = eng.info()["N"]
+        if i == 4:
+            with pytest.raises(EngineError) as ex:
+                eng.step(eps_for(1, G, 1))
+            seen["refused"] = ex.value.code
+        return False
+
+    for hook in (sleepy, nosy, None):
+        eng = HipEngine(**case)
+        try:
+            assert eng.info()["update_merge"] == 1
+            t0 = time.perf_counter()
+            tr = np.asarray(eng.run(EpsStream(9, 1, G), 8, 1e-12, poll=hook))
+            dt = time.perf_counter() - t0
+            st = eng.get_state()
+            assert np.array_equal(tr, ref), (hook, tr, ref)
+            for n in ref_state:
+                assert np.array_equal(st[n], ref_state[n]), (hook, n)
+            if hook is sleepy:
+                assert seen["busy_after_sleep"] is False          # the gated launch gave up long ago: nothing is spinning on the device
+                assert 0.45 < dt < 5.0, dt                        # the hook's own time, not a 10 s device-side timeout
+            if hook is nosy:
+                assert seen["refused"] == 6 and seen["info2"] == 2500   # CA_ERR_STATE
+        finally:
+            eng.close()
+    # the variables a hook reads are those after its iteration: the same run stopped there by max_iter
+    for i in (2, 5):
+        eng = HipEngine(**case, variant_off=("run_gate",))
+        try:
+            eng.run(EpsStream(9, 1, G), i, 1e-12)
+            assert np.array_equal(eng.get("W"), seen[f"W{i}"]), i
+        finally:
+            eng.close()
+
+
+def test_gated_update_with_a_patience_shorter_than_the_decision_falls_back_every_iteration():
+    """The relay's give-up path on EVERY iteration (gate_timeout_us = 1: the host's answer can never be in time): each queued update gives
+    up, the host learns it from the relay's verdict word and queues the update again -- the lock-step loop, bit for bit, including the
+    tolerance stop and the opt-in form that also queues the next forward sweep ahead."""
+    from clonealign_amd.engine import HipEngine
+    from clonealign_amd.rng import EpsStream
+    case = make_case(seed=49, N=1800, G=520, C=4, K=1)
+    G = case["Y"].shape[1]
+    outs = []
+    for kw in (dict(variant_off=("run_gate",)), dict(gate_timeout_us=1), dict(gate_timeout_us=1, variant_on=("run_fwd",)), dict(gate_timeout_us=200)):
+        eng = HipEngine(**case, **kw)
+        try:
+            t1 = np.asarray(eng.run(EpsStream(5, 1, G), 12, 1e-12))
+            t2 = np.asarray(eng.run(EpsStream(6, 1, G), 60, 3e-2))
+            outs.append((t1, t2, eng.get_state()))
+        finally:
+            eng.close()
+    for a in outs[1:]:
+        assert np.array_equal(a[0], outs[0][0]) and np.array_equal(a[1], outs[0][1])
+        for n in outs[0][2]:
+            assert np.array_equal(a[2][n], outs[0][2][n]), n
+
+
 def test_results_do_not_depend_on_another_process_sharing_the_gpu():
     """Round 4 (profiles/r04_flake.txt): the engine's streams are non-blocking streams, and the overflow list of a 1-byte matrix used to be uploaded with
     NULL-stream copies into buffers whose zeroing was still QUEUED on the engine's stream -- unordered.  Alone on the GPU the zeroing ran at once; with

@@ -1,6 +1,6 @@
 """Timeline of ONE merged forward launch (k_fwd_cell_mix_y) from per-block stamps: when the sweep's and the stream's blocks
 start and end, how many of each kind are resident over time, and how the stream's rate develops.  Needs a lab build:
-    hipcc ... -DCA_LAB_STAMPS -o /tmp/lab_stamps.so ...;  CLONEALIGN_HIP_LIB=/tmp/lab_stamps.so python tools/stamps.py [bench-like args]
+    hipcc ... -DCA_LAB -o /tmp/lab_stamps.so ...;  CLONEALIGN_HIP_LIB=/tmp/lab_stamps.so python tools/stamps.py [bench-like args]
 (tools/lab_stamps.sh builds and runs it on the GPU box)."""
 import argparse
 import ctypes as C

@@ -1,5 +1,5 @@
 """Block timelines of the two small kernels of an iteration (k_final_gene, k_adam_cell) from per-block stamps: which kind of block
-starts when and ends when.  Needs a lab build (-DCA_LAB_STAMPS):  tools/lab_stamps_small.sh [bench-like args]"""
+starts when and ends when.  Needs a lab build (-DCA_LAB):  tools/lab_stamps_small.sh [bench-like args]"""
 import argparse
 import ctypes as C
 import os
