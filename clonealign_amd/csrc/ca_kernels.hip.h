@@ -316,6 +316,26 @@ __global__ void k_scan_y(const ST* __restrict__ src, int64_t total, double* __re
   }
 }
 
+// Column sums of x = log2(y + 1) and of x^2 in FLOAT64, for prcomp(center = TRUE, scale. = TRUE) of R/inference-tflow.R:204-205 on the
+// device (ca_init_psi_pca): thread = gene (a block row reads 256 consecutive columns of the row-major resident matrix), block column = a
+// slice of cells; out [slices][2][G].  (Round 5: these two statistics came out of the float32 streaming pass before; the standard
+// deviation is a difference of two nearly equal sums for a well-expressed gene, and float32 partials cost the device PCA a factor ten
+// in agreement with prcomp.)  Counts stored as 255 + overflow-list excess are corrected by the caller.
+template <typename YT>
+__global__ void __launch_bounds__(CA_TB) k_col_logstats(const YT* __restrict__ Y, int64_t N, int G, int Gp, int64_t rows_per,
+                                                        double* __restrict__ out) {
+  const int g = (int)blockIdx.x * CA_TB + (int)threadIdx.x;
+  if (g >= G) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per, r1 = r0 + rows_per < N ? r0 + rows_per : N;
+  double s = 0.0, ss = 0.0;
+  for (int64_t r = r0; r < r1; ++r) {
+    const double y = (double)Y[r * (int64_t)Gp + g];
+    if (y != 0.0) { const double x = log2(y + 1.0); s += x; ss += x * x; }
+  }
+  out[((int64_t)blockIdx.y * 2 + 0) * G + g] = s;
+  out[((int64_t)blockIdx.y * 2 + 1) * G + g] = ss;
+}
+
 // ------------------------------------------------------------------ fit constants (once per fit)
 // One block per cell: s_n, c_n = lgamma(s_n+1) - sum_g lgamma(y+1), A_nc = sum_g xlogy(y, L_gc).
 // (the terms TF recomputes in every run of tfd$Multinomial$log_prob, R/inference-tflow.R:294-296)

@@ -1832,6 +1832,97 @@ int gather_y(ca_engine* h, const void* src, void** dst, int64_t sn, int64_t sg, 
   return CA_OK;
 }
 
+// ---- host -> device ingestion (round 5; profiles/r05_ingest.txt) --------------------------------------------------------------
+// The caller's matrix arrives in pageable host memory: from R an N x G column-major DOUBLE matrix (R/clonealign.R:212-222), 4 GB at
+// 100k x 5k.  Until round 4 it went up as ONE pageable hipMemcpy into an N*G*8-byte device staging buffer (measured: 70 ms = the PCIe
+// time of 4 GB, the whole fit that follows takes 60 ms).  Doubles carry nothing the engine can store -- its widest storage is float32
+// and a count that is not exactly a float is an error either way -- so the bytes are narrowed on the HOST, on their way into the pinned
+// buffers a copy has to pass through anyway: a few worker threads convert chunk c + 1 (float64 -> float32, every value checked for
+// exactness) into one pinned buffer while the DMA engine moves chunk c out of the other.  Half the PCIe bytes, half the device
+// staging, and the device sees exactly the values it saw before (the scan / conversion kernels and their results are unchanged).
+// Other source types have nothing to narrow and keep the runtime's own pageable copy, which runs at 98 % of the pinned rate on these boxes
+// (56.5 against 57.6 GB/s; the same bytes through this pipeline's memcpy threads measured SLOWER, 44 GB/s: profiles/r05_ingest.txt).
+struct ingest_result { bool inexact = false; };
+static int ingest_host_matrix(hipStream_t stream, std::string& err, const void* src, int64_t total, int src_dtype, void* dst_dev, ingest_result* res) {
+  const bool narrow = src_dtype == CA_F64;
+  const size_t esz = src_dtype == CA_F64 ? 8 : (src_dtype == CA_F32 || src_dtype == CA_I32) ? 4 : src_dtype == CA_U16 ? 2 : 1;
+  const size_t dsz = narrow ? 4 : esz;
+  // 16 MiB of staged bytes per chunk, three pinned buffers, eight threads: measured on the MI355X boxes (256 host threads), tools/ingest_sweep.py --
+  // 4 ... 24 threads are level (the loop runs at 85-90 % of the PCIe time of the narrowed bytes; 32+ threads and 64 MiB chunks lose to
+  // pinning cost and scheduling noise, 4 MiB chunks to per-chunk overhead)
+  const int64_t chunk_elems = (int64_t)(16u << 20) / (int64_t)dsz;
+  const int64_t nchunks = (total + chunk_elems - 1) / chunk_elems;
+  const int hw = (int)std::thread::hardware_concurrency();
+  const int T = (int)std::max<int64_t>(1, std::min<int64_t>(std::min(8, std::max(1, hw / 4)), (total + (1 << 18) - 1) >> 18));
+  constexpr int NBMAX = 4;
+  const int NB = (int)std::min<int64_t>(3, std::max<int64_t>(nchunks, 2));
+  void* pin[NBMAX] = {};
+  hipEvent_t ev[NBMAX] = {};
+  auto fail = [&](const char* what, hipError_t e) { err = std::string(what) + ": " + hipGetErrorString(e); return CA_ERR_HIP; };
+  hipError_t e = hipSuccess;
+  {   // ONE pinned allocation for all buffers (pinning costs ~0.1 ms per MiB plus a fixed cost per call)
+    void* base = nullptr;
+    const size_t one = (size_t)std::min<int64_t>(chunk_elems, total) * dsz;
+    e = hipHostMalloc(&base, one * NB);
+    for (int b = 0; b < NB && e == hipSuccess; ++b) { pin[b] = reinterpret_cast<char*>(base) + one * b; e = hipEventCreateWithFlags(&ev[b], hipEventDisableTiming); }
+  }
+  std::atomic<int64_t> free_for[NBMAX];   // the chunk that may now be written into pinned buffer b
+  for (int b = 0; b < NBMAX; ++b) free_for[b].store(b);
+  std::vector<std::atomic<int>> filled((size_t)nchunks);
+  for (auto& f : filled) f.store(0);
+  std::atomic<int> inexact{0}, abort_all{0};
+  auto fill_slice = [&](int64_t c, int t) {
+    const int b = (int)(c % NB);
+    const int64_t e0 = c * chunk_elems, n = std::min<int64_t>(chunk_elems, total - e0);
+    // slice t of the chunk (multiples of 4096 elements: whole pages of the source, so the threads' pieces do not share lines)
+    const int64_t per = ((n + T - 1) / T + 4095) & ~(int64_t)4095;
+    const int64_t a = std::min<int64_t>(n, (int64_t)t * per), z = std::min<int64_t>(n, a + per);
+    if (z > a) {
+      if (narrow) {
+        const double* sp = reinterpret_cast<const double*>(src) + e0;
+        float* dp = reinterpret_cast<float*>(pin[b]);
+        int bad = 0;
+        for (int64_t i = a; i < z; ++i) { const double v = sp[i]; const float f = (float)v; dp[i] = f; bad |= ((double)f != v); }   // (NaN flags itself)
+        if (bad) inexact.store(1, std::memory_order_relaxed);
+      } else {
+        memcpy(reinterpret_cast<char*>(pin[b]) + (size_t)a * esz, reinterpret_cast<const char*>(src) + (size_t)(e0 + a) * esz, (size_t)(z - a) * esz);
+      }
+    }
+    filled[(size_t)c].fetch_add(1, std::memory_order_release);
+  };
+  auto worker = [&](int t) {
+    for (int64_t c = 0; c < nchunks; ++c) {
+      while (free_for[c % NB].load(std::memory_order_acquire) < c) { if (abort_all.load(std::memory_order_relaxed)) return; std::this_thread::yield(); }
+      fill_slice(c, t);
+    }
+  };
+  std::vector<std::thread> pool;
+  if (e == hipSuccess) for (int t = 1; t < T; ++t) pool.emplace_back(worker, t);
+  int rc = CA_OK;
+  if (e != hipSuccess) rc = fail("pinned staging buffers of the count matrix", e);
+  // this thread is worker 0 of every chunk and the one that queues the copies; the other workers run ahead into the free buffers
+  for (int64_t c = 0; c < nchunks && rc == CA_OK; ++c) {
+    const int b = (int)(c % NB);
+    const int64_t e0 = c * chunk_elems, n = std::min<int64_t>(chunk_elems, total - e0);
+    fill_slice(c, 0);   // (free_for[b] >= c holds: this thread released it, below)
+    while (filled[(size_t)c].load(std::memory_order_acquire) < T) std::this_thread::yield();
+    e = hipMemcpyAsync(reinterpret_cast<char*>(dst_dev) + (size_t)e0 * dsz, pin[b], (size_t)n * dsz, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipEventRecord(ev[b], stream);
+    // the buffer that chunk c + 1 wants held chunk c + 1 - NB: once THAT copy is done it is free (the copies queued since run meanwhile)
+    const int64_t prev = c + 1 - NB;
+    if (e == hipSuccess && prev >= 0) e = hipEventSynchronize(ev[prev % NB]);
+    if (e != hipSuccess) { rc = fail("upload of the count matrix", e); break; }
+    if (prev >= 0) free_for[prev % NB].store(c + 1, std::memory_order_release);
+  }
+  if (rc != CA_OK) abort_all.store(1);
+  for (auto& th : pool) th.join();
+  if (rc == CA_OK) { e = hipStreamSynchronize(stream); if (e != hipSuccess) rc = fail("upload of the count matrix", e); }
+  for (int b = 0; b < NB; ++b) if (ev[b]) hipEventDestroy(ev[b]);
+  if (pin[0]) hipHostFree(pin[0]);
+  if (res) res->inexact = inexact.load() != 0;
+  return rc;
+}
+
 int upload_y(ca_engine* h, const ca_problem* p) {
   // the caller's matrix: N_src x G_src when a selection is given (ca_problem.cell_index / gene_index), else N x G
   const bool sel = p->cell_index || p->gene_index;
@@ -1844,9 +1935,49 @@ int upload_y(ca_engine* h, const ca_problem* p) {
   void* cut = nullptr;
   int64_t* ci_dev = nullptr; int32_t* gi_dev = nullptr;
   auto cleanup = [&]() { if (staging) hipFree(staging); if (cut) hipFree(cut); if (ci_dev) hipFree(ci_dev); if (gi_dev) hipFree(gi_dev); };
+  int y_dtype = p->y_dtype;   // of `src` as the kernels below see it
   if (!p->y_on_device) {
-    HIPCK(h, hipMalloc(&staging, (size_t)total * esz));
-    if (hipMemcpy(staging, p->Y, (size_t)total * esz, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); h->err = "upload of the count matrix failed"; return CA_ERR_HIP; }
+    // chunked through pinned double buffers, float64 narrowed to float32 on the way (ingest_host_matrix): the device staging is the
+    // source's layout at <= 4 bytes per count
+    if (y_dtype == CA_F64) esz = 4;
+    {
+      const hipError_t e = hipMalloc(&staging, (size_t)total * esz);
+      if (e != hipSuccess) { h->err = std::string("hipMalloc of ") + std::to_string((size_t)total * esz) + " bytes (count matrix staging): " + hipGetErrorString(e); return CA_ERR_NOMEM; }
+    }
+    ingest_result ir;
+    if (p->y_dtype == CA_F64) {
+      const int rci = ingest_host_matrix(h->stream, h->err, p->Y, total, p->y_dtype, staging, &ir);
+      if (rci != CA_OK) { cleanup(); return rci; }
+    } else if (hipMemcpy(staging, p->Y, (size_t)total * esz, hipMemcpyHostToDevice) != hipSuccess) {
+      cleanup(); h->err = "upload of the count matrix failed"; return CA_ERR_HIP;
+    }
+    if (p->y_dtype == CA_F64) y_dtype = CA_F32;
+    if (ir.inexact && sel) {
+      // some double of the RAW matrix is not a float, but it may lie outside the selection (which is all the fit may judge): take the
+      // matrix up again as it is, 8 bytes per count, and let the gather below cut it first -- the rare path
+      hipFree(staging); staging = nullptr;
+      const hipError_t e = hipMalloc(&staging, (size_t)total * 8);
+      if (e != hipSuccess) { cleanup(); h->err = std::string("hipMalloc of the count matrix staging: ") + hipGetErrorString(e); return CA_ERR_NOMEM; }
+      if (hipMemcpy(staging, p->Y, (size_t)total * 8, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); h->err = "upload of the count matrix failed"; return CA_ERR_HIP; }
+      y_dtype = CA_F64;
+    } else if (ir.inexact) {
+      // a double that is not exactly a float can only be an error: NaN / negative takes precedence, as in the scan below
+      double* maxv = nullptr;
+      if (hipMalloc((void**)&maxv, 32) != hipSuccess) { cleanup(); h->err = "hipMalloc failed"; return CA_ERR_NOMEM; }
+      double hm[4] = {0, 0, 0, 0};
+      hipMemsetAsync(maxv, 0, 32, h->stream);
+      hipLaunchKernelGGL((k_scan_y<float>), dim3(std::min<int64_t>(4096, cdiv(total, CA_TB))), dim3(CA_TB), 0, h->stream, (const float*)staging, total, maxv,
+                         (int*)(maxv + 1), (unsigned long long*)(maxv + 2));
+      hipMemcpyAsync(hm, maxv, 32, hipMemcpyDeviceToHost, h->stream);
+      const hipError_t e = hipStreamSynchronize(h->stream);
+      hipFree(maxv);
+      cleanup();
+      if (e != hipSuccess) { h->err = hipGetErrorString(e); return CA_ERR_HIP; }
+      int fl;
+      memcpy(&fl, &hm[1], sizeof(int));
+      h->err = (fl & 2) ? "count matrix has negative or NaN entries" : "counts are not exactly representable in the on-device storage type";
+      return CA_ERR_INVALID;
+    }
     src = staging;
   }
   int64_t sn = p->layout == CA_COL_MAJOR ? 1 : Gs;
@@ -1870,7 +2001,7 @@ int upload_y(ca_engine* h, const ca_problem* p) {
       if (hipMalloc((void**)&gi_dev, (size_t)h->G * sizeof(int32_t)) != hipSuccess ||
           hipMemcpy(gi_dev, p->gene_index, (size_t)h->G * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) return bad("gene_index upload failed");
     } else if (h->G != Gs) return bad("G must equal G_src when gene_index is NULL");
-    switch (p->y_dtype) {
+    switch (y_dtype) {
       case CA_F64: rc = gather_y<double>(h, src, &cut, sn, sg, ci_dev, gi_dev); break;
       case CA_F32: rc = gather_y<float>(h, src, &cut, sn, sg, ci_dev, gi_dev); break;
       case CA_I32: rc = gather_y<int32_t>(h, src, &cut, sn, sg, ci_dev, gi_dev); break;
@@ -1882,7 +2013,7 @@ int upload_y(ca_engine* h, const ca_problem* p) {
     if (staging) { hipFree(staging); staging = nullptr; }
     src = cut; sn = h->G; sg = 1;
   }
-  switch (p->y_dtype) {
+  switch (y_dtype) {
     case CA_F64: rc = scan_and_convert<double>(h, (const double*)src, sn, sg); break;
     case CA_F32: rc = scan_and_convert<float>(h, (const float*)src, sn, sg); break;
     case CA_I32: rc = scan_and_convert<int32_t>(h, (const int32_t*)src, sn, sg); break;
@@ -3191,11 +3322,29 @@ int ca_init_psi_pca(ca_handle h, const double* noise, int32_t n_iter, uint64_t s
   // ---- column means and standard deviations of x = log2(y + 1)
   std::vector<double> sx, sxx, ntot(1, (double)N);
   {
-    std::vector<float> ones((size_t)N, 1.f);
-    PCK(hipMemcpyAsync(Fp, ones.data(), (size_t)N * sizeof(float), hipMemcpyHostToDevice, h->stream));
-    PCK(hipMemsetAsync(Vp, 0, (size_t)Gp * sizeof(float), h->stream));
-    if ((rc = ypass_tf<1>(h, Fp, Vp, 1, YWp, YTp, csum)) != CA_OK || (rc = colsum_to_host(1, sx)) != CA_OK) { cleanup(); return rc; }
-    if ((rc = ypass_tf<2>(h, Fp, Vp, 1, YWp, YTp, csum)) != CA_OK || (rc = colsum_to_host(1, sxx)) != CA_OK) { cleanup(); return rc; }
+    // float64 sums of x and x^2 per gene over the resident matrix (k_col_logstats), slices summed in order on the host; entries held
+    // as 255 + overflow excess are put right from the host copy of the list (x = log2(256 + excess) where the dense byte gave 8)
+    const int nsl = (int)std::max<int64_t>(1, std::min<int64_t>(128, N / 256));
+    const int64_t rows_per = (N + nsl - 1) / nsl;
+    double* part = nullptr;
+    PCK(hipMalloc((void**)&part, (size_t)nsl * 2 * G * sizeof(double)));
+    const dim3 grid(cdiv(G, CA_TB), nsl);
+    if (h->ystore == CA_YSTORE_U8) hipLaunchKernelGGL((k_col_logstats<uint8_t>), grid, dim3(CA_TB), 0, h->stream, (const uint8_t*)h->Y, N, G, Gp, rows_per, part);
+    else if (h->ystore == CA_YSTORE_U16) hipLaunchKernelGGL((k_col_logstats<uint16_t>), grid, dim3(CA_TB), 0, h->stream, (const uint16_t*)h->Y, N, G, Gp, rows_per, part);
+    else hipLaunchKernelGGL((k_col_logstats<float>), grid, dim3(CA_TB), 0, h->stream, (const float*)h->Y, N, G, Gp, rows_per, part);
+    std::vector<double> hp((size_t)nsl * 2 * G);
+    hipError_t e1 = hipGetLastError();
+    if (e1 == hipSuccess) e1 = hipMemcpyAsync(hp.data(), part, hp.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e1 == hipSuccess) e1 = hipStreamSynchronize(h->stream);
+    hipFree(part);
+    PCK(e1);
+    sx.assign((size_t)G, 0.0); sxx.assign((size_t)G, 0.0);
+    for (int sl = 0; sl < nsl; ++sl)
+      for (int g = 0; g < G; ++g) { sx[g] += hp[((size_t)sl * 2 + 0) * G + g]; sxx[g] += hp[((size_t)sl * 2 + 1) * G + g]; }
+    for (int64_t i = 0; i < h->n_ovf; ++i) {
+      const double x = std::log2(256.0 + (double)h->h_oval[(size_t)i]);
+      sx[h->h_ocol[(size_t)i]] += x - 8.0; sxx[h->h_ocol[(size_t)i]] += x * x - 64.0;
+    }
     std::vector<double> pack((size_t)2 * G + 1);
     for (int g = 0; g < G; ++g) { pack[g] = sx[g]; pack[G + g] = sxx[g]; }
     pack[2 * G] = (double)N;
@@ -3543,6 +3692,7 @@ int ca_preprocess(int64_t N, int32_t G, int32_t C, int32_t layout, int32_t y_dty
   void* staging = nullptr;
   if (!y_on_device) {
     if (hipMalloc(&staging, (size_t)N * G * esz) != hipSuccess) return fail(CA_ERR_NOMEM, "ca_preprocess: device allocation of the count matrix failed");
+    // (the statistics are fixed-order fp64 sums of the caller's OWN values, so nothing is narrowed here; the runtime's pageable copy runs at 98 % of the pinned rate)
     if (hipMemcpy(staging, Y, (size_t)N * G * esz, hipMemcpyHostToDevice) != hipSuccess) { hipFree(staging); return fail(CA_ERR_HIP, "ca_preprocess: upload failed"); }
     src = staging;
   }

@@ -88,7 +88,9 @@ def pca_init(Y, K, noise=None):
     ``prcomp(log2(Y+1), center=TRUE, scale=TRUE)$x[, 1:K]`` -> ``scale()`` -> ``+ noise``
     where the reference's noise is ``rnorm(N*K, 0, 0.05)`` filled column-major; here the
     caller supplies ``noise[N,K]`` (already multiplied by 0.05) or None.
-    Signs of principal components follow LAPACK's SVD and are only defined up to +-1.
+    The sign of a principal component is not defined by prcomp (it is whatever LAPACK's SVD returns); here, as in the
+    device routine (ca_init_psi_pca), each component is oriented so that its loading of largest magnitude is positive --
+    one convention on both sides, so that host- and device-initialised fits of the same seed are the same fit.
     """
     N, G = Y.shape
     K = int(K)
@@ -105,6 +107,7 @@ def pca_init(Y, K, noise=None):
         V = Vt[:K].T
     else:
         V = _top_eigvecs(Xs, K)
+    V = V * np.where(V[np.abs(V).argmax(0), np.arange(V.shape[1])] < 0, -1.0, 1.0)[None, :]
     pcs = r_scale(Xs @ V)
     if noise is not None:
         pcs = pcs + np.asarray(noise, dtype=np.float64).reshape(N, K)

@@ -84,31 +84,46 @@ inference_tflow <- function(Y_dat,
     v_log_prob <- allele_loglik_hip(clone_allele, cov, ref)
   }
 
-  # initial values (:204-235,262): latent space from PCA, size factors, per-gene means
+  # initial values (:204-235,262): latent space from PCA, size factors, per-gene means.  Above 4e6 counts the two O(N G) host passes --
+  # prcomp() (minutes and gigabytes at 100k x 5k, for a fit that takes 60 ms) and colMeans(Y / rowMeans(Y)) -- are taken ON THE DEVICE
+  # from the matrix the fit holds resident anyway: psi0 = NULL asks the engine for prcomp + scale by subspace iteration (plus the
+  # reference's N(0, 0.05^2) noise, drawn here with rnorm() so that set.seed() still governs it), loc0 = NULL for the mu guess.
+  # options(clonealign.device_init = TRUE / FALSE) forces either way.
+  device_init <- getOption("clonealign.device_init", as.numeric(N) * G > 4e6)
   pcs <- matrix(0, N, K)
+  pcs_noise <- NULL
   if (K > 0) {
-    pca <- prcomp(log2(Y_dat + 1), center = TRUE, scale. = TRUE)
-    pcs <- scale(pca$x[, seq_len(K), drop = FALSE])
-    pcs <- pcs + matrix(rnorm(N * K, mean = 0, sd = 0.05), nrow = N)
-    attributes(pcs) <- list(dim = c(N, K))                                 # plain matrix: drop scale()'s attributes
+    pcs_noise <- matrix(rnorm(N * K, mean = 0, sd = 0.05), nrow = N)      # :208 (same draw, same place in the RNG stream, either way)
+    if (device_init) {
+      pcs <- NULL
+    } else {
+      pca <- prcomp(log2(Y_dat + 1), center = TRUE, scale. = TRUE)
+      pcs <- scale(pca$x[, seq_len(K), drop = FALSE])
+      pcs <- pcs + pcs_noise
+      attributes(pcs) <- list(dim = c(N, K))                               # plain matrix: drop scale()'s attributes
+      pcs_noise <- NULL
+    }
   }
   if (any(rowSums(Y_dat) == 0)) stop("Some cells have no counts mapping")  # :210-214
+  loc0 <- NULL
   if (is.logical(data_init_mu)) {
-    mu_guess <- if (isTRUE(data_init_mu)) colMeans(Y_dat / rowMeans(Y_dat)) else rep(1, G)
+    if (!(isTRUE(data_init_mu) && device_init)) {                          # (TRUE + device_init: loc0 stays NULL, the engine makes the same guess)
+      mu_guess <- if (isTRUE(data_init_mu)) colMeans(Y_dat / rowMeans(Y_dat)) else rep(1, G)
+      loc0 <- safe_inverse_softplus(mu_guess)                              # :262
+    }
   } else if (is.numeric(data_init_mu)) {
     say("Using user-provided mu values to start")
-    mu_guess <- data_init_mu / mean(data_init_mu)
+    stopifnot(length(data_init_mu) == G)
+    loc0 <- safe_inverse_softplus(data_init_mu / mean(data_init_mu))
   } else {
     stop("data_init_mu must be TRUE, FALSE or a numeric vector with one value per gene")
   }
-  stopifnot(length(mu_guess) == G)
-  loc0 <- safe_inverse_softplus(mu_guess)                                  # :262
 
   # the fit (:240-457): gamma initialisation, initial ELBO, the loop with its window-10 stop rule, the fetches, 20 final ELBOs
   say("Optimizing ELBO")
   n_draws <- 2L + 2L * as.integer(max_iter) + 20L                          # 1 gamma init + 1 initial ELBO + 2 per iteration + 20 final
   eps <- rnorm(n_draws * S * G)
-  res <- .Call("C_clonealign_fit", Y_dat, L_dat, pcs, loc0, x, v_log_prob, K, S, as.integer(max_iter), as.numeric(rel_tol),
+  res <- .Call("C_clonealign_fit", Y_dat, L_dat, pcs, pcs_noise, loc0, x, v_log_prob, K, S, as.integer(max_iter), as.numeric(rel_tol),
                as.numeric(learning_rate), eps, PACKAGE = "clonealign")
   say("\nELBO converged or reached max iterations")
 

@@ -9,9 +9,13 @@
  * (sess$close): everything before (gene filter, saturate, PCA / mu init) and after (naming, return list)
  * stays R code, unchanged.
  *
- *   .Call("C_clonealign_fit", Y, L, psi0, loc0, X, extra, K, S, max_iter, rel_tol, learning_rate, eps)
+ *   .Call("C_clonealign_fit", Y, L, psi0, psi_noise, loc0, X, extra, K, S, max_iter, rel_tol, learning_rate, eps)
  *     Y      numeric or integer matrix N x G (column-major, as R stores it)
- *     L      numeric matrix G x C;  psi0 N x K;  loc0 G or NULL (device-side mu_guess);  X N x P or NULL;  extra N x C or NULL
+ *     L      numeric matrix G x C;  loc0 G or NULL (device-side mu_guess, :220-235);  X N x P or NULL;  extra N x C or NULL
+ *     psi0   N x K initial latent positions (pcs + noise, :204-208), or NULL: then psi is initialised ON THE DEVICE -- prcomp +
+ *            scale of :204-207 by subspace iteration over the resident counts (ca_init_psi_pca) -- plus psi_noise (N x K, the
+ *            reference's rnorm(N * K, 0, 0.05) of :208, or NULL for none); host prcomp() of a 100k x 5k matrix takes minutes
+ *            and 4 GB, the fit it initialises 60 ms
  *     eps    numeric vector of (2 + 2*max_iter + 20) * S * G standard normals drawn with rnorm() by the
  *            caller (so set.seed() controls the fit exactly as it does through get_next_seed(), :49-51),
  *            or NULL for the engine's built-in Philox stream
@@ -50,7 +54,7 @@ static SEXP fetch(ca_handle h, const char* name, R_xlen_t nrow, R_xlen_t ncol) {
   return out;
 }
 
-SEXP C_clonealign_fit(SEXP Y, SEXP L, SEXP psi0, SEXP loc0, SEXP X, SEXP extra, SEXP K_, SEXP S_, SEXP max_iter_,
+SEXP C_clonealign_fit(SEXP Y, SEXP L, SEXP psi0, SEXP psi_noise, SEXP loc0, SEXP X, SEXP extra, SEXP K_, SEXP S_, SEXP max_iter_,
                       SEXP rel_tol_, SEXP lr_, SEXP eps_) {
   ca_problem p;
   memset(&p, 0, sizeof(p));
@@ -60,7 +64,14 @@ SEXP C_clonealign_fit(SEXP Y, SEXP L, SEXP psi0, SEXP loc0, SEXP X, SEXP extra, 
   p.layout = CA_COL_MAJOR;                                   /* R matrices as they are: no transpose, no copy */
   p.y_dtype = Rf_isInteger(Y) ? CA_I32 : CA_F64;
   p.Y = Rf_isInteger(Y) ? (const void*)INTEGER(Y) : (const void*)REAL(Y);
-  p.L = REAL(L); p.psi0 = p.K > 0 ? REAL(psi0) : NULL; p.loc0 = Rf_isNull(loc0) ? NULL : REAL(loc0);   /* NULL: data_init_mu = TRUE guess (:220-235) taken on the device */
+  const int device_pca = p.K > 0 && Rf_isNull(psi0);
+  double* psi_zero = NULL;
+  if (device_pca) {                                          /* the engine wants SOME psi0 at creation; ca_init_psi_pca overwrites it */
+    psi_zero = (double*)R_alloc((size_t)p.N * (size_t)p.K, sizeof(double));
+    memset(psi_zero, 0, sizeof(double) * (size_t)p.N * (size_t)p.K);
+  }
+  p.L = REAL(L); p.psi0 = p.K > 0 ? (device_pca ? psi_zero : REAL(psi0)) : NULL;
+  p.loc0 = Rf_isNull(loc0) ? NULL : REAL(loc0);   /* NULL: data_init_mu = TRUE guess (:220-235) taken on the device */
   p.X = p.P > 0 ? REAL(X) : NULL;
   p.extra_loglik = Rf_isNull(extra) ? NULL : REAL(extra);
   ca_options o;
@@ -68,6 +79,7 @@ SEXP C_clonealign_fit(SEXP Y, SEXP L, SEXP psi0, SEXP loc0, SEXP X, SEXP extra, 
   o.learning_rate = Rf_asReal(lr_);
   ca_handle h = NULL;
   if (ca_create(&p, &o, &h) != CA_OK) Rf_error("clonealign_hip: %s", ca_last_error(NULL));
+  if (device_pca && ca_init_psi_pca(h, Rf_isNull(psi_noise) ? NULL : REAL(psi_noise), 40, o.seed, NULL) != CA_OK) fail(h, "ca_init_psi_pca");
 
   const int max_iter = Rf_asInteger(max_iter_);
   const R_xlen_t per = (R_xlen_t)p.S * p.G, ndraw = 2 + 2 * (R_xlen_t)max_iter + 20;

@@ -5,8 +5,8 @@
 #include <string.h>
 #include "Rinternals.h"
 extern jmp_buf rstub_error_jmp; extern int rstub_error_armed; extern char rstub_error_msg[1024];
-SEXP C_clonealign_fit(SEXP Y, SEXP L, SEXP psi0, SEXP loc0, SEXP X, SEXP extra, SEXP K_, SEXP S_, SEXP max_iter_, SEXP rel_tol_,
-                      SEXP lr_, SEXP eps_);
+SEXP C_clonealign_fit(SEXP Y, SEXP L, SEXP psi0, SEXP psi_noise, SEXP loc0, SEXP X, SEXP extra, SEXP K_, SEXP S_, SEXP max_iter_,
+                      SEXP rel_tol_, SEXP lr_, SEXP eps_);
 
 static void copy_out(SEXP list, const char* name, double* dst, long cap, long* len) {
   for (R_xlen_t i = 0; i < XLENGTH(list); ++i)
@@ -20,7 +20,8 @@ static void copy_out(SEXP list, const char* name, double* dst, long cap, long* l
   if (len) *len = -1;
 }
 
-int harness_fit(const double* Yd, const int* Yi, int N, int G, const double* L, int C, const double* psi0, const double* loc0,
+/* psi0 NULL with K > 0: psi is initialised on the device (prcomp + scale) plus psi_noise (may be NULL) */
+int harness_fit(const double* Yd, const int* Yi, int N, int G, const double* L, int C, const double* psi0, const double* psi_noise, const double* loc0,
                 const double* X, int P, const double* extra, int K, int S, int max_iter, double rel_tol, double lr,
                 const double* eps, long n_eps, int interrupt_after, double* elbo, long* n_elbo, double* finals, double* mu,
                 double* clone_probs, double* s, double* alpha, double* psi, double* W, double* chi, double* beta, char* err) {
@@ -33,7 +34,8 @@ int harness_fit(const double* Yd, const int* Yi, int N, int G, const double* L, 
     return 1;
   }
   SEXP out = C_clonealign_fit(Yi ? rstub_int_matrix(Yi, N, G) : rstub_real_matrix(Yd, N, G), rstub_real_matrix(L, G, C),
-                              K > 0 ? rstub_real_matrix(psi0, N, K) : R_NilValue, loc0 ? rstub_real_vector(loc0, G) : R_NilValue,
+                              K > 0 && psi0 ? rstub_real_matrix(psi0, N, K) : R_NilValue, K > 0 && psi_noise ? rstub_real_matrix(psi_noise, N, K) : R_NilValue,
+                              loc0 ? rstub_real_vector(loc0, G) : R_NilValue,
                               P > 0 ? rstub_real_matrix(X, N, P) : R_NilValue, extra ? rstub_real_matrix(extra, N, C) : R_NilValue,
                               rstub_scalar_int(K), rstub_scalar_int(S), rstub_scalar_int(max_iter), rstub_scalar_real(rel_tol),
                               rstub_scalar_real(lr), eps ? rstub_real_vector(eps, n_eps) : R_NilValue);

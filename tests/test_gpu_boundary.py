@@ -83,6 +83,79 @@ def test_col_major_boundary_is_bitwise_the_row_major_engine(name, ydt):
         a.close(); b.close()
 
 
+@pytest.mark.parametrize("layout", ["row", "col"])
+def test_host_ingestion_of_every_dtype_and_layout_is_bitwise_the_device_pointer_upload(layout):
+    """Round 5: host matrices go up through pinned double buffers in chunks, float64 narrowed to float32 by the host
+    threads on the way (clonealign_hip.hip ingest_host_matrix) instead of one pageable copy into an N*G*8-byte staging buffer.  For all five
+    ca_dtypes and both layouts -- on a matrix that spans several 16 MiB chunks, ragged at the end, with counts above 255 (overflow list)
+    -- the engine must be bit for bit the one built from a DEVICE pointer to the same counts (the path that never touches host bytes)."""
+    import torch
+    from clonealign_amd.engine import HipEngine
+    N, G = 9100, 1031                                    # 9.4 M counts: 5 chunks as float32, 3 as int32, ragged tails
+    case = make_case(seed=91, N=N, G=G, C=5, K=1)
+    rng = np.random.default_rng(4)
+    Y = np.minimum(case["Y"], 250).astype(np.int64)
+    idx = rng.integers(0, Y.size, size=300)
+    Y.reshape(-1)[idx] += rng.integers(200, 3000, size=idx.size)    # entries above 255: u8 storage with the overflow list
+    e = [eps_for(1, G, 70 + i) for i in range(4)]
+
+    def fit(eng):
+        try:
+            eng.gamma_init(e[0])
+            a = eng.elbo(e[1])
+            eng.step(e[2])
+            return a, eng.elbo(e[3]), eng.get_state(), eng.info()["y_storage_name"]
+        finally:
+            eng.close()
+
+    order = "F" if layout == "col" else "C"
+    kw = dict(L=case["L"], psi0=case["psi0"], loc0=case["loc0"], K=1, layout=layout)
+    for dt, cap in ((np.float64, None), (np.float32, None), (np.int32, None), (np.uint16, None), (np.uint8, 255)):
+        Yt = (np.minimum(Y, cap) if cap else Y).astype(dt, order=order)
+        Yd = torch.from_numpy(np.ascontiguousarray(Yt.T if layout == "col" else Yt)).cuda()     # the same bytes on the device, same layout
+        ref = fit(HipEngine(None, y_device_ptr=Yd.data_ptr(), y_device_dtype=dt, shape=(N, G), **kw))
+        got = fit(HipEngine(Yt, **kw))
+        assert got[0] == ref[0] and got[1] == ref[1] and got[3] == ref[3] == "u8", (dt, got[:2], ref[:2], got[3])
+        for n in ref[2]:
+            assert np.array_equal(got[2][n], ref[2][n]), (dt, n)
+        del Yd
+
+
+def test_host_ingestion_reports_the_errors_of_the_device_scan():
+    """What the narrowing host pass must not change: NaN / negative counts and counts no storage type can hold are refused with the
+    messages the device scan gives -- also when the offending double sits in the LAST ragged chunk; a double that is not exactly a float
+    (0.1) is 'not exactly representable'; NaN wins over it; and with a selection (ca_problem.cell_index) a bad value OUTSIDE the
+    selected cells is nobody's business."""
+    from clonealign_amd.engine import EngineError, HipEngine
+    N, G = 5000, 900
+    case = make_case(seed=92, N=N, G=G, C=3, K=1)
+    kw = dict(L=case["L"], psi0=case["psi0"], loc0=case["loc0"], K=1)
+    Y = case["Y"].astype(np.float64)
+    for val, msg in ((np.nan, "negative or NaN"), (-1.0, "negative or NaN"), (0.1, "not exactly representable"), (2.0 ** 40 + 1.0, "not exactly representable")):
+        Yb = Y.copy()
+        Yb[N - 1, G - 1] = val
+        if val == 0.1:
+            Yb[3, 3] = np.nan; msg = "negative or NaN"          # NaN takes precedence over inexactness
+        with pytest.raises(EngineError) as ex:
+            HipEngine(Yb, **kw)
+        assert ex.value.code == 1 and msg in ex.value.msg, (val, ex.value.msg)
+    Yb = Y.copy()
+    Yb[N - 1, 5] = 0.1
+    with pytest.raises(EngineError) as ex:
+        HipEngine(Yb, **kw)
+    assert "not exactly representable" in ex.value.msg
+    # ... but outside the selection it does not matter: same engine as on the clean matrix cut the same way
+    keep = np.arange(N - 1)
+    kws = dict(L=case["L"], psi0=case["psi0"][:-1], loc0=case["loc0"], K=1, cell_index=keep)
+    a, b = HipEngine(Yb, **kws), HipEngine(Y, **kws)
+    try:
+        e0 = eps_for(1, G, 5)
+        a.gamma_init(e0); b.gamma_init(e0)
+        assert a.elbo(e0) == b.elbo(e0)
+    finally:
+        a.close(); b.close()
+
+
 def test_col_major_device_helpers_match_row_major():
     """ca_init_psi_pca (noise in, pcs out), ca_clone_gene_sums (T out), ca_preprocess, ca_allele_loglik in both layouts."""
     from clonealign_amd.engine import allele_loglik, preprocess_masks
@@ -184,7 +257,8 @@ def _harness():
     return lib
 
 
-def _call_shim(lib, Y, L, psi0, loc0, K, S, max_iter, rel_tol, lr, eps, X=None, extra=None, interrupt_after=0):
+def _call_shim(lib, Y, L, psi0, loc0, K, S, max_iter, rel_tol, lr, eps, X=None, extra=None, interrupt_after=0, psi_noise=None):
+    """psi0 None with K > 0: the shim initialises psi on the device (prcomp + scale) plus psi_noise (or nothing)."""
     N, G = Y.shape
     Cn = L.shape[1]
     P = 0 if X is None else X.shape[1]
@@ -192,7 +266,7 @@ def _call_shim(lib, Y, L, psi0, loc0, K, S, max_iter, rel_tol, lr, eps, X=None, 
     ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)                       # noqa: E731
     Yd = None if Y.dtype == np.int32 else f(Y)
     Yi = np.asfortranarray(Y) if Y.dtype == np.int32 else None
-    Lf, p0, Xf, exf = f(L), f(psi0), f(X), f(extra)
+    Lf, p0, Xf, exf, pn = f(L), f(psi0), f(X), f(extra), f(psi_noise)
     l0 = None if loc0 is None else np.ascontiguousarray(loc0, dtype=np.float64)
     ev = None if eps is None else np.ascontiguousarray(eps, dtype=np.float64).reshape(-1)
     out = dict(elbo=np.zeros(max_iter + 1), finals=np.zeros(20), mu=np.zeros(G), clone_probs=np.zeros((N, Cn), order="F"),
@@ -200,7 +274,7 @@ def _call_shim(lib, Y, L, psi0, loc0, K, S, max_iter, rel_tol, lr, eps, X=None, 
                chi=np.zeros(K), beta=np.zeros((G, P), order="F"))
     n_elbo = C.c_long()
     err = C.create_string_buffer(1024)
-    rc = lib.harness_fit(ptr(Yd), ptr(Yi), C.c_int(N), C.c_int(G), ptr(Lf), C.c_int(Cn), ptr(p0), ptr(l0), ptr(Xf), C.c_int(P),
+    rc = lib.harness_fit(ptr(Yd), ptr(Yi), C.c_int(N), C.c_int(G), ptr(Lf), C.c_int(Cn), ptr(p0), ptr(pn), ptr(l0), ptr(Xf), C.c_int(P),
                          ptr(exf), C.c_int(K), C.c_int(S), C.c_int(max_iter), C.c_double(rel_tol), C.c_double(lr), ptr(ev),
                          C.c_long(0 if ev is None else ev.size), C.c_int(interrupt_after), ptr(out["elbo"]), C.byref(n_elbo),
                          ptr(out["finals"]), ptr(out["mu"]), ptr(out["clone_probs"]), ptr(out["s"]), ptr(out["alpha"]),
@@ -235,6 +309,42 @@ def test_r_shim_call_entry_point_on_example_sce(ydt):
         eng.close()
     # the oracle's golden trace for the same eps stream (200 iterations recorded; the first 25 here)
     np.testing.assert_allclose(out["elbo"], g["elbo_trace"][:max_iter + 1], rtol=1e-5)
+
+
+def test_r_shim_single_fit_with_the_initial_values_made_on_the_device():
+    """the drop-in inference_tflow() always called host prcomp() -- minutes at 100k x 5k in front of a 60 ms fit.
+    C_clonealign_fit(psi0 = NULL, psi_noise, loc0 = NULL) makes both initial values on the device from the resident matrix
+    (ca_init_psi_pca; ca_problem.loc0 = NULL).  On example_sce, against the fit started from the host's prcomp + scale + the same noise
+    and the host's mu guess (hostprep = R/inference-tflow.R:204-235): the device PCs equal prcomp's to 2e-4 up to sign (asserted in
+    tests/test_gpu_scale.py), so from the same eps the two fits give the same clone labels and the same ml_params to 1e-3 -- after the
+    device components are given the host's sign, which prcomp itself does not define."""
+    from clonealign_amd import hostprep
+    from clonealign_amd.api import clone_assignment
+    lib = _harness()
+    Y, L, *_ = _golden.example()
+    Ls = hostprep.saturate(L, 6)
+    N, G = Y.shape
+    max_iter = 40
+    rng = np.random.default_rng(12)
+    noise = rng.normal(0, 0.05, size=(N, 1))
+    eps = rng.normal(size=(2 + 2 * max_iter + 20, G)).astype(np.float32)
+    pcs = hostprep.pca_init(Y, 1, None)
+    loc0 = hostprep.safe_inverse_softplus(hostprep.mu_guess(Y, True))
+    rc, msg, dev = _call_shim(lib, Y, Ls, None, None, 1, 1, max_iter, 1e-12, 0.1, eps, psi_noise=noise)
+    assert rc == 0, msg
+    # the device component's sign (largest loading positive) may be the opposite of LAPACK's: start the host fit from the same one
+    rc0, msg0, probe = _call_shim(lib, Y, Ls, None, None, 1, 1, 0, 1e-12, 0.1, eps[:22], psi_noise=np.zeros((N, 1)))
+    assert rc0 == 0, msg0
+    sign = 1.0 if np.abs(probe["psi"][:, 0] - pcs[:, 0]).max() < np.abs(probe["psi"][:, 0] + pcs[:, 0]).max() else -1.0
+    assert np.abs(probe["psi"][:, 0] - sign * pcs[:, 0]).max() < 2e-4
+    rc, msg, host = _call_shim(lib, Y, Ls, sign * pcs + noise, loc0, 1, 1, max_iter, 1e-12, 0.1, eps)
+    assert rc == 0, msg
+    assert len(dev["elbo"]) == len(host["elbo"]) == max_iter + 1
+    np.testing.assert_allclose(dev["elbo"], host["elbo"], rtol=1e-4)
+    la, lb = clone_assignment(dev["clone_probs"], list("ABC")), clone_assignment(host["clone_probs"], list("ABC"))
+    assert list(la) == list(lb)
+    for n in ("mu", "clone_probs", "alpha", "psi", "W", "chi", "s"):
+        assert np.abs(dev[n] - host[n]).max() <= 1e-3 * max(np.abs(host[n]).max(), 1e-30), n
 
 
 def test_r_shim_interrupt_and_error_paths_free_the_engine_first():

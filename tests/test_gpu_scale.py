@@ -276,7 +276,7 @@ def test_device_pca_init_matches_prcomp_up_to_sign():
             ref = hostprep.pca_init(Y, K, None)
             for k in range(K):
                 err = min(np.abs(dev[:, k] - ref[:, k]).max(), np.abs(dev[:, k] + ref[:, k]).max())
-                assert err < 2e-3, (K, k, err)      # fp32 streaming sums + v_log_f32 vs float64 SVD
+                assert err < 2e-4, (K, k, err)      # float64 column statistics (round 5); fp32 streaming projections + v_log_f32 vs float64 SVD
             np.testing.assert_allclose(dev.std(0, ddof=1), 1.0, rtol=1e-6)
             np.testing.assert_allclose(eng.get("psi"), dev, rtol=0, atol=1e-6)
         finally:
@@ -315,8 +315,16 @@ def test_clonealign_end_to_end_with_device_pca():
         from clonealign_amd.inference import inference_tflow
         b = inference_tflow(Y, L, max_iter=20, rel_tol=1e-6, verbose=False, seed=3, K=1, psi_init="device")
     assert len(b["convergence_info"]["elbo"]) == 21 and np.isfinite(b["convergence_info"]["final_elbo"])
-    # same data, same seeds, host vs device PCA init: ELBO after 20 iterations agrees to MC noise
-    assert abs(a["convergence_info"]["final_elbo"] - b["convergence_info"]["final_elbo"]) < 60.0
+    # same data, same seeds, host vs device PCA init (same sign convention on both sides: hostprep.pca_init fixes the sign the way the device
+    # does): the same fit -- clone labels equal, ml_params to 1e-3, ELBO trace to 1e-4 (round 4 asserted |final ELBO difference| < 60)
+    a2 = inference_tflow(Y, L, max_iter=20, rel_tol=1e-6, verbose=False, seed=3, K=1, psi_init="host")
+    from clonealign_amd.api import clone_assignment
+    np.testing.assert_allclose(b["convergence_info"]["elbo"], a2["convergence_info"]["elbo"], rtol=1e-4)
+    pa, pb = a2["ml_params"], b["ml_params"]
+    assert list(clone_assignment(pa["clone_probs"], clones)) == list(clone_assignment(pb["clone_probs"], clones))
+    for n in pa:   # (psi, W: the sign of a principal component is LAPACK's on the host and "largest loading positive" on the device; the model is symmetric in it)
+        d = min(np.abs(pa[n] - pb[n]).max(), np.abs(pa[n] + pb[n]).max()) if n in ("psi", "W") else np.abs(pa[n] - pb[n]).max()
+        assert d <= 1e-3 * max(np.abs(pa[n]).max(), 1e-30), n
 
 
 def test_device_correlation_sums_match_host_compute_correlations():
