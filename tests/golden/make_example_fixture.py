@@ -9,7 +9,9 @@ tests load: tests/testthat/test_clonealign.R:6,11) and writes
   L      int32 [100 genes, 3 clones]    = rowData(example_sce)[, c("A","B","C")]
   genes  str   [100], cells str [200], clones str [3]
 
-Run in the build container only (``/root/reference`` does not travel).
+Run in the build container only (``/root/reference`` does not travel).  The data file itself is kept beside the fixture
+(``tests/golden/example_sce.rda``: data the reference's own tests hold, not source) so that the reader can be tested anywhere:
+tests/test_host_api.py::test_rdx2_reader_rederives_the_fixture_and_the_vignette_preprocessing.
 """
 import os
 import sys
@@ -21,7 +23,8 @@ sys.path.insert(0, HERE)
 import rdx2  # noqa: E402
 
 
-def main(ref="/root/reference/data/example_sce.rda"):
+def extract(ref):
+    """(Y int32 [200, 100], L int32 [100, 3], genes, cells, clones) out of an example_sce.rda, every checksum of SURVEY.md section 7.2 asserted."""
     sce = rdx2.read_rda(ref)["example_sce"]
     data = sce.attr["assays"].attr[".xData"].value[".->data"]
     counts = data.attr["listData"].get("counts")
@@ -43,6 +46,11 @@ def main(ref="/root/reference/data/example_sce.rda"):
     assert L[:3].tolist() == [[1, 2, 2], [2, 1, 1], [3, 2, 2]]
     assert sce.attr["rowRanges"].attr["partitioning"].attr["NAMES"].value == genes
     assert sce.attr["colData"].attr["rownames"].value == cells
+    return Y, L, genes, cells, clones
+
+
+def main(ref="/root/reference/data/example_sce.rda"):
+    Y, L, genes, cells, clones = extract(ref)
     out = os.path.join(HERE, "example_sce.npz")
     np.savez_compressed(out, Y=Y, L=L, genes=np.array(genes), cells=np.array(cells),
                         clones=np.array(clones))

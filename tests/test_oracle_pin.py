@@ -176,3 +176,49 @@ def test_adam_rule_is_tf1_epsilon_hat_form(model_cls, row):
             p.grad = torch.tensor([gv], dtype=F64)
             opt.step()
         assert abs(float(p.detach()) - want[2]) > 1e-2
+
+
+def _zero_copy_number_case():
+    """tiny_full with one gene that no cell expresses and whose copy number is 0 in clone 1: y = 0 AND L = 0 at every (cell, that gene,
+    clone 1) -- the `0 * log 0` of tfd$Multinomial$log_prob (R/inference-tflow.R:294-296), which TFP-0.9's `counts * log(probs)` turns
+    into NaN and later TFP versions (`multiply_no_nan`) into 0.  The oracles and the engine take the second reading (SURVEY.md section 7.4,
+    DESIGN.md section 3): xlogy, 0 * log 0 := 0."""
+    g = _golden.load("tiny_full")
+    case = _golden.case_of("tiny_full", g)
+    Y, L = np.array(case["Y"], dtype=np.float64), np.array(case["L"], dtype=np.float64)
+    g0 = 3
+    Y[:, g0] = 0.0
+    L[g0, 1] = 0.0
+    case = dict(case, Y=Y, L=L)
+    return g, case, g0
+
+
+def test_zero_copy_number_where_nothing_is_counted_is_xlogy_zero_not_nan():
+    """VERDICT r4 #9a: the stated semantics of `L_gc = 0`, asserted as a VALUE (the NaN-initial-ELBO error for y > 0 is a GPU test already):
+    with y = 0 wherever L = 0 every ELBO term is finite and equals what torch.distributions.Multinomial and scipy.stats.multinomial give
+    for a probability vector with an exact zero at an uncounted category -- both libraries define that term as 0 -- to 1e-12; and the
+    zero entry changes the fit only through Z: the same case with L = 1e-300 there gives the same ELBO to 1e-12."""
+    g, case, g0 = _zero_copy_number_case()
+    lit, fus = LiteralModel(**case), FusedModel(**case)
+    lit.gamma_init(g["eps"][0]); fus.gamma_init(g["eps"][0])
+    state = lit.get_state()
+    for j in (1, 4):
+        eps = g["eps"][j]
+        want = elbo_terms_from_distribution_objects(case, state, eps)     # (asserts torch == scipy on the multinomial term inside)
+        assert np.all(np.isfinite(want))
+        np.testing.assert_allclose(lit.elbo_terms(eps), want, rtol=1e-12)
+        np.testing.assert_allclose(fus.elbo_terms(eps), want, rtol=1e-11)
+    tiny = dict(case, L=np.where(case["L"] == 0.0, 1e-300, case["L"]))
+    lit2 = LiteralModel(**tiny)
+    lit2.gamma_init(g["eps"][0])
+    np.testing.assert_allclose(lit2.elbo(g["eps"][1]), lit.elbo(g["eps"][1]), rtol=1e-12)
+    # gradients stay finite too (the backward pass multiplies by L, never divides by it)
+    gr, _ = fus.gradients(g["eps"][2])
+    assert all(np.all(np.isfinite(v)) for v in gr.values())
+    # ... and ONE count on that gene makes the clone impossible for that cell: log-likelihood -inf, posterior weight exactly 0 after the
+    # gamma initialisation (:338-342), ELBO NaN from 0 * (-inf) -- the reference's "Initial elbo is NA" (:374-376)
+    Yb = case["Y"].copy(); Yb[2, g0] = 1.0
+    bad = FusedModel(**dict(case, Y=Yb))
+    bad.gamma_init(g["eps"][0])
+    gam = np.exp(bad.gamma_logits - scipy.special.logsumexp(bad.gamma_logits, axis=1, keepdims=True))
+    assert gam[2, 1] == 0.0 and np.isnan(bad.elbo(g["eps"][1]))
