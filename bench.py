@@ -453,7 +453,7 @@ def main():
                 # (the peer-to-peer transport has never run across xGMI on any box this build has seen; every rank takes part, then the
                 # ranks agree on the verdict)
                 try:
-                    bad = e_new.comm_selftest(6)
+                    bad = e_new.comm_selftest(48)
                 except Exception as ex:  # noqa: BLE001
                     bad = -1
                     print(f"[rank {rank}] transport {tr}: known-answer test failed to run: {ex}", file=sys.stderr, flush=True)
@@ -569,6 +569,17 @@ def main():
             ds = float(t[0])
         steady = {"steps": steady_steps, "value": steady_steps / ds, "ms_per_step": ds / steady_steps * 1e3,
                   "what": f"one ca_iterate({steady_steps}) region, same barriers; not the headline (the headline is the --steps region above)"}
+    # the replicas after everything the timed regions did to them: every rank applied the same all-reduced sums in the same order, so the
+    # replicated variables must be bit-identical across ranks (a transport that tears or reorders rarely would show here first)
+    replicas_equal = None
+    if world > 1:
+        import hashlib
+        hsh = hashlib.sha1()
+        for nm in ("loc", "ls", "W", "alpha_unconstr", "v"):
+            hsh.update(np.ascontiguousarray(eng.get(nm)).tobytes())
+        box = [None] * world
+        dist.all_gather_object(box, hsh.hexdigest())
+        replicas_equal = len(set(box)) == 1
     # a monitor pass on its own (plain forward + its (3 + C)-double all-reduce + read-back): the latency floor of one collective
     mon_us = None
     if world > 1:
@@ -754,6 +765,8 @@ def main():
         if busy_it:
             out["untimed_busy_tail"] = {"seconds": busy_s, "iterations": busy_it, "it_per_s": busy_it / busy_s,
                                         "what": "untimed ca_iterate calls after the measurements (see --busy-seconds); not part of value"}
+        if replicas_equal is not None:
+            out["replicas_bit_identical_after_timed_regions"] = replicas_equal
         if mon_us is not None:
             out["monitor_pass_us_with_collective"] = mon_us
         if ar_us is not None:

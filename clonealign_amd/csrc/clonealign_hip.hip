@@ -3010,27 +3010,84 @@ int ca_comm_selftest(ca_handle h, int32_t n_rounds, int64_t n_doubles, int64_t* 
   CA_NOT_IN_RUN(h);
   HIPCK(h, hipSetDevice(h->device));
   *n_bad = 0;
+  // Round 5: the transport is asked what the loop asks of it, not six equal calls.  Call sizes ALTERNATE -- the train pass's
+  // payload, a monitor pass's 3 + C doubles, and a vector longer than the peer-to-peer inbox (several pieces per call) -- in BURSTS of
+  // back-to-back calls with no host synchronisation between them (both inbox parities and the sequence tags under the loop's own timing:
+  // a fast rank one call ahead of a slow one), every sum checked; and, on the peer-to-peer transport, the RIDE form of the call (the
+  // backward sweep's slabs folded and a block-partial sum added inside the all-reduce's launch, ca_p2p_args) against the same sums made
+  // on the host.  Summands are small integers and halves times (rank + 1): every partial sum is exact in a double in any order.
   const double W = (double)std::max(h->opt.world, 1), tri = W * (W + 1.0) / 2.0;
+  const bool p2p = h->p2p && h->p2p->connected;
+  const int64_t big = p2p ? 2 * h->p2p->cap + 17 : 2 * n_doubles + 17;
+  const int64_t sizes[3] = {n_doubles, std::min<int64_t>(n_doubles, 11), big};
+  constexpr int BURST = 8;
+  int64_t slot = 0;
+  for (int64_t sz : sizes) slot = std::max(slot, sz);
   double* buf = nullptr;
-  HIPCK(h, hipMalloc((void**)&buf, (size_t)n_doubles * sizeof(double)));
-  std::vector<double> host((size_t)n_doubles);
-  int rc = CA_OK;
+  HIPCK(h, hipMalloc((void**)&buf, (size_t)(slot * BURST) * sizeof(double)));
+  std::vector<double> host((size_t)(slot * BURST));
   auto pattern = [](int64_t i, int r) { return (double)((i * 7 + (int64_t)r * 13) % 251 + 1); };
+  int64_t checked = 0;
   auto run = [&]() -> int {
-    for (int r = 0; r < n_rounds; ++r) {
-      for (int64_t i = 0; i < n_doubles; ++i) host[(size_t)i] = (double)(h->opt.rank + 1) * pattern(i, r) + 0.5 * r;
-      HIPCK(h, hipMemcpyAsync(buf, host.data(), (size_t)n_doubles * sizeof(double), hipMemcpyHostToDevice, h->stream));
-      CACK(allreduce(h, buf, n_doubles));
-      HIPCK(h, hipMemcpyAsync(host.data(), buf, (size_t)n_doubles * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    for (int r0 = 0; r0 < n_rounds; r0 += BURST) {
+      const int nb = std::min(BURST, n_rounds - r0);
+      for (int j = 0; j < nb; ++j) {
+        const int r = r0 + j;
+        const int64_t sz = sizes[r % 3];
+        for (int64_t i = 0; i < sz; ++i) host[(size_t)(j * slot + i)] = (double)(h->opt.rank + 1) * pattern(i, r) + 0.5 * r;
+      }
+      HIPCK(h, hipMemcpyAsync(buf, host.data(), (size_t)(slot * nb) * sizeof(double), hipMemcpyHostToDevice, h->stream));
+      for (int j = 0; j < nb; ++j) CACK(allreduce(h, buf + j * slot, sizes[(r0 + j) % 3]));     // back to back, no host in between
+      HIPCK(h, hipMemcpyAsync(host.data(), buf, (size_t)(slot * nb) * sizeof(double), hipMemcpyDeviceToHost, h->stream));
       SYNC(h);
-      for (int64_t i = 0; i < n_doubles; ++i)
-        if (host[(size_t)i] != tri * pattern(i, r) + W * 0.5 * r) *n_bad += 1;
+      for (int j = 0; j < nb; ++j) {
+        const int r = r0 + j;
+        const int64_t sz = sizes[r % 3];
+        checked += sz;
+        for (int64_t i = 0; i < sz; ++i)
+          if (host[(size_t)(j * slot + i)] != tri * pattern(i, r) + W * 0.5 * r) *n_bad += 1;
+      }
+    }
+    if (p2p && p2p_ride_ok(h, n_doubles) && n_doubles >= 8) {
+      // ride form: entries [lo, lo + fn) are column sums of `ns` float slabs made here, entry `yi` also gets the sum of `ny` block partials
+      const int64_t n = n_doubles, lo = std::min<int64_t>(3, n - 4), fn = n - lo - 1, yi = 0;
+      const int ns = 5, ny = 37;
+      std::vector<float> slabs((size_t)(ns * fn));
+      std::vector<double> ywp((size_t)ny), base((size_t)n), want((size_t)n);
+      for (int rep = 0; rep < 4; ++rep) {
+        for (int sl = 0; sl < ns; ++sl) for (int64_t i = 0; i < fn; ++i) slabs[(size_t)(sl * fn + i)] = (float)((h->opt.rank + 1) * ((i + 3 * sl + rep) % 17));
+        for (int b2 = 0; b2 < ny; ++b2) ywp[(size_t)b2] = (double)((h->opt.rank + 1) * ((b2 + rep) % 5)) * 0.5;
+        for (int64_t i = 0; i < n; ++i) base[(size_t)i] = (double)(h->opt.rank + 1) * pattern(i, 100 + rep);
+        for (int64_t i = 0; i < n; ++i) {   // what every rank contributes, then summed over ranks: (rank + 1) factors out -> tri
+          double mine = (i >= lo && i < lo + fn) ? 0.0 : pattern(i, 100 + rep);
+          if (i >= lo && i < lo + fn) for (int sl = 0; sl < ns; ++sl) mine += (double)(((i - lo) + 3 * sl + rep) % 17);
+          if (i == yi) for (int b2 = 0; b2 < ny; ++b2) mine += 0.5 * (double)((b2 + rep) % 5);
+          want[(size_t)i] = tri * mine;
+        }
+        float* gdev = nullptr; double* ydev = nullptr;
+        HIPCK(h, hipMalloc((void**)&gdev, slabs.size() * sizeof(float)));
+        if (hipMalloc((void**)&ydev, ywp.size() * sizeof(double)) != hipSuccess) { hipFree(gdev); h->err = "hipMalloc failed"; return CA_ERR_NOMEM; }
+        hipMemcpyAsync(gdev, slabs.data(), slabs.size() * sizeof(float), hipMemcpyHostToDevice, h->stream);
+        hipMemcpyAsync(ydev, ywp.data(), ywp.size() * sizeof(double), hipMemcpyHostToDevice, h->stream);
+        hipMemcpyAsync(buf, base.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream);
+        ca_ar_ride ride;
+        ride.gpart = gdev; ride.nslice = ns; ride.fold_lo = lo; ride.fold_n = fn; ride.yw_part = ydev; ride.n_yw = ny; ride.yw_index = yi;
+        int rc2 = allreduce(h, buf, n, &ride);
+        if (rc2 == CA_OK && hipMemcpyAsync(host.data(), buf, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream) != hipSuccess) rc2 = CA_ERR_HIP;
+        const hipError_t e2 = hipStreamSynchronize(h->stream);
+        hipFree(gdev); hipFree(ydev);
+        if (rc2 != CA_OK) return rc2;
+        if (e2 != hipSuccess) { h->err = hipGetErrorString(e2); return CA_ERR_HIP; }
+        CACK(comm_check(h));
+        checked += n;
+        for (int64_t i = 0; i < n; ++i) if (host[(size_t)i] != want[(size_t)i]) *n_bad += 1;
+      }
     }
     return CA_OK;
   };
-  rc = run();
+  const int rc = run();
   hipFree(buf);
-  if (rc == CA_OK && *n_bad) h->err = "all-reduce known-answer test: " + std::to_string(*n_bad) + " of " + std::to_string((int64_t)n_rounds * n_doubles) + " sums are wrong";
+  if (rc == CA_OK && *n_bad) h->err = "all-reduce known-answer test: " + std::to_string(*n_bad) + " of " + std::to_string(checked) + " sums are wrong";
   return rc;
 }
 

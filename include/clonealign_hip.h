@@ -253,11 +253,14 @@ int ca_p2p_commit(ca_handle h, int32_t all_ranks_ok);
 /* us per all-reduce of n_doubles doubles on one device transport (CA_TRANSPORT_P2P or CA_TRANSPORT_RCCL) of this engine, n_calls
  * back to back on the engine's stream between two HIP events; collective.  bench.py reports it beside the iteration time. */
 int ca_comm_benchmark(ca_handle h, int32_t transport, int32_t n_calls, int64_t n_doubles, double* us_per_call);
-/* Known-answer test of the engine's ACTIVE all-reduce (whatever ca_info.transport says): n_rounds all-reduces of n_doubles doubles whose
- * summands are (rank + 1) * pattern(i, round) + round / 2 -- every partial sum is an integer or a half, exact in a double in any order -- checked
- * on the host against W (W + 1) / 2 * pattern + W * round / 2.  *n_bad = entries that came back wrong (0 = the transport adds what it should: both
- * inbox parities and the sequence tags of the peer-to-peer form are exercised from the second round on).  Collective.  The first time a transport
- * runs on hardware it has never run on (peer-to-peer across xGMI), this is what a launcher asks before it trusts it (bench.py does). */
+/* Known-answer test of the engine's ACTIVE all-reduce (whatever ca_info.transport says): n_rounds all-reduces whose summands are
+ * (rank + 1) * pattern(i, round) + round / 2 -- every partial sum is an integer or a half, exact in a double in any order -- checked on the host
+ * against W (W + 1) / 2 * pattern + W * round / 2.  Call sizes alternate as the loop's do -- n_doubles (the train pass's payload), min(n_doubles, 11)
+ * (a monitor pass's), and a vector longer than the peer-to-peer inbox (several pieces per call) -- in bursts of eight back-to-back calls with
+ * no host synchronisation between them (both inbox parities and the sequence tags at the loop's own pace); on the peer-to-peer transport
+ * four calls of the RIDE form follow (slab fold + block-partial sum inside the all-reduce's launch, checked against the same sums made on the
+ * host).  *n_bad = entries that came back wrong (0 = the transport adds what it should).  Collective.  The first time a transport runs on
+ * hardware it has never run on (peer-to-peer across xGMI), this is what a launcher asks before it trusts it (bench.py: 48 rounds). */
 int ca_comm_selftest(ca_handle h, int32_t n_rounds, int64_t n_doubles, int64_t* n_bad);
 /* Alternative transport for world > 1 (MPI, gloo, tests): the engine hands the summand buffer to the
  * host callback, which must replace buf[0..n) by its sum over all ranks (same order on every rank)

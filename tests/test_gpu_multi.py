@@ -204,7 +204,7 @@ def test_bare_bench_command_starts_its_own_ranks(world):
     line = json.loads(lines[0])
     assert line["n_gpus"] == world and line["config"]["collective"] == "p2p" and line["scaling"] == "strong"
     assert line["config"]["allreduce_selftest"] == {"p2p": True} and line["value"] > 0
-    assert line["config"]["parallelism"] == f"cells/{world}"
+    assert line["config"]["parallelism"] == f"cells/{world}" and line["replicas_bit_identical_after_timed_regions"] is True
 
 
 def test_bare_bench_command_refuses_more_ranks_than_devices_and_relays_a_failing_rank():

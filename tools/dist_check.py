@@ -69,7 +69,7 @@ def main():
             kw["host_allreduce"] = gloo_sum
     eng = HipEngine(case["Y"][lo:hi], case["L"], case["psi0"][lo:hi], case["loc0"], 1, S, device=local, rank=rank, world=world,
                     comm_timeout_ms=args.comm_timeout_ms, variant_off=tuple(v for v in args.variant_off.split(",") if v), **kw)
-    selftest_bad = eng.comm_selftest(5) if world > 1 else 0     # known-answer all-reduces on the transport in use, before the fit
+    selftest_bad = eng.comm_selftest(27) if world > 1 else 0     # known-answer all-reduces on the transport in use, before the fit
     eps = np.stack([eps_for(S, args.genes, 300 + i) for i in range(2 + 2 * args.iters + 4)])
     trace = eng.run(eps, args.iters, 1e-12)
     finals = eng.final_elbo(eps[2 + 2 * args.iters:], 4)
