@@ -226,8 +226,8 @@ __global__ void k_convert_y_u8ovf(const ST* __restrict__ src, uint8_t* __restric
 // overflow-list contributions to the Y stream products, one thread per cell (CSR order) / per gene (CSC order)
 __device__ __forceinline__ void ca_ovf_rows_body(int blk, const int64_t* __restrict__ rowptr, const int* __restrict__ col,
                                                  const float* __restrict__ val, const float* __restrict__ V, int Dstride,
-                                                 float* __restrict__ YWextra /*[N][K]*/, int64_t N, int K, int tf) {
-  const int64_t n = (int64_t)blk * blockDim.x + threadIdx.x;
+                                                 float* __restrict__ YWextra /*[N][K]*/, int64_t N, int K, int tf, int bdim = 0 /* rows per block; 0 = blockDim.x */) {
+  const int64_t n = (int64_t)blk * (bdim ? bdim : (int)blockDim.x) + threadIdx.x;
   if (n >= N) return;
   for (int k = 0; k < K; ++k) {
     float a = 0.f;
@@ -2289,9 +2289,13 @@ struct ca_cell_ptrs {
   // the host never answered) and every block of this launch returns at once -- nothing read, nothing stored.  null: an ordinary launch.
   const unsigned long long* gate; unsigned long long gate_go;
 };
+// Round 5: what a lane of the epilogue reads for its (cell, clone) that nothing in the sweep produces -- the q(z) logit, the library size, the
+// hoisted constant A_nc.  A small sweep block (<= 32 cells: ONE pass of the epilogue) loads them BEFORE its k-loop, so that the epilogue's fp64
+// chain starts from registers instead of from a round of loads behind the combine barrier (the block's CU has nothing else to hide it with).
+struct ca_cell_pre { float gl; double sn, Anc; };
 template <int CP, bool WR = true>   // WR = false (mc_samples = 2, four draws in one sweep): the monitor pass's pair of samples -- sums only, no coef / d logits
 __device__ __forceinline__ void ca_cell_fused_group(const ca_cell_ptrs& p, const double* la, int64_t n, int64_t N, int C, int D, int K,
-                                                    double ZA, double ZB, ca_cell_acc& acc) {
+                                                    double ZA, double ZB, ca_cell_acc& acc, const ca_cell_pre* pre = nullptr) {
   const int c = threadIdx.x % CP;
   auto gmax = [](double v) {
 #pragma unroll
@@ -2306,16 +2310,16 @@ __device__ __forceinline__ void ca_cell_fused_group(const ca_cell_ptrs& p, const
   const bool okn = n < N, ok = okn && c < C;
   const int64_t nn = okn ? n : N - 1;
   const int cc = c < C ? c : C - 1;
-  const double gl = ok ? (double)p.glogit[nn * C + cc] : -INFINITY;
+  const double gl = ok ? (double)(pre ? pre->gl : p.glogit[nn * C + cc]) : -INFINITY;
   const double mx = gmax(gl);
   const double ex = ok ? exp(gl - mx) : 0.0;
   const double se = gsum(ex);
   const double lse = mx + log(se);
   const double lg = gl - lse;
   const double gam = ok ? ex / se : 0.0;
-  const double sn = p.s64[nn];
+  const double sn = pre ? pre->sn : p.s64[nn];
   const double em = (D > 0) ? (double)p.etamax2[nn] * CA_LN2 : 0.0;
-  const double Anc = p.A[nn * C + cc];
+  const double Anc = pre ? pre->Anc : p.A[nn * C + cc];
   double llpA = Anc - sn * (log(ZA) + em);
   double llpB = Anc - sn * (log(ZB) + em);
   if (CP != 16 && p.s2) {   // (uniform) two samples of one pass: ll' = A - s mean_s log Z_s (:306-308), coef_s = -gamma s / (2 Z_s)
@@ -2538,33 +2542,19 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
   float f[TL][D], em[TL];
   ca_f32x4 acc[TL];
   CA_LAB_PH(blk, 0);
-  float vmn[D], vmx[D];   // (merged update: range of V' over all genes)
-  if (p.vmm_at) {
-#pragma unroll
-    for (int d = 0; d < D; ++d) { vmn[d] = ca_ord2f(p.vmm_at[d]); vmx[d] = ca_ord2f(p.vmm_at[8 + d]); }
+  // Round 5: a small block (<= 32 cells) is alone or nearly alone on its CU and runs as ONE latency chain -- head loads, exponent bound, first
+  // operands, k-loop, combine, epilogue loads, fp64 chain -- so its independent rounds of loads are issued together at the top: the first
+  // k-steps' operands (below, in front of the head's loads instead of behind the exponent bound) and the epilogue's (cell, clone) operands.
+  // Same values, same arithmetic, same bits.  (96-cell blocks have four or five waves per SIMD to hide these rounds, and no registers to spare.)
+  constexpr bool EARLY = TL <= 2 && !TWO;
+  [[maybe_unused]] ca_cell_pre cpre = {0.f, 0.0, 0.0};
+  if constexpr (EARLY) {
+    constexpr int CP0 = 8;
+    const int lc0 = (int)threadIdx.x / CP0, c0 = (int)threadIdx.x % CP0, cc0 = c0 < C ? c0 : C - 1;
+    const int64_t n0 = cell0 + (lc0 < TL * 16 ? lc0 : 0);
+    const int64_t nn0 = n0 < N ? n0 : N - 1;
+    cpre.gl = p.glogit[nn0 * C + cc0]; cpre.sn = p.s64[nn0]; cpre.Anc = p.A[nn0 * C + cc0];
   }
-  // (all loads of the head in ONE batch, whichever way the bound comes: a branch inside the tile loop would put a round trip per tile here)
-#pragma unroll
-  for (int t = 0; t < TL; ++t) {
-    const int64_t n = cell0 + 16 * t + j;
-    const int64_t nn = n < N ? n : N - 1;
-#pragma unroll
-    for (int d = 0; d < D; ++d) f[t][d] = F[nn * D + d];
-    em[t] = p.vmm_at ? 0.f : etamax2[nn];
-    acc[t] = (ca_f32x4){0.f, 0.f, 0.f, 0.f};
-  }
-  if (p.vmm_at) {
-#pragma unroll
-    for (int t = 0; t < TL; ++t) {
-      const int64_t n = cell0 + 16 * t + j;
-      float e = 0.f;
-#pragma unroll
-      for (int d = 0; d < D; ++d) e += fmaxf(f[t][d] * vmn[d], f[t][d] * vmx[d]);   // (k_etamax's arithmetic)
-      em[t] = e;
-      if (wv == 0 && q == 0 && n < N) p.etamax_w[n] = e;   // for this block's epilogue (behind the barriers below) and the backward sweep
-    }
-  }
-  CA_LAB_PH_AFTER(em[0], blk, 1);
   unsigned m0, m1;   // (-1, 0) and (0, -1) as bf16 pairs, see k_fwd_mfma
   asm volatile("s_mov_b32 %0, 0x0000bf80" : "=s"(m0));
   asm volatile("s_mov_b32 %0, 0xbf800000" : "=s"(m1));
@@ -2598,6 +2588,38 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
 #pragma unroll
     for (int i = 0; i < NV4; ++i) vr[set][i] = vp[i];
   };
+  const int nkw = nk > wv ? (nk - wv + 3) / 4 : 0;          // this wave's k-steps: wv, wv + 4, ...
+  [[maybe_unused]] auto kc = [&](int i) { return wv + 4 * (i < nkw ? i : nkw - 1); };
+  if constexpr (NS == 4) {   // (small blocks: the first three k-steps' operands go out NOW, beside the head's loads, not behind the exponent bound)
+    if (nkw > 0) { fetch(0, kc(0)); fetch(1, kc(1)); fetch(2, kc(2)); }
+  }
+  float vmn[D], vmx[D];   // (merged update: range of V' over all genes)
+  if (p.vmm_at) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) { vmn[d] = ca_ord2f(p.vmm_at[d]); vmx[d] = ca_ord2f(p.vmm_at[8 + d]); }
+  }
+  // (all loads of the head in ONE batch, whichever way the bound comes: a branch inside the tile loop would put a round trip per tile here)
+#pragma unroll
+  for (int t = 0; t < TL; ++t) {
+    const int64_t n = cell0 + 16 * t + j;
+    const int64_t nn = n < N ? n : N - 1;
+#pragma unroll
+    for (int d = 0; d < D; ++d) f[t][d] = F[nn * D + d];
+    em[t] = p.vmm_at ? 0.f : etamax2[nn];
+    acc[t] = (ca_f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  if (p.vmm_at) {
+#pragma unroll
+    for (int t = 0; t < TL; ++t) {
+      const int64_t n = cell0 + 16 * t + j;
+      float e = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) e += fmaxf(f[t][d] * vmn[d], f[t][d] * vmx[d]);   // (k_etamax's arithmetic)
+      em[t] = e;
+      if (wv == 0 && q == 0 && n < N) p.etamax_w[n] = e;   // for this block's epilogue (behind the barriers below) and the backward sweep
+    }
+  }
+  CA_LAB_PH_AFTER(em[0], blk, 1);
   auto step = [&](int set) {
     const ca_bf16x8 B1 = __builtin_bit_cast(ca_bf16x8, b1r[set]), B2 = __builtin_bit_cast(ca_bf16x8, b2r[set]);
     auto vf = [&](int i) -> float { const float4& w = vr[set][i >> 2]; return (i & 3) == 0 ? w.x : (i & 3) == 1 ? w.y : (i & 3) == 2 ? w.z : w.w; };
@@ -2639,14 +2661,11 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
   // every k-step (s_waitcnt vmcnt(0) ... vmcnt(2) where vmcnt(4) would do) -- the operands fetched one step earlier were then waited for
   // right away.  With four or five waves per SIMD (cfg-3) others fill that; a small shard's one or two waves ran every k-step at the L2's
   // latency: 1370 cycles against 420 of issue (profiles/r03_ab_ystream.txt section 16).
-  const int nkw = nk > wv ? (nk - wv + 3) / 4 : 0;          // this wave's k-steps: wv, wv + 4, ...
   if constexpr (NS == 4) {
     // Small blocks compute 0.2 us per k-step, a third of an L2 round trip: THREE k-steps of operands in flight, four register sets
     // in rotation, four k-steps per trip of a branch-free loop.  Refills past the end re-read the last k-step (never used); the
     // explicit wait behind the loop makes sure they have landed before their registers mean anything else.
-    auto kc = [&](int i) { return wv + 4 * (i < nkw ? i : nkw - 1); };
-    if (nkw > 0) { fetch(0, kc(0)); fetch(1, kc(1)); fetch(2, kc(2)); }
-    const int ntrip = nkw >> 2;
+    const int ntrip = nkw >> 2;   // (the first three k-steps' operands were requested in front of the head)
     int ti = 0;
 #if CA_PROG_PRIO
 #pragma unroll
@@ -2749,7 +2768,8 @@ __device__ __forceinline__ void ca_fwd_cell_body(const float* __restrict__ F, co
     auto cz = [&](int w, int col) { return (double)comb[(w * TL + t) * 64 + col][r]; };
     const double ZA = C16 ? ZA16 : (cz(0, la_) + cz(1, la_)) + (cz(2, la_) + cz(3, la_));
     const double ZB = (cz(0, lb_) + cz(1, lb_)) + (cz(2, lb_) + cz(3, lb_));
-    ca_cell_fused_group<CP>(p, la, inb ? cell0 + lc : N, N, C, D, K, ZA, ZB, cacc);
+    if constexpr (EARLY) ca_cell_fused_group<CP>(p, la, inb ? cell0 + lc : N, N, C, D, K, ZA, ZB, cacc, &cpre);   // (one pass: g0 == 0)
+    else ca_cell_fused_group<CP>(p, la, inb ? cell0 + lc : N, N, C, D, K, ZA, ZB, cacc);
   };
   if constexpr (C16) {
 #pragma unroll
@@ -3756,3 +3776,5 @@ __global__ void __launch_bounds__(CA_TB, (DEPTH == 1 && !C16 && !S2F) ? CA_YS_RI
   CA_LAB_LABEL(ca_ys_out);
   CA_LAB_BLOCK_END(sweep ? (nbig > 0 && idx >= nbig ? 2 : 1) : 0, idx);   // (kind 0 = stream / overflow, 1 = big, 2 = small sweep block)
 }
+
+#include "ca_fwdbal.hip.h"   // the balanced forward sweep for small problems (round 5)

@@ -366,7 +366,9 @@ __device__ __forceinline__ void ca_ys_mfma_body(int blk, const uint8_t* __restri
   // the wave index as a SCALAR: strip bounds, piece addresses and the piece loop are then wave-uniform (scalar registers, scalar
   // branches, loads of the form global_load v, v_off, s[base]) instead of 64-bit vector arithmetic per lane -- the kernel that rides
   // on the forward sweep has 128 vector registers for everything
-  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // (& 3, & 255 below: a 512-thread launch runs TWO units per block, waves 0-3 and 4-7 each with their own LDS region -- k_fwd_bal_ys;
+  //  in a 256-thread launch they change nothing)
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) & 3);
   const int nseg = Gp / CA_YS_GW;
   const int rg = blk / nseg, seg = blk - rg * nseg;
   unsigned char* my = ca_ys_lds + (size_t)wv * 64 * CA_YS_PITCH;
@@ -492,7 +494,7 @@ __device__ __forceinline__ void ca_ys_mfma_body(int blk, const uint8_t* __restri
     }
   }
   const double inv_p = ldexp(1.0, -io.exps[1]);
-  for (int i = threadIdx.x; i < NP * 64; i += CA_YM_TB) {
+  for (int i = (int)threadIdx.x & (CA_YM_TB - 1); i < NP * 64; i += CA_YM_TB) {
     const int l = i & 63, a = i >> 6;
     double v = 0.0;
 #pragma unroll

@@ -181,6 +181,8 @@ struct ca_engine {
   bool fwd_cell = false; int ncblk_f = 0, fc_tl = 4;   // forward sweep + cell epilogue in one kernel (k_fwd_cell)
   int fc_nbig = 0;                                     // > 0: k_fwd_cell_mix, that many blocks of 16 * fc_tl cells, the rest 32-cell blocks
   bool fwd_mfma = false; int fsplit = 1, fkchunk = 1, nk32 = 1; unsigned short* Mq = nullptr;   // matrix-core forward sweep
+  // round 5: balanced forward sweep of small problems (k_fwd_bal_ys): bal_q tiles per block, bal_r left-over tiles in bal_nchunk gene chunks each
+  bool fwd_bal = false; int bal_q = 0, bal_r = 0, bal_nchunk = 0; unsigned long long* bal_xw = nullptr; unsigned bal_tag = 0;
   // matrix-core backward sweep (k_bwd_mfma): bf16 parts of coef, its own cell split
   bool bwd_mfma = false, bwd_frac = false, c16 = false, s2 = false, s2f = false;   // s2f: mc_samples = 2 with monitor + next train pass in one sweep (CA_VAR_S2_FUSE)
   unsigned short* coefq = nullptr; int64_t N16 = 0, cchunk_m = 0; int csplit_m = 1, nwt = 0;
@@ -230,6 +232,10 @@ namespace {
 // The peer-to-peer all-reduce gives up inside the kernel when a peer does not show (k_p2p_allreduce); the host learns it here,
 // at every point where it has waited for the stream anyway.
 int comm_check(ca_engine* h) {
+  if (h->host_pinned && *reinterpret_cast<volatile unsigned int*>(h->host_pinned + 41) != 0u) {
+    h->err = "a forward-sweep block gave up waiting for a chunk of a left-over tile (k_fwd_bal_ys); the engine's state is undefined";
+    return CA_ERR_STATE;
+  }
   if (h->p2p && h->p2p->err_host && *reinterpret_cast<volatile unsigned long long*>(h->p2p->err_host) != 0ull) {
     h->err = "peer-to-peer all-reduce #" + std::to_string(*reinterpret_cast<volatile unsigned long long*>(h->p2p->err_host)) +
              ": a peer's data did not arrive within the time limit (peer lost or out of step); this engine's transport is dead -- "
@@ -1365,6 +1371,32 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
 #ifndef CA_YS_RIDE_DEPTH
 #define CA_YS_RIDE_DEPTH 1   // (lab: pieces in flight per stream wave)
 #endif
+    if (h->fwd_bal && !s2f) {   // small problems: one eight-wave sweep block per CU, left-over tiles spread gene-wise (ca_fwdbal.hip.h)
+      cell_blocks = h->n_cu;
+      ca_bal_args ba;
+      memset(&ba, 0, sizeof(ba));
+      ba.nb = h->n_cu; ba.r = h->bal_r; ba.nchunk = h->bal_nchunk; ba.xw = h->bal_xw;
+      if (++h->bal_tag == 0u) h->bal_tag = 1u;
+      ba.tag = h->bal_tag;
+      ba.timeout_ticks = 50000000ull;   // 0.5 s: every chunk a block waits for was dispatched before it and is made first
+      ba.err = reinterpret_cast<unsigned int*>(h->host_dev + 41);
+      // stream units per stream block: one (four live waves beside the sweep block's eight) while the stream still ends inside the sweep, else two
+      // (measured, 8192 ... 25 000 cells x 5000 genes: one unit per block is 2-4 us per iteration faster at every size, gpurun_out/r5/stair_units.txt;
+      //  ride_pattern = 2 asks for two)
+      ba.stream_units = h->opt.ride_pattern == 2 ? 2 : 1;
+      const dim3 gridb((unsigned)(h->n_cu + (ba.stream_units == 2 ? (ya.nb_main + 1) / 2 : ya.nb_main) + (ya.nb_y - ya.nb_main)));   // sweep blocks, stream blocks, the overflow list's
+#define CA_FBAL(TLV) LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_bal_ys<1, TLV, CA_YS_RIDE_DEPTH>), gridb, dim3(CA_BAL_TB), 0, h->stream, h->F, h->etamax2, \
+                                                                 h->Vs, h->Mq, cp, h->alpha_u, h->cell_part, h->N, h->C, h->K, h->nk32, ba, ya))
+      switch (h->bal_q) {
+        case 1: CA_FBAL(1); break;
+        case 2: CA_FBAL(2); break;
+        case 3: CA_FBAL(3); break;
+        case 4: CA_FBAL(4); break;
+        case 5: CA_FBAL(5); break;
+        default: CA_FBAL(6); break;
+      }
+#undef CA_FBAL
+    } else
     if (h->fc_tl == 6) CA_FCYS_D(6, CA_YS_RIDE_DEPTH);
     else if (h->fc_tl == 1 && !h->c16) { if (h->D == 1) CA_FCYS(1, 1, CA_YS_RIDE_DEPTH, false, false); else CA_FCYS(2, 1, CA_YS_RIDE_DEPTH, false, false); }
     else CA_FCYS_D(2, CA_YS_RIDE_DEPTH);
@@ -2314,7 +2346,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   CACK(dalloc(h, &h->Zpart, (int64_t)S * h->gsplit * h->nchunk * Nn * CA_CW));
   CACK(dalloc(h, &h->coef, (int64_t)S * h->nchunk * Nn * CA_CW));
   CACK(dalloc(h, &h->scratch, Nn * C));
-  const int64_t n_cpart = std::max(h->ncblk, h->ncblk_f);
+  const int64_t n_cpart = std::max(std::max(h->ncblk, h->ncblk_f), h->n_cu);
   CACK(dalloc(h, &h->cell_part, n_cpart * (3 + C)));
   CACK(dalloc(h, &h->ee_partB, n_cpart));
   CACK(dalloc(h, &h->gpart, (int64_t)std::max(h->csplit, h->csplit_m) * G * (S + D)));
@@ -2402,6 +2434,16 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   h->ride_ys = h->y_ys && h->fused_ok && h->fwd_cell && (h->fc_tl == 6 || tl1_ok || (h->fc_tl == 2 && h->fc_nbig == 0)) &&
                variant_on(h, CA_VAR_Y_RIDE, "CA_Y_RIDE");
   h->yfin_split = h->ride_ys && h->bwd_mfma && h->tail_fuse && variant_on(h, CA_VAR_YFIN_RIDE, "CA_YFIN_RIDE");
+  {   // balanced forward sweep (ca_fwdbal.hip.h): one to six whole tiles per CU, the int8 stream riding, eight clones at most, one latent dimension
+    const int tiles = cdiv(Nn, 16), qb = tiles / std::max(h->n_cu, 1), rb = tiles - qb * h->n_cu;
+    // ... and at least 96 k-steps of 32 genes: with eight waves per block a wave of cfg-2 (2000 genes, 63 k-steps) has eight k-steps, the two
+    // pipeline fills of a block that also sweeps a chunk cost more than the balance returns (10k x 2k x 4: 42.7 against 39.3 us per iteration)
+    h->fwd_bal = h->ride_ys && !h->c16 && !h->s2 && D == 1 && C <= 8 && qb >= 1 && qb <= 6 && h->nk32 >= 96 && h->host_dev && variant_on(h, CA_VAR_FWD_BAL, "CA_FWD_BAL");
+    if (h->fwd_bal) {
+      h->bal_q = qb; h->bal_r = rb; h->bal_nchunk = rb > 0 ? std::min(CA_BAL_MAXCHUNK, h->n_cu / rb) : 0;
+      CACK(dalloc(h, &h->bal_xw, std::max<int64_t>(1, (int64_t)rb * h->bal_nchunk * 512)));
+    }
+  }
   // mc_samples = 2, four draws per sweep: where the sweep is the cell kernel and the stream either rides as the int8 stream or not at all
   h->s2f = h->s2 && h->fused_ok && h->fwd_cell && (h->fc_tl == 2 || h->fc_tl == 6) && (h->ride_ys || !h->ride_ok) && variant_on(h, CA_VAR_S2_FUSE, "CA_S2_FUSE");
   h->off_g = 3 + C;
@@ -2798,6 +2840,7 @@ int ca_get_info(ca_handle h, ca_info* i) {
   i->transport = (h->p2p && h->p2p->connected) ? CA_TRANSPORT_P2P : h->comm ? CA_TRANSPORT_RCCL : h->host_ar ? CA_TRANSPORT_HOST : CA_TRANSPORT_NONE;
   i->red_n = h->red_n;
   i->fwd_block_cells = (h->fused_ok && h->fwd_cell) ? 16 * h->fc_tl : 0; i->fwd_blocks_big = h->fc_nbig;
+  i->fwd_balanced = h->fwd_bal ? h->bal_q : 0;
   i->fold_gsum = (h->fold_gsum && !is_sharded(h)) ? 1 : 0; i->yfin_split = (h->yfin_split && !is_sharded(h)) ? 1 : 0;
   i->update_merge = (h->upd_merge && h->fused_ok && h->fwd_cell && h->K > 0) ? 1 : 0;
   return CA_OK;

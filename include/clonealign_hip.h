@@ -96,6 +96,9 @@ enum ca_variant {
                                  it gives up, stores nothing and is queued again after the decision; off: always queued after the decision */
   CA_VAR_S2_FUSE = 1 << 18,   /* mc_samples = 2: the monitor pass's two samples and the next train pass's two samples in ONE forward sweep (two operand sets,
                                  four draws on one exp per (cell, gene)); off: a sweep per pass */
+  CA_VAR_FWD_BAL = 1 << 19,   /* small problems (one to six 16-cell tiles per CU): ONE eight-wave forward-sweep block per CU, the left-over tiles spread gene-wise over
+                                 the blocks with their partial Z exchanged through tagged words (k_fwd_bal_ys, ca_fwdbal.hip.h): every SIMD holds two waves with equal
+                                 work; off: 16- / 32-cell four-wave blocks, as many as the cells need */
   CA_VAR_P2P = 1 << 10,       /* one-shot peer-to-peer all-reduce (else ncclAllReduce) after ca_comm_init() */
   CA_VAR_FOLD_GSUM = 1 << 11, /* small problems: backward-sweep partials summed inside the per-gene kernel (else a k_colsum launch) */
   CA_VAR_Y_RIDE = 1 << 12,    /* the Y stream's blocks ride on the forward sweep's launch (else side stream / in line) */
@@ -187,7 +190,7 @@ typedef struct ca_info {
   int32_t fold_gsum;         /* 1: the backward sweep's per-gene partials are summed inside the per-gene kernel (unsharded small problems) */
   int32_t yfin_split;        /* 1: the Y stream's finishing step is split between the forward and backward launches */
   int32_t update_merge;      /* 1: the loop's update half is one launch (CA_VAR_UPDATE_MERGE) */
-  int32_t reserved0;
+  int32_t fwd_balanced;      /* > 0: the fused forward sweep is the balanced small-problem form (CA_VAR_FWD_BAL), that many tiles per block */
 } ca_info;
 enum ca_transport { CA_TRANSPORT_NONE = 0, CA_TRANSPORT_RCCL = 1, CA_TRANSPORT_HOST = 2, CA_TRANSPORT_P2P = 3 };
 

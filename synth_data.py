@@ -95,4 +95,8 @@ def make_problem_torch(N, G, C, seed=20240, median_s=2000, rows=None, device="cu
         Y[b0:b1] = torch.poisson(lam, generator=gen).to(torch.int32)
     empty = (Y.sum(1) == 0)
     Y[:, 0] += empty.to(torch.int32)
+    # the matrix is handed to the engine as a raw device pointer and read on the ENGINE's stream: the generator's kernels (torch's
+    # stream) must have finished -- an engine built straight after this call scanned a half-written matrix now and then and chose
+    # float32 storage for it (round 5: tools/stair_time.py showed 120 us iterations out of nowhere)
+    torch.cuda.synchronize(device)
     return Y, dict(L=L, z=z[lo:hi], s_target=s[lo:hi], mu_true=mu)

@@ -568,6 +568,74 @@ def test_fused_loop_at_shard_size_matches_c_oracle(shape):
         eng.close(); ora.close()
 
 
+BAL_SHAPES = {
+    # cells, genes, clones -> tiles = q n_cu + r at 256 CUs; the balanced sweep takes problems with at least 96 k-steps of 32 genes
+    "q1_r14_chunks16": (4316, 3100, 8),       # 270 tiles: one tile per block, 14 left over in sixteen gene chunks each; ragged last tile
+    "q3_r14_cfg4_shard": (12500, 3200, 8),    # the 8-GPU shard of cfg-3 (fewer genes): 782 tiles = 3 x 256 + 14
+    "q2_r113": (10000, 3080, 4),              # 625 tiles = 2 x 256 + 113, two chunks per left-over tile
+    "q4_r0_exact": (16384, 3072, 6),          # 1024 tiles: nothing left over, no exchange
+    "q2_r200_whole_tiles": (11392, 3090, 5),  # 712 tiles = 2 x 256 + 200: one chunk = the whole tile per block
+    "q6_r27": (25000, 3075, 8),               # the 4-GPU shard's cell count: 1563 tiles = 6 x 256 + 27 (nine chunks)
+}
+
+
+@pytest.mark.parametrize("name", list(BAL_SHAPES))
+def test_balanced_forward_sweep_of_small_problems_matches_c_oracle_and_the_four_wave_sweep(name):
+    """Round 5 (VERDICT r4 #2a): below ~28k cells the fused forward sweep is ONE eight-wave block per CU with q whole tiles each, the
+    left-over tiles cut gene-wise into chunks that other blocks sweep first and whose partial Z travel through tagged words in device
+    memory to the block that finishes the tile (k_fwd_bal_ys, clonealign_amd/csrc/ca_fwdbal.hip.h).  Every decomposition it has --
+    q = 1 ... 6, no left-over, sixteen / nine / two / one chunk per tile, a ragged last tile, counts above 255 -- through ca_run (gated
+    update), the pair sweeps of the final ELBOs and ca_iterate, against the float64 C oracle (trace 1e-5, parameters 1e-4, clone labels)
+    and against the four-wave sweep of the same engine (variant fwd_bal off: same sums grouped differently, 2e-6)."""
+    from clonealign_amd.engine import HipEngine
+    from clonealign_amd.inference import run_vi_loop
+    from clonealign_amd.rng import EpsStream
+    from oracle.c_port import CPortModel
+    from tests._cases import label_flips
+    N, G, C = BAL_SHAPES[name]
+    Yd, L, psi0, loc0 = _synth(N, G, C, seed=11)
+    Y = Yd.cpu().numpy().astype(np.float64)
+    rng = np.random.default_rng(1)
+    idx = rng.integers(0, Y.size, size=60)
+    Y.reshape(-1)[idx] += rng.integers(300, 900, size=60)          # overflow list beside the 1-byte matrix
+    eng, old = HipEngine(Y, L, psi0, loc0, 1), HipEngine(Y, L, psi0, loc0, 1, variant_off=("fwd_bal",))
+    ora = CPortModel(Y, L, psi0, loc0, 1, dtype="float32")
+    try:
+        info = eng.info()
+        if info["n_cu"] == 256:
+            assert info["fwd_balanced"] == (N + 15) // 16 // 256 and old.info()["fwd_balanced"] == 0, info
+        assert info["fwd_balanced"] >= 1 and info["y_storage_name"] == "u8"
+        n_iter = 4
+        tr = np.asarray(eng.run(EpsStream(9, 1, G), n_iter, 1e-12))
+        tp = np.asarray(old.run(EpsStream(9, 1, G), n_iter, 1e-12))
+        to = np.asarray(run_vi_loop(ora, EpsStream(9, 1, G), n_iter, 1e-12))
+        assert np.abs(tr - to).max() <= 1e-5 * np.abs(to).max(), (tr, to)
+        assert np.abs(tr - tp).max() <= 2e-6 * np.abs(tp).max(), (tr, tp)
+        epf = np.stack([eps_for(1, G, 70 + i) for i in range(3)])
+        fe, fp = eng.final_elbo(epf, 3), old.final_elbo(epf, 3)
+        fo = np.array([ora.elbo(e) for e in epf])
+        assert np.abs(fe - fo).max() <= 1e-5 * np.abs(fo).max() and np.abs(fe - fp).max() <= 2e-6 * np.abs(fp).max()
+        eps_it = np.stack([eps_for(1, G, 200 + i) for i in range(6)])
+        last, lastp = eng.iterate(3, eps_it), old.iterate(3, eps_it)
+        for i in range(3):
+            ora.step(eps_it[2 * i]); lo = ora.elbo(eps_it[2 * i + 1])
+        assert abs(last - lo) <= 1e-5 * abs(lo) and abs(last - lastp) <= 2e-6 * abs(lastp), (last, lastp, lo)
+        se, so = eng.get_state(), ora.get_state()
+        for n in ("W", "v", "psi", "alpha_unconstr", "loc", "ls", "gamma_logits"):
+            err = np.abs(se[n] - so[n]).max() / max(np.abs(so[n]).max(), 1e-30)
+            assert err < 1e-4, (n, err)
+        flips, far = label_flips(eng.get("clone_probs"), ora.get_params()["clone_probs"])
+        assert far == 0 and flips == 0, (flips, far)
+        # same seed, same bits: the exchange's sums do not depend on who arrived when
+        eng.reinit(psi0, loc0)
+        t2 = np.asarray(eng.run(EpsStream(9, 1, G), n_iter, 1e-12))
+        eng.reinit(psi0, loc0)
+        t3 = np.asarray(eng.run(EpsStream(9, 1, G), n_iter, 1e-12))
+        assert np.array_equal(t2, t3)
+    finally:
+        eng.close(); old.close(); ora.close()
+
+
 def test_config5_run_clonealign_eight_restarts_at_size():
     """BASELINE.json configs[4]: run_clonealign with 8 restarts on 50k cells x 3k genes x 6 clones, dealt over the visible GPUs
     (one resident engine per GPU, restarts = ca_reinit), best-ELBO selection (R/clonealign.R:50-65).  One restart's fused loop

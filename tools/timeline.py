@@ -9,7 +9,7 @@ import sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 back = int(sys.argv[2]) if len(sys.argv) > 2 else -10
-fw = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("void k_fwd_cell") or r["Kernel_Name"].startswith("k_fwd_cell")]
+fw = [i for i, r in enumerate(rows) if r["Kernel_Name"].replace("void ", "").startswith(("k_fwd_cell", "k_fwd_bal"))]
 i0, i1 = (fw[back - 1], fw[back]) if back < 0 else (fw[back], fw[back + 1])
 t0 = int(rows[i0]["Start_Timestamp"])
 print(f"iteration length {(int(rows[i1]['Start_Timestamp']) - t0) / 1000:.1f} us")
