@@ -14,9 +14,4 @@ ls -R $OUT | head -40
 cd $R
 python3 bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 tail -c 600 $OUT/bench_default.json
-for cfg in "10000 2000 4" "50000 3000 6" "12500 5000 8" "25000 5000 8" "50000 5000 8"; do  # (BASELINE configs[1], [4]; one eighth, quarter, half of configs[2])
-  set -- $cfg
-  python3 bench.py --steps 100 --warmup 10 --repeats 3 --no-cpu-baseline --busy-seconds 0 --cells $1 --genes $2 --clones $3 2>/dev/null | python3 -c "
-import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$cfg', round(d['value'],1), round(d['ms_per_step'],4))"
-done
+# (the other single-GPU BASELINE configurations and the VALU fallback shapes are in the default bench line itself since round 5: other_configs / fallbacks)
