@@ -17,12 +17,15 @@ from clonealign_amd.rng import EpsStream  # noqa: E402
 from oracle.fused_numpy import FusedModel  # noqa: E402
 from tests._cases import eps_for, make_case  # noqa: E402
 
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
-VARIANTS = [{}, {}, {}, {}, {"CA_FWD_CELL": "0"}, {"CA_FWD_MFMA": "0"}, {"CA_BWD_MFMA": "0"}, {"CA_ASYNC_Y": "0"}, {"CA_PRE": "0"},
-            {"CA_TAIL_FUSE": "0"}, {"CA_FC_TL": "4", "CA_FC_NBIG": "2"}, {"CA_PAIR_ELBO": "0"},
-            {"CA_Y_MFMA1": "0"}, {"CA_Y_MFMA1": "0", "CA_RIDE_SEQ_ON": "1"}, {"CA_Y_MFMA1": "0", "CA_Y_RIDE": "0"}, {"CA_Y_RIDE": "0"},
-            {"CA_UPDATE_MERGE": "0"}, {"CA_UPDATE_MERGE": "0", "CA_Y_MFMA1": "0"}, {"CA_S2_FUSE": "0"}]   # round 4: the two-launch update (the default is the merged launch)   # round 3: the vector stream and its riding forms
+_args = [a for a in sys.argv[1:] if not a.startswith("--")]
+n_cases = int(_args[0]) if len(_args) > 0 else 60
+rng = np.random.default_rng(int(_args[1]) if len(_args) > 1 else 7)
+# engine variants as ca_options (the release library reads no switches from the environment since round 5): (variant_off, variant_on, tune)
+VARIANTS = [((), (), {})] * 4 + [(("fwd_cell",), (), {}), (("fwd_mfma",), (), {}), (("bwd_mfma",), (), {}), (("async_y",), (), {}), (("pre",), (), {}),
+            (("tail_fuse",), (), {}), ((), (), {"fc_tl": 4, "fc_nbig": 2}), (("pair_elbo",), (), {}),
+            (("y_mfma1",), (), {}), (("y_mfma1",), ("ride_seq",), {}), (("y_mfma1", "y_ride"), (), {}), (("y_ride",), (), {}),
+            (("update_merge",), (), {}), (("update_merge", "y_mfma1"), (), {}), (("s2_fuse",), (), {}), (("run_gate",), (), {}), (("fwd_bal",), (), {})]
+BAL = "--bal" in sys.argv   # shapes of the balanced eight-wave forward sweep (4096+ cells, 3072+ genes, K = 1, up to eight clones) against the C oracle
 fails = 0
 for it in range(n_cases):
     N = int(rng.integers(1, 900))
@@ -31,7 +34,10 @@ for it in range(n_cases):
     K = int(rng.choice([0, 1, 1, 1, 2]))
     P = int(rng.choice([0, 0, 0, 1])) if K > 0 else 0
     S = 1 if rng.random() < 0.8 else 2
-    env = dict(VARIANTS[int(rng.integers(0, len(VARIANTS)))])
+    if BAL:
+        N, G, C, K, P, S = int(rng.integers(4096, 30000)), int(rng.integers(3072, 3400)), int(rng.integers(2, 9)), 1, 0, 1
+    voff, von, tune = VARIANTS[int(rng.integers(0, len(VARIANTS)))] if not BAL else ((), (), {})
+    env = {"variant_off": voff, "variant_on": von, "tune": tune}
     kw = dict(N=N, G=G, C=C, K=K, S=S)
     if P:
         kw["P"] = P
@@ -47,14 +53,16 @@ for it in range(n_cases):
         rng.integers(1, 6)
         continue
     if only is not None:
-        env.update(kv.split("=") for kv in os.environ.get("FUZZ_ENV", "").split(",") if kv)
         print("replaying case", it, kw, env)
-    env = dict(env, CLONEALIGN_DEBUG_ENV="1")      # the library reads CA_* from the environment only in this debug mode
-    old = {k: os.environ.get(k) for k in env}
-    os.environ.update(env)
-    eng = None
+    eng = ora = None
     try:
-        eng, ora = HipEngine(**case), FusedModel(**case, dtype="float32")
+        eng = HipEngine(**case, **env)
+        if BAL:
+            from oracle.c_port import CPortModel
+            assert eng.info()["fwd_balanced"] >= 1, eng.info()
+            ora = CPortModel(case["Y"], case["L"], case["psi0"], case["loc0"], 1, dtype="float32")
+        else:
+            ora = FusedModel(**case, dtype="float32")
         n_iter = int(rng.integers(1, 6))
         tr = np.asarray(eng.run(EpsStream(3, S, G), n_iter, 1e-12))
         to = np.asarray(run_vi_loop(ora, EpsStream(3, S, G), n_iter, 1e-12))
@@ -65,8 +73,8 @@ for it in range(n_cases):
         why = [] if ok else ["trace"]
         if np.abs(fe - fo).max() > 1e-4 * np.abs(fo).max():
             why.append("final elbo %.2e" % float(np.abs(fe - fo).max() / np.abs(fo).max()))
-        pe, po = eng.get_state(), {n: getattr(ora, n) for n in ora.VAR_NAMES}
-        for n in ora.VAR_NAMES:
+        pe, po = eng.get_state(), (ora.get_state() if BAL else {n: getattr(ora, n) for n in ora.VAR_NAMES})
+        for n in po:
             a, b = np.asarray(pe[n], float), np.asarray(po[n], float)
             # loose on purpose: Adam normalises every gradient, so float32-level differences in a small gradient become 1e-3-level
             # differences of its variable after a few steps (seen: W 2.8e-4 of 0.2); the ELBO trace is the tight check
@@ -83,10 +91,7 @@ for it in range(n_cases):
     finally:
         if eng is not None:
             eng.close()
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        if BAL and ora is not None:
+            ora.close()
 print(f"{n_cases - fails} of {n_cases} cases agree with the oracle")
 sys.exit(1 if fails else 0)
