@@ -38,6 +38,7 @@ struct ca_bal_args {
   unsigned long long timeout_ticks;   // bound of a consumer's wait for a chunk (s_memrealtime, 100 MHz)
   unsigned int* err;       // pinned host word: set when a wait ran out (the host reports CA_ERR_STATE at its next synchronisation)
   int stream_units;        // count-matrix stream units per 512-thread stream block: 1 (waves 4-7 leave at once) or 2 (waves 0-3 and 4-7 one unit each)
+  int extra;               // > 0 (opt-in CA_VARX_BAL_TILES): the r left-over tiles are single-tile blocks of their own behind the sweep blocks (then nchunk == 0: no exchange)
 };
 
 // `span` k-steps of TL tiles, this wave taking virtual steps wv, wv + NW, ...; virtual step v is k-step k_lo + v below `gap_at` and
@@ -170,11 +171,11 @@ __global__ void __launch_bounds__(CA_BAL_TB, 2) k_fwd_bal_ys(const float* __rest
   }
   const int b = (int)blockIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  if (b >= ba.nb) {   // ---- the count-matrix stream's blocks (and the overflow list's)
+  if (b >= ba.nb + ba.extra) {   // ---- the count-matrix stream's blocks (and the overflow list's)
     // TWO units per block, waves 0-3 and waves 4-7 each on its own LDS region (the body's two barriers are the block's: both halves pass the
     // same two, or one half has left): two waves per SIMD beside the sweep block's two, as two 256-thread stream blocks were
     const int half = wv >> 2;
-    const int sb = b - ba.nb, nsb = ba.stream_units == 2 ? (y.nb_main + 1) >> 1 : y.nb_main;
+    const int sb = b - ba.nb - ba.extra, nsb = ba.stream_units == 2 ? (y.nb_main + 1) >> 1 : y.nb_main;
     if (sb >= nsb) {   // the overflow list's blocks, counted in 256 threads: its cell side, then its gene side
       if (half) return;
       const int ob = sb - nsb;
@@ -209,11 +210,23 @@ __global__ void __launch_bounds__(CA_BAL_TB, 2) k_fwd_bal_ys(const float* __rest
     for (int o = 1; o < 64; o <<= 1) se += __shfl_xor(se, o, 64);
     if (c < C) la[c] = au - (mx + log(se));
   }
+  const bool xtile = b >= ba.nb;                      // (block-uniform) a left-over tile as a single-tile block of its own
+  const int64_t cellR = ((int64_t)TL * ba.nb) * 16;   // first left-over cell
+  const int64_t cell0 = xtile ? cellR + 16 * (int64_t)(b - ba.nb) : (int64_t)b * (TL * 16);
+  const int tls = xtile ? 1 : TL;                     // tiles per wave in the combine buffer
+  int my_tile = -1, my_chunk = 0;
+  if (xtile) {
+    // 1x. ONE tile, all genes, eight waves: no exchange.  These blocks sit behind the sweep blocks in the grid and in front of the stream's: a
+    //     CU that holds one beside its sweep block has no slot for a stream block meanwhile, so the dispatcher hands that CU fewer stream
+    //     units -- the stream (a third of a sweep block's issue time at these sizes) is what evens the CUs out, not an exchange of partials.
+    float f1[1][D], em1[1];
+    ca_f32x4 a1[1] = {(ca_f32x4){0.f, 0.f, 0.f, 0.f}};
+    ca_bal_head<D, 1>(F, etamax2, p, N, cell0, lane, wv, true, f1, em1);
+    ca_bal_sweep<D, 1, 4>(f1, em1, Vs, Bq, 0, nk, nk, 0, wv, lane, a1);
+    comb[wv * 64 + lane] = a1[0];
+  } else {
   // 1. heads: the block's own TL tiles and -- tile index TL -- the left-over tile whose chunk it sweeps (one batch of loads)
   constexpr int NS = TL >= 5 ? 3 : 4;                 // (128 registers: two sweep waves and two stream waves per SIMD)
-  const int64_t cell0 = (int64_t)b * (TL * 16);
-  const int64_t cellR = ((int64_t)TL * ba.nb) * 16;   // first left-over cell
-  int my_tile = -1, my_chunk = 0;
   if (ba.nchunk > 0 && b < ba.r * ba.nchunk) { my_tile = b / ba.nchunk; my_chunk = b - my_tile * ba.nchunk; }
   float f[TL + 1][D], em[TL + 1];
   ca_f32x4 acc[TL + 1];
@@ -244,10 +257,11 @@ __global__ void __launch_bounds__(CA_BAL_TB, 2) k_fwd_bal_ys(const float* __rest
   }
 #pragma unroll
   for (int t = 0; t < TL; ++t) comb[(wv * TL + t) * 64 + lane] = acc[t];
+  }
   // 3. the left-over tile this block finishes: its chunks, each word taken as soon as it can be read complete.  Thread e holds word e of
   //    every chunk (even e: the low half of double e / 2, odd e: the high half); the halves meet by a lane shuffle, the even lanes add the
   //    chunks in chunk order -- the same additions whoever arrived when
-  const bool consume = my_tile >= 0 && my_chunk == ba.nchunk - 1;
+  const bool consume = !xtile && my_tile >= 0 && my_chunk == ba.nchunk - 1;
   if (consume) {
     const int e = (int)threadIdx.x;
     const unsigned long long* src = ba.xw + (int64_t)my_tile * ba.nchunk * 512 + e;
@@ -275,22 +289,22 @@ __global__ void __launch_bounds__(CA_BAL_TB, 2) k_fwd_bal_ys(const float* __rest
   constexpr int CP = 8, CPB = CA_BAL_TB / CP;
   const int c = threadIdx.x % CP, cc = c < C ? c : C - 1;
   ca_cell_acc cacc = {0.0, 0.0, 0.0, 0.0, 0.0};
-  const int ncell = TL * 16 + (consume ? 16 : 0);
+  const int nown = tls * 16, ncell = nown + (consume ? 16 : 0);
   for (int g0 = 0; g0 < ncell; g0 += CPB) {
     const int lc = g0 + (int)threadIdx.x / CP;
     const bool inb = lc < ncell;
     const int lcc = inb ? lc : 0;
     double ZA, ZB;
     int64_t n;
-    if (lcc < TL * 16) {
+    if (lcc < nown) {
       const int t = lcc >> 4, row = lcc & 15, qq = row >> 2, r = row & 3;
       const int la_ = 16 * qq + cc, lb_ = 16 * qq + C + cc;
-      auto cz = [&](int w, int col) { return (double)comb[(w * TL + t) * 64 + col][r]; };
+      auto cz = [&](int w, int col) { return (double)comb[(w * tls + t) * 64 + col][r]; };
       ZA = ((cz(0, la_) + cz(1, la_)) + (cz(2, la_) + cz(3, la_))) + ((cz(4, la_) + cz(5, la_)) + (cz(6, la_) + cz(7, la_)));
       ZB = ((cz(0, lb_) + cz(1, lb_)) + (cz(2, lb_) + cz(3, lb_))) + ((cz(4, lb_) + cz(5, lb_)) + (cz(6, lb_) + cz(7, lb_)));
       n = cell0 + lcc;
     } else {
-      const int row = lcc - TL * 16, qq = row >> 2, r = row & 3;
+      const int row = lcc - nown, qq = row >> 2, r = row & 3;
       ZA = zx[(16 * qq + cc) * 4 + r];
       ZB = zx[(16 * qq + C + cc) * 4 + r];
       n = cellR + 16 * (int64_t)my_tile + row;

@@ -1372,10 +1372,11 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
 #define CA_YS_RIDE_DEPTH 1   // (lab: pieces in flight per stream wave)
 #endif
     if (h->fwd_bal && !s2f) {   // small problems: one eight-wave sweep block per CU, left-over tiles spread gene-wise (ca_fwdbal.hip.h)
-      cell_blocks = h->n_cu;
       ca_bal_args ba;
       memset(&ba, 0, sizeof(ba));
       ba.nb = h->n_cu; ba.r = h->bal_r; ba.nchunk = h->bal_nchunk; ba.xw = h->bal_xw;
+      ba.extra = h->bal_nchunk == 0 ? h->bal_r : 0;   // left-over tiles exchanged in gene chunks (default), or as single-tile blocks of their own
+      cell_blocks = h->n_cu + ba.extra;               // (a row of block partials per block that runs an epilogue)
       if (++h->bal_tag == 0u) h->bal_tag = 1u;
       ba.tag = h->bal_tag;
       ba.timeout_ticks = 50000000ull;   // 0.5 s: every chunk a block waits for was dispatched before it and is made first
@@ -1384,7 +1385,7 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
       // (measured, 8192 ... 25 000 cells x 5000 genes: one unit per block is 2-4 us per iteration faster at every size, gpurun_out/r5/stair_units.txt;
       //  ride_pattern = 2 asks for two)
       ba.stream_units = h->opt.ride_pattern == 2 ? 2 : 1;
-      const dim3 gridb((unsigned)(h->n_cu + (ba.stream_units == 2 ? (ya.nb_main + 1) / 2 : ya.nb_main) + (ya.nb_y - ya.nb_main)));   // sweep blocks, stream blocks, the overflow list's
+      const dim3 gridb((unsigned)(h->n_cu + ba.extra + (ba.stream_units == 2 ? (ya.nb_main + 1) / 2 : ya.nb_main) + (ya.nb_y - ya.nb_main)));   // sweep blocks, left-over tiles' blocks, stream blocks, the overflow list's
 #define CA_FBAL(TLV) LAUNCH(h, CA_KERNEL_FWD, hipLaunchKernelGGL((k_fwd_bal_ys<1, TLV, CA_YS_RIDE_DEPTH>), gridb, dim3(CA_BAL_TB), 0, h->stream, h->F, h->etamax2, \
                                                                  h->Vs, h->Mq, cp, h->alpha_u, h->cell_part, h->N, h->C, h->K, h->nk32, ba, ya))
       switch (h->bal_q) {
@@ -2346,7 +2347,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   CACK(dalloc(h, &h->Zpart, (int64_t)S * h->gsplit * h->nchunk * Nn * CA_CW));
   CACK(dalloc(h, &h->coef, (int64_t)S * h->nchunk * Nn * CA_CW));
   CACK(dalloc(h, &h->scratch, Nn * C));
-  const int64_t n_cpart = std::max(std::max(h->ncblk, h->ncblk_f), h->n_cu);
+  const int64_t n_cpart = std::max(std::max(h->ncblk, h->ncblk_f), 2 * h->n_cu);   // (balanced sweep: n_cu blocks + up to n_cu - 1 left-over tiles' blocks)
   CACK(dalloc(h, &h->cell_part, n_cpart * (3 + C)));
   CACK(dalloc(h, &h->ee_partB, n_cpart));
   CACK(dalloc(h, &h->gpart, (int64_t)std::max(h->csplit, h->csplit_m) * G * (S + D)));
@@ -2440,7 +2441,12 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     // pipeline fills of a block that also sweeps a chunk cost more than the balance returns (10k x 2k x 4: 42.7 against 39.3 us per iteration)
     h->fwd_bal = h->ride_ys && !h->c16 && !h->s2 && D == 1 && C <= 8 && qb >= 1 && qb <= 6 && h->nk32 >= 96 && h->host_dev && variant_on(h, CA_VAR_FWD_BAL, "CA_FWD_BAL");
     if (h->fwd_bal) {
-      h->bal_q = qb; h->bal_r = rb; h->bal_nchunk = rb > 0 ? std::min(CA_BAL_MAXCHUNK, h->n_cu / rb) : 0;
+      // left-over tiles: gene chunks swept by the sweep blocks beside their own tiles (the default), or -- opt-in CA_VARX_BAL_TILES, bal_nchunk = 0 -- single-tile
+      // blocks of their own with no exchange (measured, us per iteration at 12 500 / 25 000 / 10 240 / 14 336 cells, i.e. 14 / 27 / 128 / 128 left-over tiles:
+      // chunks 63.6 / 95.1 / 57.3 / 68.0, tile blocks 63.2 / 96.7 / 60.6 / 72.0, four-wave sweep 65.0 / 98.7 / 58.5 / 69.3: level at few left-over tiles --
+      // the stream's blocks go to the CUs without a tile block -- and slower at many; profiles/r05_small_shapes.txt)
+      h->bal_q = qb; h->bal_r = rb;
+      h->bal_nchunk = (rb > 0 && !variantx_on(h, CA_VARX_BAL_TILES, "CA_BAL_TILES")) ? std::min(CA_BAL_MAXCHUNK, h->n_cu / rb) : 0;
       CACK(dalloc(h, &h->bal_xw, std::max<int64_t>(1, (int64_t)rb * h->bal_nchunk * 512)));
     }
   }

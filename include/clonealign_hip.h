@@ -129,6 +129,10 @@ enum ca_variant_on {
                                  the sweep is queued while the gated update may already be waiting for the host, and a runtime call made in that window can block
                                  behind another thread that holds a runtime lock while IT waits for the GPU (two engines of one process on one device did exactly
                                  that: the update then gives up after its 10 s and ca_run returns CA_ERR_STATE).  Worth about 1 us per iteration. */
+  CA_VARX_BAL_TILES = 1 << 7, /* balanced forward sweep of small problems (CA_VAR_FWD_BAL): a single-tile block of its own per left-over tile behind the sweep
+                                 blocks, no exchange (the stream's blocks then go to the CUs without one); default: the left-over tiles cut gene-wise into chunks
+                                 that the sweep blocks sweep beside their own tiles, partial Z exchanged through tagged words.  Level at few left-over tiles,
+                                 slower at many */
   CA_VARX_ASYNC_SMALL = 1 << 1 /* side stream also below 4e7 counts (small shards run the Y stream in line: the two cross-stream
                                  events cost more than the overlap returns there) */
 };

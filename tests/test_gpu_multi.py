@@ -108,6 +108,19 @@ def test_ranks_on_one_gpu_at_shard_sizes_across_the_kernel_selection_thresholds(
     _check(res, one, "p2p", cells)
 
 
+@pytest.mark.parametrize("world,cells", [(2, 12000), (3, 26000)])
+def test_ranks_whose_shards_take_the_balanced_forward_sweep(tmp_path, world, cells):
+    """Round 5: shards of 4096 ... ~28k cells with 3072+ genes run the balanced eight-wave forward sweep (k_fwd_bal_ys: left-over tiles exchanged
+    between blocks through tagged words) inside a sharded fit -- its block partials feed the same all-reduced sums.  Two ranks of 6000 cells
+    (one tile per CU + 119 left over) and three of ~8667 (two per CU + 30): replicas bit-identical, the fit of the one-handle engine (which takes
+    another decomposition: three / six tiles per CU)."""
+    shape = ["--cells", str(cells), "--genes", "3100", "--clones", "5", "--iters", "3"]
+    one = _run(1, "none", tmp_path / "one.json", True, shape)["ranks"][0]
+    res = _run(world, "p2p", tmp_path / "p2p.json", True, shape)
+    assert all(r["fwd_balanced"] >= 1 for r in res["ranks"]) and one["fwd_balanced"] >= 1, [r["fwd_balanced"] for r in res["ranks"]]
+    _check(res, one, "p2p", cells)
+
+
 def test_two_ranks_on_one_gpu_with_two_mc_samples(tmp_path):
     """mc_samples = 2 across two processes over the peer-to-peer transport: the four-draw forward sweep, the two-sample backward sweep whose
     column sums (three columns per gene: one per sample, one for W) are folded inside the all-reduce's launch, the pending monitor tail

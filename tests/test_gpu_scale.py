@@ -579,14 +579,17 @@ BAL_SHAPES = {
 }
 
 
+@pytest.mark.parametrize("exchange", [True, False], ids=["gene_chunks", "tile_blocks"])
 @pytest.mark.parametrize("name", list(BAL_SHAPES))
-def test_balanced_forward_sweep_of_small_problems_matches_c_oracle_and_the_four_wave_sweep(name):
+def test_balanced_forward_sweep_of_small_problems_matches_c_oracle_and_the_four_wave_sweep(name, exchange):
     """Round 5 (VERDICT r4 #2a): below ~28k cells the fused forward sweep is ONE eight-wave block per CU with q whole tiles each, the
     left-over tiles cut gene-wise into chunks that other blocks sweep first and whose partial Z travel through tagged words in device
     memory to the block that finishes the tile (k_fwd_bal_ys, clonealign_amd/csrc/ca_fwdbal.hip.h).  Every decomposition it has --
     q = 1 ... 6, no left-over, sixteen / nine / two / one chunk per tile, a ragged last tile, counts above 255 -- through ca_run (gated
     update), the pair sweeps of the final ELBOs and ca_iterate, against the float64 C oracle (trace 1e-5, parameters 1e-4, clone labels)
-    and against the four-wave sweep of the same engine (variant fwd_bal off: same sums grouped differently, 2e-6)."""
+    and against the four-wave sweep of the same engine (variant fwd_bal off: same sums grouped differently, 2e-6).  Both treatments of the
+    left-over tiles: the gene-chunk exchange (the default) and a single-tile block of its own per tile behind the sweep blocks (variant_on
+    bal_tiles: no exchange, the stream's blocks even the CUs out)."""
     from clonealign_amd.engine import HipEngine
     from clonealign_amd.inference import run_vi_loop
     from clonealign_amd.rng import EpsStream
@@ -598,7 +601,8 @@ def test_balanced_forward_sweep_of_small_problems_matches_c_oracle_and_the_four_
     rng = np.random.default_rng(1)
     idx = rng.integers(0, Y.size, size=60)
     Y.reshape(-1)[idx] += rng.integers(300, 900, size=60)          # overflow list beside the 1-byte matrix
-    eng, old = HipEngine(Y, L, psi0, loc0, 1), HipEngine(Y, L, psi0, loc0, 1, variant_off=("fwd_bal",))
+    eng = HipEngine(Y, L, psi0, loc0, 1, variant_on=() if exchange else ("bal_tiles",))
+    old = HipEngine(Y, L, psi0, loc0, 1, variant_off=("fwd_bal",))
     ora = CPortModel(Y, L, psi0, loc0, 1, dtype="float32")
     try:
         info = eng.info()

@@ -88,7 +88,7 @@ def main():
         raise SystemExit(0)
     rep = {n: eng.get(n).tolist() for n in ("W", "loc", "ls", "alpha_unconstr", "v")}
     mine = dict(rank=rank, trace=trace.tolist(), finals=finals.tolist(), transport=info["transport_name"], red_n=int(info["red_n"]),
-                fwd_block_cells=int(info["fwd_block_cells"]), selftest_bad=int(selftest_bad),
+                fwd_block_cells=int(info["fwd_block_cells"]), fwd_balanced=int(info.get("fwd_balanced", 0)), selftest_bad=int(selftest_bad),
                 rep=rep, psi_head=eng.get("psi")[:5, 0].tolist(), lo=lo, hi=hi)
     eng.close()
     if world > 1:
