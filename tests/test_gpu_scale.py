@@ -630,6 +630,20 @@ def test_balanced_forward_sweep_of_small_problems_matches_c_oracle_and_the_four_
             assert err < 1e-4, (n, err)
         flips, far = label_flips(eng.get("clone_probs"), ora.get_params()["clone_probs"])
         assert far == 0 and flips == 0, (flips, far)
+        if name == "q3_r14_cfg4_shard" and exchange:
+            # ca_run with the NEXT forward sweep queued behind the gated update ahead of the host's decision (opt-in run_fwd): the balanced kernel
+            # honours the relay's verdict word like the four-wave kernel does -- bit for bit the default loop, whatever ends it
+            fw = HipEngine(Y, L, psi0, loc0, 1, variant_on=("run_fwd",))
+            try:
+                eng.reinit(psi0, loc0)
+                a1 = np.asarray(eng.run(EpsStream(9, 1, G), 14, 5e-2))
+                b1 = np.asarray(fw.run(EpsStream(9, 1, G), 14, 5e-2))
+                assert np.array_equal(a1, b1) and 11 <= len(a1) <= 15, (a1, b1)
+                sa, sb = eng.get_state(), fw.get_state()
+                for n in sa:
+                    assert np.array_equal(sa[n], sb[n]), n
+            finally:
+                fw.close()
         # same seed, same bits: the exchange's sums do not depend on who arrived when
         eng.reinit(psi0, loc0)
         t2 = np.asarray(eng.run(EpsStream(9, 1, G), n_iter, 1e-12))
