@@ -654,10 +654,11 @@ struct ca_yfin_args {
   const int* col_chunk_ptr; const float* csum; int G;
   const float* YWpart; int nseg; const float* F; int D; int64_t N; float* YW; double* yw_part;
 };
-__device__ __forceinline__ void ca_yfin_col_wave(const ca_yfin_args& a, int job) {
+__device__ __forceinline__ void ca_yfin_col_wave_few(const ca_yfin_args& a, int job) {
   constexpr int RL = 16;
   const int c = job * 64 + (int)(threadIdx.x & 63);
   if (c >= a.cols) return;
+  // (the form for FEW slab rows -- under 64: most row lanes then have no whole trip of four rows, and one lane after the other is the faster order)
   // row lanes in bit-reversed order (0, 8, 4, 12, 2, 10, 6, 14, then the odd ones), eight at a time -- the sweep's register budget --
   // so that each half folds into one subtree of k_colsum's LDS tree: ((x0 + x1) + (x2 + x3)) + ((x4 + x5) + (x6 + x7))
   double half[2];
@@ -686,6 +687,76 @@ __device__ __forceinline__ void ca_yfin_col_wave(const ca_yfin_args& a, int job)
         if (r + i * RL < a.rows) a0 += (double)t[i];
       a0 += a2; a1 += a3;
       if (ty == 0 && a.csum && c < a.G)
+        for (int ch = a.col_chunk_ptr[c]; ch < a.col_chunk_ptr[c + 1]; ++ch) a1 += (double)a.csum[ch];
+      x[k] = a0 + a1;
+    }
+    half[i8] = ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
+  }
+  a.out[c] = half[0] + half[1];
+}
+__device__ __forceinline__ void ca_yfin_col_wave(const ca_yfin_args& a, int job) {
+  constexpr int RL = 16;
+  if (a.rows < 4 * RL) { ca_yfin_col_wave_few(a, job); return; }   // (uniform; same additions in the same order either way -- measured: 12 500 cells, 50 rows: 64.2 vs 65.2 us per iteration)
+  const int c = job * 64 + (int)(threadIdx.x & 63);
+  if (c >= a.cols) return;
+  // row lanes in bit-reversed order (0, 8, 4, 12, 2, 10, 6, 14, then the odd ones), eight at a time, so that each half folds into one subtree
+  // of k_colsum's LDS tree: ((x0 + x1) + (x2 + x3)) + ((x4 + x5) + (x6 + x7)).  Round 5: the eight row lanes of a half advance TOGETHER --
+  // 32 loads in flight per trip instead of eight chains of 4 one after the other (2 x 8 x 2 dependent rounds of loads at 98 slab rows: on a
+  // small shard, where every sweep block of the one resident round ends at the same moment, these trailing blocks run behind the sweep, and
+  // at 25 000 cells they were 4.9 us of the backward launch).  Every chain receives the same addends in the same order: the same bits.
+  const float* col = a.part + c;
+  double half[2];
+#pragma unroll 1
+  for (int i8 = 0; i8 < 2; ++i8) {
+    double acc[8][4];
+    int ty[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      ty[k] = ((k & 1) << 3) | ((k & 2) << 1) | ((k & 4) >> 1) | i8;
+      acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.0;
+    }
+    // whole trips of four rows per lane: lane ty covers rows ty + 64 t + {0, 16, 32, 48} while the last of them exists
+    const int tmax = a.rows > 3 * RL ? (a.rows - 3 * RL - 1) / (4 * RL) + 1 : 0;   // trips of row lane 0 (the longest)
+    for (int t = 0; t < tmax; ++t) {
+      float v[8][4];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int r = ty[k] + 4 * RL * t;
+        const bool ok = r + 3 * RL < a.rows;
+        const int rr = ok ? r : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[k][u] = col[(int64_t)(rr + u * RL) * a.ld];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (ty[k] + 4 * RL * t + 3 * RL < a.rows) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[k][u] += (double)v[k][u];
+        }
+      }
+    }
+    // the (at most three) rows left of every lane go to its first chain in order: loaded together, rows past the end skipped
+    float tl[8][3];
+    int rl[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      int r = ty[k];
+      while (r + 3 * RL < a.rows) r += 4 * RL;   // (uniform per k: where this lane's whole trips ended)
+      rl[k] = r;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int rr = r + i * RL;
+        tl[k][i] = col[(int64_t)(rr < a.rows ? rr : 0) * a.ld];
+      }
+    }
+    double x[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        if (rl[k] + i * RL < a.rows) acc[k][0] += (double)tl[k][i];
+      double a0 = acc[k][0] + acc[k][2], a1 = acc[k][1] + acc[k][3];
+      if (ty[k] == 0 && a.csum && c < a.G)
         for (int ch = a.col_chunk_ptr[c]; ch < a.col_chunk_ptr[c + 1]; ++ch) a1 += (double)a.csum[ch];
       x[k] = a0 + a1;
     }
