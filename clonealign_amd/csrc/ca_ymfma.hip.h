@@ -333,7 +333,17 @@ __device__ __forceinline__ void ca_ds_read_tr_b8_x8(unsigned addr, uint2 (&lo)[4
       : "v"(addr)
       : "memory");
 }
-static_assert(8 * CA_YS_PITCH == 640, "offsets in ca_ds_read_tr_b8_x8 assume the 80-byte pitch");
+// two gene tiles at a time (the riding form: eight result registers live instead of sixteen; addr + 32 for tiles 2 and 3)
+__device__ __forceinline__ void ca_ds_read_tr_b8_x4(unsigned addr, uint2 (&lo)[2], uint2 (&hi)[2]) {
+  asm volatile(
+      "ds_read_b64_tr_b8 %0, %4\n\tds_read_b64_tr_b8 %2, %4 offset:640\n\t"
+      "ds_read_b64_tr_b8 %1, %4 offset:16\n\tds_read_b64_tr_b8 %3, %4 offset:656\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(lo[0]), "=&v"(lo[1]), "=&v"(hi[0]), "=&v"(hi[1])
+      : "v"(addr)
+      : "memory");
+}
+static_assert(8 * CA_YS_PITCH == 640, "offsets in ca_ds_read_tr_b8_x8 / _x4 assume the 80-byte pitch");
 __device__ __forceinline__ uint4 ca_and4(uint4 a, unsigned m) { return (uint4){a.x & m, a.y & m, a.z & m, a.w & m}; }
 
 // The bias (stored byte = y - 128) is undone by the finisher: 128 x the digit sums of the parameter images, which the
@@ -391,19 +401,38 @@ __device__ __forceinline__ void ca_ys_mfma_body(int blk, const uint8_t* __restri
   const uint4* wsrc = Wr + (int64_t)(g0 >> 6) * 64;                                 // (scalar)
   const unsigned voff = 16u * (unsigned)lane;                                       // the lane's 16 bytes of a 1-KiB load
   uint4 R[DEPTH][4], W[DEPTH];
-  // piece number k of the strip: cell step k / NP, gene block k % NP
-  const int npieces = c0 < c1 ? (int)((c1 - c0 + 63) / 64) * NP : 0;
-  auto issue = [&](int slot, int k) {
-    const uint8_t* p = src + ((int64_t)(k / NP) * (int64_t)(Gp / 64) + (k % NP)) * 4096;   // (scalar)
+  // pieces of the strip: cell step st (64 cells), gene block a (0 .. NP-1); DEPTH pieces in flight
+  const int nsteps = c0 < c1 ? (int)((c1 - c0 + 63) / 64) : 0;
+  // Buffer loads: a scalar base (the strip's first piece; the segment's W image; psi's image) in a resource descriptor, the piece's byte offset in a
+  // scalar register, the lane's 16 bytes in ONE vector register -- no 64-bit vector address per stream, which the riding form's register budget
+  // (128, the sweep's) has no room for.  Offsets are 32-bit: the host uses this stream only where RS * Gp and 16 N stay far below 2^31.
+  typedef unsigned ca_v4u __attribute__((ext_vector_type(4)));
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, 0x7FFFFFFF, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(wsrc), 0, NP * 1024, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(Pr + (c0 >> 6) * 64), 0, 0x7FFFFFFF, 0x00020000);
+  auto issue = [&](int slot, int st, int a) {
+    const int so = (st * (Gp / 64) + a) * 4096;   // (scalar)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) R[slot][i] = ca_ld_stream(reinterpret_cast<const uint4*>(p + 1024 * i + voff));
-    W[slot] = *reinterpret_cast<const uint4*>(reinterpret_cast<const uint8_t*>(wsrc + (k % NP) * 64) + voff);
+    for (int i = 0; i < 4; ++i) {
+      const ca_v4u v = __builtin_amdgcn_raw_buffer_load_b128(ry, (int)(voff + 1024u * (unsigned)i), so, 2 /* nt: streamed once */);
+      R[slot][i] = (uint4){v.x, v.y, v.z, v.w};
+    }
+    const ca_v4u w = __builtin_amdgcn_raw_buffer_load_b128(rw, (int)voff, a * 1024, 0);
+    W[slot] = (uint4){w.x, w.y, w.z, w.w};
   };
+  if (nsteps > 0) {
 #pragma unroll
-  for (int d_ = 0; d_ < DEPTH; ++d_)
-    if (d_ < npieces) issue(d_, d_);
-  ca_i32x4 acc_yw = {0, 0, 0, 0};
-  uint4 pr = {0u, 0u, 0u, 0u};
+    for (int d_ = 0; d_ < DEPTH; ++d_) issue(d_, 0, d_);
+  }
+  // Round 5: the gene blocks of a cell step are UNROLLED, so that every accumulator is a fixed register (the loop over pieces with a switch on the
+  // block index moved the 32 accumulator registers through chains of copies: ~40 v_mov per piece), the column products chain straight onto their
+  // accumulator, and the images are never masked per piece -- row products: one accumulator per cell tile against the UNMASKED W image (K = 1: its
+  // four column groups repeat the digits, so every group holds the tile's sums and the flush picks its own); column products: psi's image masked to
+  // one row group per gene tile once per cell step.  Vector instructions per 4-KiB piece: ~76 -> 2, and with the buffer loads above the merged forward kernel
+  // no longer spills (128 VGPRs, 6 spilled -> 0).  Measured: the launch's time at cfg-3 does NOT change (within +-1 us; 25k cells -1 us) -- what the
+  // riding stream costs the sweep is its wave slot, not its instructions (profiles/r05_stream_slot.txt).
+  ca_i32x4 acc_yw[4];
+  uint4 prm[4];
   // bias of the row products: 128 x (digit sums of the segment's W image) per digit -- wave-uniform addresses, so the sums live
   // in scalar registers for the whole strip and cost the piece loop no vector register; a lane picks digit p = j & 3 at the flush
   int wtot[4] = {0, 0, 0, 0};
@@ -415,59 +444,49 @@ __device__ __forceinline__ void ca_ys_mfma_body(int blk, const uint8_t* __restri
       for (int p_ = 0; p_ < 4; ++p_) wtot[p_] += ws[a * 4 + p_];
   }
   const int e_w = io.exps[0];
-  for (int k0 = 0; k0 < npieces; k0 += DEPTH) {
-    const int gb0 = k0 % NP;
-    const int64_t cs = c0 + (int64_t)(k0 / NP) * 64;
-    if (gb0 == 0) {   // (wave-uniform) a new cell step
-      acc_yw = (ca_i32x4){0, 0, 0, 0};
-      pr = Pr[(cs >> 6) * 64 + lane];
+  for (int st = 0; st < nsteps; ++st) {
+    const int64_t cs = c0 + (int64_t)st * 64;
+    const bool more = st + 1 < nsteps;   // (wave-uniform)
+    {
+      // (the wait for this load is also the wait for the step's first piece, which is needed next anyway; a stream wave has ~2000 cycles per piece)
+      const ca_v4u pv = __builtin_amdgcn_raw_buffer_load_b128(rp, (int)voff, st * 1024, 0);
+      const uint4 pr = {pv.x, pv.y, pv.z, pv.w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { acc_yw[t] = (ca_i32x4){0, 0, 0, 0}; prm[t] = ca_and4(pr, msk[t]); }
     }
-    ca_i32x4 dd[DEPTH];
 #pragma unroll
-    for (int d_ = 0; d_ < DEPTH; ++d_) {
-      // the piece is in R[d_]: park it in LDS, start the loads of the piece DEPTH further on, then feed the matrix core
+    for (int a = 0; a < NP; ++a) {
+      const int slot = a % DEPTH;
+      __builtin_amdgcn_sched_barrier(0);   // (pieces one after the other: hoisting the next piece's LDS reads over this one's costs registers the sweep's budget has not)
+      // the piece is in R[slot]: park it in LDS, start the loads of the piece DEPTH further on, then feed the matrix core
 #pragma unroll
-      for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(wr_dst + 16 * i * CA_YS_PITCH) = R[d_][i];
-      const uint4 wr = W[d_];
-      if (k0 + d_ + DEPTH < npieces) issue(d_, k0 + d_ + DEPTH);
-      // row products: the four cell tiles against this 64-gene block, one accumulator (tile t -> columns 4t .. 4t+3)
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(wr_dst + 16 * i * CA_YS_PITCH) = R[slot][i];
+      const uint4 wr = W[slot];
+      if (a + DEPTH < NP) issue(slot, st, a + DEPTH);
+      else if (more) issue(slot, st + 1, a + DEPTH - NP);
+      // row products: the four cell tiles against this 64-gene block
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const uint4 a = *reinterpret_cast<const uint4*>(rd_row + 16 * t * CA_YS_PITCH);
-        acc_yw = ca_mfma_i8(a, ca_and4(wr, msk[t]), acc_yw);
+        const uint4 av = *reinterpret_cast<const uint4*>(rd_row + 16 * t * CA_YS_PITCH);
+        acc_yw[t] = ca_mfma_i8(av, wr, acc_yw[t]);
       }
       // column products: the four gene tiles of the block against the 64 cells, one accumulator (tile t -> rows 4t .. 4t+3)
-      ca_i32x4 d = {0, 0, 0, 0};
-      {
-        uint2 lo[4], hi[4];
-        ca_ds_read_tr_b8_x8(rd_tr, lo, hi);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) d = ca_mfma_i8(ca_and4(pr, msk[t]), (uint4){lo[t].x, lo[t].y, hi[t].x, hi[t].y}, d);
+      for (int h2 = 0; h2 < 2; ++h2) {
+        uint2 lo[2], hi[2];
+        ca_ds_read_tr_b8_x4(rd_tr + 32u * (unsigned)h2, lo, hi);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc_yt[a] = ca_mfma_i8(prm[2 * h2 + t], (uint4){lo[t].x, lo[t].y, hi[t].x, hi[t].y}, acc_yt[a]);
       }
-      dd[d_] = d;
     }
-    // which accumulators the DEPTH pieces belong to depends on the (dynamic) block index only through this switch
-#define CA_YS_ADD(B)                                                       \
-  case B:                                                                  \
-    _Pragma("unroll") for (int d_ = 0; d_ < DEPTH; ++d_) acc_yt[B + d_] += dd[d_]; \
-    break;
-    if constexpr (DEPTH == 1) {
-      switch (gb0) { CA_YS_ADD(0) CA_YS_ADD(1) CA_YS_ADD(2) CA_YS_ADD(3) CA_YS_ADD(4) CA_YS_ADD(5) CA_YS_ADD(6) CA_YS_ADD(7) default: break; }
-    } else if constexpr (DEPTH == 2) {
-      switch (gb0) { CA_YS_ADD(0) CA_YS_ADD(2) CA_YS_ADD(4) CA_YS_ADD(6) default: break; }
-    } else if constexpr (DEPTH == 4) {
-      switch (gb0) { CA_YS_ADD(0) CA_YS_ADD(4) default: break; }
-    } else {
-      switch (gb0) { CA_YS_ADD(0) default: break; }
-    }
-#undef CA_YS_ADD
-    if (gb0 + DEPTH == NP) {   // (uniform) the cell step is complete: lane (column 4t + p, q) holds cells 16 t + 4 q + r, digit p
+    {   // the cell step is complete: lane (column 4t + p, q) holds cells 16 t + 4 q + r, digit p
       const int t = j >> 2, p = j & 3;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int64_t n = cs + 16 * t + 4 * q + r;
         const int wb = p == 0 ? wtot[0] : p == 1 ? wtot[1] : p == 2 ? wtot[2] : wtot[3];
-        long long v = ((long long)acc_yw[r] + 128ll * (long long)wb) << (8 * p);   // digit p of the quad's four (lanes j & 3): exact in 64 bits
+        const int ar = t == 0 ? acc_yw[0][r] : t == 1 ? acc_yw[1][r] : t == 2 ? acc_yw[2][r] : acc_yw[3][r];
+        long long v = ((long long)ar + 128ll * (long long)wb) << (8 * p);   // digit p of the quad's four (lanes j & 3): exact in 64 bits
         v += __shfl_xor(v, 1, 64);
         v += __shfl_xor(v, 2, 64);
         if (p == 0 && n < N) io.YWpart[(int64_t)seg * N + n] = (float)ldexp((double)v, -e_w);

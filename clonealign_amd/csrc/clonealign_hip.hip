@@ -2389,7 +2389,8 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     h->y_dev_bytes += (h->ym_NT * h->ym_GS + (int64_t)h->ym_GT * h->ym_NS) * 1024;
   }
   // ---- both products from ONE tiled copy (k_ys_mfma): K = 1, 1-byte storage
-  if (h->ystore == CA_YSTORE_U8 && K == 1 && !h->y_mfma && variant_on(h, CA_VAR_Y_MFMA1, "CA_Y_MFMA1")) {
+  // (the stream's buffer loads carry 32-bit byte offsets inside a strip: RS <= 512 cells x Gp bytes, and 16 N bytes of psi's image -- far inside 2^31 below these bounds)
+  if (h->ystore == CA_YSTORE_U8 && K == 1 && !h->y_mfma && h->Gp < (1 << 21) && Nn < ((int64_t)1 << 26) && variant_on(h, CA_VAR_Y_MFMA1, "CA_Y_MFMA1")) {
     h->ys_N64 = (Nn + 63) / 64 * 64;
     h->ys_nseg = h->Gp / CA_YS_GW;                  // Gp is a multiple of 1024
     // strips of RS cells per wave: about one resident round of blocks (3 per CU), at least 64 cells
