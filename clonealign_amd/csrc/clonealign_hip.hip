@@ -186,6 +186,7 @@ struct ca_engine {
   // matrix-core backward sweep (k_bwd_mfma): bf16 parts of coef, its own cell split
   bool bwd_mfma = false, bwd_frac = false, c16 = false, s2 = false, s2f = false;   // s2f: mc_samples = 2 with monitor + next train pass in one sweep (CA_VAR_S2_FUSE)
   unsigned short* coefq = nullptr; int64_t N16 = 0, cchunk_m = 0; int csplit_m = 1, nwt = 0;
+  int bwd_tl = CA_BWD_TL;   // gene tiles of 16 per wave in the matrix-core backward sweep: 4, or 3 for small problems (more, shorter wave jobs)
   uint64_t draw = 0;  // built-in stream position
   // count-matrix products on the int8 matrix cores (ca_ymfma.hip.h): tiled copies, fixed-point parameter images
   bool y_mfma = false;
@@ -957,6 +958,9 @@ int flush_mon_tail(ca_engine* h) {
 }
 inline ca_small_args no_small_args() { ca_small_args a; memset(&a, 0, sizeof(a)); return a; }
 
+#ifndef CA_BWD_TL3_MAXN
+#define CA_BWD_TL3_MAXN 18432   // cells up to which the backward sweep takes three gene tiles per wave (see create_impl)
+#endif
 // backward half of a train pass: the sweep, the column sums of its partials and the cross-shard reduction.  Changes no
 // variable, so ca_run may issue it before it knows whether the loop goes on (train_bwd_speculative).
 int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
@@ -964,7 +968,6 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
   bool merged = false, ride_ar = false;
   ca_ar_ride ride;
   if (h->bwd_mfma) {
-    constexpr int TL = CA_BWD_TL;
     const int xb = cdiv(h->nwt, CA_TB / 64);
     // A pending monitor pass's tail rides on the sweep as one extra block (its fp64 chains hide under 130 us of sweep):
     // whole when unsharded; sharded, only the local sums of the cell / psi.(YW) partials -- ONE all-reduce per iteration
@@ -1003,9 +1006,9 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
     memset(&no_yfin, 0, sizeof(no_yfin));
     // mc_samples = 2 (round 4): both samples in ONE sweep (k_bwd_mfma<.., S2>: one exp per (cell, gene) for the two of them)
     const bool s2b = h->s2f && h->S == 2 && !h->c16;
-#define CA_BWDM(DDV) do { if (h->c16) CA_BWDM_(DDV, false, true, false); else if (s2b) { if (h->bwd_frac) CA_BWDM_(DDV, true, false, true); else CA_BWDM_(DDV, false, false, true); } \
-                          else if (h->bwd_frac) CA_BWDM_(DDV, true, false, false); else CA_BWDM_(DDV, false, false, false); } while (0)
-#define CA_BWDM_(DDV, FRV, C16V, S2V)                                                                                       \
+#define CA_BWDM(DDV) do { if (h->c16) CA_BWDM_(CA_BWD_TL, DDV, false, true, false); else if (s2b) { if (h->bwd_frac) CA_BWDM_(CA_BWD_TL, DDV, true, false, true); else CA_BWDM_(CA_BWD_TL, DDV, false, false, true); } \
+                          else if (h->bwd_frac) CA_BWDM_(CA_BWD_TL, DDV, true, false, false); else if (h->bwd_tl == 3) CA_BWDM_(3, DDV, false, false, false); else CA_BWDM_(CA_BWD_TL, DDV, false, false, false); } while (0)
+#define CA_BWDM_(TL, DDV, FRV, C16V, S2V)                                                                                   \
   LAUNCH(h, CA_KERNEL_BWD,                                                                                                 \
          hipLaunchKernelGGL((k_bwd_mfma<TL, DDV, FRV, C16V, S2V>), dim3(xb, h->csplit_m + (s == 0 ? yextra : 0)), dim3(CA_TB), \
                             (size_t)h->cchunk_m * 4 * DDV * sizeof(float) * (S2V ? 2 : 1), h->stream,                       \
@@ -2189,13 +2192,18 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     h->bwd_mfma = (D == 1 || D == 2) && (h->nchunk == 1 || (h->nchunk == 2 && exact && S == 1)) && variant_on(h, CA_VAR_BWD_MFMA, "CA_BWD_MFMA");
     h->N16 = (Nn + 15) / 16 * 16;
     if (h->bwd_mfma) {
-      h->nwt = cdiv(G, CA_BWD_TL * 16);
+      // Gene tiles per wave.  Four amortise the coef operand best (cfg-3: 111.6 us against 122.5 with three, although three fit four waves per SIMD);
+      // a small problem has too few wave jobs at four (cfg-2: 32 of them, eight blocks across) and gains from three: cfg-2 39.3 -> 37.5 us per
+      // iteration, 12.5k x 5k 63.7 -> 62.6; 25k cells 91.2 -> 95.1 (profiles/r05_small_shapes.txt section 9).  Main variant only.
+      h->bwd_tl = (Nn <= CA_BWD_TL3_MAXN && !h->c16 && exact && S == 1 && h->nchunk == 1 && variant_on(h, CA_VAR_BWD_TL3, "CA_BWD_TL3")) ? 3 : CA_BWD_TL;
+      h->nwt = cdiv(G, h->bwd_tl * 16);
       const int xb = cdiv(h->nwt, CA_TB / 64);
       {
         // resident blocks per CU from the compiler's register count (LDS, 16 B per cell of the slice, is not the limit
         // at the slice lengths this produces); one or two full rounds instead of "about 8 blocks per CU"
         int per_cu = 4;
-        const void* bfn = D == 1 ? (const void*)k_bwd_mfma<CA_BWD_TL, 1, false> : (const void*)k_bwd_mfma<CA_BWD_TL, 2, false>;
+        const void* bfn = h->bwd_tl == 3 ? (D == 1 ? (const void*)k_bwd_mfma<3, 1, false> : (const void*)k_bwd_mfma<3, 2, false>)
+                                         : (D == 1 ? (const void*)k_bwd_mfma<CA_BWD_TL, 1, false> : (const void*)k_bwd_mfma<CA_BWD_TL, 2, false>);
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, bfn, CA_TB, 16 * 1024) != hipSuccess || per_cu < 1)
           per_cu = 4;
         (void)hipGetLastError();

@@ -24,7 +24,7 @@ YSTORE_NAME = {v: k for k, v in YSTORE.items()}
 KERNEL_NAMES = ("fwd", "bwd", "ypass", "cell", "other")
 # ca_variant bits (ca_options.variant_off: a set bit switches the variant OFF) and ca_tune_id slots
 VARIANTS = {"fused": 1 << 0, "fwd_mfma": 1 << 1, "fwd_cell": 1 << 2, "bwd_mfma": 1 << 3, "tail_fuse": 1 << 4, "async_y": 1 << 5,
-            "pre": 1 << 6, "pair_elbo": 1 << 7, "prep_fast": 1 << 8, "update_merge": 1 << 9, "p2p": 1 << 10, "fold_gsum": 1 << 11, "y_ride": 1 << 12, "ride_seq": 1 << 13, "y_mfma1": 1 << 14, "yfin_ride": 1 << 15, "p2p_ride": 1 << 16, "run_gate": 1 << 17, "s2_fuse": 1 << 18, "fwd_bal": 1 << 19}
+            "pre": 1 << 6, "pair_elbo": 1 << 7, "prep_fast": 1 << 8, "update_merge": 1 << 9, "p2p": 1 << 10, "fold_gsum": 1 << 11, "y_ride": 1 << 12, "ride_seq": 1 << 13, "y_mfma1": 1 << 14, "yfin_ride": 1 << 15, "p2p_ride": 1 << 16, "run_gate": 1 << 17, "s2_fuse": 1 << 18, "fwd_bal": 1 << 19, "bwd_tl3": 1 << 20}
 VARIANTS_ON = {"y_mfma2": 1 << 0, "async_small": 1 << 1, "y_mfma1": 1 << 2, "fold_always": 1 << 3, "ride_seq": 1 << 4, "p2p_same_device": 1 << 5, "run_fwd": 1 << 6, "bal_tiles": 1 << 7}      # ca_variant_on: opt-in variants
 OPT_VERBOSE = 0x80000000
 TUNE = {"gsplit": 0, "fsplit": 1, "fc_tl": 2, "fc_nbig": 3, "csplit": 4, "csplit_m": 5, "tr": 6, "rg": 7}

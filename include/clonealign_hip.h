@@ -99,6 +99,8 @@ enum ca_variant {
   CA_VAR_FWD_BAL = 1 << 19,   /* small problems (one to six 16-cell tiles per CU): ONE eight-wave forward-sweep block per CU, the left-over tiles spread gene-wise over
                                  the blocks with their partial Z exchanged through tagged words (k_fwd_bal_ys, ca_fwdbal.hip.h): every SIMD holds two waves with equal
                                  work; off: 16- / 32-cell four-wave blocks, as many as the cells need */
+  CA_VAR_BWD_TL3 = 1 << 20,   /* small problems (up to 18 432 cells): the matrix-core backward sweep takes three gene tiles per wave instead of four -- more and
+                                 shorter wave jobs; off: four at every size */
   CA_VAR_P2P = 1 << 10,       /* one-shot peer-to-peer all-reduce (else ncclAllReduce) after ca_comm_init() */
   CA_VAR_FOLD_GSUM = 1 << 11, /* small problems: backward-sweep partials summed inside the per-gene kernel (else a k_colsum launch) */
   CA_VAR_Y_RIDE = 1 << 12,    /* the Y stream's blocks ride on the forward sweep's launch (else side stream / in line) */
