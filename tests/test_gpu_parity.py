@@ -767,6 +767,32 @@ def test_merged_update_launch_is_bitwise_the_two_launch_update(name, mode):
         assert np.array_equal(a[8][n], b[8][n]), n
 
 
+@pytest.mark.parametrize("shape", [dict(N=900, G=410, C=4, K=1), dict(N=333, G=47, C=3, K=1), dict(N=2100, G=1000, C=8, K=1), dict(N=700, G=130, C=5, K=2)])
+def test_backward_sweep_with_three_gene_tiles_per_wave_agrees_with_four(shape):
+    """Round 5: up to 18 432 cells the matrix-core backward sweep gives a wave three 16-gene tiles instead of four (k_bwd_mfma<3, ...>: more and shorter
+    wave jobs; the cell slices follow the new block count).  Same per-gene and per-cell sums grouped differently over the cells: the loop must agree
+    with the four-tile sweep (variant bwd_tl3 off) to float32 rounding, clone labels exactly, and the pick must be visible where it applies."""
+    from clonealign_amd.engine import HipEngine
+    from clonealign_amd.rng import EpsStream
+    case = make_case(seed=47, **shape)
+    G = shape["G"]
+    outs = []
+    for voff in ((), ("bwd_tl3",)):
+        eng = HipEngine(**case, variant_off=voff)
+        try:
+            assert eng.info()["bwd_mfma"] == 1
+            tr = np.asarray(eng.run(EpsStream(5, 1, G), 12, 1e-12))
+            outs.append((tr, eng.get_params(), eng.get("clone_probs")))
+        finally:
+            eng.close()
+    (ta, pa, ca), (tb, pb, cb) = outs
+    assert np.all(np.isfinite(ta)) and np.allclose(ta, tb, rtol=2e-6, atol=0), (ta, tb)
+    for n in pb:
+        scale = max(1e-3, float(np.max(np.abs(pb[n]))))
+        assert np.max(np.abs(np.asarray(pa[n]) - np.asarray(pb[n]))) <= 2e-4 * scale, n
+    assert np.array_equal(np.argmax(ca, 1), np.argmax(cb, 1))
+
+
 def test_merged_update_survives_a_cancelled_run_and_a_restart():
     """The merged update leaves the exponent bound to the NEXT forward sweep and chi / alpha in swapped buffers: a run that is cancelled
     right after an update (poll hook), parameter fetches, ca_set_param and ca_reinit in between must all see a consistent state --

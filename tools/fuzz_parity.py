@@ -24,7 +24,7 @@ rng = np.random.default_rng(int(_args[1]) if len(_args) > 1 else 7)
 VARIANTS = [((), (), {})] * 4 + [(("fwd_cell",), (), {}), (("fwd_mfma",), (), {}), (("bwd_mfma",), (), {}), (("async_y",), (), {}), (("pre",), (), {}),
             (("tail_fuse",), (), {}), ((), (), {"fc_tl": 4, "fc_nbig": 2}), (("pair_elbo",), (), {}),
             (("y_mfma1",), (), {}), (("y_mfma1",), ("ride_seq",), {}), (("y_mfma1", "y_ride"), (), {}), (("y_ride",), (), {}),
-            (("update_merge",), (), {}), (("update_merge", "y_mfma1"), (), {}), (("s2_fuse",), (), {}), (("run_gate",), (), {}), (("fwd_bal",), (), {})]
+            (("update_merge",), (), {}), (("update_merge", "y_mfma1"), (), {}), (("s2_fuse",), (), {}), (("run_gate",), (), {}), (("fwd_bal",), (), {}), (("bwd_tl3",), (), {})]
 BAL = "--bal" in sys.argv   # shapes of the balanced eight-wave forward sweep (4096+ cells, 3072+ genes, K = 1, up to eight clones) against the C oracle
 fails = 0
 for it in range(n_cases):
@@ -82,6 +82,22 @@ for it in range(n_cases):
                 why.append("%s %.2e of %.2e" % (n, float(np.abs(a - b).max()), float(np.abs(b).max())))
         if only is not None:
             print("trace engine", tr.tolist(), "oracle", to.tolist(), "rel", float(np.abs(tr - to).max() / np.abs(to).max()))
+            # where a variable disagrees, and how small the oracle's gradient was there at each step (Adam turns the SIGN of a gradient of rounding-noise
+            # size into a step of lr): a fresh oracle replays the loop and records |g| at the worst element against the variable's median |g|
+            bad = [n for n in po if np.asarray(po[n]).size and np.abs(np.asarray(pe[n], float) - np.asarray(po[n], float)).max() > 5e-3 * max(np.abs(np.asarray(po[n], float)).max(), 1e-2)]
+            if bad and not BAL:
+                o2 = FusedModel(**case, dtype="float32")
+                es = EpsStream(3, S, G)
+                o2.gamma_init(es.next()); o2.elbo(es.next())     # (run_vi_loop's order of draws)
+                for step in range(n_iter):
+                    e = es.next()
+                    g, _ = o2.gradients(e)
+                    for n in bad:
+                        d = np.abs(np.asarray(pe[n], float) - np.asarray(po[n], float)).reshape(-1)
+                        j = int(np.argmax(d))
+                        gv = np.abs(np.asarray(g[n], float)).reshape(-1)
+                        print(f"  step {step}: {n}[{j}] final diff {d[j]:.3e}; oracle |g| there {gv[j]:.3e}, median |g| of {n} {np.median(gv):.3e}, elements with |g| < 1e-6 median: {int((gv < 1e-6 * np.median(gv)).sum())}")
+                    o2.step(e); o2.elbo(es.next())
         if why:
             fails += 1
             print("FAIL case", it, kw, env, "iters", n_iter, "trace diff", float(np.abs(tr - to).max() / np.abs(to).max()), "|", "; ".join(why))
