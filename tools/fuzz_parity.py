@@ -35,7 +35,7 @@ for it in range(n_cases):
     P = int(rng.choice([0, 0, 0, 1])) if K > 0 else 0
     S = 1 if rng.random() < 0.8 else 2
     if BAL:
-        N, G, C, K, P, S = int(rng.integers(4096, 30000)), int(rng.integers(3072, 3400)), int(rng.integers(2, 9)), 1, 0, 1
+        N, G, C, K, P, S = int(rng.integers(4096, 28672)), int(rng.integers(3072, 3400)), int(rng.integers(2, 9)), 1, 0, 1   # (up to six whole tiles per CU: the balanced range)
     voff, von, tune = VARIANTS[int(rng.integers(0, len(VARIANTS)))] if not BAL else ((), (), {})
     env = {"variant_off": voff, "variant_on": von, "tune": tune}
     kw = dict(N=N, G=G, C=C, K=K, S=S)
