@@ -165,11 +165,17 @@ __device__ __forceinline__ float ca_ytf_rt(float y, int tf) {
 }
 
 // ------------------------------------------------------------------ upload / conversion
+// One thread per element of the N x Gp matrix: a launch's x extent is a 32-bit count of work-items (the dispatch packet's grid size), so 2^32 elements --
+// 838 860 cells at 5120 padded genes -- is where a one-dimensional grid silently wraps (round 5: a 1M-cell matrix came up with its first 161 140 cells
+// converted and the rest zero).  These kernels take a two-dimensional grid (ca_grid_flat on the host) and flatten it here.
+__device__ __forceinline__ int64_t ca_flat_index() {
+  return ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+}
 // src is N x G in either layout and any ca_dtype; dst is row-major [N][Gp] of YT, zero padded.
 template <typename ST, typename YT>
 __global__ void k_convert_y(const ST* __restrict__ src, YT* __restrict__ dst, int64_t N, int G, int Gp,
                             int64_t sn, int64_t sg, int* __restrict__ flags) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = ca_flat_index();
   if (i >= N * (int64_t)Gp) return;
   const int64_t n = i / Gp;
   const int g = (int)(i - n * Gp);
@@ -189,7 +195,7 @@ __global__ void k_convert_y(const ST* __restrict__ src, YT* __restrict__ dst, in
 template <typename ST>
 __global__ void k_gather_y(const ST* __restrict__ src, ST* __restrict__ dst, int64_t N, int G, int64_t sn, int64_t sg,
                            const int64_t* __restrict__ cell_index, const int32_t* __restrict__ gene_index) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = ca_flat_index();
   if (i >= N * (int64_t)G) return;
   const int64_t n = i / G;
   const int g = (int)(i - n * G);
@@ -205,7 +211,7 @@ template <typename ST>
 __global__ void k_convert_y_u8ovf(const ST* __restrict__ src, uint8_t* __restrict__ dst, int64_t N, int G, int Gp, int64_t sn,
                                   int64_t sg, unsigned long long* __restrict__ counter, int* __restrict__ orow,
                                   int* __restrict__ ocol, float* __restrict__ oval) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = ca_flat_index();
   if (i >= N * (int64_t)Gp) return;
   const int64_t n = i / Gp;
   const int g = (int)(i - n * Gp);

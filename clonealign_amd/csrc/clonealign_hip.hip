@@ -325,6 +325,12 @@ int prof_end(ca_engine* h) {
   } while (0)
 
 inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+// grid of `threads`-wide blocks for `total` elements, one thread each, flattened by ca_flat_index(): x stays below 2^22 blocks (2^30 work-items)
+inline dim3 ca_grid_flat(int64_t total, int threads) {
+  const int64_t nb = (total + threads - 1) / threads;
+  const int64_t gx = std::min<int64_t>(nb, (int64_t)1 << 22);
+  return dim3((unsigned)std::max<int64_t>(gx, 1), (unsigned)std::max<int64_t>((nb + gx - 1) / std::max<int64_t>(gx, 1), 1));
+}
 
 // Configuration comes from ca_options (variant_off / variant_on / tune).  The RELEASE library reads no tuning from the process
 // environment at all; a timing-lab build (-DCA_LAB, tools/lab/) consults it when CLONEALIGN_DEBUG_ENV is set (tools/tune.py,
@@ -1782,12 +1788,18 @@ int scan_and_convert(ca_engine* h, const ST* src_dev, int64_t sn, int64_t sg) {
   h->nseg = cdiv(h->G, segw);
   h->Gp = h->nseg * segw;
   h->y_dev_bytes = h->N * (int64_t)h->Gp * h->ybytes;
+  // Kernels that take one thread per 16 BYTES of the resident matrix (k_bias_y, the tilers) use one-dimensional grids: 2^32 work-items = 64 GiB of matrix,
+  // more than a quarter of this device's memory in ONE matrix (there are two copies).  Refuse instead of wrapping.
+  if ((h->N * (int64_t)h->Gp) / 16 >= ((int64_t)1 << 32) || h->N >= ((int64_t)1 << 31)) {
+    h->err = "count matrix too large for this build (cells x padded genes >= 2^36 bytes, or 2^31 cells)";
+    return CA_ERR_INVALID;
+  }
   uint8_t* yb = nullptr;
   CACK(dalloc(h, &yb, h->y_dev_bytes));
   h->Y = yb;
   HIPCK(h, hipMemsetAsync(maxv, 0, 32, h->stream));
   const int64_t tot = h->N * (int64_t)h->Gp;
-  dim3 grid(cdiv(tot, CA_TB));
+  const dim3 grid = ca_grid_flat(tot, CA_TB);
   if (store == CA_YSTORE_U8 && n255 > 0) {
     h->n_ovf = (int64_t)n255;
     int *orow = nullptr, *ocol = nullptr; float* oval = nullptr;
@@ -1861,7 +1873,7 @@ template <typename ST>
 int gather_y(ca_engine* h, const void* src, void** dst, int64_t sn, int64_t sg, const int64_t* ci_dev, const int32_t* gi_dev) {
   const int64_t total = h->N * (int64_t)h->G;
   HIPCK(h, hipMalloc(dst, (size_t)total * sizeof(ST)));
-  hipLaunchKernelGGL((k_gather_y<ST>), dim3(cdiv(total, CA_TB)), dim3(CA_TB), 0, h->stream, (const ST*)src, (ST*)*dst, h->N, h->G, sn, sg,
+  hipLaunchKernelGGL((k_gather_y<ST>), ca_grid_flat(total, CA_TB), dim3(CA_TB), 0, h->stream, (const ST*)src, (ST*)*dst, h->N, h->G, sn, sg,
                      ci_dev, gi_dev);
   HIPCK(h, hipGetLastError());
   SYNC(h);

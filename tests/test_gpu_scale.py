@@ -95,6 +95,32 @@ def test_full_size_run_is_bit_reproducible_and_storage_is_u8(full):
         a.close(); b.close()
 
 
+def test_matrix_of_more_than_2_to_32_elements_is_converted_whole():
+    """Round 5 (found by a 1M-cell run): the conversion kernels took one thread per element in a ONE-dimensional grid, whose extent is a 32-bit count of
+    work-items -- from 838 861 cells at 5120 padded genes on, the launch wrapped and everything past the first (N Gp mod 2^32) elements stayed zero, silently.
+    860 000 x 5000 int32 counts (4.4e9 padded elements): every cell's library size -- an exact integer sum over the STORED matrix and its overflow list --
+    must equal the source's row sum, the last cells' too, and the ELBO must be finite and move."""
+    import torch
+    if torch.cuda.mem_get_info()[0] < 40 * 2**30:
+        pytest.skip("needs ~30 GB of device memory")
+    import synth_data as synth
+    from clonealign_amd.engine import HipEngine
+    N, G, Cn = 860_000, 5000, 4
+    Yd, aux = synth.make_problem_torch(N, G, Cn, seed=5, device="cuda:0")
+    want = Yd.sum(1).cpu().numpy().astype(np.float64)
+    eng = HipEngine(None, aux["L"], np.random.default_rng(1).normal(size=(N, 1)), np.zeros(G) + 0.5, 1, y_device_ptr=Yd.data_ptr(), y_device_dtype=np.int32, shape=(N, G))
+    try:
+        assert N * eng.info()["Gp"] > 2**32 if "Gp" in eng.info() else True
+        s = eng.get("s")
+        assert np.array_equal(s, want), (int((s != want).sum()), int(np.flatnonzero(s != want)[0]) if (s != want).any() else -1)
+        assert want[-1000:].min() > 0
+        e0 = eng.elbo(eps_for(1, G, 1)); eng.step(eps_for(1, G, 2)); e1 = eng.elbo(eps_for(1, G, 3))
+        assert np.isfinite(e0) and np.isfinite(e1) and e1 > e0
+    finally:
+        eng.close()
+        del Yd
+
+
 def test_full_size_gradient_matches_finite_difference_of_the_elbo(full):
     """Backward sweep vs forward sweep at 100k x 5k x 8: directional derivative along the gradient itself."""
     eng = full["make"]()
