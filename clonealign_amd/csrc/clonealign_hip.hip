@@ -2355,6 +2355,11 @@ int create_impl(ca_engine* h, const ca_problem* p) {
     CACK(dalloc(h, &h->gene_partB_alt, (int64_t)h->ngblk * (3 + K)));
     if (!h->fwd_cell) CACK(dalloc(h, &h->Zpart2, (int64_t)zsplit * Nn * h->frow));   // k_fwd_cell keeps Z in the block
   }
+  // The side stream accompanies the cell-kernel path only.  Round 5, found by a parity run at 150k cells x 18 clones: with the plain passes (more than sixteen
+  // clones, D >= 3, K = 0 ...) the loop's pipelining (deferred monitor tail, prologue hand-over, gated update) and the side stream's deferred start are not ordered
+  // against each other -- ca_run's ELBOs from the second iteration on were wrong by 1e-4 ... 1e-1 and differed from run to run, silently, from 4e7 counts up
+  // (below that the Y pass runs in line; the suite's side-stream cases all take the cell kernel).  Those shapes run the Y pass in line at every size.
+  if (!h->fwd_cell) h->async_y = false;
   if (verbose(h))
     fprintf(stderr, "[clonealign_hip] N=%lld G=%d C=%d D=%d n_cu=%d gsplit=%d gchunk=%d csplit=%d fused=%d fwd_mfma=%d fsplit=%d fkchunk=%d "
             "bwd_mfma=%d csplit_m=%d cchunk_m=%lld nwt=%d fwd_cell=%d fc_tl=%d fc_nbig=%d ncblk_f=%d ystore=%d async_y=%d\n", (long long)Nn, G, C, D, h->n_cu, h->gsplit,

@@ -121,6 +121,40 @@ def test_matrix_of_more_than_2_to_32_elements_is_converted_whole():
         del Yd
 
 
+@pytest.mark.parametrize("shape", [dict(C=18, K=1), dict(C=4, K=2, P=1), dict(C=5, K=0), dict(C=4, K=1, S=3)], ids=["18clones", "d3", "k0", "s3"])
+def test_plain_pass_shapes_above_the_side_stream_threshold_match_the_oracle(shape):
+    """Round 5 (found by a parity run at 150k cells x 18 clones): from 4e7 counts up the Y products went to a side stream, and with the PLAIN passes (more than
+    sixteen clones, D >= 3, K = 0, mc_samples > 2: no cell kernel) that stream's deferred start was not ordered against ca_run's pipelining -- the ELBOs from the
+    second iteration on were wrong by 1e-4 ... 1e-1, differently from run to run, while every call-by-call check and every smaller test passed.  Whole loops
+    (ca_run, four iterations) on 9000 x 5000 counts against the float64 oracle, and twice to the same bits."""
+    from clonealign_amd.engine import HipEngine
+    from clonealign_amd.inference import run_vi_loop
+    from clonealign_amd.rng import EpsStream
+    from oracle.fused_numpy import FusedModel
+    from tests._cases import make_case
+    S = shape.get("S", 1)
+    case = make_case(seed=91, N=9000, G=5000, **shape)
+    G = 5000
+    assert case["Y"].size >= 4e7
+    trs = []
+    for rep in range(2):
+        eng = HipEngine(**case)
+        try:
+            assert eng.info()["fwd_cell"] == 0
+            trs.append(np.asarray(eng.run(EpsStream(3, S, G), 4, 1e-12)))
+            st = eng.get_state()
+        finally:
+            eng.close()
+    assert np.array_equal(trs[0], trs[1]), (trs[0], trs[1])
+    ora = FusedModel(**case, dtype="float32")
+    to = np.asarray(run_vi_loop(ora, EpsStream(3, S, G), 4, 1e-12))
+    assert trs[0].shape == to.shape and np.abs(trs[0] - to).max() <= 1e-5 * np.abs(to).max(), (trs[0], to)
+    for n in ("W", "loc", "ls", "psi"):
+        b = np.asarray(getattr(ora, n), float)
+        if b.size:
+            assert np.abs(np.asarray(st[n], float) - b).max() <= 2e-3 * max(np.abs(b).max(), 1e-2), n
+
+
 def test_full_size_gradient_matches_finite_difference_of_the_elbo(full):
     """Backward sweep vs forward sweep at 100k x 5k x 8: directional derivative along the gradient itself."""
     eng = full["make"]()
