@@ -2461,6 +2461,10 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   h->ride_ys = h->y_ys && h->fused_ok && h->fwd_cell && (h->fc_tl == 6 || tl1_ok || (h->fc_tl == 2 && h->fc_nbig == 0)) &&
                variant_on(h, CA_VAR_Y_RIDE, "CA_Y_RIDE");
   h->yfin_split = h->ride_ys && h->bwd_mfma && h->tail_fuse && variant_on(h, CA_VAR_YFIN_RIDE, "CA_YFIN_RIDE");
+  // The int8 one-copy stream either rides or runs in line: as a launch of its own on the SIDE stream (variant y_ride off at 4e7 counts and more) its parameter
+  // images -- rewritten by the update launch -- are not ordered against that stream (tools/fuzz_large.py --wide: 22 165 x 4734 x 3, trace 6e-5 off).  Not a
+  // default path (1-byte storage with K = 1 rides); the side stream stays for the vector streams of 2- / 4-byte storage and K != 1, which the large runs confirm.
+  if (h->y_ys && !h->ride_ys) h->async_y = false;
   {   // balanced forward sweep (ca_fwdbal.hip.h): one to six whole tiles per CU, the int8 stream riding, eight clones at most, one latent dimension
     const int tiles = cdiv(Nn, 16), qb = tiles / std::max(h->n_cu, 1), rb = tiles - qb * h->n_cu;
     // ... and at least 96 k-steps of 32 genes: with eight waves per block a wave of cfg-2 (2000 genes, 63 k-steps) has eight k-steps, the two
