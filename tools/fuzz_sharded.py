@@ -35,8 +35,10 @@ class HostAllreduce:
         return fn
 
 
-n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 3)
+_a = [a for a in sys.argv[1:] if not a.startswith("--")]
+WIDE = "--wide" in sys.argv   # round 5: shards ABOVE the side-stream threshold (4e7 counts each), up to 20 clones, mc_samples up to 3
+n_cases = int(_a[0]) if len(_a) > 0 else 40
+rng = np.random.default_rng(int(_a[1]) if len(_a) > 1 else 3)
 fails = 0
 for it in range(n_cases):
     W = int(rng.choice([2, 2, 3]))
@@ -46,6 +48,11 @@ for it in range(n_cases):
     K = int(rng.choice([0, 1, 1, 2]))
     P = int(rng.choice([0, 0, 1])) if K > 0 else 0
     S = 1 if rng.random() < 0.85 else 2
+    if WIDE:
+        G = int(rng.integers(1500, 5200))
+        N = W * int(rng.integers(int(4.2e7 / G), int(7e7 / G)))
+        C = int(rng.choice([3, 8, 8, 12, 16, 18, 20]))
+        S = int(rng.choice([1, 1, 2, 3]))
     kw = dict(N=N, G=G, C=C, K=K, S=S)
     if P:
         kw["P"] = P
@@ -98,7 +105,9 @@ for it in range(n_cases):
                     why.append("rank %d replica of %s differs" % (r, n))
         if why:
             fails += 1
-            print("FAIL", kw, "W", W, "iters", n_iter, "|", "; ".join(why))
+            print("FAIL", kw, "W", W, "iters", n_iter, "|", "; ".join(why), flush=True)
+        elif WIDE:
+            print("ok  ", kw, "W", W, "iters", n_iter, flush=True)
     except Exception as exc:   # noqa: BLE001
         fails += 1
         print("ERROR", kw, "W", W, repr(exc))
