@@ -118,6 +118,17 @@ def test_matrix_of_more_than_2_to_32_elements_is_converted_whole():
         assert np.isfinite(e0) and np.isfinite(e1) and e1 > e0
     finally:
         eng.close()
+    # ... and the selection kernel (k_gather_y, same one-thread-per-element shape): all but a few rows and columns of the same raw matrix
+    ci = np.setdiff1d(np.arange(N, dtype=np.int64), np.array([3, N // 2, N - 2]))
+    gi = np.setdiff1d(np.arange(G, dtype=np.int32), np.array([0, 17, G - 1])).astype(np.int32)
+    assert ci.size * ((gi.size + 1023) // 1024 * 1024) > 2**32
+    want_sel = Yd[:, torch.as_tensor(gi.astype(np.int64), device="cuda:0")].sum(1)[torch.as_tensor(ci, device="cuda:0")].cpu().numpy().astype(np.float64)
+    eng = HipEngine(None, aux["L"][gi], np.random.default_rng(2).normal(size=(ci.size, 1)), np.zeros(gi.size) + 0.5, 1, y_device_ptr=Yd.data_ptr(), y_device_dtype=np.int32,
+                    shape=(N, G), cell_index=ci, gene_index=gi)
+    try:
+        assert np.array_equal(eng.get("s"), want_sel)
+    finally:
+        eng.close()
         del Yd
 
 
