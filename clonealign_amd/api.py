@@ -155,14 +155,16 @@ def clonealign(gene_expression_data, copy_number_data, max_iter=200, rel_tol=1e-
                cov=None, ref=None, fix_alpha=False, dtype="float32", saturate=True,
                saturation_threshold=6, K=None, mc_samples=1, verbose=True, initial_shrink=5,
                clone_call_probability=0.95, data_init_mu=True, *, seed=None, engine=None,
-               engine_opts=None, clone_names=None, allele_ref="cov", cell_index=None, gene_index=None, _reuse=None):
+               engine_opts=None, clone_names=None, allele_ref="cov", cell_index=None, gene_index=None, devices=None, _reuse=None):
     """Assign scRNA-seq cells to clones.  Arguments as R/clonealign.R:184-203.
 
     Keyword-only extras: ``allele_ref`` -- "cov" (default) reproduces the reference, which forwards ``ref = cov`` to
     inference_tflow (R/clonealign.R:271) so that the allele-specific term sees alt = 0; "ref" forwards the caller's ``ref``
     (the evident intent: an explicit opt-in, the default stays reference-identical).  ``cell_index`` / ``gene_index``: masks or
     index arrays from ``preprocess_for_clonealign(..., return_masks=True)``; the raw matrix is then fitted on that selection
-    without a filtered copy (``copy_number_data`` etc. are given for the selected genes / cells)."""
+    without a filtered copy (``copy_number_data`` etc. are given for the selected genes / cells).  ``devices``: HIP ordinals -- this ONE fit
+    cell-sharded over those devices of this process (forwarded untouched to ``inference_tflow``; ``run_clonealign(devices=)`` is the
+    other thing: independent restarts dealt over devices)."""
     if allele_ref not in ("cov", "ref"):
         raise ValueError("allele_ref must be 'cov' (reference behaviour) or 'ref'")
     Y, gene_names = _parse_expression(gene_expression_data)
@@ -206,7 +208,8 @@ def clonealign(gene_expression_data, copy_number_data, max_iter=200, rel_tol=1e-
                           dtype=dtype, saturate=saturate, saturation_threshold=saturation_threshold,
                           K=K, mc_samples=mc_samples, verbose=verbose, initial_shrink=initial_shrink,
                           data_init_mu=data_init_mu, gene_names=gene_names, seed=seed,
-                          engine=engine, engine_opts=engine_opts, post=_post, cell_index=sel_c, gene_index=sel_g, _reuse=_reuse)
+                          engine=engine, engine_opts=engine_opts, post=_post, cell_index=sel_c, gene_index=sel_g, devices=devices,
+                          _reuse=_reuse)
     res = ClonealignFit(res)
     res["clone"] = clone_assignment(res["ml_params"]["clone_probs"], clone_names,
                                     clone_call_probability)          # :283

@@ -153,6 +153,7 @@ struct ca_engine {
   double* elbo_dev = nullptr; int64_t elbo_cap = 0; double* terms_dev = nullptr;
   double* host_pinned = nullptr;  // 8 doubles
   bool ycache_valid = false, sums_global = false, sums_started = false;
+  std::vector<double> mu_part;   // sharded with loc0 = NULL: this rank's per-gene sums of y_ng / rowMeans(Y)_n, completed over all cells in setup_global_sums
   // fused two-eps sweep (monitor pass of iteration i + forward half of train pass i+1, same parameters)
   bool fused_ok = false, look_valid = false; int64_t look_slot = 0; int frow = 8;
   float *Mb2 = nullptr, *mu32B = nullptr, *Zpart2 = nullptr; double* gene_partB = nullptr;
@@ -905,6 +906,28 @@ int setup_global_sums(ca_engine* h) {
   CACK(allreduce(h, h->colsum, h->G));
   if (h->P > 0 && h->K > 0) CACK(allreduce(h, h->YtX, (int64_t)h->G * h->P));
   SYNC(h);
+  if (!h->mu_part.empty()) {
+    // loc0 = NULL on a shard (ABI 6): mu_guess_g = mean over ALL cells of y_ng / rowMeans(Y)_n (R/inference-tflow.R:220-235) -- the ranks' partial sums and
+    // cell counts are added here, then loc0 = safe_inverse_softplus(mu_guess) (:262, :6-11) exactly as create_impl does it for one handle
+    const int G = h->G;
+    std::vector<double> pack(h->mu_part);
+    pack.push_back((double)h->N);
+    HIPCK(h, hipMemcpyAsync(h->red, pack.data(), pack.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    CACK(allreduce(h, h->red, (int64_t)pack.size()));
+    HIPCK(h, hipMemcpyAsync(pack.data(), h->red, pack.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    SYNC(h);
+    std::vector<float> l0((size_t)G);
+    for (int g = 0; g < G; ++g) {
+      const double mu = pack[(size_t)g] / pack[(size_t)G];
+      l0[g] = (float)(std::log(1.0 - std::exp(-std::fabs(mu))) + std::max(mu, 0.0));
+    }
+    CACK(upload_f(h, h->loc, l0));
+    HIPCK(h, hipMemcpyAsync(h->loc_init, h->loc, (size_t)G * sizeof(float), hipMemcpyDeviceToDevice, h->stream));
+    HIPCK(h, hipMemsetAsync(h->red, 0, pack.size() * sizeof(double), h->stream));
+    CACK(refresh_derived(h));
+    SYNC(h);
+    h->mu_part.clear();
+  }
   h->sums_global = true;
   return CA_OK;
 }
@@ -1891,7 +1914,11 @@ int gather_y(ca_engine* h, const void* src, void** dst, int64_t sn, int64_t sg, 
 // Other source types have nothing to narrow and keep the runtime's own pageable copy, which runs at 98 % of the pinned rate on these boxes
 // (56.5 against 57.6 GB/s; the same bytes through this pipeline's memcpy threads measured SLOWER, 44 GB/s: profiles/r05_ingest.txt).
 struct ingest_result { bool inexact = false; };
-static int ingest_host_matrix(hipStream_t stream, std::string& err, const void* src, int64_t total, int src_dtype, void* dst_dev, ingest_result* res) {
+static int ingest_host_matrix(hipStream_t stream, std::string& err, const void* src, int64_t total, int src_dtype, void* dst_dev, ingest_result* res,
+                              int64_t seg_len = 0, int64_t src_ld = 0) {
+  // seg_len / src_ld (ABI 6, ca_problem.y_ld): the source is `total / seg_len` runs of seg_len contiguous elements, src_ld elements apart (a block of
+  // rows of a column-major matrix); the device copy is compact.  0 = one dense run.
+  if (seg_len <= 0 || src_ld == seg_len) { seg_len = total; src_ld = total; }
   const bool narrow = src_dtype == CA_F64;
   const size_t esz = src_dtype == CA_F64 ? 8 : (src_dtype == CA_F32 || src_dtype == CA_I32) ? 4 : src_dtype == CA_U16 ? 2 : 1;
   const size_t dsz = narrow ? 4 : esz;
@@ -1925,17 +1952,20 @@ static int ingest_host_matrix(hipStream_t stream, std::string& err, const void* 
     // slice t of the chunk (multiples of 4096 elements: whole pages of the source, so the threads' pieces do not share lines)
     const int64_t per = ((n + T - 1) / T + 4095) & ~(int64_t)4095;
     const int64_t a = std::min<int64_t>(n, (int64_t)t * per), z = std::min<int64_t>(n, a + per);
-    if (z > a) {
+    int bad = 0;
+    for (int64_t i = a; i < z;) {   // run by run of the source (one run when it is dense)
+      const int64_t lin = e0 + i, seg = lin / seg_len, off = lin - seg * seg_len, m = std::min<int64_t>(z - i, seg_len - off);
+      const int64_t s0 = seg * src_ld + off;
       if (narrow) {
-        const double* sp = reinterpret_cast<const double*>(src) + e0;
-        float* dp = reinterpret_cast<float*>(pin[b]);
-        int bad = 0;
-        for (int64_t i = a; i < z; ++i) { const double v = sp[i]; const float f = (float)v; dp[i] = f; bad |= ((double)f != v); }   // (NaN flags itself)
-        if (bad) inexact.store(1, std::memory_order_relaxed);
+        const double* sp = reinterpret_cast<const double*>(src) + s0;
+        float* dp = reinterpret_cast<float*>(pin[b]) + i;
+        for (int64_t j = 0; j < m; ++j) { const double v = sp[j]; const float f = (float)v; dp[j] = f; bad |= ((double)f != v); }   // (NaN flags itself)
       } else {
-        memcpy(reinterpret_cast<char*>(pin[b]) + (size_t)a * esz, reinterpret_cast<const char*>(src) + (size_t)(e0 + a) * esz, (size_t)(z - a) * esz);
+        memcpy(reinterpret_cast<char*>(pin[b]) + (size_t)i * esz, reinterpret_cast<const char*>(src) + (size_t)s0 * esz, (size_t)m * esz);
       }
+      i += m;
     }
+    if (bad) inexact.store(1, std::memory_order_relaxed);
     filled[(size_t)c].fetch_add(1, std::memory_order_release);
   };
   auto worker = [&](int t) {
@@ -1945,7 +1975,17 @@ static int ingest_host_matrix(hipStream_t stream, std::string& err, const void* 
     }
   };
   std::vector<std::thread> pool;
-  if (e == hipSuccess) for (int t = 1; t < T; ++t) pool.emplace_back(worker, t);
+  if (e == hipSuccess) {
+    try { for (int t = 1; t < T; ++t) pool.emplace_back(worker, t); }
+    catch (...) {   // thread limit of a restricted container: a std::system_error must not cross the C ABI -- stop cleanly
+      abort_all.store(1);
+      for (auto& th : pool) th.join();
+      for (int b = 0; b < NB; ++b) if (ev[b]) hipEventDestroy(ev[b]);
+      if (pin[0]) hipHostFree(pin[0]);
+      err = "upload of the count matrix: cannot start the host conversion threads";
+      return CA_ERR_NOMEM;
+    }
+  }
   int rc = CA_OK;
   if (e != hipSuccess) rc = fail("pinned staging buffers of the count matrix", e);
   // this thread is worker 0 of every chunk and the one that queues the copies; the other workers run ahead into the free buffers
@@ -1978,6 +2018,10 @@ int upload_y(ca_engine* h, const ca_problem* p) {
   const int64_t Gs = sel ? (int64_t)p->G_src : (int64_t)h->G;
   const int64_t total = Ns * Gs;
   size_t esz = p->y_dtype == CA_F64 ? 8 : (p->y_dtype == CA_F32 || p->y_dtype == CA_I32) ? 4 : p->y_dtype == CA_U16 ? 2 : 1;
+  // ABI 6: the source may be a block of a larger matrix (ca_problem.y_ld): `nrun` runs of `run` contiguous counts, `ld` counts apart
+  const int64_t run = p->layout == CA_COL_MAJOR ? Ns : Gs, nrun = p->layout == CA_COL_MAJOR ? Gs : Ns;
+  const int64_t ld = p->y_ld > 0 ? p->y_ld : run;
+  if (ld < run) { h->err = "y_ld is smaller than the matrix it strides over"; return CA_ERR_INVALID; }
   const void* src = p->Y;
   void* staging = nullptr;
   void* cut = nullptr;
@@ -1994,9 +2038,12 @@ int upload_y(ca_engine* h, const ca_problem* p) {
     }
     ingest_result ir;
     if (p->y_dtype == CA_F64) {
-      const int rci = ingest_host_matrix(h->stream, h->err, p->Y, total, p->y_dtype, staging, &ir);
+      int rci;
+      try { rci = ingest_host_matrix(h->stream, h->err, p->Y, total, p->y_dtype, staging, &ir, run, ld); }
+      catch (const std::exception& ex) { h->err = std::string("upload of the count matrix: ") + ex.what(); rci = CA_ERR_NOMEM; }   // (nothing unwinds through the C ABI)
       if (rci != CA_OK) { cleanup(); return rci; }
-    } else if (hipMemcpy(staging, p->Y, (size_t)total * esz, hipMemcpyHostToDevice) != hipSuccess) {
+    } else if ((ld == run ? hipMemcpy(staging, p->Y, (size_t)total * esz, hipMemcpyHostToDevice)
+                          : hipMemcpy2D(staging, (size_t)run * esz, p->Y, (size_t)ld * esz, (size_t)run * esz, (size_t)nrun, hipMemcpyHostToDevice)) != hipSuccess) {
       cleanup(); h->err = "upload of the count matrix failed"; return CA_ERR_HIP;
     }
     if (p->y_dtype == CA_F64) y_dtype = CA_F32;
@@ -2006,7 +2053,10 @@ int upload_y(ca_engine* h, const ca_problem* p) {
       hipFree(staging); staging = nullptr;
       const hipError_t e = hipMalloc(&staging, (size_t)total * 8);
       if (e != hipSuccess) { cleanup(); h->err = std::string("hipMalloc of the count matrix staging: ") + hipGetErrorString(e); return CA_ERR_NOMEM; }
-      if (hipMemcpy(staging, p->Y, (size_t)total * 8, hipMemcpyHostToDevice) != hipSuccess) { cleanup(); h->err = "upload of the count matrix failed"; return CA_ERR_HIP; }
+      if ((ld == run ? hipMemcpy(staging, p->Y, (size_t)total * 8, hipMemcpyHostToDevice)
+                     : hipMemcpy2D(staging, (size_t)run * 8, p->Y, (size_t)ld * 8, (size_t)run * 8, (size_t)nrun, hipMemcpyHostToDevice)) != hipSuccess) {
+        cleanup(); h->err = "upload of the count matrix failed"; return CA_ERR_HIP;
+      }
       y_dtype = CA_F64;
     } else if (ir.inexact) {
       // a double that is not exactly a float can only be an error: NaN / negative takes precedence, as in the scan below
@@ -2028,10 +2078,12 @@ int upload_y(ca_engine* h, const ca_problem* p) {
     }
     src = staging;
   }
-  int64_t sn = p->layout == CA_COL_MAJOR ? 1 : Gs;
-  int64_t sg = p->layout == CA_COL_MAJOR ? Ns : 1;
+  // strides of `src` as the kernels below see it: the staging copy of a host matrix is compact, a device matrix keeps its leading dimension
+  const int64_t ldd = p->y_on_device ? ld : run;
+  int64_t sn = p->layout == CA_COL_MAJOR ? 1 : ldd;
+  int64_t sg = p->layout == CA_COL_MAJOR ? ldd : 1;
   int rc = CA_OK;
-  if (sel) {
+  if (sel || (p->y_on_device && ld != run)) {   // (a strided device block is compacted the same way: the scan below walks a dense matrix)
     // selection lists: validated on the host (strictly increasing, in range), applied by a device gather into a compact
     // row-major copy of the source type -- the storage scan / conversion below then sees only the selected counts
     auto bad = [&](const char* m) { cleanup(); h->err = m; return CA_ERR_INVALID; };
@@ -2534,6 +2586,7 @@ int create_impl(ca_engine* h, const ca_problem* p) {
       for (int64_t e = 0; e < h->n_ovf; ++e)   // overflow list, fixed (cell, gene) order
         tmp[h->h_ocol[e]] += (double)h->h_oval[e] * (double)col[h->h_orow[e]];
       if (j >= cols) {
+        if (h->opt.world > 1) h->mu_part = tmp;   // a shard: the guess over ALL cells is completed when the transport is set (setup_global_sums)
         std::vector<float> l0((size_t)G);
         for (int g = 0; g < G; ++g) {
           const double mu = tmp[g] / (double)Nn;
@@ -2773,14 +2826,7 @@ int ca_abi_version(void) { return CA_ABI_VERSION; }
 #ifdef CA_LAB   // timing-lab builds only: readers of the block stamps (tools/lab/)
 #include "../../tools/lab/ca_lab_host.inc"
 #endif
-#ifndef CA_BUILD_ID
-#define CA_BUILD_ID "unknown"
-#endif
-#ifdef CA_LAB
-const char* ca_build_id(void) { return "lab-" CA_BUILD_ID; }   // never the tree's id: bench.py and the tests refuse a lab build
-#else
-const char* ca_build_id(void) { return CA_BUILD_ID; }
-#endif
+// (ca_build_id(): ca_build_id.cpp -- its own translation unit, so that the hash of ALL sources does not recompile this one)
 
 int ca_device_count(int32_t* n) {
   int c = 0;
@@ -2815,7 +2861,6 @@ int ca_create(const ca_problem* p, const ca_options* o, ca_handle* out) {
   const int D = p->K > 0 ? p->K + p->P : 0;
   if (D > 8) return bad("K + P > 8 not supported");
   if (!p->Y || !p->L) return bad("Y and L are required");
-  if (!p->loc0 && opt.world > 1) return bad("loc0 = NULL (data-driven initialisation on the device) needs all cells: pass loc0 when world > 1");
   if (p->K > 0 && !p->psi0) return bad("psi0 is required when K > 0");
   if (p->P > 0 && !p->X) return bad("X is required when P > 0");
   if (opt.world < 1 || opt.rank < 0 || opt.rank >= opt.world) return bad("bad rank/world");
@@ -2823,7 +2868,9 @@ int ca_create(const ca_problem* p, const ca_options* o, ca_handle* out) {
   ca_engine* h = new ca_engine();
   h->N = p->N; h->G = p->G; h->C = p->C; h->K = p->K; h->P = p->P; h->S = p->S; h->D = D;
   h->layout = p->layout; h->opt = opt; h->device = opt.device;
-  int rc = create_impl(h, p);
+  int rc;
+  try { rc = create_impl(h, p); }
+  catch (const std::exception& ex) { h->err = std::string("ca_create: ") + ex.what(); rc = CA_ERR_NOMEM; }   // (bad_alloc / system_error never cross the C ABI)
   if (rc != CA_OK) {
     g_last_error = h->err;
     ca_destroy(h);

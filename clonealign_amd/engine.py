@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libclonealign_hip.so")
 CA_OK = 0
 CA_ERR_NAN = 4
 CA_INTERRUPTED = 7
-CA_ABI_VERSION = 5
+CA_ABI_VERSION = 6
 P2P_HANDLE_BYTES = 128
 CA_F64, CA_F32, CA_I32, CA_U16, CA_U8 = 0, 1, 2, 3, 4
 CA_ROW_MAJOR, CA_COL_MAJOR = 0, 1
@@ -35,6 +35,10 @@ EXPORTS = (
     "ca_synchronize", "ca_stream_busy", "ca_comm_unique_id", "ca_comm_init", "ca_p2p_export", "ca_p2p_connect", "ca_p2p_commit", "ca_comm_benchmark", "ca_comm_selftest", "ca_set_host_allreduce", "ca_gamma_init", "ca_elbo", "ca_elbo_terms",
     "ca_step", "ca_gradients", "ca_run", "ca_run_ex", "ca_iterate", "ca_final_elbo", "ca_init_psi_pca", "ca_clone_gene_sums", "ca_get_param", "ca_set_param",
     "ca_get_gradient", "ca_reinit", "ca_get_kernel_times", "ca_reset_kernel_times", "ca_set_profile", "ca_eps_draw", "ca_allele_loglik", "ca_preprocess",
+    # ABI 6: one fit cell-sharded over several devices of one process
+    "ca_group_create", "ca_group_destroy", "ca_group_last_error", "ca_group_get_info", "ca_group_rank_handle", "ca_group_init_psi_pca", "ca_group_gamma_init",
+    "ca_group_elbo", "ca_group_step", "ca_group_run_ex", "ca_group_iterate", "ca_group_final_elbo", "ca_group_get_param", "ca_group_reinit",
+    "ca_group_clone_gene_sums",
 )
 
 
@@ -43,7 +47,8 @@ class CaProblem(C.Structure):
                 ("S", C.c_int32), ("layout", C.c_int32), ("y_dtype", C.c_int32), ("y_on_device", C.c_int32),
                 ("Y", C.c_void_p), ("L", C.c_void_p), ("psi0", C.c_void_p), ("loc0", C.c_void_p),
                 ("X", C.c_void_p), ("extra_loglik", C.c_void_p),
-                ("N_src", C.c_int64), ("G_src", C.c_int32), ("cell_index", C.c_void_p), ("gene_index", C.c_void_p)]
+                ("N_src", C.c_int64), ("G_src", C.c_int32), ("cell_index", C.c_void_p), ("gene_index", C.c_void_p),
+                ("y_ld", C.c_int64)]
 
 
 class CaOptions(C.Structure):
@@ -63,6 +68,11 @@ class CaInfo(C.Structure):
                 ("transport", C.c_int32), ("y_ride", C.c_int32), ("red_n", C.c_int64),
                 ("fwd_block_cells", C.c_int32), ("fwd_blocks_big", C.c_int32), ("fold_gsum", C.c_int32), ("yfin_split", C.c_int32),
                 ("update_merge", C.c_int32), ("fwd_balanced", C.c_int32)]
+
+
+class CaGroupInfo(C.Structure):
+    _fields_ = [("world", C.c_int32), ("transport", C.c_int32), ("p2p_status", C.c_int32), ("rccl_status", C.c_int32),
+                ("rebuilds", C.c_int32), ("selftest_rounds", C.c_int32), ("N", C.c_int64), ("note", C.c_char * 384)]
 
 
 class CaPreprocessParams(C.Structure):
@@ -92,8 +102,10 @@ def load_library(path=None):
     lib.ca_last_error.argtypes = [C.c_void_p]
     lib.ca_build_id.restype = C.c_char_p
     lib.ca_build_id.argtypes = []
+    lib.ca_group_last_error.restype = C.c_char_p
+    lib.ca_group_last_error.argtypes = [C.c_void_p]
     for name in EXPORTS:
-        if name not in ("ca_last_error", "ca_build_id"):
+        if name not in ("ca_last_error", "ca_build_id", "ca_group_last_error"):
             getattr(lib, name).restype = C.c_int
     lib.ca_device_count.argtypes = [C.POINTER(C.c_int32)]
     lib.ca_create.argtypes = [C.POINTER(CaProblem), C.POINTER(CaOptions), C.POINTER(C.c_void_p)]
@@ -135,6 +147,20 @@ def load_library(path=None):
                                   C.POINTER(CaPreprocessParams), C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p]
     lib.ca_allele_loglik.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32,
                                      C.c_void_p, C.c_char_p]
+    lib.ca_group_create.argtypes = [C.POINTER(CaProblem), C.POINTER(CaOptions), C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.ca_group_destroy.argtypes = [C.c_void_p]
+    lib.ca_group_get_info.argtypes = [C.c_void_p, C.POINTER(CaGroupInfo)]
+    lib.ca_group_rank_handle.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.ca_group_init_psi_pca.argtypes = lib.ca_init_psi_pca.argtypes
+    lib.ca_group_gamma_init.argtypes = lib.ca_gamma_init.argtypes
+    lib.ca_group_elbo.argtypes = lib.ca_elbo.argtypes
+    lib.ca_group_step.argtypes = lib.ca_step.argtypes
+    lib.ca_group_run_ex.argtypes = lib.ca_run_ex.argtypes
+    lib.ca_group_iterate.argtypes = lib.ca_iterate.argtypes
+    lib.ca_group_final_elbo.argtypes = lib.ca_final_elbo.argtypes
+    lib.ca_group_get_param.argtypes = lib.ca_get_param.argtypes
+    lib.ca_group_reinit.argtypes = lib.ca_reinit.argtypes
+    lib.ca_group_clone_gene_sums.argtypes = lib.ca_clone_gene_sums.argtypes
     # initialise this library's HIP runtime NOW: torch bundles its own, and whichever runtime is loaded first must also be
     # initialised first (loaded first but initialised second it reports "no ROCm-capable device is detected")
     lib.ca_device_count(None)
@@ -150,7 +176,7 @@ def device_count():
 
 
 _SOURCES = ("clonealign_amd/csrc/clonealign_hip.hip", "clonealign_amd/csrc/ca_kernels.hip.h", "clonealign_amd/csrc/ca_ymfma.hip.h", "clonealign_amd/csrc/ca_fwdbal.hip.h",
-            "clonealign_amd/csrc/philox_host.h", "include/clonealign_hip.h")
+            "clonealign_amd/csrc/philox_host.h", "include/clonealign_hip.h", "clonealign_amd/csrc/ca_group.cpp")
 
 
 def source_build_id():
@@ -209,6 +235,50 @@ class HipEngine:
         queued again afterwards (0 = 1000 us; ca_options).
         ``variant_off``: names from VARIANTS (or a bitmask) to switch off; ``variant_on``: names from VARIANTS_ON to switch on;
         ``tune``: {name from TUNE: value}."""
+        prob, opt = self._prepare(Y, L, psi0, loc0, K, S, X, extra_loglik, learning_rate, device, y_storage, seed, rank, world, profile,
+                                  y_device_ptr, y_device_dtype, shape, layout, cell_index, gene_index, variant_off, variant_on, tune, verbose,
+                                  comm_timeout_ms, gate_timeout_us)
+        rc = self.lib.ca_create(C.byref(prob), C.byref(opt), C.byref(self.h))
+        if rc != CA_OK:
+            msg = (self.lib.ca_last_error(None) or b"").decode()
+            self.h = C.c_void_p()
+            raise EngineError(rc, msg)
+        if world > 1:
+            if host_allreduce is not None:
+                # host_allreduce(np.ndarray float64 view) must sum the array in place over all ranks
+                def _cb(_user, buf, n, _f=host_allreduce):
+                    try:
+                        _f(np.ctypeslib.as_array(buf, shape=(n,)))
+                        return 0
+                    except Exception:          # never unwind through C
+                        import traceback
+                        traceback.print_exc()
+                        return 1
+                self._cb = HOST_ALLREDUCE_FN(_cb)
+                self._ck(self.lib.ca_set_host_allreduce(self.h, self._cb, None))
+            elif p2p_exchange is not None:
+                try:
+                    self._p2p_setup(p2p_exchange, world)
+                except BaseException:
+                    self.close()          # (frees the device resources now, not whenever the half-built object is collected)
+                    raise
+            elif comm_id is not None:
+                self._ck(self.lib.ca_comm_init(self.h, comm_id))
+            elif not defer_transport:   # (defer_transport: the caller brings the transport up itself -- _p2p_setup / comm_init)
+                raise ValueError("world > 1 needs p2p_exchange, comm_id (bytes from comm_unique_id(), broadcast from rank 0) "
+                                 "or host_allreduce")
+
+    # names of the C entry points this object drives (HipGroupEngine: the ca_group_* family on a group handle)
+    _PREFIX = "ca_"
+    _LAST_ERROR = "ca_last_error"
+
+    def _fn(self, name):
+        return getattr(self.lib, self._PREFIX + name)
+
+    def _prepare(self, Y, L, psi0, loc0, K, S, X, extra_loglik, learning_rate, device, y_storage, seed, rank, world, profile,
+                 y_device_ptr, y_device_dtype, shape, layout, cell_index, gene_index, variant_off, variant_on, tune, verbose,
+                 comm_timeout_ms, gate_timeout_us):
+        """The ca_problem / ca_options of the constructor's arguments (inputs kept alive on self)."""
         self.lib = load_library()
         self.h = C.c_void_p()
         if layout not in ("row", "col"):
@@ -270,35 +340,7 @@ class HipEngine:
                 opt.ride_pattern = (lambda a, b: (int(a) << 8) | int(b))(*str(v).split(":")) if ":" in str(v) else int(v)
             else:
                 opt.tune[TUNE[k]] = int(v)
-        rc = self.lib.ca_create(C.byref(prob), C.byref(opt), C.byref(self.h))
-        if rc != CA_OK:
-            msg = (self.lib.ca_last_error(None) or b"").decode()
-            self.h = C.c_void_p()
-            raise EngineError(rc, msg)
-        if world > 1:
-            if host_allreduce is not None:
-                # host_allreduce(np.ndarray float64 view) must sum the array in place over all ranks
-                def _cb(_user, buf, n, _f=host_allreduce):
-                    try:
-                        _f(np.ctypeslib.as_array(buf, shape=(n,)))
-                        return 0
-                    except Exception:          # never unwind through C
-                        import traceback
-                        traceback.print_exc()
-                        return 1
-                self._cb = HOST_ALLREDUCE_FN(_cb)
-                self._ck(self.lib.ca_set_host_allreduce(self.h, self._cb, None))
-            elif p2p_exchange is not None:
-                try:
-                    self._p2p_setup(p2p_exchange, world)
-                except BaseException:
-                    self.close()          # (frees the device resources now, not whenever the half-built object is collected)
-                    raise
-            elif comm_id is not None:
-                self._ck(self.lib.ca_comm_init(self.h, comm_id))
-            elif not defer_transport:   # (defer_transport: the caller brings the transport up itself -- _p2p_setup / comm_init)
-                raise ValueError("world > 1 needs p2p_exchange, comm_id (bytes from comm_unique_id(), broadcast from rank 0) "
-                                 "or host_allreduce")
+        return prob, opt
 
     def _p2p_setup(self, p2p_exchange, world):
         """Two-phase bring-up of the one-shot peer-to-peer all-reduce (include/clonealign_hip.h): export, all-gather the handles,
@@ -344,7 +386,7 @@ class HipEngine:
     # -------------------------------------------------------------- plumbing
     def _ck(self, rc):
         if rc != CA_OK:
-            raise EngineError(rc, (self.lib.ca_last_error(self.h) or b"").decode())
+            raise EngineError(rc, (getattr(self.lib, self._LAST_ERROR)(self.h) or b"").decode())
 
     def _eps(self, eps):
         if eps is None:
@@ -374,12 +416,12 @@ class HipEngine:
     # -------------------------------------------------------------- sess$run equivalents
     def gamma_init(self, eps):
         _k, p = self._eps(eps)
-        self._ck(self.lib.ca_gamma_init(self.h, p))
+        self._ck(self._fn("gamma_init")(self.h, p))
 
     def elbo(self, eps):
         _k, p = self._eps(eps)
         out = C.c_double()
-        self._ck(self.lib.ca_elbo(self.h, p, C.byref(out)))
+        self._ck(self._fn("elbo")(self.h, p, C.byref(out)))
         return out.value
 
     def elbo_terms(self, eps):
@@ -390,7 +432,7 @@ class HipEngine:
 
     def step(self, eps):
         _k, p = self._eps(eps)
-        self._ck(self.lib.ca_step(self.h, p))
+        self._ck(self._fn("step")(self.h, p))
 
     def gradients(self, eps):
         _k, p = self._eps(eps)
@@ -413,8 +455,8 @@ class HipEngine:
         cnt = C.c_int32()
         self.interrupted = False
         if poll is None:
-            rc = self.lib.ca_run(self.h, int(max_iter), float(rel_tol), p, n, trace.ctypes.data_as(C.c_void_p),
-                                 C.byref(cnt))
+            rc = self._fn("run_ex")(self.h, int(max_iter), float(rel_tol), p, n, trace.ctypes.data_as(C.c_void_p),
+                                    C.byref(cnt), POLL_FN(0), None)
         else:
             err = []
 
@@ -425,12 +467,12 @@ class HipEngine:
                     err.append(e)
                     return 1
             cb = POLL_FN(_cb)
-            rc = self.lib.ca_run_ex(self.h, int(max_iter), float(rel_tol), p, n, trace.ctypes.data_as(C.c_void_p),
+            rc = self._fn("run_ex")(self.h, int(max_iter), float(rel_tol), p, n, trace.ctypes.data_as(C.c_void_p),
                                     C.byref(cnt), cb, None)
             if err:
                 raise err[0]
         if rc == CA_ERR_NAN:
-            raise FloatingPointError((self.lib.ca_last_error(self.h) or b"").decode())
+            raise FloatingPointError((getattr(self.lib, self._LAST_ERROR)(self.h) or b"").decode())
         if rc == CA_INTERRUPTED:
             self.interrupted = True
         else:
@@ -442,13 +484,13 @@ class HipEngine:
     def iterate(self, n_iter, eps_stream=None, want_elbo=True):
         _k, p, n = self._stream(eps_stream, 2 * int(n_iter))
         out = C.c_double()
-        self._ck(self.lib.ca_iterate(self.h, int(n_iter), p, n, C.byref(out) if want_elbo else None))
+        self._ck(self._fn("iterate")(self.h, int(n_iter), p, n, C.byref(out) if want_elbo else None))
         return out.value
 
     def final_elbo(self, eps_stream, n_rep=20):
         _k, p, n = self._stream(eps_stream, int(n_rep))
         vals = np.zeros(int(n_rep), dtype=np.float64)
-        self._ck(self.lib.ca_final_elbo(self.h, int(n_rep), p, n, vals.ctypes.data_as(C.c_void_p), None, None))
+        self._ck(self._fn("final_elbo")(self.h, int(n_rep), p, n, vals.ctypes.data_as(C.c_void_p), None, None))
         return vals
 
     def pca_init(self, noise=None, n_iter=40, seed=0):
@@ -457,7 +499,7 @@ class HipEngine:
         nz = None if noise is None else np.require(np.asarray(noise, dtype=np.float64).reshape(self.N, self.K),
                                                    requirements=[self._order, "A"])
         if self.K > 0:
-            self._ck(self.lib.ca_init_psi_pca(self.h, None if nz is None else nz.ctypes.data_as(C.c_void_p), int(n_iter),
+            self._ck(self._fn("init_psi_pca")(self.h, None if nz is None else nz.ctypes.data_as(C.c_void_p), int(n_iter),
                                               int(seed) & 0xFFFFFFFFFFFFFFFF, out.ctypes.data_as(C.c_void_p)))
         return out
 
@@ -466,7 +508,7 @@ class HipEngine:
         ci = np.ascontiguousarray(np.asarray(clone_idx, dtype=np.int32).reshape(self.N))
         T = np.zeros((self.G, self.C), dtype=np.float64, order=self._order)
         Syy = np.zeros(self.G, dtype=np.float64)
-        self._ck(self.lib.ca_clone_gene_sums(self.h, ci.ctypes.data_as(C.c_void_p), T.ctypes.data_as(C.c_void_p),
+        self._ck(self._fn("clone_gene_sums")(self.h, ci.ctypes.data_as(C.c_void_p), T.ctypes.data_as(C.c_void_p),
                                              Syy.ctypes.data_as(C.c_void_p)))
         return T, Syy
 
@@ -493,7 +535,7 @@ class HipEngine:
         return out
 
     def get(self, name):
-        return self._get(self.lib.ca_get_param, name)
+        return self._get(self._fn("get_param"), name)
 
     def set(self, name, value):
         v = np.require(np.asarray(value, dtype=np.float64).reshape(self._shape(name)), requirements=[self._order, "A"])
@@ -507,7 +549,7 @@ class HipEngine:
         if self.K > 0:
             p0 = np.require(np.asarray(psi0, dtype=np.float64).reshape(self.N, self.K), requirements=[self._order, "A"])
         l0 = None if loc0 is None else np.ascontiguousarray(np.asarray(loc0, dtype=np.float64).reshape(self.G))
-        self._ck(self.lib.ca_reinit(self.h, None if p0 is None else p0.ctypes.data_as(C.c_void_p),
+        self._ck(self._fn("reinit")(self.h, None if p0 is None else p0.ctypes.data_as(C.c_void_p),
                                     None if l0 is None else l0.ctypes.data_as(C.c_void_p)))
 
     def get_params(self):
@@ -536,7 +578,7 @@ class HipEngine:
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
-            self.lib.ca_destroy(self.h)
+            self._fn("destroy")(self.h)
             self.h = C.c_void_p()
 
     def __del__(self):
@@ -544,6 +586,58 @@ class HipEngine:
             self.close()
         except Exception:
             pass
+
+
+class HipGroupEngine(HipEngine):
+    """ONE fit cell-sharded over several devices of this process (ca_group_*, include/clonealign_hip.h ABI 6): the engine behind
+    ``inference_tflow(..., devices=[...])``.  Same constructor arguments as :class:`HipEngine` for ALL cells, plus ``devices`` (HIP
+    ordinals in rank order; an ordinal may repeat on a one-GPU rig) and ``transport`` ("auto": peer-to-peer by address -> RCCL -> host
+    reduction between the rank threads, each after a known-answer test; or one of "p2p" / "rccl" / "host" to insist on it).  Every method returns
+    what the one-handle method returns for all cells.  Calls that have no group form (gradients, set, kernel_times ...) raise."""
+
+    _PREFIX = "ca_group_"
+    _LAST_ERROR = "ca_group_last_error"
+    _TRANSPORT = {"auto": 0, "rccl": 1, "host": 2, "p2p": 3}
+
+    def __init__(self, Y, L, psi0, loc0, K, S=1, X=None, extra_loglik=None, learning_rate=0.1, devices=(0,), transport="auto",
+                 y_storage="auto", seed=0x5EED5EED, profile=False, y_device_ptr=None, y_device_dtype=None, shape=None, layout="row",
+                 cell_index=None, gene_index=None, variant_off=(), variant_on=(), tune=None, verbose=False, comm_timeout_ms=0, gate_timeout_us=0):
+        prob, opt = self._prepare(Y, L, psi0, loc0, K, S, X, extra_loglik, learning_rate, 0, y_storage, seed, 0, 1, profile,
+                                  y_device_ptr, y_device_dtype, shape, layout, cell_index, gene_index, variant_off, variant_on, tune, verbose,
+                                  comm_timeout_ms, gate_timeout_us)
+        self.devices = [int(d) for d in devices]
+        dev = (C.c_int32 * len(self.devices))(*self.devices)
+        rc = self.lib.ca_group_create(C.byref(prob), C.byref(opt), dev, len(self.devices), self._TRANSPORT[transport], C.byref(self.h))
+        if rc != CA_OK:
+            msg = (self.lib.ca_group_last_error(None) or b"").decode()
+            self.h = C.c_void_p()
+            raise EngineError(rc, msg)
+
+    def group_info(self):
+        i = CaGroupInfo()
+        self._ck(self.lib.ca_group_get_info(self.h, C.byref(i)))
+        return {"world": i.world, "transport": i.transport, "transport_name": TRANSPORT_NAME.get(i.transport, "?"), "p2p_status": i.p2p_status,
+                "rccl_status": i.rccl_status, "rebuilds": i.rebuilds, "selftest_rounds": i.selftest_rounds, "N": i.N, "note": i.note.decode()}
+
+    def rank_info(self, rank):
+        """ca_get_info of one rank's engine (its shard's cells, its kernel picks)."""
+        h = C.c_void_p()
+        self._ck(self.lib.ca_group_rank_handle(self.h, int(rank), C.byref(h)))
+        i = CaInfo()
+        rc = self.lib.ca_get_info(h, C.byref(i))
+        if rc != CA_OK:
+            raise EngineError(rc, "ca_get_info")
+        return {f[0]: getattr(i, f[0]) for f in CaInfo._fields_} | {"y_storage_name": YSTORE_NAME[i.y_storage],
+                                                                    "transport_name": TRANSPORT_NAME.get(i.transport, "?")}
+
+    def info(self):
+        return self.rank_info(0) | {"N": self.N, "group": self.group_info()}
+
+    def _no(self, *a, **k):
+        raise NotImplementedError("not available on a device group (use the rank engines through rank_info / a single HipEngine)")
+
+    elbo_terms = gradients = set = kernel_times = set_profile = synchronize = stream_busy = _no
+    comm_init = comm_benchmark = comm_selftest = _no
 
 
 def eps_draw(seed, draw, n):

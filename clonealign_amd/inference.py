@@ -43,9 +43,9 @@ def sanitize_allele_info(V, clone_allele, cov, ref, N, C):
     assert ref.shape[1] == V and cov.shape[1] == V
 
 
-def _default_engine_factory():
-    from .engine import HipEngine  # fails loudly when the HIP library is missing
-    return HipEngine
+def _default_engine_factory(group=False):
+    from .engine import HipEngine, HipGroupEngine  # fails loudly when the HIP library is missing
+    return HipGroupEngine if group else HipEngine
 
 
 def run_vi_loop(eng, eps, max_iter, rel_tol, verbose=False):
@@ -79,7 +79,7 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
                     K=1, mc_samples=1, verbose=True, initial_shrink=5, data_init_mu=True,
                     *, gene_names=None, seed=None, engine=None, engine_opts=None,
                     psi_noise=None, eps_stream=None, psi_init="auto", post=None, allele_on="auto", cell_index=None,
-                    gene_index=None, _reuse=None):
+                    gene_index=None, devices=None, _reuse=None):
     """EM/VI inference on the MI355X engine.  Arguments as R/inference-tflow.R:71-89.
 
     Keyword-only extras (no reference counterpart): ``seed`` (replaces R's ``set.seed``
@@ -97,6 +97,11 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
     for the SELECTED genes / cells.  Above 4e6 selected counts the HIP engine takes the raw matrix and the index lists
     (``ca_problem.cell_index / gene_index``): no filtered copy of the matrix is made on the host, neither here nor for the gene
     filter of :117-124 (the reference copies in R: R/preprocess.R:141-147, R/inference-tflow.R:117-124).
+    ``devices``: HIP ordinals, e.g. ``range(8)`` -- ONE fit cell-sharded over these devices of this process (SURVEY.md section 8b/8e,
+    BASELINE configs[3]): rank r holds the cells ``sharding.cell_range(N, r, W)``, one worker thread and one engine handle per device,
+    joined by the first transport that passes its known-answer test (peer-to-peer by address -> RCCL -> host reduction;
+    ``engine_opts={"transport": ...}`` insists on one).  The return value is the one-device fit's for all cells (trace to the
+    grouping of the fp64 cell sums).  One ordinal, or None, is the plain single-device fit on that device.
     ``_reuse``: a dict owned by run_clonealign()'s restart loop (multirun.py).  The first fit leaves its prepared inputs and
     its engine in it; later fits on the SAME data and settings skip the host passes and the upload and restart the resident
     engine (``ca_reinit``).  The owner closes the engine.
@@ -111,6 +116,20 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
         raise NotImplementedError(
             "dtype='float64': the reference graph cannot be built for float64 "
             "(R/inference-tflow.R:323 divides a float64 tensor by tf$to_float(S)); only float32 is supported")
+    if devices is not None:
+        devices = [int(d) for d in devices]
+        if not devices:
+            raise ValueError("devices must name at least one device")
+        if engine is not None:
+            raise ValueError("devices selects the HIP engine's device group; it cannot be combined with engine=")
+        if int((engine_opts or {}).get("world", 1)) != 1:
+            raise ValueError("devices shards the fit inside this process; rank/world (one process per GPU) are the other way to shard")
+        engine_opts = dict(engine_opts or {})
+        if len(devices) == 1:
+            engine_opts["device"] = devices[0]
+            devices = None
+        else:
+            engine_opts["devices"] = devices
     cached = None if _reuse is None else _reuse.get("prep")
     if cached is None:
         Y_dat = np.asarray(Y_dat)
@@ -185,7 +204,7 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
             sanitize_allele_info(V, clone_allele, cov, ref, N, C)
             if allele_on in ("device", "auto") and engine is None and (allele_on == "device" or N * V > 200_000):
                 from .engine import allele_loglik                          # 12 lgamma per (variant, cell)
-                dev = int((engine_opts or {}).get("device", 0))
+                dev = int((engine_opts or {}).get("device", (devices or [0])[0]))
                 extra = allele_loglik(clone_allele, cov, ref, device=dev)  # [N,C]
             else:
                 alt = cov.T - ref.T
@@ -204,7 +223,7 @@ def inference_tflow(Y_dat, L_dat, max_iter=100, rel_tol=1e-5, learning_rate=0.1,
     # initialisation (:204-235)
     if psi_noise is None:
         psi_noise = rng.normal(0.0, 0.05, size=(K, N)).T if K > 0 else np.zeros((N, 0))  # column-major fill
-    Engine = engine if engine is not None else _default_engine_factory()
+    Engine = engine if engine is not None else _default_engine_factory(group=devices is not None)
     # a matrix that is cut on the device (decided on the size BEFORE the gene filter) takes both device-side initialisations,
     # whatever is left after the filter: the filtered copy does not exist on the host
     big = N * G > 4_000_000 or device_cut

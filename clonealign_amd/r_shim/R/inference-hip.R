@@ -22,6 +22,11 @@
 #      * no per-iteration progress bar: the loop runs inside the library (it polls R_CheckUserInterrupt() every iteration, so
 #        Ctrl-C works as in the R-level loop of :394-417).
 #      * fix_alpha and initial_shrink are accepted and not used -- as in the reference, which never reads them either.
+#      * `devices` (a 20th, trailing argument; default options(clonealign.devices), else device 0): HIP device ordinals.  More than
+#        one -- options(clonealign.devices = 0:7), which reaches this function through clonealign() and run_clonealign() without
+#        touching either (R/clonealign.R:262-280 passes a fixed argument list) -- makes this ONE fit cell-sharded over those
+#        devices inside the .Call: cells [N r / W, N (r + 1) / W) on device r, one all-reduce of the per-gene sums per iteration
+#        (SURVEY.md section 8e).  Inputs and outputs are unchanged: whole matrices in, whole matrices out.
 inference_tflow <- function(Y_dat,
                             L_dat,
                             max_iter = 100,
@@ -40,7 +45,8 @@ inference_tflow <- function(Y_dat,
                             mc_samples = 1,
                             verbose = TRUE,
                             initial_shrink = 5,
-                            data_init_mu = TRUE) {
+                            data_init_mu = TRUE,
+                            devices = getOption("clonealign.devices", 0L)) {
   say <- function(...) if (verbose) message(...)
   say("Constructing HIP engine inputs")
   dtype <- match.arg(dtype)
@@ -124,7 +130,7 @@ inference_tflow <- function(Y_dat,
   n_draws <- 2L + 2L * as.integer(max_iter) + 20L                          # 1 gamma init + 1 initial ELBO + 2 per iteration + 20 final
   eps <- rnorm(n_draws * S * G)
   res <- .Call("C_clonealign_fit", Y_dat, L_dat, pcs, pcs_noise, loc0, x, v_log_prob, K, S, as.integer(max_iter), as.numeric(rel_tol),
-               as.numeric(learning_rate), eps, PACKAGE = "clonealign")
+               as.numeric(learning_rate), eps, as.integer(devices), PACKAGE = "clonealign")
   say("\nELBO converged or reached max iterations")
 
   # fetches in the reference's order, then the reference's naming (:424-434,465-473) -- including its quirk: with covariates and

@@ -9,7 +9,7 @@
  * (sess$close): everything before (gene filter, saturate, PCA / mu init) and after (naming, return list)
  * stays R code, unchanged.
  *
- *   .Call("C_clonealign_fit", Y, L, psi0, psi_noise, loc0, X, extra, K, S, max_iter, rel_tol, learning_rate, eps)
+ *   .Call("C_clonealign_fit", Y, L, psi0, psi_noise, loc0, X, extra, K, S, max_iter, rel_tol, learning_rate, eps, devices)
  *     Y      numeric or integer matrix N x G (column-major, as R stores it)
  *     L      numeric matrix G x C;  loc0 G or NULL (device-side mu_guess, :220-235);  X N x P or NULL;  extra N x C or NULL
  *     psi0   N x K initial latent positions (pcs + noise, :204-208), or NULL: then psi is initialised ON THE DEVICE -- prcomp +
@@ -19,6 +19,7 @@
  *     eps    numeric vector of (2 + 2*max_iter + 20) * S * G standard normals drawn with rnorm() by the
  *            caller (so set.seed() controls the fit exactly as it does through get_next_seed(), :49-51),
  *            or NULL for the engine's built-in Philox stream
+ *     devices integer vector of HIP device ordinals (or NULL = device 0): more than one = this ONE fit cell-sharded over them
  *   returns list(mu, clone_probs, s, alpha, beta, psi, W, chi, elbo, final_elbos)
  */
 #define _GNU_SOURCE   /* pthread_timedjoin_np (C_clonealign_multifit) */
@@ -29,33 +30,38 @@
 #include <string.h>
 #include "clonealign_hip.h"
 
-static void fail(ca_handle h, const char* what) {
+static void fail(ca_group_handle g, const char* what) {
   char msg[512];
-  strncpy(msg, ca_last_error(h), sizeof(msg) - 1);
+  strncpy(msg, ca_group_last_error(g), sizeof(msg) - 1);
   msg[sizeof(msg) - 1] = 0;
-  ca_destroy(h);                       /* free device memory BEFORE the longjmp of Rf_error */
+  ca_group_destroy(g);                 /* free device memory (every rank's) BEFORE the longjmp of Rf_error */
   Rf_error("%s: %s", what, msg);
 }
 
-/* The reference's loop is R-level and can be interrupted every iteration (R/inference-tflow.R:394-417).  ca_run_ex() calls
- * this between iterations; R_CheckUserInterrupt() may longjmp, so it runs inside R_ToplevelExec() and never unwinds through
- * the library: a pending interrupt makes the loop stop cleanly (CA_INTERRUPTED), the handle is freed, then R is told. */
+/* The reference's loop is R-level and can be interrupted every iteration (R/inference-tflow.R:394-417).  ca_group_run_ex() calls
+ * this between iterations ON THE CALLING THREAD (rank 0 of the device group is driven by it; the other ranks follow its decision);
+ * R_CheckUserInterrupt() may longjmp, so it runs inside R_ToplevelExec() and never unwinds through the library: a pending interrupt
+ * makes the loop stop cleanly (CA_INTERRUPTED), the engines are freed, then R is told. */
 static void check_interrupt(void* unused) { (void)unused; R_CheckUserInterrupt(); }
 static int poll_interrupt(void* user, int32_t iter, double elbo) {
   (void)user; (void)iter; (void)elbo;
   return R_ToplevelExec(check_interrupt, NULL) == FALSE;
 }
 
-static SEXP fetch(ca_handle h, const char* name, R_xlen_t nrow, R_xlen_t ncol) {
+static SEXP fetch(ca_group_handle g, const char* name, R_xlen_t nrow, R_xlen_t ncol) {
   SEXP out = PROTECT(ncol < 0 ? Rf_allocVector(REALSXP, nrow) : Rf_allocMatrix(REALSXP, nrow, ncol));
   memset(REAL(out), 0, sizeof(double) * XLENGTH(out));
-  if (XLENGTH(out) > 0 && ca_get_param(h, name, REAL(out)) != CA_OK) { UNPROTECT(1); fail(h, name); }
+  if (XLENGTH(out) > 0 && ca_group_get_param(g, name, REAL(out)) != CA_OK) { UNPROTECT(1); fail(g, name); }
   UNPROTECT(1);
   return out;
 }
 
+/* `devices` (integer vector of HIP ordinals; ABI 6): ONE fit cell-sharded over these devices of this R session -- rank r holds the
+ * cells [N r / W, N (r + 1) / W), one engine handle and one host thread per device (ca_group_*), joined by the first transport that
+ * passes its known-answer test (peer-to-peer by address -> RCCL -> host reduction).  A single ordinal is the plain one-device fit.
+ * Everything R sees is as before: inputs for all cells, outputs for all cells, column-major. */
 SEXP C_clonealign_fit(SEXP Y, SEXP L, SEXP psi0, SEXP psi_noise, SEXP loc0, SEXP X, SEXP extra, SEXP K_, SEXP S_, SEXP max_iter_,
-                      SEXP rel_tol_, SEXP lr_, SEXP eps_) {
+                      SEXP rel_tol_, SEXP lr_, SEXP eps_, SEXP devices_) {
   ca_problem p;
   memset(&p, 0, sizeof(p));
   p.N = Rf_nrows(Y); p.G = Rf_ncols(Y); p.C = Rf_ncols(L);
@@ -71,34 +77,38 @@ SEXP C_clonealign_fit(SEXP Y, SEXP L, SEXP psi0, SEXP psi_noise, SEXP loc0, SEXP
     memset(psi_zero, 0, sizeof(double) * (size_t)p.N * (size_t)p.K);
   }
   p.L = REAL(L); p.psi0 = p.K > 0 ? (device_pca ? psi_zero : REAL(psi0)) : NULL;
-  p.loc0 = Rf_isNull(loc0) ? NULL : REAL(loc0);   /* NULL: data_init_mu = TRUE guess (:220-235) taken on the device */
+  p.loc0 = Rf_isNull(loc0) ? NULL : REAL(loc0);   /* NULL: data_init_mu = TRUE guess (:220-235) taken on the device(s) */
   p.X = p.P > 0 ? REAL(X) : NULL;
   p.extra_loglik = Rf_isNull(extra) ? NULL : REAL(extra);
   ca_options o;
   ca_default_options(&o);
   o.learning_rate = Rf_asReal(lr_);
-  ca_handle h = NULL;
-  if (ca_create(&p, &o, &h) != CA_OK) Rf_error("clonealign_hip: %s", ca_last_error(NULL));
-  if (device_pca && ca_init_psi_pca(h, Rf_isNull(psi_noise) ? NULL : REAL(psi_noise), 40, o.seed, NULL) != CA_OK) fail(h, "ca_init_psi_pca");
+  int32_t one_device = 0;
+  const int n_dev = Rf_isNull(devices_) ? 1 : (int)XLENGTH(devices_);
+  if (n_dev < 1) Rf_error("clonealign_hip: devices must name at least one device");
+  const int32_t* devs = Rf_isNull(devices_) ? &one_device : (const int32_t*)INTEGER(devices_);
+  ca_group_handle h = NULL;
+  if (ca_group_create(&p, &o, devs, n_dev, 0, &h) != CA_OK) Rf_error("clonealign_hip: %s", ca_group_last_error(NULL));
+  if (device_pca && ca_group_init_psi_pca(h, Rf_isNull(psi_noise) ? NULL : REAL(psi_noise), 40, o.seed, NULL) != CA_OK) fail(h, "ca_init_psi_pca");
 
   const int max_iter = Rf_asInteger(max_iter_);
   const R_xlen_t per = (R_xlen_t)p.S * p.G, ndraw = 2 + 2 * (R_xlen_t)max_iter + 20;
   float* eps = NULL;
   if (!Rf_isNull(eps_)) {                                    /* rnorm() doubles -> float32 stream */
-    if (XLENGTH(eps_) < ndraw * per) { ca_destroy(h); Rf_error("eps stream too short"); }
+    if (XLENGTH(eps_) < ndraw * per) { ca_group_destroy(h); Rf_error("eps stream too short"); }
     eps = (float*)R_alloc((size_t)(ndraw * per), sizeof(float));
     for (R_xlen_t i = 0; i < ndraw * per; ++i) eps[i] = (float)REAL(eps_)[i];
   }
   SEXP elbo = PROTECT(Rf_allocVector(REALSXP, max_iter + 1));
   int n_elbo = 0;
   /* whole loop of :368-417 in the library, interruptible between iterations like the reference's R-level loop */
-  int rc = ca_run_ex(h, max_iter, Rf_asReal(rel_tol_), eps, eps ? ndraw : 0, REAL(elbo), &n_elbo, poll_interrupt, NULL);
-  if (rc == CA_INTERRUPTED) { UNPROTECT(1); ca_destroy(h); Rf_error("clonealign: interrupted"); }
+  int rc = ca_group_run_ex(h, max_iter, Rf_asReal(rel_tol_), eps, eps ? ndraw : 0, REAL(elbo), &n_elbo, poll_interrupt, NULL);
+  if (rc == CA_INTERRUPTED) { UNPROTECT(1); ca_group_destroy(h); Rf_error("clonealign: interrupted"); }
   if (rc == CA_ERR_NAN) { UNPROTECT(1); fail(h, "clonealign");  /* "Initial elbo is NA", :374-376 */ }
   if (rc != CA_OK) { UNPROTECT(1); fail(h, "ca_run"); }
   SEXP finals = PROTECT(Rf_allocVector(REALSXP, 20));        /* :447-449 */
   const R_xlen_t used = 2 * (R_xlen_t)n_elbo;
-  if (ca_final_elbo(h, 20, eps ? eps + used * per : NULL, eps ? ndraw - used : 0, REAL(finals), NULL, NULL) != CA_OK) {
+  if (ca_group_final_elbo(h, 20, eps ? eps + used * per : NULL, eps ? ndraw - used : 0, REAL(finals), NULL, NULL) != CA_OK) {
     UNPROTECT(2); fail(h, "ca_final_elbo");
   }
   const char* names[] = {"mu", "clone_probs", "s", "alpha", "beta", "psi", "W", "chi", "elbo", "final_elbos", ""};
@@ -113,7 +123,7 @@ SEXP C_clonealign_fit(SEXP Y, SEXP L, SEXP psi0, SEXP psi_noise, SEXP loc0, SEXP
   SET_VECTOR_ELT(out, 7, fetch(h, "chi", p.K, -1));
   SET_VECTOR_ELT(out, 8, Rf_xlengthgets(elbo, n_elbo));
   SET_VECTOR_ELT(out, 9, finals);
-  ca_destroy(h);                                             /* :457 sess$close() */
+  ca_group_destroy(h);                                       /* :457 sess$close() */
   UNPROTECT(3);
   return out;
 }

@@ -8,7 +8,7 @@
 #include <stddef.h>
 
 extern SEXP C_clonealign_fit(SEXP Y, SEXP L, SEXP psi0, SEXP psi_noise, SEXP loc0, SEXP X, SEXP extra, SEXP K, SEXP S, SEXP max_iter,
-                             SEXP rel_tol, SEXP learning_rate, SEXP eps);
+                             SEXP rel_tol, SEXP learning_rate, SEXP eps, SEXP devices);
 extern SEXP C_clonealign_multifit(SEXP Y, SEXP L, SEXP psi0, SEXP psi_noise, SEXP loc0, SEXP X, SEXP extra, SEXP K, SEXP S, SEXP max_iter,
                                   SEXP rel_tol, SEXP learning_rate, SEXP eps, SEXP devices, SEXP want_sums, SEXP call_prob);
 extern SEXP C_clonealign_preprocess(SEXP Y, SEXP L, SEXP min_gene, SEXP min_cell, SEXP outlying, SEXP nmads, SEXP max_cn, SEXP same_cn,
@@ -16,7 +16,7 @@ extern SEXP C_clonealign_preprocess(SEXP Y, SEXP L, SEXP min_gene, SEXP min_cell
 extern SEXP C_clonealign_allele_loglik(SEXP clone_allele, SEXP cov, SEXP ref, SEXP device);
 
 static const R_CallMethodDef CallEntries[] = {
-  {"C_clonealign_fit", (DL_FUNC)&C_clonealign_fit, 13},
+  {"C_clonealign_fit", (DL_FUNC)&C_clonealign_fit, 14},
   {"C_clonealign_multifit", (DL_FUNC)&C_clonealign_multifit, 16},
   {"C_clonealign_preprocess", (DL_FUNC)&C_clonealign_preprocess, 9},
   {"C_clonealign_allele_loglik", (DL_FUNC)&C_clonealign_allele_loglik, 4},

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CA_ABI_VERSION 5
+#define CA_ABI_VERSION 6
 
 typedef struct ca_engine* ca_handle;
 
@@ -61,7 +61,9 @@ typedef struct ca_problem {
   const double* L;     /* G x C copy number (:191) */
   const double* psi0;  /* N x K  (:204-208, `pcs`)   -- may be NULL when K == 0 */
   const double* loc0;  /* G      (:262, safe_inverse_softplus(mu_guess)); NULL = the data_init_mu = TRUE guess of :220-235
-                          computed from the resident matrix (single-shard problems only) */
+                          computed from the resident matrix.  Sharded (world > 1, ABI 6): every rank keeps its cells' part of the
+                          per-gene sums and the guess is completed over ALL cells by the first reduction of the transport the
+                          engine is given (ca_comm_init / ca_p2p_commit / ca_set_host_allreduce), before any pass can run */
   const double* X;     /* N x P covariates or NULL (:147-153) */
   const double* extra_loglik; /* N x C additive log-lik (allele term, :302-304) or NULL */
   /* Optional row / column selection of Y, so that the masks of ca_preprocess() (R/preprocess.R:141-147 returns filtered
@@ -73,6 +75,10 @@ typedef struct ca_problem {
   int32_t G_src;
   const int64_t* cell_index;  /* N entries or NULL */
   const int32_t* gene_index;  /* G entries or NULL */
+  /* ABI 6: leading dimension of Y in ELEMENTS, 0 = dense.  CA_COL_MAJOR: distance between two columns (>= the rows of the source
+   * matrix); CA_ROW_MAJOR: distance between two rows (>= its columns).  With it a block of ROWS of a column-major matrix -- what a
+   * shard of R's N x G matrix is -- is handed over in place (Y = &M[lo], y_ld = nrow(M)), and only that block crosses PCIe. */
+  int64_t y_ld;
 } ca_problem;
 
 /* Decomposition variants (bits of ca_options.variant_off: a set bit switches the variant OFF; 0 = the measured defaults).
@@ -169,8 +175,8 @@ typedef struct ca_options {
                                      * the update again after its decision (0 = 1000 us).  Not an error and not a result: only who waits for whom */
   int32_t reserved[2];
 } ca_options;
-/* (The same switches can be set from the environment -- CA_FUSED=0, CA_CSPLIT=12, ... -- but ONLY when
- *  CLONEALIGN_DEBUG_ENV is set: the library reads no configuration from the process environment otherwise.) */
+/* (The library reads no tuning from the process environment.  Only the timing-lab build, -DCA_LAB -- never the product's .so, its
+ *  ca_build_id() starts with "lab-" -- accepts the same switches as CA_* variables, and only when CLONEALIGN_DEBUG_ENV is set.) */
 
 typedef struct ca_info {
   int64_t N;
@@ -382,6 +388,56 @@ typedef struct ca_preprocess_params {
 int ca_preprocess(int64_t N, int32_t G, int32_t C, int32_t layout, int32_t y_dtype, int32_t y_on_device, const void* Y,
                   const double* L, const ca_preprocess_params* params, int32_t device, uint8_t* keep_gene,
                   uint8_t* keep_cell, double* gene_sums, double* cell_sums, char* err);
+
+/* ------------------------------------------------------------------------------------------------------------------------------
+ * ONE fit, cell-sharded over several devices of ONE process (ABI 6; SURVEY.md section 8b "multi-GPU via one process / 8 devices,
+ * communicator created per fit", section 8e).  The reference's caller is a single R session: inference_tflow() is called once
+ * (R/clonealign.R:262-280) and must come back with the whole fit.  A group holds one engine handle per entry of `devices`, rank r
+ * on the cells cell_range(N, r, W) = [N r / W, N (r + 1) / W) of the problem, each driven by its own host thread (rank 0 by the
+ * CALLING thread, so a poll hook runs where R's API may be used), joined by the first transport that passes the known-answer test
+ * (ca_comm_selftest) on every rank:
+ *     one-shot peer-to-peer by address (ca_p2p_*: the ranks' slabs are mapped by their own addresses, peer access between the
+ *     devices)  ->  RCCL (ncclCommInitRank from the W threads)  ->  a host reduction between the threads (always available).
+ * A transport that was committed and then failed its test leaves engines that cannot take another one: the group re-creates
+ * them (second upload) and moves on -- ca_group_info says what happened and why.  The fit is the single-handle fit up to the
+ * grouping of the fp64 cell sums; the ranks' replicated variables are bit-identical, and every call below returns what the
+ * one-handle call of the same name returns, for ALL cells (cell-indexed outputs are gathered in the problem's layout).
+ *
+ * problem: as for ca_create, holding ALL cells (host pointers; a device pointer only when every rank is on that device);
+ * loc0 = NULL and ca_group_init_psi_pca work sharded (sums completed over the transport).  opts: as for ca_create; device, rank and
+ * world are ignored.  devices: n_devices HIP ordinals, rank order; an ordinal may repeat (test rigs on one GPU: host transport, or
+ * peer-to-peer with CA_VARX_P2P_SAME_DEVICE).  transport: 0 = the chain above, or ONE ca_transport to insist on (error if it fails).
+ * Calls on one group are made from one thread at a time, always the same one. */
+typedef struct ca_group* ca_group_handle;
+typedef struct ca_group_info {
+  int32_t world;
+  int32_t transport;          /* ca_transport in use */
+  int32_t p2p_status;         /* 0 not tried, 1 in use, -1 set-up failed (no peer access, repeated device ...), -2 known-answer test failed */
+  int32_t rccl_status;        /* same */
+  int32_t rebuilds;           /* times the engines were created again after a committed transport failed */
+  int32_t selftest_rounds;    /* all-reduces of the known-answer test the transport in use passed */
+  int64_t N;                  /* all cells */
+  char note[384];             /* why transports were skipped, in words */
+} ca_group_info;
+int ca_group_create(const ca_problem* problem, const ca_options* opts, const int32_t* devices, int32_t n_devices, int32_t transport,
+                    ca_group_handle* out);
+int ca_group_destroy(ca_group_handle g);
+const char* ca_group_last_error(ca_group_handle g);   /* g may be NULL: the last failed ca_group_create on this thread */
+int ca_group_get_info(ca_group_handle g, ca_group_info* info);
+int ca_group_rank_handle(ca_group_handle g, int32_t rank, ca_handle* h);   /* read-only use (ca_get_info, ca_get_kernel_times ...) */
+/* the one-handle calls, collectively on every rank; eps arguments are shared by the ranks (every rank must see the same draws) */
+int ca_group_init_psi_pca(ca_group_handle g, const double* noise /* N x K, all cells, or NULL */, int32_t n_iter, uint64_t seed, double* pcs_out);
+int ca_group_gamma_init(ca_group_handle g, const float* eps);
+int ca_group_elbo(ca_group_handle g, const float* eps, double* elbo);
+int ca_group_step(ca_group_handle g, const float* eps);
+/* poll: called on the calling thread (rank 0's); its decision is handed to the other ranks, which wait for it at the same iteration */
+int ca_group_run_ex(ca_group_handle g, int32_t max_iter, double rel_tol, const float* eps_stream, int64_t n_draws, double* elbo_trace,
+                    int32_t* n_elbo, ca_poll_fn poll, void* user);
+int ca_group_iterate(ca_group_handle g, int32_t n_iter, const float* eps_stream, int64_t n_draws, double* last_elbo);
+int ca_group_final_elbo(ca_group_handle g, int32_t n_rep, const float* eps_stream, int64_t n_draws, double* values, double* mean, double* sd);
+int ca_group_get_param(ca_group_handle g, const char* name, double* out);
+int ca_group_reinit(ca_group_handle g, const double* psi0 /* N x K, all cells */, const double* loc0);
+int ca_group_clone_gene_sums(ca_group_handle g, const int32_t* clone_of_cell /* N, all cells */, double* T, double* Syy);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ def pytest_configure(config):
 
 # Order of the GPU suite under `pytest -x`: the oracle-parity evidence first, process plumbing last, so that one flaky
 # multi-process launch can never hide the numerical record (r03: test_gpu_multi stopped the run before parity was collected).
-_FILE_ORDER = ["test_gpu_parity.py", "test_gpu_scale.py", "test_gpu_boundary.py", "test_gpu_sharding.py", "test_gpu_multi.py"]
+_FILE_ORDER = ["test_gpu_parity.py", "test_gpu_scale.py", "test_gpu_boundary.py", "test_gpu_group.py", "test_gpu_sharding.py", "test_gpu_multi.py"]
 # inside test_gpu_scale.py the BASELINE.json configurations come first (cfg-2, cfg-3, cfg-5), then the rest in file order
 _SCALE_FIRST = ["test_cfg2_iterations_match_c_oracle", "test_fused_loop_at_shard_size_matches_c_oracle", "test_full_size_cfg3_matches_c_oracle",
                 "test_full_size_run_is_bit_reproducible_and_storage_is_u8", "test_full_size_gradient_matches_finite_difference_of_the_elbo",

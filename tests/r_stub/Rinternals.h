@@ -56,6 +56,9 @@ SEXP rstub_scalar_int(int v);
 SEXP rstub_scalar_real(double v);
 const char* rstub_name(SEXP list, R_xlen_t i);
 void rstub_free_all(void);
+void rstub_begin_call(void);                      /* arguments built: from here on every allocation collects (gctorture) */
+int rstub_violations(char* msg, int cap);         /* memory-rule violations seen since the last rstub_free_all (use of a collected object, UNPROTECT underflow) */
+int rstub_protect_depth(void);                    /* must be 0 when a .Call returns */
 extern int rstub_interrupt_after;   /* R_CheckUserInterrupt() "sees Ctrl-C" on its n-th call (0 = never) */
 #ifdef __cplusplus
 }

@@ -7,13 +7,49 @@
 #include "Rinternals.h"
 #include "R_ext/Utils.h"
 
+/* Round 6: the stub keeps R's two memory rules, so that the shim's PROTECT discipline is TESTED and not just compiled:
+ *   - a protect stack (Rf_protect / Rf_unprotect); a .Call must return with the depth it was entered with ("stack imbalance");
+ *   - "gctorture": EVERY allocation collects -- an object that is neither on the protect stack, nor an argument of the call (R protects
+ *     those), nor reachable from one of these through list elements, is dead: its payload is overwritten and any later access through
+ *     the API is recorded as a violation (rstub_violations()).  The object allocated last is alive until the next allocation, as in R.
+ * R_alloc memory lives until the call returns (R frees it then), also on the error path. */
 struct rstub_sexp {
   int type; R_xlen_t n; int nrow, ncol;   /* nrow = -1: plain vector */
   void* data; const char** names; struct rstub_sexp* next;
+  int is_arg, dead, mark;
 };
-static struct rstub_sexp nil_obj = {NILSXP, 0, -1, -1, NULL, NULL, NULL};
+static struct rstub_sexp nil_obj = {NILSXP, 0, -1, -1, NULL, NULL, NULL, 1, 0, 0};
+#define PSTACK_MAX 256
+static SEXP pstack[PSTACK_MAX]; static int pdepth = 0;
+static int args_phase = 1;          /* objects made by the harness before the call are the call's arguments */
+static int n_violations = 0; static char violation_msg[256];
+static void violation(const char* m) { if (!n_violations) { strncpy(violation_msg, m, sizeof(violation_msg) - 1); } ++n_violations; }
+static void mark_from(SEXP x) {
+  if (!x || x->mark) return;
+  x->mark = 1;
+  if (x->type == VECSXP) for (R_xlen_t i = 0; i < x->n; ++i) mark_from(((SEXP*)x->data)[i]);
+}
+static struct rstub_sexp* all_objs;
+static void collect(void) {          /* what R's collector would be entitled to do right now */
+  for (struct rstub_sexp* o = all_objs; o; o = o->next) o->mark = 0;
+  nil_obj.mark = 0;
+  for (int i = 0; i < pdepth; ++i) mark_from(pstack[i]);
+  for (struct rstub_sexp* o = all_objs; o; o = o->next) if (o->is_arg) mark_from(o);
+  for (struct rstub_sexp* o = all_objs; o; o = o->next)
+    if (!o->mark && !o->dead) {
+      const size_t esz = o->type == REALSXP ? sizeof(double) : (o->type == INTSXP || o->type == LGLSXP) ? sizeof(int) : sizeof(SEXP);
+      o->dead = 1;
+      if (o->type != VECSXP) memset(o->data, 0xA5, (size_t)(o->n > 0 ? o->n : 1) * esz);
+    }
+}
+static SEXP live(SEXP x, const char* what) { if (x && x->dead) violation(what); return x; }
+int rstub_violations(char* msg, int cap) {
+  if (msg && cap > 0) { strncpy(msg, n_violations ? violation_msg : "", (size_t)cap - 1); msg[cap - 1] = 0; }
+  return n_violations;
+}
+int rstub_protect_depth(void) { return pdepth; }
+void rstub_begin_call(void) { args_phase = 0; }   /* the harness has built the arguments; what is allocated from now on is the callee's */
 SEXP R_NilValue = &nil_obj;
-static struct rstub_sexp* all_objs = NULL;
 static void* all_ralloc[64]; static int n_ralloc = 0;
 int rstub_interrupt_after = 0;
 static int n_checks = 0;
@@ -21,7 +57,9 @@ jmp_buf rstub_error_jmp; int rstub_error_armed = 0; char rstub_error_msg[1024];
 static jmp_buf* toplevel_jmp = NULL;
 
 static SEXP mk(int type, R_xlen_t n, int nrow, int ncol) {
+  if (!args_phase) collect();
   struct rstub_sexp* s = (struct rstub_sexp*)calloc(1, sizeof(*s));
+  s->is_arg = args_phase;
   const size_t esz = type == REALSXP ? sizeof(double) : (type == INTSXP || type == LGLSXP) ? sizeof(int) : sizeof(SEXP);
   s->type = type; s->n = n; s->nrow = nrow; s->ncol = ncol;
   s->data = calloc((size_t)(n > 0 ? n : 1), esz);
@@ -34,10 +72,10 @@ int Rf_asInteger(SEXP x) { return x->type == INTSXP ? ((int*)x->data)[0] : (int)
 double Rf_asReal(SEXP x) { return x->type == INTSXP ? (double)((int*)x->data)[0] : ((double*)x->data)[0]; }
 int Rf_isNull(SEXP x) { return x == R_NilValue || x->type == NILSXP; }
 int Rf_isInteger(SEXP x) { return x->type == INTSXP; }
-double* REAL(SEXP x) { return (double*)x->data; }
-int* INTEGER(SEXP x) { return (int*)x->data; }
-int* LOGICAL(SEXP x) { return (int*)x->data; }
-R_xlen_t XLENGTH(SEXP x) { return x->n; }
+double* REAL(SEXP x) { return (double*)live(x, "REAL() of a collected object")->data; }
+int* INTEGER(SEXP x) { return (int*)live(x, "INTEGER() of a collected object")->data; }
+int* LOGICAL(SEXP x) { return (int*)live(x, "LOGICAL() of a collected object")->data; }
+R_xlen_t XLENGTH(SEXP x) { return live(x, "XLENGTH() of a collected object")->n; }
 SEXP Rf_allocVector(int type, R_xlen_t n) {
   SEXP s = mk(type, n, -1, -1);
   if (type == VECSXP) for (R_xlen_t i = 0; i < n; ++i) ((SEXP*)s->data)[i] = R_NilValue;
@@ -52,18 +90,27 @@ SEXP Rf_mkNamed(int type, const char** names) {
   for (R_xlen_t i = 0; i < n; ++i) ((SEXP*)s->data)[i] = R_NilValue;
   return s;
 }
-SEXP SET_VECTOR_ELT(SEXP x, R_xlen_t i, SEXP v) { ((SEXP*)x->data)[i] = v; return v; }
-SEXP VECTOR_ELT(SEXP x, R_xlen_t i) { return ((SEXP*)x->data)[i]; }
+SEXP SET_VECTOR_ELT(SEXP x, R_xlen_t i, SEXP v) { live(x, "SET_VECTOR_ELT() into a collected list"); live(v, "SET_VECTOR_ELT() of a collected object"); ((SEXP*)x->data)[i] = v; return v; }
+SEXP VECTOR_ELT(SEXP x, R_xlen_t i) { return ((SEXP*)live(x, "VECTOR_ELT() of a collected list")->data)[i]; }
 SEXP Rf_xlengthgets(SEXP x, R_xlen_t n) {
+  live(x, "Rf_xlengthgets() of a collected object");
+  const int was_arg = x->is_arg;
+  x->is_arg = 1;                       /* (R protects its argument for the duration of the call) */
   SEXP y = mk(x->type, n, -1, -1);
+  x->is_arg = was_arg;
   const size_t esz = x->type == REALSXP ? sizeof(double) : (x->type == INTSXP || x->type == LGLSXP) ? sizeof(int) : sizeof(SEXP);
   memcpy(y->data, x->data, (size_t)(n < x->n ? n : x->n) * esz);
   return y;
 }
-SEXP Rf_protect(SEXP x) { return x; }
-void Rf_unprotect(int n) { (void)n; }
+SEXP Rf_protect(SEXP x) {
+  live(x, "PROTECT() of an object that was already collected");
+  if (pdepth < PSTACK_MAX) pstack[pdepth++] = x; else violation("protect stack overflow");
+  return x;
+}
+void Rf_unprotect(int n) { if (n > pdepth) { violation("UNPROTECT() of more objects than are protected"); n = pdepth; } pdepth -= n; }
 void Rf_error(const char* fmt, ...) {
   va_list ap; va_start(ap, fmt); vsnprintf(rstub_error_msg, sizeof(rstub_error_msg), fmt, ap); va_end(ap);
+  pdepth = 0;                          /* R unwinds the protect stack to the context the error returns to */
   if (rstub_error_armed) longjmp(rstub_error_jmp, 1);
   fprintf(stderr, "Rf_error: %s\n", rstub_error_msg);
   abort();
@@ -103,4 +150,5 @@ void rstub_free_all(void) {
   while (all_objs) { struct rstub_sexp* nx = all_objs->next; free(all_objs->data); free(all_objs); all_objs = nx; }
   for (int i = 0; i < n_ralloc; ++i) free(all_ralloc[i]);
   n_ralloc = 0; n_checks = 0;
+  pdepth = 0; args_phase = 1; n_violations = 0;
 }

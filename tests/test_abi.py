@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), s
     assert set(syms) == set(engine.EXPORTS)
-    assert lib.ca_abi_version() == engine.CA_ABI_VERSION == 5
+    assert lib.ca_abi_version() == engine.CA_ABI_VERSION == 6
 
 
 PROBE = r"""
@@ -32,9 +32,10 @@ PROBE = r"""
 #include "clonealign_hip.h"
 #define F(T, f) printf(#T "." #f " %zu\n", offsetof(T, f))
 int main(void) {
-  printf("ca_problem %zu\nca_options %zu\nca_info %zu\nca_preprocess_params %zu\n", sizeof(ca_problem), sizeof(ca_options),
-         sizeof(ca_info), sizeof(ca_preprocess_params));
-  F(ca_problem, Y); F(ca_problem, extra_loglik); F(ca_problem, N_src); F(ca_problem, G_src); F(ca_problem, cell_index); F(ca_problem, gene_index);
+  printf("ca_problem %zu\nca_options %zu\nca_info %zu\nca_preprocess_params %zu\nca_group_info %zu\n", sizeof(ca_problem), sizeof(ca_options),
+         sizeof(ca_info), sizeof(ca_preprocess_params), sizeof(ca_group_info));
+  F(ca_problem, Y); F(ca_problem, extra_loglik); F(ca_problem, N_src); F(ca_problem, G_src); F(ca_problem, cell_index); F(ca_problem, gene_index); F(ca_problem, y_ld);
+  F(ca_group_info, transport); F(ca_group_info, rebuilds); F(ca_group_info, N); F(ca_group_info, note);
   F(ca_options, seed); F(ca_options, profile); F(ca_options, variant_off); F(ca_options, tune); F(ca_options, variant_on); F(ca_options, ride_pattern); F(ca_options, comm_timeout_ms); F(ca_options, gate_timeout_us); F(ca_options, reserved);
   F(ca_info, y_device_bytes); F(ca_info, fwd_cell); F(ca_info, y_mfma); F(ca_info, transport); F(ca_info, y_ride); F(ca_info, red_n); F(ca_info, fwd_block_cells); F(ca_info, yfin_split);
   printf("version %d\n", CA_ABI_VERSION);
@@ -53,7 +54,7 @@ def test_structs_match_the_header_as_the_c_compiler_lays_them_out(tmp_path):
     subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)])
     got = dict(line.rsplit(" ", 1) for line in subprocess.check_output([str(exe)], text=True).strip().splitlines())
     mirror = {"ca_problem": engine.CaProblem, "ca_options": engine.CaOptions, "ca_info": engine.CaInfo,
-              "ca_preprocess_params": engine.CaPreprocessParams}
+              "ca_preprocess_params": engine.CaPreprocessParams, "ca_group_info": engine.CaGroupInfo}
     for name, cls in mirror.items():
         assert int(got[name]) == ctypes.sizeof(cls), name
     for key, val in got.items():
@@ -97,7 +98,7 @@ def test_product_kernels_carry_no_switchable_wrong_answer_paths():
         assert "wrong results" not in src and "results WRONG" not in src, f
     hooks = open(os.path.join(ROOT, "tools", "lab", "ca_lab_hooks.inc")).read()
     assert "s_memrealtime" in hooks and "return;" not in hooks
-    assert 'return "lab-" CA_BUILD_ID' in open(os.path.join(ROOT, "clonealign_amd", "csrc", "clonealign_hip.hip")).read()
+    assert 'return "lab-" CA_BUILD_ID' in open(os.path.join(ROOT, "clonealign_amd", "csrc", "ca_build_id.cpp")).read()
 
 
 def test_create_fails_loudly_without_gpu_or_with_bad_args():

@@ -1,0 +1,329 @@
+"""ONE fit cell-sharded over several devices of ONE process, reached through the drop-in (SURVEY.md section 8b "one
+process / 8 devices", section 8e; BASELINE.json configs[3]).
+
+What runs here: the device group of include/clonealign_hip.h (ca_group_*, clonealign_amd/csrc/ca_group.cpp) through its three bindings --
+``HipGroupEngine`` (ctypes), ``inference_tflow(..., devices=)`` / ``clonealign(..., devices=)`` (the Python mirror of the R drop-in) and
+``C_clonealign_fit(..., devices)`` (the R shim's .Call, driven by the C harness).  A one-GPU box can only repeat an ordinal, ``devices=[0, 0]``:
+the ranks are then joined by the host reduction between the rank threads (the chain's last link; peer-to-peer and RCCL need one rank per
+device and are exercised by the two-GPU tests below, which skip here).  Everything else -- slicing R's column-major matrix in place (y_ld),
+sharded loc0 = NULL and device PCA, the followers of the poll hook, gathering -- is the code an 8-GPU node runs.
+
+Bars: replicas bit-identical (the group checks every rank's trace against rank 0's itself), ELBO trace within 3e-7 of the one-handle fit
+(another grouping of the fp64 cell sums), clone labels equal."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from tests import _golden
+from tests._cases import eps_for, label_flips, make_case
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _n_gpus():
+    import torch
+    return torch.cuda.device_count()
+
+
+def _close(a, b, tol):
+    return np.abs(np.asarray(a) - np.asarray(b)).max(initial=0) <= tol * max(np.abs(np.asarray(b)).max(initial=0), 1e-30)
+
+
+def _drive(eng, G, S, n_iter=8):
+    from clonealign_amd.rng import EpsStream
+    tr = eng.run(EpsStream(77, S, G), n_iter, 1e-12)
+    fin = eng.final_elbo(EpsStream(78, S, G), 4)
+    return np.asarray(tr), np.asarray(fin), eng.get_state(), eng.get_params()
+
+
+CASES = {
+    "k1": dict(N=1301, G=700, C=8, K=1),
+    "k2p1s2x": dict(N=260, G=90, C=4, K=2, P=1, S=2, extra=True),
+    "k0": dict(N=333, G=120, C=3, K=0),
+    "c12": dict(N=900, G=260, C=12, K=1),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("world", [2, 3])
+def test_group_on_one_device_equals_the_one_handle_fit(name, world):
+    from clonealign_amd.engine import HipEngine, HipGroupEngine
+    case = make_case(seed=31, **CASES[name])
+    G, S = case["Y"].shape[1], case["S"]
+    one = HipEngine(**case)
+    tr1, fin1, st1, p1 = _drive(one, G, S)
+    one.close()
+    grp = HipGroupEngine(**case, devices=[0] * world)
+    try:
+        gi = grp.group_info()
+        assert gi["world"] == world and gi["transport_name"] == "host" and gi["selftest_rounds"] >= 8, gi
+        assert "more than one rank" in gi["note"]          # why the device transports were not tried
+        los = [grp.rank_info(r)["N"] for r in range(world)]
+        assert sum(los) == case["Y"].shape[0] and max(los) - min(los) <= 1
+        trg, fing, stg, pg = _drive(grp, G, S)
+    finally:
+        grp.close()
+    assert trg.shape == tr1.shape and _close(trg, tr1, 3e-7), np.abs(trg - tr1).max() / np.abs(tr1).max()
+    assert _close(fing, fin1, 2e-6)
+    for n, v in st1.items():
+        assert stg[n].shape == v.shape and _close(stg[n], v, 5e-5), n
+    flips, _ = label_flips(pg["clone_probs"], p1["clone_probs"])
+    assert flips == 0
+    assert np.array_equal(pg["s"], p1["s"])
+
+
+@pytest.mark.parametrize("ydt", [np.float64, np.int32, np.uint8])
+def test_group_slices_a_column_major_matrix_in_place(ydt):
+    """R hands over ONE N x G column-major matrix; rank r's rows [lo, hi) are not contiguous in it.  ca_problem.y_ld (ABI 6) lets the shard
+    be taken in place -- only its block crosses PCIe (float64 through the narrowing ingest threads, other dtypes by a 2-D copy).  Same fit as
+    from the row-major matrix, bit for bit, for every source dtype."""
+    from clonealign_amd.engine import HipGroupEngine
+    case = make_case(seed=5, N=2311, G=333, C=5, K=1, P=1)
+    case["Y"] = np.minimum(case["Y"], 250).astype(ydt)
+    G, S = case["Y"].shape[1], case["S"]
+    out = {}
+    for lay in ("row", "col"):
+        grp = HipGroupEngine(**case, devices=[0, 0, 0], layout=lay)
+        try:
+            out[lay] = _drive(grp, G, S, 5)
+        finally:
+            grp.close()
+    assert np.array_equal(out["row"][0], out["col"][0]) and np.array_equal(out["row"][1], out["col"][1])
+    for n in out["row"][2]:
+        assert np.array_equal(out["row"][2][n], out["col"][2][n]), n
+
+
+def test_group_takes_row_and_column_selections_of_the_raw_matrix():
+    """cell_index / gene_index (the masks of preprocess_for_clonealign) on a group: every rank gets the rows of the RAW matrix between its first
+    and last selected cell, in place, and its own piece of the index list."""
+    from clonealign_amd.engine import HipEngine, HipGroupEngine
+    rng = np.random.default_rng(3)
+    case = make_case(seed=8, N=1500, G=400, C=4, K=1)
+    ci = np.sort(rng.choice(1500, 1100, replace=False)).astype(np.int64)
+    gi = np.sort(rng.choice(400, 310, replace=False)).astype(np.int32)
+    sub = dict(case, L=case["L"][gi], psi0=case["psi0"][ci], loc0=case["loc0"][gi])
+    cut = dict(sub, Y=case["Y"][np.ix_(ci, gi)])
+    one = HipEngine(**cut)
+    tr1, fin1, st1, p1 = _drive(one, 310, 1, 6)
+    one.close()
+    for lay in ("row", "col"):
+        grp = HipGroupEngine(**sub, devices=[0, 0], cell_index=ci, gene_index=gi, layout=lay)
+        try:
+            trg, fing, stg, pg = _drive(grp, 310, 1, 6)
+        finally:
+            grp.close()
+        assert _close(trg, tr1, 3e-7) and label_flips(pg["clone_probs"], p1["clone_probs"])[0] == 0
+
+
+def test_group_makes_both_initial_values_on_the_devices():
+    """loc0 = NULL (mu_guess of R/inference-tflow.R:220-235) and the PCA initialisation of :204-208 on a sharded fit: the per-gene sums of
+    y / rowMeans(y), the column statistics and the subspace iteration's products are completed over ALL cells through the group's transport.
+    Against the one-handle engine given the same (NULL) inputs: loc to float32 rounding, psi to 2e-4 up to nothing (one sign rule), same fit."""
+    from clonealign_amd.engine import HipEngine, HipGroupEngine
+    case = make_case(seed=13, N=2600, G=500, C=4, K=2)
+    case["loc0"] = None
+    noise = np.random.default_rng(1).normal(0, 0.05, size=(2600, 2))
+    one = HipEngine(**case)
+    pc1 = one.pca_init(noise, seed=4)
+    loc1, psi1 = one.get("loc"), one.get("psi")
+    tr1 = np.asarray(one.run(np.stack([eps_for(1, 500, i) for i in range(14)]), 6, 1e-12))
+    one.close()
+    grp = HipGroupEngine(**case, devices=[0, 0, 0])
+    try:
+        pcg = grp.pca_init(noise, seed=4)
+        locg, psig = grp.get("loc"), grp.get("psi")
+        trg = np.asarray(grp.run(np.stack([eps_for(1, 500, i) for i in range(14)]), 6, 1e-12))
+    finally:
+        grp.close()
+    assert _close(locg, loc1, 1e-6), np.abs(locg - loc1).max()
+    assert np.abs(pcg - pc1).max() <= 2e-4 and np.abs(psig - psi1).max() <= 2e-4, (np.abs(pcg - pc1).max(), np.abs(psig - psi1).max())
+    assert _close(trg, tr1, 1e-5)
+
+
+def test_poll_hook_of_a_group_runs_on_the_calling_thread_and_stops_every_rank():
+    import threading
+    from clonealign_amd.engine import HipEngine, HipGroupEngine
+    from clonealign_amd.rng import EpsStream
+    case = make_case(seed=2, N=900, G=200, C=3, K=1)
+    me = threading.get_ident()
+    seen = []
+
+    def hook(i, v):
+        seen.append((i, v, threading.get_ident()))
+        return i == 4
+    grp = HipGroupEngine(**case, devices=[0, 0])
+    one = HipEngine(**case)
+    try:
+        tr = grp.run(EpsStream(3, 1, 200), 30, 1e-12, poll=hook)
+        assert grp.interrupted and len(tr) == 5 and [s[0] for s in seen] == [0, 1, 2, 3, 4] and all(s[2] == me for s in seen)
+        assert np.array_equal(np.array([s[1] for s in seen]), tr)
+        # the variables are those after iteration 4 on EVERY rank: the same loop on one handle, stopped at the same place
+        tr1 = one.run(EpsStream(3, 1, 200), 30, 1e-12, poll=lambda i, v: i == 4)
+        assert _close(tr, tr1, 3e-7)
+        assert _close(grp.get("gamma_logits"), one.get("gamma_logits"), 5e-5) and _close(grp.get("W"), one.get("W"), 5e-5)
+        # and the group is alive: the next call works
+        assert np.isfinite(grp.final_elbo(EpsStream(9, 1, 200), 2)).all()
+    finally:
+        grp.close(); one.close()
+
+
+def test_a_rank_that_cannot_be_created_fails_the_group_with_its_message_and_nobody_waits():
+    import time
+    from clonealign_amd.engine import EngineError, HipGroupEngine
+    case = make_case(seed=4, N=600, G=100, C=3, K=1)
+    case["Y"][450, :] = -1.0                      # a negative count in rank 1's shard only
+    t0 = time.perf_counter()
+    with pytest.raises(EngineError) as ei:
+        HipGroupEngine(**case, devices=[0, 0])
+    assert "rank 1" in str(ei.value) and "negative or NaN" in str(ei.value), str(ei.value)
+    assert time.perf_counter() - t0 < 30
+    with pytest.raises(EngineError):              # a transport that cannot work here, insisted on: an error, not a fallback
+        HipGroupEngine(**make_case(seed=4, N=600, G=100, C=3, K=1), devices=[0, 0], transport="rccl")
+
+
+def test_nan_initial_elbo_comes_back_from_a_group_in_the_engines_words():
+    from clonealign_amd.engine import HipGroupEngine
+    from clonealign_amd.rng import EpsStream
+    case = make_case(seed=6, N=500, G=80, C=3, K=1)
+    case["L"][:, 1] = 0.0                         # a clone with copy number 0 everywhere a count is: gamma = 0, NaN ELBO
+    grp = HipGroupEngine(**case, devices=[0, 0])
+    try:
+        with pytest.raises(FloatingPointError, match="Initial elbo is NA"):
+            grp.run(EpsStream(1, 1, 80), 5, 1e-6)
+    finally:
+        grp.close()
+
+
+# ------------------------------------------------------------------------------------------------ through the drop-in
+def _hard_problem(name, seed=1):
+    import synth_data
+    return synth_data.make_problem(**{k: v for k, v in synth_data.CONFIGS[name].items()}, seed=seed)
+
+
+@pytest.mark.parametrize("cfg,max_iter", [("cfg2", 40), ("cfg3", 12)])
+def test_clonealign_with_devices_equals_clonealign_on_one_device(cfg, max_iter):
+    """``clonealign(Y, L, devices=[0, 0])`` against ``clonealign(Y, L)`` at BASELINE's cfg-2 (10k x 2k x 4) and at cfg-3's size (100k x 5k x 8):
+    same seed, device-side initial values on both (sharded loc0 = NULL and PCA on the group), ELBO trace within 3e-7, final ELBO, labels equal,
+    correlations (device sums over the group, ca_group_clone_gene_sums) to 1e-6."""
+    from clonealign_amd.api import clonealign
+    prob = _hard_problem(cfg)
+    kw = dict(max_iter=max_iter, rel_tol=1e-12, verbose=False, seed=17)
+    one = clonealign(prob["Y"], prob["L"], **kw)
+    two = clonealign(prob["Y"], prob["L"], devices=[0, 0], **kw)
+    t1, t2 = one["convergence_info"]["elbo"], two["convergence_info"]["elbo"]
+    assert t1.shape == t2.shape and _close(t2, t1, 3e-7), np.abs(t2 - t1).max() / np.abs(t1).max()
+    assert abs(two["convergence_info"]["final_elbo"] - one["convergence_info"]["final_elbo"]) <= 2e-6 * abs(one["convergence_info"]["final_elbo"])
+    assert np.array_equal(one["clone"], two["clone"])
+    for n in ("mu", "alpha", "W", "chi"):
+        assert _close(two["ml_params"][n], one["ml_params"][n], 1e-4), n
+    ok = ~np.isnan(one["correlations"])
+    assert np.array_equal(ok, ~np.isnan(two["correlations"])) and np.abs(two["correlations"][ok] - one["correlations"][ok]).max() <= 1e-6
+
+
+def test_inference_tflow_with_one_device_in_the_list_is_the_plain_fit():
+    from clonealign_amd.inference import inference_tflow
+    Y, L, *_ = _golden.example()
+    a = inference_tflow(Y, L, max_iter=15, verbose=False, seed=3)
+    b = inference_tflow(Y, L, max_iter=15, verbose=False, seed=3, devices=[0])
+    assert np.array_equal(a["convergence_info"]["elbo"], b["convergence_info"]["elbo"])
+    with pytest.raises(ValueError):
+        inference_tflow(Y, L, max_iter=2, verbose=False, devices=[])
+
+
+# ------------------------------------------------------------------------------------------------ through the R shim
+def _harness():
+    lib = C.CDLL(os.path.join(ROOT, "tests", "r_stub", "libshim_harness.so"))
+    lib.harness_fit_devices.restype = C.c_int
+    return lib
+
+
+def _call_shim_devices(lib, Y, L, psi0, loc0, K, S, max_iter, rel_tol, eps, devices, psi_noise=None, interrupt_after=0):
+    N, G = Y.shape
+    Cn = L.shape[1]
+    f = lambda a: None if a is None else np.asfortranarray(a, dtype=np.float64)  # noqa: E731
+    ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)          # noqa: E731
+    Yd = np.asfortranarray(Y, dtype=np.float64)
+    Lf, p0, pn = f(L), f(psi0), f(psi_noise)
+    l0 = None if loc0 is None else np.ascontiguousarray(loc0, dtype=np.float64)
+    ev = np.ascontiguousarray(eps, dtype=np.float64).reshape(-1)
+    dv = None if devices is None else np.ascontiguousarray(devices, dtype=np.int32)
+    out = dict(elbo=np.zeros(max_iter + 1), finals=np.zeros(20), mu=np.zeros(G), clone_probs=np.zeros((N, Cn), order="F"), s=np.zeros(N),
+               alpha=np.zeros(Cn), psi=np.zeros((N, K), order="F"), W=np.zeros((G, K), order="F"), chi=np.zeros(K), beta=np.zeros((G, 0), order="F"))
+    n_elbo = C.c_long()
+    err = C.create_string_buffer(1024)
+    rc = lib.harness_fit_devices(ptr(Yd), None, C.c_int(N), C.c_int(G), ptr(Lf), C.c_int(Cn), ptr(p0), ptr(pn), ptr(l0), None, C.c_int(0), None,
+                                 C.c_int(K), C.c_int(S), C.c_int(max_iter), C.c_double(rel_tol), C.c_double(0.1), ptr(ev), C.c_long(ev.size),
+                                 C.c_int(interrupt_after), ptr(out["elbo"]), C.byref(n_elbo), ptr(out["finals"]), ptr(out["mu"]), ptr(out["clone_probs"]),
+                                 ptr(out["s"]), ptr(out["alpha"]), ptr(out["psi"]), ptr(out["W"]), ptr(out["chi"]), ptr(out["beta"]), err,
+                                 ptr(dv), C.c_int(0 if dv is None else dv.size))
+    out["elbo"] = out["elbo"][:max(n_elbo.value, 0)]
+    return rc, err.value.decode(), out
+
+
+def test_r_shim_fit_over_a_device_group():
+    """C_clonealign_fit(..., devices = c(0L, 0L)) from C with column-major R-style inputs, initial values made on the devices (psi0 = NULL,
+    loc0 = NULL): the .Call a sharded inference_tflow() makes.  Same fit as devices = NULL (trace 3e-7, labels equal); the stub's protect
+    accounting and collect-at-every-allocation hold on the way (a violation would come back as "R memory rule: ...")."""
+    from clonealign_amd.api import clone_assignment
+    lib = _harness()
+    prob = _hard_problem("cfg2")
+    Y, L = prob["Y"][:3000, :600].astype(np.float64), prob["L"][:600]
+    keep = Y.sum(0) > 0
+    Y, L = Y[:, keep], L[keep]
+    Y[:, 0] += (Y.sum(1) == 0)
+    N, G = Y.shape
+    max_iter = 30
+    rng = np.random.default_rng(5)
+    noise = rng.normal(0, 0.05, size=(N, 1))
+    eps = rng.normal(size=(2 + 2 * max_iter + 20, G)).astype(np.float32)
+    rc1, m1, o1 = _call_shim_devices(lib, Y, L, None, None, 1, 1, max_iter, 1e-12, eps, None, psi_noise=noise)
+    assert rc1 == 0, m1
+    rc2, m2, o2 = _call_shim_devices(lib, Y, L, None, None, 1, 1, max_iter, 1e-12, eps, [0, 0], psi_noise=noise)
+    assert rc2 == 0, m2
+    assert len(o2["elbo"]) == max_iter + 1 and _close(o2["elbo"], o1["elbo"], 3e-7) and _close(o2["finals"], o1["finals"], 2e-6)
+    names = [f"c{i}" for i in range(L.shape[1])]
+    assert np.array_equal(clone_assignment(o1["clone_probs"], names), clone_assignment(o2["clone_probs"], names))
+    for n in ("mu", "alpha", "W", "psi"):
+        assert _close(o2[n], o1[n], 1e-4), n
+    # Ctrl-C in the middle of a sharded fit: every rank stops, the engines are freed, R gets its error
+    rc3, m3, _ = _call_shim_devices(lib, Y, L, None, None, 1, 1, max_iter, 1e-12, eps, [0, 0], psi_noise=noise, interrupt_after=7)
+    assert rc3 == 1 and "interrupted" in m3, m3
+    rc4, m4, o4 = _call_shim_devices(lib, Y, L, None, None, 1, 1, 3, 1e-12, eps[:28], [0, 0, 0], psi_noise=noise)
+    assert rc4 == 0 and len(o4["elbo"]) == 4, m4
+
+
+# ------------------------------------------------------------------------------------------------ two devices and more (skip on a one-GPU box)
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs: a device transport wants one rank per device")
+@pytest.mark.parametrize("transport", ["auto", "p2p", "rccl", "host"])
+def test_group_over_distinct_devices(transport):
+    """The first contact of the device group with real peers: W = min(#GPUs, 8) ranks, one per device.  "auto" must settle on a device transport
+    that passed its known-answer test (or say in its note why not); the fit is the one-handle fit."""
+    from clonealign_amd.engine import HipEngine, HipGroupEngine
+    W = min(_n_gpus(), 8)
+    case = make_case(seed=41, N=6000, G=800, C=6, K=1)
+    one = HipEngine(**case)
+    tr1, fin1, st1, p1 = _drive(one, 800, 1)
+    one.close()
+    grp = HipGroupEngine(**case, devices=list(range(W)), transport=transport, comm_timeout_ms=20000)
+    try:
+        gi = grp.group_info()
+        print("group over", W, "devices:", gi)
+        if transport != "auto":
+            assert gi["transport_name"] == transport
+        trg, fing, stg, pg = _drive(grp, 800, 1)
+    finally:
+        grp.close()
+    assert _close(trg, tr1, 3e-7) and label_flips(pg["clone_probs"], p1["clone_probs"])[0] == 0
+
+
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs")
+def test_clonealign_over_all_devices_at_cfg3():
+    from clonealign_amd.api import clonealign
+    prob = _hard_problem("cfg3")
+    kw = dict(max_iter=12, rel_tol=1e-12, verbose=False, seed=17)
+    one = clonealign(prob["Y"], prob["L"], **kw)
+    many = clonealign(prob["Y"], prob["L"], devices=list(range(min(_n_gpus(), 8))), **kw)
+    assert _close(many["convergence_info"]["elbo"], one["convergence_info"]["elbo"], 3e-7) and np.array_equal(one["clone"], many["clone"])

@@ -58,10 +58,55 @@ def test_shim_uses_the_column_major_boundary_and_the_interrupt_hook():
     src = open(SHIM).read()
     assert "p.layout = CA_COL_MAJOR" in src
     assert "ca_run_ex(" in src and "R_CheckUserInterrupt" in src and "R_ToplevelExec" in src
-    assert src.index("ca_destroy(h)") < src.index("Rf_error(\"%s: %s\"")     # device memory is freed before the longjmp
+    assert src.index("ca_group_destroy(g)") < src.index("Rf_error(\"%s: %s\"")     # device memory (every rank's) is freed before the longjmp
+    # round 6: the single fit goes through the device-group entry points (one device = a group of one), the hook runs on the R thread
+    assert "ca_group_create(&p, &o, devs, n_dev, 0, &h)" in src and "ca_group_run_ex(" in src and "poll_interrupt" in src
 
 
 def test_harness_links_against_the_engine_library():
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "tests", "r_stub")], stdout=subprocess.DEVNULL)
     lib = ctypes.CDLL(os.path.join(ROOT, "tests", "r_stub", "libshim_harness.so"))
     assert hasattr(lib, "harness_fit") and hasattr(lib, "C_clonealign_fit") and hasattr(lib, "R_init_clonealign")
+    assert hasattr(lib, "harness_fit_devices") and hasattr(lib, "rstub_violations") and hasattr(lib, "rstub_protect_depth")
+
+
+def test_the_r_stub_enforces_the_protect_rules_it_claims_to():
+    """Round 6: the stand-in R runtime collects at EVERY allocation and keeps a protect stack, so the shim's PROTECT discipline is
+    tested on the GPU box (tests/test_gpu_boundary.py), not only compiled.  Here, without a GPU, the stub itself is held to its word: an
+    unprotected object is dead after the next allocation and touching it is recorded; a protected one, and one reachable from a protected list,
+    survive; UNPROTECT underflow is recorded; the depth is what PROTECT / UNPROTECT left."""
+    prog = r'''
+#include <stdio.h>
+#include "Rinternals.h"
+int main(void) {
+  char m[256];
+  rstub_begin_call();
+  SEXP a = Rf_allocVector(REALSXP, 4);            /* never protected */
+  SEXP b = PROTECT(Rf_allocVector(REALSXP, 4));   /* this allocation collects a */
+  REAL(b)[0] = 1.0;
+  SEXP l = PROTECT(Rf_allocVector(VECSXP, 2));
+  SET_VECTOR_ELT(l, 0, Rf_allocVector(REALSXP, 3));   /* reachable from l as soon as it is stored */
+  SEXP c = Rf_allocVector(REALSXP, 2);
+  (void)c;
+  if (rstub_violations(m, 256) != 0) { printf("early violation: %s\n", m); return 1; }
+  REAL(VECTOR_ELT(l, 0))[0] = 2.0;
+  if (rstub_violations(m, 256) != 0) { printf("a reachable object was collected: %s\n", m); return 1; }
+  REAL(a)[0] = 3.0;                               /* use after collection */
+  if (rstub_violations(m, 256) != 1) { printf("use of a collected object went unnoticed\n"); return 1; }
+  if (rstub_protect_depth() != 2) { printf("depth %d\n", rstub_protect_depth()); return 1; }
+  UNPROTECT(2);
+  UNPROTECT(1);                                   /* underflow */
+  if (rstub_violations(m, 256) != 2 || rstub_protect_depth() != 0) { printf("underflow unnoticed\n"); return 1; }
+  rstub_free_all();
+  printf("ok\n");
+  return 0;
+}
+'''
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "t.c")
+        open(src, "w").write(prog)
+        exe = os.path.join(d, "t")
+        subprocess.check_call(["gcc", "-std=c11", "-I", os.path.join(ROOT, "tests", "r_stub"), "-o", exe, src, os.path.join(ROOT, "tests", "r_stub", "rstub.c")])
+        out = subprocess.run([exe], capture_output=True, text=True)
+        assert out.returncode == 0 and out.stdout.strip() == "ok", out.stdout + out.stderr
