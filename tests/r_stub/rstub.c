@@ -1,4 +1,5 @@
 /* Fake R runtime behind tests/r_stub/Rinternals.h (test infrastructure only). */
+#define _POSIX_C_SOURCE 200809L   /* strdup */
 #include <setjmp.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -86,7 +87,10 @@ SEXP Rf_mkNamed(int type, const char** names) {
   R_xlen_t n = 0;
   while (names[n][0]) ++n;
   SEXP s = mk(type, n, -1, -1);
-  s->names = names;
+  /* R copies the names into the object (the caller's array is usually a local of the .Call routine) */
+  const char** copy = (const char**)calloc((size_t)n + 1, sizeof(char*));
+  for (R_xlen_t i = 0; i < n; ++i) copy[i] = strdup(names[i]);
+  s->names = copy;
   for (R_xlen_t i = 0; i < n; ++i) ((SEXP*)s->data)[i] = R_NilValue;
   return s;
 }
@@ -147,7 +151,11 @@ SEXP rstub_scalar_int(int v) { SEXP s = Rf_allocVector(INTSXP, 1); ((int*)s->dat
 SEXP rstub_scalar_real(double v) { SEXP s = Rf_allocVector(REALSXP, 1); ((double*)s->data)[0] = v; return s; }
 const char* rstub_name(SEXP l, R_xlen_t i) { return l->names ? l->names[i] : ""; }
 void rstub_free_all(void) {
-  while (all_objs) { struct rstub_sexp* nx = all_objs->next; free(all_objs->data); free(all_objs); all_objs = nx; }
+  while (all_objs) {
+    struct rstub_sexp* nx = all_objs->next;
+    if (all_objs->names) { for (R_xlen_t i = 0; i < all_objs->n; ++i) free((void*)all_objs->names[i]); free((void*)all_objs->names); }
+    free(all_objs->data); free(all_objs); all_objs = nx;
+  }
   for (int i = 0; i < n_ralloc; ++i) free(all_ralloc[i]);
   n_ralloc = 0; n_checks = 0;
   pdepth = 0; args_phase = 1; n_violations = 0;
