@@ -223,6 +223,58 @@ def side_config(name, N, G, C, K=1, S=1, P=0, steps=200, regions=3, seed=20251, 
             "fwd_block_cells": int(info["fwd_block_cells"]), "update_merge": bool(info["update_merge"]), "final_elbo_finite": bool(np.isfinite(last))}
 
 
+def through_api(N, G, C, K, devices, steps, warmup, regions=3, seed=20243, transport="auto", budget_ms=60.0):
+    """ONE fit of the workload, cell-sharded over `devices` INSIDE THIS PROCESS -- the path the drop-in takes for
+    `inference_tflow(..., devices=)` / `C_clonealign_fit(..., devices)` (ca_group_*: one engine handle + one host thread per device, joined by
+    the first transport that passes its known-answer test: peer-to-peer by address -> RCCL -> host reduction).  The count matrix is handed
+    over from HOST memory as one N x G matrix, like R's; loc0 = NULL (the data-driven initial values are made on the devices, over all cells).
+    Times `regions` regions of `steps` ca_group_iterate iterations (median), after `warmup` iterations and ~budget_ms of pre-heat."""
+    import synth_data as synth
+    from clonealign_amd.engine import HipGroupEngine
+    prob = synth.make_problem(N, G, C, seed=seed)
+    Y = prob["Y"]
+    if Y.max() <= 255:
+        Y = Y.astype(np.uint8)
+    rng = np.random.default_rng(seed + 1)
+    psi0 = rng.normal(size=(N, K))
+    t0 = time.perf_counter()
+    grp = HipGroupEngine(Y, prob["L"], psi0, None, K, 1, devices=list(devices), transport=transport)
+    create_s = time.perf_counter() - t0
+    try:
+        gi = grp.group_info()
+        eps0 = rng.normal(size=(1, G)).astype(np.float32)
+        grp.gamma_init(eps0)
+        eps_w = rng.normal(size=(2 * max(warmup, 1), 1, G)).astype(np.float32)
+        grp.iterate(max(warmup, 1), eps_w)
+        eps_t = rng.normal(size=(2 * steps, 1, G)).astype(np.float32)
+        tb = time.perf_counter()
+        while (time.perf_counter() - tb) * 1e3 < budget_ms:
+            grp.iterate(steps, eps_t)
+        times, last = [], float("nan")
+        for _ in range(max(regions, 1)):
+            t1 = time.perf_counter()
+            last = grp.iterate(steps, eps_t)      # (returns after every rank has synchronised its stream and read its ELBO back)
+            times.append(time.perf_counter() - t1)
+        dt = float(np.median(times))
+        # the default fit through the same object, from its initial values: ca_group_run_ex (every rank's trace is compared with rank 0's
+        # inside the call: replicas out of step would be an error here) + 20 final ELBOs
+        grp.reinit(psi0, None)
+        t2 = time.perf_counter()
+        trace = grp.run(None, 200, 1e-6)
+        finals = grp.final_elbo(None, 20)
+        fit_s = time.perf_counter() - t2
+        shard = [int(grp.rank_info(r)["N"]) for r in range(len(devices))]
+        return {"value": steps / dt, "unit": "iterations/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "regions_ms_per_step": [t / steps * 1e3 for t in times],
+                "devices": [int(d) for d in devices], "transport": gi["transport_name"], "p2p_status": gi["p2p_status"], "rccl_status": gi["rccl_status"],
+                "rebuilds": gi["rebuilds"], "selftest_rounds": gi["selftest_rounds"], "note": gi["note"], "cells_per_rank": shard,
+                "create_seconds": create_s, "final_elbo": last, "finite": bool(np.isfinite(last)),
+                "fit_wallclock": {"seconds": fit_s, "iterations": int(len(trace) - 1), "final_elbo_mean": float(np.mean(finals))},
+                "what": "the same workload as ONE fit sharded over the devices inside one process (ca_group_*: what inference_tflow(devices=) and "
+                        "C_clonealign_fit(devices) run); host matrix in, loc0 made on the devices; regions timed on the host around ca_group_iterate"}
+    finally:
+        grp.close()
+
+
 def sq_fractions(build_id, kernel_class):
     """VALU-active and MFMA-busy fractions of a kernel class from the SQ counter pass committed under profiles/ for THIS build
     (profiles/*_sq_counters.json); None when there is none.  The fp32 roof is soft for kernels whose contraction runs as bf16 MFMAs
@@ -337,9 +389,47 @@ def main():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the 200-step regions of the other single-GPU BASELINE configurations (cfg-2, one cfg-5 restart, the 12.5k-cell shard) "
                          "and of the VALU fallback shapes that follow the headline measurement (single GPU only)")
+    ap.add_argument("--through-api", action="store_true",
+                    help="run the workload as ONE fit cell-sharded over --gpus devices INSIDE THIS PROCESS (the device group behind "
+                         "inference_tflow(devices=) / C_clonealign_fit(devices)) instead of one process per GPU; no launcher is used or needed")
+    ap.add_argument("--no-through-api-leg", action="store_true",
+                    help="at --gpus > 1 (one process per GPU): skip the extra measurement in which rank 0, after the headline, runs the same workload "
+                         "through the in-process device group over all the devices")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
+    if args.through_api:
+        if int(os.environ.get("WORLD_SIZE", "1")) != 1:
+            raise SystemExit("bench.py --through-api is ONE process driving --gpus devices: run it bare, not under a launcher")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import torch   # (first: torch's bundled HIP runtime has to be the first one initialised)
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (torch.cuda.is_available() is False); there is no CPU fallback")
+        from clonealign_amd import engine as eng_mod
+        if eng_mod.build_id() != eng_mod.source_build_id() and not args.allow_foreign_lib:
+            raise SystemExit("bench.py: the engine library is not built from this tree")
+        if "CLONEALIGN_BENCH_DEVICE" in os.environ:   # plumbing test on a 1-GPU box: every rank on the same device (host transport)
+            devices = [int(os.environ["CLONEALIGN_BENCH_DEVICE"])] * args.gpus
+        else:
+            if eng_mod.device_count() < args.gpus:
+                raise SystemExit(f"bench.py --through-api: --gpus {args.gpus} but {eng_mod.device_count()} device(s) visible "
+                                 "(CLONEALIGN_BENCH_DEVICE=<ordinal> repeats one device for plumbing tests)")
+            devices = list(range(args.gpus))
+        N, G, C, K = args.cells, args.genes, args.clones, args.latent
+        r = through_api(N, G, C, K, devices, args.steps, args.warmup, max(args.repeats, 1), args.seed,
+                        {"auto": "auto", "p2p": "p2p", "rccl": "rccl", "host": "host"}[args.collective])
+        if not r["finite"]:
+            raise SystemExit(f"non-finite ELBO after the timed steps: {r['final_elbo']}")
+        print(json.dumps({
+            "metric": "ELBO iterations/sec", "value": r["value"], "unit": "iterations/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 (bf16x3-split MFMA contraction, fp32 accumulate)", "data": "synthetic",
+            "config": {"workload": f"synthetic {N} cells x {G} genes x {C} clones, K={K}, S=1, ONE fit cell-sharded over {args.gpus} device(s) of one process "
+                                   f"(BASELINE.json configs[{2 if args.gpus == 1 else 3}] through the drop-in's device group)",
+                       "cells": N, "genes": G, "clones": C, "K": K, "parallelism": f"cells/{args.gpus}, one process (ca_group)", "collective": r["transport"],
+                       "build_id": eng_mod.build_id()},
+            "through_api": r, "roofline": None, "cpu_baseline": None}), flush=True)
+        return
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -667,6 +757,33 @@ def main():
         busy_s = time.perf_counter() - tb
     if not np.isfinite(last):
         raise SystemExit(f"non-finite ELBO after the timed steps: {last}")
+    # The drop-in's own way to use several GPUs: after the headline, with every rank's engine closed, rank 0 ALONE runs the
+    # same workload as one fit over all the devices through the in-process device group -- the driver's multi-GPU command thereby exercises the
+    # path inference_tflow(devices=) / C_clonealign_fit(devices) take, next to the one-process-per-GPU number.  Never part of `value`; an error
+    # in it is reported inside the line, it cannot fail the headline.
+    api_leg = None
+    if world > 1 and not args.no_through_api_leg:
+        keep_info = info
+        eng.close()
+        dist.barrier()
+        if rank == 0:
+            # a fresh CHILD process (`bench.py --through-api`, bare: no launcher variables), under a time limit: a transport that has never run on
+            # this hardware must not be able to hang or crash the process that holds the headline
+            import subprocess
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT",
+                                                                     "GROUP_RANK", "ROLE_RANK", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID", "CLONEALIGN_BENCH_SELF_LAUNCHED")}
+            cmd = [sys.executable, os.path.abspath(__file__), "--through-api", "--gpus", str(world), "--steps", str(args.steps), "--warmup", str(args.warmup),
+                   "--repeats", "3", "--cells", str(N), "--genes", str(G), "--clones", str(C), "--latent", str(K), "--seed", str(args.seed)]
+            try:
+                r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420)
+                line = next((l for l in reversed(r.stdout.splitlines()) if l.startswith("{")), None)
+                api_leg = json.loads(line)["through_api"] if (r.returncode == 0 and line) else {"error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-400:]}"}
+            except subprocess.TimeoutExpired:
+                api_leg = {"error": "timed out after 420 s (child process ended)"}
+            except Exception as ex:  # noqa: BLE001
+                api_leg = {"error": f"{type(ex).__name__}: {str(ex)[:400]}"}
+        dist.barrier()
+        info = keep_info
 
     if rank == 0:
         build = eng_mod.build_id()
@@ -771,6 +888,8 @@ def main():
             out["monitor_pass_us_with_collective"] = mon_us
         if ar_us is not None:
             out["allreduce_us"] = ar_us
+        if api_leg is not None:
+            out["through_api"] = api_leg
         if want_cpu:
             n_cpu = args.cpu_sample_cells
             if n_cpu <= 0:

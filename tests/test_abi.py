@@ -115,3 +115,10 @@ def test_create_fails_loudly_without_gpu_or_with_bad_args():
     if not has_gpu:
         with pytest.raises(EngineError):  # no silent CPU fallback
             HipEngine(np.ones((4, 3)), np.ones((3, 2)), np.zeros((4, 1)), np.zeros(3), K=1)
+        # ... nor through the device group: every rank's thread comes back, the message names the rank and its device
+        from clonealign_amd.engine import HipGroupEngine
+        with pytest.raises(EngineError, match=r"rank \d on device \d"):
+            HipGroupEngine(np.ones((8, 3)), np.ones((3, 2)), np.zeros((8, 1)), np.zeros(3), K=1, devices=[0, 1, 2])
+    with pytest.raises(EngineError, match="fewer cells than devices"):
+        from clonealign_amd.engine import HipGroupEngine
+        HipGroupEngine(np.ones((2, 3)), np.ones((3, 2)), np.zeros((2, 1)), np.zeros(3), K=1, devices=[0, 0, 0])

@@ -184,13 +184,13 @@ def test_two_gpus_peer_to_peer_allreduce(tmp_path, single):
     _check(_run(2, "p2p", tmp_path / "p2p2.json", False), single, "p2p")
 
 
-def _bench(world, extra, same_device=True, shape=("--cells", "20000", "--genes", "1000", "--clones", "4")):
+def _bench(world, extra, same_device=True, shape=("--cells", "20000", "--genes", "1000", "--clones", "4"), api_leg=False):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     if same_device:
         env["CLONEALIGN_BENCH_DEVICE"] = "0"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2",
-           "--repeats", "2", *shape, "--no-cpu-baseline", "--busy-seconds", "0", *extra]
+           "--repeats", "2", *shape, "--no-cpu-baseline", "--busy-seconds", "0", *([] if api_leg else ["--no-through-api-leg"]), *extra]
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=420, cwd=ROOT)   # (a run takes 15-60 s)
 
 
@@ -202,8 +202,27 @@ def _bench_bare(world, extra=(), same_device=True, shape=("--cells", "20000", "-
     if same_device:
         env["CLONEALIGN_BENCH_DEVICE"] = "0"
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2", "--repeats", "2", *shape,
-           "--no-cpu-baseline", "--busy-seconds", "0", "--steady-steps", "0", *extra]
+           "--no-cpu-baseline", "--busy-seconds", "0", "--steady-steps", "0", *([] if ("--through-api" in extra or "--api-leg" in extra) else ["--no-through-api-leg"]),
+           *[e for e in extra if e != "--api-leg"]]
     return subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+
+
+def test_bench_through_the_api_runs_one_sharded_fit_inside_one_process():
+    """`bench.py --through-api --gpus N` is ONE process driving N devices through the device group (what
+    inference_tflow(devices=) / C_clonealign_fit(devices) run); and the driver's multi-GPU command -- one process per GPU -- carries the
+    same measurement as an extra leg made by rank 0 in a fresh child process, so that the driver's first multi-GPU contact exercises the
+    drop-in's own path.  Here both ranks sit on device 0: the group settles on the host reduction and says why."""
+    r = _bench_bare(2, ["--through-api"])
+    assert r.returncode == 0, child_report(r)
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    t = line["through_api"]
+    assert line["n_gpus"] == 2 and line["config"]["collective"] == "host" and t["transport"] == "host" and "more than one rank" in t["note"]
+    assert t["cells_per_rank"] == [10000, 10000] and t["finite"] and line["value"] == t["value"] > 0 and t["fit_wallclock"]["iterations"] >= 10
+    r = _bench_bare(2, ["--api-leg", "--preheat-ms", "20"])
+    assert r.returncode == 0, child_report(r)
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["collective"] == "p2p" and "error" not in line["through_api"], line.get("through_api")
+    assert line["through_api"]["transport"] == "host" and line["through_api"]["value"] > 0 and line["through_api"]["devices"] == [0, 0]
 
 
 @pytest.mark.parametrize("world", [2, 8])
