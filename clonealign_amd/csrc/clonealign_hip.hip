@@ -129,6 +129,7 @@ struct ca_engine {
   // that launch was queued; gate_open / gate_snap: the window between queuing it and answering it, in which a poll hook may call back into the API
   // (gate_close()); in_run: ca_run_ex is on this thread's stack (hooks may only call the read-only entry points)
   unsigned long long gate_ticks = 100000ull; std::chrono::steady_clock::time_point gate_t0;
+  double ticks_per_us = 100.0;   // rate of s_memrealtime on this device (hipDeviceAttributeWallClockRate; 100 MHz on gfx950), the unit of every device-side time limit
   bool gate_open = false, gate_aborted = false, in_run = false; struct gate_snapshot* gate_snap = nullptr; struct fwd_snapshot* gate_fsnap = nullptr;
   bool run_fwd = false;    // ca_run: queue the forward sweep behind a gated update ahead of the host's decision (CA_VAR_RUN_FWD)
   bool fwd_gate = false;   // ca_run: the forward sweep being queued is behind a gated update and must look at that launch's answer (ca_cell_ptrs::gate)
@@ -156,6 +157,9 @@ struct ca_engine {
   std::vector<double> mu_part;   // sharded with loc0 = NULL: this rank's per-gene sums of y_ng / rowMeans(Y)_n, completed over all cells in setup_global_sums
   // fused two-eps sweep (monitor pass of iteration i + forward half of train pass i+1, same parameters)
   bool fused_ok = false, look_valid = false; int64_t look_slot = 0; int frow = 8;
+  // ca_iterate, ABI 6: the last sweep of a call may carry the forward half of the NEXT call's first train pass (draw 2n of a 2n + 1 draw stream); `carry` marks
+  // that look-ahead as one a following ca_iterate may pick up, carry_eps keeps the draw it was made with (the next call's draw 0 must be this draw, bit for bit)
+  bool carry = false, carry_builtin = false; std::vector<float> carry_eps;
   float *Mb2 = nullptr, *mu32B = nullptr, *Zpart2 = nullptr; double* gene_partB = nullptr;
   bool y_defer = false;
   bool ride_ok = false;   // the Y stream's blocks ride on the forward sweep's launch (k_fwd_cell_mix_y) instead of a side stream
@@ -2169,7 +2173,12 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   h->upd_merge = h->tail_fuse && h->pre_ok && variant_on(h, CA_VAR_UPDATE_MERGE, "CA_UPDATE_MERGE");
   h->p2p_ride = h->tail_fuse && variant_on(h, CA_VAR_P2P_RIDE, "CA_P2P_RIDE");
   h->run_gate = h->upd_merge && variant_on(h, CA_VAR_RUN_GATE, "CA_RUN_GATE");
-  h->gate_ticks = 100ull * (unsigned long long)(h->opt.gate_timeout_us > 0 ? h->opt.gate_timeout_us : 1000);   // s_memrealtime: 100 MHz
+  {   // the device's wall clock (s_memrealtime) in ticks per microsecond, asked of the runtime instead of assumed
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->device) == hipSuccess && khz >= 1000) h->ticks_per_us = (double)khz / 1000.0;
+    else (void)hipGetLastError();
+  }
+  h->gate_ticks = (unsigned long long)(h->ticks_per_us * (double)(h->opt.gate_timeout_us > 0 ? h->opt.gate_timeout_us : 1000));
   h->run_fwd = h->run_gate && variantx_on(h, CA_VARX_RUN_FWD, "CA_RUN_FWD");   // opt-in: see the header (no runtime call may block between a gated launch and its answer)
   h->pair_elbo = variant_on(h, CA_VAR_PAIR_ELBO, "CA_PAIR_ELBO");
   CACK(upload_y(h, p));
@@ -2777,8 +2786,13 @@ inline void gate_answer(ca_engine* h, int go) {
 int gate_resolve(ca_engine* h, int go) {
   gate_answer(h, go);
   if (!go) return 0;
+  // The shortcut compares two clocks (the host's, and the relay's s_memrealtime that starts later) and needs the pinned write to land before the
+  // relay's last poll: it is taken only with room to spare -- a patience of 200 us or more, answered within half of it (with 10-50 us the
+  // margin was 5-25 us, and a relay that had already given up while the host assumed "ran" would be a silently wrong fit).  Shorter patience: always
+  // the relay's own word.
+  const double patience_us = (double)h->gate_ticks / h->ticks_per_us;
   const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - h->gate_t0).count();
-  if (us < 0.5 * (double)h->gate_ticks / 100.0) return 1;
+  if (patience_us >= 200.0 && us < 0.5 * patience_us) return 1;
   volatile unsigned long long* ack = reinterpret_cast<volatile unsigned long long*>(h->host_pinned + 56);
   unsigned spins = 0;
   auto t_next = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
@@ -3003,7 +3017,7 @@ int ca_p2p_export(ca_handle h, char handle[CA_P2P_HANDLE_BYTES]) {
     *pp->err_host = 0ull;
     if (hipHostGetDevicePointer((void**)&pp->err_dev, pp->err_host, 0) != hipSuccess) return fail("hipHostGetDevicePointer (p2p error word) failed");
     const int ms = h->opt.comm_timeout_ms > 0 ? h->opt.comm_timeout_ms : 10000;
-    pp->timeout_ticks = (unsigned long long)ms * 100000ull;   // s_memrealtime counts at 100 MHz
+    pp->timeout_ticks = (unsigned long long)((double)ms * 1000.0 * h->ticks_per_us);   // s_memrealtime ticks
     h->p2p = pp;
   }
   ca_p2p_wire w;
@@ -3409,7 +3423,20 @@ int ca_iterate(ca_handle h, int32_t n_iter, const float* eps_stream, int64_t n_d
   if (!h || n_iter < 0) return CA_ERR_INVALID;
   CA_NOT_IN_RUN(h);
   HIPCK(h, hipSetDevice(h->device));
-  CACK(stage_eps(h, eps_stream, n_draws, 2 * (int64_t)n_iter));
+  // ABI 6: with one draw MORE than the 2 n the call consumes (or the built-in stream, which can look one draw ahead), the last sweep carries the forward
+  // half of the NEXT ca_iterate call's first train pass instead of a duplicate of its own draw, and that call -- if its first draw IS that draw, bit for
+  // bit -- starts from it: back-to-back calls of n iterations then run n sweeps each, not n + 1 (a 20-iteration call paid 21/20 of the steady state).
+  const int64_t per = (int64_t)h->S * h->G;
+  const bool can_carry = n_iter > 0 && h->fused_ok && !h->s2 && (h->bwd_mfma || !is_sharded(h));
+  const bool carry_out = can_carry && (eps_stream ? n_draws >= 2 * (int64_t)n_iter + 1 : true);
+  bool carry_in = can_carry && h->carry && h->look_valid && h->look_slot == 0;
+  if (carry_in) carry_in = eps_stream ? (!h->carry_builtin && (int64_t)h->carry_eps.size() == per && n_draws >= 1 &&
+                                         memcmp(h->carry_eps.data(), eps_stream, (size_t)per * sizeof(float)) == 0)
+                                      : h->carry_builtin;
+  h->carry = false;
+  CACK(stage_eps(h, eps_stream, n_draws, 2 * (int64_t)n_iter + (carry_out ? 1 : 0)));   // (clears the look-ahead: the staged slots change ...)
+  if (!eps_stream && carry_out) h->draw -= 1;                                             // (built-in stream: the extra draw was a look ahead, the next call draws it again)
+  if (carry_in) { h->look_valid = true; h->look_slot = 0; }                               // (... but slot 0 of the new block is the draw the carried half was made with)
   CACK(ensure_elbo_cap(h, std::max(1, n_iter) + 1));
   const auto t_host0 = std::chrono::steady_clock::now();
   // The first train pass has no monitor pass before it to share a sweep with.  Instead of the plain kernels (fp32 VALU sweep,
@@ -3421,13 +3448,18 @@ int ca_iterate(ca_handle h, int32_t n_iter, const float* eps_stream, int64_t n_d
   for (int i = 0; i < n_iter; ++i) {
     // (the last monitor pass has no train pass to share its sweep with: its own draw in both halves, as above -- the plain
     //  kernels with the Y stream in line cost 0.33 ms at cfg-3 against 0.2)
-    const int64_t mon = 2 * (int64_t)i + 1, next = i + 1 < n_iter ? mon + 1 : (h->fused_ok ? mon : -1);
+    const int64_t mon = 2 * (int64_t)i + 1, next = (i + 1 < n_iter || carry_out) ? mon + 1 : (h->fused_ok ? mon : -1);
     h->hint_A = mon; h->hint_B = next;
     CACK(train_pass(h, 2 * (int64_t)i));
     CACK(monitor_pass(h, mon, next, h->elbo_dev + i));
   }
   CACK(flush_mon_tail(h));
-  h->look_valid = false;   // the duplicate half of the last sweep is nobody's look-ahead
+  if (carry_out && h->look_valid && h->look_slot == 2 * (int64_t)n_iter) {
+    h->carry = true; h->carry_builtin = eps_stream == nullptr; h->look_slot = 0;
+    if (eps_stream) h->carry_eps.assign(eps_stream + 2 * (int64_t)n_iter * per, eps_stream + (2 * (int64_t)n_iter + 1) * per);
+  } else {
+    h->look_valid = false;   // the duplicate half of the last sweep is nobody's look-ahead
+  }
   if (verbose(h) && n_iter > 0)
     fprintf(stderr, "[clonealign_hip] ca_iterate: host enqueue %.1f us per iteration\n",
             std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_host0).count() / n_iter);
@@ -3758,6 +3790,10 @@ int ca_reinit(ca_handle h, const double* psi0, const double* loc0) {
   if (h->K > 0 && !psi0) { h->err = "psi0 is required when K > 0"; return CA_ERR_INVALID; }
   HIPCK(h, hipSetDevice(h->device));
   CACK(wait_y(h, true));
+  // A forward-sweep block that gave up on a left-over tile leaves a sticky word (comm_check: "the engine's state is undefined").  A restart defines every
+  // variable and every Adam slot again, so THIS call -- and only this one -- clears it; a dead peer-to-peer transport stays dead.
+  HIPCK(h, hipStreamSynchronize(h->stream));
+  if (h->host_pinned) *reinterpret_cast<volatile unsigned int*>(h->host_pinned + 41) = 0u;
   SYNC(h);
   const int64_t N = h->N; const int G = h->G, C = h->C, K = h->K, D = h->D;
   auto zero = [&](float* p, int64_t n) { return p && n > 0 ? hipMemsetAsync(p, 0, (size_t)n * sizeof(float), h->stream) : hipSuccess; };
@@ -3807,6 +3843,7 @@ int ca_get_kernel_times(ca_handle h, double ms[CA_KERNEL_COUNT], int64_t launche
 
 int ca_reset_kernel_times(ca_handle h) {
   if (!h) return CA_ERR_INVALID;
+  CA_NOT_IN_RUN(h);   // (changes the profiling state around a launch that may be undone and queued again: not from a poll hook)
   CACK(prof_flush(h));
   for (int i = 0; i < CA_KERNEL_COUNT; ++i) { h->k_ms[i] = 0; h->k_n[i] = 0; }
   return CA_OK;
@@ -3814,6 +3851,7 @@ int ca_reset_kernel_times(ca_handle h) {
 
 int ca_set_profile(ca_handle h, int32_t mask) {
   if (!h) return CA_ERR_INVALID;
+  CA_NOT_IN_RUN(h);
   CACK(prof_flush(h));
   h->opt.profile = mask;
   for (unsigned& c : h->prof_seen) c = 0;

@@ -317,7 +317,11 @@ typedef int (*ca_poll_fn)(void* user, int32_t iter, double elbo);
 int ca_run_ex(ca_handle h, int32_t max_iter, double rel_tol, const float* eps_stream, int64_t n_draws,
               double* elbo_trace, int32_t* n_elbo, ca_poll_fn poll, void* user);
 /* n_iter iterations of {train, monitor} with no convergence test and no host sync inside
- * (the benchmark "step"); last_elbo may be NULL. */
+ * (the benchmark "step"); last_elbo may be NULL.  eps_stream: 2 n_iter draws consumed in order.  ABI 6: given ONE MORE draw (2 n_iter + 1), the
+ * call's last sweep also makes the forward half of the first train pass of the NEXT ca_iterate call with it; that call picks it up when its own
+ * first draw is that draw bit for bit (else it is dropped, nothing else changes): back-to-back calls then run n_iter sweeps each instead of
+ * n_iter + 1.  The variables, the ELBOs and the number of draws CONSUMED (2 n_iter) are the same either way; the built-in stream (NULL) looks
+ * one draw ahead by itself.  Any other call in between drops the carried half. */
 int ca_iterate(ca_handle h, int32_t n_iter, const float* eps_stream, int64_t n_draws, double* last_elbo);
 /* `replicate(20, sess$run(elbo))` (:447-454): values[n_rep], mean and sample sd */
 int ca_final_elbo(ca_handle h, int32_t n_rep, const float* eps_stream, int64_t n_draws, double* values,
