@@ -51,6 +51,15 @@ def algorithmic_work(kernel, N, G, C, K, fused=False, steps=1, ride=False):
     return "hbm", 0.0
 
 
+def draws_for_calls(rng, steps, S, G):
+    """2 steps + 1 draws for back-to-back ca_iterate(steps) calls on the SAME array: the extra draw is a copy of the first, so that every call's
+    last sweep makes the forward half of the next call's first train pass (ca_iterate, ABI 6) and a call of K iterations runs K sweeps, as in the
+    steady state of the reference's loop -- not K + 1 with a duplicate half at the end (r5: the 20-step command paid 21/20)."""
+    eps = rng.normal(size=(2 * steps + 1, S, G)).astype(np.float32)
+    eps[-1] = eps[0]
+    return eps
+
+
 def agreed_calls(budget_ms, call_ms, cap=4096):
     """How many equal calls fill ``budget_ms`` when one takes ``call_ms`` -- a pure function of two numbers every rank holds
     identically (call_ms is the all-reduced MAX), so a loop of collective calls sized by it has the same length on every rank."""
@@ -197,8 +206,9 @@ def side_config(name, N, G, C, K=1, S=1, P=0, steps=200, regions=3, seed=20251, 
     try:
         info = eng.info()
         eng.gamma_init(rng.normal(size=(S, G)).astype(np.float32))
-        eps = rng.normal(size=(2 * steps, S, G)).astype(np.float32)
+        eps = draws_for_calls(rng, steps, S, G)
         eng.iterate(min(steps, 20), eps[:2 * min(steps, 20)])
+        eng.iterate(steps, eps)                       # (untimed: the first timed call then starts from a carried half like every later one)
         eng.synchronize()
         ts = []
         for _ in range(regions):
@@ -246,7 +256,8 @@ def through_api(N, G, C, K, devices, steps, warmup, regions=3, seed=20243, trans
         grp.gamma_init(eps0)
         eps_w = rng.normal(size=(2 * max(warmup, 1), 1, G)).astype(np.float32)
         grp.iterate(max(warmup, 1), eps_w)
-        eps_t = rng.normal(size=(2 * steps, 1, G)).astype(np.float32)
+        eps_t = draws_for_calls(rng, steps, 1, G)
+        grp.iterate(steps, eps_t)
         tb = time.perf_counter()
         while (time.perf_counter() - tb) * 1e3 < budget_ms:
             grp.iterate(steps, eps_t)
@@ -592,7 +603,7 @@ def main():
     # live HIP events around every 8th launch of the dominant class (an event pair costs the stream 5-6 us: 1.6 % at cfg-3, 9 % at
     # cfg-2 when every launch is timed -- measured with --no-live-events; sampled, the timed region is left alone)
     eng.set_profile(0 if args.no_live_events else (1 << kid) | ((EVENT_STRIDE - 1) << 8))
-    eps_t = rng.normal(size=(2 * args.steps, 1, G)).astype(np.float32)
+    eps_t = draws_for_calls(rng, args.steps, 1, G)   # (2 K + 1 draws: every timed call carries the next call's forward half, K sweeps per K iterations)
 
     def barrier():
         if world > 1:
@@ -614,6 +625,8 @@ def main():
         t_pre = time.perf_counter()
         pre_calls = run_agreed_calls(lambda: eng.iterate(args.steps, eps_t), args.preheat_ms, dist if world > 1 else None)
         pre_it = pre_calls * args.steps
+    else:
+        eng.iterate(args.steps, eps_t)   # (one untimed call all the same: the first timed region must start from a carried half like the others)
     pre_ms = (time.perf_counter() - t_pre) * 1e3
     # --- timed: `repeats` regions of exactly `steps` iterations, each bracketed by barrier + synchronize on both sides and
     #     maxed over the ranks; the quoted value is the MEDIAN region (a 20-step region at cfg-3 is only 6 ms long)
@@ -642,7 +655,7 @@ def main():
     if steady_steps > 0:
         # (under a profiler this region's 2 x steady_steps iterations -- steady_steps + 1 sweeps per call, another call shape -- would mix into the
         #  per-launch statistics of the --steps regions: off by default there)
-        eps_s = rng.normal(size=(2 * steady_steps, 1, G)).astype(np.float32)
+        eps_s = draws_for_calls(rng, steady_steps, 1, G)
         eng.set_profile(0)
         eng.iterate(steady_steps, eps_s)
         barrier()
@@ -805,13 +818,13 @@ def main():
             y_s = per_launch_s if ride else kt["ypass"][0] / kt["ypass"][1] * 1e-3
             canon = n_loc * G * 4.0 + (n_loc + G) * K * 4.0 * 2
             ytraffic, ysrc = pmc_traffic(build, "fwd" if ride else "ypass") if same_workload else (None, None)
-            ystream = {"bound": "hbm", "kernel": "ypass (blocks inside the forward sweep's launch)" if ride else "ypass", "achieved": canon / y_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                       "frac_canonical": canon / y_s / 1e9 / PEAK_HBM_GBS, "traffic": ytraffic, "traffic_source": ysrc, "launch_ms": y_s * 1e3,
-                       "stored_GBps": n_loc * G * float(info["y_bytes_per_elem"]) / y_s / 1e9,
-                       "frac_stored": n_loc * G * float(info["y_bytes_per_elem"]) / y_s / 1e9 / PEAK_HBM_GBS,
-                       "note": "achieved / frac_canonical count the canonical 4 B per count (the reference feeds float32, SURVEY.md section 8d) "
-                               f"-- bytes this build does NOT move: the matrix is stored at {info['y_bytes_per_elem']} B per count.  "
-                               "stored_GBps / frac_stored are the physical rate of the stream over the launch it rides in"}
+            stored = n_loc * G * float(info["y_bytes_per_elem"])
+            ystream = {"bound": "hbm", "kernel": "ypass (blocks inside the forward sweep's launch)" if ride else "ypass",
+                       "achieved": stored / y_s / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": stored / y_s / 1e9 / PEAK_HBM_GBS,
+                       "traffic": ytraffic, "traffic_source": ysrc, "launch_ms": y_s * 1e3, "canonical_bytes": canon, "stored_bytes": stored,
+                       "note": f"physical rate: the {info['y_bytes_per_elem']} B per count the matrix is stored at, over the launch the stream rides in.  (The "
+                               "canonical 4 B per count of SURVEY.md section 8d would read as more than the HBM peak here -- bytes this build does not move; "
+                               "that figure is no longer printed.)  HBM is not what binds this launch: see roofline.binding"}
         step_s = dt / args.steps
         it_flops = N * G * (8.0 * C + 12.0 * K + 3.0)                       # SURVEY.md section 8d, whole iteration, all ranks
         it_bytes = N * G * 4.0 + N * (8.0 * C + 6.0 * K + 2.0) * 4.0
@@ -843,6 +856,8 @@ def main():
                          **({k: v for k, v in (sq_fractions(build, dominant) or {}).items() if k != "file"} if same_workload else {}),
                          "sq_source": (sq_fractions(build, dominant) or {}).get("file") if same_workload else None,
                          "event_stride": 1 if args.no_live_events else EVENT_STRIDE,
+                         "binding": "vector issue (VALU + MFMA share the SIMD's issue port; valu_active_frac / mfma_busy_frac from the SQ counter pass of this "
+                                    "build; HBM: traffic per launch against launch_ms is ~0.5 of peak)",
                          "note": ("algorithmic fp32 flops of the fused two-eps sweep against the fp32 peak; the contraction "
                                   "itself runs as bf16 hi/lo MFMAs (fp32-accurate), the kernel is bound by VALU issue "
                                   "(v_exp_f32 + bf16 split)"

@@ -104,7 +104,10 @@ inference_tflow <- function(Y_dat,
       pcs <- NULL
     } else {
       pca <- prcomp(log2(Y_dat + 1), center = TRUE, scale. = TRUE)
-      pcs <- scale(pca$x[, seq_len(K), drop = FALSE])
+      # ONE sign convention on both sides of the device_init switch: prcomp's signs are LAPACK's and arbitrary, the device routine makes each
+      # component's loading of largest magnitude positive -- the same rule here, so that one seed gives one fit whichever side initialises
+      sgn <- apply(pca$rotation[, seq_len(K), drop = FALSE], 2, function(v) sign(v[which.max(abs(v))]))
+      pcs <- scale(sweep(pca$x[, seq_len(K), drop = FALSE], 2, sgn, `*`))
       pcs <- pcs + pcs_noise
       attributes(pcs) <- list(dim = c(N, K))                               # plain matrix: drop scale()'s attributes
       pcs_noise <- NULL
