@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "ca_kernels.hip.h"
+#include "ca_poly.h"
 #include "philox_host.h"
 
 namespace {
@@ -160,6 +161,10 @@ struct ca_engine {
   // ca_iterate, ABI 6: the last sweep of a call may carry the forward half of the NEXT call's first train pass (draw 2n of a 2n + 1 draw stream); `carry` marks
   // that look-ahead as one a following ca_iterate may pick up, carry_eps keeps the draw it was made with (the next call's draw 0 must be this draw, bit for bit)
   bool carry = false, carry_builtin = false; std::vector<float> carry_eps;
+  // the series form of the forward / backward contraction (ca_poly.hip; one exponent dimension, one MC sample, 3..8 clones): an overlay on the fused loop --
+  // fused_pass makes Z by it and leaves the backward moments in the workspace (poly_fresh: they belong to the look-ahead half look_valid refers to),
+  // train_bwd turns them into the per-gene sums, train_update reads d/dF from ONE slab (poly_df)
+  bool poly = false, poly_fresh = false, poly_df = false; ca_poly_ws pws; float* poly_zero = nullptr; unsigned char* poly_mem = nullptr;
   float *Mb2 = nullptr, *mu32B = nullptr, *Zpart2 = nullptr; double* gene_partB = nullptr;
   bool y_defer = false;
   bool ride_ok = false;   // the Y stream's blocks ride on the forward sweep's launch (k_fwd_cell_mix_y) instead of a side stream
@@ -240,6 +245,11 @@ namespace {
 int comm_check(ca_engine* h) {
   if (h->host_pinned && *reinterpret_cast<volatile unsigned int*>(h->host_pinned + 41) != 0u) {
     h->err = "a forward-sweep block gave up waiting for a chunk of a left-over tile (k_fwd_bal_ys); the engine's state is undefined";
+    return CA_ERR_STATE;
+  }
+  if (h->host_pinned && *reinterpret_cast<volatile unsigned int*>(h->host_pinned + 42) != 0u) {
+    h->err = "the series form of the contraction (CA_VARX_SERIES) cannot cover this fit's exponent range: max|psi| (max W - min W) exceeds 4 x " +
+             std::to_string(CA_PL_NB) + " bins' worth; the passes since are truncated -- start over without the series form";
     return CA_ERR_STATE;
   }
   if (h->p2p && h->p2p->err_host && *reinterpret_cast<volatile unsigned long long*>(h->p2p->err_host) != 0ull) {
@@ -549,6 +559,7 @@ int refresh_derived(ca_engine* h) {
   h->ycache_valid = false;
   h->yfin_pending = false;
   h->look_valid = false;
+  h->poly_fresh = false;
   return CA_OK;
 }
 
@@ -1000,6 +1011,17 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
   const int W_ = h->S + h->D;
   bool merged = false, ride_ar = false;
   ca_ar_ride ride;
+  if (h->poly_fresh) {   // the backward moments of this look-ahead half are in the workspace: per-gene sums straight into red (no slabs, no column sums)
+    h->poly_fresh = false;
+    h->fold_now = false;
+    CACK(yfin_flush(h));
+    CACK(flush_mon_tail(h));
+    CACK(prof_begin(h, CA_KERNEL_BWD));
+    const hipError_t e = ca_poly_backward(h->stream, &h->pws, h->V, mu32, h->Lb, h->G, h->C, h->red + h->off_g);
+    HIPCK(h, e);
+    CACK(prof_end(h));
+    h->poly_df = true;
+  } else
   if (h->bwd_mfma) {
     const int xb = cdiv(h->nwt, CA_TB / 64);
     // A pending monitor pass's tail rides on the sweep as one extra block (its fp64 chains hide under 130 us of sweep):
@@ -1104,7 +1126,8 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
 // sweep that follows can make the exponent bound itself, K >= 1)
 inline bool update_merges(const ca_engine* h, int apply, const double* elbo_dst) {
   const int64_t mB = h->s2 ? 2 * h->hint_A + 1 : h->hint_B;
-  return apply && h->upd_merge && !elbo_dst && h->pre_ok && h->hint_A >= 0 && mB >= 0 && h->fused_ok && h->gene_part_alt && h->fwd_cell && h->K > 0;
+  // (the series form keeps the two-launch update: the merged one leaves the exponent bound of the stepped state to a forward SWEEP's blocks)
+  return apply && h->upd_merge && !elbo_dst && h->pre_ok && h->hint_A >= 0 && mB >= 0 && h->fused_ok && h->gene_part_alt && h->fwd_cell && h->K > 0 && !h->poly;
 }
 int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
   const int N256 = cdiv(h->N, CA_TB);
@@ -1124,8 +1147,9 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
   memset(&psi, 0, sizeof(psi));
   if (h->K > 0) {
     psi.nblk = N256; psi.F = h->F; psi.YW = h->YW; psi.dFpart = h->dFpart; psi.m_psi = h->m_psi; psi.v_psi = h->v_psi; psi.g_psi = h->g_psi;
-    psi.N = h->N; psi.D = h->D; psi.K = h->K; psi.ntile = h->bwd_mfma ? cdiv(h->nwt, CA_TB / 64) : h->ntile;
+    psi.N = h->N; psi.D = h->D; psi.K = h->K; psi.ntile = h->poly_df ? 1 : h->bwd_mfma ? cdiv(h->nwt, CA_TB / 64) : h->ntile;
   }
+  h->poly_df = false;
   h->pre_valid = false;
   // Round 4: the whole update half in ONE launch (k_update_merged) whenever the loop has announced the next eps pair, the fused forward
   // sweep that follows can make the exponent bound itself (fwd_cell) and K >= 1 -- see the kernel.  Everything else (call-by-call API,
@@ -1280,6 +1304,7 @@ int train_tail(ca_engine* h, const float* eps, const float* mu32, int apply, dou
 //   mode CA_MODE_TRAIN: forward + backward (+ Adam when apply)  (`sess$run(train)`)
 int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_dst) {
   const float* eps = h->eps_dev + eps_slot * (int64_t)h->S * h->G;
+  h->poly_fresh = false;   // (a plain pass makes its own forward half: backward moments left by an unused look-ahead are nobody's)
   CACK(flush_mon_tail(h));
   CACK(ensure_etamax(h));
   if (mode != CA_MODE_TRAIN) h->hint_A = h->hint_B = -1;
@@ -1362,7 +1387,8 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
   }
   h->pre_valid = false;
   // the Y products of this parameter state: riding on the sweep's own launch (below), or from the side stream / in line
-  const bool ride = (h->ride_ok || h->ride_ys) && !h->ycache_valid && h->fwd_cell && !h->y_defer && !h->y_pending;
+  const bool ride = (h->ride_ok || h->ride_ys) && !h->ycache_valid && h->fwd_cell && !h->y_defer && !h->y_pending &&
+                    !(h->poly && trainA < 0 && !elbo_dstB && !h->fwd_gate);   // (the series form has no sweep launch to ride on)
   if (!ride) CACK(ensure_ycache(h));
   ca_cell_ptrs cp;
   cp.A = h->A; cp.cn = h->cn; cp.s64 = h->s64; cp.etamax2 = h->etamax2; cp.glogit = h->glogit; cp.F = h->F;
@@ -1380,6 +1406,20 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
   int CP = 1;
   while (CP < h->C) CP <<= 1;
   int cell_blocks = h->ncblk;
+  const bool series = h->poly && !s2f && !elbo_dstB && !h->fwd_gate;
+  if (series) {
+    // Z of both draws from the moments of M over gene bins (ca_poly.hip), the same cell epilogue, d/dF and the backward moments in one pass over
+    // the CELLS: no cells x genes sweep.  The count-matrix products of this state run as their own launch (in line).
+    CACK(ensure_ycache(h));
+    cp.etamax2 = h->poly_zero; cp.coefq = nullptr; cp.vmm_at = nullptr; cp.etamax_w = nullptr;
+    CACK(prof_begin(h, CA_KERNEL_FWD));
+    const hipError_t e = ca_poly_forward(h->stream, &h->pws, h->V, h->F, h->mu32, h->mu32B, h->Lb, h->G, h->N, h->C, h->K, &cp, h->alpha_u, h->cell_part, h->dFpart,
+                                         h->host_dev ? reinterpret_cast<unsigned int*>(h->host_dev + 42) : nullptr);
+    HIPCK(h, e);
+    CACK(prof_end(h));
+    cell_blocks = h->pws.n_cell_blocks;
+    h->poly_fresh = true;
+  } else
   if (h->fwd_cell && ride && h->ride_ys) {   // the one-copy int8 matrix-core stream's blocks interleaved with the sweep's
     cell_blocks = h->ncblk_f;
     CACK(ys_quant(h));
@@ -2435,6 +2475,18 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   CACK(dalloc(h, &h->scratch, Nn * C));
   const int64_t n_cpart = std::max(std::max(h->ncblk, h->ncblk_f), 2 * h->n_cu);   // (balanced sweep: n_cu blocks + up to n_cu - 1 left-over tiles' blocks)
   CACK(dalloc(h, &h->cell_part, n_cpart * (3 + C)));
+  h->poly = ca_poly_ok(D, S, C) && h->fused_ok && !h->c16 && !h->s2 && K == 1 && variantx_on(h, CA_VARX_SERIES, "CA_SERIES");
+  if (h->poly) {
+    int CPp = 1;
+    while (CPp < C) CPp <<= 1;
+    const int ncb = (int)std::min<int64_t>(cdiv(Nn, CA_TB / CPp), 2 * (int64_t)h->n_cu);
+    const size_t wb = ca_poly_workspace_bytes(G, ncb);
+    CACK(dalloc(h, &h->poly_mem, (int64_t)wb));
+    HIPCK(h, hipMemsetAsync(h->poly_mem, 0, wb, h->stream));
+    ca_poly_bind(&h->pws, h->poly_mem, G, ncb);
+    CACK(dalloc(h, &h->poly_zero, Nn));
+    HIPCK(h, hipMemsetAsync(h->poly_zero, 0, (size_t)Nn * sizeof(float), h->stream));
+  }
   CACK(dalloc(h, &h->ee_partB, n_cpart));
   CACK(dalloc(h, &h->gpart, (int64_t)std::max(h->csplit, h->csplit_m) * G * (S + D)));
   CACK(dalloc(h, &h->dFpart, (int64_t)std::max(h->ntile, h->nwt) * Nn * std::max(D, 1)));
@@ -2938,6 +2990,7 @@ int ca_get_info(ca_handle h, ca_info* i) {
   i->red_n = h->red_n;
   i->fwd_block_cells = (h->fused_ok && h->fwd_cell) ? 16 * h->fc_tl : 0; i->fwd_blocks_big = h->fc_nbig;
   i->fwd_balanced = h->fwd_bal ? h->bal_q : 0;
+  i->fwd_series = h->poly ? 1 : 0;
   i->fold_gsum = (h->fold_gsum && !is_sharded(h)) ? 1 : 0; i->yfin_split = (h->yfin_split && !is_sharded(h)) ? 1 : 0;
   i->update_merge = (h->upd_merge && h->fused_ok && h->fwd_cell && h->K > 0) ? 1 : 0;
   return CA_OK;
@@ -3793,7 +3846,7 @@ int ca_reinit(ca_handle h, const double* psi0, const double* loc0) {
   // A forward-sweep block that gave up on a left-over tile leaves a sticky word (comm_check: "the engine's state is undefined").  A restart defines every
   // variable and every Adam slot again, so THIS call -- and only this one -- clears it; a dead peer-to-peer transport stays dead.
   HIPCK(h, hipStreamSynchronize(h->stream));
-  if (h->host_pinned) *reinterpret_cast<volatile unsigned int*>(h->host_pinned + 41) = 0u;
+  if (h->host_pinned) { *reinterpret_cast<volatile unsigned int*>(h->host_pinned + 41) = 0u; *reinterpret_cast<volatile unsigned int*>(h->host_pinned + 42) = 0u; }
   SYNC(h);
   const int64_t N = h->N; const int G = h->G, C = h->C, K = h->K, D = h->D;
   auto zero = [&](float* p, int64_t n) { return p && n > 0 ? hipMemsetAsync(p, 0, (size_t)n * sizeof(float), h->stream) : hipSuccess; };

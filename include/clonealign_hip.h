@@ -141,6 +141,10 @@ enum ca_variant_on {
                                  blocks, no exchange (the stream's blocks then go to the CUs without one); default: the left-over tiles cut gene-wise into chunks
                                  that the sweep blocks sweep beside their own tiles, partial Z exchanged through tagged words.  Level at few left-over tiles,
                                  slower at many */
+  CA_VARX_SERIES = 1 << 8,    /* ABI 6: the loop's contraction in its SERIES form (ca_poly.hip) where the exponent is rank one -- K + P = 1, one MC sample, 3..8
+                                 clones: Z_nc = sum_g M_gc exp(x_n v_g) is one function of x per clone; genes binned by v, a 20-term expansion per bin (argument <= 2,
+                                 float64): moments over genes, evaluation over cells, the same form on the way back.  No cells x genes sweep: O(N nb R C + G R C)
+                                 instead of O(N G C) per pass; the cell epilogue is the sweep's.  Other shapes keep the matrix-core sweeps */
   CA_VARX_ASYNC_SMALL = 1 << 1 /* side stream also below 4e7 counts (small shards run the Y stream in line: the two cross-stream
                                  events cost more than the overlap returns there) */
 };
@@ -203,6 +207,7 @@ typedef struct ca_info {
   int32_t yfin_split;        /* 1: the Y stream's finishing step is split between the forward and backward launches */
   int32_t update_merge;      /* 1: the loop's update half is one launch (CA_VAR_UPDATE_MERGE) */
   int32_t fwd_balanced;      /* > 0: the fused forward sweep is the balanced small-problem form (CA_VAR_FWD_BAL), that many tiles per block */
+  int32_t fwd_series;        /* ABI 6: 1: the loop's contraction runs in its series form (CA_VARX_SERIES, ca_poly.hip) */
 } ca_info;
 enum ca_transport { CA_TRANSPORT_NONE = 0, CA_TRANSPORT_RCCL = 1, CA_TRANSPORT_HOST = 2, CA_TRANSPORT_P2P = 3 };
 

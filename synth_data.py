@@ -64,6 +64,31 @@ def make_problem(N, G, C, seed=20240, median_s=2000, rows=None):
     return dict(Y=Y, L=L, z=z[lo:hi], s_target=s[lo:hi], mu_true=mu)
 
 
+def make_hard_problem(N, G, C, seed=20246, median_s=400, informative=0.03):
+    """A problem on which clone assignment is NOT trivially separable (on the default generator every max-gamma ends at exactly 1.0,
+    so "0 label flips" said nothing): shallow libraries (median 400 counts per cell, the example's order of magnitude, R/data example_sce: 71) and a
+    copy-number profile that is THE SAME in every clone except on a few percent of the genes -- what a real tumour's subclones look like.  After the
+    default fit roughly half of the cells stay below the 0.95 call threshold, about a quarter end with max-gamma in [0.9, 0.99), and tens of cells sit
+    within 1e-3 of the threshold (tests/test_gpu_scale.py::test_full_default_fit_on_a_hard_problem_* print the numbers).  Returns dict(Y int32 [N, G'], L [G', C], z) with empty genes removed."""
+    rng = np.random.default_rng(seed)
+    base = rng.choice(CN_VALUES, size=(G, 1), p=CN_WEIGHTS)
+    L = np.repeat(base, C, 1)
+    inf = rng.choice(G, max(C, int(round(informative * G))), replace=False)
+    L[inf] = make_copy_number(len(inf), C, rng)
+    mu = rng.lognormal(0.0, 1.6, size=G)
+    z = rng.integers(0, C, size=N)
+    s = np.maximum(rng.lognormal(np.log(median_s), 0.5, size=N), 20.0)
+    M = mu[:, None] * L
+    P = M / M.sum(0, keepdims=True)
+    Y = np.empty((N, G), dtype=np.int32)
+    for b0 in range(0, N, 4096):
+        b1 = min(b0 + 4096, N)
+        Y[b0:b1] = np.random.default_rng([seed, 2, b0 // 4096]).poisson(s[b0:b1, None] * P[:, z[b0:b1]].T)
+    Y[:, 0] += (Y.sum(1) == 0)
+    keep = Y.sum(0) > 0
+    return dict(Y=np.ascontiguousarray(Y[:, keep]), L=L[keep], z=z, informative_genes=int(np.isin(np.flatnonzero(keep), inf).sum()))
+
+
 def cheap_init(Y, K=1, seed=0):
     """Initialisation for benchmarks: psi0 ~ N(0,1) (the iteration rate does not depend on
     it; prcomp at 100k x 5k would dwarf the loop) and the reference's

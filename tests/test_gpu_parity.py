@@ -12,7 +12,7 @@ import os
 import numpy as np
 import pytest
 
-from tests._cases import eps_for, make_case, perturbed_state
+from tests._cases import eps_for, label_flips, make_case, perturbed_state
 
 pytestmark = pytest.mark.gpu
 
@@ -1064,3 +1064,57 @@ def test_results_do_not_depend_on_another_process_sharing_the_gpu():
     finally:
         co.kill()
         co.wait()
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# Round 6: the matrix-core sweeps carry E and M as two bf16 parts each and keep three of the four products -- about 2^-16 per
+# operand, which the sum over thousands of genes averages down to the float32 level.  With FEW genes, or ONE gene carrying nearly all of Z, nothing
+# averages: the error of log Z is then up to ~3 * 2^-16, and it reaches the q(z) logits multiplied by the cell's library size s_n.  This test
+# makes that case on purpose and BOUNDS the error against the float64 oracle explicitly, per cell: |logit - oracle| <= 4 * 2^-16 * s_n + 1e-4.
+@pytest.mark.parametrize("G,dominant", [(2, 0.99), (8, 0.99), (33, 0.99), (700, 0.99), (700, 0.0)])
+def test_few_genes_or_one_dominant_gene_bound_the_split_operand_error(G, dominant):
+    from clonealign_amd.engine import HipEngine
+    from clonealign_amd.hostprep import mu_guess, safe_inverse_softplus
+    from clonealign_amd.inference import run_vi_loop
+    from clonealign_amd.rng import EpsStream
+    from oracle.fused_numpy import FusedModel
+    rng = np.random.default_rng(100 + G)
+    N, C = 3000, 4
+    L = rng.integers(1, 5, size=(G, C)).astype(np.float64)
+    L[0] = [1, 2, 3, 4]                                      # the dominant gene separates the clones
+    mu = rng.lognormal(0, 1, G)
+    if dominant > 0:
+        mu[0] = dominant / (1.0 - dominant) * mu[1:].sum()  # gene 0 carries `dominant` of the expected counts
+    z = rng.integers(0, C, N)
+    s = rng.integers(500, 4000, N).astype(np.float64)
+    M = mu[:, None] * L
+    P = M / M.sum(0, keepdims=True)
+    Y = rng.poisson(s[:, None] * P[:, z].T).astype(np.float64)
+    Y[:, 0] += (Y.sum(1) == 0)
+    Y[0, :] += (Y.sum(0) == 0)
+    psi0 = rng.normal(size=(N, 1)) * 0.1
+    loc0 = safe_inverse_softplus(np.maximum(mu_guess(Y, True), 1e-6))
+    case = dict(Y=Y, L=L, psi0=psi0, loc0=loc0, K=1, S=1)
+    eng, ora = HipEngine(**case), FusedModel(**case, dtype="float32")
+    try:
+        info = eng.info()
+        e0 = eps_for(1, G, 1)
+        eng.gamma_init(e0); ora.gamma_init(e0)
+        sn = Y.sum(1)
+        d = np.abs(eng.get("gamma_logits") - np.asarray(ora.gamma_logits, dtype=np.float64)).max(1)
+        bound = 4.0 * 2.0 ** -16 * sn + 1e-4
+        worst = float((d / sn).max())
+        print(f"G={G} dominant={dominant}: fwd_mfma {info['fwd_mfma']}, fwd_cell {info['fwd_cell']}; max |logit error| {d.max():.3e}, max error / s_n {worst:.3e} "
+              f"(2^-16 = {2.0 ** -16:.3e}), float32 would be ~{2.0 ** -24:.1e}")
+        assert np.all(d <= bound), (float(d.max()), float((d / bound).max()))
+        # ... and the fit that starts there: five iterations of the loop, ELBO to 1e-5, parameters to 1e-4 (north_star), labels equal away from the margin
+        tr = np.asarray(eng.run(EpsStream(9, 1, G), 5, 1e-12))
+        to = np.asarray(run_vi_loop(ora, EpsStream(9, 1, G), 5, 1e-12))
+        assert np.abs(tr - to).max() <= 1e-5 * np.abs(to).max(), np.abs(tr - to).max() / np.abs(to).max()
+        pe, po = eng.get_params(), ora.get_params()
+        for n in ("mu", "alpha", "W", "psi"):
+            assert np.abs(pe[n] - po[n]).max() <= 1e-4 * np.abs(po[n]).max(), (n, np.abs(pe[n] - po[n]).max() / np.abs(po[n]).max())
+        flips, far = label_flips(pe["clone_probs"], po["clone_probs"], margin=float(np.max(bound)))
+        assert far == 0, (flips, far)
+    finally:
+        eng.close()
