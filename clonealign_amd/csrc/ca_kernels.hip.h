@@ -2372,7 +2372,8 @@ struct ca_cell_ptrs {
 struct ca_cell_pre { float gl; double sn, Anc; };
 template <int CP, bool WR = true>   // WR = false (mc_samples = 2, four draws in one sweep): the monitor pass's pair of samples -- sums only, no coef / d logits
 __device__ __forceinline__ void ca_cell_fused_group(const ca_cell_ptrs& p, const double* la, int64_t n, int64_t N, int C, int D, int K,
-                                                    double ZA, double ZB, ca_cell_acc& acc, const ca_cell_pre* pre = nullptr) {
+                                                    double ZA, double ZB, ca_cell_acc& acc, const ca_cell_pre* pre = nullptr,
+                                                    float* cf_out = nullptr /* this lane's coef as stored (0 where none), for a caller that goes on with it */) {
   const int c = threadIdx.x % CP;
   auto gmax = [](double v) {
 #pragma unroll
@@ -2418,6 +2419,7 @@ __device__ __forceinline__ void ca_cell_fused_group(const ca_cell_ptrs& p, const
   } else
   if (ok) {
     const float cfv = (float)(-gam * sn / ZB);
+    if (cf_out) *cf_out = cfv;
     if constexpr (CP == 16) {   // 9..16 clones: coef in clone chunks of 8 like Lb; two bf16 parts, slot = 2 * part + chunk (k_bwd_mfma<.., C16>)
       p.coef[((int64_t)(cc >> 3) * N + nn) * CA_CW + (cc & 7)] = cfv;
       if (p.coefq) {

@@ -11,7 +11,7 @@
 
 struct ca_poly_hdr { double vlo, delta, xmax; int nb, bad; };
 struct ca_poly_ws {
-  ca_poly_hdr* hdr; double *tabB, *partB, *tabQ, *Qpart;
+  ca_poly_hdr* hdr; unsigned int* xbits; double *tabB, *partB, *tabQ, *Qpart;
   int n_cell_blocks, n_gene_blocks;
 };
 
@@ -19,9 +19,19 @@ struct ca_poly_ws {
 inline bool ca_poly_ok(int D, int S, int C) { return D == 1 && S == 1 && C >= 3 && C <= 8; }
 size_t ca_poly_workspace_bytes(int G, int n_cell_blocks);
 void ca_poly_bind(ca_poly_ws* w, void* base, int G, int n_cell_blocks);
-// forward: the moments of both draws' M, then per cell Z (both draws), dZ/dx (train draw), the cell epilogue (cell_ptrs: a ca_cell_ptrs whose etamax2 is a
-// zero vector), d/dF into dF[N] and the backward moments.  backward: red_g[g][0] = d/dmu, red_g[g][1] = d/dV (the sweep's share, as k_bwd_mfma + k_colsum leave it).
-hipError_t ca_poly_forward(hipStream_t st, const ca_poly_ws* w, const float* V, const float* F, const float* muA, const float* muB, const float* Lb, int G,
-                           int64_t N, int C, int K, const void* cell_ptrs, const float* alpha_u, double* cell_part, float* dF,
-                           unsigned int* bad_word /* mapped host word set to 1 when the exponent range needs more than CA_PL_NB bins, or NULL */);
-hipError_t ca_poly_backward(hipStream_t st, const ca_poly_ws* w, const float* V, const float* mu, const float* Lb, int G, int C, double* red_g);
+// forward, two steps: (1) the moments of both draws' M over the gene bins (three small launches); (2) per cell Z (both draws), dZ/dx (train draw), the cell
+// epilogue (cell_ptrs: a ca_cell_ptrs whose etamax2 is a zero vector), d/dF into dF[N] and the backward moments.  backward: red_g[g][0] = d/dmu,
+// red_g[g][1] = d/dV (the sweep's share, as k_bwd_mfma + k_colsum leave it).
+hipError_t ca_poly_moments(hipStream_t st, const ca_poly_ws* w, const float* V, const float* F, const float* muA, const float* muB, const float* Lb, int G,
+                           int64_t N, int C, unsigned int* bad_word /* mapped host word set to 1 when the exponent range needs more than CA_PL_NB bins, or NULL */,
+                           double* mirror /* mapped host slot {seq, max|x|, min v, max v} of this state's ranges, or NULL */, double seq);
+// the ranges alone (two tiny launches): a pass that takes the sweeps keeps the host's picture current with it
+hipError_t ca_poly_ranges(hipStream_t st, const ca_poly_ws* w, const float* V, const float* F, int G, int64_t N, double* mirror, double seq);
+// can the series form cover a state whose ranges were (xmax, vlo, vhi) `steps` Adam steps ago, none of which moved a variable by more than `step_bound`?
+inline bool ca_poly_covers(double xmax, double vlo, double vhi, int steps, double step_bound) {
+  const double x = xmax + steps * step_bound, wdt = (vhi - vlo) + 2.0 * steps * step_bound;
+  return x == x && wdt == wdt && x * wdt <= 2.0 * CA_PL_A * CA_PL_NB;   // nb = ceil(x w / (2 a)) <= NB
+}
+hipError_t ca_poly_cells(hipStream_t st, const ca_poly_ws* w, int64_t N, int C, int K, const void* cell_ptrs, const float* alpha_u, double* cell_part, float* dF);
+hipError_t ca_poly_backward(hipStream_t st, const ca_poly_ws* w, const float* V, const float* mu, const float* Lb, int G, int C, double* red_g,
+                            const void* small_tail /* a ca_small_args (pending monitor tail, run by an extra block) or NULL */);

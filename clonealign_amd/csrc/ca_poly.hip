@@ -19,14 +19,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+#include <cstring>
+
 #include "ca_poly.h"
 
 namespace {
 #include "ca_kernels.hip.h"   // the cell epilogue and its helpers (internal linkage here: this unit instantiates only what it launches)
 
 constexpr int R = CA_PL_R, NB = CA_PL_NB;
-constexpr int TB_B = 256;       // k_poly_B block
-constexpr int GPB = 128;        // genes per k_poly_B block
+constexpr int TB_B = 384;       // k_poly_B block: one thread per (k, column) output (21 x 16 = 336)
+constexpr int GPB = 32;         // genes per k_poly_B block
 
 __device__ __forceinline__ float warp_max(float v) {
 #pragma unroll
@@ -39,30 +42,94 @@ __device__ __forceinline__ float warp_min(float v) {
   return v;
 }
 
+// the ranges of one parameter state, for the host's look ahead (ca_poly_guard in the engine): values first, the sequence number last
+__device__ __forceinline__ void ca_poly_mirror_store(double* m, double seq, double xmax, double vlo, double vhi) {
+  __hip_atomic_store(m + 1, xmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(m + 2, vlo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(m + 3, vhi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  __hip_atomic_store(m, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ---- K0: max |x| over the cells (an order-preserving unsigned maximum: exact whatever the order); k_poly_red resets the word behind its reader ------------
+__global__ void __launch_bounds__(CA_TB) k_poly_xmax(const float* __restrict__ F, int64_t N, unsigned int* __restrict__ xbits) {
+  __shared__ float sx[CA_TB / 64];
+  float ax = 0.f;
+  const int64_t n4 = N / 4;
+  const float4* F4 = reinterpret_cast<const float4*>(F);
+  for (int64_t i = (int64_t)blockIdx.x * CA_TB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * CA_TB) {
+    const float4 v = F4[i];
+    ax = fmaxf(fmaxf(ax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(N - n4 * 4)) ax = fmaxf(ax, fabsf(F[n4 * 4 + threadIdx.x]));
+  ax = warp_max(ax);
+  if ((threadIdx.x & 63) == 0) sx[threadIdx.x >> 6] = ax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ax = fmaxf(fmaxf(sx[0], sx[1]), fmaxf(sx[2], sx[3]));
+    if (!(ax == ax)) ax = INFINITY;                      // (a NaN latent position: the header's `bad` says so)
+    atomicMax(xbits, __float_as_uint(ax));               // non-negative floats order like their bit patterns
+  }
+}
+
+// ---- ranges only: one block scans V, takes the cells' maximum from k_poly_xmax's word (and resets it), mirrors both to the host -------------------------
+__global__ void __launch_bounds__(CA_TB) k_poly_ranges(const float* __restrict__ V, int G, unsigned int* __restrict__ xbits, double* __restrict__ mirror, double seq) {
+  __shared__ float smn[CA_TB / 64], smx[CA_TB / 64];
+  const int t = threadIdx.x;
+  float mn = INFINITY, mx = -INFINITY;
+  constexpr int U = 8;
+  for (int g0_ = 0; g0_ < G; g0_ += CA_TB * U) {
+    float v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const int g = g0_ + u * CA_TB + t; v[u] = V[g < G ? g : G - 1]; }
+#pragma unroll
+    for (int u = 0; u < U; ++u) { mn = fminf(mn, v[u]); mx = fmaxf(mx, v[u]); }
+  }
+  mn = warp_min(mn); mx = warp_max(mx);
+  if ((t & 63) == 0) { smn[t >> 6] = mn; smx[t >> 6] = mx; }
+  __syncthreads();
+  if (t == 0) {
+    mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+    mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+    const double xmax = (double)__uint_as_float(*xbits);
+    *xbits = 0u;
+    ca_poly_mirror_store(mirror, seq, xmax, (double)mn, (double)mx);
+  }
+}
+
 // ---- K1: bin geometry (every block makes the same one: min / max are exact in any order) and the forward moments ----------------------------------
 // part[blk][b][k][col] block partials (the 1 / k! inside the powers), summed in block order by k_poly_red into tabB[b][k][col].
 // col: draw A clones 0..7 | draw B clones 0..7.  (The blocks of one launch share nothing: the XCDs' L2s are not coherent with each other, and a
 // device-scope fence per block costs more than the kernel boundary the reduction gets for free.)
-__global__ void __launch_bounds__(TB_B) k_poly_B(const float* __restrict__ V, const float* __restrict__ F, const float* __restrict__ muA,
-                                                 const float* __restrict__ muB, const float* __restrict__ Lb /*[G][8]*/, int G, int64_t N, int C,
-                                                 ca_poly_hdr* __restrict__ hdr, double* __restrict__ part, unsigned int* __restrict__ bad_word) {
-  __shared__ float smn[TB_B / 64], smx[TB_B / 64], sax[TB_B / 64];
+__global__ void __launch_bounds__(TB_B) k_poly_B(const float* __restrict__ V, const unsigned int* __restrict__ xbits, const float* __restrict__ muA,
+                                                 const float* __restrict__ muB, const float* __restrict__ Lb /*[G][8]*/, int G, int C,
+                                                 ca_poly_hdr* __restrict__ hdr, double* __restrict__ part, unsigned int* __restrict__ bad_word,
+                                                 double* __restrict__ mirror /* mapped host ring slot {seq, xmax, vlo, vhi} or null */, double seq) {
+  __shared__ float smn[TB_B / 64], smx[TB_B / 64];
   __shared__ double pw[GPB][R + 1];
   __shared__ double Mg[GPB][16];
   __shared__ int binof[GPB];
   __shared__ unsigned int present[(NB + 31) / 32];
   const int t = threadIdx.x;
-  float mn = INFINITY, mx = -INFINITY, ax = 0.f;
-  for (int g = t; g < G; g += TB_B) { const float v = V[g]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
-  for (int64_t n = t; n < N; n += TB_B) ax = fmaxf(ax, fabsf(F[n]));
-  mn = warp_min(mn); mx = warp_max(mx); ax = warp_max(ax);
-  if ((t & 63) == 0) { smn[t >> 6] = mn; smx[t >> 6] = mx; sax[t >> 6] = ax; }
+  float mn = INFINITY, mx = -INFINITY;
+  {   // (eight loads in flight: a load per iteration waited for the one before -- 0.5 us each)
+    constexpr int U = 8;
+    for (int g0_ = 0; g0_ < G; g0_ += TB_B * U) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { const int g = g0_ + u * TB_B + t; v[u] = V[g < G ? g : G - 1]; }
+#pragma unroll
+      for (int u = 0; u < U; ++u) { mn = fminf(mn, v[u]); mx = fmaxf(mx, v[u]); }
+    }
+  }
+  mn = warp_min(mn); mx = warp_max(mx);
+  if ((t & 63) == 0) { smn[t >> 6] = mn; smx[t >> 6] = mx; }
   if (t < (NB + 31) / 32) present[t] = 0u;
   __syncthreads();
-  mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
-  mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
-  ax = fmaxf(fmaxf(sax[0], sax[1]), fmaxf(sax[2], sax[3]));
-  const double vlo = (double)mn, width = (double)mx - (double)mn, xmax = (double)ax;
+  mn = smn[0]; mx = smx[0];
+#pragma unroll
+  for (int w_ = 1; w_ < TB_B / 64; ++w_) { mn = fminf(mn, smn[w_]); mx = fmaxf(mx, smx[w_]); }
+  const double vlo = (double)mn, width = (double)mx - (double)mn, xmax = (double)__uint_as_float(*xbits);
   int nb = (int)ceil(xmax * width / (2.0 * CA_PL_A));
   nb = nb < 1 ? 1 : (nb > NB ? NB : nb);
   const double delta = width > 0.0 ? width / nb : 1.0;
@@ -70,6 +137,7 @@ __global__ void __launch_bounds__(TB_B) k_poly_B(const float* __restrict__ V, co
   if (blockIdx.x == 0 && t == 0) {
     hdr->vlo = vlo; hdr->delta = delta; hdr->xmax = xmax; hdr->nb = nb;
     if (bad) { hdr->bad = 1; if (bad_word) __hip_atomic_store(bad_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }   // (the host looks at its next synchronisation)
+    if (mirror) ca_poly_mirror_store(mirror, seq, xmax, vlo, (double)mx);
   }
   // this block's genes: bin, powers of (v - v_b) over k!, the sixteen M columns
   const int g0 = blockIdx.x * GPB;
@@ -83,7 +151,8 @@ __global__ void __launch_bounds__(TB_B) k_poly_B(const float* __restrict__ V, co
       atomicOr(&present[b >> 5], 1u << (b & 31));
       const double dv = v - (vlo + ((double)b + 0.5) * delta);
       double p = 1.0;
-      for (int k = 0; k <= R; ++k) { pw[t][k] = p; p = p * dv / (double)(k + 1); }
+#pragma unroll
+      for (int k = 0; k <= R; ++k) { pw[t][k] = p; p = p * dv * (1.0 / (double)(k + 1)); }   // (the reciprocals are compile-time constants)
       const double ma = (double)muA[g], mb = (double)muB[g];
       for (int c = 0; c < 8; ++c) {
         const double l = c < C ? (double)Lb[(int64_t)g * CA_CW + c] : 0.0;
@@ -95,15 +164,30 @@ __global__ void __launch_bounds__(TB_B) k_poly_B(const float* __restrict__ V, co
   const int ng = min(GPB, G - g0);
   constexpr int NO = (R + 1) * 16;
   double* mine = part + (int64_t)blockIdx.x * NB * NO;
-  for (int b = 0; b < nb; ++b) {
-    const bool any = (present[b >> 5] >> (b & 31)) & 1u;   // (uniform)
-    for (int o = t; o < NO; o += TB_B) {
-      double acc = 0.0;
-      if (any) {
-        const int k = o >> 4, col = o & 15;
-        for (int i = 0; i < ng; ++i) acc += binof[i] == b ? pw[i][k] * Mg[i][col] : 0.0;
+  if (t < NO) {
+    const int k = t >> 4, col = t & 15;
+    // ONE pass over the block's genes for the first four bins (the usual case is one to three): four accumulators, genes in order
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    if (nb == 1) {   // (uniform: one bin, no selects)
+#pragma unroll 8
+      for (int i = 0; i < ng; ++i) a0 += pw[i][k] * Mg[i][col];
+    } else {
+#pragma unroll 4
+      for (int i = 0; i < ng; ++i) {
+        const double pr = pw[i][k] * Mg[i][col];
+        const int bi = binof[i];
+        a0 += bi == 0 ? pr : 0.0; a1 += bi == 1 ? pr : 0.0; a2 += bi == 2 ? pr : 0.0; a3 += bi == 3 ? pr : 0.0;
       }
-      mine[(int64_t)b * NO + o] = acc;
+    }
+    mine[0 * NO + t] = a0;
+    if (nb > 1) mine[1 * NO + t] = a1;
+    if (nb > 2) mine[2 * NO + t] = a2;
+    if (nb > 3) mine[3 * NO + t] = a3;
+    for (int b = 4; b < nb; ++b) {          // (a wide exponent range)
+      double acc = 0.0;
+      if ((present[b >> 5] >> (b & 31)) & 1u)
+        for (int i = 0; i < ng; ++i) acc += binof[i] == b ? pw[i][k] * Mg[i][col] : 0.0;
+      mine[(int64_t)b * NO + t] = acc;
     }
   }
 }
@@ -115,21 +199,24 @@ __global__ void __launch_bounds__(CA_TB) k_poly_cell(const ca_poly_hdr* __restri
                                                      float* __restrict__ dF /*[N]*/, double* __restrict__ Qpart /*[grid][nb][R+2][C]*/) {
   constexpr int CPB = CA_TB / CP;             // cells per pass of the block
   constexpr int RQ = R + 2;                   // moments 0 .. R + 1 (the derivative of q needs one more)
-  constexpr int NOI = (NB * RQ * 8 + CA_TB - 1) / CA_TB;
+  constexpr int NBR = 4;                      // bins whose moments a thread keeps in registers (the usual case: one to three bins); the rest go through its slab
   __shared__ double sm[CA_TB];
   __shared__ double la[64];
   __shared__ double s_eb[CPB][NB];            // exp(x v_b)
   __shared__ double s_xp[CPB][RQ];            // x^k
   __shared__ double s_cf[CPB][8];             // coef
   ca_log_softmax_alpha(alpha_u, C, la);
+  for (int i = threadIdx.x; i < CPB * NB; i += CA_TB) (&s_eb[0][0])[i] = 0.0;   // (bins past nb: zeros, so that the gather needs no bounds)
   __syncthreads();
   const int t = threadIdx.x, c = t % CP, slot = t / CP;
   const int nb = hdr->nb;
   const double vlo = hdr->vlo, delta = hdr->delta;
-  const int nout = nb * RQ * C;
-  double qacc[NOI];
-#pragma unroll
-  for (int i = 0; i < NOI; ++i) qacc[i] = 0.0;
+  // backward moments: thread t < (R + 2) C owns (k, clone) = (t / C, t % C) of EVERY bin -- nobody else adds to its outputs, cells are added in cell order
+  const bool qown = t < RQ * C;
+  const int qk = qown ? t / C : 0, qc = qown ? t % C : 0;
+  double qa[NBR] = {0.0, 0.0, 0.0, 0.0};
+  double* mine = Qpart + (int64_t)blockIdx.x * (NB * RQ * 8);
+  if (qown) for (int b = NBR; b < nb; ++b) mine[(b * RQ + qk) * C + qc] = 0.0;
   ca_cell_acc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
   const int64_t ngroups = (N + CPB - 1) / CPB;
   const int cc = c < C ? c : C - 1;
@@ -143,7 +230,7 @@ __global__ void __launch_bounds__(CA_TB) k_poly_cell(const ca_poly_hdr* __restri
       const double e = exp(x * vb);
       const double* tb = tabB + ((int64_t)b * (R + 1)) * 16;
       double pa = tb[R * 16 + cc], pb = tb[R * 16 + 8 + cc], dpb = 0.0;
-#pragma unroll 4
+#pragma unroll 10
       for (int k = R - 1; k >= 0; --k) {
         dpb = dpb * x + pb;
         pa = pa * x + tb[k * 16 + cc];
@@ -152,69 +239,86 @@ __global__ void __launch_bounds__(CA_TB) k_poly_cell(const ca_poly_hdr* __restri
       ZA += e * pa; ZB += e * pb; dZB += e * (vb * pb + dpb);
       if (c == 0) s_eb[slot][b] = e;
     }
-    {   // x^k, the lanes of a cell sharing the work
+    {   // x^k, the lanes of a cell sharing the stores
       double xk = 1.0;
       for (int k = 0; k < RQ; ++k) { if (k % CP == c) s_xp[slot][k] = xk; xk *= x; }
     }
-    ca_cell_fused_group<CP>(p, la, n, N, C, 1, K, ZA, ZB, acc);
+    float cff = 0.f;
+    ca_cell_fused_group<CP>(p, la, n, N, C, 1, K, ZA, ZB, acc, nullptr, &cff);
     // this lane's coef as the epilogue stored it (float: what the matrix-core way back reads as well); d/dF = sum_c coef dZ/dx
-    const bool ok = n < N && c < C;
-    const double cf = ok ? (double)p.coef[nn * CA_CW + cc] : 0.0;
+    const double cf = (double)cff;
     double df = cf * dZB;
 #pragma unroll
     for (int o = CP / 2; o > 0; o >>= 1) df += __shfl_xor(df, o, CP);
     if (c == 0 && n < N) dF[n] = (float)df;
     if (c < 8) s_cf[slot][c] = cf;
     __syncthreads();
-    // backward moments: output j = (b, k, clone) gathers over the cells of this pass, in cell order
-#pragma unroll
-    for (int i = 0; i < NOI; ++i) {
-      const int j = t + i * CA_TB;
-      if (j < nout) {
-        const int cl = j % C, k = (j / C) % RQ, b = j / (C * RQ);
-        double a = qacc[i];
-        for (int s = 0; s < CPB; ++s) a += s_cf[s][cl] * s_eb[s][b] * s_xp[s][k];
-        qacc[i] = a;
+    if (qown) {
+      // (loads batched eight cells at a time: a load per step waited for the one before, and that chain WAS this kernel; bins past nb hold zeros)
+      if (nb == 1) {
+#pragma unroll 8
+        for (int s = 0; s < CPB; ++s) qa[0] += s_cf[s][qc] * s_xp[s][qk] * s_eb[s][0];
+      } else {
+#pragma unroll 8
+        for (int s = 0; s < CPB; ++s) {
+          const double w = s_cf[s][qc] * s_xp[s][qk];
+          qa[0] += w * s_eb[s][0]; qa[1] += w * s_eb[s][1]; qa[2] += w * s_eb[s][2]; qa[3] += w * s_eb[s][3];
+        }
+      }
+      for (int b = NBR; b < nb; ++b) {        // (a wide exponent range: the thread's own words of its block's slab, cell order all the same)
+        double a = mine[(b * RQ + qk) * C + qc];
+        for (int s = 0; s < CPB; ++s) a += s_cf[s][qc] * s_xp[s][qk] * s_eb[s][b];
+        mine[(b * RQ + qk) * C + qc] = a;
       }
     }
     __syncthreads();
   }
   ca_cell_fused_finish<CP>(acc, sm, cell_part, blockIdx.x, C);
-  double* mine = Qpart + (int64_t)blockIdx.x * (NB * RQ * 8);
+  if (qown) {
 #pragma unroll
-  for (int i = 0; i < NOI; ++i) {
-    const int j = t + i * CA_TB;
-    if (j < nout) mine[j] = qacc[i];
+    for (int b = 0; b < NBR; ++b) if (b < nb) mine[(b * RQ + qk) * C + qc] = qa[b];
   }
 }
 
 // ---- fixed-order sums of the block partials: one wave per output, lanes stride over the blocks, then the wave's tree (same order every time) --------
 // mode 0: plain sum (tabB); mode 1: sum / k! with k = (j / C) % (R + 2) (tabQ = Q_k / k!)
 __global__ void __launch_bounds__(CA_TB) k_poly_red(const double* __restrict__ part, int nblk, int64_t stride, const ca_poly_hdr* __restrict__ hdr, int per_bin,
-                                                    int mode, int C, double* __restrict__ out) {
-  const int j = blockIdx.x * (CA_TB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+                                                    int mode, int C, double* __restrict__ out, unsigned int* __restrict__ xbits) {
+  if (xbits && blockIdx.x == 0 && threadIdx.x == 0) *xbits = 0u;   // (its reader, k_poly_B, is complete: ready for the next state's maximum)
+  const int lane = threadIdx.x & 63, nwave = gridDim.x * (CA_TB / 64);
   const int nout = hdr->nb * per_bin;
-  if (j >= nout) return;
-  double a = 0.0;
-  for (int blk = lane; blk < nblk; blk += 64) a += part[(int64_t)blk * stride + j];
+  for (int j = blockIdx.x * (CA_TB / 64) + (threadIdx.x >> 6); j < nout; j += nwave) {
+    // (up to eight loads in flight per lane: a miss to another XCD's data costs a microsecond, a chain of them is the kernel)
+    double v[8];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
-  if (lane == 0) {
-    if (mode == 1) {
-      const int k = (j / C) % (R + 2);
-      double f = 1.0;
-      for (int i = 2; i <= k; ++i) f *= (double)i;
-      a /= f;
+    for (int u = 0; u < 8; ++u) { const int blk = lane + 64 * u; v[u] = blk < nblk ? part[(int64_t)blk * stride + j] : 0.0; }
+    double a = 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a += v[u];
+    for (int blk = lane + 512; blk < nblk; blk += 64) a += part[(int64_t)blk * stride + j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
+    if (lane == 0) {
+      if (mode == 1) {
+        const int k = (j / C) % (R + 2);
+        double f = 1.0;
+        for (int i = 2; i <= k; ++i) f *= (double)i;
+        a /= f;
+      }
+      out[j] = a;
     }
-    out[j] = a;
   }
 }
 
 // ---- K3: per gene: the two gradient sums from its bin's polynomial ---------------------------------------------------------------------------------
 __global__ void __launch_bounds__(CA_TB) k_poly_gene(const ca_poly_hdr* __restrict__ hdr, const double* __restrict__ tabQ, const float* __restrict__ V,
                                                      const float* __restrict__ mu, const float* __restrict__ Lb, int G, int C,
-                                                     double* __restrict__ red_g /*[G][2]: d/dmu, d/dV*/) {
+                                                     double* __restrict__ red_g /*[G][2]: d/dmu, d/dV*/, ca_small_args tail, int ngblk) {
   constexpr int RQ = R + 2;
+  if ((int)blockIdx.x >= ngblk) {   // a pending monitor pass's tail (cell partials -> red, psi.(YW) sum, ELBO assembly): the extra block, as on the matrix-core way back
+    if (tail.enabled) ca_final_small_body(tail);
+    return;
+  }
   const int g = blockIdx.x * CA_TB + threadIdx.x;
   if (g >= G) return;
   const int nb = hdr->nb;
@@ -245,12 +349,13 @@ inline int cdiv_i(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 size_t ca_poly_workspace_bytes(int G, int n_cell_blocks) {
   const size_t nbg = (size_t)cdiv_i(G, GPB);
-  return sizeof(ca_poly_hdr) + sizeof(double) * ((size_t)NB * (R + 1) * 16 * (nbg + 1) + (size_t)NB * (R + 2) * 8 * ((size_t)n_cell_blocks + 1));
+  return sizeof(ca_poly_hdr) + 64 + sizeof(double) * ((size_t)NB * (R + 1) * 16 * (nbg + 1) + (size_t)NB * (R + 2) * 8 * ((size_t)n_cell_blocks + 1));
 }
 
 void ca_poly_bind(ca_poly_ws* w, void* base, int G, int n_cell_blocks) {
   char* q = static_cast<char*>(base);
   w->hdr = reinterpret_cast<ca_poly_hdr*>(q); q += sizeof(ca_poly_hdr);
+  w->xbits = reinterpret_cast<unsigned int*>(q); q += 64;
   const size_t nbg = (size_t)cdiv_i(G, GPB);
   w->tabB = reinterpret_cast<double*>(q); q += sizeof(double) * (size_t)NB * (R + 1) * 16;
   w->partB = reinterpret_cast<double*>(q); q += sizeof(double) * (size_t)NB * (R + 1) * 16 * nbg;
@@ -259,24 +364,39 @@ void ca_poly_bind(ca_poly_ws* w, void* base, int G, int n_cell_blocks) {
   w->n_cell_blocks = n_cell_blocks; w->n_gene_blocks = (int)nbg;
 }
 
-hipError_t ca_poly_forward(hipStream_t st, const ca_poly_ws* w, const float* V, const float* F, const float* muA, const float* muB, const float* Lb, int G,
-                           int64_t N, int C, int K, const void* cell_ptrs, const float* alpha_u, double* cell_part, float* dF, unsigned int* bad_word) {
+hipError_t ca_poly_ranges(hipStream_t st, const ca_poly_ws* w, const float* V, const float* F, int G, int64_t N, double* mirror, double seq) {
+  hipLaunchKernelGGL(k_poly_xmax, dim3((unsigned)std::min<int64_t>(128, (N + 4 * CA_TB - 1) / (4 * CA_TB))), dim3(CA_TB), 0, st, F, N, w->xbits);
+  hipLaunchKernelGGL(k_poly_ranges, dim3(1), dim3(CA_TB), 0, st, V, G, w->xbits, mirror, seq);
+  return hipGetLastError();
+}
+
+hipError_t ca_poly_moments(hipStream_t st, const ca_poly_ws* w, const float* V, const float* F, const float* muA, const float* muB, const float* Lb, int G,
+                           int64_t N, int C, unsigned int* bad_word, double* mirror, double seq) {
+  hipLaunchKernelGGL(k_poly_xmax, dim3((unsigned)std::min<int64_t>(128, (N + 4 * CA_TB - 1) / (4 * CA_TB))), dim3(CA_TB), 0, st, F, N, w->xbits);
+  hipLaunchKernelGGL(k_poly_B, dim3(w->n_gene_blocks), dim3(TB_B), 0, st, V, w->xbits, muA, muB, Lb, G, C, w->hdr, w->partB, bad_word, mirror, seq);
+  hipLaunchKernelGGL(k_poly_red, dim3(256), dim3(CA_TB), 0, st, w->partB, w->n_gene_blocks, (int64_t)NB * (R + 1) * 16, w->hdr,
+                     (R + 1) * 16, 0, C, w->tabB, w->xbits);
+  return hipGetLastError();
+}
+
+hipError_t ca_poly_cells(hipStream_t st, const ca_poly_ws* w, int64_t N, int C, int K, const void* cell_ptrs, const float* alpha_u, double* cell_part, float* dF) {
   const ca_cell_ptrs& p = *static_cast<const ca_cell_ptrs*>(cell_ptrs);
-  hipLaunchKernelGGL(k_poly_B, dim3(w->n_gene_blocks), dim3(TB_B), 0, st, V, F, muA, muB, Lb, G, N, C, w->hdr, w->partB, bad_word);
-  hipLaunchKernelGGL(k_poly_red, dim3(cdiv_i((int64_t)NB * (R + 1) * 16, CA_TB / 64)), dim3(CA_TB), 0, st, w->partB, w->n_gene_blocks, (int64_t)NB * (R + 1) * 16, w->hdr,
-                     (R + 1) * 16, 0, C, w->tabB);
   int CP = 1;
   while (CP < C) CP <<= 1;
   const dim3 grid(w->n_cell_blocks);
 #define CA_PCELL(CPV) hipLaunchKernelGGL((k_poly_cell<CPV>), grid, dim3(CA_TB), 0, st, w->hdr, w->tabB, p, alpha_u, cell_part, N, C, K, dF, w->Qpart)
   if (CP == 4) CA_PCELL(4); else CA_PCELL(8);   // (3 .. 8 clones: ca_poly_ok)
 #undef CA_PCELL
-  hipLaunchKernelGGL(k_poly_red, dim3(cdiv_i((int64_t)NB * (R + 2) * C, CA_TB / 64)), dim3(CA_TB), 0, st, w->Qpart, w->n_cell_blocks, (int64_t)NB * (R + 2) * 8, w->hdr,
-                     (R + 2) * C, 1, C, w->tabQ);
+  hipLaunchKernelGGL(k_poly_red, dim3(256), dim3(CA_TB), 0, st, w->Qpart, w->n_cell_blocks, (int64_t)NB * (R + 2) * 8, w->hdr,
+                     (R + 2) * C, 1, C, w->tabQ, nullptr);
   return hipGetLastError();
 }
 
-hipError_t ca_poly_backward(hipStream_t st, const ca_poly_ws* w, const float* V, const float* mu, const float* Lb, int G, int C, double* red_g) {
-  hipLaunchKernelGGL(k_poly_gene, dim3(cdiv_i(G, CA_TB)), dim3(CA_TB), 0, st, w->hdr, w->tabQ, V, mu, Lb, G, C, red_g);
+hipError_t ca_poly_backward(hipStream_t st, const ca_poly_ws* w, const float* V, const float* mu, const float* Lb, int G, int C, double* red_g, const void* small_tail) {
+  ca_small_args tail;
+  static_assert(sizeof(ca_small_args) <= 512, "ca_small_args");
+  if (small_tail) memcpy(&tail, small_tail, sizeof(tail)); else memset(&tail, 0, sizeof(tail));
+  const int ngblk = cdiv_i(G, CA_TB);
+  hipLaunchKernelGGL(k_poly_gene, dim3(ngblk + (tail.enabled ? 1 : 0)), dim3(CA_TB), 0, st, w->hdr, w->tabQ, V, mu, Lb, G, C, red_g, tail, ngblk);
   return hipGetLastError();
 }

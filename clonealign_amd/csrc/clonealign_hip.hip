@@ -164,7 +164,12 @@ struct ca_engine {
   // the series form of the forward / backward contraction (ca_poly.hip; one exponent dimension, one MC sample, 3..8 clones): an overlay on the fused loop --
   // fused_pass makes Z by it and leaves the backward moments in the workspace (poly_fresh: they belong to the look-ahead half look_valid refers to),
   // train_bwd turns them into the per-gene sums, train_update reads d/dF from ONE slab (poly_df)
-  bool poly = false, poly_fresh = false, poly_df = false; ca_poly_ws pws; float* poly_zero = nullptr; unsigned char* poly_mem = nullptr;
+  // the host's look ahead at the exponent range (poly_guard): every pass of a series-capable engine leaves {seq, max|psi|, min W, max W} of ITS state in a
+  // mapped ring; the pass with sequence number s decides from the entry s - CA_POLY_LAG exactly (waiting for it if need be: the queue is never more than
+  // that deep) and the bound of an Adam step -- a deterministic decision, the same on every run, and never a truncated series
+  int64_t n_series = 0, n_series_fallback = 0;
+  double *poly_ring = nullptr, *poly_ring_dev = nullptr; uint64_t poly_seq = 0, poly_seq_base = 1, adam_steps = 0, poly_steps_at[16] = {};
+  bool poly = false, poly_side = false, poly_y_defer = false, poly_fresh = false, poly_df = false /* the last backward half was the series form's: d/dF is ONE slab */; ca_poly_ws pws; float* poly_zero = nullptr; unsigned char* poly_mem = nullptr;
   float *Mb2 = nullptr, *mu32B = nullptr, *Zpart2 = nullptr; double* gene_partB = nullptr;
   bool y_defer = false;
   bool ride_ok = false;   // the Y stream's blocks ride on the forward sweep's launch (k_fwd_cell_mix_y) instead of a side stream
@@ -560,6 +565,7 @@ int refresh_derived(ca_engine* h) {
   h->yfin_pending = false;
   h->look_valid = false;
   h->poly_fresh = false;
+  h->poly_seq_base = h->poly_seq + 1;   // (an arbitrary parameter change: ranges seen before it say nothing)
   return CA_OK;
 }
 
@@ -1015,14 +1021,19 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
     h->poly_fresh = false;
     h->fold_now = false;
     CACK(yfin_flush(h));
-    CACK(flush_mon_tail(h));
+    // a pending monitor pass's tail (reduction of the cell partials into red -- which this pass's alpha step reads --, psi.(YW) sum, ELBO assembly) rides as
+    // an extra block of the per-gene launch, as it does on the matrix-core way back; sharded it is a collective of its own
+    ca_small_args bwd_tail = no_small_args();
+    if (is_sharded(h)) CACK(flush_mon_tail(h));
+    else if (h->mon_tail.enabled) { CACK(wait_y(h, false)); bwd_tail = h->mon_tail; h->mon_tail.enabled = 0; }
     CACK(prof_begin(h, CA_KERNEL_BWD));
-    const hipError_t e = ca_poly_backward(h->stream, &h->pws, h->V, mu32, h->Lb, h->G, h->C, h->red + h->off_g);
+    const hipError_t e = ca_poly_backward(h->stream, &h->pws, h->V, mu32, h->Lb, h->G, h->C, h->red + h->off_g, &bwd_tail);
     HIPCK(h, e);
     CACK(prof_end(h));
     h->poly_df = true;
   } else
   if (h->bwd_mfma) {
+    h->poly_df = false;
     const int xb = cdiv(h->nwt, CA_TB / 64);
     // A pending monitor pass's tail rides on the sweep as one extra block (its fp64 chains hide under 130 us of sweep):
     // whole when unsharded; sharded, only the local sums of the cell / psi.(YW) partials -- ONE all-reduce per iteration
@@ -1092,6 +1103,7 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
                                 h->red + h->off_g, h->csplit_m, (int64_t)h->G * W_, h->G * W_));
   } else {
     h->fold_now = false;
+    h->poly_df = false;
     CACK(yfin_flush(h));
     CACK(flush_mon_tail(h));
     for (int s = 0; s < h->S; ++s)
@@ -1126,8 +1138,7 @@ int train_bwd(ca_engine* h, const float* mu32, bool cell_sums_global) {
 // sweep that follows can make the exponent bound itself, K >= 1)
 inline bool update_merges(const ca_engine* h, int apply, const double* elbo_dst) {
   const int64_t mB = h->s2 ? 2 * h->hint_A + 1 : h->hint_B;
-  // (the series form keeps the two-launch update: the merged one leaves the exponent bound of the stepped state to a forward SWEEP's blocks)
-  return apply && h->upd_merge && !elbo_dst && h->pre_ok && h->hint_A >= 0 && mB >= 0 && h->fused_ok && h->gene_part_alt && h->fwd_cell && h->K > 0 && !h->poly;
+  return apply && h->upd_merge && !elbo_dst && h->pre_ok && h->hint_A >= 0 && mB >= 0 && h->fused_ok && h->gene_part_alt && h->fwd_cell && h->K > 0;
 }
 int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
   const int N256 = cdiv(h->N, CA_TB);
@@ -1149,7 +1160,6 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
     psi.nblk = N256; psi.F = h->F; psi.YW = h->YW; psi.dFpart = h->dFpart; psi.m_psi = h->m_psi; psi.v_psi = h->v_psi; psi.g_psi = h->g_psi;
     psi.N = h->N; psi.D = h->D; psi.K = h->K; psi.ntile = h->poly_df ? 1 : h->bwd_mfma ? cdiv(h->nwt, CA_TB / 64) : h->ntile;
   }
-  h->poly_df = false;
   h->pre_valid = false;
   // Round 4: the whole update half in ONE launch (k_update_merged) whenever the loop has announced the next eps pair, the fused forward
   // sweep that follows can make the exponent bound itself (fwd_cell) and K >= 1 -- see the kernel.  Everything else (call-by-call API,
@@ -1229,9 +1239,11 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
       if (h->ys_steps >= 0) h->ys_steps += 1;
       h->b1p *= (float)h->opt.beta1;
       h->b2p *= (float)h->opt.beta2;
+      h->adam_steps += 1;
       h->ycache_valid = false;
       h->yfin_pending = false;
       h->look_valid = false;
+      if (h->poly && h->y_ys) h->poly_y_defer = true;   // series form: the next series pass sends the count-matrix products of the stepped state to the side stream
       return CA_OK;
     }
   }
@@ -1286,9 +1298,11 @@ int train_update(ca_engine* h, const float* eps, int apply, double* elbo_dst) {
     if (h->ys_steps >= 0) h->ys_steps += 1;
     h->b1p *= (float)h->opt.beta1;
     h->b2p *= (float)h->opt.beta2;
+    h->adam_steps += 1;
     h->ycache_valid = false;   // V', its range and etamax2 were refreshed inside the step's own kernels
     h->yfin_pending = false;
     h->look_valid = false;
+    if (h->poly && h->y_ys && h->K > 0) h->poly_y_defer = true;   // (as in the one-launch form above)
   }
   return CA_OK;
 }
@@ -1305,6 +1319,7 @@ int train_tail(ca_engine* h, const float* eps, const float* mu32, int apply, dou
 int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_dst) {
   const float* eps = h->eps_dev + eps_slot * (int64_t)h->S * h->G;
   h->poly_fresh = false;   // (a plain pass makes its own forward half: backward moments left by an unused look-ahead are nobody's)
+  h->poly_y_defer = false;   // (... and runs its count-matrix pass in line, as ever: the deferral was for a series pass)
   CACK(flush_mon_tail(h));
   CACK(ensure_etamax(h));
   if (mode != CA_MODE_TRAIN) h->hint_A = h->hint_B = -1;
@@ -1361,6 +1376,59 @@ int run_pass(ca_engine* h, int64_t eps_slot, int mode, int apply, double* elbo_d
   return CA_OK;
 }
 
+// Series form or sweeps for the pass about to be queued?  See ca_engine::poly_ring.  *use_series = the decision; *mirror / *seq = where and under which
+// number this pass leaves its own ranges (the series form's first launch does; a pass that takes the sweeps queues the two tiny range launches itself,
+// poly_ranges_for_sweeps).
+#define CA_POLY_LAG 4
+int poly_wait_entry(ca_engine* h, uint64_t want, double out[3]) {
+  volatile double* e = h->poly_ring + (want % 16) * 4;
+  unsigned spins = 0;
+  auto t_next = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+  const auto t_end = std::chrono::steady_clock::now() + std::chrono::seconds(20);
+  while (e[0] != (double)want) {
+    if ((++spins & 0x3FFu) == 0 && std::chrono::steady_clock::now() >= t_next) {
+      t_next = std::chrono::steady_clock::now() + std::chrono::milliseconds(20);
+      const hipError_t q = hipStreamQuery(h->stream);
+      if (q != hipSuccess && q != hipErrorNotReady) HIPCK(h, q);
+      if ((q == hipSuccess && e[0] != (double)want) || std::chrono::steady_clock::now() >= t_end) {
+        h->err = "internal: the ranges of an earlier pass never reached the host (series form's look ahead)";
+        return CA_ERR_STATE;
+      }
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  out[0] = e[1]; out[1] = e[2]; out[2] = e[3];
+  return CA_OK;
+}
+int poly_guard(ca_engine* h, bool* use_series, double** mirror, double* seq, bool* ranges_queued) {
+  const uint64_t s = h->poly_seq + 1;
+  *ranges_queued = false;
+  *mirror = h->poly_ring_dev + (s % 16) * 4;
+  *seq = (double)s;
+  double r[3];
+  int steps;
+  if (s < h->poly_seq_base + CA_POLY_LAG) {
+    // the first passes after the ranges became unknown (a new engine, a restart, a set_param): this state's own ranges, now -- the one wait for the device
+    // the look ahead ever makes; the passes behind it count their steps from the base entry
+    if (s == h->poly_seq_base) {
+      HIPCK(h, ca_poly_ranges(h->stream, &h->pws, h->V, h->F, h->G, h->N, *mirror, *seq));
+      *ranges_queued = true;
+      h->poly_steps_at[s % 16] = h->adam_steps;
+    }
+    CACK(poly_wait_entry(h, h->poly_seq_base, r));
+    steps = (int)(h->adam_steps - h->poly_steps_at[h->poly_seq_base % 16]);
+  } else {
+    CACK(poly_wait_entry(h, s - CA_POLY_LAG, r));
+    steps = (int)(h->adam_steps - h->poly_steps_at[(s - CA_POLY_LAG) % 16]);
+  }
+  const double lr = h->opt.learning_rate;
+  const double bound = std::max(lr, lr * (1.0 - h->opt.beta1) / std::sqrt(1.0 - h->opt.beta2)) * 1.0001;   // no Adam step moves a variable further (TF1 form, lr_t <= lr / sqrt(1 - beta2) ...)
+  *use_series = ca_poly_covers(r[0], r[1], r[2], steps, bound);
+  h->poly_seq = s;
+  h->poly_steps_at[s % 16] = h->adam_steps;
+  return CA_OK;
+}
+
 // Monitor pass for eps slot A fused with the forward half of the NEXT train pass (eps slot B): one sweep,
 // one exp per (cell, gene) for both (same parameters, R/inference-tflow.R:401,403 of consecutive iterations).
 int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, double* elbo_dstB = nullptr, int64_t trainA = -1) {
@@ -1387,9 +1455,17 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
   }
   h->pre_valid = false;
   // the Y products of this parameter state: riding on the sweep's own launch (below), or from the side stream / in line
-  const bool ride = (h->ride_ok || h->ride_ys) && !h->ycache_valid && h->fwd_cell && !h->y_defer && !h->y_pending &&
-                    !(h->poly && trainA < 0 && !elbo_dstB && !h->fwd_gate);   // (the series form has no sweep launch to ride on)
-  if (!ride) CACK(ensure_ycache(h));
+  h->poly_fresh = false;   // (backward moments of an earlier, unused look-ahead half are nobody's from here on)
+  bool series = h->poly && !s2f && !elbo_dstB && !h->fwd_gate && !is_sharded(h);   // (sharded: the ranks see different cells, they could decide differently)
+  double* pl_mirror = nullptr; double pl_seq = 0.0;
+  if (series) {
+    bool queued = false;
+    CACK(poly_guard(h, &series, &pl_mirror, &pl_seq, &queued));
+    if (!series && !queued) HIPCK(h, ca_poly_ranges(h->stream, &h->pws, h->V, h->F, h->G, h->N, pl_mirror, pl_seq));   // (the sweeps take this pass: its ranges all the same)
+    if (series) h->n_series += 1; else h->n_series_fallback += 1;
+  }
+  const bool ride = (h->ride_ok || h->ride_ys) && !h->ycache_valid && h->fwd_cell && !h->y_defer && !h->y_pending && !series;   // (the series form has no sweep launch to ride on)
+  if (!ride && !series) CACK(ensure_ycache(h));   // (series: placed between its own launches, below)
   ca_cell_ptrs cp;
   cp.A = h->A; cp.cn = h->cn; cp.s64 = h->s64; cp.etamax2 = h->etamax2; cp.glogit = h->glogit; cp.F = h->F;
   cp.coef = h->coef; cp.dgl = h->dgl; cp.coefq = h->bwd_mfma ? h->coefq : nullptr;
@@ -1399,22 +1475,35 @@ int fused_pass(ca_engine* h, int64_t slotA, int64_t slotB, double* elbo_dst, dou
     if (!(h->fwd_cell && ride && h->ride_ys) || !h->gate_local) { h->err = "internal: a forward sweep queued ahead of the host's decision must be the one-launch form"; return CA_ERR_STATE; }
     cp.gate = h->gate_local; cp.gate_go = (h->gate_seq << 1) | 1ull;
   }
-  if (h->em_stale && h->fwd_cell && h->D > 0) { cp.vmm_at = h->vmm_at + 16 * (1 - h->vmm_at_idx); cp.etamax_w = h->etamax2; h->em_stale = false; }
+  // (the series form needs no exponent bound: after a merged update it stays stale until a pass that wants it asks, ensure_etamax)
+  if (series) {}
+  else if (h->em_stale && h->fwd_cell && h->D > 0) { cp.vmm_at = h->vmm_at + 16 * (1 - h->vmm_at_idx); cp.etamax_w = h->etamax2; h->em_stale = false; }
   else CACK(ensure_etamax(h));
   cp.ee_partB = (elbo_dstB && h->fwd_cell) ? h->ee_partB : nullptr;
   cp.s2 = h->s2 ? 1 : 0; cp.N16 = h->N16;
   int CP = 1;
   while (CP < h->C) CP <<= 1;
   int cell_blocks = h->ncblk;
-  const bool series = h->poly && !s2f && !elbo_dstB && !h->fwd_gate;
   if (series) {
     // Z of both draws from the moments of M over gene bins (ca_poly.hip), the same cell epilogue, d/dF and the backward moments in one pass over
     // the CELLS: no cells x genes sweep.  The count-matrix products of this state run as their own launch (in line).
-    CACK(ensure_ycache(h));
+    // Order: the three small moment launches FIRST, on an empty device (they are chains of memory latencies: beside the stream's blocks they took twice
+    // as long, and the cell launch waits for them); THEN the count-matrix stream goes to the side stream (deferred since the update: poly_y_defer) and runs
+    // beside the cell launch, which is arithmetic.
     cp.etamax2 = h->poly_zero; cp.coefq = nullptr; cp.vmm_at = nullptr; cp.etamax_w = nullptr;
     CACK(prof_begin(h, CA_KERNEL_FWD));
-    const hipError_t e = ca_poly_forward(h->stream, &h->pws, h->V, h->F, h->mu32, h->mu32B, h->Lb, h->G, h->N, h->C, h->K, &cp, h->alpha_u, h->cell_part, h->dFpart,
-                                         h->host_dev ? reinterpret_cast<unsigned int*>(h->host_dev + 42) : nullptr);
+    hipError_t e = ca_poly_moments(h->stream, &h->pws, h->V, h->F, h->mu32, h->mu32B, h->Lb, h->G, h->N, h->C,
+                                   h->host_dev ? reinterpret_cast<unsigned int*>(h->host_dev + 42) : nullptr, pl_mirror, pl_seq);
+    HIPCK(h, e);
+    CACK(prof_end(h));
+    if (h->poly_side && h->poly_y_defer && !h->ycache_valid) {
+      h->poly_y_defer = false;
+      HIPCK(h, hipEventRecord(h->ev_params, h->stream));
+      h->y_defer = true;
+    }
+    CACK(ensure_ycache(h));
+    CACK(prof_begin(h, CA_KERNEL_FWD));
+    e = ca_poly_cells(h->stream, &h->pws, h->N, h->C, h->K, &cp, h->alpha_u, h->cell_part, h->dFpart);
     HIPCK(h, e);
     CACK(prof_end(h));
     cell_blocks = h->pws.n_cell_blocks;
@@ -2475,15 +2564,30 @@ int create_impl(ca_engine* h, const ca_problem* p) {
   CACK(dalloc(h, &h->scratch, Nn * C));
   const int64_t n_cpart = std::max(std::max(h->ncblk, h->ncblk_f), 2 * h->n_cu);   // (balanced sweep: n_cu blocks + up to n_cu - 1 left-over tiles' blocks)
   CACK(dalloc(h, &h->cell_part, n_cpart * (3 + C)));
-  h->poly = ca_poly_ok(D, S, C) && h->fused_ok && !h->c16 && !h->s2 && K == 1 && variantx_on(h, CA_VARX_SERIES, "CA_SERIES");
+  // The series form of the contraction (ca_poly.hip) where it is measured faster than the sweeps: the count-matrix stream then runs as a launch of its own
+  // (in line) and the rest is O(N + G) work in half a dozen small launches -- a gain once the sweeps' N G C dominates (100k x 5k x 8: 191 against 253 us per
+  // iteration; 50k x 3k x 6: 101 against 107), a loss below (25k x 5k: 112 against 91; 10k x 2k: 76 against 38: launch latencies).  CA_VAR_SERIES switches the
+  // pick off, CA_VARX_SERIES forces the form at any size (tests; profiles/r06_series.txt).
+#ifdef CA_SERIES_ALWAYS
+  const bool series_auto = true;   // (shake-out builds: every eligible shape through the series form, whole GPU suite)
+#else
+  const bool series_auto = (double)Nn * (double)G >= 1.4e8 && Nn >= 32768;
+#endif
+  h->poly = ca_poly_ok(D, S, C) && h->fused_ok && !h->c16 && !h->s2 && K == 1 &&
+            ((series_auto && variant_on(h, CA_VAR_SERIES, "CA_SERIES")) || variantx_on(h, CA_VARX_SERIES, "CA_SERIES_ON"));
   if (h->poly) {
     int CPp = 1;
     while (CPp < C) CPp <<= 1;
-    const int ncb = (int)std::min<int64_t>(cdiv(Nn, CA_TB / CPp), 2 * (int64_t)h->n_cu);
+    const int per_cu = (h->opt.reserved[0] >= 1 && h->opt.reserved[0] <= 8) ? h->opt.reserved[0] : 2;   // (ca_options.reserved[0]: cell blocks per CU of the series form, lab)
+    const int ncb = (int)std::min<int64_t>(cdiv(Nn, CA_TB / CPp), (int64_t)per_cu * h->n_cu);   // (<= ncblk: cell_part has a row for each)
+    h->poly_side = h->opt.reserved[1] == 1;   // (ca_options.reserved[1] = 1: the count-matrix stream on the side stream beside the cell launch; default in line)
     const size_t wb = ca_poly_workspace_bytes(G, ncb);
     CACK(dalloc(h, &h->poly_mem, (int64_t)wb));
     HIPCK(h, hipMemsetAsync(h->poly_mem, 0, wb, h->stream));
     ca_poly_bind(&h->pws, h->poly_mem, G, ncb);
+    HIPCK(h, hipHostMalloc((void**)&h->poly_ring, 16 * 4 * sizeof(double), hipHostMallocMapped));
+    memset(h->poly_ring, 0, 16 * 4 * sizeof(double));
+    if (hipHostGetDevicePointer((void**)&h->poly_ring_dev, h->poly_ring, 0) != hipSuccess) { (void)hipGetLastError(); h->poly = false; }
     CACK(dalloc(h, &h->poly_zero, Nn));
     HIPCK(h, hipMemsetAsync(h->poly_zero, 0, (size_t)Nn * sizeof(float), h->stream));
   }
@@ -2775,7 +2879,7 @@ struct gate_snapshot {
   bool look_valid, bwd_ready, pre_valid, em_stale, y_defer, ys_quant_ready, ycache_valid, yfin_pending, fold_now;
   int64_t pre_A, pre_B, hint_A, hint_B, gaux_slot;
   int vmm_at_idx, gaux_idx, ys_steps, ys_namax[3];
-  float b1p, b2p;
+  float b1p, b2p; uint64_t adam_steps;
   float *vchi, *vchi_alt, *alpha_u, *alpha_u_alt;
   void take(const ca_engine* h) {
     look_valid = h->look_valid; bwd_ready = h->bwd_ready; pre_valid = h->pre_valid; em_stale = h->em_stale; y_defer = h->y_defer;
@@ -2783,7 +2887,7 @@ struct gate_snapshot {
     pre_A = h->pre_A; pre_B = h->pre_B; hint_A = h->hint_A; hint_B = h->hint_B; gaux_slot = h->gaux_slot;
     vmm_at_idx = h->vmm_at_idx; gaux_idx = h->gaux_idx; ys_steps = h->ys_steps;
     for (int i = 0; i < 3; ++i) ys_namax[i] = h->ys_namax[i];
-    b1p = h->b1p; b2p = h->b2p;
+    b1p = h->b1p; b2p = h->b2p; adam_steps = h->adam_steps;
     vchi = h->vchi; vchi_alt = h->vchi_alt; alpha_u = h->alpha_u; alpha_u_alt = h->alpha_u_alt;
   }
   void restore(ca_engine* h) const {
@@ -2792,7 +2896,7 @@ struct gate_snapshot {
     h->pre_A = pre_A; h->pre_B = pre_B; h->hint_A = -1; h->hint_B = -1; h->gaux_slot = gaux_slot;
     h->vmm_at_idx = vmm_at_idx; h->gaux_idx = gaux_idx; h->ys_steps = ys_steps;
     for (int i = 0; i < 3; ++i) h->ys_namax[i] = ys_namax[i];
-    h->b1p = b1p; h->b2p = b2p;
+    h->b1p = b1p; h->b2p = b2p; h->adam_steps = adam_steps;
     h->vchi = vchi; h->vchi_alt = vchi_alt; h->alpha_u = alpha_u; h->alpha_u_alt = alpha_u_alt;
   }
 };
@@ -2972,6 +3076,7 @@ int ca_destroy(ca_handle h) {
   if (h->host_pinned) hipHostFree(h->host_pinned);
   if (h->eps_stage) hipHostFree(h->eps_stage);
   if (h->host_ar_buf) hipHostFree(h->host_ar_buf);
+  if (h->poly_ring) hipHostFree(h->poly_ring);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
   return CA_OK;
@@ -2990,7 +3095,7 @@ int ca_get_info(ca_handle h, ca_info* i) {
   i->red_n = h->red_n;
   i->fwd_block_cells = (h->fused_ok && h->fwd_cell) ? 16 * h->fc_tl : 0; i->fwd_blocks_big = h->fc_nbig;
   i->fwd_balanced = h->fwd_bal ? h->bal_q : 0;
-  i->fwd_series = h->poly ? 1 : 0;
+  i->fwd_series = h->poly ? 1 : 0; i->series_passes = h->n_series; i->series_fallbacks = h->n_series_fallback;
   i->fold_gsum = (h->fold_gsum && !is_sharded(h)) ? 1 : 0; i->yfin_split = (h->yfin_split && !is_sharded(h)) ? 1 : 0;
   i->update_merge = (h->upd_merge && h->fused_ok && h->fwd_cell && h->K > 0) ? 1 : 0;
   return CA_OK;

@@ -24,7 +24,7 @@ YSTORE_NAME = {v: k for k, v in YSTORE.items()}
 KERNEL_NAMES = ("fwd", "bwd", "ypass", "cell", "other")
 # ca_variant bits (ca_options.variant_off: a set bit switches the variant OFF) and ca_tune_id slots
 VARIANTS = {"fused": 1 << 0, "fwd_mfma": 1 << 1, "fwd_cell": 1 << 2, "bwd_mfma": 1 << 3, "tail_fuse": 1 << 4, "async_y": 1 << 5,
-            "pre": 1 << 6, "pair_elbo": 1 << 7, "prep_fast": 1 << 8, "update_merge": 1 << 9, "p2p": 1 << 10, "fold_gsum": 1 << 11, "y_ride": 1 << 12, "ride_seq": 1 << 13, "y_mfma1": 1 << 14, "yfin_ride": 1 << 15, "p2p_ride": 1 << 16, "run_gate": 1 << 17, "s2_fuse": 1 << 18, "fwd_bal": 1 << 19, "bwd_tl3": 1 << 20}
+            "pre": 1 << 6, "pair_elbo": 1 << 7, "prep_fast": 1 << 8, "update_merge": 1 << 9, "p2p": 1 << 10, "fold_gsum": 1 << 11, "y_ride": 1 << 12, "ride_seq": 1 << 13, "y_mfma1": 1 << 14, "yfin_ride": 1 << 15, "p2p_ride": 1 << 16, "run_gate": 1 << 17, "s2_fuse": 1 << 18, "fwd_bal": 1 << 19, "bwd_tl3": 1 << 20, "series": 1 << 21}
 VARIANTS_ON = {"y_mfma2": 1 << 0, "async_small": 1 << 1, "y_mfma1": 1 << 2, "fold_always": 1 << 3, "ride_seq": 1 << 4, "p2p_same_device": 1 << 5, "run_fwd": 1 << 6, "bal_tiles": 1 << 7, "series": 1 << 8}      # ca_variant_on: opt-in variants
 OPT_VERBOSE = 0x80000000
 TUNE = {"gsplit": 0, "fsplit": 1, "fc_tl": 2, "fc_nbig": 3, "csplit": 4, "csplit_m": 5, "tr": 6, "rg": 7}
@@ -67,7 +67,8 @@ class CaInfo(C.Structure):
                 ("bwd_mfma", C.c_int32), ("fsplit", C.c_int32), ("fwd_cell", C.c_int32), ("y_mfma", C.c_int32),
                 ("transport", C.c_int32), ("y_ride", C.c_int32), ("red_n", C.c_int64),
                 ("fwd_block_cells", C.c_int32), ("fwd_blocks_big", C.c_int32), ("fold_gsum", C.c_int32), ("yfin_split", C.c_int32),
-                ("update_merge", C.c_int32), ("fwd_balanced", C.c_int32), ("fwd_series", C.c_int32)]
+                ("update_merge", C.c_int32), ("fwd_balanced", C.c_int32), ("fwd_series", C.c_int32), ("reserved_", C.c_int32),
+                ("series_passes", C.c_int64), ("series_fallbacks", C.c_int64)]
 
 
 class CaGroupInfo(C.Structure):
@@ -337,7 +338,9 @@ class HipEngine:
         opt.variant_off = (voff | (OPT_VERBOSE if verbose else 0)) & 0xFFFFFFFF
         opt.variant_on = int(variant_on) if isinstance(variant_on, int) else sum(VARIANTS_ON[v] for v in variant_on)
         for k, v in (tune or {}).items():
-            if k == "ride_pattern":       # (a << 8) | b, or "a:b"
+            if k in ("series_blocks", "series_side"):   # lab knobs of the series form (ca_options.reserved[0 / 1])
+                opt.reserved[0 if k == "series_blocks" else 1] = int(v)
+            elif k == "ride_pattern":       # (a << 8) | b, or "a:b"
                 opt.ride_pattern = (lambda a, b: (int(a) << 8) | int(b))(*str(v).split(":")) if ":" in str(v) else int(v)
             else:
                 opt.tune[TUNE[k]] = int(v)

@@ -107,6 +107,9 @@ enum ca_variant {
                                  work; off: 16- / 32-cell four-wave blocks, as many as the cells need */
   CA_VAR_BWD_TL3 = 1 << 20,   /* small problems (up to 18 432 cells): the matrix-core backward sweep takes three gene tiles per wave instead of four -- more and
                                  shorter wave jobs; off: four at every size */
+  CA_VAR_SERIES = 1 << 21,    /* ABI 6: large problems with a rank-one exponent (K + P = 1, one MC sample, 3..8 clones, 1-byte storage; from 32k cells and 1.4e8
+                                 counts): the loop's contraction in its SERIES form (ca_poly.hip, see CA_VARX_SERIES) -- moments over gene bins instead of the
+                                 cells x genes sweeps; off: the matrix-core sweeps at every size */
   CA_VAR_P2P = 1 << 10,       /* one-shot peer-to-peer all-reduce (else ncclAllReduce) after ca_comm_init() */
   CA_VAR_FOLD_GSUM = 1 << 11, /* small problems: backward-sweep partials summed inside the per-gene kernel (else a k_colsum launch) */
   CA_VAR_Y_RIDE = 1 << 12,    /* the Y stream's blocks ride on the forward sweep's launch (else side stream / in line) */
@@ -141,7 +144,7 @@ enum ca_variant_on {
                                  blocks, no exchange (the stream's blocks then go to the CUs without one); default: the left-over tiles cut gene-wise into chunks
                                  that the sweep blocks sweep beside their own tiles, partial Z exchanged through tagged words.  Level at few left-over tiles,
                                  slower at many */
-  CA_VARX_SERIES = 1 << 8,    /* ABI 6: the loop's contraction in its SERIES form (ca_poly.hip) where the exponent is rank one -- K + P = 1, one MC sample, 3..8
+  CA_VARX_SERIES = 1 << 8,    /* ABI 6: force the series form (CA_VAR_SERIES) at ANY size.  The form: where the exponent is rank one -- K + P = 1, one MC sample, 3..8
                                  clones: Z_nc = sum_g M_gc exp(x_n v_g) is one function of x per clone; genes binned by v, a 20-term expansion per bin (argument <= 2,
                                  float64): moments over genes, evaluation over cells, the same form on the way back.  No cells x genes sweep: O(N nb R C + G R C)
                                  instead of O(N G C) per pass; the cell epilogue is the sweep's.  Other shapes keep the matrix-core sweeps */
@@ -177,7 +180,7 @@ typedef struct ca_options {
   int32_t gate_timeout_us;          /* ca_run with the gated update (CA_VAR_RUN_GATE): how long the queued update's relay block polls for the host's
                                      * go / stop word before the launch gives up -- it then stores nothing, the device goes idle, and the host queues
                                      * the update again after its decision (0 = 1000 us).  Not an error and not a result: only who waits for whom */
-  int32_t reserved[2];
+  int32_t reserved[2];              /* lab knobs of the series form: [0] cell blocks per CU (0 = 2), [1] = 1: its count-matrix stream on the side stream (measured slower) */
 } ca_options;
 /* (The library reads no tuning from the process environment.  Only the timing-lab build, -DCA_LAB -- never the product's .so, its
  *  ca_build_id() starts with "lab-" -- accepts the same switches as CA_* variables, and only when CLONEALIGN_DEBUG_ENV is set.) */
@@ -207,7 +210,10 @@ typedef struct ca_info {
   int32_t yfin_split;        /* 1: the Y stream's finishing step is split between the forward and backward launches */
   int32_t update_merge;      /* 1: the loop's update half is one launch (CA_VAR_UPDATE_MERGE) */
   int32_t fwd_balanced;      /* > 0: the fused forward sweep is the balanced small-problem form (CA_VAR_FWD_BAL), that many tiles per block */
-  int32_t fwd_series;        /* ABI 6: 1: the loop's contraction runs in its series form (CA_VARX_SERIES, ca_poly.hip) */
+  int32_t fwd_series;        /* ABI 6: 1: the loop's contraction takes its series form (CA_VAR_SERIES / CA_VARX_SERIES, ca_poly.hip) wherever the exponent range allows */
+  int32_t reserved_;
+  int64_t series_passes;     /* fused passes of this engine that ran in the series form ... */
+  int64_t series_fallbacks;  /* ... and those the look ahead at the exponent range (max|psi| (max W - min W), plus what the Adam steps since can add) gave to the sweeps */
 } ca_info;
 enum ca_transport { CA_TRANSPORT_NONE = 0, CA_TRANSPORT_RCCL = 1, CA_TRANSPORT_HOST = 2, CA_TRANSPORT_P2P = 3 };
 

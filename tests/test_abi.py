@@ -37,7 +37,7 @@ int main(void) {
   F(ca_problem, Y); F(ca_problem, extra_loglik); F(ca_problem, N_src); F(ca_problem, G_src); F(ca_problem, cell_index); F(ca_problem, gene_index); F(ca_problem, y_ld);
   F(ca_group_info, transport); F(ca_group_info, rebuilds); F(ca_group_info, N); F(ca_group_info, note);
   F(ca_options, seed); F(ca_options, profile); F(ca_options, variant_off); F(ca_options, tune); F(ca_options, variant_on); F(ca_options, ride_pattern); F(ca_options, comm_timeout_ms); F(ca_options, gate_timeout_us); F(ca_options, reserved);
-  F(ca_info, y_device_bytes); F(ca_info, fwd_cell); F(ca_info, y_mfma); F(ca_info, transport); F(ca_info, y_ride); F(ca_info, red_n); F(ca_info, fwd_block_cells); F(ca_info, yfin_split); F(ca_info, fwd_series);
+  F(ca_info, y_device_bytes); F(ca_info, fwd_cell); F(ca_info, y_mfma); F(ca_info, transport); F(ca_info, y_ride); F(ca_info, red_n); F(ca_info, fwd_block_cells); F(ca_info, yfin_split); F(ca_info, fwd_series); F(ca_info, series_passes); F(ca_info, series_fallbacks);
   printf("version %d\n", CA_ABI_VERSION);
   return 0;
 }

@@ -24,7 +24,7 @@ def test_series_loop_matches_the_oracle_and_the_sweeps(name):
     swp = HipEngine(**case)
     ora = FusedModel(**case, dtype="float32")
     try:
-        assert ser.info()["fwd_series"] == 1 and swp.info()["fwd_series"] == 0
+        assert ser.info()["fwd_series"] == 1 and swp.info()["fwd_series"] == 0 and swp.info()["series_passes"] == 0
         ts = np.asarray(ser.run(EpsStream(5, 1, G), n_iter, 1e-12))
         tw = np.asarray(swp.run(EpsStream(5, 1, G), n_iter, 1e-12))
         to = np.asarray(run_vi_loop(ora, EpsStream(5, 1, G), n_iter, 1e-12))
@@ -68,10 +68,11 @@ def test_series_gradients_match_the_oracle():
         ser.close()
 
 
-def test_series_handles_a_wide_exponent_range_with_more_bins_and_says_so_when_it_cannot():
-    """psi and W pushed apart (|x v| up to ~30): more bins, same accuracy; beyond 4 x 32 bins' worth the engine reports it instead of returning a
-    truncated series."""
-    from clonealign_amd.engine import EngineError, HipEngine
+def test_series_handles_a_wide_exponent_range_with_more_bins_and_hands_over_to_the_sweeps_beyond():
+    """psi and W pushed apart (|x v| up to ~30): more bins, same accuracy.  Beyond what 32 bins cover -- max|psi| (max W - min W) > 128, counting what the
+    Adam steps since the last look can add -- the pass is given to the matrix-core sweeps BEFORE it is queued (the host looks ahead at the ranges every
+    pass leaves in mapped memory; ca_info counts both kinds): never a truncated series, never an error, and the same decision on every run."""
+    from clonealign_amd.engine import HipEngine
     from oracle.fused_numpy import FusedModel
     case = make_case(seed=33, N=600, G=200, C=4, K=1)
     G = 200
@@ -86,9 +87,40 @@ def test_series_handles_a_wide_exponent_range_with_more_bins_and_says_so_when_it
         for i in range(2):
             ora.step(eps[2 * i]); e = ora.elbo(eps[2 * i + 1])
         assert abs(a - e) <= 1e-5 * abs(e), (a, e)
-        ser.set("W", W * 40.0)               # |x v| in the hundreds: past what 32 bins cover
-        with pytest.raises(EngineError, match="exponent range"):
-            ser.iterate(2, eps)
-            ser.synchronize()
+        i0 = ser.info()
+        assert i0["series_passes"] >= 2 and i0["series_fallbacks"] == 0, i0
+        Wb = (W * 14.0).astype(np.float32).astype(np.float64)      # max|psi| (max W - min W) of several hundred: past what 32 bins cover
+        ser.set("W", Wb); ora.W = Wb.astype(np.float32)
+        b = ser.iterate(2, eps)
+        for i in range(2):
+            ora.step(eps[2 * i]); e = ora.elbo(eps[2 * i + 1])
+        i1 = ser.info()
+        assert i1["series_passes"] == i0["series_passes"] and i1["series_fallbacks"] >= 2, (i0, i1)
+        assert np.isfinite(b) == np.isfinite(e) and (not np.isfinite(e) or abs(b - e) <= 1e-5 * abs(e)), (b, e)
     finally:
         ser.close()
+
+
+def test_series_decisions_are_the_same_on_every_run():
+    """The look ahead decides from the ranges of the pass CA_POLY_LAG passes back, exactly -- not from whatever happens to have arrived: two runs of a fit
+    that crosses the limit (W growing by hand between calls) make the same decisions and give the same bits."""
+    from clonealign_amd.engine import HipEngine
+    case = make_case(seed=35, N=900, G=300, C=5, K=1)
+    G = 300
+    eps = np.stack([eps_for(1, G, 70 + i) for i in range(13)])
+    outs = []
+    for rep in range(2):
+        eng = HipEngine(**case, variant_on=("series",))
+        try:
+            eng.gamma_init(eps_for(1, G, 0))
+            eng.iterate(6, eps)
+            W = eng.get("W")
+            eng.set("W", W * 60.0 + 3.0 * np.sign(W))
+            eng.iterate(6, eps)
+            i = eng.info()
+            outs.append((eng.get_state(), i["series_passes"], i["series_fallbacks"]))
+        finally:
+            eng.close()
+    assert outs[0][1:] == outs[1][1:] and outs[0][1] >= 6, (outs[0][1:], outs[1][1:])
+    for n, v in outs[0][0].items():
+        assert np.array_equal(v, outs[1][0][n], equal_nan=True), n

@@ -29,8 +29,10 @@ for N, G, C in shapes:
     eps = rng.normal(size=(2 * steps + 1, 1, G)).astype(np.float32)
     eps[-1] = eps[0]
     res = {}
-    for name, von in (("sweeps", ()), ("series", ("series",))):
-        eng = HipEngine(None, aux["L"], psi0, loc0, 1, 1, y_device_ptr=Yd.data_ptr(), y_device_dtype=np.int32, shape=(N, G), variant_on=von, profile=0)
+    import os
+    knobs = [("series", {})] + [(f"series b{b} side{sd}", {"series_blocks": b, "series_side": sd}) for b, sd in ((1, 1), (2, 1), (3, 1), (2, 0), (8, 0))] if os.environ.get("SERIES_SWEEP") else [("series", {})]
+    for name, von, tn in [("sweeps", (), {})] + [(n_, ("series",), t_) for n_, t_ in knobs]:
+        eng = HipEngine(None, aux["L"], psi0, loc0, 1, 1, y_device_ptr=Yd.data_ptr(), y_device_dtype=np.int32, shape=(N, G), variant_on=von, profile=0, tune=tn)
         eng.gamma_init(eps[0])
         eng.iterate(steps, eps); eng.iterate(steps, eps)
         eng.synchronize()
@@ -47,7 +49,7 @@ for N, G, C in shapes:
         eng.close()
     s, w = res["series"], res["sweeps"]
     print(f"{N} x {G} x {C}: sweeps {w[0]:.1f} us/iter, series {s[0]:.1f} us/iter ({w[0] / s[0]:.2f}x); last ELBO rel diff {abs(s[1] - w[1]) / abs(w[1]):.2e}")
-    print(f"   sweeps per class us {w[2]} launches {w[3]}")
-    print(f"   series per class us {s[2]} launches {s[3]}", flush=True)
+    for nm, r in res.items():
+        print(f"   {nm:18s} {r[0]:7.1f} us/iter; per class us {r[2]}", flush=True)
     del Yd
     torch.cuda.empty_cache()
