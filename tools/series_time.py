@@ -32,7 +32,8 @@ for N, G, C in shapes:
     import os
     knobs = [("series", {})] + [(f"series b{b} side{sd}", {"series_blocks": b, "series_side": sd}) for b, sd in ((1, 1), (2, 1), (3, 1), (2, 0), (8, 0))] if os.environ.get("SERIES_SWEEP") else [("series", {})]
     for name, von, tn in [("sweeps", (), {})] + [(n_, ("series",), t_) for n_, t_ in knobs]:
-        eng = HipEngine(None, aux["L"], psi0, loc0, 1, 1, y_device_ptr=Yd.data_ptr(), y_device_dtype=np.int32, shape=(N, G), variant_on=von, profile=0, tune=tn)
+        voff = ("series",) if name == "sweeps" else ()
+        eng = HipEngine(None, aux["L"], psi0, loc0, 1, 1, y_device_ptr=Yd.data_ptr(), y_device_dtype=np.int32, shape=(N, G), variant_on=von, variant_off=voff, profile=0, tune=tn)
         eng.gamma_init(eps[0])
         eng.iterate(steps, eps); eng.iterate(steps, eps)
         eng.synchronize()
