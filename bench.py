@@ -647,6 +647,7 @@ def main():
         regions.append(dt)
     dt = float(np.median(regions))
     kt_timed = eng.kernel_times(reset=True)
+    info = {**info, **{k: v for k, v in eng.info().items() if k in ("series_passes", "series_fallbacks")}}   # (how the passes so far were carried out)
     # the same call at the reference's default max_iter = 200 (one region): a ca_iterate call of k steps makes k + 1 forward sweeps
     # (first and last carry one draw), so a 20-step region pays 21/20 of the steady-state sweep cost -- this shows the difference
     steady = None
@@ -804,6 +805,12 @@ def main():
         per_launch_s = ms / max(launches, 1) * 1e-3
         ride = bool(info.get("y_ride")) and dominant == "fwd"
         bound, work = algorithmic_work(dominant, n_loc, G, C, K, bool(info.get("fused_sweep")), args.steps, ride)
+        canonical_work = work
+        if dominant == "ypass":
+            # the count-matrix stream is the dominant launch (series form of the contraction): its roof is HBM, and what it MOVES is the matrix at its
+            # stored width -- the canonical 4 B per count of SURVEY.md section 8d would read as 2.6x the HBM peak (a fraction above one by
+            # construction is not printed); the canonical figure is kept beside it, labelled
+            work = n_loc * G * float(info["y_bytes_per_elem"]) + (n_loc + G) * K * 4.0 * 2
         if bound == "hbm":
             achieved, peak, unit = work / per_launch_s / 1e9, PEAK_HBM_GBS, "GB/s"
         else:
@@ -835,13 +842,14 @@ def main():
             "metric": "ELBO iterations/sec", "value": args.steps / dt, "unit": "iterations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": step_s * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 (bf16x3-split MFMA contraction, fp32 accumulate)" if info.get("fwd_mfma") else "f32",
+            "dtype": ("f32 variables (contraction: float64 series over gene bins; count-matrix products: int8 MFMA, exact)" if info.get("fwd_series") and info.get("series_passes", 0) > 0
+                      else "f32 (bf16x3-split MFMA contraction, fp32 accumulate)" if info.get("fwd_mfma") else "f32"),
             "data": "synthetic",
             "config": {"workload": f"synthetic {N} cells x {G} genes x {C} clones, K={K}, S=1, cell-sharded over "
                                    f"{world} GPU(s) (BASELINE.json configs[{2 if world == 1 else 3}])",
                        "cells": N, "genes": G, "clones": C, "K": K, "mc_samples": 1, "learning_rate": 0.1,
                        "y_storage": info["y_storage_name"], "y_bytes_per_elem": info["y_bytes_per_elem"],
-                       "fused_sweep": bool(info.get("fused_sweep")), "fwd_mfma": bool(info.get("fwd_mfma")),
+                       "fused_sweep": bool(info.get("fused_sweep")), "fwd_mfma": bool(info.get("fwd_mfma")), "series_form": bool(info.get("fwd_series")),
                        "bwd_mfma": bool(info.get("bwd_mfma")), "y_mfma": bool(info.get("y_mfma")),
                        "parallelism": f"cells/{world}" if world > 1 else "single", "collective": collective,
                        "collectives_tried": tried, "allreduce_selftest": selftest, "allreduce_doubles_per_train_pass": int(info["red_n"]),
@@ -852,13 +860,21 @@ def main():
                                 "value / ms_per_step are the median region"},
             "roofline": {"bound": bound, "kernel": dominant, "achieved": achieved, "peak": peak, "unit": unit,
                          "frac": achieved / peak, "traffic": traffic, "traffic_source": traffic_src,
+                         **({"bytes_per_launch_stored": work, "bytes_per_launch_canonical_f32": canonical_work,
+                             "series_form": {"passes": int(info.get("series_passes", 0)), "handed_to_the_sweeps": int(info.get("series_fallbacks", 0))}}
+                            if dominant == "ypass" else {}),
                          "launch_ms": per_launch_s * 1e3, "launches": int(launches),
                          **({k: v for k, v in (sq_fractions(build, dominant) or {}).items() if k != "file"} if same_workload else {}),
                          "sq_source": (sq_fractions(build, dominant) or {}).get("file") if same_workload else None,
                          "event_stride": 1 if args.no_live_events else EVENT_STRIDE,
-                         "binding": "vector issue (VALU + MFMA share the SIMD's issue port; valu_active_frac / mfma_busy_frac from the SQ counter pass of this "
-                                    "build; HBM: traffic per launch against launch_ms is ~0.5 of peak)",
-                         "note": ("algorithmic fp32 flops of the fused two-eps sweep against the fp32 peak; the contraction "
+                         "binding": ("HBM latency / occupancy of the stream kernel (5.3-5.7 TB/s of the 8 TB/s peak with every CU streaming)" if dominant == "ypass" else
+                                     "vector issue (VALU + MFMA share the SIMD's issue port; valu_active_frac / mfma_busy_frac from the SQ counter pass of this "
+                                     "build; HBM: traffic per launch against launch_ms is ~0.5 of peak)"),
+                         "note": ("the count-matrix stream (Y.W and Y^T.psi on the int8 matrix cores, one pass over the 1-byte matrix) is the iteration's longest launch: "
+                                  "the cells x genes x clones contraction runs in its series form (ca_poly.hip: moments over gene bins, O(N + G) work), so the "
+                                  "O(N G) work left is this stream; achieved = stored bytes / launch time"
+                                  if dominant == "ypass" else
+                                  "algorithmic fp32 flops of the fused two-eps sweep against the fp32 peak; the contraction "
                                   "itself runs as bf16 hi/lo MFMAs (fp32-accurate), the kernel is bound by VALU issue "
                                   "(v_exp_f32 + bf16 split)"
                                   + ("; the Y stream's blocks ride inside this launch (its 4K flop per count are counted, its "

@@ -24,8 +24,8 @@
 
 #include "ca_poly.h"
 
-namespace {
-#include "ca_kernels.hip.h"   // the cell epilogue and its helpers (internal linkage here: this unit instantiates only what it launches)
+namespace ca_series {   // (a namespace of its own: the header's kernels get names that do not clash with the engine unit's, and profiles read "ca_series::k_poly_cell")
+#include "ca_kernels.hip.h"   // the cell epilogue and its helpers (this unit instantiates only what it launches)
 
 constexpr int R = CA_PL_R, NB = CA_PL_NB;
 constexpr int TB_B = 384;       // k_poly_B block: one thread per (k, column) output (21 x 16 = 336)
@@ -133,7 +133,8 @@ __global__ void __launch_bounds__(TB_B) k_poly_B(const float* __restrict__ V, co
   int nb = (int)ceil(xmax * width / (2.0 * CA_PL_A));
   nb = nb < 1 ? 1 : (nb > NB ? NB : nb);
   const double delta = width > 0.0 ? width / nb : 1.0;
-  const int bad = !(xmax * delta * 0.5 <= CA_PL_A * 1.25) || !isfinite(xmax) || !isfinite(width);
+  // (all loadings equal -- W = 0 at the start of every fit -- is one bin of width zero: any |x| is covered)
+  const int bad = !(xmax * (width > 0.0 ? delta : 0.0) * 0.5 <= CA_PL_A * 1.25) || !isfinite(xmax) || !isfinite(width);
   if (blockIdx.x == 0 && t == 0) {
     hdr->vlo = vlo; hdr->delta = delta; hdr->xmax = xmax; hdr->nb = nb;
     if (bad) { hdr->bad = 1; if (bad_word) __hip_atomic_store(bad_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }   // (the host looks at its next synchronisation)
@@ -345,7 +346,8 @@ __global__ void __launch_bounds__(CA_TB) k_poly_gene(const ca_poly_hdr* __restri
 
 inline int cdiv_i(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-}  // namespace
+}  // namespace ca_series
+using namespace ca_series;
 
 size_t ca_poly_workspace_bytes(int G, int n_cell_blocks) {
   const size_t nbg = (size_t)cdiv_i(G, GPB);

