@@ -221,10 +221,18 @@ __global__ void __launch_bounds__(CA_TB) k_poly_cell(const ca_poly_hdr* __restri
   ca_cell_acc acc = {0.0, 0.0, 0.0, 0.0, 0.0};
   const int64_t ngroups = (N + CPB - 1) / CPB;
   const int cc = c < C ? c : C - 1;
+  // what the epilogue reads for this lane's (cell, clone) that nothing here produces: loaded a pass AHEAD, beside the arithmetic of the current one
+  auto load_pass = [&](int64_t grp, double& x_, ca_cell_pre& pre_) {
+    const int64_t n_ = grp * CPB + slot, nn_ = n_ < N ? n_ : N - 1;
+    x_ = (double)p.F[nn_];
+    pre_.gl = p.glogit[nn_ * C + cc]; pre_.sn = p.s64[nn_]; pre_.Anc = p.A[nn_ * C + cc];
+  };
+  double x_next = 0.0; ca_cell_pre pre_next = {0.f, 0.0, 0.0};
+  if ((int64_t)blockIdx.x < ngroups) load_pass(blockIdx.x, x_next, pre_next);
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int64_t n = grp * CPB + slot;
-    const int64_t nn = n < N ? n : N - 1;
-    const double x = (double)p.F[nn];
+    const double x = x_next; const ca_cell_pre pre = pre_next;
+    if (grp + gridDim.x < ngroups) load_pass(grp + gridDim.x, x_next, pre_next);
     double ZA = 0.0, ZB = 0.0, dZB = 0.0;
     for (int b = 0; b < nb; ++b) {
       const double vb = vlo + ((double)b + 0.5) * delta;
@@ -245,7 +253,7 @@ __global__ void __launch_bounds__(CA_TB) k_poly_cell(const ca_poly_hdr* __restri
       for (int k = 0; k < RQ; ++k) { if (k % CP == c) s_xp[slot][k] = xk; xk *= x; }
     }
     float cff = 0.f;
-    ca_cell_fused_group<CP>(p, la, n, N, C, 1, K, ZA, ZB, acc, nullptr, &cff);
+    ca_cell_fused_group<CP>(p, la, n, N, C, 1, K, ZA, ZB, acc, &pre, &cff);
     // this lane's coef as the epilogue stored it (float: what the matrix-core way back reads as well); d/dF = sum_c coef dZ/dx
     const double cf = (double)cff;
     double df = cf * dZB;
