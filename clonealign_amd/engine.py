@@ -176,18 +176,20 @@ def device_count():
     return n.value
 
 
-_SOURCES = ("clonealign_amd/csrc/clonealign_hip.hip", "clonealign_amd/csrc/ca_kernels.hip.h", "clonealign_amd/csrc/ca_ymfma.hip.h", "clonealign_amd/csrc/ca_fwdbal.hip.h",
-            "clonealign_amd/csrc/philox_host.h", "include/clonealign_hip.h", "clonealign_amd/csrc/ca_group.cpp",
-            "clonealign_amd/csrc/ca_poly.hip", "clonealign_amd/csrc/ca_poly.h")
+def _sources():
+    """The library's sources in the order csrc/Makefile hashes them: every .hip / .h / .inc / .cpp of csrc/ but ca_build_id.cpp, sorted, then the C ABI."""
+    import glob
+    d = os.path.join(_HERE, "csrc")
+    fs = sorted(f for ext in ("*.hip", "*.h", "*.inc", "*.cpp") for f in glob.glob(os.path.join(d, ext)) if os.path.basename(f) != "ca_build_id.cpp")
+    return fs + [os.path.join(os.path.dirname(_HERE), "include", "clonealign_hip.h")]
 
 
 def source_build_id():
     """What ca_build_id() of a library built from the sources in this tree returns (same recipe as csrc/Makefile)."""
     import hashlib
-    root = os.path.dirname(_HERE)
     h = hashlib.sha1()
-    for f in _SOURCES:
-        h.update(open(os.path.join(root, f), "rb").read())
+    for f in _sources():
+        h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
 

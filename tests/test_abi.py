@@ -80,7 +80,8 @@ def test_library_reads_no_tuning_from_the_environment():
     getenv calls for it exist only in timing-lab builds (-DCA_LAB: `debug_env()` is the constant false otherwise).  The two names read
     unconditionally are not tuning: CLONEALIGN_RCCL_LIB (which librccl to dlopen -- a deployment path, tried before the standard
     names) and CA_VERBOSE (diagnostics to stderr, itself behind debug_env())."""
-    src = open(os.path.join(ROOT, "clonealign_amd", "csrc", "clonealign_hip.hip")).read()
+    import glob
+    src = "".join(open(f).read() for f in [os.path.join(ROOT, "clonealign_amd", "csrc", "clonealign_hip.hip")] + sorted(glob.glob(os.path.join(ROOT, "clonealign_amd", "csrc", "ca_eng_*.inc"))))
     uses = re.findall(r'getenv\("([A-Z_]+)"\)', src)
     assert set(uses) <= {"CLONEALIGN_DEBUG_ENV", "CLONEALIGN_RCCL_LIB", "CA_VERBOSE"}, uses
     assert src.count("getenv(env)") == 3 and "constexpr bool debug_env() { return false; }" in src
@@ -92,7 +93,8 @@ def test_product_kernels_carry_no_switchable_wrong_answer_paths():
     """timing-lab code lives under tools/lab/ and comes into the kernels only through hooks that a -DCA_LAB build fills
     in (block stamps; such a build reports a "lab-" build id, which bench.py refuses).  No #if on a CA_LAB_* macro is left in the product
     sources, and nothing under tools/lab/ alters a result."""
-    for f in ("ca_kernels.hip.h", "ca_ymfma.hip.h", "clonealign_hip.hip"):
+    import glob
+    for f in sorted(os.path.basename(x) for ext in ("*.hip", "*.h", "*.inc") for x in glob.glob(os.path.join(ROOT, "clonealign_amd", "csrc", ext))):
         src = open(os.path.join(ROOT, "clonealign_amd", "csrc", f)).read()
         assert not re.findall(r"#\s*if[^\n]*CA_LAB_", src), f
         assert "wrong results" not in src and "results WRONG" not in src, f
