@@ -182,7 +182,7 @@ def cpu_ref_dataflow(budget_s=10.0):
                     f"per iteration, {it} iterations in {dt:.1f} s"}
 
 
-def side_config(name, N, G, C, K=1, S=1, P=0, steps=200, regions=3, seed=20251, device=0, what=""):
+def side_config(name, N, G, C, K=1, S=1, P=0, steps=200, regions=3, seed=20251, device=0, what="", kernel_classes=False, engine_kw=None):
     """One more shape on the driver's clock, OUTSIDE the headline regions: a fresh synthetic problem of that shape (generated on the
     GPU), a fresh engine, gamma init, 20 warm-up iterations, then `regions` regions of one ca_iterate(steps) call between
     synchronisations; the median region is reported against the shape's own roof (the larger of the canonical
@@ -202,7 +202,8 @@ def side_config(name, N, G, C, K=1, S=1, P=0, steps=200, regions=3, seed=20251, 
     psi0 = rng.normal(size=(N, K))
     X = rng.normal(size=(N, P)) if P > 0 else None
     torch.cuda.synchronize()
-    eng = HipEngine(None, aux["L"], psi0, loc0, K, S, X=X, y_device_ptr=Yd.data_ptr(), y_device_dtype=np.int32, shape=(N, G), device=device, profile=0)
+    eng = HipEngine(None, aux["L"], psi0, loc0, K, S, X=X, y_device_ptr=Yd.data_ptr(), y_device_dtype=np.int32, shape=(N, G), device=device, profile=0, **(engine_kw or {}))
+    classes = None
     try:
         info = eng.info()
         eng.gamma_init(rng.normal(size=(S, G)).astype(np.float32))
@@ -219,6 +220,10 @@ def side_config(name, N, G, C, K=1, S=1, P=0, steps=200, regions=3, seed=20251, 
             ts.append(time.perf_counter() - t0)
         dt = float(np.median(ts)) / steps
         info_end = eng.info()
+        if kernel_classes:   # (tools/side_time.py: after the timed regions, events around every launch)
+            eng.set_profile(0x1F)
+            eng.iterate(min(steps, 20), eps[:2 * min(steps, 20) + 1])
+            classes = {k: round(v[0] / min(steps, 20) * 1e3, 1) for k, v in eng.kernel_times(reset=True).items()}
     finally:
         eng.close()
         del Yd
@@ -233,7 +238,8 @@ def side_config(name, N, G, C, K=1, S=1, P=0, steps=200, regions=3, seed=20251, 
         flops = 0.0
         bytes_c = N * G * float(info["y_bytes_per_elem"]) + N * (8.0 * C + 6.0 * K + 2.0) * 4.0
     t_roof = max(flops / (PEAK_F32_TFLOPS * 1e12), bytes_c / (PEAK_HBM_GBS * 1e9))
-    return {"workload": f"synthetic {N} cells x {G} genes x {C} clones, K={K}, P={P}, S={S}" + (f" ({what})" if what else ""),
+    return {**({"kernel_class_us_per_iter": classes} if classes else {}),
+            "workload": f"synthetic {N} cells x {G} genes x {C} clones, K={K}, P={P}, S={S}" + (f" ({what})" if what else ""),
             "it_per_s": 1.0 / dt, "us_per_iter": dt * 1e6, "steps": steps, "regions": regions,
             "roof_us": t_roof * 1e6, "frac_of_roof": t_roof / dt, "roof_is": "hbm (stored bytes; series form)" if series else "fp32" if flops / (PEAK_F32_TFLOPS * 1e12) >= bytes_c / (PEAK_HBM_GBS * 1e9) else "hbm",
             "fwd_mfma": bool(info["fwd_mfma"]), "bwd_mfma": bool(info["bwd_mfma"]), "fused_sweep": bool(info["fused_sweep"]), "series_form": series,
@@ -761,7 +767,8 @@ def main():
                 other[nm] = {"error": str(ex)[:200]}
         for nm, kw in (("S3", dict(N=N, G=G, C=C, S=3, what="mc_samples = 3: plain passes")),
                        ("C20", dict(N=N, G=G, C=20, what="20 clones: VALU sweeps")),
-                       ("K2P1", dict(N=N, G=G, C=C, K=2, P=1, what="D = K + P = 3: VALU sweeps"))):
+                       ("K2P1", dict(N=N, G=G, C=C, K=2, P=1, what="D = K + P = 3: matrix-core sweeps since round 6, the count-matrix stream a launch of its own")),
+                       ("K1P2", dict(N=N, G=G, C=C, K=1, P=2, what="D = K + P = 3 with one latent dimension and two covariates"))):
             try:
                 fallbacks[nm] = side_config(nm, device=local_rank, steps=40, regions=2, **kw)
             except Exception as ex:  # noqa: BLE001

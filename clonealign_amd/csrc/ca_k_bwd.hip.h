@@ -376,6 +376,9 @@ __device__ __forceinline__ void ca_split3(float x, unsigned short& p1, unsigned 
 #ifndef CA_BWD_TL
 #define CA_BWD_TL 4   // gene tiles of 16 per wave in the backward sweep
 #endif
+#ifndef CA_BWD_TL_D34
+#define CA_BWD_TL_D34 3   // ... with three or four exponent dimensions (the per-gene accumulators grow with D: 207 / 250 registers at three tiles)
+#endif
 #ifndef CA_BWD_PD
 #define CA_BWD_PD 2   // batches of operands in flight per wave (3 and more cost the third wave per SIMD: 140 -> 200 us)
 #endif

@@ -567,7 +567,7 @@ __global__ void __launch_bounds__(CA_UM_TB) k_update_merged(const double* __rest
     // four gene groups in order -- bitwise the same partials.
     __shared__ int stop_s;
     __shared__ float h_loc[CA_TB], h_ls[CA_TB], h_v0[CA_TB];
-    __shared__ double smt[4][8];
+    __shared__ double smt[4][10];   // (three sums of either draw, then the sums of squared loadings of up to four latent dimensions)
     __shared__ float smn[8][4], smx[8][4], sma[4];
     const int tid = (int)threadIdx.x, l = tid & 63, wv = tid >> 6, role = wv >> 2, grp = wv & 3;
     const int g = bx * CA_TB + grp * 64 + l;
@@ -605,11 +605,16 @@ __global__ void __launch_bounds__(CA_UM_TB) k_update_merged(const double* __rest
       }
       // sums of squared loadings (terms 6 and 7 of the prologue's block sums)
       const float wk0 = K > 0 ? V0n : 0.f;
-      double e6 = ok ? (double)wk0 * (double)wk0 : 0.0, e7 = 0.0;
-      if (K > 1 && ok) { const double w1 = (double)V[(int64_t)g * D + 1]; e7 = w1 * w1; }
+      double esq[4] = {ok ? (double)wk0 * (double)wk0 : 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int q = 1; q < 64; q <<= 1) { e6 += __shfl_xor(e6, q, 64); e7 += __shfl_xor(e7, q, 64); }
-      if (l == 0) { smt[grp][6] = e6; smt[grp][7] = e7; }
+      for (int k = 1; k < 4; ++k)
+        if (k < K && ok) { const double wk = (double)V[(int64_t)g * D + k]; esq[k] = wk * wk; }
+#pragma unroll
+      for (int q = 1; q < 64; q <<= 1) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) esq[k] += __shfl_xor(esq[k], q, 64);
+      }
+      if (l == 0) { smt[grp][6] = esq[0]; smt[grp][7] = esq[1]; smt[grp][8] = esq[2]; smt[grp][9] = esq[3]; }
     } else if (role < 3) {
       double t[3] = {0.0, 0.0, 0.0};
       if (ok) {
@@ -635,16 +640,16 @@ __global__ void __launch_bounds__(CA_UM_TB) k_update_merged(const double* __rest
     __syncthreads();
     CA_LAB_CP(bx, 2);
     if (tid == 0) {
-      double e[8];
+      double e[10];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { double r = smt[0][i]; r += smt[1][i]; r += smt[2][i]; r += smt[3][i]; e[i] = r; }
+      for (int i = 0; i < 10; ++i) { double r = smt[0][i]; r += smt[1][i]; r += smt[2][i]; r += smt[3][i]; e[i] = r; }
       const int W_ = 3 + K;
       double* ga = mg.pre.gene_partA + (int64_t)bx * W_;
       double* gb = mg.pre.gene_partB + (int64_t)bx * W_;
       if (mg.pre.s2) { ga[0] = 0.5 * (e[0] + e[3]); ga[1] = 0.5 * (e[1] + e[4]); ga[2] = 0.5 * (e[2] + e[5]); }
       else { ga[0] = e[0]; ga[1] = e[1]; ga[2] = e[2]; }
       gb[0] = e[3]; gb[1] = e[4]; gb[2] = e[5];
-      for (int k = 0; k < K && k < 2; ++k) { ga[3 + k] = e[6 + k]; gb[3 + k] = e[6 + k]; }
+      for (int k = 0; k < K && k < 4; ++k) { ga[3 + k] = e[6 + k]; gb[3 + k] = e[6 + k]; }
       for (int d = 0; d < D && d < 8; ++d) {
         vmm_part[((int64_t)bx * 2 + 0) * D + d] = fminf(fminf(smn[d][0], smn[d][1]), fminf(smn[d][2], smn[d][3]));
         vmm_part[((int64_t)bx * 2 + 1) * D + d] = fmaxf(fmaxf(smx[d][0], smx[d][1]), fmaxf(smx[d][2], smx[d][3]));

@@ -276,7 +276,9 @@ FUSED_SHAPES = {
     "d1_c8_ragged": dict(N=333, G=95, C=8, K=1),          # G not a multiple of 32, N not a multiple of 256
     "d2_k1p1": dict(N=520, G=300, C=6, K=1, P=1),
     "d2_k2": dict(N=257, G=161, C=2, K=2),
-    "d3_fallback": dict(N=200, G=90, C=4, K=2, P=1),       # D = 3: the VALU sweep is the only one
+    "d3_k2p1": dict(N=200, G=90, C=4, K=2, P=1),           # D = 3, 4 (round 6): the sweep + cell epilogue kernel and the matrix-core way back
+    "d4_k2p2": dict(N=530, G=333, C=7, K=2, P=2),
+    "d5_fallback": dict(N=200, G=90, C=4, K=3, P=2),       # D = 5: the VALU sweep is the only one
 }
 
 
@@ -285,8 +287,8 @@ FUSED_SHAPES = {
 def test_fused_sweep_forward_variants_agree_with_oracle(shape, fwd):
     """ca_iterate takes the fused two-eps sweep (monitor pass i + forward half of train pass i+1 from one exp per
     (cell, gene)); its forward contraction runs on the matrix cores (D in {1, 2}) -- in one kernel with the cell
-    epilogue (k_fwd_cell, the default) or as k_fwd_mfma + k_cell_fused (variant "fwd_cell" off) -- or on the VALU
-    (variant "fwd_mfma" off, and always for D >= 3).  "cell_mix" forces the two-block-size launch of the large shapes
+    epilogue (k_fwd_cell, the default; D up to 4) or as k_fwd_mfma + k_cell_fused (variant "fwd_cell" off; D in {1, 2}) -- or
+    on the VALU (variant "fwd_mfma" off, and always for D >= 5).  "cell_mix" forces the two-block-size launch of the large shapes
     (k_fwd_cell_mix: 3 blocks of 64 cells, the rest in 32-cell blocks).  All against the oracle's call-by-call loop."""
     from clonealign_amd.engine import HipEngine
     from oracle.fused_numpy import FusedModel
@@ -301,8 +303,8 @@ def test_fused_sweep_forward_variants_agree_with_oracle(shape, fwd):
     case = make_case(seed=5, **FUSED_SHAPES[shape])
     eng, ora = HipEngine(**case, **opts), FusedModel(**case, dtype="float32")
     try:
-        assert eng.info()["fwd_mfma"] == int(fwd in ("cell", "mfma") and ora.D in (1, 2))
-        assert eng.info()["fwd_cell"] == int(fwd == "cell" and ora.D in (1, 2))
+        assert eng.info()["fwd_mfma"] == int((fwd in ("cell", "mfma") and ora.D in (1, 2)) or (fwd == "cell" and ora.D in (3, 4)))
+        assert eng.info()["fwd_cell"] == int(fwd == "cell" and ora.D in (1, 2, 3, 4))
         st = perturbed_state({n: getattr(ora, n).shape for n in ora.VAR_NAMES}, amp=0.2)
         for n, v in st.items():
             setattr(ora, n, v.astype(ora.pdt))
@@ -621,6 +623,70 @@ def test_nine_to_sixteen_clones_run_the_matrix_core_sweeps(shape):
         assert tr.shape == to.shape and np.abs(tr - to).max() <= 1e-5 * np.abs(to).max(), (tr, to)
         fe = eng.final_elbo(np.stack([eps_for(1, G, 70 + i) for i in range(3)]), 3)
         fo = np.array([ora.elbo(eps_for(1, G, 70 + i)) for i in range(3)])
+        assert np.abs(fe - fo).max() <= 1e-5 * np.abs(fo).max()
+    finally:
+        eng.close()
+
+
+@pytest.mark.parametrize("shape", [dict(N=700, G=1100, C=5, K=2, P=1), dict(N=333, G=95, C=8, K=1, P=2), dict(N=2100, G=600, C=3, K=3),
+                                   dict(N=257, G=161, C=2, K=2, P=2), dict(N=40_100, G=700, C=6, K=4), dict(N=900, G=410, C=4, K=1, P=3, extra=True),
+                                   dict(N=1500, G=500, C=5, K=3, P=1, frac=True), dict(N=640, G=200, C=6, K=2, P=1, S=2)],
+                         ids=["k2p1", "k1p2_ragged", "k3", "k2p2", "k4_40k", "k1p3_extra", "k3p1_fractional_L", "k2p1_s2"])
+def test_three_and_four_exponent_dimensions_run_the_matrix_core_sweeps(shape):
+    """n_extra_genes / K latent dimensions and P covariates make eta = sum_d F_nd V_gd a D = K + P term sum (R/inference-tflow.R:85-86,136,147-153).
+    Up to round 5, D >= 3 fell from the matrix-core sweeps to the VALU ones (4.6x per iteration at 100k cells).  Round 6: eta is D multiply-adds on the
+    vector unit either way and the matrix-core products do not depend on D, so D = 3 and 4 take k_fwd_cell<D, .> and k_bwd_mfma<3, D, .>; the count
+    matrix's two products run as a launch of their own.  Gradients, ca_iterate, ca_run and the final ELBOs against the oracle, the bounds of the
+    D <= 2 path.  mc_samples = 2 with D = 3 keeps the plain forward passes and takes the matrix-core way back, sample by sample."""
+    from clonealign_amd.engine import HipEngine
+    from clonealign_amd.inference import run_vi_loop
+    from clonealign_amd.rng import EpsStream
+    from oracle.fused_numpy import FusedModel
+    shape = dict(shape)
+    frac = shape.pop("frac", False)
+    case = make_case(seed=67, **shape)
+    if frac:
+        case["L"] = case["L"] * 0.37 + 0.11          # copy numbers that are not bf16-exact: the two-part form of the way back
+    rng = np.random.default_rng(9)
+    idx = rng.integers(0, case["Y"].size, size=max(3, case["Y"].size // 4000))
+    case["Y"].reshape(-1)[idx] += rng.integers(200, 900, size=idx.size)           # overflow-list entries
+    eng, ora = HipEngine(**case), FusedModel(**case, dtype="float32")
+    try:
+        info = eng.info()
+        S = ora.S
+        assert ora.D in (3, 4) and info["bwd_mfma"] == 1, info
+        if S == 1:
+            assert (info["fused_sweep"], info["fwd_mfma"], info["fwd_cell"]) == (1, 1, 1), info
+        G = ora.G
+        st = perturbed_state({n: getattr(ora, n).shape for n in ora.VAR_NAMES}, amp=0.2)
+        for n, v in st.items():
+            setattr(ora, n, v.astype(ora.pdt))
+            eng.set(n, v)
+        eps = eps_for(S, G, 3)
+        ge, ee = eng.gradients(eps)
+        go, eo = ora.gradients(eps)
+        assert abs(ee - eo) <= 2e-5 * abs(eo)
+        for n in ora.VAR_NAMES:
+            assert _rel(ge[n], go[n]) < 2e-5, (n, _rel(ge[n], go[n]))
+        n_iter = 5
+        epss = np.stack([eps_for(S, G, 100 + i) for i in range(2 * n_iter)])
+        last = eng.iterate(n_iter, epss)
+        for i in range(n_iter):
+            ora.step(epss[2 * i])
+            e = ora.elbo(epss[2 * i + 1])
+        assert abs(last - e) <= 2e-5 * abs(e), (last, e)
+        p = eng.get_state()
+        for n in ora.VAR_NAMES:
+            if n == "gamma_logits":   # (see the sixteen-clone test: a handful of noise-level coordinates after Adam's first steps)
+                d = np.abs(p[n] - np.asarray(getattr(ora, n), dtype=np.float64)) / np.abs(getattr(ora, n)).max()
+                assert (d > 1e-4).sum() <= max(2, d.size // 20000) and d.max() < 5e-3, (int((d > 1e-4).sum()), d.max())
+                continue
+            assert _rel(p[n], getattr(ora, n)) < 1e-4, (n, _rel(p[n], getattr(ora, n)))
+        tr = np.asarray(eng.run(EpsStream(5, S, G), 4, 1e-12))
+        to = np.asarray(run_vi_loop(ora, EpsStream(5, S, G), 4, 1e-12))
+        assert tr.shape == to.shape and np.abs(tr - to).max() <= 1e-5 * np.abs(to).max(), (tr, to)
+        fe = eng.final_elbo(np.stack([eps_for(S, G, 70 + i) for i in range(3)]), 3)
+        fo = np.array([ora.elbo(eps_for(S, G, 70 + i)) for i in range(3)])
         assert np.abs(fe - fo).max() <= 1e-5 * np.abs(fo).max()
     finally:
         eng.close()
