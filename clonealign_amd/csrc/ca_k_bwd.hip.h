@@ -388,6 +388,10 @@ __device__ __forceinline__ void ca_split3(float x, unsigned short& p1, unsigned 
 // forward sweep's own accuracy.  Integer copy numbers keep the exact three-part form.
 // C16 (round 3): 9..16 clones with integer copy numbers.  The 32 operand slots carry two bf16 parts of coef for sixteen clones,
 // slot group q = 2 * part + chunk (what the sixteen-lane cell epilogue writes), against L of clone chunk q & 1 in both parts.
+// Round 6: the THIRD part rides in a second operand image (cq1: slot groups 0, 1 = part 3 of the two chunks, groups 2, 3 zero and never written) through a
+// second matrix-core product into the same accumulator.  With two parts a product was good to 2^-17, and the per-gene gradients -- differences of sums over
+// the cells that nearly cancel at a fit's start -- came out 40x less accurate than the vector sweep's (9000 x 5000 x 18 clones, four iterations: W off by
+// 5e-5 at the median and by 0.2 at one gene, 1.3e-6 / 2e-5 on the vector unit; tools/lab/diag_c18.py).  The matrix cores are idle four fifths of this sweep.
 // S2 (round 4, mc_samples = 2): BOTH samples of a train pass in one sweep.  exp(eta) does not depend on the sample (same psi, same W): one
 // exponential per (cell, gene) serves two products -- the second sample brings its own coef operand (cq1), its own mu (mu1), its own matrix-core
 // products and its own accumulators, and everything is summed in the order the sweep-per-sample form sums it (sample 0's partial first, then
@@ -507,13 +511,14 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
   const int qc = (FRAC && q == 2) ? 0 : q;   // which part of coef this lane group carries (FRAC: c1, c2, c1 again)
   const int len = active ? (int)(n1 - n0) : 0;
   const unsigned short* cqb = cq + n0 * 32;
-  [[maybe_unused]] const unsigned short* cqb1 = S2 ? cq1 + n0 * 32 : nullptr;
+  [[maybe_unused]] const unsigned short* cqb1 = (S2 || C16) ? cq1 + n0 * 32 : nullptr;
   const float* Fb = F + n0 * DD;
   const float* eb = etamax2 + n0;
   const unsigned lo_c = (unsigned)((j * 4 + qc) * 8), lo_f = (unsigned)(j * DD), lo_e = (unsigned)j;
   const int jl = len - j;                    // cell r + j is inside the slice iff r < jl
   float* myd_lane = myd + j * DD;
   uint4 craw_r[NSM][PD];
+  [[maybe_unused]] uint4 c3_r[PD];
   float fc_r[PD][DD], ec_r[PD];
   auto fetch = [&](int slot, int r) {        // r: uniform, a multiple of 16, inside the padded arrays
     const unsigned short* pc = cqb + (int64_t)r * 32;
@@ -521,6 +526,7 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
     const float* pe = eb + r;
     craw_r[0][slot] = *reinterpret_cast<const uint4*>(pc + lo_c);
     if constexpr (S2) craw_r[1][slot] = *reinterpret_cast<const uint4*>(cqb1 + (int64_t)r * 32 + lo_c);
+    if constexpr (C16) c3_r[slot] = *reinterpret_cast<const uint4*>(cqb1 + (int64_t)r * 32 + lo_c);
 #pragma unroll
     for (int d = 0; d < DD; ++d) fc_r[slot][d] = pf[lo_f + d];
     ec_r[slot] = pe[lo_e];
@@ -544,6 +550,8 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
     uint4 craw[NSM];
 #pragma unroll
     for (int sm_ = 0; sm_ < NSM; ++sm_) craw[sm_] = craw_r[sm_][d_];
+    [[maybe_unused]] ca_bf16x8 Cf3;
+    if constexpr (C16) Cf3 = __builtin_bit_cast(ca_bf16x8, c3_r[d_]);
     float fc[DD];
 #pragma unroll
     for (int d = 0; d < DD; ++d) fc[d] = fc_r[d_][d];
@@ -570,8 +578,15 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
 #pragma unroll
       for (int sm_ = 0; sm_ < NSM; ++sm_) {
         tt[sm_][m] = (ca_f32x4){0.f, 0.f, 0.f, 0.f};
-        tt[sm_][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Lf[m], Cf[sm_], tt[sm_][m], 0, 0, 0);   // tt[.][m][r]: gene gbase+16m+4q+r, cell n0+r0+j
+        // (the smallest part first, and for all tiles before the main products: a product into the accumulator of the one just issued waits for it)
+        if constexpr (C16) tt[sm_][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Lf[m], Cf3, tt[sm_][m], 0, 0, 0);
       }
+    }
+#pragma unroll
+    for (int m = 0; m < AH; ++m) {
+#pragma unroll
+      for (int sm_ = 0; sm_ < NSM; ++sm_)
+        tt[sm_][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Lf[m], Cf[sm_], tt[sm_][m], 0, 0, 0);   // tt[.][m][r]: gene gbase+16m+4q+r, cell n0+r0+j
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -581,6 +596,7 @@ __global__ void __launch_bounds__(CA_TB) k_bwd_mfma(const unsigned short* __rest
 #pragma unroll
           for (int sm_ = 0; sm_ < NSM; ++sm_) {
             tt[sm_][m + AH] = (ca_f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (C16) tt[sm_][m + AH] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Lf[m + AH], Cf3, tt[sm_][m + AH], 0, 0, 0);
             tt[sm_][m + AH] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Lf[m + AH], Cf[sm_], tt[sm_][m + AH], 0, 0, 0);
           }
         }

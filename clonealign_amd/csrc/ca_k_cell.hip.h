@@ -119,7 +119,9 @@ __global__ void __launch_bounds__(CA_TB) k_cell_par(const float* __restrict__ Zp
                                                     float* __restrict__ coef, float* __restrict__ dgl,
                                                     double* __restrict__ cell_part, int64_t N, int C, int S, int D, int K,
                                                     int gsplit, int nchunk, int nseg, int mode,
-                                                    unsigned short* __restrict__ coefq, int64_t N16) {
+                                                    unsigned short* __restrict__ coefq, int64_t N16, int zpairs = 0, int64_t q3_off = 0) {
+  // zpairs (round 6): Z comes from matrix-core sweeps over PAIRS of (sample, clone chunk) slices, [pair][gsplit][N][16] with slice j = s nchunk + ch in
+  // columns 8 (j & 1) .. of pair j >> 1 (k_mq_pairs / k_fwd_mfma), instead of one vector sweep per slice, [slice][gsplit][N][8]
   __shared__ double sm[CA_TB];
   __shared__ double la[64];
   constexpr int CPB = CA_TB / CP;  // cells per block
@@ -156,7 +158,12 @@ __global__ void __launch_bounds__(CA_TB) k_cell_par(const float* __restrict__ Zp
     double lzsum = 0.0;
     for (int s = 0; s < S; ++s) {
       double Z = 0.0;
-      for (int sp = 0; sp < gsplit; ++sp) Z += (double)Zpart[((((int64_t)s * nchunk + ch) * gsplit + sp) * N + nn) * CA_CW + cc];
+      if (zpairs) {
+        const int j = s * nchunk + ch;
+        for (int sp = 0; sp < gsplit; ++sp) Z += (double)Zpart[(((int64_t)(j >> 1) * gsplit + sp) * N + nn) * 16 + 8 * (j & 1) + cc];
+      } else {
+        for (int sp = 0; sp < gsplit; ++sp) Z += (double)Zpart[((((int64_t)s * nchunk + ch) * gsplit + sp) * N + nn) * CA_CW + cc];
+      }
       lzsum += log(Z) + em;
       if (mode == CA_MODE_TRAIN && ok) {
         const float cfv = (float)(-gam * sn / ((double)S * Z));
@@ -164,9 +171,10 @@ __global__ void __launch_bounds__(CA_TB) k_cell_par(const float* __restrict__ Zp
         if (coefq) {   // bf16 parts for the matrix-core backward sweep: three for up to eight clones, two per clone chunk for 9..16
           unsigned short p1, p2, p3;
           ca_split3(cfv, p1, p2, p3);
-          if (nchunk == 2) {   // (slot = 2 * part + chunk, as the sixteen-lane fused epilogue writes it)
-            unsigned short* qp = coefq + (((int64_t)s * N16 + nn) * 4 + ch) * 8 + cc;
+          if (nchunk >= 2) {   // (slot = 2 * part + chunk of the pair, as the sixteen-lane fused epilogue writes it; one image per sample and chunk pair)
+            unsigned short* qp = coefq + ((((int64_t)s * ((nchunk + 1) >> 1) + (ch >> 1)) * N16 + nn) * 4 + (ch & 1)) * 8 + cc;
             qp[0] = p1; qp[16] = p2;
+            qp[q3_off] = p3;   // (the third part: same slot of the second image, k_bwd_mfma<.., C16>)
           } else {
             unsigned short* qp = coefq + (((int64_t)s * N16 + nn) * 4) * 8 + cc;
             qp[0] = p1; qp[8] = p2; qp[16] = p3;
@@ -314,6 +322,7 @@ __device__ __forceinline__ void ca_cell_fused_group(const ca_cell_ptrs& p, const
         ca_split3(cfv, p1, p2, p3);
         unsigned short* qp = p.coefq + (nn * 4 + (cc >> 3)) * 8 + (cc & 7);
         qp[0] = p1; qp[16] = p2;
+        qp[p.N16 * 32] = p3;   // (the third part: same slot of the second image, k_bwd_mfma<.., C16>)
       }
     } else {
     p.coef[nn * CA_CW + cc] = cfv;

@@ -735,6 +735,23 @@ __global__ void __launch_bounds__(CA_TB) k_gene_pre(const float* __restrict__ lo
   }
 }
 
+// Plain passes on the matrix cores (round 6): the float rows of a pass's (sample, clone chunk) slices, Mb [nslice][G][8], as two bf16 parts in the B-operand
+// layout of k_fwd_mfma, two slices to a sixteen-column image: Mq [pair][g / 32][part][16 (g % 32) / 8 + 8 (slice & 1) + column][g % 8].  Padding genes and a
+// missing last slice are never written (the image is zero-filled once).
+__global__ void __launch_bounds__(CA_TB) k_mq_pairs(const float* __restrict__ Mb, unsigned short* __restrict__ Mq, int G, int nk) {
+  const int g = blockIdx.x * CA_TB + threadIdx.x, j = blockIdx.y;
+  if (g >= G) return;
+  const float4 r0 = *reinterpret_cast<const float4*>(Mb + ((int64_t)j * G + g) * CA_CW), r1 = *reinterpret_cast<const float4*>(Mb + ((int64_t)j * G + g) * CA_CW + 4);
+  const float x[CA_CW] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+  unsigned short* mq = Mq + (int64_t)(j >> 1) * nk * 1024 + ((int64_t)(g >> 5) * 128 + 16 * ((g & 31) >> 3) + 8 * (j & 1)) * 8 + (g & 7);
+#pragma unroll
+  for (int c = 0; c < CA_CW; ++c) {
+    const unsigned short p1 = ca_bf16_rn(x[c]);
+    mq[c * 8] = p1;
+    mq[(64 + c) * 8] = ca_bf16_rn(x[c] - __uint_as_float((unsigned)p1 << 16));
+  }
+}
+
 // Fused two-eps variant (S == 1, one clone chunk): both draws A (monitor pass) and B (next train pass) in one
 // launch; M row = [mu_A L (C cols) | mu_B L (C cols)], per-draw mu and gene partials kept apart.  With Mq the row
 // goes out as two bf16 parts in the operand layout of the matrix-core sweep instead (k_fwd_mfma).

@@ -319,7 +319,7 @@ int ca_get_info(ca_handle h, ca_info* i) {
   i->N = h->N; i->G = h->G; i->C = h->C; i->K = h->K; i->P = h->P; i->S = h->S;
   i->y_storage = h->ystore; i->y_bytes_per_elem = h->ybytes; i->y_device_bytes = h->y_dev_bytes; i->device_bytes = h->dev_bytes;
   i->gsplit = h->gsplit; i->csplit = h->csplit; i->n_cu = h->n_cu; i->fused_sweep = h->fused_ok ? 1 : 0;
-  i->fwd_mfma = (h->fused_ok && h->fwd_mfma) ? 1 : 0; i->bwd_mfma = h->bwd_mfma ? 1 : 0; i->fsplit = h->fsplit; i->fwd_cell = (h->fused_ok && h->fwd_cell) ? 1 : 0;
+  i->fwd_mfma = ((h->fused_ok && h->fwd_mfma) || h->pfwd) ? 1 : 0; i->bwd_mfma = h->bwd_mfma ? 1 : 0; i->fsplit = h->fsplit; i->fwd_cell = (h->fused_ok && h->fwd_cell) ? 1 : 0;
   i->y_mfma = h->y_ys ? 2 : h->y_mfma ? 1 : 0;
   i->y_ride = (h->ride_ok || h->ride_ys) ? 1 : 0;
   i->transport = (h->p2p && h->p2p->connected) ? CA_TRANSPORT_P2P : h->comm ? CA_TRANSPORT_RCCL : h->host_ar ? CA_TRANSPORT_HOST : CA_TRANSPORT_NONE;

@@ -692,6 +692,80 @@ def test_three_and_four_exponent_dimensions_run_the_matrix_core_sweeps(shape):
         eng.close()
 
 
+@pytest.mark.parametrize("shape", [dict(N=700, G=1100, C=5, K=1, S=3), dict(N=333, G=95, C=8, K=1, P=1, S=3), dict(N=900, G=410, C=3, K=2, S=4),
+                                   dict(N=700, G=1100, C=20, K=1), dict(N=333, G=95, C=32, K=1), dict(N=2100, G=600, C=17, K=1, P=1),
+                                   dict(N=520, G=300, C=12, K=1, S=2), dict(N=640, G=200, C=20, K=2, S=2), dict(N=40_100, G=700, C=24, K=1),
+                                   dict(N=800, G=350, C=20, K=1, frac=True), dict(N=600, G=260, C=5, K=2, P=1, S=3), dict(N=450, G=180, C=40, K=1)],
+                         ids=["s3", "s3_k1p1_ragged", "s4_k2", "c20", "c32_ragged", "c17_k1p1", "c12_s2", "c20_k2_s2", "c24_40k", "c20_fractional_L", "s3_d3", "c40"])
+def test_plain_pass_shapes_run_the_matrix_core_sweeps(shape):
+    """mc_samples > 2 and more than sixteen clones (R/clonealign.R:184-203, R/inference-tflow.R:268) are shapes whose loop is made of plain passes.  Up to round 5
+    their forward contraction ran as one vector sweep per (sample, clone chunk) slice and, beyond sixteen clones, so did the way back.  Round 6: the slices of a pass
+    go two to a sixteen-column matrix-core sweep (k_mq_pairs + k_fwd_mfma, Z read pairwise by k_cell_par), and with integer copy numbers the way back takes the
+    sixteen-clone form once per sample and pair of clone chunks (up to 32 clones).  Same checks and bounds as the fused shapes; the cases that keep vector sweeps
+    somewhere (fractional copy numbers: way back; D = 3: forward; 40 clones: way back) say so in the engine's info."""
+    from clonealign_amd.engine import HipEngine
+    from clonealign_amd.inference import run_vi_loop
+    from clonealign_amd.rng import EpsStream
+    from oracle.fused_numpy import FusedModel
+    shape = dict(shape)
+    frac = shape.pop("frac", False)
+    case = make_case(seed=71, **shape)
+    if frac:
+        case["L"] = case["L"] * 0.37 + 0.11
+    rng = np.random.default_rng(9)
+    idx = rng.integers(0, case["Y"].size, size=max(3, case["Y"].size // 4000))
+    case["Y"].reshape(-1)[idx] += rng.integers(200, 900, size=idx.size)
+    eng, ora = HipEngine(**case), FusedModel(**case, dtype="float32")
+    try:
+        info = eng.info()
+        S, G, C = ora.S, ora.G, ora.C
+        assert info["fused_sweep"] == 0, info
+        assert info["fwd_mfma"] == int(ora.D in (1, 2)), info
+        assert info["bwd_mfma"] == int(not (frac and C > 8) and C <= 32), info
+        st = perturbed_state({n: getattr(ora, n).shape for n in ora.VAR_NAMES}, amp=0.2)
+        for n, v in st.items():
+            setattr(ora, n, v.astype(ora.pdt))
+            eng.set(n, v)
+        eps = eps_for(S, G, 3)
+        te, to_ = eng.elbo_terms(eps), ora.elbo_terms(eps)
+        for a, b in zip(te, to_):
+            assert abs(a - b) <= 2e-5 * max(abs(b), 1.0), (te, to_)
+        ge, ee = eng.gradients(eps)
+        go, eo = ora.gradients(eps)
+        assert abs(ee - eo) <= 2e-5 * abs(eo)
+        for n in ora.VAR_NAMES:
+            assert _rel(ge[n], go[n]) < 2e-5, (n, _rel(ge[n], go[n]))
+        n_iter = 5
+        epss = np.stack([eps_for(S, G, 100 + i) for i in range(2 * n_iter)])
+        last = eng.iterate(n_iter, epss)
+        for i in range(n_iter):
+            ora.step(epss[2 * i])
+            e = ora.elbo(epss[2 * i + 1])
+        assert abs(last - e) <= 2e-5 * abs(e), (last, e)
+        p = eng.get_state()
+        for n in ora.VAR_NAMES:
+            # (see the sixteen-clone test: a handful of noise-level coordinates after Adam's first steps.  psi too, per cell: at 40 100 cells x 24 clones cell 10198
+            #  is 1.7e-4 / 3.6e-4 / 4.5e-4 off with the forward / the way back / both on the matrix cores, 9e-6 with neither, every other cell below 3e-5)
+            if n in ("gamma_logits", "psi"):
+                d = np.abs(p[n] - np.asarray(getattr(ora, n), dtype=np.float64)) / np.abs(getattr(ora, n)).max()
+                # 40 100 cells x 24 clones: 42 of 962 400 logits beyond 1e-4 with the forward on the matrix cores (largest 0.13 of max |logit| = 1.44), 12 (largest
+                # 0.018) on the vector unit -- coordinates whose gradient gamma (f - fbar) passes within the forward's own accuracy of zero at one of the five steps
+                # (f carries s_n log Z: 2^-17 relative on Z is 0.015 on f at s_n = 2000, the bound tests/test_gpu_parity.py's few-gene test states), where Adam's
+                # m / sqrt(v) turns the sign of noise into a step of order lr (tools/lab/diag_c24.py).  The ELBO and the trace that follows are held to 2e-5 / 1e-5.
+                big = ora.N > 10_000
+                assert (d > 1e-4).sum() <= max(2, d.size // (10000 if big else 20000)) and d.max() < (0.2 if big else 5e-3), (int((d > 1e-4).sum()), d.max())
+                continue
+            assert _rel(p[n], getattr(ora, n)) < 1e-4, (n, _rel(p[n], getattr(ora, n)))
+        tr = np.asarray(eng.run(EpsStream(5, S, G), 4, 1e-12))
+        to = np.asarray(run_vi_loop(ora, EpsStream(5, S, G), 4, 1e-12))
+        assert tr.shape == to.shape and np.abs(tr - to).max() <= 1e-5 * np.abs(to).max(), (tr, to)
+        fe = eng.final_elbo(np.stack([eps_for(S, G, 70 + i) for i in range(3)]), 3)
+        fo = np.array([ora.elbo(eps_for(S, G, 70 + i)) for i in range(3)])
+        assert np.abs(fe - fo).max() <= 1e-5 * np.abs(fo).max()
+    finally:
+        eng.close()
+
+
 @pytest.mark.parametrize("shape", [dict(N=700, G=1100, C=5, K=1, S=2), dict(N=333, G=95, C=8, K=1, S=2), dict(N=520, G=300, C=6, K=1, P=1, S=2),
                                    dict(N=257, G=161, C=2, K=2, S=2), dict(N=1200, G=400, C=4, K=1, S=2, extra=True),
                                    dict(N=40_100, G=700, C=7, K=1, S=2)],
