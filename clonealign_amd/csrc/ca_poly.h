@@ -32,6 +32,7 @@ inline bool ca_poly_covers(double xmax, double vlo, double vhi, int steps, doubl
   const double x = xmax + steps * step_bound, wdt = (vhi - vlo) + 2.0 * steps * step_bound;
   return x == x && wdt == wdt && x * wdt <= 2.0 * CA_PL_A * CA_PL_NB;   // nb = ceil(x w / (2 a)) <= NB
 }
-hipError_t ca_poly_cells(hipStream_t st, const ca_poly_ws* w, int64_t N, int C, int K, const void* cell_ptrs, const float* alpha_u, double* cell_part, float* dF);
+hipError_t ca_poly_cells(hipStream_t st, const ca_poly_ws* w, int64_t N, int C, int K, const void* cell_ptrs, const float* alpha_u, double* cell_part, float* dF,
+                         const void* yfin_args /* a ca_yfin_args: the count-matrix stream's finishing sums as extra blocks of the cell launch, or NULL */);
 hipError_t ca_poly_backward(hipStream_t st, const ca_poly_ws* w, const float* V, const float* mu, const float* Lb, int G, int C, double* red_g,
                             const void* small_tail /* a ca_small_args (pending monitor tail, run by an extra block) or NULL */);

@@ -197,7 +197,22 @@ __global__ void __launch_bounds__(TB_B) k_poly_B(const float* __restrict__ V, co
 template <int CP>
 __global__ void __launch_bounds__(CA_TB) k_poly_cell(const ca_poly_hdr* __restrict__ hdr, const double* __restrict__ tabB, ca_cell_ptrs p,
                                                      const float* __restrict__ alpha_u, double* __restrict__ cell_part, int64_t N, int C, int K,
-                                                     float* __restrict__ dF /*[N]*/, double* __restrict__ Qpart /*[grid][nb][R+2][C]*/) {
+                                                     float* __restrict__ dF /*[N]*/, double* __restrict__ Qpart /*[grid][nb][R+2][C]*/, int ncb, ca_yfin_args yfin) {
+  // Blocks behind the ncb cell blocks finish the count-matrix stream's two products (column sums, row sums and psi.(YW) partials: what k_yfinish does as a
+  // launch of its own, 5.4 us and a launch gap on the iteration's critical path): nothing in this launch reads them, the per-gene launch that follows does.
+  // The cell blocks are two to a CU and live as long as the launch; these few hundred short blocks take the free slots beside them.
+  if ((int)blockIdx.x >= ncb) {
+    const int e = (int)blockIdx.x - ncb;
+    const int ncolblk = (yfin.ncol + CA_TB / 64 - 1) / (CA_TB / 64);
+    if (e < ncolblk) {
+      const int job = e * (CA_TB / 64) + (int)(threadIdx.x >> 6);
+      if (job < yfin.ncol) ca_yfin_col_wave(yfin, job);
+    } else if (e - ncolblk < yfin.nrow) {
+      __shared__ double ca_yfin_sm[CA_TB / 64];
+      ca_yfin_row_block(yfin, e - ncolblk, ca_yfin_sm);
+    }
+    return;
+  }
   constexpr int CPB = CA_TB / CP;             // cells per pass of the block
   constexpr int RQ = R + 2;                   // moments 0 .. R + 1 (the derivative of q needs one more)
   constexpr int NBR = 4;                      // bins whose moments a thread keeps in registers (the usual case: one to three bins); the rest go through its slab
@@ -229,10 +244,10 @@ __global__ void __launch_bounds__(CA_TB) k_poly_cell(const ca_poly_hdr* __restri
   };
   double x_next = 0.0; ca_cell_pre pre_next = {0.f, 0.0, 0.0};
   if ((int64_t)blockIdx.x < ngroups) load_pass(blockIdx.x, x_next, pre_next);
-  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += ncb) {
     const int64_t n = grp * CPB + slot;
     const double x = x_next; const ca_cell_pre pre = pre_next;
-    if (grp + gridDim.x < ngroups) load_pass(grp + gridDim.x, x_next, pre_next);
+    if (grp + ncb < ngroups) load_pass(grp + ncb, x_next, pre_next);
     double ZA = 0.0, ZB = 0.0, dZB = 0.0;
     for (int b = 0; b < nb; ++b) {
       const double vb = vlo + ((double)b + 0.5) * delta;
@@ -389,12 +404,17 @@ hipError_t ca_poly_moments(hipStream_t st, const ca_poly_ws* w, const float* V, 
   return hipGetLastError();
 }
 
-hipError_t ca_poly_cells(hipStream_t st, const ca_poly_ws* w, int64_t N, int C, int K, const void* cell_ptrs, const float* alpha_u, double* cell_part, float* dF) {
+hipError_t ca_poly_cells(hipStream_t st, const ca_poly_ws* w, int64_t N, int C, int K, const void* cell_ptrs, const float* alpha_u, double* cell_part, float* dF,
+                         const void* yfin_args) {
   const ca_cell_ptrs& p = *static_cast<const ca_cell_ptrs*>(cell_ptrs);
+  ca_yfin_args yfin;
+  if (yfin_args) memcpy(&yfin, yfin_args, sizeof(yfin)); else memset(&yfin, 0, sizeof(yfin));
   int CP = 1;
   while (CP < C) CP <<= 1;
-  const dim3 grid(w->n_cell_blocks);
-#define CA_PCELL(CPV) hipLaunchKernelGGL((k_poly_cell<CPV>), grid, dim3(CA_TB), 0, st, w->hdr, w->tabB, p, alpha_u, cell_part, N, C, K, dF, w->Qpart)
+  const int nextra = yfin_args ? cdiv_i(yfin.ncol, CA_TB / 64) + yfin.nrow : 0;
+  const dim3 grid(w->n_cell_blocks + nextra);
+#define CA_PCELL(CPV) hipLaunchKernelGGL((k_poly_cell<CPV>), grid, dim3(CA_TB), 0, st, w->hdr, w->tabB, p, alpha_u, cell_part, N, C, K, dF, w->Qpart, \
+                                         w->n_cell_blocks, yfin)
   if (CP == 4) CA_PCELL(4); else CA_PCELL(8);   // (3 .. 8 clones: ca_poly_ok)
 #undef CA_PCELL
   hipLaunchKernelGGL(k_poly_red, dim3(256), dim3(CA_TB), 0, st, w->Qpart, w->n_cell_blocks, (int64_t)NB * (R + 2) * 8, w->hdr,

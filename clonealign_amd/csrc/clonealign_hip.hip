@@ -289,6 +289,9 @@ int ca_destroy(ca_handle h) {
   if (h->stream2) { hipStreamSynchronize(h->stream2); hipStreamDestroy(h->stream2); }
   if (h->ev_params) hipEventDestroy(h->ev_params);
   if (h->ev_ydone) hipEventDestroy(h->ev_ydone);
+  if (h->stream3) { hipStreamSynchronize(h->stream3); hipStreamDestroy(h->stream3); }
+  if (h->ev_poly0) hipEventDestroy(h->ev_poly0);
+  if (h->ev_poly1) hipEventDestroy(h->ev_poly1);
   if (h->ev_ywdone) hipEventDestroy(h->ev_ywdone);
   if (h->ev_stage) hipEventDestroy(h->ev_stage);
   if (h->comm) g_rccl.CommDestroy(h->comm);
