@@ -490,6 +490,9 @@ struct ca_merge_args {
   unsigned long long* gate_local;   // device memory: the relay's verdict, (gate_seq << 1) | go; the other blocks (and a forward sweep queued behind) read this
   int* vmm_at; int* vmm_at_next;   // range of V' over ALL genes as ordered ints [2][8]: every gene block folds its own in with one atomic min / max per
                                    // dimension (the next sweep reads 2 D words); the chi / alpha block resets the buffer of the NEXT merged update
+  float* xpart;                    // series form (ca_poly.hip, K = D = 1): max |psi| of the STEPPED state per 256-cell piece, [psi.nblk] -- k_poly_B / k_poly_ranges take
+                                   // the maximum of these instead of the word k_poly_xmax makes as a launch of its own; null: nobody wants it.  (One atomic
+                                   // maximum per wave into that word instead made this launch 14 us longer: 1563 atomics on one address.)
 };
 #define CA_GATE_WAITER_EXTRA (10ull * 100000000ull)   // a waiter's deadline over the relay's: 10 s of s_memrealtime ticks
 // every thread of the block calls it; true = go on (no gate, or the verdict is go).  relay: this block is the one that reads the host's word
@@ -675,6 +678,17 @@ __global__ void __launch_bounds__(CA_UM_TB) k_update_merged(const double* __rest
     if (b == 0) CA_LAB_CP(42, 0);
     if (pb < psi.nblk) {
       if (!ca_psi_adam_body_at(psi, (int64_t)pb * CA_TB + ((int)threadIdx.x & (CA_TB - 1)), 1, lr_t, b1, b2, aeps, &pn, &gt)) return;
+    }
+    if (mg.xpart) {   // (behind the gate: a launch that stores nothing stores nothing here either)
+      __shared__ float smx2[CA_UM_TB / 64];
+      float ax = fabsf(pn);
+      if (!(ax == ax)) ax = INFINITY;   // (k_poly_xmax's rule: a NaN latent position shows as an unbounded range)
+#pragma unroll
+      for (int q = 1; q < 64; q <<= 1) ax = fmaxf(ax, __shfl_xor(ax, q, 64));
+      if ((threadIdx.x & 63) == 0) smx2[threadIdx.x >> 6] = ax;
+      __syncthreads();
+      if ((threadIdx.x & (CA_TB - 1)) == 0 && pb < psi.nblk)
+        mg.xpart[pb] = fmaxf(fmaxf(smx2[4 * sub], smx2[4 * sub + 1]), fmaxf(smx2[4 * sub + 2], smx2[4 * sub + 3]));
     }
     if (b == 0) CA_LAB_CP(42, 1);
     if (mg.ysq.nblk) {   // the psi image: one wave per 64-step (ca_ys_quant_wave), the piece's pair of maxima from its four waves

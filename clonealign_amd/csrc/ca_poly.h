@@ -22,11 +22,13 @@ void ca_poly_bind(ca_poly_ws* w, void* base, int G, int n_cell_blocks);
 // forward, two steps: (1) the moments of both draws' M over the gene bins (three small launches); (2) per cell Z (both draws), dZ/dx (train draw), the cell
 // epilogue (cell_ptrs: a ca_cell_ptrs whose etamax2 is a zero vector), d/dF into dF[N] and the backward moments.  backward: red_g[g][0] = d/dmu,
 // red_g[g][1] = d/dV (the sweep's share, as k_bwd_mfma + k_colsum leave it).
+// (xpart / nx in either: max |x| of this state per piece of cells as the merged update that made the state left it, ca_merge_args::xpart -- no k_poly_xmax launch;
+//  NULL / 0: the launch is made)
 hipError_t ca_poly_moments(hipStream_t st, const ca_poly_ws* w, const float* V, const float* F, const float* muA, const float* muB, const float* Lb, int G,
                            int64_t N, int C, unsigned int* bad_word /* mapped host word set to 1 when the exponent range needs more than CA_PL_NB bins, or NULL */,
-                           double* mirror /* mapped host slot {seq, max|x|, min v, max v} of this state's ranges, or NULL */, double seq);
+                           double* mirror /* mapped host slot {seq, max|x|, min v, max v} of this state's ranges, or NULL */, double seq, const float* xpart, int nx);
 // the ranges alone (two tiny launches): a pass that takes the sweeps keeps the host's picture current with it
-hipError_t ca_poly_ranges(hipStream_t st, const ca_poly_ws* w, const float* V, const float* F, int G, int64_t N, double* mirror, double seq);
+hipError_t ca_poly_ranges(hipStream_t st, const ca_poly_ws* w, const float* V, const float* F, int G, int64_t N, double* mirror, double seq, const float* xpart, int nx);
 // can the series form cover a state whose ranges were (xmax, vlo, vhi) `steps` Adam steps ago, none of which moved a variable by more than `step_bound`?
 inline bool ca_poly_covers(double xmax, double vlo, double vhi, int steps, double step_bound) {
   const double x = xmax + steps * step_bound, wdt = (vhi - vlo) + 2.0 * steps * step_bound;

@@ -73,10 +73,15 @@ __global__ void __launch_bounds__(CA_TB) k_poly_xmax(const float* __restrict__ F
 }
 
 // ---- ranges only: one block scans V, takes the cells' maximum from k_poly_xmax's word (and resets it), mirrors both to the host -------------------------
-__global__ void __launch_bounds__(CA_TB) k_poly_ranges(const float* __restrict__ V, int G, unsigned int* __restrict__ xbits, double* __restrict__ mirror, double seq) {
-  __shared__ float smn[CA_TB / 64], smx[CA_TB / 64];
+__global__ void __launch_bounds__(CA_TB) k_poly_ranges(const float* __restrict__ V, int G, unsigned int* __restrict__ xbits, double* __restrict__ mirror, double seq,
+                                                       const float* __restrict__ xpart, int nx) {
+  __shared__ float smn[CA_TB / 64], smx[CA_TB / 64], sxm[CA_TB / 64];
   const int t = threadIdx.x;
   float mn = INFINITY, mx = -INFINITY;
+  float xm = 0.f;   // (nx > 0: max |x| per piece of cells as the merged update left it)
+  for (int i = t; i < nx; i += CA_TB) xm = fmaxf(xm, xpart[i]);
+  xm = warp_max(xm);
+  if ((t & 63) == 0) sxm[t >> 6] = xm;
   constexpr int U = 8;
   for (int g0_ = 0; g0_ < G; g0_ += CA_TB * U) {
     float v[U];
@@ -91,7 +96,7 @@ __global__ void __launch_bounds__(CA_TB) k_poly_ranges(const float* __restrict__
   if (t == 0) {
     mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
     mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
-    const double xmax = (double)__uint_as_float(*xbits);
+    const double xmax = nx > 0 ? (double)fmaxf(fmaxf(sxm[0], sxm[1]), fmaxf(sxm[2], sxm[3])) : (double)__uint_as_float(*xbits);
     *xbits = 0u;
     ca_poly_mirror_store(mirror, seq, xmax, (double)mn, (double)mx);
   }
@@ -104,8 +109,9 @@ __global__ void __launch_bounds__(CA_TB) k_poly_ranges(const float* __restrict__
 __global__ void __launch_bounds__(TB_B) k_poly_B(const float* __restrict__ V, const unsigned int* __restrict__ xbits, const float* __restrict__ muA,
                                                  const float* __restrict__ muB, const float* __restrict__ Lb /*[G][8]*/, int G, int C,
                                                  ca_poly_hdr* __restrict__ hdr, double* __restrict__ part, unsigned int* __restrict__ bad_word,
-                                                 double* __restrict__ mirror /* mapped host ring slot {seq, xmax, vlo, vhi} or null */, double seq) {
-  __shared__ float smn[TB_B / 64], smx[TB_B / 64];
+                                                 double* __restrict__ mirror /* mapped host ring slot {seq, xmax, vlo, vhi} or null */, double seq,
+                                                 const float* __restrict__ xpart /* nx > 0: max |x| per piece of cells (the merged update's), instead of *xbits */, int nx) {
+  __shared__ float smn[TB_B / 64], smx[TB_B / 64], sxm[TB_B / 64];
   __shared__ double pw[GPB][R + 1];
   __shared__ double Mg[GPB][16];
   __shared__ int binof[GPB];
@@ -122,14 +128,25 @@ __global__ void __launch_bounds__(TB_B) k_poly_B(const float* __restrict__ V, co
       for (int u = 0; u < U; ++u) { mn = fminf(mn, v[u]); mx = fmaxf(mx, v[u]); }
     }
   }
-  mn = warp_min(mn); mx = warp_max(mx);
-  if ((t & 63) == 0) { smn[t >> 6] = mn; smx[t >> 6] = mx; }
+  float xm = 0.f;
+  {
+    constexpr int U = 4;
+    for (int i0 = 0; i0 < nx; i0 += TB_B * U) {
+      float v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) { const int i = i0 + u * TB_B + t; v[u] = xpart[i < nx ? i : nx - 1]; }
+#pragma unroll
+      for (int u = 0; u < U; ++u) xm = fmaxf(xm, v[u]);
+    }
+  }
+  mn = warp_min(mn); mx = warp_max(mx); xm = warp_max(xm);
+  if ((t & 63) == 0) { smn[t >> 6] = mn; smx[t >> 6] = mx; sxm[t >> 6] = xm; }
   if (t < (NB + 31) / 32) present[t] = 0u;
   __syncthreads();
-  mn = smn[0]; mx = smx[0];
+  mn = smn[0]; mx = smx[0]; xm = sxm[0];
 #pragma unroll
-  for (int w_ = 1; w_ < TB_B / 64; ++w_) { mn = fminf(mn, smn[w_]); mx = fmaxf(mx, smx[w_]); }
-  const double vlo = (double)mn, width = (double)mx - (double)mn, xmax = (double)__uint_as_float(*xbits);
+  for (int w_ = 1; w_ < TB_B / 64; ++w_) { mn = fminf(mn, smn[w_]); mx = fmaxf(mx, smx[w_]); xm = fmaxf(xm, sxm[w_]); }
+  const double vlo = (double)mn, width = (double)mx - (double)mn, xmax = nx > 0 ? (double)xm : (double)__uint_as_float(*xbits);
   int nb = (int)ceil(xmax * width / (2.0 * CA_PL_A));
   nb = nb < 1 ? 1 : (nb > NB ? NB : nb);
   const double delta = width > 0.0 ? width / nb : 1.0;
@@ -389,16 +406,18 @@ void ca_poly_bind(ca_poly_ws* w, void* base, int G, int n_cell_blocks) {
   w->n_cell_blocks = n_cell_blocks; w->n_gene_blocks = (int)nbg;
 }
 
-hipError_t ca_poly_ranges(hipStream_t st, const ca_poly_ws* w, const float* V, const float* F, int G, int64_t N, double* mirror, double seq) {
-  hipLaunchKernelGGL(k_poly_xmax, dim3((unsigned)std::min<int64_t>(128, (N + 4 * CA_TB - 1) / (4 * CA_TB))), dim3(CA_TB), 0, st, F, N, w->xbits);
-  hipLaunchKernelGGL(k_poly_ranges, dim3(1), dim3(CA_TB), 0, st, V, G, w->xbits, mirror, seq);
+hipError_t ca_poly_ranges(hipStream_t st, const ca_poly_ws* w, const float* V, const float* F, int G, int64_t N, double* mirror, double seq, const float* xpart, int nx) {
+  if (!xpart) nx = 0;
+  if (nx == 0) hipLaunchKernelGGL(k_poly_xmax, dim3((unsigned)std::min<int64_t>(128, (N + 4 * CA_TB - 1) / (4 * CA_TB))), dim3(CA_TB), 0, st, F, N, w->xbits);
+  hipLaunchKernelGGL(k_poly_ranges, dim3(1), dim3(CA_TB), 0, st, V, G, w->xbits, mirror, seq, xpart, nx);
   return hipGetLastError();
 }
 
 hipError_t ca_poly_moments(hipStream_t st, const ca_poly_ws* w, const float* V, const float* F, const float* muA, const float* muB, const float* Lb, int G,
-                           int64_t N, int C, unsigned int* bad_word, double* mirror, double seq) {
-  hipLaunchKernelGGL(k_poly_xmax, dim3((unsigned)std::min<int64_t>(128, (N + 4 * CA_TB - 1) / (4 * CA_TB))), dim3(CA_TB), 0, st, F, N, w->xbits);
-  hipLaunchKernelGGL(k_poly_B, dim3(w->n_gene_blocks), dim3(TB_B), 0, st, V, w->xbits, muA, muB, Lb, G, C, w->hdr, w->partB, bad_word, mirror, seq);
+                           int64_t N, int C, unsigned int* bad_word, double* mirror, double seq, const float* xpart, int nx) {
+  if (!xpart) nx = 0;
+  if (nx == 0) hipLaunchKernelGGL(k_poly_xmax, dim3((unsigned)std::min<int64_t>(128, (N + 4 * CA_TB - 1) / (4 * CA_TB))), dim3(CA_TB), 0, st, F, N, w->xbits);
+  hipLaunchKernelGGL(k_poly_B, dim3(w->n_gene_blocks), dim3(TB_B), 0, st, V, w->xbits, muA, muB, Lb, G, C, w->hdr, w->partB, bad_word, mirror, seq, xpart, nx);
   hipLaunchKernelGGL(k_poly_red, dim3(256), dim3(CA_TB), 0, st, w->partB, w->n_gene_blocks, (int64_t)NB * (R + 1) * 16, w->hdr,
                      (R + 1) * 16, 0, C, w->tabB, w->xbits);
   return hipGetLastError();

@@ -30,7 +30,9 @@ for N, G, C in shapes:
     eps[-1] = eps[0]
     res = {}
     import os
-    knobs = [("series", {})] + [(f"series b{b} side{sd}", {"series_blocks": b, "series_side": sd}) for b, sd in ((1, 1), (2, 1), (3, 1), (2, 0), (8, 0))] if os.environ.get("SERIES_SWEEP") else [("series", {})]
+    # SERIES_SWEEP=1: the lab knobs (ca_options.reserved): cell blocks per CU; side 1 = the count-matrix stream on the side stream, 3 = the stream's finisher as a launch of its own,
+    # 4 = the moment launches on the side stream, 5 = k_poly_xmax as a launch of its own
+    knobs = [("series", {})] + [(f"series b{b} side{sd}", {"series_blocks": b, "series_side": sd}) for b, sd in ((2, 5), (2, 4), (2, 3), (2, 0))] if os.environ.get("SERIES_SWEEP") else [("series", {})]
     for name, von, tn in [("sweeps", (), {})] + [(n_, ("series",), t_) for n_, t_ in knobs]:
         voff = ("series",) if name == "sweeps" else ()
         eng = HipEngine(None, aux["L"], psi0, loc0, 1, 1, y_device_ptr=Yd.data_ptr(), y_device_dtype=np.int32, shape=(N, G), variant_on=von, variant_off=voff, profile=0, tune=tn)
