@@ -725,6 +725,7 @@ __global__ void __launch_bounds__(CA_YM_TB) k_yt_mfma(const uint4* __restrict__ 
   }
   ca_yt_block<TL, DEPTH>(Yb, Pq, GT, NS, schunk, out);
 }
+#ifdef CA_LAB   // (CA_VARX_Y_MFMA2's finisher)
 // Y^T psi from the slices' digit sums: integer sum over the slices (exact), digits combined in fp64, the fixed-point scale
 // taken out, the overflow list's chunk sums of the gene added.  One thread per (gene, k); red_y is [G][K].
 __global__ void __launch_bounds__(CA_TB) k_yt_finish(const int* __restrict__ out /*[csplit][GT * 16][16]*/, int csplit, int GT, int G, int K,
@@ -746,6 +747,7 @@ __global__ void __launch_bounds__(CA_TB) k_yt_finish(const int* __restrict__ out
   red_y[i] = v;
 }
 
+#endif   // CA_LAB
 // ------------------------------------------------------------------ one-shot peer-to-peer all-reduce
 // Round 4: the flag travels IN the data.  Slab of a rank (fine-grained device memory, IPC-mapped by every peer):
 //   inbox[parity 2][source rank W][cap entries], one entry = 16 bytes = {low half of the double, tag} {high half, tag}, each 8-byte half

@@ -29,6 +29,7 @@ typedef int ca_i32x4 __attribute__((ext_vector_type(4)));
 // fixed point of a parameter block: x = rint(v * 2^e) with |x| <= 2^30, e from the block's largest magnitude
 __device__ __forceinline__ int ca_fix_exp(float amax) { return amax > 0.f ? 29 - ilogbf(amax) : 0; }
 
+#ifdef CA_LAB   // (the two-copy form, CA_VARX_Y_MFMA2: measured slower than the one-copy stream, lab library only)
 // ---------------------------------------------------------------- tiling of the count matrix (once per fit)
 // row-major u8 [N][Gp] (Gp a multiple of 64) -> Yf.  One thread per 16-byte chunk of the image.
 __global__ void __launch_bounds__(CA_YM_TB) k_tile_yf(const uint8_t* __restrict__ Y, uint4* __restrict__ Yf, int64_t N, int Gp,
@@ -75,6 +76,7 @@ __global__ void __launch_bounds__(CA_YM_TB) k_tile_yb(const uint8_t* __restrict_
   Yb[((int64_t)T * NS + s) * 64 + l] = (uint4){w[0], w[1], w[2], w[3]};
 }
 
+#endif   // CA_LAB
 // ---------------------------------------------------------------- parameter images
 // amax[0] = max |W_gk|, amax[1] = max |psi_nk| as float bit patterns (non-negative floats order like unsigned ints, so
 // atomicMax gives the same value in any order); zeroed before each use.

@@ -266,6 +266,11 @@ int ca_create(const ca_problem* p, const ca_options* o, ca_handle* out) {
   if (p->K > 0 && !p->psi0) return bad("psi0 is required when K > 0");
   if (p->P > 0 && !p->X) return bad("X is required when P > 0");
   if (opt.world < 1 || opt.rank < 0 || opt.rank >= opt.world) return bad("bad rank/world");
+#ifndef CA_LAB
+  if (opt.variant_on & CA_LAB_VARX)
+    return bad("ca_options.variant_on asks for a variant that is built into the lab library only (CA_VARX_Y_MFMA2, CA_VARX_RIDE_SEQ, CA_VARX_BAL_TILES: measured slower than "
+               "what ships; `make -C clonealign_amd/csrc lab`)");
+#endif
   if ((p->cell_index || p->gene_index) && (p->N_src < p->N || p->G_src < p->G)) return bad("N_src / G_src must be at least N / G when a selection is given");
   ca_engine* h = new ca_engine();
   h->N = p->N; h->G = p->G; h->C = p->C; h->K = p->K; h->P = p->P; h->S = p->S; h->D = D;

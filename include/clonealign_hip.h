@@ -123,15 +123,15 @@ enum ca_variant {
   CA_VAR_RIDE_SEQ = 1 << 13   /* off: the riding stream as blocks of its own interleaved in the sweep's grid (k_fwd_cell_mix_y), never fused in
                                  sequence into the sweep's blocks (k_fwd_cell_seq_y; see CA_VARX_RIDE_SEQ) */
 };
-/* Opt-in variants (bits of ca_options.variant_on): measured slower than the default on the headline workload, kept built and
- * under test because they are the evidence for the choice. */
+/* Opt-in variants (bits of ca_options.variant_on).  Those marked LAB were measured slower than what ships and are kept as the evidence for the choice (DESIGN_HISTORY.md):
+ * since round 6 they are compiled into the lab library only (`make -C clonealign_amd/csrc lab`, -DCA_LAB); ca_create of the product library returns CA_ERR_INVALID for them. */
 enum ca_variant_on {
-  CA_VARX_Y_MFMA2 = 1 << 0,   /* count-matrix products on the int8 matrix cores from TWO tiled copies (cell-tiled for Y.W,
+  CA_VARX_Y_MFMA2 = 1 << 0,   /* LAB.  count-matrix products on the int8 matrix cores from TWO tiled copies (cell-tiled for Y.W,
                                  gene-tiled for Y^T.psi; ca_ymfma.hip.h): 6.0 TB/s per stream against 4.7 for k_ypass, but twice
                                  the bytes per iteration */
   CA_VARX_Y_MFMA1 = 1 << 2,   /* (round 2's opt-in for what is now the default, CA_VAR_Y_MFMA1; accepted and ignored) */
   CA_VARX_FOLD_ALWAYS = 1 << 3, /* backward-sweep partials summed inside the per-gene kernel at every size (default: up to 32k cells) */
-  CA_VARX_RIDE_SEQ = 1 << 4,  /* riding Y stream fused in sequence: every forward-sweep block also streams one unit of the count matrix,
+  CA_VARX_RIDE_SEQ = 1 << 4,  /* LAB.  riding Y stream fused in sequence: every forward-sweep block also streams one unit of the count matrix,
                                  before or after its sweep (k_fwd_cell_seq_y), instead of separate stream blocks in the same grid */
   CA_VARX_P2P_SAME_DEVICE = 1 << 5, /* test rigs only: let ca_p2p_connect map a peer handle of the SAME process on the SAME device (refused
                                  otherwise: device-wide synchronising runtime calls of one handle would wait on the other's all-reduce) */
@@ -140,7 +140,7 @@ enum ca_variant_on {
                                  the sweep is queued while the gated update may already be waiting for the host, and a runtime call made in that window can block
                                  behind another thread that holds a runtime lock while IT waits for the GPU (two engines of one process on one device did exactly
                                  that: the update then gives up after its 10 s and ca_run returns CA_ERR_STATE).  Worth about 1 us per iteration. */
-  CA_VARX_BAL_TILES = 1 << 7, /* balanced forward sweep of small problems (CA_VAR_FWD_BAL): a single-tile block of its own per left-over tile behind the sweep
+  CA_VARX_BAL_TILES = 1 << 7, /* LAB.  balanced forward sweep of small problems (CA_VAR_FWD_BAL): a single-tile block of its own per left-over tile behind the sweep
                                  blocks, no exchange (the stream's blocks then go to the CUs without one); default: the left-over tiles cut gene-wise into chunks
                                  that the sweep blocks sweep beside their own tiles, partial Z exchanged through tagged words.  Level at few left-over tiles,
                                  slower at many */

@@ -449,15 +449,25 @@ def test_final_elbos_from_pair_sweeps_equal_single_passes(shape):
         eng.close()
 
 
-@pytest.mark.parametrize("variant", ["y_mfma2", "y_mfma1"])
-@pytest.mark.parametrize("shape", [dict(N=1000, G=333, C=4, K=1), dict(N=777, G=130, C=3, K=2), dict(N=2100, G=1500, C=6, K=1, P=1),
-                                   dict(N=70, G=40, C=2, K=4), dict(N=4133, G=1030, C=8, K=1)])
+def test_variants_measured_slower_are_refused_by_the_product_library():
+    """Round 6: the two-copy int8 stream (y_mfma2), the riding stream fused in sequence into the sweep's blocks (ride_seq) and the balanced sweep's
+    single-tile blocks (bal_tiles) were measured slower than what ships and live in the LAB library only (`make -C clonealign_amd/csrc lab`).  The product library
+    says so at ca_create instead of ignoring the request."""
+    from clonealign_amd.engine import EngineError, HipEngine
+    case = make_case(seed=41, N=300, G=130, C=3, K=1)
+    for v in ("y_mfma2", "ride_seq", "bal_tiles"):
+        with pytest.raises(EngineError) as ei:
+            HipEngine(**case, variant_on=(v,))
+        assert ei.value.code == 1 and "lab library only" in str(ei.value), (v, str(ei.value))
+
+
+@pytest.mark.parametrize("variant", ["y_mfma1"])
+@pytest.mark.parametrize("shape", [dict(N=1000, G=333, C=4, K=1), dict(N=2100, G=1500, C=6, K=1, P=1), dict(N=4133, G=1030, C=8, K=1)])
 def test_count_matrix_products_on_the_int8_matrix_cores(shape, variant):
-    """Y.W and Y^T.psi of the loop from the tiled int8 copies (k_yw_mfma / k_yt_mfma: fixed-point parameters in four
-    base-256 digits, exact integer accumulation; the opt-in variant "y_mfma2"), or both from ONE tiled copy whose column form
-    comes out of the transposing LDS read (k_ys_mfma, "y_mfma1", K = 1; its fixed-point exponents are bounded from the previous
-    state's maxima inside the loop), against the VALU stream (k_ypass) and the oracle: ragged N and G (padding tiles), K up to
-    4, counts above 255 (overflow list next to the 1-byte copies), call by call and through the fused loop."""
+    """Y.W and Y^T.psi of the loop on the int8 matrix cores: fixed-point parameters in four base-256 digits, exact integer accumulation, both products from
+    ONE tiled copy whose column form comes out of the transposing LDS read (k_ys_mfma, "y_mfma1", K = 1; its fixed-point exponents are bounded from the previous
+    state's maxima inside the loop), against the VALU stream (k_ypass) and the oracle: ragged N and G (padding tiles), counts above 255 (overflow list next to
+    the 1-byte copy), call by call and through the fused loop.  (The two-copy form of round 2, "y_mfma2", K up to 4, is in the lab library only since round 6.)"""
     from clonealign_amd.engine import HipEngine
     from oracle.fused_numpy import FusedModel
     case = make_case(seed=41, **shape)
@@ -467,10 +477,10 @@ def test_count_matrix_products_on_the_int8_matrix_cores(shape, variant):
     if variant == "y_mfma1" and shape["K"] != 1:
         pytest.skip("the one-copy stream is built for K = 1")
     # ("y_mfma1" is the default stream since round 3 -- K = 1, 1-byte storage; `va` is the vector stream it replaced)
-    mf = HipEngine(**case, **(dict(variant_on=("y_mfma2",)) if variant == "y_mfma2" else {}))
+    mf = HipEngine(**case)
     va, ora = HipEngine(**case, variant_off=("y_mfma1",)), FusedModel(**case, dtype="float32")
     try:
-        assert (mf.info()["y_mfma"], va.info()["y_mfma"]) == ({"y_mfma2": 1, "y_mfma1": 2}[variant], 0) and mf.info()["y_storage_name"] == "u8"
+        assert (mf.info()["y_mfma"], va.info()["y_mfma"]) == (2, 0) and mf.info()["y_storage_name"] == "u8"
         st = perturbed_state({n: getattr(ora, n).shape for n in ora.VAR_NAMES}, amp=0.25)
         for n, v in st.items():
             setattr(ora, n, v.astype(ora.pdt))
@@ -503,27 +513,22 @@ def test_fixed_point_images_follow_the_parameter_scale():
     from clonealign_amd.engine import HipEngine
     case = make_case(seed=43, N=900, G=260, C=3, K=1)
     m1 = HipEngine(**case)                                  # the default: one tiled copy (y_mfma1)
-    mf, va = HipEngine(**case, variant_on=("y_mfma2",)), HipEngine(**case, variant_off=("y_mfma1",))
-    assert (m1.info()["y_mfma"], mf.info()["y_mfma"], va.info()["y_mfma"]) == (2, 1, 0)
+    va = HipEngine(**case, variant_off=("y_mfma1",))
+    assert (m1.info()["y_mfma"], va.info()["y_mfma"]) == (2, 0)
     try:
         rng = np.random.default_rng(1)
         for wamp, pamp in ((1e-6, 50.0), (3.0, 1e-4), (0.0, 1.0)):
             W = rng.normal(size=(260, 1)) * wamp
             psi = rng.normal(size=(900, 1)) * pamp
-            for eng in (mf, va, m1):
+            for eng in (va, m1):
                 eng.set("W", W); eng.set("psi", psi)
             eps = eps_for(1, 260, 5)
-            gm, _ = mf.gradients(eps)
             g1, _ = m1.gradients(eps)
             gv, _ = va.gradients(eps)
             for n in ("psi", "W"):
-                assert _rel(gm[n], gv[n]) < 3e-6, (wamp, pamp, n, _rel(gm[n], gv[n]))
                 assert _rel(g1[n], gv[n]) < 3e-6, (wamp, pamp, n, _rel(g1[n], gv[n]))
-                # same fixed-point images and exact integer sums in both MFMA forms; the one-copy form rounds each gene segment's /
-                # row group's share to float32 before the finisher adds them (the vector stream's slabs), the two-copy form once
-                assert _rel(g1[n], gm[n]) < 5e-7, (n, _rel(g1[n], gm[n]))
     finally:
-        mf.close(); va.close(); m1.close()
+        va.close(); m1.close()
 
 
 @pytest.mark.parametrize("shape", [dict(N=3000, G=700, C=5, K=1), dict(N=40_100, G=1100, C=8, K=1), dict(N=33, G=1030, C=3, K=1)])
@@ -541,15 +546,15 @@ def test_riding_dispatch_order_does_not_change_a_single_bit(shape):
     epss = np.stack([eps_for(1, G, 300 + i) for i in range(10)])
     for stream in ("int8", "vector"):          # the default int8 matrix-core stream (y_mfma1) and the vector stream it replaced
       ref = None
-      for pat in (None, "1:1", "3:2", "16:8", "1:200", "255:1", -3, -64, "seq", "mixed", "fin"):
-        # (negative: that many long-lived stream blocks lead the grid.  "seq" / "mixed", vector stream only: fused in sequence into the
-        #  sweep's own blocks, k_fwd_cell_seq_y, or as blocks of their own in the same grid, k_fwd_cell_mix_y.  "fin", int8 stream only:
+      for pat in (None, "1:1", "3:2", "16:8", "1:200", "255:1", -3, -64, "mixed", "fin"):
+        # (negative: that many long-lived stream blocks lead the grid.  "mixed", vector stream only: the sequence-fused form switched off outright -- it is
+        #  in the lab library only since round 6 --, the stream as blocks of its own in the same grid, k_fwd_cell_mix_y.  "fin", int8 stream only:
         #  the stream's finishing sums as a launch of their own between the sweeps, k_yfinish, instead of extra blocks of the backward
         #  sweep -- the same additions in the same order, and the monitor pass's ELBO assembled in one stage instead of two)
-        if (stream == "int8" and pat in ("seq", "mixed")) or (stream == "vector" and pat == "fin"):
+        if (stream == "int8" and pat == "mixed") or (stream == "vector" and pat == "fin"):
             continue
         voff = () if stream == "int8" else ("y_mfma1",)
-        kw = (dict(variant_on=("ride_seq",), variant_off=voff) if pat == "seq" else dict(variant_off=voff + ("ride_seq",)) if pat == "mixed" else
+        kw = (dict(variant_off=voff + ("ride_seq",)) if pat == "mixed" else
               dict(variant_off=voff + ("yfin_ride",)) if pat == "fin" else
               dict(variant_off=voff, tune=({} if pat is None else {"ride_pattern": pat})))
         eng = HipEngine(**case, **kw)

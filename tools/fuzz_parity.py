@@ -23,7 +23,7 @@ rng = np.random.default_rng(int(_args[1]) if len(_args) > 1 else 7)
 # engine variants as ca_options (the release library reads no switches from the environment since round 5): (variant_off, variant_on, tune)
 VARIANTS = [((), (), {})] * 4 + [(("fwd_cell",), (), {}), (("fwd_mfma",), (), {}), (("bwd_mfma",), (), {}), (("async_y",), (), {}), (("pre",), (), {}),
             (("tail_fuse",), (), {}), ((), (), {"fc_tl": 4, "fc_nbig": 2}), (("pair_elbo",), (), {}),
-            (("y_mfma1",), (), {}), (("y_mfma1",), ("ride_seq",), {}), (("y_mfma1", "y_ride"), (), {}), (("y_ride",), (), {}),
+            (("y_mfma1",), (), {}), (("y_mfma1", "y_ride"), (), {}), (("y_ride",), (), {}),
             (("update_merge",), (), {}), (("update_merge", "y_mfma1"), (), {}), (("s2_fuse",), (), {}), (("run_gate",), (), {}), (("fwd_bal",), (), {}), (("bwd_tl3",), (), {})]
 BAL = "--bal" in sys.argv   # shapes of the balanced eight-wave forward sweep (4096+ cells, 3072+ genes, K = 1, up to eight clones) against the C oracle
 fails = 0
