@@ -171,7 +171,12 @@ __global__ void __launch_bounds__(CA_TB) k_cell_par(const float* __restrict__ Zp
         if (coefq) {   // bf16 parts for the matrix-core backward sweep: three for up to eight clones, two per clone chunk for 9..16
           unsigned short p1, p2, p3;
           ca_split3(cfv, p1, p2, p3);
-          if (nchunk >= 2) {   // (slot = 2 * part + chunk of the pair, as the sixteen-lane fused epilogue writes it; one image per sample and chunk pair)
+          if (nchunk >= 2 && (nchunk & 1) && ch == nchunk - 1) {
+            // an odd LAST chunk stands alone: its image takes the eight-clone layout (three parts in slot groups 0..2) and the eight-clone form of the way back --
+            // 106 us at cfg-3's size where the sixteen-clone form against a chunk of zeros takes 127
+            unsigned short* qp = coefq + ((((int64_t)s * ((nchunk + 1) >> 1) + (ch >> 1)) * N16 + nn) * 4) * 8 + cc;
+            qp[0] = p1; qp[8] = p2; qp[16] = p3;
+          } else if (nchunk >= 2) {   // (slot = 2 * part + chunk of the pair, as the sixteen-lane fused epilogue writes it; one image per sample and chunk pair)
             unsigned short* qp = coefq + ((((int64_t)s * ((nchunk + 1) >> 1) + (ch >> 1)) * N16 + nn) * 4 + (ch & 1)) * 8 + cc;
             qp[0] = p1; qp[16] = p2;
             qp[q3_off] = p3;   // (the third part: same slot of the second image, k_bwd_mfma<.., C16>)
