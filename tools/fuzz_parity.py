@@ -34,6 +34,14 @@ for it in range(n_cases):
     K = int(rng.choice([0, 1, 1, 1, 2]))
     P = int(rng.choice([0, 0, 0, 1])) if K > 0 else 0
     S = 1 if rng.random() < 0.8 else 2
+    if "--r6" in sys.argv:   # round 6's argument space: D = K + P up to 5, up to 36 clones, up to four MC samples (matrix-core plain passes, D = 3 / 4 sweeps)
+        C = int(rng.integers(1, 37))
+        K = int(rng.choice([0, 1, 1, 2, 3, 4]))
+        P = int(rng.choice([0, 0, 1, 2, 3])) if K > 0 else 0
+        if K + P > 5:
+            P = 5 - K
+        S = int(rng.choice([1, 1, 2, 3, 4]))
+        N = int(rng.integers(1, 2500))
     if BAL:
         N, G, C, K, P, S = int(rng.integers(4096, 28672)), int(rng.integers(3072, 3400)), int(rng.integers(2, 9)), 1, 0, 1   # (up to six whole tiles per CU: the balanced range)
     voff, von, tune = VARIANTS[int(rng.integers(0, len(VARIANTS)))] if not BAL else ((), (), {})
