@@ -8,6 +8,9 @@
 #define CA_PL_R 20      // degree of a bin's Taylor piece
 #define CA_PL_NB 32     // most gene bins: covers |x|max (vmax - vmin) <= 4 CA_PL_NB
 #define CA_PL_A 2.0     // bound of |x| times half a bin's width
+#ifndef CA_PL_NBL
+#define CA_PL_NBL 4     // bins whose coefficient tables the cell kernel keeps in LDS
+#endif
 
 struct ca_poly_hdr { double vlo, delta, xmax; int nb, bad; };
 struct ca_poly_ws {

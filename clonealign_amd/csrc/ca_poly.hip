@@ -238,11 +238,16 @@ __global__ void __launch_bounds__(CA_TB) k_poly_cell(const ca_poly_hdr* __restri
   __shared__ double s_eb[CPB][NB];            // exp(x v_b)
   __shared__ double s_xp[CPB][RQ];            // x^k
   __shared__ double s_cf[CPB][8];             // coef
+  // the coefficient tables of the first NBL bins (the usual case has one to three) in LDS: every pass of the block reads them again, 42 loads per lane and bin,
+  // and from global memory those loads -- not the arithmetic -- were what a pass took
+  constexpr int NBL = CA_PL_NBL;
+  __shared__ double s_tb[NBL][(R + 1) * 16];
+  const int nb = hdr->nb;
   ca_log_softmax_alpha(alpha_u, C, la);
   for (int i = threadIdx.x; i < CPB * NB; i += CA_TB) (&s_eb[0][0])[i] = 0.0;   // (bins past nb: zeros, so that the gather needs no bounds)
+  for (int i = threadIdx.x; i < (nb < NBL ? nb : NBL) * (R + 1) * 16; i += CA_TB) (&s_tb[0][0])[i] = tabB[i];
   __syncthreads();
   const int t = threadIdx.x, c = t % CP, slot = t / CP;
-  const int nb = hdr->nb;
   const double vlo = hdr->vlo, delta = hdr->delta;
   // backward moments: thread t < (R + 2) C owns (k, clone) = (t / C, t % C) of EVERY bin -- nobody else adds to its outputs, cells are added in cell order
   const bool qown = t < RQ * C;
@@ -269,14 +274,18 @@ __global__ void __launch_bounds__(CA_TB) k_poly_cell(const ca_poly_hdr* __restri
     for (int b = 0; b < nb; ++b) {
       const double vb = vlo + ((double)b + 0.5) * delta;
       const double e = exp(x * vb);
-      const double* tb = tabB + ((int64_t)b * (R + 1)) * 16;
-      double pa = tb[R * 16 + cc], pb = tb[R * 16 + 8 + cc], dpb = 0.0;
-#pragma unroll 10
-      for (int k = R - 1; k >= 0; --k) {
-        dpb = dpb * x + pb;
-        pa = pa * x + tb[k * 16 + cc];
-        pb = pb * x + tb[k * 16 + 8 + cc];
+      double pa, pb, dpb = 0.0;
+#define CA_PL_HORNER(TB)                                                  \
+      pa = (TB)[R * 16 + cc]; pb = (TB)[R * 16 + 8 + cc];                 \
+      _Pragma("unroll 10")                                                \
+      for (int k = R - 1; k >= 0; --k) {                                  \
+        dpb = dpb * x + pb;                                               \
+        pa = pa * x + (TB)[k * 16 + cc];                                  \
+        pb = pb * x + (TB)[k * 16 + 8 + cc];                              \
       }
+      if (b < NBL) { CA_PL_HORNER(s_tb[b]) }                              // (LDS)
+      else { const double* tb = tabB + ((int64_t)b * (R + 1)) * 16; CA_PL_HORNER(tb) }
+#undef CA_PL_HORNER
       ZA += e * pa; ZB += e * pb; dZB += e * (vb * pb + dpb);
       if (c == 0) s_eb[slot][b] = e;
     }
