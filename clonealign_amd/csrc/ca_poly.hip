@@ -369,26 +369,46 @@ __global__ void __launch_bounds__(CA_TB) k_poly_gene(const ca_poly_hdr* __restri
     if (tail.enabled) ca_final_small_body(tail);
     return;
   }
-  const int g = blockIdx.x * CA_TB + threadIdx.x;
-  if (g >= G) return;
+  // The moment tables of the first NBL bins (the usual case has one to three) in LDS: a gene reads 176 doubles of its bin's table, and from global memory that
+  // was a chain of 320 dependent-latency loads per thread -- the 11.9 us this launch took.  One load per step: T_{k+1} of a step is T_k of the one before.
+  constexpr int NBL = CA_PL_NBL;
+  __shared__ double s_tq[NBL][RQ * 8];
   const int nb = hdr->nb;
   const double vlo = hdr->vlo, delta = hdr->delta;
+  for (int i = threadIdx.x; i < (nb < NBL ? nb : NBL) * RQ * C; i += CA_TB) s_tq[i / (RQ * C)][i % (RQ * C)] = tabQ[i];
+  __syncthreads();
+  const int g = blockIdx.x * CA_TB + threadIdx.x;
+  if (g >= G) return;
   const double v = (double)V[g];
   int b = (int)floor((v - vlo) / delta);
   b = b < 0 ? 0 : (b >= nb ? nb - 1 : b);
   const double dv = v - (vlo + ((double)b + 0.5) * delta);
-  const double* tq = tabQ + (int64_t)b * RQ * C;       // T_k = Q_k / k!
-  double s0 = 0.0, s1 = 0.0;
-  for (int c = 0; c < C; ++c) {
-    // q = sum_{k <= R} dv^k T_k;  q' = sum_{k <= R} dv^k (k + 1) T_{k+1}
-    double q = tq[R * C + c], dq = (double)(R + 1) * tq[(R + 1) * C + c];
-    for (int k = R - 1; k >= 0; --k) {
-      q = q * dv + tq[k * C + c];
-      dq = dq * dv + (double)(k + 1) * tq[(k + 1) * C + c];
-    }
-    const double l = (double)Lb[(int64_t)g * CA_CW + c];
-    s0 += l * q; s1 += l * dq;
+  float lrow[8];
+  {
+    const float4 l0 = *reinterpret_cast<const float4*>(Lb + (int64_t)g * CA_CW), l1 = *reinterpret_cast<const float4*>(Lb + (int64_t)g * CA_CW + 4);
+    lrow[0] = l0.x; lrow[1] = l0.y; lrow[2] = l0.z; lrow[3] = l0.w; lrow[4] = l1.x; lrow[5] = l1.y; lrow[6] = l1.z; lrow[7] = l1.w;
   }
+  double s0 = 0.0, s1 = 0.0;
+  // q = sum_{k <= R} dv^k T_k;  q' = sum_{k <= R} dv^k (k + 1) T_{k+1}   (T_k = Q_k / k!)
+#define CA_PL_GENE(TQ)                                                            \
+  _Pragma("unroll")                                                               \
+  for (int c = 0; c < 8; ++c) {                                                   \
+    if (c < C) {                                                                  \
+      double tn = (TQ)[(R + 1) * C + c], tk = (TQ)[R * C + c];                    \
+      double q = tk, dq = (double)(R + 1) * tn;                                   \
+      _Pragma("unroll 10")                                                        \
+      for (int k = R - 1; k >= 0; --k) {                                          \
+        tn = tk; tk = (TQ)[k * C + c];                                            \
+        q = q * dv + tk;                                                          \
+        dq = dq * dv + (double)(k + 1) * tn;                                      \
+      }                                                                           \
+      const double l = (double)lrow[c];                                           \
+      s0 += l * q; s1 += l * dq;                                                  \
+    }                                                                             \
+  }
+  if (nb <= NBL) { CA_PL_GENE(s_tq[b]) }   // (uniform)
+  else { const double* tq = tabQ + (int64_t)b * RQ * C; CA_PL_GENE(tq) }
+#undef CA_PL_GENE
   red_g[(int64_t)g * 2 + 0] = s0;
   red_g[(int64_t)g * 2 + 1] = (double)mu[g] * s1;
 }
