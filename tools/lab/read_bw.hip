@@ -122,5 +122,24 @@ int main() {
       }
     }
   }
+  {   // the same reader held to the stream's occupancy: dynamic LDS sized so that only `bpc` four-wave blocks fit a CU (160 KB)
+    const int gb = 80, nst = 1563, steps = 4;
+    uint4* big; CK(hipMalloc(&big, (size_t)nst * gb * 4096)); CK(hipMemset(big, 1, (size_t)nst * gb * 4096));
+    const size_t eb = (size_t)nst * gb * 4096;
+    const int nrg = (nst + 4 * steps - 1) / (4 * steps), blocks = nrg * (gb / 8);
+    for (int bpc : {1, 2, 3, 4, 6}) {
+      const size_t lds = (size_t)(160 * 1024 / bpc) - 1024;
+      CK(hipFuncSetAttribute((const void*)k_read_engine<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      CK(hipFuncSetAttribute((const void*)k_read_engine<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      for (int dep = 2; dep <= 4; dep += 2) {
+        auto go = [&] { if (dep == 2) hipLaunchKernelGGL((k_read_engine<2>), dim3(blocks), dim3(256), lds, 0, big, nst, gb, steps, out); else hipLaunchKernelGGL((k_read_engine<4>), dim3(blocks), dim3(256), lds, 0, big, nst, gb, steps, out); };
+        for (int i = 0; i < 3; ++i) go();
+        (void)hipDeviceSynchronize();
+        float best = 1e9f;
+        for (int r = 0; r < 10; ++r) { (void)hipEventRecord(a); go(); (void)hipEventRecord(b); (void)hipEventSynchronize(b); float ms; (void)hipEventElapsedTime(&ms, a, b); best = ms < best ? ms : best; }
+        printf("engine layout, %d blocks per CU (%d waves per SIMD), %d pieces in flight per wave: best %.1f us = %.2f TB/s\n", bpc, bpc, dep, best * 1e3, eb / (best * 1e-3) / 1e12);
+      }
+    }
+  }
   return 0;
 }
