@@ -601,7 +601,8 @@ def main():
     info = eng.info()
     if world > 1:
         assert info["transport_name"] == {"p2p": "p2p", "rccl": "rccl"}.get(collective, "host"), info["transport_name"]
-        assert info["red_n"] == sharding.reduce_plan(G, C, K, 0, 1)["total"], (info["red_n"], sharding.reduce_plan(G, C, K, 0, 1))
+        plan = sharding.reduce_plan(G, C, K, 0, 1, series=bool(info["fwd_series"]), world=world)
+        assert info["red_n"] == plan["total"], (info["red_n"], plan)
     # The CPU baseline's copy of the counts is taken AFTER the GPU measurements (the generated matrix stays on the device until
     # then): fetching and converting 2 GB here left the GPU idle for seconds in front of the timed region, and W = 5 warm-up
     # iterations (1.7 ms) do not bring its clocks back -- the driver-style run read 3 % low whenever the baseline was on.
@@ -621,6 +622,11 @@ def main():
     eng.iterate(max(args.warmup, 1), eps_w)
     kt = eng.kernel_times(reset=True)
     dominant = max(("fwd", "bwd", "ypass"), key=lambda k: kt[k][0])
+    if info.get("fwd_series") and kt["ypass"][0] > 0:
+        # the series form: the count-matrix stream is the one launch whose work is proportional to the matrix (HBM-bound); the "fwd" class there is a handful of
+        # small launches and the cell kernel, with no flop count of the reference's formulation to price them against -- at 2+ ranks (half the matrix per rank)
+        # their summed warm-up time can edge past the stream's, and the sweeps' flop roofline would be quoted for kernels that do not execute those flops
+        dominant = "ypass"
     kid = {"fwd": 0, "bwd": 1, "ypass": 2}[dominant]
     # live HIP events around every 8th launch of the dominant class (an event pair costs the stream 5-6 us: 1.6 % at cfg-3, 9 % at
     # cfg-2 when every launch is timed -- measured with --no-live-events; sampled, the timed region is left alone)
@@ -875,7 +881,7 @@ def main():
                        "fused_sweep": bool(info.get("fused_sweep")), "fwd_mfma": bool(info.get("fwd_mfma")), "series_form": bool(info.get("fwd_series")),
                        "bwd_mfma": bool(info.get("bwd_mfma")), "y_mfma": bool(info.get("y_mfma")),
                        "parallelism": f"cells/{world}" if world > 1 else "single", "collective": collective,
-                       "collectives_tried": tried, "allreduce_selftest": selftest, "allreduce_doubles_per_train_pass": int(info["red_n"]),
+                       "collectives_tried": tried, "allreduce_selftest": selftest, "allreduce_doubles_per_train_pass": int(sharding.reduce_plan(G, C, K, 0, 1, series=bool(info["fwd_series"]), world=world).get("series_total", info["red_n"])) if world > 1 else int(info["red_n"]),
                        "build_id": build, **({"foreign_library": True} if foreign else {})},
             "repeats": {"n": len(regions), "ms_per_step_median": step_s * 1e3, "ms_per_step_min": min(regions) / args.steps * 1e3,
                         "ms_per_step_max": max(regions) / args.steps * 1e3,

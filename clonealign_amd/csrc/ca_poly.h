@@ -29,9 +29,13 @@ void ca_poly_bind(ca_poly_ws* w, void* base, int G, int n_cell_blocks);
 //  NULL / 0: the launch is made)
 hipError_t ca_poly_moments(hipStream_t st, const ca_poly_ws* w, const float* V, const float* F, const float* muA, const float* muB, const float* Lb, int G,
                            int64_t N, int C, unsigned int* bad_word /* mapped host word set to 1 when the exponent range needs more than CA_PL_NB bins, or NULL */,
-                           double* mirror /* mapped host slot {seq, max|x|, min v, max v} of this state's ranges, or NULL */, double seq, const float* xpart, int nx);
+                           double* mirror /* mapped host slot {seq, max|x|, min v, max v} of this state's ranges, or NULL */, double seq, const float* xpart, int nx,
+                           const double* xglob /* sharded: every rank's max |x| one Adam step back (ca_poly_xslot + the collective), or NULL */, int nglob, double xadd);
 // the ranges alone (two tiny launches): a pass that takes the sweeps keeps the host's picture current with it
-hipError_t ca_poly_ranges(hipStream_t st, const ca_poly_ws* w, const float* V, const float* F, int G, int64_t N, double* mirror, double seq, const float* xpart, int nx);
+hipError_t ca_poly_ranges(hipStream_t st, const ca_poly_ws* w, const float* V, const float* F, int G, int64_t N, double* mirror, double seq, const float* xpart, int nx,
+                          const double* xglob, int nglob, double xadd);
+// sharded: this rank's max |x| of the current state into slots[rank], zeros into the other world - 1 slots (they are summed by the fit's collective)
+hipError_t ca_poly_xslot(hipStream_t st, const float* xpart, int nx, const float* F, int64_t N, double* slots, int rank, int world);
 // can the series form cover a state whose ranges were (xmax, vlo, vhi) `steps` Adam steps ago, none of which moved a variable by more than `step_bound`?
 inline bool ca_poly_covers(double xmax, double vlo, double vhi, int steps, double step_bound) {
   const double x = xmax + steps * step_bound, wdt = (vhi - vlo) + 2.0 * steps * step_bound;

@@ -73,8 +73,10 @@ __global__ void __launch_bounds__(CA_TB) k_poly_xmax(const float* __restrict__ F
 }
 
 // ---- ranges only: one block scans V, takes the cells' maximum from k_poly_xmax's word (and resets it), mirrors both to the host -------------------------
+// (xglob / nglob / xadd: a cell-sharded fit -- max |x| over ALL ranks' cells as the last collective left it, one slot per rank, for the state one Adam step back,
+//  plus what that step can have added: the same number on every rank, so that every rank takes the same decisions; see ca_poly_xslot)
 __global__ void __launch_bounds__(CA_TB) k_poly_ranges(const float* __restrict__ V, int G, unsigned int* __restrict__ xbits, double* __restrict__ mirror, double seq,
-                                                       const float* __restrict__ xpart, int nx) {
+                                                       const float* __restrict__ xpart, int nx, const double* __restrict__ xglob, int nglob, double xadd) {
   __shared__ float smn[CA_TB / 64], smx[CA_TB / 64], sxm[CA_TB / 64];
   const int t = threadIdx.x;
   float mn = INFINITY, mx = -INFINITY;
@@ -96,7 +98,8 @@ __global__ void __launch_bounds__(CA_TB) k_poly_ranges(const float* __restrict__
   if (t == 0) {
     mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
     mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
-    const double xmax = nx > 0 ? (double)fmaxf(fmaxf(sxm[0], sxm[1]), fmaxf(sxm[2], sxm[3])) : (double)__uint_as_float(*xbits);
+    double xmax = nx > 0 ? (double)fmaxf(fmaxf(sxm[0], sxm[1]), fmaxf(sxm[2], sxm[3])) : (double)__uint_as_float(*xbits);
+    if (nglob > 0) { xmax = 0.0; for (int r = 0; r < nglob; ++r) xmax = fmax(xmax, xglob[r]); xmax += xadd; }
     *xbits = 0u;
     ca_poly_mirror_store(mirror, seq, xmax, (double)mn, (double)mx);
   }
@@ -110,7 +113,8 @@ __global__ void __launch_bounds__(TB_B) k_poly_B(const float* __restrict__ V, co
                                                  const float* __restrict__ muB, const float* __restrict__ Lb /*[G][8]*/, int G, int C,
                                                  ca_poly_hdr* __restrict__ hdr, double* __restrict__ part, unsigned int* __restrict__ bad_word,
                                                  double* __restrict__ mirror /* mapped host ring slot {seq, xmax, vlo, vhi} or null */, double seq,
-                                                 const float* __restrict__ xpart /* nx > 0: max |x| per piece of cells (the merged update's), instead of *xbits */, int nx) {
+                                                 const float* __restrict__ xpart /* nx > 0: max |x| per piece of cells (the merged update's), instead of *xbits */, int nx,
+                                                 const double* __restrict__ xglob, int nglob, double xadd) {
   __shared__ float smn[TB_B / 64], smx[TB_B / 64], sxm[TB_B / 64];
   __shared__ double pw[GPB][R + 1];
   __shared__ double Mg[GPB][16];
@@ -146,7 +150,9 @@ __global__ void __launch_bounds__(TB_B) k_poly_B(const float* __restrict__ V, co
   mn = smn[0]; mx = smx[0]; xm = sxm[0];
 #pragma unroll
   for (int w_ = 1; w_ < TB_B / 64; ++w_) { mn = fminf(mn, smn[w_]); mx = fmaxf(mx, smx[w_]); xm = fmaxf(xm, sxm[w_]); }
-  const double vlo = (double)mn, width = (double)mx - (double)mn, xmax = nx > 0 ? (double)xm : (double)__uint_as_float(*xbits);
+  double xmax = nx > 0 ? (double)xm : (double)__uint_as_float(*xbits);
+  if (nglob > 0) { xmax = 0.0; for (int r = 0; r < nglob; ++r) xmax = fmax(xmax, xglob[r]); xmax += xadd; }   // (uniform; a handful of ranks)
+  const double vlo = (double)mn, width = (double)mx - (double)mn;
   int nb = (int)ceil(xmax * width / (2.0 * CA_PL_A));
   nb = nb < 1 ? 1 : (nb > NB ? NB : nb);
   const double delta = width > 0.0 ? width / nb : 1.0;
@@ -435,18 +441,40 @@ void ca_poly_bind(ca_poly_ws* w, void* base, int G, int n_cell_blocks) {
   w->n_cell_blocks = n_cell_blocks; w->n_gene_blocks = (int)nbg;
 }
 
-hipError_t ca_poly_ranges(hipStream_t st, const ca_poly_ws* w, const float* V, const float* F, int G, int64_t N, double* mirror, double seq, const float* xpart, int nx) {
+// a cell-sharded fit: this rank's max |x| of the CURRENT state into its slot of `slots[world]`, zeros into the others -- the sum over the ranks (the fit's one collective
+// per iteration carries the slots) then holds every rank's maximum.  One block; from the merged update's per-piece maxima where they are current, else from F.
+__global__ void __launch_bounds__(CA_TB) k_poly_xslot(const float* __restrict__ xpart, int nx, const float* __restrict__ F, int64_t N, double* __restrict__ slots, int rank,
+                                                      int world) {
+  __shared__ float sx[CA_TB / 64];
+  float ax = 0.f;
+  if (nx > 0) { for (int i = threadIdx.x; i < nx; i += CA_TB) ax = fmaxf(ax, xpart[i]); }
+  else { for (int64_t i = threadIdx.x; i < N; i += CA_TB) { const float a = fabsf(F[i]); ax = fmaxf(ax, a == a ? a : INFINITY); } }
+  ax = warp_max(ax);
+  if ((threadIdx.x & 63) == 0) sx[threadIdx.x >> 6] = ax;
+  __syncthreads();
+  if ((int)threadIdx.x < world) slots[threadIdx.x] = (int)threadIdx.x == rank ? (double)fmaxf(fmaxf(sx[0], sx[1]), fmaxf(sx[2], sx[3])) : 0.0;
+}
+hipError_t ca_poly_xslot(hipStream_t st, const float* xpart, int nx, const float* F, int64_t N, double* slots, int rank, int world) {
+  hipLaunchKernelGGL(k_poly_xslot, dim3(1), dim3(CA_TB), 0, st, xpart, xpart ? nx : 0, F, N, slots, rank, world);
+  return hipGetLastError();
+}
+
+hipError_t ca_poly_ranges(hipStream_t st, const ca_poly_ws* w, const float* V, const float* F, int G, int64_t N, double* mirror, double seq, const float* xpart, int nx,
+                          const double* xglob, int nglob, double xadd) {
   if (!xpart) nx = 0;
-  if (nx == 0) hipLaunchKernelGGL(k_poly_xmax, dim3((unsigned)std::min<int64_t>(128, (N + 4 * CA_TB - 1) / (4 * CA_TB))), dim3(CA_TB), 0, st, F, N, w->xbits);
-  hipLaunchKernelGGL(k_poly_ranges, dim3(1), dim3(CA_TB), 0, st, V, G, w->xbits, mirror, seq, xpart, nx);
+  if (!xglob) nglob = 0;
+  if (nx == 0 && nglob == 0) hipLaunchKernelGGL(k_poly_xmax, dim3((unsigned)std::min<int64_t>(128, (N + 4 * CA_TB - 1) / (4 * CA_TB))), dim3(CA_TB), 0, st, F, N, w->xbits);
+  hipLaunchKernelGGL(k_poly_ranges, dim3(1), dim3(CA_TB), 0, st, V, G, w->xbits, mirror, seq, xpart, nglob ? 0 : nx, xglob, nglob, xadd);
   return hipGetLastError();
 }
 
 hipError_t ca_poly_moments(hipStream_t st, const ca_poly_ws* w, const float* V, const float* F, const float* muA, const float* muB, const float* Lb, int G,
-                           int64_t N, int C, unsigned int* bad_word, double* mirror, double seq, const float* xpart, int nx) {
+                           int64_t N, int C, unsigned int* bad_word, double* mirror, double seq, const float* xpart, int nx, const double* xglob, int nglob, double xadd) {
   if (!xpart) nx = 0;
-  if (nx == 0) hipLaunchKernelGGL(k_poly_xmax, dim3((unsigned)std::min<int64_t>(128, (N + 4 * CA_TB - 1) / (4 * CA_TB))), dim3(CA_TB), 0, st, F, N, w->xbits);
-  hipLaunchKernelGGL(k_poly_B, dim3(w->n_gene_blocks), dim3(TB_B), 0, st, V, w->xbits, muA, muB, Lb, G, C, w->hdr, w->partB, bad_word, mirror, seq, xpart, nx);
+  if (!xglob) nglob = 0;
+  if (nx == 0 && nglob == 0) hipLaunchKernelGGL(k_poly_xmax, dim3((unsigned)std::min<int64_t>(128, (N + 4 * CA_TB - 1) / (4 * CA_TB))), dim3(CA_TB), 0, st, F, N, w->xbits);
+  hipLaunchKernelGGL(k_poly_B, dim3(w->n_gene_blocks), dim3(TB_B), 0, st, V, w->xbits, muA, muB, Lb, G, C, w->hdr, w->partB, bad_word, mirror, seq, xpart, nglob ? 0 : nx,
+                     xglob, nglob, xadd);
   hipLaunchKernelGGL(k_poly_red, dim3(256), dim3(CA_TB), 0, st, w->partB, w->n_gene_blocks, (int64_t)NB * (R + 1) * 16, w->hdr,
                      (R + 1) * 16, 0, C, w->tabB, w->xbits);
   return hipGetLastError();

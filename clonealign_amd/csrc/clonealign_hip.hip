@@ -129,6 +129,7 @@ struct gate_snapshot {
     for (int i = 0; i < 3; ++i) h->ys_namax[i] = ys_namax[i];
     h->b1p = b1p; h->b2p = b2p; h->adam_steps = adam_steps;
     h->poly_xmax_ready = false;   // (the cancelled launch added nothing to the series form's max |psi| word)
+    h->poly_xglob_steps = -1;
     h->vchi = vchi; h->vchi_alt = vchi_alt; h->alpha_u = alpha_u; h->alpha_u_alt = alpha_u_alt;
   }
 };

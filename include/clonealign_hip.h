@@ -107,7 +107,7 @@ enum ca_variant {
                                  work; off: 16- / 32-cell four-wave blocks, as many as the cells need */
   CA_VAR_BWD_TL3 = 1 << 20,   /* small problems (up to 18 432 cells): the matrix-core backward sweep takes three gene tiles per wave instead of four -- more and
                                  shorter wave jobs; off: four at every size */
-  CA_VAR_SERIES = 1 << 21,    /* ABI 6: large problems with a rank-one exponent (K + P = 1, one MC sample, 3..8 clones, 1-byte storage; from 32k cells and 1.4e8
+  CA_VAR_SERIES = 1 << 21,    /* ABI 6: large problems with a rank-one exponent (K + P = 1, one MC sample, 3..8 clones, 1-byte storage; where G >= 2000 + 2.5e7 / N -- the round's first form: from 32k cells and 1.4e8
                                  counts): the loop's contraction in its SERIES form (ca_poly.hip, see CA_VARX_SERIES) -- moments over gene bins instead of the
                                  cells x genes sweeps; off: the matrix-core sweeps at every size */
   CA_VAR_P2P = 1 << 10,       /* one-shot peer-to-peer all-reduce (else ncclAllReduce) after ca_comm_init() */

@@ -388,3 +388,48 @@ def test_inference_tflow_over_the_peer_to_peer_transport_on_one_device_at_cfg2()
     t1, t2 = one["convergence_info"]["elbo"], two["convergence_info"]["elbo"]
     assert t1.shape == t2.shape and _close(t2, t1, 3e-7)
     assert label_flips(two["ml_params"]["clone_probs"], one["ml_params"]["clone_probs"])[0] == 0
+
+
+@pytest.mark.parametrize("world,transport", [(2, "host"), (3, "host"), (2, "p2p")])
+def test_group_takes_the_series_form_of_the_contraction_sharded(world, transport):
+    """Round 6, late: a cell-sharded fit takes the series form of the contraction (ca_poly.hip) like an unsharded one.  What makes the ranks agree: the bin geometry
+    and the host's series-or-sweeps decision follow from max |psi| over ALL cells -- every rank's maximum travels in the fit's one collective per iteration for the
+    state before the update, and what one Adam step can add covers the state after it -- and the backward moments Q are what that collective sums instead of the
+    per-gene gradients.  ca_run (flushed monitor passes: the cell sums are global before the train pass's collective), ca_iterate (pending monitor tails: local sums
+    travel) and the final ELBOs against the one-handle series fit; replicas bit-identical (the group checks); every pass of every rank on the series form."""
+    from clonealign_amd.engine import HipEngine, HipGroupEngine
+    from clonealign_amd.rng import EpsStream
+    case = make_case(seed=31, **CASES["k1"])
+    G, S = case["Y"].shape[1], case["S"]
+    eps = np.stack([eps_for(S, G, 500 + i) for i in range(13)])
+
+    def drive(eng):
+        tr = np.asarray(eng.run(EpsStream(77, S, G), 6, 1e-12))
+        last = eng.iterate(6, eps)
+        tr2 = np.asarray(eng.run(EpsStream(79, S, G), 3, 1e-12))
+        fin = np.asarray(eng.final_elbo(EpsStream(78, S, G), 4))
+        return tr, last, tr2, fin, eng.get_state(), eng.get_params()
+
+    one = HipEngine(**case, variant_on=("series",))
+    try:
+        ref = drive(one)
+        i1 = one.info()
+        assert i1["fwd_series"] == 1 and i1["series_passes"] > 10 and i1["series_fallbacks"] == 0, i1
+    finally:
+        one.close()
+    von = ("series",) + (("p2p_same_device",) if transport == "p2p" else ())
+    mk = lambda: HipGroupEngine(**case, devices=[0] * world, transport=transport, variant_on=von, comm_timeout_ms=5000)   # noqa: E731
+    grp = _rig_or_skip(mk) if transport == "p2p" else mk()
+    try:
+        assert grp.group_info()["transport_name"] == transport
+        got = _rig_or_skip(lambda: drive(grp)) if transport == "p2p" else drive(grp)
+        for r in range(world):
+            ri = grp.rank_info(r)
+            assert ri["fwd_series"] == 1 and ri["series_passes"] == i1["series_passes"] and ri["series_fallbacks"] == 0, (r, ri)
+    finally:
+        grp.close()
+    assert _close(got[0], ref[0], 3e-7) and abs(got[1] - ref[1]) <= 3e-7 * abs(ref[1]) and _close(got[2], ref[2], 3e-7) and _close(got[3], ref[3], 2e-6)
+    for n, v in ref[4].items():
+        assert got[4][n].shape == v.shape and _close(got[4][n], v, 5e-5), n
+    flips, _ = label_flips(got[5]["clone_probs"], ref[5]["clone_probs"])
+    assert flips == 0
