@@ -321,3 +321,20 @@ def test_bench_on_eight_gpus_uses_a_device_collective_and_replicas_agree(tmp_pat
     single = _run(1, "none", tmp_path / "one.json", True)["ranks"][0]
     for tr in ("p2p", "rccl"):
         _check(_run(8, tr, tmp_path / f"{tr}8.json", False), single, tr)
+
+
+def test_bench_two_ranks_take_the_series_form_sharded():
+    """Round 6, late: one process per rank (IPC-mapped peer-to-peer inboxes), a shape whose ranks take the series form of the contraction (15 000 cells x 5000
+    genes per rank): every pass on the series form on both ranks, replicas bit-identical after the timed regions, and the payload of the collective is the
+    series prefix of sharding.reduce_plan (cell sums, Y^T psi, backward moments, a max |psi| slot per rank) -- not the per-gene sums."""
+    from clonealign_amd import sharding
+    r = _bench(2, [], shape=("--cells", "30000", "--genes", "5000", "--clones", "8"))
+    assert r.returncode == 0, child_report(r)
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["collective"] == "p2p" and line["config"]["series_form"] is True, line["config"]
+    sf = line["roofline"]["series_form"]
+    assert sf["passes"] > 0 and sf["handed_to_the_sweeps"] == 0, sf
+    assert line["replicas_bit_identical_after_timed_regions"] is True
+    plan = sharding.reduce_plan(5000, 8, 1, 0, 1, series=True, world=2)
+    assert line["config"]["allreduce_doubles_per_train_pass"] == plan["series_total"] == 3 + 8 + 5120 + 32 * 22 * 8 + 2
+    assert line["roofline"]["kernel"] == "ypass" and line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
