@@ -433,3 +433,39 @@ def test_group_takes_the_series_form_of_the_contraction_sharded(world, transport
         assert got[4][n].shape == v.shape and _close(got[4][n], v, 5e-5), n
     flips, _ = label_flips(got[5]["clone_probs"], ref[5]["clone_probs"])
     assert flips == 0
+
+
+def test_group_ranks_hand_the_same_passes_to_the_sweeps_when_the_exponent_range_is_too_wide():
+    """The sharded series form's other half: where max |psi| (max W - min W) outgrows what 32 bins cover, EVERY rank gives the same passes to the sweeps (the
+    decision follows from the global maximum), the collective of such a pass carries the whole buffer, and the fit is the one-handle fit."""
+    from clonealign_amd.engine import HipEngine, HipGroupEngine
+    from clonealign_amd.rng import EpsStream
+    case = make_case(seed=35, **CASES["k1"])
+    case["psi0"] = case["psi0"] * 30.0           # latent positions past a hundred: the guard (four steps of look-ahead at 0.32 each way) gives most passes to the sweeps
+    G, S = case["Y"].shape[1], case["S"]
+    eps = np.stack([eps_for(S, G, 700 + i) for i in range(25)])
+
+    def drive(eng):
+        eng.gamma_init(eps[0])
+        a = eng.iterate(6, eps[:13])
+        b = eng.iterate(6, eps[12:25])
+        return a, b, eng.get_state()
+
+    one = HipEngine(**case, variant_on=("series",))
+    try:
+        ra, rb, rst = drive(one)
+        i1 = one.info()
+        assert i1["series_passes"] > 0 and i1["series_fallbacks"] > 0, i1      # both kinds of pass in this run
+    finally:
+        one.close()
+    grp = HipGroupEngine(**case, devices=[0, 0], variant_on=("series",))
+    try:
+        ga, gb, gst = drive(grp)
+        infos = [grp.rank_info(r) for r in range(2)]
+    finally:
+        grp.close()
+    assert infos[0]["series_passes"] == infos[1]["series_passes"] > 0 and infos[0]["series_fallbacks"] == infos[1]["series_fallbacks"] > 0, infos
+    assert np.isfinite(ra) and np.isfinite(rb)
+    assert abs(ga - ra) <= 3e-7 * abs(ra) and abs(gb - rb) <= 3e-7 * abs(rb), (ga, ra, gb, rb)
+    for n, v in rst.items():
+        assert _close(gst[n], v, 5e-5), n
