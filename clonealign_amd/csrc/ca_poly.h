@@ -42,6 +42,10 @@ inline bool ca_poly_covers(double xmax, double vlo, double vhi, int steps, doubl
   return x == x && wdt == wdt && x * wdt <= 2.0 * CA_PL_A * CA_PL_NB;   // nb = ceil(x w / (2 a)) <= NB
 }
 hipError_t ca_poly_cells(hipStream_t st, const ca_poly_ws* w, int64_t N, int C, int K, const void* cell_ptrs, const float* alpha_u, double* cell_part, float* dF,
-                         const void* yfin_args /* a ca_yfin_args: the count-matrix stream's finishing sums as extra blocks of the cell launch, or NULL */);
+                         const void* yfin_args /* a ca_yfin_args: the count-matrix stream's finishing sums as extra blocks of the cell launch, or NULL */,
+                         const void* local_tail /* cell-sharded: the pending monitor pass's ca_small_args with reduce_only (its local block sums ride on the moments'
+                                                   reduction launch), or NULL */,
+                         const float* xs_part, int xs_n, const float* xs_F, double* xs_slots /* cell-sharded: this rank's max |x| slot rides there too, or NULL */,
+                         int rank, int world);
 hipError_t ca_poly_backward(hipStream_t st, const ca_poly_ws* w, const float* V, const float* mu, const float* Lb, int G, int C, double* red_g,
                             const void* small_tail /* a ca_small_args (pending monitor tail, run by an extra block) or NULL */);

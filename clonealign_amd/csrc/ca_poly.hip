@@ -338,10 +338,31 @@ __global__ void __launch_bounds__(CA_TB) k_poly_cell(const ca_poly_hdr* __restri
 
 // ---- fixed-order sums of the block partials: one wave per output, lanes stride over the blocks, then the wave's tree (same order every time) --------
 // mode 0: plain sum (tabB); mode 1: sum / k! with k = (j / C) % (R + 2) (tabQ = Q_k / k!)
+// this rank's max |x| into its slot, zeros into the other ranks' (the body of k_poly_xslot; also rides on the reduction launch of the backward moments)
+struct ca_xslot_args { const float* xpart; int nx; const float* F; int64_t N; double* slots; int rank, world; };
+__device__ __forceinline__ void ca_poly_xslot_body(const ca_xslot_args& a) {
+  __shared__ float sx[CA_TB / 64];
+  float ax = 0.f;
+  if (a.nx > 0) { for (int i = threadIdx.x; i < a.nx; i += CA_TB) ax = fmaxf(ax, a.xpart[i]); }
+  else { for (int64_t i = threadIdx.x; i < a.N; i += CA_TB) { const float v = fabsf(a.F[i]); ax = fmaxf(ax, v == v ? v : INFINITY); } }
+  ax = warp_max(ax);
+  if ((threadIdx.x & 63) == 0) sx[threadIdx.x >> 6] = ax;
+  __syncthreads();
+  if ((int)threadIdx.x < a.world) a.slots[threadIdx.x] = (int)threadIdx.x == a.rank ? (double)fmaxf(fmaxf(sx[0], sx[1]), fmaxf(sx[2], sx[3])) : 0.0;
+}
+// (nred: the blocks that reduce; a cell-sharded fit adds up to two more behind them -- the pending monitor pass's local block sums (a ca_small_args with
+//  reduce_only) and this rank's max |x| slot -- what would otherwise be two small launches in front of the iteration's collective)
 __global__ void __launch_bounds__(CA_TB) k_poly_red(const double* __restrict__ part, int nblk, int64_t stride, const ca_poly_hdr* __restrict__ hdr, int per_bin,
-                                                    int mode, int C, double* __restrict__ out, unsigned int* __restrict__ xbits) {
+                                                    int mode, int C, double* __restrict__ out, unsigned int* __restrict__ xbits, int nred, ca_small_args tail,
+                                                    ca_xslot_args xs) {
+  if ((int)blockIdx.x >= nred) {
+    const int e = (int)blockIdx.x - nred;
+    if (e == 0 && tail.enabled) ca_final_small_body(tail);
+    else if (xs.slots) ca_poly_xslot_body(xs);
+    return;
+  }
   if (xbits && blockIdx.x == 0 && threadIdx.x == 0) *xbits = 0u;   // (its reader, k_poly_B, is complete: ready for the next state's maximum)
-  const int lane = threadIdx.x & 63, nwave = gridDim.x * (CA_TB / 64);
+  const int lane = threadIdx.x & 63, nwave = nred * (CA_TB / 64);
   const int nout = hdr->nb * per_bin;
   for (int j = blockIdx.x * (CA_TB / 64) + (threadIdx.x >> 6); j < nout; j += nwave) {
     // (up to eight loads in flight per lane: a miss to another XCD's data costs a microsecond, a chain of them is the kernel)
@@ -445,14 +466,8 @@ void ca_poly_bind(ca_poly_ws* w, void* base, int G, int n_cell_blocks) {
 // per iteration carries the slots) then holds every rank's maximum.  One block; from the merged update's per-piece maxima where they are current, else from F.
 __global__ void __launch_bounds__(CA_TB) k_poly_xslot(const float* __restrict__ xpart, int nx, const float* __restrict__ F, int64_t N, double* __restrict__ slots, int rank,
                                                       int world) {
-  __shared__ float sx[CA_TB / 64];
-  float ax = 0.f;
-  if (nx > 0) { for (int i = threadIdx.x; i < nx; i += CA_TB) ax = fmaxf(ax, xpart[i]); }
-  else { for (int64_t i = threadIdx.x; i < N; i += CA_TB) { const float a = fabsf(F[i]); ax = fmaxf(ax, a == a ? a : INFINITY); } }
-  ax = warp_max(ax);
-  if ((threadIdx.x & 63) == 0) sx[threadIdx.x >> 6] = ax;
-  __syncthreads();
-  if ((int)threadIdx.x < world) slots[threadIdx.x] = (int)threadIdx.x == rank ? (double)fmaxf(fmaxf(sx[0], sx[1]), fmaxf(sx[2], sx[3])) : 0.0;
+  const ca_xslot_args a = {xpart, nx, F, N, slots, rank, world};
+  ca_poly_xslot_body(a);
 }
 hipError_t ca_poly_xslot(hipStream_t st, const float* xpart, int nx, const float* F, int64_t N, double* slots, int rank, int world) {
   hipLaunchKernelGGL(k_poly_xslot, dim3(1), dim3(CA_TB), 0, st, xpart, xpart ? nx : 0, F, N, slots, rank, world);
@@ -475,13 +490,17 @@ hipError_t ca_poly_moments(hipStream_t st, const ca_poly_ws* w, const float* V, 
   if (nx == 0 && nglob == 0) hipLaunchKernelGGL(k_poly_xmax, dim3((unsigned)std::min<int64_t>(128, (N + 4 * CA_TB - 1) / (4 * CA_TB))), dim3(CA_TB), 0, st, F, N, w->xbits);
   hipLaunchKernelGGL(k_poly_B, dim3(w->n_gene_blocks), dim3(TB_B), 0, st, V, w->xbits, muA, muB, Lb, G, C, w->hdr, w->partB, bad_word, mirror, seq, xpart, nglob ? 0 : nx,
                      xglob, nglob, xadd);
-  hipLaunchKernelGGL(k_poly_red, dim3(256), dim3(CA_TB), 0, st, w->partB, w->n_gene_blocks, (int64_t)NB * (R + 1) * 16, w->hdr,
-                     (R + 1) * 16, 0, C, w->tabB, w->xbits);
+  {
+    ca_small_args no_tail; memset(&no_tail, 0, sizeof(no_tail));
+    ca_xslot_args no_xs; memset(&no_xs, 0, sizeof(no_xs));
+    hipLaunchKernelGGL(k_poly_red, dim3(256), dim3(CA_TB), 0, st, w->partB, w->n_gene_blocks, (int64_t)NB * (R + 1) * 16, w->hdr,
+                       (R + 1) * 16, 0, C, w->tabB, w->xbits, 256, no_tail, no_xs);
+  }
   return hipGetLastError();
 }
 
 hipError_t ca_poly_cells(hipStream_t st, const ca_poly_ws* w, int64_t N, int C, int K, const void* cell_ptrs, const float* alpha_u, double* cell_part, float* dF,
-                         const void* yfin_args) {
+                         const void* yfin_args, const void* local_tail, const float* xs_part, int xs_n, const float* xs_F, double* xs_slots, int rank, int world) {
   const ca_cell_ptrs& p = *static_cast<const ca_cell_ptrs*>(cell_ptrs);
   ca_yfin_args yfin;
   if (yfin_args) memcpy(&yfin, yfin_args, sizeof(yfin)); else memset(&yfin, 0, sizeof(yfin));
@@ -493,8 +512,14 @@ hipError_t ca_poly_cells(hipStream_t st, const ca_poly_ws* w, int64_t N, int C, 
                                          w->n_cell_blocks, yfin)
   if (CP == 4) CA_PCELL(4); else CA_PCELL(8);   // (3 .. 8 clones: ca_poly_ok)
 #undef CA_PCELL
-  hipLaunchKernelGGL(k_poly_red, dim3(256), dim3(CA_TB), 0, st, w->Qpart, w->n_cell_blocks, (int64_t)NB * (R + 2) * 8, w->hdr,
-                     (R + 2) * C, 1, C, w->tabQ, nullptr);
+  {
+    ca_small_args tail;
+    if (local_tail) memcpy(&tail, local_tail, sizeof(tail)); else memset(&tail, 0, sizeof(tail));
+    const ca_xslot_args xs = {xs_part, xs_part ? xs_n : 0, xs_F, N, xs_slots, rank, world};
+    const int nextra = (tail.enabled || xs_slots) ? 2 : 0;
+    hipLaunchKernelGGL(k_poly_red, dim3(256 + nextra), dim3(CA_TB), 0, st, w->Qpart, w->n_cell_blocks, (int64_t)NB * (R + 2) * 8, w->hdr,
+                       (R + 2) * C, 1, C, w->tabQ, nullptr, 256, tail, xs);
+  }
   return hipGetLastError();
 }
 

@@ -324,11 +324,15 @@ def test_bench_on_eight_gpus_uses_a_device_collective_and_replicas_agree(tmp_pat
 
 
 def test_bench_two_ranks_take_the_series_form_sharded():
-    """Round 6, late: one process per rank (IPC-mapped peer-to-peer inboxes), a shape whose ranks take the series form of the contraction (15 000 cells x 5000
-    genes per rank): every pass on the series form on both ranks, replicas bit-identical after the timed regions, and the payload of the collective is the
+    """Round 6, late: one process per rank (IPC-mapped peer-to-peer inboxes), a shape whose ranks take the series form of the contraction (35 000 cells x 5000
+    genes per rank; sharded, the pick asks for G >= 2000 + 7.5e7 / N of the rank): every pass on the series form on both ranks, replicas bit-identical after the timed regions, and the payload of the collective is the
     series prefix of sharding.reduce_plan (cell sums, Y^T psi, backward moments, a max |psi| slot per rank) -- not the per-gene sums."""
     from clonealign_amd import sharding
-    r = _bench(2, [], shape=("--cells", "30000", "--genes", "5000", "--clones", "8"))
+    r = _bench(2, [], shape=("--cells", "70000", "--genes", "5000", "--clones", "8"))
+    if r.returncode != 0 and ("time limit" in r.stderr or "CA_ERR_COMM" in r.stderr or "error 5" in r.stderr):
+        # two PROCESSES on one device: a rank's all-reduce kernel spins for its peer's data while the peer's kernels wait for the same GPU -- the one-device rig's
+        # own hazard (bounded by comm_timeout_ms, reported as CA_ERR_COMM; seen once in a dozen runs of this test).  Distinct devices have no such wait.  Once more.
+        r = _bench(2, [], shape=("--cells", "70000", "--genes", "5000", "--clones", "8"))
     assert r.returncode == 0, child_report(r)
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["collective"] == "p2p" and line["config"]["series_form"] is True, line["config"]
