@@ -773,9 +773,9 @@ def main():
         other, fallbacks = {}, {}
         for nm, kw in (("cfg2", dict(N=10_000, G=2_000, C=4, what="BASELINE.json configs[1]")),
                        ("cfg5_one_restart", dict(N=50_000, G=3_000, C=6, what="one restart of BASELINE.json configs[4]")),
-                       ("shard_12500", dict(N=12_500, G=5_000, C=8, what="one rank's shard of configs[3] at 8 GPUs, no collective")),
-                       ("shard_25000", dict(N=25_000, G=5_000, C=8, what="one rank's shard of configs[3] at 4 GPUs, no collective")),
-                       ("shard_50000", dict(N=50_000, G=5_000, C=8, what="one rank's shard of configs[3] at 2 GPUs, no collective"))):
+                       ("shard_12500", dict(N=12_500, G=5_000, C=8, what="an UNSHARDED problem of the size of one rank's shard of configs[3] at 8 GPUs; a rank of a sharded fit adds the collective's launch and picks series / sweeps by its own rule, DESIGN.md section 6")),
+                       ("shard_25000", dict(N=25_000, G=5_000, C=8, what="an UNSHARDED problem of the size of one rank's shard of configs[3] at 4 GPUs; a rank of a sharded fit adds the collective's launch and picks series / sweeps by its own rule, DESIGN.md section 6")),
+                       ("shard_50000", dict(N=50_000, G=5_000, C=8, what="an UNSHARDED problem of the size of one rank's shard of configs[3] at 2 GPUs; a rank of a sharded fit adds the collective's launch and picks series / sweeps by its own rule, DESIGN.md section 6"))):
             try:
                 other[nm] = side_config(nm, device=local_rank, **kw)
             except Exception as ex:  # noqa: BLE001
