@@ -42,6 +42,7 @@ for it in range(n_cases):
             P = 5 - K
         S = int(rng.choice([1, 1, 2, 3, 4]))
         N = int(rng.integers(1, 2500))
+        G = max(G, 2)   # (one gene: the likelihood does not depend on the parameters, every gradient is the sign of rounding noise -- profiles/r06_fuzz.txt)
     if BAL:
         N, G, C, K, P, S = int(rng.integers(4096, 28672)), int(rng.integers(3072, 3400)), int(rng.integers(2, 9)), 1, 0, 1   # (up to six whole tiles per CU: the balanced range)
     voff, von, tune = VARIANTS[int(rng.integers(0, len(VARIANTS)))] if not BAL else ((), (), {})
