@@ -469,3 +469,40 @@ def test_group_ranks_hand_the_same_passes_to_the_sweeps_when_the_exponent_range_
     assert abs(ga - ra) <= 3e-7 * abs(ra) and abs(gb - rb) <= 3e-7 * abs(rb), (ga, ra, gb, rb)
     for n, v in rst.items():
         assert _close(gst[n], v, 5e-5), n
+
+
+def test_group_ranks_agree_on_the_series_form_when_their_own_picks_differ():
+    """The pick of the series form looks at the rank's own cell count (sharded: G >= 2000 + 7.5e7 / N), and shards differ by a cell: 29 999 cells x 7000 genes over
+    two ranks is 14 999 / 15 000 -- one rank's rule says no (7000.3 genes wanted), the other's yes.  The lengths of the collectives follow from the choice, so
+    the ranks agree when the transport comes up (setup_global_sums): the form is used only where EVERY rank picked it, and everybody takes the classic layout of
+    the reduction buffer otherwise.  Here: nobody takes the form, both ranks reduce the classic 3 + C + 3 G doubles, and the fit is the one-handle sweeps fit."""
+    from clonealign_amd.engine import HipEngine, HipGroupEngine
+    from clonealign_amd.rng import EpsStream
+    N, G, C = 29_999, 7000, 8
+    rng = np.random.default_rng(5)
+    L = rng.integers(1, 5, size=(G, C)).astype(np.float64)
+    z = rng.integers(0, C, N)
+    mu = rng.lognormal(0, 1, G).astype(np.float32)
+    Y = np.empty((N, G), dtype=np.uint8)
+    for b0 in range(0, N, 4096):
+        zz = z[b0:b0 + 4096]
+        Y[b0:b0 + 4096] = np.minimum(rng.poisson(mu[None, :] * L[:, zz].T.astype(np.float32) * 0.5), 255).astype(np.uint8)
+    Y[:, 0] |= 1
+    psi0 = rng.normal(size=(N, 1))
+    loc0 = rng.normal(size=G) + 1.0
+    one = HipEngine(Y, L, psi0, loc0, 1, variant_off=("series",))
+    try:
+        tr1 = np.asarray(one.run(EpsStream(77, 1, G), 4, 1e-12))
+    finally:
+        one.close()
+    grp = HipGroupEngine(Y, L, psi0, loc0, 1, devices=[0, 0])
+    try:
+        infos = [grp.rank_info(r) for r in range(2)]
+        assert sorted(i["N"] for i in infos) == [14_999, 15_000]
+        assert all(i["fwd_series"] == 0 for i in infos), infos
+        assert all(i["red_n"] == 3 + C + G * 2 + G for i in infos), [i["red_n"] for i in infos]
+        trg = np.asarray(grp.run(EpsStream(77, 1, G), 4, 1e-12))
+        assert all(grp.rank_info(r)["series_passes"] == 0 for r in range(2))
+    finally:
+        grp.close()
+    assert _close(trg, tr1, 3e-7), np.abs(trg - tr1).max() / np.abs(tr1).max()
