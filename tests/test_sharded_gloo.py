@@ -175,3 +175,21 @@ def test_bare_bench_launcher_starts_fresh_ranks_and_exits_with_the_worst_code():
     r = _bare_bench(["--gpus", "2", "--steps", "2"], CLONEALIGN_BENCH_DEVICE="0")
     assert r.returncode != 0 and "{" not in r.stdout
     assert r.stderr.count("needs an MI355X") == 2 and "launcher: rank 0 exited" in r.stderr and "launcher: rank 1 exited" in r.stderr, r.stderr[-800:]
+
+
+def test_reduce_plan_of_a_series_capable_engine_is_a_prefix_layout():
+    """Round 6: an engine whose shape takes the series form lays the reduction buffer out so that what a series pass reduces (cell sums, Y^T psi, the backward
+    moments, a max |psi| slot per rank) is a contiguous PREFIX and the per-gene sums come last; the classic layout is unchanged."""
+    G, C, W = 5000, 8, 8
+    classic = reduce_plan(G, C, 1, 0, 1)
+    assert classic["total"] == 3 + C + G * 2 + G == 15011 and classic["gene"][0] == 3 + C
+    ser = reduce_plan(G, C, 1, 0, 1, series=True, world=W)
+    Gp = 5120
+    assert ser["ytpsi"] == (3 + C, G) and ser["moments"] == (3 + C + Gp, 32 * 22 * 8) and ser["max_psi"] == (3 + C + Gp + 5632, W)
+    assert ser["series_total"] == ser["gene"][0] == 3 + C + Gp + 5632 + W == 10771
+    assert ser["total"] == ser["series_total"] + 2 * G
+    # every region inside the buffer, in order, without overlap
+    regions = sorted(v for k, v in ser.items() if isinstance(v, tuple))
+    for (o0, n0), (o1, _n1) in zip(regions, regions[1:]):
+        assert o0 + n0 <= o1
+    assert regions[-1][0] + regions[-1][1] == ser["total"]
