@@ -294,8 +294,10 @@ def through_api(N, G, C, K, devices, steps, warmup, regions=3, seed=20243, trans
         trace = grp.run(None, 200, 1e-6)
         finals = grp.final_elbo(None, 20)
         fit_s = time.perf_counter() - t2
-        shard = [int(grp.rank_info(r)["N"]) for r in range(len(devices))]
-        return {"value": steps / dt, "unit": "iterations/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "regions_ms_per_step": [t / steps * 1e3 for t in times],
+        rinfo = [grp.rank_info(r) for r in range(len(devices))]
+        shard = [int(i["N"]) for i in rinfo]
+        series = {"on": bool(rinfo[0]["fwd_series"]), "passes": [int(i["series_passes"]) for i in rinfo], "handed_to_the_sweeps": [int(i["series_fallbacks"]) for i in rinfo]}
+        return {"series_form": series, "value": steps / dt, "unit": "iterations/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "regions_ms_per_step": [t / steps * 1e3 for t in times],
                 "devices": [int(d) for d in devices], "transport": gi["transport_name"], "p2p_status": gi["p2p_status"], "rccl_status": gi["rccl_status"],
                 "rebuilds": gi["rebuilds"], "selftest_rounds": gi["selftest_rounds"], "note": gi["note"], "cells_per_rank": shard,
                 "create_seconds": create_s, "final_elbo": last, "finite": bool(np.isfinite(last)),
@@ -454,7 +456,8 @@ def main():
         print(json.dumps({
             "metric": "ELBO iterations/sec", "value": r["value"], "unit": "iterations/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 (bf16x3-split MFMA contraction, fp32 accumulate)", "data": "synthetic",
+            "dtype": ("f32 variables (contraction: float64 series over gene bins; count-matrix products: int8 MFMA, exact)" if r["series_form"]["on"] and r["series_form"]["passes"][0] > 0
+                      else "f32 (bf16x3-split MFMA contraction, fp32 accumulate)"), "data": "synthetic",
             "config": {"workload": f"synthetic {N} cells x {G} genes x {C} clones, K={K}, S=1, ONE fit cell-sharded over {args.gpus} device(s) of one process "
                                    f"(BASELINE.json configs[{2 if args.gpus == 1 else 3}] through the drop-in's device group)",
                        "cells": N, "genes": G, "clones": C, "K": K, "parallelism": f"cells/{args.gpus}, one process (ca_group)", "collective": r["transport"],
