@@ -111,6 +111,7 @@ struct gate_snapshot {
   int64_t pre_A, pre_B, hint_A, hint_B, gaux_slot;
   int vmm_at_idx, gaux_idx, ys_steps, ys_namax[3];
   float b1p, b2p; uint64_t adam_steps;
+  int poly_xglob_steps;
   float *vchi, *vchi_alt, *alpha_u, *alpha_u_alt;
   void take(const ca_engine* h) {
     look_valid = h->look_valid; bwd_ready = h->bwd_ready; pre_valid = h->pre_valid; em_stale = h->em_stale; y_defer = h->y_defer;
@@ -119,6 +120,7 @@ struct gate_snapshot {
     vmm_at_idx = h->vmm_at_idx; gaux_idx = h->gaux_idx; ys_steps = h->ys_steps;
     for (int i = 0; i < 3; ++i) ys_namax[i] = h->ys_namax[i];
     b1p = h->b1p; b2p = h->b2p; adam_steps = h->adam_steps;
+    poly_xglob_steps = h->poly_xglob_steps;
     vchi = h->vchi; vchi_alt = h->vchi_alt; alpha_u = h->alpha_u; alpha_u_alt = h->alpha_u_alt;
   }
   void restore(ca_engine* h) const {
@@ -129,7 +131,10 @@ struct gate_snapshot {
     for (int i = 0; i < 3; ++i) h->ys_namax[i] = ys_namax[i];
     h->b1p = b1p; h->b2p = b2p; h->adam_steps = adam_steps;
     h->poly_xmax_ready = false;   // (the cancelled launch added nothing to the series form's max |psi| word)
-    h->poly_xglob_steps = -1;
+    // Sharded series: the slots describe the state this launch did NOT change -- the count goes back, it is NOT invalidated: a launch that gave up is a rank's own
+    // affair (its host was late), and a refresh of the slots is a collective -- one rank refreshing alone paired its four doubles with its peers' next all-reduce
+    // (their cell sums landed in its slots: max |psi| of 1e8, "cannot cover the exponent range", the peers timing out; four ranks on one device, found late round 6)
+    h->poly_xglob_steps = poly_xglob_steps;
     h->vchi = vchi; h->vchi_alt = vchi_alt; h->alpha_u = alpha_u; h->alpha_u_alt = alpha_u_alt;
   }
 };

@@ -342,3 +342,20 @@ def test_bench_two_ranks_take_the_series_form_sharded():
     plan = sharding.reduce_plan(5000, 8, 1, 0, 1, series=True, world=2)
     assert line["config"]["allreduce_doubles_per_train_pass"] == plan["series_total"] == 3 + 8 + 5120 + 32 * 22 * 8 + 2
     assert line["roofline"]["kernel"] == "ypass" and line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
+
+
+def test_bench_four_ranks_on_one_device_keep_their_collectives_in_step_when_a_gated_update_gives_up():
+    """Found late in round 6: four rank PROCESSES sharing one device are slow enough for a rank's gated update to give up now and then (its host's decision came
+    late: the launch stores nothing and is queued again -- a rank's own affair).  The sharded series form used to invalidate its max |psi| slots on that path, the
+    next pass refreshed them with a small collective of ITS OWN, and that rank's four doubles paired with its peers' next all-reduce: their cell sums landed in its
+    slots ("cannot cover the exponent range"), the peers timed out -- every other run of this command.  The slots' step count is part of the gate's snapshot now.
+    cfg-3 over four ranks (25 000 cells each: the series form), the driver's command shape, twice."""
+    shape = ("--cells", "100000", "--genes", "5000", "--clones", "8")
+    for _ in range(2):
+        r = _bench(4, [], shape=shape)
+        if r.returncode != 0 and "time limit" in r.stderr and "cannot cover" not in r.stderr:
+            r = _bench(4, [], shape=shape)   # (the one-device rig's own hazard: a rank's all-reduce spinning for a peer whose kernels wait for the same GPU)
+        assert r.returncode == 0, child_report(r)
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert line["n_gpus"] == 4 and line["config"]["series_form"] is True and line["replicas_bit_identical_after_timed_regions"] is True, line["config"]
+        assert line["fit_wallclock"]["iterations"] >= 1 and np.isfinite(line["fit_wallclock"]["final_elbo_mean"])
